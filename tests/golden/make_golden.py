@@ -1,0 +1,473 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  It imports the reference's
+numeric modules -- and nothing else of the reference -- through the two stand-ins
+described in SURVEY.md section 8c:
+
+  * a module ``onnx_ir`` that only offers ``DataType`` (an IntEnum with ``numpy()`` and
+    ``bitwidth``), because ``onnx_ir`` is not installed here;
+  * an empty package object ``onnx_quantize`` whose ``__path__`` points at the reference
+    sources, so ``onnx_quantize/__init__.py`` (which pulls in onnx / onnxscript) is
+    bypassed.
+
+Only DATA leaves this script: inputs, parameters and the arrays the reference returned,
+as ``.npz`` / ``.json``.  No reference source, bytecode or pickled object is written.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz|json
+"""
+
+from __future__ import annotations
+
+import enum
+import hashlib
+import importlib
+import itertools
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src/onnx_quantize"
+
+
+def _load_reference():
+    sys.dont_write_bytecode = True
+
+    class DataType(enum.IntEnum):
+        UINT8 = 2
+        INT8 = 3
+        INT32 = 6
+        UINT32 = 12
+        UINT4 = 21
+        INT4 = 22
+
+        def numpy(self):
+            return {
+                2: np.dtype(np.uint8), 3: np.dtype(np.int8), 6: np.dtype(np.int32),
+                12: np.dtype(np.uint32), 21: np.dtype(np.uint8), 22: np.dtype(np.int8),
+            }[int(self)]
+
+        @property
+        def bitwidth(self):
+            return {2: 8, 3: 8, 6: 32, 12: 32, 21: 4, 22: 4}[int(self)]
+
+    ir = types.ModuleType("onnx_ir")
+    ir.DataType = DataType
+    sys.modules["onnx_ir"] = ir
+    pkg = types.ModuleType("onnx_quantize")
+    pkg.__path__ = [REF]
+    sys.modules["onnx_quantize"] = pkg
+
+    mods = types.SimpleNamespace()
+    mods.utils = importlib.import_module("onnx_quantize.core._algorithms.utils")
+    mods.rtn = importlib.import_module("onnx_quantize.core._algorithms.rtn")
+    mods.gptq = importlib.import_module("onnx_quantize.core._algorithms.gptq")
+    mods.minmax = importlib.import_module("onnx_quantize.core._calibration.minmax")
+    mods.pack = importlib.import_module("onnx_quantize.core._pack")
+    mods.dtypes = importlib.import_module("onnx_quantize.core._dtypes")
+    mods.qconfig = importlib.import_module("onnx_quantize.core._qconfig")
+    return mods
+
+
+R = _load_reference()
+QT = {
+    "int4": R.dtypes.QuantType.QInt4, "uint4": R.dtypes.QuantType.QUInt4,
+    "int8": R.dtypes.QuantType.QInt8, "uint8": R.dtypes.QuantType.QUInt8,
+    "int32": R.dtypes.QuantType.QInt32, "uint32": R.dtypes.QuantType.QUInt32,
+}
+ST = {
+    "tensor": R.qconfig.QuantizationStrategy.TENSOR,
+    "channel": R.qconfig.QuantizationStrategy.CHANNEL,
+    "group": R.qconfig.QuantizationStrategy.GROUP,
+}
+
+
+def sha16(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def weight(kind: str, seed: int, k: int, n: int) -> np.ndarray:
+    """Synthetic fp32 weights; the same recipe is re-run by the tests for the big cases."""
+    rng = np.random.default_rng(seed)
+    if kind == "normal":
+        return rng.standard_normal((k, n), dtype=np.float32)
+    if kind == "heavy":
+        return rng.standard_t(3, size=(k, n)).astype(np.float32)
+    if kind == "positive":
+        return rng.random((k, n), dtype=np.float32) + np.float32(0.25)
+    if kind == "negative":
+        return -(rng.random((k, n), dtype=np.float32) + np.float32(0.25))
+    if kind == "zero_groups":
+        w = rng.standard_normal((k, n), dtype=np.float32)
+        w[: k // 2, ::3] = 0.0            # whole groups of zeros -> tiny-scale guard
+        w[:, 1] = 0.0                     # a whole dead output channel
+        return w
+    if kind == "tiny":
+        return (rng.standard_normal((k, n), dtype=np.float32) * np.float32(1e-39)).astype(np.float32)
+    if kind == "halves":
+        # values that land exactly on .5 after division -> exercises ties-to-even
+        return (rng.integers(-31, 32, size=(k, n)).astype(np.float32)) * np.float32(0.5)
+    raise ValueError(kind)
+
+
+def rtn_call(w, qtype, strategy, g, sym, red, clip, mse):
+    q, s, z = R.rtn._rtn_quantize(
+        w, QT[qtype], ST[strategy], g, sym, red, clip, mse,
+        np.dtype(np.float32), QT[qtype].np_dtype)
+    return np.ascontiguousarray(q), np.asarray(s), np.asarray(z)
+
+
+def gen_rtn_small(out):
+    """Every dtype x strategy x symmetric x reduce_range on <=64x48 matrices."""
+    cases = []
+    arrays = {}
+    shapes = [(64, 48), (32, 20), (48, 7)]
+    kinds = ["normal", "heavy", "zero_groups", "positive", "negative", "halves", "tiny"]
+    idx = 0
+    for qtype in ("int4", "uint4", "int8", "uint8"):
+        for strategy, g in (("tensor", -1), ("channel", -1), ("group", 16), ("group", 8),
+                            ("group", 32), ("group", 128), ("group", -1)):
+            for sym in (False, True):
+                for red in (False, True):
+                    k, n = shapes[idx % len(shapes)]
+                    if strategy == "group" and g > 0 and k % min(g, k):
+                        k = 64
+                    kind = kinds[idx % len(kinds)]
+                    clip = (1.0, 0.9, 0.75)[idx % 3]
+                    seed = 100 + idx
+                    w = weight(kind, seed, k, n)
+                    q, s, z = rtn_call(w, qtype, strategy, g, sym, red, clip, False)
+                    cid = f"c{idx:03d}"
+                    arrays[f"{cid}_w"] = w
+                    arrays[f"{cid}_q"] = q
+                    arrays[f"{cid}_s"] = s
+                    arrays[f"{cid}_z"] = z
+                    cases.append(dict(id=cid, qtype=qtype, strategy=strategy, group_size=g,
+                                      symmetric=sym, reduce_range=red, clip_ratio=clip,
+                                      mse=False, kind=kind, seed=seed, k=k, n=n))
+                    idx += 1
+    # ragged / odd shapes: group that straddles columns (N*K % g == 0 but K % g != 0),
+    # g = 1, single row, single column
+    extra = [
+        ("uint4", "group", 8, False, False, 12, 6, "normal"),
+        ("int8", "group", 1, False, False, 8, 5, "normal"),
+        ("int4", "group", 4, True, False, 4, 9, "heavy"),
+        ("uint8", "channel", -1, False, False, 1, 33, "normal"),
+        ("int8", "tensor", -1, True, False, 33, 1, "normal"),
+        ("uint4", "group", 16, False, False, 256, 3, "normal"),
+        ("int4", "group", 64, False, False, 128, 130, "heavy"),
+        ("uint8", "group", 256, True, False, 512, 66, "normal"),
+    ]
+    for qtype, strategy, g, sym, red, k, n, kind in extra:
+        seed = 100 + idx
+        w = weight(kind, seed, k, n)
+        q, s, z = rtn_call(w, qtype, strategy, g, sym, red, 1.0, False)
+        cid = f"c{idx:03d}"
+        arrays[f"{cid}_w"] = w
+        arrays[f"{cid}_q"] = q
+        arrays[f"{cid}_s"] = s
+        arrays[f"{cid}_z"] = z
+        cases.append(dict(id=cid, qtype=qtype, strategy=strategy, group_size=g, symmetric=sym,
+                          reduce_range=red, clip_ratio=1.0, mse=False, kind=kind, seed=seed,
+                          k=k, n=n))
+        idx += 1
+    np.savez_compressed(os.path.join(out, "rtn_small.npz"), **arrays)
+    with open(os.path.join(out, "rtn_small.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+    print("rtn_small:", len(cases), "cases")
+
+
+def gen_rtn_mse(out):
+    cases, arrays = [], {}
+    grid = [
+        ("uint4", "group", 32, False, "normal", 64, 24),
+        ("int4", "group", 16, True, "heavy", 64, 24),
+        ("int8", "channel", -1, False, "heavy", 48, 20),
+        ("uint8", "tensor", -1, False, "normal", 32, 16),
+        ("int8", "tensor", -1, True, "heavy", 32, 16),
+        ("uint4", "group", 128, False, "heavy", 256, 16),
+    ]
+    for idx, (qtype, strategy, g, sym, kind, k, n) in enumerate(grid):
+        seed = 700 + idx
+        w = weight(kind, seed, k, n)
+        q, s, z = rtn_call(w, qtype, strategy, g, sym, False, 1.0, True)
+        rows = R.utils._preprocess_array(w, ST[strategy], g)
+        lo, hi = R.utils._compute_min_max_mse(
+            rows, QT[qtype], ST[strategy], g, sym, False, np.dtype(np.float32),
+            QT[qtype].np_dtype)
+        cid = f"m{idx:02d}"
+        arrays.update({f"{cid}_w": w, f"{cid}_q": q, f"{cid}_s": s, f"{cid}_z": z,
+                       f"{cid}_lo": np.asarray(lo), f"{cid}_hi": np.asarray(hi)})
+        cases.append(dict(id=cid, qtype=qtype, strategy=strategy, group_size=g, symmetric=sym,
+                          reduce_range=False, clip_ratio=1.0, mse=True, kind=kind, seed=seed,
+                          k=k, n=n))
+    np.savez_compressed(os.path.join(out, "rtn_mse.npz"), **arrays)
+    with open(os.path.join(out, "rtn_mse.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+    print("rtn_mse:", len(cases), "cases")
+
+
+def gen_kernels(out):
+    """quantize / dequantize / fake-quantize / bias / qparams on explicit inputs."""
+    arrays = {}
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((40, 24), dtype=np.float32) * np.float32(3.0)
+    for qtype in ("int4", "uint4", "int8", "uint8"):
+        for sym in (False, True):
+            for red in (False, True):
+                tag = f"{qtype}_{int(sym)}{int(red)}"
+                lo = np.minimum(x.min(axis=1, keepdims=True), 0)
+                hi = np.maximum(x.max(axis=1, keepdims=True), 0)
+                s, z = R.utils._compute_qparams(lo, hi, QT[qtype], sym, red,
+                                                np.dtype(np.float32), QT[qtype].np_dtype)
+                q = R.utils._quantize_array_from_qparams(x, s, z, QT[qtype], sym, red)
+                dq = R.utils._dequantize_array(q, s, z)
+                arrays[f"qp_{tag}_s"] = s
+                arrays[f"qp_{tag}_z"] = z
+                arrays[f"qp_{tag}_q"] = q
+                arrays[f"qp_{tag}_dq"] = dq
+    arrays["x"] = x
+    # dequantize with preprocess=True in the three layouts
+    w = weight("normal", 12, 64, 24)
+    for strategy, g in (("tensor", -1), ("channel", -1), ("group", 16)):
+        q, s, z = rtn_call(w, "uint8", strategy, g, False, False, 1.0, False)
+        dq = R.utils._dequantize_array(q, s, z, preprocess=True, strategy=ST[strategy],
+                                       group_size=g)
+        arrays[f"dq_{strategy}_q"] = q
+        arrays[f"dq_{strategy}_s"] = s
+        arrays[f"dq_{strategy}_z"] = z
+        arrays[f"dq_{strategy}_out"] = np.ascontiguousarray(dq)
+    arrays["dq_w"] = w
+    # bias
+    bias = rng.standard_normal(48, dtype=np.float32)
+    wscale = (rng.random(48, dtype=np.float32) + np.float32(0.01)) * np.float32(0.02)
+    qb, bs, _ = R.rtn._quantize_bias(bias, np.float32(0.0371), wscale)
+    arrays.update(bias=bias, bias_wscale=wscale, bias_xscale=np.float32(0.0371), bias_q=qb,
+                  bias_scale=bs)
+    np.savez_compressed(os.path.join(out, "kernels.npz"), **arrays)
+    print("kernels: ok")
+
+
+def gen_scalar_kats(out):
+    """Known answers transcribed from the reference's own tests (data only) and checked
+    here against the reference implementation before being written."""
+    qparam_kats = [
+        # (values, qtype, symmetric, expected_scale, expected_zp)  test_rtn.py:21-40
+        ([0.0, 0.0, 0.0], "int8", False, 1.0, -128),
+        ([0.0, 0.0, 0.0], "int8", True, 1.0, 0),
+        ([0.0, 0.0, 0.0], "uint8", False, 1.0, 0),
+        ([0.0, 0.0, 5.0], "int8", False, 5.0 / 255, -128),
+        ([0.0, 0.0, 5.0], "int8", True, 10.0 / 254, 0),
+        ([-5.0, -2.0, 0.0], "int8", False, 5.0 / 255, 127),
+        ([-5.0, -2.0, 0.0], "int8", True, 5.0 / 127, 0),
+        ([-5.0, 0.0, 5.0], "int8", False, 10.0 / 255, 0),
+        ([-10.0, -5.0, 5.0, 10.0], "int8", True, 10.0 / 127, 0),
+        ([0.0, 5.0, 10.0], "uint8", False, 10.0 / 255, 0),
+        ([0.0, 5.0, 10.0], "uint8", True, 10.0 / 127, 128),
+    ]
+    for vals, qtype, sym, es, ez in qparam_kats:
+        for mse in (False, True):
+            s, z = R.utils._compute_qparams_from_array(
+                np.array(vals), QT[qtype], ST["tensor"], -1, sym, False, 1.0, mse,
+                np.float32, QT[qtype].np_dtype)
+            np.testing.assert_allclose(s, np.float32(es), rtol=1e-5)
+            assert int(z) == ez
+    qrange_table = []
+    for qtype in ("int4", "uint4", "int8", "uint8", "int32", "uint32"):
+        for sym, red in ((False, False), (True, False), (True, True), (False, True)):
+            qrange_table.append([qtype, sym, red, list(QT[qtype].qrange(sym, red))])
+    pack_kats = [
+        # test_pack.py:11-27, :59-75 (array, dtype, expected bytes)
+        ([3, 7], "int4", [115]),
+        ([-5, 3, 4, 7, 0, 3, 7, -2], "int4", [59, 116, 48, 231]),
+        ([-8, 7], "int4", [120]),
+        ([0, 0, 0, 0], "int4", [0, 0]),
+        ([-1, -2, -3, -4], "int4", [239, 205]),
+        ([1, 2, 3], "int4", [33, 3]),
+        ([3, 7], "uint4", [115]),
+        ([11, 3, 4, 7, 0, 3, 7, 14], "uint4", [59, 116, 48, 231]),
+        ([0, 15], "uint4", [240]),
+        ([15, 15, 15, 15], "uint4", [255, 255]),
+        ([1, 2, 3], "uint4", [33, 3]),
+    ]
+    for vals, qtype, exp in pack_kats:
+        a = np.array(vals, dtype=np.int8 if qtype == "int4" else np.uint8)
+        got = R.pack.pack(a, QT[qtype])
+        assert got.tolist() == exp, (vals, got, exp)
+    # EMA known answer  test_minmax_calibrator.py:127-144
+    c = R.minmax.MinMaxCalibrator(momentum=0.8)
+    c.collect("t", np.array([-1.0, 2.0, 3.0]))
+    c.collect("t", np.array([-0.5, 2.5, 4.0]))
+    assert np.isclose(c.data["t"].min_val, -0.9) and np.isclose(c.data["t"].max_val, 3.2)
+    with open(os.path.join(out, "scalar_kats.json"), "w") as f:
+        json.dump(dict(qparams=qparam_kats, qrange=qrange_table, pack=pack_kats,
+                       ema=dict(momentum=0.8, batches=[[-1.0, 2.0, 3.0], [-0.5, 2.5, 4.0]],
+                                min=-0.9, max=3.2)), f, indent=0)
+    print("scalar_kats: ok")
+
+
+def gen_minmax(out):
+    arrays, meta = {}, []
+    rng = np.random.default_rng(21)
+    for idx, (momentum, nb, shape) in enumerate([(0.0, 5, (4, 33, 17)), (0.8, 6, (3, 129)),
+                                                 (0.5, 4, (2, 5, 7, 11)), (0.0, 3, (1,)),
+                                                 (0.0, 4, (7, 64, 40))]):
+        cal = R.minmax.MinMaxCalibrator(momentum=momentum)
+        scale = np.float32(1.0)
+        for b in range(nb):
+            x = (rng.standard_normal(shape, dtype=np.float32) * scale
+                 + np.float32(0.3 * b - 0.5)).astype(np.float32)
+            scale = np.float32(scale * 1.3)
+            cal.collect("t", x)
+            arrays[f"s{idx}_b{b}"] = x
+            arrays[f"s{idx}_b{b}_min"] = np.asarray(cal.data["t"].min_val)
+            arrays[f"s{idx}_b{b}_max"] = np.asarray(cal.data["t"].max_val)
+        lo, hi = cal.compute_range("t")
+        arrays[f"s{idx}_lo"] = lo
+        arrays[f"s{idx}_hi"] = hi
+        for qtype, sym in (("int8", False), ("uint8", False), ("int8", True)):
+            s, z = R.utils._compute_qparams(lo, hi, QT[qtype], sym, False,
+                                            np.dtype(np.float32), QT[qtype].np_dtype)
+            arrays[f"s{idx}_{qtype}_{int(sym)}_scale"] = np.asarray(s)
+            arrays[f"s{idx}_{qtype}_{int(sym)}_zp"] = np.asarray(z)
+        meta.append(dict(id=f"s{idx}", momentum=momentum, batches=nb, shape=list(shape)))
+    np.savez_compressed(os.path.join(out, "minmax.npz"), **arrays)
+    with open(os.path.join(out, "minmax.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    print("minmax:", len(meta), "sequences")
+
+
+def gptq_call(w, x, qtype, strategy, g, sym, red, clip, block, damp, actorder, mse):
+    q, s, z = R.gptq._gptq_quantize(
+        w, x, quant_type=QT[qtype], strategy=ST[strategy], group_size=g, is_symmetric=sym,
+        reduce_range=red, clip_ratio=clip, block_size=block, percdamp=damp,
+        actorder=actorder, mse=mse, scale_dtype=np.float32, zp_dtype=QT[qtype].np_dtype)
+    return np.ascontiguousarray(q), np.asarray(s), np.asarray(z)
+
+
+def gen_gptq(out):
+    arrays, cases = {}, []
+    # (a) the reference test's own tensors: rng(42) W(16x32) then X(32x16)  test_gptq.py:8-17
+    rng = np.random.default_rng(42)
+    w0 = rng.normal(0, 1, (16, 32)).astype(np.float32)
+    x0 = rng.normal(0, 1, (32, 16)).astype(np.float32)
+    arrays["a_w"], arrays["a_x"] = w0, x0
+    idx = 0
+    combos = list(itertools.product(
+        (("int4", "group", 8), ("int8", "tensor", 8), ("int8", "tensor", 64),
+         ("uint8", "channel", -1), ("int4", "group", 16), ("uint4", "group", 4),
+         ("int8", "tensor", -1), ("int8", "channel", 32)),
+        (16, 128, 5), (0.01, 0.1), (False, True)))
+    for (qtype, strategy, g), block, damp, actorder in combos:
+        if actorder and strategy == "group":
+            # group + actorder is well defined only without diag(H) ties; rng data has none
+            pass
+        q, s, z = gptq_call(w0, x0, qtype, strategy, g, False, False, 1.0, block, damp,
+                            actorder, False)
+        cid = f"a{idx:03d}"
+        arrays[f"{cid}_q"], arrays[f"{cid}_s"], arrays[f"{cid}_z"] = q, s, z
+        cases.append(dict(id=cid, data="a", qtype=qtype, strategy=strategy, group_size=g,
+                          symmetric=False, reduce_range=False, clip_ratio=1.0,
+                          block_size=block, percdamp=damp, actorder=actorder, mse=False))
+        idx += 1
+    # (b) a layer-shaped case with dead input channels, 3-D activations, sym / reduce_range
+    rng = np.random.default_rng(43)
+    k, n = 256, 96
+    w1 = (rng.standard_normal((k, n), dtype=np.float32) * np.float32(0.05))
+    x1 = rng.standard_normal((6, 40, k), dtype=np.float32)
+    x1 *= (np.float32(0.1) + rng.random(k, dtype=np.float32) * np.float32(4.0))
+    x1[..., [3, 77, 200]] = 0.0          # dead channels -> diag(H) == 0
+    arrays["b_w"], arrays["b_x"] = w1, x1
+    h = np.zeros((k, k), np.float32)
+    h, ns = R.gptq._accumulate_hessian(x1, h, 0)
+    arrays["b_h"] = h
+    arrays["b_nsamples"] = np.int64(ns)
+    for jdx, (qtype, strategy, g, sym, red, clip, block, damp, actorder) in enumerate([
+            ("int4", "group", 128, False, False, 1.0, 128, 0.01, False),
+            ("int4", "group", 128, False, False, 1.0, 128, 0.01, True),
+            ("int4", "group", 32, True, False, 1.0, 64, 0.01, False),
+            ("uint4", "group", 64, False, False, 0.9, 128, 0.05, False),
+            ("int8", "channel", -1, False, False, 1.0, 128, 0.01, False),
+            ("int8", "channel", -1, True, True, 1.0, 96, 0.01, True),
+            ("uint8", "tensor", -1, False, False, 1.0, 128, 0.01, False),
+            ("int8", "group", 256, False, False, 1.0, 128, 0.01, False)]):
+        q, s, z = gptq_call(w1, x1, qtype, strategy, g, sym, red, clip, block, damp,
+                            actorder, False)
+        cid = f"b{jdx:03d}"
+        arrays[f"{cid}_q"], arrays[f"{cid}_s"], arrays[f"{cid}_z"] = q, s, z
+        cases.append(dict(id=cid, data="b", qtype=qtype, strategy=strategy, group_size=g,
+                          symmetric=sym, reduce_range=red, clip_ratio=clip, block_size=block,
+                          percdamp=damp, actorder=actorder, mse=False))
+    # (c) two-step Hessian accumulate (running average algebra) on split batches
+    h2 = np.zeros((k, k), np.float32)
+    h2, n2 = R.gptq._accumulate_hessian(x1[:4], h2, 0)
+    h2, n2 = R.gptq._accumulate_hessian(x1[4:], h2, n2)
+    arrays["b_h_two_step"] = h2
+    np.savez_compressed(os.path.join(out, "gptq.npz"), **arrays)
+    with open(os.path.join(out, "gptq.json"), "w") as f:
+        json.dump(cases, f, indent=0)
+    print("gptq:", len(cases), "cases")
+
+
+def gen_digests(out):
+    """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
+    d = {}
+    w = weight("normal", 0, 256, 512)
+    q, s, z = rtn_call(w, "int8", "tensor", -1, True, False, 1.0, False)
+    d["config1"] = dict(k=256, n=512, seed=0, kind="normal", qtype="int8", strategy="tensor",
+                        group_size=-1, symmetric=True, w_sha=sha16(w), q_sha=sha16(q),
+                        scale_hex=s.tobytes().hex(), zp=int(z))
+    w = weight("normal", 0, 4096, 11008)
+    for sym in (False, True):
+        q, s, z = rtn_call(w, "uint4", "group", 128, sym, False, 1.0, False)
+        d[f"config2_{'sym' if sym else 'asym'}"] = dict(
+            k=4096, n=11008, seed=0, kind="normal", qtype="uint4", strategy="group",
+            group_size=128, symmetric=sym, w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(s),
+            z_sha=sha16(z), scale0_hex=s[0].tobytes().hex(), zp_head=z[:4, 0].tolist(),
+            q_head=q[:4, 0].tolist())
+    w = weight("heavy", 1, 4096, 11008)
+    q, s, z = rtn_call(w, "uint4", "group", 128, False, False, 1.0, False)
+    d["config2_heavy"] = dict(k=4096, n=11008, seed=1, kind="heavy", qtype="uint4",
+                              strategy="group", group_size=128, symmetric=False,
+                              w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(s), z_sha=sha16(z))
+    w = weight("zero_groups", 2, 4096, 11008)
+    q, s, z = rtn_call(w, "uint4", "group", 128, False, False, 1.0, False)
+    d["config2_zero_groups"] = dict(k=4096, n=11008, seed=2, kind="zero_groups", qtype="uint4",
+                                    strategy="group", group_size=128, symmetric=False,
+                                    w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(s),
+                                    z_sha=sha16(z))
+    w = weight("normal", 5, 4096, 4096)
+    q, s, z = rtn_call(w, "int8", "channel", -1, False, False, 1.0, False)
+    d["channel_4096"] = dict(k=4096, n=4096, seed=5, kind="normal", qtype="int8",
+                             strategy="channel", group_size=-1, symmetric=False,
+                             w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(s), z_sha=sha16(z))
+    q, s, z = rtn_call(w, "int4", "group", 128, False, False, 1.0, False)
+    d["int4_g128_4096"] = dict(k=4096, n=4096, seed=5, kind="normal", qtype="int4",
+                               strategy="group", group_size=128, symmetric=False,
+                               w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(s), z_sha=sha16(z))
+    with open(os.path.join(out, "digests.json"), "w") as f:
+        json.dump(d, f, indent=1)
+    print("digests: ok")
+
+
+def main():
+    out = HERE
+    gen_scalar_kats(out)
+    gen_rtn_small(out)
+    gen_rtn_mse(out)
+    gen_kernels(out)
+    gen_minmax(out)
+    gen_gptq(out)
+    gen_digests(out)
+    meta = dict(numpy=np.__version__, python=sys.version.split()[0],
+                reference="/root/reference (AyoubMDL/onnx_quantize v0.3.0 checkout)")
+    with open(os.path.join(out, "PROVENANCE.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
