@@ -1,0 +1,190 @@
+/*
+ * oq_hip.h -- C ABI of the MI355X (gfx950) implementation of onnx_quantize's numeric hot path.
+ *
+ * This is the drop-in boundary.  The reference is pure Python/NumPy and has no
+ * FFI of its own; every entry point below replaces one NumPy function of the reference, cited as
+ * file:line relative to /root/reference/src/onnx_quantize.  The binding a reference maintainer would
+ * add is a ctypes stub -- shown in INTEGRATION.md and implemented in onnx_quantize_amd/hip/_lib.py.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no torch / HIP types.  `stream` is a hipStream_t passed as
+ *     void* (NULL = the null stream).  All data pointers are DEVICE pointers unless marked HOST.
+ *   - every function is asynchronous on `stream` and never allocates: the caller owns inputs, outputs
+ *     and the workspace (size from the matching *_workspace_bytes query).  Inputs are never mutated
+ *     unless the parameter is documented in/out.
+ *   - return value: 0 (OQ_OK) or a negative oq_status; oq_last_error() returns a thread-local,
+ *     human-readable description of the last failure on the calling thread.
+ *   - weights are fp32, row-major [K, N] = (in_channels, out_channels) with leading dimension ldw
+ *     (elements); groups run along K for a fixed output channel, exactly like
+ *     core/_algorithms/utils.py:6-26.
+ *   - 4-bit results are returned one value per byte (int8/uint8 containers, like the reference's
+ *     in-memory ml_dtypes arrays) unless a packed layout is requested.
+ */
+#ifndef OQ_HIP_H
+#define OQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OQ_ABI_VERSION 1
+
+typedef enum {
+    OQ_OK = 0,
+    OQ_ERR_INVALID_ARGUMENT = -1, /* null pointer, negative size, bad enum ...            */
+    OQ_ERR_UNSUPPORTED = -2,      /* valid request this build has no kernel for           */
+    OQ_ERR_WORKSPACE = -3,        /* workspace missing or too small                       */
+    OQ_ERR_LAUNCH = -4,           /* HIP reported an error (text in oq_last_error())      */
+    OQ_ERR_NOT_SPD = -5           /* Cholesky hit a non-positive pivot (see oq_gptq_factor) */
+} oq_status;
+
+/* core/_dtypes.py:33-41 (QuantType); ranges core/_dtypes.py:8-30 */
+typedef enum { OQ_INT4 = 0, OQ_UINT4 = 1, OQ_INT8 = 2, OQ_UINT8 = 3, OQ_INT32 = 4, OQ_UINT32 = 5 } oq_qtype;
+/* core/_qconfig.py:31-36 (QuantizationStrategy) */
+typedef enum { OQ_TENSOR = 0, OQ_CHANNEL = 1, OQ_GROUP = 2 } oq_strategy;
+/* layout of the integer output of oq_rtn_quantize_f32 */
+typedef enum {
+    OQ_LAYOUT_KN = 0,    /* [K, N], one value per byte: what _rtn_quantize returns (rtn.py:106-109)     */
+    OQ_LAYOUT_NBITS = 1  /* MatMulNBits blob [N, K/g, g*bits/8] (qrules/_common.py:65-87), 4/8-bit group */
+} oq_layout;
+/* error-feedback indexing of the GPTQ loop */
+typedef enum {
+    OQ_GPTQ_PARITY = 0,   /* gptq.py:199,:208 as written: column of the UPPER factor below the diagonal (zeros) */
+    OQ_GPTQ_CORRECTED = 1 /* row of the upper factor right of the diagonal (what GPTQ intends); opt-in          */
+} oq_gptq_mode;
+
+int32_t oq_abi_version(void);
+const char* oq_last_error(void);
+const char* oq_status_string(int32_t status);
+/* name of the device code object the library was built for ("gfx950") */
+const char* oq_target_arch(void);
+
+/* T1: core/_dtypes.py:61-70 QuantType.qrange(is_symmetric, reduce_range).  HOST pointers. */
+int32_t oq_qrange(int32_t qtype, int32_t symmetric, int32_t reduce_range, int64_t* qmin, int64_t* qmax);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1  core/_algorithms/rtn.py:54-109  _rtn_quantize  (= L1 utils.py:6 + R1 utils.py:42 + Q1 utils.py:242
+ *     [+ M1 utils.py:140 when mse] + K1 utils.py:72 + L2 utils.py:29, fused).
+ *
+ *   W          [K, N] fp32, leading dimension ldw >= N
+ *   group_size GROUP only: > 0 (clamped to K), or -1 (= K).  K % group_size must be 0 (the reference's
+ *              product path guarantees it, qrules/_common.py:13-29) or N*K % group_size == 0 (groups
+ *              then straddle columns exactly like W.T.reshape(-1, g)).
+ *   q_out      OQ_LAYOUT_KN: K*N bytes.  OQ_LAYOUT_NBITS: N*(K/g)*(g*bits/8) bytes.
+ *   scale_out  fp32: 1 (tensor) | N (channel) | N*K/g (group; entry n*(K/g)+kg)
+ *   zp_out     same count, 1 byte each (the weight container dtype)
+ * ------------------------------------------------------------------------------------------- */
+size_t oq_rtn_workspace_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size, int32_t mse);
+int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,
+                            int32_t strategy, int64_t group_size, int32_t symmetric,
+                            int32_t reduce_range, float clip_ratio, int32_t mse, void* q_out,
+                            float* scale_out, void* zp_out, int32_t layout, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* Q2  core/_algorithms/utils.py:302-348  _compute_qparams_from_array on [K, N] weights (no integer
+ *     output): same arguments and outputs as above minus q_out. */
+int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,
+                           int32_t strategy, int64_t group_size, int32_t symmetric,
+                           int32_t reduce_range, float clip_ratio, int32_t mse, float* scale_out,
+                           void* zp_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Q1  core/_algorithms/utils.py:242-299  _compute_qparams on `count` (rmin, rmax) pairs.
+ *     zp_out is written as int32 (caller narrows to the zero-point dtype). */
+int32_t oq_qparams_f32(const float* rmin, const float* rmax, int64_t count, int32_t qtype,
+                       int32_t symmetric, int32_t reduce_range, float* scale_out, int32_t* zp_out,
+                       void* stream);
+
+/* K1  core/_algorithms/utils.py:72-79  _quantize_array_from_qparams, and
+ * K2  core/_algorithms/utils.py:102-137 _dequantize_array, on a row-major [R, C] array.
+ *     The (scale, zp) entry used by element (r, c) is  (r / row_div) * row_stride + c * col_stride :
+ *       per tensor            row_div=1 row_stride=0 col_stride=0
+ *       per row  ([R] params) row_div=1 row_stride=1 col_stride=0   (the reference's preprocessed layout)
+ *       per column ([C])      row_div=1 row_stride=0 col_stride=1   (channel params on [K, N])
+ *       groups of g rows      row_div=g row_stride=1 col_stride=R/g (group params on [K, N])
+ *     zp is int32 per entry; q is 1 byte per value (4/8-bit types) or int32 (32-bit types). */
+int32_t oq_quantize_f32(const float* x, int64_t R, int64_t C, int64_t ldx, const float* scale,
+                        const int32_t* zp, int64_t row_div, int64_t row_stride, int64_t col_stride,
+                        int32_t qtype, int32_t symmetric, int32_t reduce_range, void* q_out, void* stream);
+int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, const float* scale,
+                          const int32_t* zp, int64_t row_div, int64_t row_stride, int64_t col_stride,
+                          float* x_out, int64_t ldo, void* stream);
+
+/* A3  core/_algorithms/rtn.py:112-138  _quantize_bias: bias_scale = w_scale * x_scale (fp32),
+ *     q = clip(int32(rint(bias / bias_scale))).  w_scale has 1 or n entries. */
+int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale,
+                             float x_scale, int32_t* q_out, float* bias_scale_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C1  core/_calibration/minmax.py:40-64  MinMaxCalibrator.collect for one activation tensor:
+ *     cur = (min(x), max(x)); first sight: state = cur; momentum > 0: state = m*state + (1-m)*cur
+ *     (fp32, the two products rounded separately); else running min / max.
+ *   state  DEVICE float[4] in/out: {min, max, seen (0.0 = nothing collected yet), unused}
+ *   momentum is the Python float of the reference; the kernel uses T(momentum) and T(1 - momentum)
+ *   exactly as NumPy's weak-scalar promotion does.  The whole update happens on the device; nothing
+ *   is copied back.
+ * ------------------------------------------------------------------------------------------- */
+size_t oq_minmax_workspace_bytes(int64_t count);
+int32_t oq_minmax_collect_f32(const float* x, int64_t count, float* state, double momentum,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int32_t oq_minmax_collect_f64(const double* x, int64_t count, double* state, double momentum,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* S1  pre_passes/smooth_quant.py:62-74: out[c] = max_r |x[r, c]| for a row-major [R, C] array
+ *     (activations flattened to [T, K]; for a weight's per-in-channel absmax pass transposed=1 to
+ *     get out[r] = max_c |x[r, c]|). */
+size_t oq_absmax_workspace_bytes(int64_t R, int64_t C, int32_t transposed);
+int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t transposed,
+                      float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * G1  core/_algorithms/gptq.py:246-260  _accumulate_hessian:
+ *       H *= n_seen / (n_seen + n_add);  H += (2 / (n_seen + n_add)) * X^T X      (fp32, MFMA)
+ *     X [T, K] row-major (ldx), H [K, K] row-major, in/out, full symmetric matrix is maintained.
+ *     n_add is the LEADING dimension of the activation before flattening (gptq.py:247), i.e. the
+ *     number of samples, not T.
+ * ------------------------------------------------------------------------------------------- */
+int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen,
+                                  int64_t n_add, float* H, void* stream);
+
+/* G3 prologue  gptq.py:118-127: dead = diag(H) == 0 -> H[d,d] = 1, W[d,:] = 0 (both in place);
+ *     when actorder: perm_out = argsort(diag(H)) reversed (ties: larger index first) and W, H are
+ *     permuted in place (Wtmp/Htmp-free: uses the workspace).  perm_out may be NULL otherwise. */
+size_t oq_gptq_prepare_workspace_bytes(int64_t K, int64_t N, int32_t actorder);
+int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t actorder,
+                            int32_t* perm_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* G2  gptq.py:134-150: H += percdamp*mean(diag H) on the diagonal, then the UPPER factor U with
+ *     inv(H) = U^T U, written to U_out [K, K] (strictly-lower part zeroed).  H is consumed (overwritten).
+ *     info (DEVICE int32): 0 = ok; > 0 = first non-positive pivot (1-based), in which case U_out = I
+ *     (the reference's LinAlgError fallback, gptq.py:143-150).  The call itself still returns OQ_OK. */
+size_t oq_gptq_factor_workspace_bytes(int64_t K);
+int32_t oq_gptq_factor_f32(float* H, int64_t K, float percdamp, float* U_out, int32_t* info,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* G3  gptq.py:153-216: the block / row loop.  W [K, N] is consumed (overwritten with the working
+ *     copy).  Outputs: Q_int [K, N] one value per byte, Q_deq [K, N] fp32 (the dequantized rows the
+ *     final qparams are re-derived from, gptq.py:219-231), and -- for OQ_GPTQ_CORRECTED -- the
+ *     (scale, zp) actually applied per (k-group, column): used_scale/used_zp [K/g_loop, N] (may be NULL).
+ *     group_size: the reference's loop value (<=0 or -1: no regrouping inside the loop).
+ *     loop_strategy: OQ_TENSOR or OQ_CHANNEL (gptq.py:92-96: GROUP is mapped to CHANNEL by the caller). */
+size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size);
+int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype,
+                         int32_t loop_strategy, int64_t group_size, int32_t symmetric,
+                         int32_t reduce_range, float clip_ratio, int32_t mse, int64_t block_size,
+                         int32_t mode, void* q_int_out, float* q_deq_out, float* used_scale,
+                         int32_t* used_zp, void* workspace, size_t workspace_bytes, void* stream);
+
+/* N3  qrules/_common.py:65-123: MatMulNBits zero-point packing [N, ceil(K/g / 2)] (pad nibble 0x8)
+ *     from the per-group zero points [N*K/g] (1 byte each).  4-bit only. */
+int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out, void* stream);
+/* N3  core/_pack.py:8-22: flat nibble packing (element 2j -> low nibble of byte j) of `count` 4-bit
+ *     values stored one per byte; out has (count+1)/2 bytes. */
+int32_t oq_pack_nibbles(const void* values, int64_t count, uint8_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OQ_HIP_H */

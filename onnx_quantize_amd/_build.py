@@ -1,0 +1,82 @@
+"""Build liboq_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m onnx_quantize_amd._build          # incremental
+    python -m onnx_quantize_amd._build --force
+
+hipcc cross-compiles without a GPU.  Objects go to ``build/`` (git-ignored), the shared
+library to ``onnx_quantize_amd/lib/liboq_hip.so`` (git-ignored, but it travels with the
+repo snapshot to the GPU box).
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(ROOT, "build", "oq_hip")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "liboq_hip.so")
+ARCH = "gfx950"
+
+# -ffp-contract=off: the reference rounds every product/sum separately (SURVEY.md finding 3);
+# no fast-math anywhere: fp32 division must stay IEEE (utils.py:73).
+CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+            "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def sources() -> list[str]:
+    return sorted(os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".hip"))
+
+
+def _deps_mtime() -> float:
+    hdrs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".hpp", ".h"))]
+    hdrs.append(os.path.join(ROOT, "include", "oq_hip.h"))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    newest = max(os.path.getmtime(src), _deps_mtime())
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        return obj
+    cmd = [hipcc(), *CXXFLAGS, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    srcs = sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[oq build] linked {LIB}")
+    elif verbose:
+        print(f"[oq build] up to date: {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

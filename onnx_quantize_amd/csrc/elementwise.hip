@@ -1,0 +1,193 @@
+// Q1 / K1 / K2 / A3 and the wire-format packers as standalone gfx950 kernels.  These are the small
+// building blocks the reference calls by name (utils.py:72-137, :242-299; rtn.py:112-138;
+// qrules/_common.py:96-121; _pack.py:8-22); the bulk RTN path fuses them in rtn.hip instead.
+#include "oq_common.hpp"
+
+namespace oq {
+
+__global__ void qparams_kernel(const float* rmin, const float* rmax, int64_t count, QGrid grid, float* scale,
+                               int32_t* zp) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    // utils.py:242 takes ranges that already include zero and the clip ratio: no R1 tail here.
+    const QParam p = qparam_from_range(rmin[i], rmax[i], grid);
+    scale[i] = p.scale;
+    zp[i] = p.zp;
+}
+
+struct ParamIndex {
+    int64_t row_div, row_stride, col_stride;
+    __device__ __forceinline__ int64_t operator()(int64_t r, int64_t c) const {
+        return (r / row_div) * row_stride + c * col_stride;
+    }
+};
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void quantize_kernel(const float* x, int64_t R, int64_t C, int64_t ldx,
+                                                       const float* scale, const int32_t* zp, ParamIndex pi,
+                                                       int64_t qmin, int64_t qmax, OutT* q) {
+    const int64_t total = R * C;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+         t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t r = t / C, c = t - r * C;
+        const int64_t p = pi(r, c);
+        if constexpr (sizeof(OutT) == 1) {
+            q[t] = static_cast<OutT>(quantize_one(x[r * ldx + c], scale[p], zp[p], static_cast<int32_t>(qmin),
+                                                  static_cast<int32_t>(qmax)));
+        } else {
+            // 32-bit containers: int32(rint(x / s)) + zp is evaluated in int64 before the clamp, which is
+            // what NumPy does for uint32 zero points and is equivalent for int32 ones inside the range.
+            const int64_t v = static_cast<int64_t>(static_cast<int32_t>(rintf(x[r * ldx + c] / scale[p]))) + zp[p];
+            q[t] = static_cast<OutT>(v < qmin ? qmin : (v > qmax ? qmax : v));
+        }
+    }
+}
+
+template <typename InT>
+__global__ __launch_bounds__(256) void dequantize_kernel(const InT* q, int64_t R, int64_t C, const float* scale,
+                                                         const int32_t* zp, ParamIndex pi, float* out, int64_t ldo) {
+    const int64_t total = R * C;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+         t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t r = t / C, c = t - r * C;
+        const int64_t p = pi(r, c);
+        // utils.py:130-132: both operands go to fp32 first (exact for |q| < 2^24; int32 rounds like astype)
+        out[r * ldo + c] = (static_cast<float>(q[t]) - static_cast<float>(zp[p])) * scale[p];
+    }
+}
+
+__global__ void bias_kernel(const float* bias, int64_t n, const float* w_scale, int64_t n_w, float x_scale,
+                            int32_t* q, float* bscale) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = w_scale[n_w == 1 ? 0 : i] * x_scale;  // rtn.py:129 (fp32 product)
+    bscale[i] = s;
+    // rtn.py:130-137 -> utils.py:72-79 with QInt32 full range, zero point 0; the int32 cast of an
+    // out-of-range quotient saturates here (NumPy's is platform-defined there).
+    q[i] = static_cast<int32_t>(rintf(bias[i] / s));
+}
+
+__global__ void pack_zp_u4_kernel(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out) {
+    const int64_t half = (blocks + 1) / 2;
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= N * half) return;
+    const int64_t n = t / half, j = t - n * half;
+    const uint32_t lo = zp[n * blocks + 2 * j] & 0x0fu;
+    const uint32_t hi = (2 * j + 1 < blocks) ? (zp[n * blocks + 2 * j + 1] & 0x0fu) : 0x8u;  // _common.py:106-109
+    out[t] = static_cast<uint8_t>(lo | (hi << 4));
+}
+
+__global__ void pack_nibbles_kernel(const uint8_t* v, int64_t count, uint8_t* out) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= (count + 1) / 2) return;
+    const uint32_t lo = v[2 * t] & 0x0fu;
+    const uint32_t hi = (2 * t + 1 < count) ? (v[2 * t + 1] & 0x0fu) : 0u;  // _pack.py:15-17 zero pad
+    out[t] = static_cast<uint8_t>(lo | (hi << 4));
+}
+
+static uint32_t grid_for(int64_t work, int block = 256) {
+    const int64_t b = ceil_div(work, block);
+    return static_cast<uint32_t>(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+}  // namespace oq
+
+extern "C" {
+
+using namespace oq;
+
+int32_t oq_qparams_f32(const float* rmin, const float* rmax, int64_t count, int32_t qtype, int32_t symmetric,
+                       int32_t reduce_range, float* scale_out, int32_t* zp_out, void* stream) {
+    OQ_REQUIRE(rmin && rmax && scale_out && zp_out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_qparams_f32: bad argument");
+    QGrid grid;
+    const int32_t st = make_grid(qtype, symmetric, reduce_range, 1.0f, &grid);
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(qparams_kernel, dim3(static_cast<uint32_t>(ceil_div(count, 256))), dim3(256), 0, as_stream(stream),
+                       rmin, rmax, count, grid, scale_out, zp_out);
+    return check_launch("qparams_kernel");
+}
+
+int32_t oq_quantize_f32(const float* x, int64_t R, int64_t C, int64_t ldx, const float* scale, const int32_t* zp,
+                        int64_t row_div, int64_t row_stride, int64_t col_stride, int32_t qtype, int32_t symmetric,
+                        int32_t reduce_range, void* q_out, void* stream) {
+    OQ_REQUIRE(x && scale && zp && q_out && R > 0 && C > 0 && ldx >= C && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_quantize_f32: bad argument");
+    int64_t qmin, qmax;
+    OQ_REQUIRE(qrange_host(qtype, symmetric, reduce_range, &qmin, &qmax), OQ_ERR_INVALID_ARGUMENT,
+               "oq_quantize_f32: unknown quantization type %d", qtype);
+    const ParamIndex pi{row_div, row_stride, col_stride};
+    const dim3 grid(grid_for(R * C)), block(256);
+    hipStream_t s = as_stream(stream);
+    switch (qtype) {
+        case OQ_INT4: case OQ_INT8:
+            hipLaunchKernelGGL(quantize_kernel<int8_t>, grid, block, 0, s, x, R, C, ldx, scale, zp, pi, qmin, qmax,
+                               static_cast<int8_t*>(q_out));
+            break;
+        case OQ_UINT4: case OQ_UINT8:
+            hipLaunchKernelGGL(quantize_kernel<uint8_t>, grid, block, 0, s, x, R, C, ldx, scale, zp, pi, qmin, qmax,
+                               static_cast<uint8_t*>(q_out));
+            break;
+        case OQ_INT32:
+            hipLaunchKernelGGL(quantize_kernel<int32_t>, grid, block, 0, s, x, R, C, ldx, scale, zp, pi, qmin, qmax,
+                               static_cast<int32_t*>(q_out));
+            break;
+        default:
+            hipLaunchKernelGGL(quantize_kernel<uint32_t>, grid, block, 0, s, x, R, C, ldx, scale, zp, pi, qmin, qmax,
+                               static_cast<uint32_t*>(q_out));
+            break;
+    }
+    return check_launch("quantize_kernel");
+}
+
+int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, const float* scale, const int32_t* zp,
+                          int64_t row_div, int64_t row_stride, int64_t col_stride, float* x_out, int64_t ldo,
+                          void* stream) {
+    OQ_REQUIRE(q && scale && zp && x_out && R > 0 && C > 0 && ldo >= C && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_dequantize_f32: bad argument");
+    OQ_REQUIRE(qtype >= OQ_INT4 && qtype <= OQ_UINT32, OQ_ERR_INVALID_ARGUMENT, "oq_dequantize_f32: unknown type %d", qtype);
+    const ParamIndex pi{row_div, row_stride, col_stride};
+    const dim3 grid(grid_for(R * C)), block(256);
+    hipStream_t s = as_stream(stream);
+    switch (qtype) {
+        case OQ_INT4: case OQ_INT8:
+            hipLaunchKernelGGL(dequantize_kernel<int8_t>, grid, block, 0, s, static_cast<const int8_t*>(q), R, C, scale, zp, pi, x_out, ldo);
+            break;
+        case OQ_UINT4: case OQ_UINT8:
+            hipLaunchKernelGGL(dequantize_kernel<uint8_t>, grid, block, 0, s, static_cast<const uint8_t*>(q), R, C, scale, zp, pi, x_out, ldo);
+            break;
+        case OQ_INT32:
+            hipLaunchKernelGGL(dequantize_kernel<int32_t>, grid, block, 0, s, static_cast<const int32_t*>(q), R, C, scale, zp, pi, x_out, ldo);
+            break;
+        default:
+            hipLaunchKernelGGL(dequantize_kernel<uint32_t>, grid, block, 0, s, static_cast<const uint32_t*>(q), R, C, scale, zp, pi, x_out, ldo);
+            break;
+    }
+    return check_launch("dequantize_kernel");
+}
+
+int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale, float x_scale,
+                             int32_t* q_out, float* bias_scale_out, void* stream) {
+    OQ_REQUIRE(bias && w_scale && q_out && bias_scale_out && n > 0, OQ_ERR_INVALID_ARGUMENT, "oq_quantize_bias_f32: bad argument");
+    OQ_REQUIRE(n_w_scale == 1 || n_w_scale == n, OQ_ERR_INVALID_ARGUMENT,
+               "oq_quantize_bias_f32: weight scale must have 1 or %lld entries, got %lld", (long long)n, (long long)n_w_scale);
+    hipLaunchKernelGGL(bias_kernel, dim3(static_cast<uint32_t>(ceil_div(n, 256))), dim3(256), 0, as_stream(stream), bias, n,
+                       w_scale, n_w_scale, x_scale, q_out, bias_scale_out);
+    return check_launch("bias_kernel");
+}
+
+int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out, void* stream) {
+    OQ_REQUIRE(zp && out && N > 0 && blocks > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_zero_points_u4: bad argument");
+    const int64_t work = N * ((blocks + 1) / 2);
+    hipLaunchKernelGGL(pack_zp_u4_kernel, dim3(static_cast<uint32_t>(ceil_div(work, 256))), dim3(256), 0, as_stream(stream), zp,
+                       N, blocks, out);
+    return check_launch("pack_zp_u4_kernel");
+}
+
+int32_t oq_pack_nibbles(const void* values, int64_t count, uint8_t* out, void* stream) {
+    OQ_REQUIRE(values && out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_nibbles: bad argument");
+    hipLaunchKernelGGL(pack_nibbles_kernel, dim3(static_cast<uint32_t>(ceil_div((count + 1) / 2, 256))), dim3(256), 0,
+                       as_stream(stream), static_cast<const uint8_t*>(values), count, out);
+    return check_launch("pack_nibbles_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+// Internal helpers shared by the gfx950 kernels of liboq_hip.so.  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/oq_hip.h"
+
+namespace oq {
+
+constexpr int kWave = 64;  // CDNA wavefront width (hard-coded: no wave-size macro on gfx950)
+
+// ------------------------------------------------------------------ errors (host side)
+void set_error(const char* fmt, ...);
+int32_t fail(int32_t status, const char* fmt, ...);
+int32_t check_launch(const char* what);
+
+#define OQ_REQUIRE(cond, status, ...)                 \
+    do {                                              \
+        if (!(cond)) return ::oq::fail((status), __VA_ARGS__); \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ------------------------------------------------------------------ quantization grid (T1)
+// core/_dtypes.py:8-30, :61-70.  Host-evaluated once per call and passed to kernels by value.
+struct QGrid {
+    int32_t qmin;      // qrange(symmetric, reduce_range): clamp range AND the range the scale is derived from
+    int32_t qmax;
+    int32_t symmetric;
+    int32_t zero;      // symmetric zero point: round_half_even((qmax+qmin)/2)
+    double levels;     // symmetric: min(qmax - zero, zero - qmin)   (float64 in the reference)
+    float clip_ratio;  // utils.py:63-64
+    int32_t bits;
+};
+
+bool qrange_host(int32_t qtype, int32_t symmetric, int32_t reduce_range, int64_t* qmin, int64_t* qmax);
+int32_t make_grid(int32_t qtype, int32_t symmetric, int32_t reduce_range, float clip_ratio, QGrid* out);
+
+// ------------------------------------------------------------------ device arithmetic
+// All of this file is compiled with -ffp-contract=off: the reference rounds every product and sum
+// separately, a fused multiply-add would change results.
+
+struct QParam {
+    float scale;
+    int32_t zp;
+};
+
+// R1 tail + Q1: raw (min, max) of a row -> (scale, zero point).
+//   utils.py:63-69   lo = min(min*clip, 0), hi = max(max*clip, 0)
+//   utils.py:258-271 asymmetric   utils.py:273-298 symmetric (float64 division, see oracle)
+__device__ __forceinline__ QParam qparam_from_range(float lo, float hi, const QGrid& g) {
+    QParam p;
+    if (g.symmetric) {
+        float amax = fmaxf(fabsf(lo), fabsf(hi));
+        double s = static_cast<double>(amax) / g.levels;
+        if (s < static_cast<double>(FLT_MIN)) s = 1.0;
+        p.scale = static_cast<float>(s);
+        p.zp = g.zero;
+    } else {
+        float s = (hi - lo) / static_cast<float>(g.qmax - g.qmin);
+        if (s < FLT_MIN) s = 1.0f;
+        float z = static_cast<float>(g.qmin) - lo / s;
+        z = fminf(fmaxf(z, static_cast<float>(g.qmin)), static_cast<float>(g.qmax));
+        p.scale = s;
+        p.zp = static_cast<int32_t>(rintf(z));
+    }
+    return p;
+}
+
+__device__ __forceinline__ QParam qparam_from_minmax(float mn, float mx, const QGrid& g) {
+    float lo = fminf(mn * g.clip_ratio, 0.0f);
+    float hi = fmaxf(mx * g.clip_ratio, 0.0f);
+    return qparam_from_range(lo, hi, g);
+}
+
+// K1 utils.py:72-79: fp32 divide (IEEE, correctly rounded), round-half-even, int32, + zp, clamp.
+__device__ __forceinline__ int32_t quantize_one(float x, float scale, int32_t zp, int32_t qmin, int32_t qmax) {
+    int32_t r = static_cast<int32_t>(rintf(x / scale));
+    r = static_cast<int32_t>(static_cast<uint32_t>(r) + static_cast<uint32_t>(zp));
+    return min(max(r, qmin), qmax);
+}
+
+// K2 utils.py:130-132: (f32(q) - f32(zp)) * scale, two roundings.
+__device__ __forceinline__ float dequantize_one(int32_t q, float scale, int32_t zp) {
+    return (static_cast<float>(q) - static_cast<float>(zp)) * scale;
+}
+
+// 64-lane butterfly reductions (no LDS).
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Blocks that share blockIdx % 8 share an XCD (and its L2) under the observed round-robin
+// placement.  Remap so that each XCD works on one CONTIGUOUS range of logical block ids:
+// speed only (partial lines of the scattered scale / zero-point outputs meet in one L2),
+// never correctness.  Bijective for any nblk (cdna_hip_programming.md section 5, XCD swizzle).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblk) {
+    const uint32_t q = nblk >> 3, r = nblk & 7u, x = b & 7u;
+    const uint32_t base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (b >> 3);
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace oq

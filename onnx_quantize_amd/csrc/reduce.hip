@@ -1,0 +1,240 @@
+// C1 (calibration min/max, minmax.py:40-64) and S1 (absmax, smooth_quant.py:62-74) for gfx950.
+// HBM-bound reductions: every element is read once with 16-byte loads, reduced in registers, across
+// the wave with butterfly shuffles, across the block through LDS; the running (min, max) state of a
+// tensor name lives in device memory and is updated by the last stage, so a calibration loop never
+// synchronises with the host.
+#include "oq_common.hpp"
+
+namespace oq {
+
+constexpr int kRedBlock = 512;      // 8 waves
+constexpr int kRedMaxBlocks = 2048;  // <= 256 CUs x 8 blocks (cdna_hip_programming.md Guideline 11)
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+template <typename T>
+__device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
+
+template <typename T>
+__device__ __forceinline__ void block_minmax(T& mn, T& mx, T* s_mn, T* s_mx) {
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w) {
+            mn = mn < s_mn[w] ? mn : s_mn[w];
+            mx = mx > s_mx[w] ? mx : s_mx[w];
+        }
+    }
+}
+
+// Stage 1: per-block partial (min, max).  x must be element-aligned only; the 16/32-byte body is
+// peeled by the host into [head | vector body | tail] through `vec_off`.
+template <typename T>
+__global__ __launch_bounds__(kRedBlock) void minmax_partial(const T* x, int64_t count, int64_t vec_off, T* partial) {
+    using V = typename Vec4<T>::type;
+    __shared__ T s_mn[kRedBlock / 64], s_mx[kRedBlock / 64];
+    T mn = INFINITY, mx = -INFINITY;
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    const int64_t nvec = (count - vec_off) / 4;
+    const V* xv = reinterpret_cast<const V*>(x + vec_off);
+    int64_t i = tid;
+    // two independent 16-byte loads in flight per lane and iteration
+    for (; i + stride < nvec; i += 2 * stride) {
+        const V a = xv[i], b = xv[i + stride];
+        mn = fmin(fmin(fmin(mn, a.x), fmin(a.y, a.z)), fmin(fmin(a.w, b.x), fmin(b.y, fmin(b.z, b.w))));
+        mx = fmax(fmax(fmax(mx, a.x), fmax(a.y, a.z)), fmax(fmax(a.w, b.x), fmax(b.y, fmax(b.z, b.w))));
+    }
+    for (; i < nvec; i += stride) {
+        const V a = xv[i];
+        mn = fmin(fmin(mn, a.x), fmin(fmin(a.y, a.z), a.w));
+        mx = fmax(fmax(mx, a.x), fmax(fmax(a.y, a.z), a.w));
+    }
+    // head and tail scalars
+    for (int64_t j = tid; j < vec_off; j += stride) { mn = fmin(mn, x[j]); mx = fmax(mx, x[j]); }
+    for (int64_t j = vec_off + nvec * 4 + tid; j < count; j += stride) { mn = fmin(mn, x[j]); mx = fmax(mx, x[j]); }
+    block_minmax(mn, mx, s_mn, s_mx);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = mn;
+        partial[2 * blockIdx.x + 1] = mx;
+    }
+}
+
+// Stage 2: fold the partials and apply minmax.py:50-64 to the device-resident state.
+template <typename T>
+__global__ __launch_bounds__(kRedBlock) void minmax_update(const T* partial, int nblocks, T* state, double momentum) {
+    __shared__ T s_mn[kRedBlock / 64], s_mx[kRedBlock / 64];
+    T mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        mn = fmin(mn, partial[2 * i]);
+        mx = fmax(mx, partial[2 * i + 1]);
+    }
+    block_minmax(mn, mx, s_mn, s_mx);
+    if (threadIdx.x != 0) return;
+    if (state[2] == T(0)) {            // minmax.py:50-51 first sight
+        state[0] = mn;
+        state[1] = mx;
+        state[2] = T(1);
+    } else if (momentum > 0.0) {       // minmax.py:53-60 EMA; products rounded separately (no FMA)
+        const T m = static_cast<T>(momentum), om = static_cast<T>(1.0 - momentum);
+        state[0] = m * state[0] + om * mn;
+        state[1] = m * state[1] + om * mx;
+    } else {                           // minmax.py:63-64
+        state[0] = fmin(state[0], mn);
+        state[1] = fmax(state[1], mx);
+    }
+}
+
+template <typename T>
+static int32_t minmax_collect(const T* x, int64_t count, T* state, double momentum, void* ws, size_t ws_bytes,
+                              void* stream) {
+    OQ_REQUIRE(x && state && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_collect: bad argument");
+    OQ_REQUIRE(momentum >= 0.0 && momentum < 1.0, OQ_ERR_INVALID_ARGUMENT, "Momentum must be in the range [0, 1).");
+    OQ_REQUIRE((reinterpret_cast<uintptr_t>(x) % sizeof(T)) == 0, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_collect: misaligned input");
+    int64_t nblocks = ceil_div(count, static_cast<int64_t>(kRedBlock) * 8);
+    if (nblocks > kRedMaxBlocks) nblocks = kRedMaxBlocks;
+    if (nblocks < 1) nblocks = 1;
+    const size_t need = static_cast<size_t>(kRedMaxBlocks) * 2 * sizeof(double);
+    OQ_REQUIRE(ws && ws_bytes >= need, OQ_ERR_WORKSPACE, "oq_minmax_collect: workspace of %zu bytes needed, %zu given", need, ws_bytes);
+    // peel to the vector alignment (4 elements)
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(x);
+    const uintptr_t valign = 4 * sizeof(T);
+    int64_t vec_off = static_cast<int64_t>(((valign - addr % valign) % valign) / sizeof(T));
+    if (vec_off > count) vec_off = count;
+    hipStream_t s = as_stream(stream);
+    T* partial = static_cast<T*>(ws);
+    hipLaunchKernelGGL(minmax_partial<T>, dim3(static_cast<uint32_t>(nblocks)), dim3(kRedBlock), 0, s, x, count, vec_off, partial);
+    int32_t st = check_launch("minmax_partial");
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(minmax_update<T>, dim3(1), dim3(kRedBlock), 0, s, partial, static_cast<int>(nblocks), state, momentum);
+    return check_launch("minmax_update");
+}
+
+// ------------------------------------------------------------------------------------- absmax
+constexpr int kAbsChunkRows = 128;
+
+__global__ __launch_bounds__(512) void absmax_cols_partial(const float* x, int64_t R, int64_t C, int64_t ldx, bool vec4,
+                                                           float* partial, uint32_t ncol_tiles) {
+    __shared__ float4 s_mx[8][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t col_tile = blockIdx.x % ncol_tiles, chunk = blockIdx.x / ncol_tiles;
+    const int64_t row0 = static_cast<int64_t>(chunk) * kAbsChunkRows + wave * 16;
+    const int64_t col0 = static_cast<int64_t>(col_tile) * 256;
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vec4) {
+        const int64_t c = col0 + lane * 4;
+        if (c < C) {
+            float4 t[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                t[r] = (row0 + r < R) ? *reinterpret_cast<const float4*>(x + (row0 + r) * ldx + c) : make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                mx[0] = fmaxf(mx[0], fabsf(t[r].x)); mx[1] = fmaxf(mx[1], fabsf(t[r].y));
+                mx[2] = fmaxf(mx[2], fabsf(t[r].z)); mx[3] = fmaxf(mx[3], fabsf(t[r].w));
+            }
+        }
+    } else {
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t c = col0 + i * 64 + lane;
+                if (c < C && row0 + r < R) mx[i] = fmaxf(mx[i], fabsf(x[(row0 + r) * ldx + c]));
+            }
+    }
+    s_mx[wave][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < 8; ++w) {
+        const float4 t = s_mx[w][lane];
+        mx[0] = fmaxf(mx[0], t.x); mx[1] = fmaxf(mx[1], t.y); mx[2] = fmaxf(mx[2], t.z); mx[3] = fmaxf(mx[3], t.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t c = vec4 ? col0 + lane * 4 + i : col0 + i * 64 + lane;
+        if (c < C) partial[static_cast<int64_t>(chunk) * C + c] = mx[i];
+    }
+}
+
+__global__ void absmax_cols_finalize(const float* partial, int64_t chunks, int64_t C, float* out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float m = 0.f;
+    for (int64_t k = 0; k < chunks; ++k) m = fmaxf(m, partial[k * C + c]);
+    out[c] = m;
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void absmax_rows(const float* x, int64_t R, int64_t C, int64_t ldx, bool vec4, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* row = x + r * ldx;
+    float m = 0.f;
+    if (vec4) {
+        for (int64_t c = lane * 4; c < C; c += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(row + c);
+            m = fmaxf(fmaxf(m, fabsf(t.x)), fmaxf(fmaxf(fabsf(t.y), fabsf(t.z)), fabsf(t.w)));
+        }
+    } else {
+        for (int64_t c = lane; c < C; c += 64) m = fmaxf(m, fabsf(row[c]));
+    }
+    m = wave_max(m);
+    if (lane == 0) out[r] = m;
+}
+
+}  // namespace oq
+
+extern "C" {
+
+using namespace oq;
+
+size_t oq_minmax_workspace_bytes(int64_t count) {
+    (void)count;
+    return static_cast<size_t>(kRedMaxBlocks) * 2 * sizeof(double);
+}
+
+int32_t oq_minmax_collect_f32(const float* x, int64_t count, float* state, double momentum, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    return minmax_collect<float>(x, count, state, momentum, workspace, workspace_bytes, stream);
+}
+
+int32_t oq_minmax_collect_f64(const double* x, int64_t count, double* state, double momentum, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    return minmax_collect<double>(x, count, state, momentum, workspace, workspace_bytes, stream);
+}
+
+size_t oq_absmax_workspace_bytes(int64_t R, int64_t C, int32_t transposed) {
+    if (transposed || R <= 0 || C <= 0) return 256;
+    return static_cast<size_t>(ceil_div(R, kAbsChunkRows) * C) * sizeof(float) + 256;
+}
+
+int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t transposed, float* out,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(x && out && R > 0 && C > 0 && ldx >= C, OQ_ERR_INVALID_ARGUMENT, "oq_absmax_f32: bad argument");
+    const bool vec4 = (C % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    hipStream_t s = as_stream(stream);
+    if (transposed) {
+        hipLaunchKernelGGL(absmax_rows, dim3(static_cast<uint32_t>(ceil_div(R, 4))), dim3(256), 0, s, x, R, C, ldx, vec4, out);
+        return check_launch("absmax_rows");
+    }
+    const int64_t chunks = ceil_div(R, kAbsChunkRows);
+    const size_t need = static_cast<size_t>(chunks * C) * sizeof(float);
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_absmax_f32: workspace of %zu bytes needed, %zu given",
+               need, workspace_bytes);
+    const uint32_t ncol_tiles = static_cast<uint32_t>(ceil_div(C, 256));
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(absmax_cols_partial, dim3(ncol_tiles * static_cast<uint32_t>(chunks)), dim3(512), 0, s, x, R, C, ldx,
+                       vec4, partial, ncol_tiles);
+    int32_t st = check_launch("absmax_cols_partial");
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(absmax_cols_finalize, dim3(static_cast<uint32_t>(ceil_div(C, 256))), dim3(256), 0, s, partial, chunks, C, out);
+    return check_launch("absmax_cols_finalize");
+}
+
+}  // extern "C"

@@ -1,0 +1,604 @@
+// A1: fused RTN weight quantization for gfx950 (rtn.py:54-109 of the reference, with utils.py:6-79
+// folded in).  HBM-bound byte work: W[K, N] fp32 is read exactly once with 16-byte coalesced loads,
+// held in registers, reduced down the K axis per column (lane-local, then across waves through a
+// small LDS exchange), turned into (scale, zero point) in registers and quantized from the same
+// registers.  Nothing is reshaped into a GEMM and no transposed copy (utils.py:24) is ever made.
+#include "oq_common.hpp"
+
+namespace oq {
+
+struct RtnArgs {
+    const float* W;
+    int64_t K, N, ldw;
+    int64_t g;        // rows per group (K for channel / tensor)
+    int64_t kgroups;  // K / g
+    uint8_t* q;       // may be null (qparams only)
+    float* scale;
+    uint8_t* zp;
+    QGrid grid;
+    int32_t layout;
+    int32_t wpg;      // waves per group
+    int32_t gpb;      // groups per block
+    uint32_t ncol_tiles, nrow_tiles;
+};
+
+constexpr int kColsPerWave = 256;  // 64 lanes x 4 columns: 1 KiB of one fp32 row per wave-instruction
+constexpr int kMaxWaves = 8;
+
+// Column owned by slot i of a lane.  VEC4: four neighbouring columns (one 16-byte load per row).
+// Scalar fallback (N % 4 != 0 or unaligned base): lane-strided so every load stays coalesced.
+template <bool VEC4>
+__device__ __forceinline__ int64_t slot_col(int64_t tile_col0, int lane, int i) {
+    return VEC4 ? tile_col0 + lane * 4 + i : tile_col0 + i * 64 + lane;
+}
+
+// NW consecutive little-endian 32-bit words to a (4*NW)-byte aligned address, widest stores first.
+template <int NW>
+__device__ __forceinline__ void store_words(uint8_t* dst, const uint32_t (&w)[NW]) {
+    if constexpr (NW % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < NW; j += 4) *reinterpret_cast<uint4*>(dst + 4 * j) = make_uint4(w[j], w[j + 1], w[j + 2], w[j + 3]);
+    } else if constexpr (NW % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < NW; j += 2) *reinterpret_cast<uint2*>(dst + 4 * j) = make_uint2(w[j], w[j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) *reinterpret_cast<uint32_t*>(dst + 4 * j) = w[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused one-pass kernel.  One block = GPB groups (stacked along K) x 256 columns; one group =
+// WPG waves x RPW rows.  Registers per lane: RPW x 4 fp32 of W.
+// ---------------------------------------------------------------------------------------------
+template <int RPW, bool VEC4, bool EMIT_Q>
+__global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArgs a) {
+    __shared__ float4 s_mn[kMaxWaves][kWave];
+    __shared__ float4 s_mx[kMaxWaves][kWave];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wig = wave % a.wpg;   // wave inside its group
+    const int gib = wave / a.wpg;   // group inside the block
+
+    const uint32_t nblk = a.ncol_tiles * a.nrow_tiles;
+    const uint32_t id = xcd_remap(blockIdx.x, nblk);
+    const uint32_t col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
+    const uint32_t row_tile = id - col_tile * a.nrow_tiles;
+
+    const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + gib;
+    const bool group_ok = kg < a.kgroups;
+    const int64_t row0 = kg * a.g + static_cast<int64_t>(wig) * RPW;
+    const int64_t tile_col0 = static_cast<int64_t>(col_tile) * kColsPerWave;
+
+    bool col_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) col_ok[i] = slot_col<VEC4>(tile_col0, lane, i) < a.N;
+
+    float v[RPW][4];
+    if (group_ok) {
+        if constexpr (VEC4) {
+            const float* p = a.W + row0 * a.ldw + tile_col0 + lane * 4;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                float4 t = col_ok[0] ? *reinterpret_cast<const float4*>(p + r * a.ldw) : make_float4(0, 0, 0, 0);
+                v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    v[r][i] = col_ok[i] ? a.W[(row0 + r) * a.ldw + slot_col<false>(tile_col0, lane, i)] : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[r][i] = 0.0f;
+    }
+
+    // R1 (utils.py:60-61): lane-local column min / max over this wave's rows.
+    float mn[4], mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mn[i] = mx[i] = v[0][i];
+#pragma unroll
+    for (int r = 1; r < RPW; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v[r][i]);
+            mx[i] = fmaxf(mx[i], v[r][i]);
+        }
+
+    if (a.wpg > 1) {  // uniform over the block: cross-wave combine of the group's partials in LDS
+        s_mn[wave][lane] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        s_mx[wave][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+        __syncthreads();
+        const int w0 = gib * a.wpg;
+        for (int w = 0; w < a.wpg; ++w) {
+            const float4 tn = s_mn[w0 + w][lane];
+            const float4 tx = s_mx[w0 + w][lane];
+            mn[0] = fminf(mn[0], tn.x); mn[1] = fminf(mn[1], tn.y);
+            mn[2] = fminf(mn[2], tn.z); mn[3] = fminf(mn[3], tn.w);
+            mx[0] = fmaxf(mx[0], tx.x); mx[1] = fmaxf(mx[1], tx.y);
+            mx[2] = fmaxf(mx[2], tx.z); mx[3] = fmaxf(mx[3], tx.w);
+        }
+    }
+    if (!group_ok) return;
+
+    // Q1 in registers (every wave of the group derives the same parameters).
+    QParam qp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qp[i] = qparam_from_minmax(mn[i], mx[i], a.grid);
+
+    if (wig == 0) {  // rtn.py:98-109 result layout: row n*(K/g)+kg of the [N*K/g, 1] arrays
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (col_ok[i]) {
+                const int64_t o = slot_col<VEC4>(tile_col0, lane, i) * a.kgroups + kg;
+                a.scale[o] = qp[i].scale;
+                a.zp[o] = static_cast<uint8_t>(qp[i].zp);
+            }
+    }
+    if constexpr (!EMIT_Q) return;
+
+    // K1 from registers.
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    if (a.layout == OQ_LAYOUT_KN) {
+        if constexpr (VEC4) {
+            if (col_ok[0]) {
+                uint8_t* o = a.q + row0 * a.N + tile_col0 + lane * 4;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        w |= (static_cast<uint32_t>(quantize_one(v[r][i], qp[i].scale, qp[i].zp, qmin, qmax)) & 0xffu) << (8 * i);
+                    *reinterpret_cast<uint32_t*>(o + r * a.N) = w;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (col_ok[i])
+                        a.q[(row0 + r) * a.N + slot_col<false>(tile_col0, lane, i)] =
+                            static_cast<uint8_t>(quantize_one(v[r][i], qp[i].scale, qp[i].zp, qmin, qmax));
+        }
+    } else {
+        // MatMulNBits blob (qrules/_common.py:72-87): for out-channel n, k-group kg: g*bits/8 bytes,
+        // k ascending, even k in the low nibble.  This wave owns bytes [wig*RPW*bits/8, +RPW*bits/8).
+        const int64_t blob = a.g * a.grid.bits / 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!col_ok[i]) continue;
+            const int64_t col = slot_col<VEC4>(tile_col0, lane, i);
+            uint8_t* o = a.q + (col * a.kgroups + kg) * blob;
+            if (a.grid.bits == 4) {
+                if constexpr (RPW >= 8) {
+                    uint32_t words[RPW / 8];
+#pragma unroll
+                    for (int wd = 0; wd < RPW / 8; ++wd) {
+                        uint32_t acc = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            acc |= (static_cast<uint32_t>(quantize_one(v[wd * 8 + j][i], qp[i].scale, qp[i].zp, qmin, qmax)) & 0xfu) << (4 * j);
+                        words[wd] = acc;
+                    }
+                    store_words<RPW / 8>(o + wig * (RPW / 2), words);
+                }
+            } else {
+                if constexpr (RPW >= 4) {
+                    uint32_t words[RPW / 4];
+#pragma unroll
+                    for (int wd = 0; wd < RPW / 4; ++wd) {
+                        uint32_t acc = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc |= (static_cast<uint32_t>(quantize_one(v[wd * 4 + j][i], qp[i].scale, qp[i].zp, qmin, qmax)) & 0xffu) << (8 * j);
+                        words[wd] = acc;
+                    }
+                    store_words<RPW / 4>(o + wig * RPW, words);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-pass path (channel, tensor, groups too tall for registers).  Pass 1: per (row chunk, column)
+// min / max.  Pass 2: fold the chunks of one group -> qparams.  Pass 3: elementwise K1.
+// ---------------------------------------------------------------------------------------------
+constexpr int kChunkRows = 128;  // 8 waves x 16 rows
+
+struct RangeArgs {
+    const float* W;
+    int64_t K, N, ldw;
+    int64_t g, kgroups, chunks;  // chunks per group = ceil(g / kChunkRows)
+    float* pmin;                 // [kgroups*chunks, N]
+    float* pmax;
+    uint32_t ncol_tiles, nrow_tiles;  // nrow_tiles = kgroups*chunks
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(kMaxWaves* kWave) void col_range_partial(const RangeArgs a) {
+    __shared__ float4 s_mn[kMaxWaves][kWave];
+    __shared__ float4 s_mx[kMaxWaves][kWave];
+    constexpr int RPW = kChunkRows / kMaxWaves;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t nblk = a.ncol_tiles * a.nrow_tiles;
+    const uint32_t id = xcd_remap(blockIdx.x, nblk);
+    const uint32_t col_tile = id / a.nrow_tiles;
+    const uint32_t row_tile = id - col_tile * a.nrow_tiles;
+    const int64_t kg = row_tile / a.chunks, c = row_tile % a.chunks;
+    const int64_t row_end = min(kg * a.g + a.g, a.K);
+    const int64_t row0 = kg * a.g + c * kChunkRows + wave * RPW;
+    const int64_t tile_col0 = static_cast<int64_t>(col_tile) * kColsPerWave;
+
+    float mn[4], mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mn[i] = INFINITY; mx[i] = -INFINITY; }
+    if constexpr (VEC4) {
+        const bool ok = tile_col0 + lane * 4 < a.N;
+        const float* p = a.W + row0 * a.ldw + tile_col0 + lane * 4;
+        float4 t[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+            t[r] = (ok && row0 + r < row_end) ? *reinterpret_cast<const float4*>(p + r * a.ldw)
+                                              : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const bool live = ok && row0 + r < row_end;
+            mn[0] = fminf(mn[0], t[r].x); mn[1] = fminf(mn[1], t[r].y);
+            mn[2] = fminf(mn[2], t[r].z); mn[3] = fminf(mn[3], t[r].w);
+            if (live) {
+                mx[0] = fmaxf(mx[0], t[r].x); mx[1] = fmaxf(mx[1], t[r].y);
+                mx[2] = fmaxf(mx[2], t[r].z); mx[3] = fmaxf(mx[3], t[r].w);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t col = slot_col<false>(tile_col0, lane, i);
+                if (col < a.N && row0 + r < row_end) {
+                    const float x = a.W[(row0 + r) * a.ldw + col];
+                    mn[i] = fminf(mn[i], x);
+                    mx[i] = fmaxf(mx[i], x);
+                }
+            }
+    }
+    s_mn[wave][lane] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+    s_mx[wave][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < kMaxWaves; ++w) {
+        const float4 tn = s_mn[w][lane], tx = s_mx[w][lane];
+        mn[0] = fminf(mn[0], tn.x); mn[1] = fminf(mn[1], tn.y); mn[2] = fminf(mn[2], tn.z); mn[3] = fminf(mn[3], tn.w);
+        mx[0] = fmaxf(mx[0], tx.x); mx[1] = fmaxf(mx[1], tx.y); mx[2] = fmaxf(mx[2], tx.z); mx[3] = fmaxf(mx[3], tx.w);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t col = slot_col<VEC4>(tile_col0, lane, i);
+        if (col < a.N) {
+            a.pmin[static_cast<int64_t>(row_tile) * a.N + col] = mn[i];
+            a.pmax[static_cast<int64_t>(row_tile) * a.N + col] = mx[i];
+        }
+    }
+}
+
+// Pass 2 (group / channel): thread per (kg, column).
+__global__ void col_range_finalize(const float* pmin, const float* pmax, int64_t N, int64_t kgroups,
+                                   int64_t chunks, QGrid grid, float* scale, uint8_t* zp) {
+    const int64_t col = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t kg = blockIdx.y;
+    if (col >= N) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t c = 0; c < chunks; ++c) {
+        mn = fminf(mn, pmin[(kg * chunks + c) * N + col]);
+        mx = fmaxf(mx, pmax[(kg * chunks + c) * N + col]);
+    }
+    const QParam p = qparam_from_minmax(mn, mx, grid);
+    scale[col * kgroups + kg] = p.scale;
+    zp[col * kgroups + kg] = static_cast<uint8_t>(p.zp);
+}
+
+// Pass 2 (tensor): one block folds every partial into one (scale, zp).
+__global__ __launch_bounds__(1024) void tensor_range_finalize(const float* pmin, const float* pmax, int64_t count,
+                                                              QGrid grid, float* scale, uint8_t* zp) {
+    __shared__ float s_mn[16], s_mx[16];
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
+        mn = fminf(mn, pmin[i]);
+        mx = fmaxf(mx, pmax[i]);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w) {
+            mn = fminf(mn, s_mn[w]);
+            mx = fmaxf(mx, s_mx[w]);
+        }
+        const QParam p = qparam_from_minmax(mn, mx, grid);
+        scale[0] = p.scale;
+        zp[0] = static_cast<uint8_t>(p.zp);
+    }
+}
+
+// Pass 3: q[k, n] = K1(W[k, n]; params[(k / g) + n * kgroups])  (tensor: one entry).
+struct QuantKnArgs {
+    const float* W;
+    int64_t K, N, ldw, g, kgroups;
+    const float* scale;
+    const uint8_t* zp;
+    uint8_t* q;
+    int32_t qmin, qmax, zp_signed, tensor;
+};
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void quantize_kn(const QuantKnArgs a) {
+    const int64_t cols4 = VEC4 ? a.N / 4 : a.N;
+    const int64_t total = a.K * cols4;
+    for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
+         t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t k = t / cols4, c = t - k * cols4;
+        if constexpr (VEC4) {
+            const float4 x = *reinterpret_cast<const float4*>(a.W + k * a.ldw + c * 4);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+            uint32_t w = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t pi = a.tensor ? 0 : (c * 4 + i) * a.kgroups + k / a.g;
+                const int32_t z = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.zp[pi])) : static_cast<int32_t>(a.zp[pi]);
+                w |= (static_cast<uint32_t>(quantize_one(xs[i], a.scale[pi], z, a.qmin, a.qmax)) & 0xffu) << (8 * i);
+            }
+            *reinterpret_cast<uint32_t*>(a.q + k * a.N + c * 4) = w;
+        } else {
+            const int64_t pi = a.tensor ? 0 : c * a.kgroups + k / a.g;
+            const int32_t z = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.zp[pi])) : static_cast<int32_t>(a.zp[pi]);
+            a.q[k * a.N + c] = static_cast<uint8_t>(quantize_one(a.W[k * a.ldw + c], a.scale[pi], z, a.qmin, a.qmax));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ragged fallback: K % g != 0 but N*K % g == 0, i.e. W.T.reshape(-1, g) lets a group run from the
+// tail of one column into the head of the next (utils.py:24).  One wave per group, strided gathers.
+// Correctness path only; the reference's product path never produces it (qrules/_common.py:13-29).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rtn_flat_groups(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t g,
+                                                       int64_t ngroups, QGrid grid, uint8_t* q, float* scale,
+                                                       uint8_t* zp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t grp = static_cast<int64_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (grp >= ngroups) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t t = lane; t < g; t += 64) {
+        const int64_t f = grp * g + t, n = f / K, k = f - n * K;
+        const float x = W[k * ldw + n];
+        mn = fminf(mn, x);
+        mx = fmaxf(mx, x);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const QParam p = qparam_from_minmax(mn, mx, grid);
+    if (lane == 0) {
+        scale[grp] = p.scale;
+        zp[grp] = static_cast<uint8_t>(p.zp);
+    }
+    if (q == nullptr) return;
+    for (int64_t t = lane; t < g; t += 64) {
+        const int64_t f = grp * g + t, n = f / K, k = f - n * K;
+        q[k * N + n] = static_cast<uint8_t>(quantize_one(W[k * ldw + n], p.scale, p.zp, grid.qmin, grid.qmax));
+    }
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Rows per wave / waves per group for the fused kernel; false when the group is too tall.
+static bool fused_shape(int64_t g, int* rpw, int* wpg) {
+    for (int r : {16, 8, 4, 2, 1}) {
+        if (g % r == 0 && g / r <= kMaxWaves) {
+            *rpw = r;
+            *wpg = static_cast<int>(g / r);
+            return true;
+        }
+    }
+    if (g % 32 == 0 && g / 32 <= kMaxWaves) {
+        *rpw = 32;
+        *wpg = static_cast<int>(g / 32);
+        return true;
+    }
+    return false;
+}
+
+template <bool VEC4, bool EMIT_Q>
+static void launch_fused(int rpw, const RtnArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    switch (rpw) {
+        case 1: hipLaunchKernelGGL((rtn_group_fused<1, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((rtn_group_fused<2, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+        case 4: hipLaunchKernelGGL((rtn_group_fused<4, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+        case 8: hipLaunchKernelGGL((rtn_group_fused<8, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+        case 16: hipLaunchKernelGGL((rtn_group_fused<16, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((rtn_group_fused<32, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+    }
+}
+
+static size_t twopass_ws(int64_t K, int64_t N, int64_t g) {
+    const int64_t kgroups = K / g, chunks = ceil_div(g, kChunkRows);
+    return static_cast<size_t>(2 * kgroups * chunks * N) * sizeof(float);
+}
+
+static int32_t resolve_group(int32_t strategy, int64_t K, int64_t group_size, int64_t* g) {
+    if (strategy == OQ_GROUP) {
+        OQ_REQUIRE(group_size > 0 || group_size == -1, OQ_ERR_INVALID_ARGUMENT,
+                   "group strategy needs group_size > 0 or -1, got %lld", (long long)group_size);
+        int64_t gs = group_size > K ? K : group_size;  // utils.py:19-20
+        if (gs == -1) gs = K;                          // utils.py:22
+        *g = gs;
+    } else if (strategy == OQ_CHANNEL || strategy == OQ_TENSOR) {
+        *g = K;
+    } else {
+        return fail(OQ_ERR_INVALID_ARGUMENT, "unknown strategy %d", strategy);
+    }
+    return OQ_OK;
+}
+
+int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                 int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
+                 void* q_out, float* scale_out, void* zp_out, int32_t layout, void* workspace,
+                 size_t workspace_bytes, void* stream, bool emit_q);
+
+}  // namespace oq
+
+// MSE search lives in rtn_mse.hip
+namespace oq {
+int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy,
+                     int64_t g, void* q_out, float* scale_out, void* zp_out, int32_t zp_signed, void* workspace,
+                     size_t workspace_bytes, hipStream_t s, bool emit_q);
+size_t rtn_mse_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
+
+int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                 int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
+                 void* q_out, float* scale_out, void* zp_out, int32_t layout, void* workspace,
+                 size_t workspace_bytes, void* stream, bool emit_q) {
+    OQ_REQUIRE(W && scale_out && zp_out && (q_out || !emit_q), OQ_ERR_INVALID_ARGUMENT, "rtn: null pointer argument");
+    OQ_REQUIRE(K > 0 && N > 0 && ldw >= N, OQ_ERR_INVALID_ARGUMENT, "rtn: bad shape K=%lld N=%lld ldw=%lld",
+               (long long)K, (long long)N, (long long)ldw);
+    OQ_REQUIRE(K * N < (1LL << 40), OQ_ERR_UNSUPPORTED, "rtn: matrix too large");
+    OQ_REQUIRE(clip_ratio > 0.0f && clip_ratio <= 1.0f, OQ_ERR_INVALID_ARGUMENT,
+               "clip_ratio must be in (0.0, 1.0], got %g", clip_ratio);
+    OQ_REQUIRE(layout == OQ_LAYOUT_KN || layout == OQ_LAYOUT_NBITS, OQ_ERR_INVALID_ARGUMENT, "rtn: bad layout %d", layout);
+    QGrid grid;
+    int32_t st = make_grid(qtype, symmetric, reduce_range, clip_ratio, &grid);
+    if (st != OQ_OK) return st;
+    int64_t g;
+    st = resolve_group(strategy, K, group_size, &g);
+    if (st != OQ_OK) return st;
+    hipStream_t s = as_stream(stream);
+    const int32_t zp_signed = (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0;
+    uint8_t* q8 = static_cast<uint8_t*>(q_out);
+    uint8_t* zp8 = static_cast<uint8_t*>(zp_out);
+
+    if (strategy == OQ_GROUP && K % g != 0) {
+        OQ_REQUIRE((K * N) % g == 0, OQ_ERR_INVALID_ARGUMENT,
+                   "cannot reshape array of size %lld into rows of %lld", (long long)(K * N), (long long)g);
+        OQ_REQUIRE(!mse, OQ_ERR_UNSUPPORTED, "mse with groups that straddle columns (K %% group_size != 0) is not supported");
+        OQ_REQUIRE(layout == OQ_LAYOUT_KN, OQ_ERR_UNSUPPORTED, "NBITS layout needs K %% group_size == 0");
+        const int64_t ngroups = K * N / g;
+        hipLaunchKernelGGL(rtn_flat_groups, dim3(static_cast<uint32_t>(ceil_div(ngroups, 4))), dim3(256), 0, s, W, K, N,
+                           ldw, g, ngroups, grid, emit_q ? q8 : nullptr, scale_out, zp8);
+        return check_launch("rtn_flat_groups");
+    }
+
+    if (mse) {
+        OQ_REQUIRE(layout == OQ_LAYOUT_KN, OQ_ERR_UNSUPPORTED, "NBITS layout with mse is not supported");
+        return rtn_mse_impl(W, K, N, ldw, grid, strategy, g, q_out, scale_out, zp_out, zp_signed, workspace,
+                            workspace_bytes, s, emit_q);
+    }
+
+    const bool vec4 = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(W) && (!emit_q || (reinterpret_cast<uintptr_t>(q_out) & 3u) == 0);
+    const int64_t kgroups = K / g;
+    int rpw = 0, wpg = 0;
+    const bool fused = strategy == OQ_GROUP && fused_shape(g, &rpw, &wpg);
+    if (layout == OQ_LAYOUT_NBITS) {
+        OQ_REQUIRE(fused && emit_q, OQ_ERR_UNSUPPORTED, "NBITS layout needs the group strategy with group_size <= 256");
+        OQ_REQUIRE(g % 16 == 0 && aligned16(q_out), OQ_ERR_UNSUPPORTED,
+                   "NBITS layout needs group_size %% 16 == 0 and a 16-byte aligned output");
+    }
+
+    if (fused) {
+        RtnArgs a;
+        a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
+        a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
+        a.wpg = wpg;
+        a.gpb = kMaxWaves / wpg > 0 ? kMaxWaves / wpg : 1;
+        if (a.gpb > kgroups) a.gpb = static_cast<int32_t>(kgroups);
+        a.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));
+        a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, a.gpb));
+        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        if (vec4) {
+            if (emit_q) launch_fused<true, true>(rpw, a, grid_dim, block, s);
+            else launch_fused<true, false>(rpw, a, grid_dim, block, s);
+        } else {
+            if (emit_q) launch_fused<false, true>(rpw, a, grid_dim, block, s);
+            else launch_fused<false, false>(rpw, a, grid_dim, block, s);
+        }
+        return check_launch("rtn_group_fused");
+    }
+
+    // two-pass
+    const size_t need = twopass_ws(K, N, g);
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "rtn: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    RangeArgs r;
+    r.W = W; r.K = K; r.N = N; r.ldw = ldw; r.g = g; r.kgroups = kgroups;
+    r.chunks = ceil_div(g, kChunkRows);
+    r.pmin = static_cast<float*>(workspace);
+    r.pmax = r.pmin + kgroups * r.chunks * N;
+    r.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));
+    r.nrow_tiles = static_cast<uint32_t>(kgroups * r.chunks);
+    const bool vec_in = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(W);
+    if (vec_in)
+        hipLaunchKernelGGL(col_range_partial<true>, dim3(r.ncol_tiles * r.nrow_tiles), dim3(kMaxWaves * kWave), 0, s, r);
+    else
+        hipLaunchKernelGGL(col_range_partial<false>, dim3(r.ncol_tiles * r.nrow_tiles), dim3(kMaxWaves * kWave), 0, s, r);
+    st = check_launch("col_range_partial");
+    if (st != OQ_OK) return st;
+    if (strategy == OQ_TENSOR) {
+        hipLaunchKernelGGL(tensor_range_finalize, dim3(1), dim3(1024), 0, s, r.pmin, r.pmax, kgroups * r.chunks * N, grid,
+                           scale_out, zp8);
+    } else {
+        hipLaunchKernelGGL(col_range_finalize, dim3(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups)),
+                           dim3(256), 0, s, r.pmin, r.pmax, N, kgroups, r.chunks, grid, scale_out, zp8);
+    }
+    st = check_launch("range_finalize");
+    if (st != OQ_OK || !emit_q) return st;
+    QuantKnArgs qa;
+    qa.W = W; qa.K = K; qa.N = N; qa.ldw = ldw; qa.g = g; qa.kgroups = kgroups;
+    qa.scale = scale_out; qa.zp = zp8; qa.q = q8;
+    qa.qmin = grid.qmin; qa.qmax = grid.qmax; qa.zp_signed = zp_signed; qa.tensor = strategy == OQ_TENSOR;
+    const int64_t work = vec4 ? K * (N / 4) : K * N;
+    const uint32_t blocks = static_cast<uint32_t>(work / 256 + 1 < 256 * 16 ? work / 256 + 1 : 256 * 16);
+    if (vec4) hipLaunchKernelGGL(quantize_kn<true>, dim3(blocks), dim3(256), 0, s, qa);
+    else hipLaunchKernelGGL(quantize_kn<false>, dim3(blocks), dim3(256), 0, s, qa);
+    return check_launch("quantize_kn");
+}
+
+}  // namespace oq
+
+extern "C" {
+
+size_t oq_rtn_workspace_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size, int32_t mse) {
+    if (K <= 0 || N <= 0) return 0;
+    int64_t g;
+    if (oq::resolve_group(strategy, K, group_size, &g) != OQ_OK) return 0;
+    if (strategy == OQ_GROUP && K % g != 0) return 0;
+    size_t need = oq::twopass_ws(K, N, g);
+    if (mse) need += oq::rtn_mse_workspace(K, N, strategy, g);
+    return need + 256;
+}
+
+int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                            int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio,
+                            int32_t mse, void* q_out, float* scale_out, void* zp_out, int32_t layout,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return oq::rtn_impl(W, K, N, ldw, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, mse, q_out,
+                        scale_out, zp_out, layout, workspace, workspace_bytes, stream, true);
+}
+
+int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                           int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio,
+                           int32_t mse, float* scale_out, void* zp_out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    return oq::rtn_impl(W, K, N, ldw, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, mse, nullptr,
+                        scale_out, zp_out, OQ_LAYOUT_KN, workspace, workspace_bytes, stream, false);
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+"""Device-level operators: torch tensors in HBM in, torch tensors in HBM out.
+
+torch is plumbing here (device memory, streams); every computation is a call through the
+C ABI of liboq_hip.so on the current torch stream.  No function in this module has a CPU
+implementation: a missing library or a non-CUDA tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_CONTAINER = {"int4": torch.int8, "uint4": torch.uint8, "int8": torch.int8, "uint8": torch.uint8,
+              "int32": torch.int32, "uint32": torch.uint32}
+BITS = {"int4": 4, "uint4": 4, "int8": 8, "uint8": 8, "int32": 32, "uint32": 32}
+
+
+def container_dtype(qtype: str) -> torch.dtype:
+    return _CONTAINER[qtype]
+
+
+def _ptr(t: torch.Tensor | None) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_device(t: torch.Tensor, name: str, dtype=None) -> None:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f"{name} must be a torch tensor in GPU memory (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor | None:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _row_major(t: torch.Tensor) -> tuple[torch.Tensor, int]:
+    """Return (tensor, leading dimension) for a 2-D tensor whose rows are contiguous."""
+    assert t.dim() == 2
+    if t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t, t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def resolve_group(strategy: str, k: int, group_size) -> int:
+    """Rows per (scale, zp): utils.py:16-22 for groups, K for channel / tensor."""
+    if strategy != "group":
+        return k
+    g = min(group_size, k)
+    return k if g == -1 else g
+
+
+# ----------------------------------------------------------------------------- A1 / Q2
+def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symmetric=False,
+                 reduce_range=False, clip_ratio=1.0, mse=False, layout: str = "kn", emit_q: bool = True,
+                 out=None):
+    """rtn.py:54-109 on the GPU.  ``w`` [K, N] fp32 in HBM.
+
+    Returns (q, scale, zp) -- q [K, N] (layout "kn") or the MatMulNBits blob [N, K/g, g*bits/8]
+    (layout "nbits"); scale/zp 0-d | [N] | [N*K/g, 1].  With ``emit_q=False`` q is None
+    (utils.py:302-348 only).
+    """
+    _require_device(w, "w", torch.float32)
+    if w.dim() != 2:
+        raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
+    w, ldw = _row_major(w)
+    k, n = w.shape
+    lib = L.load()
+    g = resolve_group(strategy, k, group_size if group_size is not None else -1)
+    if strategy == "group":
+        if g <= 0 or (k * n) % g:
+            raise ValueError(f"cannot reshape array of size {k * n} into shape (-1, {g})")
+        count, shape = (k * n) // g, ((k * n) // g, 1)
+    elif strategy == "channel":
+        count, shape = n, (n,)
+    else:
+        count, shape = 1, ()
+    cdt = container_dtype(qtype)
+    dev = w.device
+    if out is not None:
+        q, scale, zp = out
+    else:
+        if not emit_q:
+            q = None
+        elif layout == "kn":
+            q = torch.empty((k, n), dtype=cdt, device=dev)
+        else:
+            q = torch.empty((n, k // g, g * BITS[qtype] // 8), dtype=torch.uint8, device=dev)
+        scale = torch.empty(count, dtype=torch.float32, device=dev)
+        zp = torch.empty(count, dtype=cdt, device=dev)
+    gs = -1 if group_size is None else int(group_size)
+    ws_bytes = lib.oq_rtn_workspace_bytes(k, n, L.STRATEGY_CODE[strategy], gs, int(mse))
+    ws = _workspace(ws_bytes, dev)
+    if emit_q:
+        st = lib.oq_rtn_quantize_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
+                                     int(symmetric), int(reduce_range), float(clip_ratio), int(mse), _ptr(q),
+                                     _ptr(scale), _ptr(zp), L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS,
+                                     _ptr(ws), ws.numel(), _stream())
+    else:
+        st = lib.oq_rtn_qparams_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
+                                    int(symmetric), int(reduce_range), float(clip_ratio), int(mse), _ptr(scale),
+                                    _ptr(zp), _ptr(ws), ws.numel(), _stream())
+    L.check(st)
+    return q, scale.reshape(shape), zp.reshape(shape)
+
+
+# ----------------------------------------------------------------------------- Q1
+def qparams(rmin: torch.Tensor, rmax: torch.Tensor, qtype: str, symmetric: bool, reduce_range: bool):
+    """utils.py:242-299 on device ranges (any shape); returns (scale fp32, zp int32) of that shape."""
+    _require_device(rmin, "rmin", torch.float32)
+    _require_device(rmax, "rmax", torch.float32)
+    a, b = rmin.contiguous().reshape(-1), rmax.contiguous().reshape(-1)
+    scale = torch.empty_like(a)
+    zp = torch.empty(a.numel(), dtype=torch.int32, device=a.device)
+    L.check(L.load().oq_qparams_f32(_ptr(a), _ptr(b), a.numel(), L.QTYPE_CODE[qtype], int(symmetric),
+                                    int(reduce_range), _ptr(scale), _ptr(zp), _stream()))
+    return scale.reshape(rmin.shape), zp.reshape(rmin.shape)
+
+
+# ----------------------------------------------------------------------------- K1 / K2
+def _param_index(mode: str, r: int, c: int, group: int = 1):
+    if mode == "tensor":
+        return 1, 0, 0
+    if mode == "row":
+        return 1, 1, 0
+    if mode == "col":
+        return 1, 0, 1
+    if mode == "group":        # groups of `group` rows on a [K, N] matrix, entry n*(K/g)+kg
+        return group, 1, r // group
+    raise ValueError(mode)
+
+
+def quantize(x: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, qtype: str, symmetric: bool,
+             reduce_range: bool, mode: str = "tensor", group: int = 1) -> torch.Tensor:
+    """utils.py:72-79.  x [R, C] fp32; (scale, zp) indexed per `mode` (see oq_quantize_f32)."""
+    _require_device(x, "x", torch.float32)
+    x2 = x.reshape(1, -1) if x.dim() != 2 else x
+    x2, ldx = _row_major(x2)
+    r, c = x2.shape
+    s = scale.to(torch.float32).contiguous().reshape(-1)
+    z = zp.to(torch.int32).contiguous().reshape(-1)
+    q = torch.empty((r, c), dtype=container_dtype(qtype), device=x.device)
+    rd, rs, cs = _param_index(mode, r, c, group)
+    L.check(L.load().oq_quantize_f32(_ptr(x2), r, c, ldx, _ptr(s), _ptr(z), rd, rs, cs, L.QTYPE_CODE[qtype],
+                                     int(symmetric), int(reduce_range), _ptr(q), _stream()))
+    return q.reshape(x.shape)
+
+
+def dequantize(q: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, qtype: str, mode: str = "tensor",
+               group: int = 1) -> torch.Tensor:
+    """utils.py:102-137 (without the layout shuffles: `mode` addresses the parameters in place)."""
+    _require_device(q, "q", container_dtype(qtype))
+    q2 = q.reshape(1, -1) if q.dim() != 2 else q
+    q2 = q2.contiguous()
+    r, c = q2.shape
+    s = scale.to(torch.float32).contiguous().reshape(-1)
+    z = zp.to(torch.int32).contiguous().reshape(-1)
+    out = torch.empty((r, c), dtype=torch.float32, device=q.device)
+    rd, rs, cs = _param_index(mode, r, c, group)
+    L.check(L.load().oq_dequantize_f32(_ptr(q2), r, c, L.QTYPE_CODE[qtype], _ptr(s), _ptr(z), rd, rs, cs,
+                                       _ptr(out), c, _stream()))
+    return out.reshape(q.shape)
+
+
+def quantize_bias(bias: torch.Tensor, x_scale: float, w_scale: torch.Tensor):
+    """rtn.py:112-138 -> (int32 bias, fp32 bias scale)."""
+    _require_device(bias, "bias", torch.float32)
+    _require_device(w_scale, "weight_scale", torch.float32)
+    b = bias.contiguous()
+    ws = w_scale.contiguous().reshape(-1)
+    q = torch.empty(b.numel(), dtype=torch.int32, device=b.device)
+    bs = torch.empty(b.numel(), dtype=torch.float32, device=b.device)
+    L.check(L.load().oq_quantize_bias_f32(_ptr(b), b.numel(), _ptr(ws), ws.numel(), float(x_scale), _ptr(q),
+                                          _ptr(bs), _stream()))
+    return q, bs
+
+
+# ----------------------------------------------------------------------------- C1 / S1
+def minmax_state(device, dtype=torch.float32) -> torch.Tensor:
+    """Fresh device-resident calibrator state {min, max, seen, -} (see oq_minmax_collect_f32)."""
+    return torch.zeros(4, dtype=dtype, device=device)
+
+
+def minmax_collect(x: torch.Tensor, state: torch.Tensor, momentum: float = 0.0) -> None:
+    """minmax.py:40-64: fold one activation batch into `state`, entirely on the device."""
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("activations must be fp32/fp64 tensors in GPU memory")
+    if state.dtype != x.dtype:
+        raise TypeError("state dtype must match the activation dtype")
+    flat = x.contiguous().reshape(-1)
+    if flat.numel() == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    lib = L.load()
+    ws = _workspace(lib.oq_minmax_workspace_bytes(flat.numel()), x.device)
+    fn = lib.oq_minmax_collect_f32 if x.dtype == torch.float32 else lib.oq_minmax_collect_f64
+    L.check(fn(_ptr(flat), flat.numel(), _ptr(state), float(momentum), _ptr(ws), ws.numel(), _stream()))
+
+
+def absmax(x: torch.Tensor, per_row: bool = False) -> torch.Tensor:
+    """smooth_quant.py:62-74: max |x| per last-axis channel ([..., C] -> [C]); per_row=True gives the
+    per-row absmax of a 2-D matrix (weights [K, N] -> [K])."""
+    _require_device(x, "x", torch.float32)
+    x2 = x.reshape(-1, x.shape[-1])
+    x2, ldx = _row_major(x2)
+    r, c = x2.shape
+    lib = L.load()
+    out = torch.empty(r if per_row else c, dtype=torch.float32, device=x.device)
+    ws = _workspace(lib.oq_absmax_workspace_bytes(r, c, int(per_row)), x.device)
+    L.check(lib.oq_absmax_f32(_ptr(x2), r, c, ldx, int(per_row), _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- N3
+def pack_zero_points_u4(zp: torch.Tensor, n: int, blocks: int) -> torch.Tensor:
+    """_common.py:96-121: [N*blocks] 4-bit zero points -> [N, ceil(blocks/2)] (pad nibble 0x8)."""
+    _require_device(zp, "zp")
+    z = zp.contiguous().reshape(-1).view(torch.uint8)
+    out = torch.empty((n, (blocks + 1) // 2), dtype=torch.uint8, device=zp.device)
+    L.check(L.load().oq_pack_zero_points_u4(_ptr(z), n, blocks, _ptr(out), _stream()))
+    return out
+
+
+def pack_nibbles(values: torch.Tensor) -> torch.Tensor:
+    """_pack.py:8-22: flat 4-bit packing, element 2j in the low nibble."""
+    _require_device(values, "values")
+    v = values.contiguous().reshape(-1).view(torch.uint8)
+    out = torch.empty((v.numel() + 1) // 2, dtype=torch.uint8, device=values.device)
+    L.check(L.load().oq_pack_nibbles(_ptr(v), v.numel(), _ptr(out), _stream()))
+    return out

@@ -1,0 +1,180 @@
+"""GPU parity of the RTN path (A1 and its parts) through the C ABI: bit-exact integers and
+zero points, fp32 scales within 1e-5 relative (in practice bit-equal) -- the tolerance the
+north star states."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oq_oracle as O
+from conftest import load_json, load_npz, synth_weight
+
+pytestmark = pytest.mark.gpu
+
+SCALE_RTOL = 1e-5
+
+
+def sha16(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import torch
+    from onnx_quantize_amd.hip import ops as _ops
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_rtn(ops, w, case, **kw):
+    q, s, z = ops.rtn_quantize(dev(w), case["qtype"], case["strategy"], case["group_size"],
+                               case["symmetric"], case["reduce_range"], case["clip_ratio"],
+                               case.get("mse", False), **kw)
+    return (None if q is None else q.cpu().numpy()), s.cpu().numpy(), z.cpu().numpy()
+
+
+RTN_CASES = load_json("rtn_small.json")
+RTN = load_npz("rtn_small.npz")
+
+
+@pytest.mark.parametrize("case", RTN_CASES, ids=[c["id"] for c in RTN_CASES])
+def test_rtn_small_vs_golden(ops, case):
+    cid = case["id"]
+    q, s, z = run_rtn(ops, RTN[f"{cid}_w"], case)
+    gq, gs, gz = RTN[f"{cid}_q"], RTN[f"{cid}_s"], RTN[f"{cid}_z"]
+    assert q.dtype == gq.dtype and q.shape == gq.shape
+    np.testing.assert_array_equal(q, gq)
+    assert z.dtype == gz.dtype and z.shape == gz.shape
+    np.testing.assert_array_equal(z, gz)
+    assert s.dtype == np.float32 and s.shape == gs.shape
+    np.testing.assert_allclose(s, gs, rtol=SCALE_RTOL, atol=0)
+    assert s.tobytes() == gs.tobytes()       # stronger than required: same bits
+
+
+@pytest.mark.parametrize("case", RTN_CASES[::7], ids=[c["id"] for c in RTN_CASES[::7]])
+def test_rtn_qparams_only(ops, case):
+    cid = case["id"]
+    q, s, z = run_rtn(ops, RTN[f"{cid}_w"], case, emit_q=False)
+    assert q is None
+    assert s.tobytes() == RTN[f"{cid}_s"].tobytes()
+    np.testing.assert_array_equal(z, RTN[f"{cid}_z"])
+
+
+@pytest.mark.parametrize("shape", [(128, 1024), (256, 260), (512, 255), (96, 1), (130, 2052)])
+@pytest.mark.parametrize("g", [16, 32, 64, 128, 2, 48])
+def test_rtn_group_ragged_columns_vs_oracle(ops, shape, g):
+    """Column tails (N % 256, N % 4) and non-contiguous leading dimension."""
+    k, n = shape
+    if k % g:
+        k = (k // g + 1) * g
+    rng = np.random.default_rng(k * 131 + n + g)
+    big = rng.standard_normal((k, n + 12), dtype=np.float32)
+    import torch
+    wd = dev(big)[:, 4:4 + n]                                  # ldw = n + 12, base offset 16 B
+    w = big[:, 4:4 + n]
+    for qtype, sym in (("uint4", False), ("int8", True)):
+        q, s, z = ops.rtn_quantize(wd, qtype, "group", g, sym)
+        eq, es, ez = O.rtn_quantize(w, qtype, "group", g, sym)
+        np.testing.assert_array_equal(q.cpu().numpy(), eq)
+        np.testing.assert_array_equal(z.cpu().numpy(), ez)
+        assert s.cpu().numpy().tobytes() == es.tobytes()
+    wd2 = dev(big)[:, 1:1 + n]                                  # misaligned base -> scalar path
+    q, s, z = ops.rtn_quantize(wd2, "uint4", "group", g, False)
+    eq, es, ez = O.rtn_quantize(big[:, 1:1 + n], "uint4", "group", g, False)
+    np.testing.assert_array_equal(q.cpu().numpy(), eq)
+    assert s.cpu().numpy().tobytes() == es.tobytes()
+    np.testing.assert_array_equal(z.cpu().numpy(), ez)
+
+
+@pytest.mark.parametrize("strategy,g", [("channel", -1), ("tensor", -1), ("group", 512), ("group", 384),
+                                        ("group", -1)])
+def test_rtn_two_pass_vs_oracle(ops, strategy, g):
+    rng = np.random.default_rng(9)
+    w = rng.standard_t(3, size=(1536, 516)).astype(np.float32)
+    for qtype, sym, red in (("int8", False, False), ("uint8", True, False), ("int4", True, True),
+                            ("uint4", False, False)):
+        q, s, z = ops.rtn_quantize(dev(w), qtype, strategy, g, sym, red, 0.95)
+        eq, es, ez = O.rtn_quantize(w, qtype, strategy, g, sym, red, 0.95)
+        np.testing.assert_array_equal(q.cpu().numpy(), eq)
+        np.testing.assert_array_equal(z.cpu().numpy(), ez)
+        assert s.cpu().numpy().tobytes() == np.asarray(es).tobytes()
+        assert s.shape == es.shape and z.shape == ez.shape
+
+
+DIGESTS = load_json("digests.json")
+
+
+def test_config1_plumbing(ops):
+    """BASELINE.json configs[0]: 256x512, QInt8 symmetric per-tensor."""
+    d = DIGESTS["config1"]
+    w = synth_weight(d["kind"], d["seed"], d["k"], d["n"])
+    q, s, z = ops.rtn_quantize(dev(w), d["qtype"], d["strategy"], d["group_size"], d["symmetric"])
+    assert sha16(q.cpu().numpy()) == d["q_sha"]
+    assert s.cpu().numpy().tobytes().hex() == d["scale_hex"] and int(z.cpu()) == d["zp"]
+
+
+@pytest.mark.parametrize("key", ["config2_asym", "config2_sym", "config2_heavy", "config2_zero_groups",
+                                 "channel_4096", "int4_g128_4096"])
+def test_full_size_digests(ops, key):
+    """BASELINE.json configs[1] (4096x11008 uint4 g128) and friends at full size, against digests
+    of what the reference itself produced (tests/golden/make_golden.py::gen_digests)."""
+    d = DIGESTS[key]
+    w = synth_weight(d["kind"], d["seed"], d["k"], d["n"])
+    assert sha16(w) == d["w_sha"]
+    q, s, z = ops.rtn_quantize(dev(w), d["qtype"], d["strategy"], d["group_size"], d["symmetric"])
+    assert sha16(q.cpu().numpy()) == d["q_sha"]
+    assert sha16(s.cpu().numpy()) == d["s_sha"]
+    assert sha16(z.cpu().numpy()) == d["z_sha"]
+
+
+def test_nbits_layout_matches_reference_packing(ops):
+    """OQ_LAYOUT_NBITS == qrules/_common.py:65-123 applied to the [K, N] result."""
+    rng = np.random.default_rng(17)
+    for (k, n, g, qtype) in [(512, 520, 128, "uint4"), (256, 36, 16, "uint4"), (512, 260, 64, "uint8"),
+                             (768, 256, 256, "uint4"), (160, 40, 32, "uint8")]:
+        w = rng.standard_normal((k, n), dtype=np.float32)
+        eq, es, ez = O.rtn_quantize(w, qtype, "group", g)
+        eb, es2, epz = O.matmul_nbits_layout(eq, es, ez, g, O.BITWIDTH[qtype])
+        b, s, z = ops.rtn_quantize(dev(w), qtype, "group", g, layout="nbits")
+        np.testing.assert_array_equal(b.cpu().numpy(), eb)
+        assert s.cpu().numpy().reshape(n, k // g).tobytes() == es2.tobytes()
+        if qtype == "uint4" and k // g > 1:
+            pz = ops.pack_zero_points_u4(z, n, k // g)
+            np.testing.assert_array_equal(pz.cpu().numpy(), epz)
+
+
+def test_roundtrip_property_full_size(ops):
+    """Size-independent property at BASELINE size: |dequant(q) - w| <= scale/2 (+1 ulp slack)
+    wherever the value was not clipped, and every group hits both ends of the integer range."""
+    import torch
+    k, n, g = 4096, 11008, 128
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    w = torch.randn((k, n), generator=gen, device="cuda", dtype=torch.float32)
+    q, s, z = ops.rtn_quantize(w, "uint4", "group", g)
+    dq = ops.dequantize(q, s, z, "uint4", mode="group", group=g)
+    s_full = s.reshape(n, k // g).t().repeat_interleave(g, dim=0)      # [K, N]
+    err = (dq - w).abs()
+    assert bool((err <= s_full * 0.5000001 + 1e-7).all())
+    qg = q.t().reshape(n, k // g, g)
+    assert int(qg.amin(dim=2).max()) == 0 and int(qg.amax(dim=2).min()) == 15
+    # idempotence: quantizing the dequantized weights reproduces the integers
+    q2, _, _ = ops.rtn_quantize(dq, "uint4", "group", g)
+    mism = int((q2 != q).sum())
+    assert mism <= k * n // 1000          # ties at .5 may move by one after a round trip
+
+
+def test_errors_are_loud(ops):
+    import torch
+    from onnx_quantize_amd.hip import OqHipError
+    w = torch.zeros((64, 64), device="cuda")
+    with pytest.raises(TypeError):
+        ops.rtn_quantize(w.cpu(), "int8", "tensor")
+    with pytest.raises(OqHipError, match="clip_ratio must be in"):
+        ops.rtn_quantize(w, "int8", "tensor", clip_ratio=1.5)
+    with pytest.raises(ValueError, match="cannot reshape"):
+        ops.rtn_quantize(torch.zeros((10, 3), device="cuda"), "int8", "group", 4)
