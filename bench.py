@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Headline benchmark: group-128 uint4 RTN quantization of a 4096x11008 fp32 weight on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path (reference rtn.py:54-109, `_rtn_quantize`) over one
+4096x11008 matrix already resident in HBM: one launch of the fused HIP kernel through the C ABI
+(oq_rtn_quantize_f32).  Inputs rotate over `--rotate` distinct HBM buffers (default 4 x 180 MB,
+more than the 256 MiB Infinity Cache) so every step streams from HBM, not from cache.
+
+N > 1 is weak scaling: every rank quantizes its own matrices (independent MatMul weights shard with
+no data-path collective); `value` = params of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline      algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak
+  cpu_baseline  the NumPy oracle (oracle/oq_oracle.py) timed on the host, rank 0 at N=1 only
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_DIM, N_DIM, GROUP = 4096, 11008, 128
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(layout: str) -> int:
+    """read W once + packed int4 + fp32 scales + 1-byte zero points = 4.539 B/param."""
+    params = K_DIM * N_DIM
+    groups = params // GROUP
+    return params * 4 + params // 2 + groups * 4 + groups
+
+
+def moved_bytes(layout: str) -> int:
+    params = K_DIM * N_DIM
+    groups = params // GROUP
+    return params * 4 + (params if layout == "kn" else params // 2) + groups * 5
+
+
+def sha16(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def cpu_baseline(w: np.ndarray, budget_s: float = 20.0) -> dict:
+    """Time the oracle (checker, never the product) on the host cores: kind = "port"."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oq_oracle as O
+    t_best, runs = float("inf"), 0
+    t_start = time.perf_counter()
+    while runs < 5 and (runs < 2 or time.perf_counter() - t_start < budget_s):
+        t0 = time.perf_counter()
+        q, s, z = O.rtn_quantize(w, "uint4", "group", GROUP)
+        t_best = min(t_best, time.perf_counter() - t0)
+        runs += 1
+    return {
+        "value": round(K_DIM * N_DIM / t_best / 1e6, 2), "unit": "M-param/s", "cores": 1,
+        "kind": "port",
+        "sample": f"full workload (one 4096x11008 matrix), best of {runs} runs, {t_best:.3f} s each; "
+                  f"NumPy {np.__version__} elementwise path is single-threaded; host has {os.cpu_count()} CPUs",
+        "seconds": round(t_best, 4),
+        "digest_ok": None,
+    }, (q, s, z)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rotate", type=int, default=4, help="distinct input/output buffer sets cycled through")
+    ap.add_argument("--layout", choices=["kn", "nbits"], default="kn",
+                    help="kn: [K,N] one value per byte (what _rtn_quantize returns); "
+                         "nbits: MatMulNBits blob [N,K/g,g/2] (what the emitted graph holds for this config)")
+    ap.add_argument("--symmetric", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from onnx_quantize_amd.hip import _lib as L
+    lib = L.load()
+
+    # ---- synthetic input: the BASELINE.json config-2 matrix (seed = rank so ranks hold different weights;
+    # rank 0 is the KAT2 matrix whose reference digests are committed in tests/golden/digests.json)
+    w_host = np.random.default_rng(rank).standard_normal((K_DIM, N_DIM), dtype=np.float32)
+    w_src = torch.from_numpy(w_host).to(dev)
+    ws = [w_src] + [w_src.clone() for _ in range(max(1, args.rotate) - 1)]
+    groups = K_DIM * N_DIM // GROUP
+    q_elems = K_DIM * N_DIM if args.layout == "kn" else K_DIM * N_DIM // 2
+    outs = [(torch.empty(q_elems, dtype=torch.uint8, device=dev),
+             torch.empty(groups, dtype=torch.float32, device=dev),
+             torch.empty(groups, dtype=torch.uint8, device=dev)) for _ in ws]
+    ws_bytes = lib.oq_rtn_workspace_bytes(K_DIM, N_DIM, L.OQ_GROUP, GROUP, 0)
+    wsbuf = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    layout = L.OQ_LAYOUT_KN if args.layout == "kn" else L.OQ_LAYOUT_NBITS
+    sym = int(args.symmetric)
+
+    calls = []
+    for w, (q, s, z) in zip(ws, outs):
+        calls.append((C.c_void_p(w.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(s.data_ptr()),
+                      C.c_void_p(z.data_ptr())))
+    wsp, wsn = C.c_void_p(wsbuf.data_ptr()), wsbuf.numel()
+    fn = lib.oq_rtn_quantize_f32
+
+    def step(i: int) -> None:
+        wp, qp, sp, zp = calls[i % len(calls)]
+        if args.qparams_only:
+            st = lib.oq_rtn_qparams_f32(wp, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, sp, zp,
+                                        wsp, wsn, stream)
+        else:
+            st = fn(wp, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, qp, sp, zp, layout,
+                    wsp, wsn, stream)
+        if st != 0:
+            L.check(st)
+
+    def fence() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    fence()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream: device time of the K launches
+
+    t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, dev_ms = float(t[0]), float(t[1])
+
+    # ---- verify rank 0's last outputs against the reference digests (asymmetric / symmetric KAT2)
+    verified = None
+    if rank == 0:
+        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+            d = json.load(f)["config2_sym" if args.symmetric else "config2_asym"]
+        q, s, z = outs[(args.steps - 1) % len(outs)] if args.steps else outs[0]
+        ok = sha16(s.cpu().numpy()) == d["s_sha"] and sha16(z.cpu().numpy()) == d["z_sha"]
+        if args.qparams_only:
+            pass
+        elif args.layout == "kn":
+            ok = ok and sha16(q.cpu().numpy()) == d["q_sha"]
+        else:   # unpack the blob back to [K, N] and compare with the same digest
+            b = q.cpu().numpy().reshape(N_DIM, K_DIM // GROUP, GROUP // 2)
+            full = np.empty((N_DIM, K_DIM // GROUP, GROUP), np.uint8)
+            full[..., 0::2] = b & 0x0F
+            full[..., 1::2] = b >> 4
+            ok = ok and sha16(np.ascontiguousarray(full.reshape(N_DIM, K_DIM).T)) == d["q_sha"]
+        verified = bool(ok)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    params_total = K_DIM * N_DIM * args.steps * world
+    ms_per_step = wall * 1e3 / max(args.steps, 1)
+    launch_us = dev_ms * 1e3 / max(args.steps, 1)
+    alg = algorithmic_bytes(args.layout)
+    achieved = alg / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "rtn_pmc_traffic.json")
+    if os.path.exists(pmc):
+        with open(pmc) as f:
+            traffic = json.load(f).get(args.layout)
+
+    result = {
+        "metric": "M-params quantized/sec, group-128 uint4 RTN on 4096x11008 fp32",
+        "value": round(params_total / wall / 1e6, 1),
+        "unit": "M-param/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"rtn_quint4_g128_{'sym' if args.symmetric else 'asym'}_4096x11008_f32",
+                   "out_layout": args.layout, "rotating_buffers": len(ws), "matrices_per_step_per_gpu": 1},
+        "verified_vs_reference_digest": verified,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "kernel": "oq::rtn_group_fused<16,true,true>", "launch_us": round(launch_us, 2),
+                     "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        base, (cq, cs, cz) = cpu_baseline(w_host)
+        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+            d = json.load(f)["config2_asym"]
+        base["digest_ok"] = bool(sha16(cq) == d["q_sha"] and sha16(cs) == d["s_sha"])
+        result["cpu_baseline"] = base
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,48 @@ __device__ __forceinline__ int32_t quantize_one(float x, float scale, int32_t zp
     return min(max(r, qmin), qmax);
 }
 
+// ---- K1 fast path ---------------------------------------------------------------------------
+// The IEEE divide of utils.py:73 costs ~11 VALU instructions per element, which makes the fused
+// kernel VALU-bound instead of HBM-bound.  Per column we therefore keep rinv = fl(1/s) and compute
+// t = fl(x * rinv), k = rint(t).  |t - fl(x/s)| <= |x/s| * (2^-23 + 2^-24) (two correctly rounded
+// operations vs one), so whenever t is farther than `thr` = 0.5 - B*2^-21 from a half-integer
+// (B >= max |x/s| of the column's group) no tie can separate rint(t) from rint(fl(x/s)) and k is
+// exactly the reference's integer.  The rare elements inside that band (and any NaN/inf) are redone
+// with the true division, so the result is bit-identical by construction, not by tolerance.
+struct ColQ {
+    float scale;
+    float rinv;  // fl(1 / scale)
+    float zpb;   // float(zp + bias), bias maps signed ranges onto 0..255 / 0..15 for v_cvt_pk_u8_f32
+    float thr;   // <= 0 forces the exact path
+    int32_t zp;
+};
+
+__device__ __forceinline__ ColQ make_colq(const QParam& p, float raw_min, float raw_max, int32_t bias) {
+    ColQ c;
+    c.scale = p.scale;
+    c.zp = p.zp;
+    c.rinv = 1.0f / p.scale;
+    c.zpb = static_cast<float>(p.zp + bias);
+    const float bound = fmaxf(fabsf(raw_min), fabsf(raw_max)) * c.rinv * 1.0001f;
+    float thr = 0.5f - bound * 4.76837158203125e-07f /* 2^-21 */ - 1e-30f;
+    if (!(p.scale < 1e30f) || !(bound < 4194304.0f /* 2^22: k + zp must stay exact in fp32 */)) thr = -1.0f;
+    c.thr = thr;
+    return c;
+}
+
+// Returns the clamped, biased level as an exact small float; sets `unsafe` when the fast product
+// could not be proven equal to the reference (caller redoes the row with quantize_exact_biased).
+__device__ __forceinline__ float quantize_fast_biased(float x, const ColQ& c, float lo_b, float hi_b, bool& unsafe) {
+    const float t = x * c.rinv;
+    const float k = rintf(t);
+    unsafe = unsafe || !(fabsf(t - k) < c.thr);
+    return __builtin_amdgcn_fmed3f(k + c.zpb, lo_b, hi_b);
+}
+
+__device__ __forceinline__ float quantize_exact_biased(float x, const ColQ& c, int32_t qmin, int32_t qmax, int32_t bias) {
+    return static_cast<float>(quantize_one(x, c.scale, c.zp, qmin, qmax) + bias);
+}
+
 // K2 utils.py:130-132: (f32(q) - f32(zp)) * scale, two roundings.
 __device__ __forceinline__ float dequantize_one(int32_t q, float scale, int32_t zp) {
     return (static_cast<float>(q) - static_cast<float>(zp)) * scale;

@@ -5,6 +5,9 @@
 // registers.  Nothing is reshaped into a GEMM and no transposed copy (utils.py:24) is ever made.
 #include "oq_common.hpp"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace oq {
 
 struct RtnArgs {
@@ -15,12 +18,18 @@ struct RtnArgs {
     uint8_t* q;       // may be null (qparams only)
     float* scale;
     uint8_t* zp;
+    float* scale_t;   // optional staging [kgroups, N] (coalesced); transposed to `scale` by transpose_qparams
+    uint8_t* zp_t;
     QGrid grid;
     int32_t layout;
     int32_t wpg;      // waves per group
     int32_t gpb;      // groups per block
     uint32_t ncol_tiles, nrow_tiles;
+    int32_t order;    // 0: K-direction fastest + XCD strips, 1: column tiles fastest (row-sequential DRAM stream)
+    int32_t nt;       // non-temporal loads of W
 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kColsPerWave = 256;  // 64 lanes x 4 columns: 1 KiB of one fp32 row per wave-instruction
 constexpr int kMaxWaves = 8;
@@ -51,7 +60,7 @@ __device__ __forceinline__ void store_words(uint8_t* dst, const uint32_t (&w)[NW
 // Fused one-pass kernel.  One block = GPB groups (stacked along K) x 256 columns; one group =
 // WPG waves x RPW rows.  Registers per lane: RPW x 4 fp32 of W.
 // ---------------------------------------------------------------------------------------------
-template <int RPW, bool VEC4, bool EMIT_Q>
+template <int RPW, bool VEC4, bool EMIT_Q, bool NT = false>
 __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArgs a) {
     __shared__ float4 s_mn[kMaxWaves][kWave];
     __shared__ float4 s_mx[kMaxWaves][kWave];
@@ -62,9 +71,15 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     const int gib = wave / a.wpg;   // group inside the block
 
     const uint32_t nblk = a.ncol_tiles * a.nrow_tiles;
-    const uint32_t id = xcd_remap(blockIdx.x, nblk);
-    const uint32_t col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
-    const uint32_t row_tile = id - col_tile * a.nrow_tiles;
+    uint32_t col_tile, row_tile;
+    if (a.order == 0) {
+        const uint32_t id = xcd_remap(blockIdx.x, nblk);
+        col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
+        row_tile = id - col_tile * a.nrow_tiles;
+    } else {
+        row_tile = blockIdx.x / a.ncol_tiles;  // column tiles fastest: co-resident blocks stream whole rows
+        col_tile = blockIdx.x - row_tile * a.ncol_tiles;
+    }
 
     const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + gib;
     const bool group_ok = kg < a.kgroups;
@@ -75,27 +90,38 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
 #pragma unroll
     for (int i = 0; i < 4; ++i) col_ok[i] = slot_col<VEC4>(tile_col0, lane, i) < a.N;
 
+    // Loads are unconditional: lanes past the right edge and waves past the last group read a clamped
+    // (valid, duplicate) address instead of being predicated off.  A predicated load makes hipcc wrap every
+    // load in its own exec branch with a vmcnt(0) behind it (cdna_hip_programming.md section 5, trap (c)),
+    // which serialises the 16 row loads of a wave.  Only the stores are masked.
     float v[RPW][4];
-    if (group_ok) {
+    {
+        const int64_t lrow0 = group_ok ? row0 : static_cast<int64_t>(wig) * RPW;
         if constexpr (VEC4) {
-            const float* p = a.W + row0 * a.ldw + tile_col0 + lane * 4;
+            int64_t lcol = tile_col0 + lane * 4;
+            lcol = lcol < a.N ? lcol : a.N - 4;
+            const float* p = a.W + lrow0 * a.ldw + lcol;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                float4 t = col_ok[0] ? *reinterpret_cast<const float4*>(p + r * a.ldw) : make_float4(0, 0, 0, 0);
+                float4 t;
+                if constexpr (NT) {
+                    const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + r * a.ldw));
+                    t = make_float4(u[0], u[1], u[2], u[3]);
+                } else {
+                    t = *reinterpret_cast<const float4*>(p + r * a.ldw);
+                }
                 v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
             }
         } else {
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    v[r][i] = col_ok[i] ? a.W[(row0 + r) * a.ldw + slot_col<false>(tile_col0, lane, i)] : 0.0f;
+                for (int i = 0; i < 4; ++i) {
+                    int64_t c = slot_col<false>(tile_col0, lane, i);
+                    c = c < a.N ? c : a.N - 1;
+                    v[r][i] = a.W[(lrow0 + r) * a.ldw + c];
+                }
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[r][i] = 0.0f;
     }
 
     // R1 (utils.py:60-61): lane-local column min / max over this wave's rows.
@@ -127,34 +153,67 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     if (!group_ok) return;
 
     // Q1 in registers (every wave of the group derives the same parameters).
-    QParam qp[4];
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    // bias: signed levels are produced as 0..255 (0..15 for packed nibbles) and flipped back with one XOR per word
+    const int32_t bias = qmin < 0 ? ((a.layout == OQ_LAYOUT_NBITS && a.grid.bits == 4) ? 8 : 128) : 0;
+    ColQ cq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qp[i] = qparam_from_minmax(mn[i], mx[i], a.grid);
+    for (int i = 0; i < 4; ++i) {
+        const QParam p = qparam_from_minmax(mn[i], mx[i], a.grid);
+        cq[i] = make_colq(p, mn[i], mx[i], bias);
+    }
 
-    if (wig == 0) {  // rtn.py:98-109 result layout: row n*(K/g)+kg of the [N*K/g, 1] arrays
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (col_ok[i]) {
-                const int64_t o = slot_col<VEC4>(tile_col0, lane, i) * a.kgroups + kg;
-                a.scale[o] = qp[i].scale;
-                a.zp[o] = static_cast<uint8_t>(qp[i].zp);
+    if (wig == 0) {
+        if (VEC4 && a.scale_t != nullptr) {
+            // staged [kg, n]: 16 B + 4 B per lane, fully coalesced (the n-major scatter of 4-byte pieces at a
+            // 128-byte stride costs ~7 us on this matrix: partial-line writes)
+            if (col_ok[0]) {
+                const int64_t o = kg * a.N + tile_col0 + lane * 4;
+                *reinterpret_cast<float4*>(a.scale_t + o) = make_float4(cq[0].scale, cq[1].scale, cq[2].scale, cq[3].scale);
+                *reinterpret_cast<uint32_t*>(a.zp_t + o) = (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 8) |
+                                                           ((static_cast<uint32_t>(cq[2].zp) & 0xffu) << 16) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 24);
             }
+        } else {  // rtn.py:98-109 result layout: row n*(K/g)+kg of the [N*K/g, 1] arrays
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (col_ok[i]) {
+                    const int64_t o = slot_col<VEC4>(tile_col0, lane, i) * a.kgroups + kg;
+                    a.scale[o] = cq[i].scale;
+                    a.zp[o] = static_cast<uint8_t>(cq[i].zp);
+                }
+        }
     }
     if constexpr (!EMIT_Q) return;
 
-    // K1 from registers.
-    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    // K1 from registers: v[r][i] <- clamped, biased level (an exact small float).
+    const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float f[4];
+        bool unsafe = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(v[r][i], cq[i], lo_b, hi_b, unsafe);
+        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {  // wave-uniform, rare: redo this row with the IEEE divide
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(v[r][i], cq[i], qmin, qmax, bias);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[r][i] = f[i];
+    }
+
     if (a.layout == OQ_LAYOUT_KN) {
+        const uint32_t flip = bias ? 0x80808080u : 0u;
         if constexpr (VEC4) {
             if (col_ok[0]) {
                 uint8_t* o = a.q + row0 * a.N + tile_col0 + lane * 4;
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        w |= (static_cast<uint32_t>(quantize_one(v[r][i], qp[i].scale, qp[i].zp, qmin, qmax)) & 0xffu) << (8 * i);
-                    *reinterpret_cast<uint32_t*>(o + r * a.N) = w;
+                    uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][0], 0, 0);
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][1], 1, w);
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][2], 2, w);
+                    w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][3], 3, w);
+                    if constexpr (NT) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
+                    else *reinterpret_cast<uint32_t*>(o + r * a.N) = w ^ flip;
                 }
             }
         } else {
@@ -164,7 +223,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                 for (int i = 0; i < 4; ++i)
                     if (col_ok[i])
                         a.q[(row0 + r) * a.N + slot_col<false>(tile_col0, lane, i)] =
-                            static_cast<uint8_t>(quantize_one(v[r][i], qp[i].scale, qp[i].zp, qmin, qmax));
+                            static_cast<uint8_t>((__builtin_amdgcn_cvt_pk_u8_f32(v[r][i], 0, 0) ^ flip) & 0xffu);
         }
     } else {
         // MatMulNBits blob (qrules/_common.py:72-87): for out-channel n, k-group kg: g*bits/8 bytes,
@@ -177,33 +236,256 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
             uint8_t* o = a.q + (col * a.kgroups + kg) * blob;
             if (a.grid.bits == 4) {
                 if constexpr (RPW >= 8) {
+                    const uint32_t flip = bias ? 0x88888888u : 0u;
                     uint32_t words[RPW / 8];
 #pragma unroll
                     for (int wd = 0; wd < RPW / 8; ++wd) {
-                        uint32_t acc = 0;
+                        uint32_t ev = 0, od = 0;  // bytes of the even-k / odd-k levels
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            acc |= (static_cast<uint32_t>(quantize_one(v[wd * 8 + j][i], qp[i].scale, qp[i].zp, qmin, qmax)) & 0xfu) << (4 * j);
-                        words[wd] = acc;
+                        for (int j = 0; j < 4; ++j) {
+                            ev = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 8 + 2 * j][i], j, ev);
+                            od = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 8 + 2 * j + 1][i], j, od);
+                        }
+                        words[wd] = (ev | (od << 4)) ^ flip;
                     }
                     store_words<RPW / 8>(o + wig * (RPW / 2), words);
                 }
             } else {
                 if constexpr (RPW >= 4) {
+                    const uint32_t flip = bias ? 0x80808080u : 0u;
                     uint32_t words[RPW / 4];
 #pragma unroll
                     for (int wd = 0; wd < RPW / 4; ++wd) {
                         uint32_t acc = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            acc |= (static_cast<uint32_t>(quantize_one(v[wd * 4 + j][i], qp[i].scale, qp[i].zp, qmin, qmax)) & 0xffu) << (8 * j);
-                        words[wd] = acc;
+                        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 4 + j][i], j, acc);
+                        words[wd] = acc ^ flip;
                     }
                     store_words<RPW / 4>(o + wig * RPW, words);
                 }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant of the fused kernel (the one the headline benchmark runs).
+//
+// The plain fused kernel runs load -> reduce -> quantize -> store as separate phases of a short-lived
+// block, so HBM idles while the VALU works and vice versa (measured: 53 us where a pure tile read
+// takes 30 us).  Here a block is persistent over a run of consecutive units (a unit = 128 rows x 256
+// columns, K direction fastest) and the register tile is recycled row by row: as soon as row r of the
+// current unit has been quantized and stored, the same registers receive row r of the NEXT unit, so
+// loads stay in flight during all of the VALU / store work.  Consecutive k-groups of a column strip
+// are handled by one block, so the 4-byte scale writes of a 128-byte line meet in one L2.
+// Requires RPW == 16, 16-byte aligned rows (VEC4) and g | 128 or g == 128.
+// ---------------------------------------------------------------------------------------------
+template <bool EMIT_Q, int LAYOUT, int BITS, bool NT>
+__global__ __launch_bounds__(kMaxWaves* kWave, 4) void rtn_group_stream(const RtnArgs a, const uint32_t nunits) {
+    constexpr int RPW = 16;
+    __shared__ float4 s_mn[2][kMaxWaves][kWave];
+    __shared__ float4 s_mx[2][kMaxWaves][kWave];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wig = wave % a.wpg;
+    const int gib = wave / a.wpg;
+
+    const uint32_t u_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * nunits / gridDim.x);
+    const uint32_t u_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * nunits / gridDim.x);
+    if (u_begin >= u_end) return;
+
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    const int32_t bias = qmin < 0 ? ((LAYOUT == OQ_LAYOUT_NBITS && BITS == 4) ? 8 : 128) : 0;
+    const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+
+    // unit -> first row of this wave, first column of this lane, validity
+    auto locate = [&](uint32_t u, int64_t& kg, int64_t& row0, int64_t& col0, bool& ok) {
+        const uint32_t col_tile = u / a.nrow_tiles;
+        const uint32_t row_tile = u - col_tile * a.nrow_tiles;
+        kg = static_cast<int64_t>(row_tile) * a.gpb + gib;
+        row0 = kg * a.g + static_cast<int64_t>(wig) * RPW;
+        col0 = static_cast<int64_t>(col_tile) * kColsPerWave + lane * 4;
+        ok = (kg < a.kgroups) && (col0 < a.N);
+    };
+    // Loads are never predicated (see rtn_group_fused): out-of-range lanes / waves read a clamped address.
+    auto load_base = [&](int64_t kg, int64_t row0, int64_t col0) -> const float* {
+        const int64_t lrow0 = kg < a.kgroups ? row0 : static_cast<int64_t>(wig) * RPW;
+        const int64_t lcol = col0 < a.N ? col0 : a.N - 4;
+        return a.W + lrow0 * a.ldw + lcol;
+    };
+    auto load_row = [&](const float* p) -> float4 {
+        if constexpr (NT) {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+            return make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+            return *reinterpret_cast<const float4*>(p);
+        }
+    };
+
+    float4 v[RPW];
+    int64_t kg, row0, col0;
+    bool ok;
+    locate(u_begin, kg, row0, col0, ok);
+    {
+        const float* p = load_base(kg, row0, col0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) v[r] = load_row(p + r * a.ldw);
+    }
+
+    // One unit; RELOAD (compile-time) refills the register tile from unit u+1 while unit u is quantized.
+    auto unit_body = [&](const uint32_t u, auto reload_tag) {
+        constexpr bool RELOAD = decltype(reload_tag)::value;
+        const int buf = (u - u_begin) & 1;
+        // R1: lane-local column min / max of this wave's 16 rows (first use of v: waits for the loads)
+        float4 mn = v[0], mx = v[0];
+#pragma unroll
+        for (int r = 1; r < RPW; ++r) {
+            mn.x = fminf(mn.x, v[r].x); mn.y = fminf(mn.y, v[r].y); mn.z = fminf(mn.z, v[r].z); mn.w = fminf(mn.w, v[r].w);
+            mx.x = fmaxf(mx.x, v[r].x); mx.y = fmaxf(mx.y, v[r].y); mx.z = fmaxf(mx.z, v[r].z); mx.w = fmaxf(mx.w, v[r].w);
+        }
+        if (a.wpg > 1) {
+            s_mn[buf][wave][lane] = mn;
+            s_mx[buf][wave][lane] = mx;
+            __syncthreads();
+            const int w0 = gib * a.wpg;
+            for (int w = 0; w < a.wpg; ++w) {
+                const float4 tn = s_mn[buf][w0 + w][lane], tx = s_mx[buf][w0 + w][lane];
+                mn.x = fminf(mn.x, tn.x); mn.y = fminf(mn.y, tn.y); mn.z = fminf(mn.z, tn.z); mn.w = fminf(mn.w, tn.w);
+                mx.x = fmaxf(mx.x, tx.x); mx.y = fmaxf(mx.y, tx.y); mx.z = fmaxf(mx.z, tx.z); mx.w = fmaxf(mx.w, tx.w);
+            }
+        }
+        // Q1
+        ColQ cq[4];
+        {
+            const float mns[4] = {mn.x, mn.y, mn.z, mn.w}, mxs[4] = {mx.x, mx.y, mx.z, mx.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cq[i] = make_colq(qparam_from_minmax(mns[i], mxs[i], a.grid), mns[i], mxs[i], bias);
+        }
+        if (ok && wig == 0) {
+            if (a.scale_t != nullptr) {
+                const int64_t o = kg * a.N + col0;
+                *reinterpret_cast<float4*>(a.scale_t + o) = make_float4(cq[0].scale, cq[1].scale, cq[2].scale, cq[3].scale);
+                *reinterpret_cast<uint32_t*>(a.zp_t + o) = (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 8) |
+                                                           ((static_cast<uint32_t>(cq[2].zp) & 0xffu) << 16) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 24);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t o = (col0 + i) * a.kgroups + kg;
+                    a.scale[o] = cq[i].scale;
+                    a.zp[o] = static_cast<uint8_t>(cq[i].zp);
+                }
+            }
+        }
+
+        // where the next unit's rows go
+        const bool have_next = RELOAD;
+        int64_t nkg = kg, nrow0 = row0, ncol0 = col0;
+        bool nok = false;
+        if (have_next) locate(u + 1, nkg, nrow0, ncol0, nok);
+        const float* np = load_base(nkg, nrow0, ncol0);
+
+        if constexpr (!EMIT_Q) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);
+        } else if constexpr (LAYOUT == OQ_LAYOUT_KN) {
+            const uint32_t flip = bias ? 0x80808080u : 0u;
+            uint8_t* o = a.q + row0 * a.N + col0;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float xs[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+                float f[4];
+                bool unsafe = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(xs[i], cq[i], lo_b, hi_b, unsafe);
+                if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(xs[i], cq[i], qmin, qmax, bias);
+                }
+                uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
+                if (ok) {
+                    if constexpr (NT) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
+                    else *reinterpret_cast<uint32_t*>(o + r * a.N) = w ^ flip;
+                }
+                if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);   // recycle the registers
+            }
+        } else {
+            // MatMulNBits blob (qrules/_common.py:72-87): levels replace the weights in place (exact small
+            // floats); once the rows of one 32-bit word are complete (8 rows of nibbles / 4 rows of bytes) they
+            // are packed and the registers are refilled from the next unit.
+            const int64_t blob = a.g * BITS / 8;
+            uint32_t words[BITS == 4 ? 2 : 4][4];  // [word][column]
+            auto levels_row = [&](int r) {
+                const float xs[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+                float f[4];
+                bool unsafe = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(xs[i], cq[i], lo_b, hi_b, unsafe);
+                if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(xs[i], cq[i], qmin, qmax, bias);
+                }
+                v[r] = make_float4(f[0], f[1], f[2], f[3]);
+            };
+            auto comp = [](const float4& t, int i) { return i == 0 ? t.x : (i == 1 ? t.y : (i == 2 ? t.z : t.w)); };
+            if constexpr (BITS == 4) {
+                const uint32_t flip = bias ? 0x88888888u : 0u;
+#pragma unroll
+                for (int wd = 0; wd < 2; ++wd) {
+#pragma unroll
+                    for (int r = wd * 8; r < wd * 8 + 8; ++r) levels_row(r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t ev = 0, od = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ev = __builtin_amdgcn_cvt_pk_u8_f32(comp(v[wd * 8 + 2 * j], i), j, ev);
+                            od = __builtin_amdgcn_cvt_pk_u8_f32(comp(v[wd * 8 + 2 * j + 1], i), j, od);
+                        }
+                        words[wd][i] = (ev | (od << 4)) ^ flip;
+                    }
+#pragma unroll
+                    for (int r = wd * 8; r < wd * 8 + 8; ++r) if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint8_t* o = a.q + ((col0 + i) * a.kgroups + kg) * blob + wig * 8;
+                        *reinterpret_cast<uint2*>(o) = make_uint2(words[0][i], words[1][i]);
+                    }
+                }
+            } else {
+                const uint32_t flip = bias ? 0x80808080u : 0u;
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) {
+#pragma unroll
+                    for (int r = wd * 4; r < wd * 4 + 4; ++r) levels_row(r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t acc = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(comp(v[wd * 4 + j], i), j, acc);
+                        words[wd][i] = acc ^ flip;
+                    }
+#pragma unroll
+                    for (int r = wd * 4; r < wd * 4 + 4; ++r) if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        uint8_t* o = a.q + ((col0 + i) * a.kgroups + kg) * blob + wig * 16;
+                        *reinterpret_cast<uint4*>(o) = make_uint4(words[0][i], words[1][i], words[2][i], words[3][i]);
+                    }
+                }
+            }
+        }
+        kg = nkg; row0 = nrow0; col0 = ncol0; ok = nok;
+    };
+    for (uint32_t u = u_begin; u + 1 < u_end; ++u) unit_body(u, std::true_type{});
+    unit_body(u_end - 1, std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,6 +680,32 @@ __global__ __launch_bounds__(256) void rtn_flat_groups(const float* W, int64_t K
     }
 }
 
+// [kgroups, N] staging -> the reference's n-major [N*K/g] arrays (entry n*kgroups + kg), 32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, const uint8_t* zp_t, int64_t kgroups, int64_t N,
+                                                         float* scale, uint8_t* zp) {
+    __shared__ float ts[32][33];
+    __shared__ uint8_t tz[32][36];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int64_t n0 = static_cast<int64_t>(blockIdx.x) * 32, k0 = static_cast<int64_t>(blockIdx.y) * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int64_t kg = k0 + ty + j, n = n0 + tx;
+        if (kg < kgroups && n < N) {
+            ts[ty + j][tx] = scale_t[kg * N + n];
+            tz[ty + j][tx] = zp_t[kg * N + n];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+        const int64_t n = n0 + ty + j, kg = k0 + tx;
+        if (kg < kgroups && n < N) {
+            scale[n * kgroups + kg] = ts[tx][ty + j];
+            zp[n * kgroups + kg] = tz[tx][ty + j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ dispatch
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -425,9 +733,17 @@ static void launch_fused(int rpw, const RtnArgs& a, dim3 grid, dim3 block, hipSt
         case 2: hipLaunchKernelGGL((rtn_group_fused<2, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
         case 4: hipLaunchKernelGGL((rtn_group_fused<4, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL((rtn_group_fused<8, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
-        case 16: hipLaunchKernelGGL((rtn_group_fused<16, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
+        case 16:
+            if (a.nt) hipLaunchKernelGGL((rtn_group_fused<16, VEC4, EMIT_Q, true>), grid, block, 0, s, a);
+            else hipLaunchKernelGGL((rtn_group_fused<16, VEC4, EMIT_Q, false>), grid, block, 0, s, a);
+            break;
         default: hipLaunchKernelGGL((rtn_group_fused<32, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
     }
+}
+
+static size_t stage_ws(int64_t K, int64_t N, int64_t g) {  // [kgroups, N] fp32 scales + bytes, 256-byte aligned halves
+    const int64_t kgroups = K / g;
+    return static_cast<size_t>((kgroups * N * 4 + 255) / 256 * 256 + (kgroups * N + 255) / 256 * 256);
 }
 
 static size_t twopass_ws(int64_t K, int64_t N, int64_t g) {
@@ -517,12 +833,54 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         RtnArgs a;
         a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
         a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
+        a.scale_t = nullptr; a.zp_t = nullptr;
+        static const int env_stage = getenv("OQ_RTN_STAGE") ? atoi(getenv("OQ_RTN_STAGE")) : 1;
+        const bool staged = env_stage && vec4 && kgroups > 1 && workspace != nullptr && workspace_bytes >= stage_ws(K, N, g) &&
+                            (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
+        if (staged) {
+            a.scale_t = static_cast<float*>(workspace);
+            a.zp_t = static_cast<uint8_t*>(workspace) + (kgroups * N * 4 + 255) / 256 * 256;
+        }
         a.wpg = wpg;
         a.gpb = kMaxWaves / wpg > 0 ? kMaxWaves / wpg : 1;
         if (a.gpb > kgroups) a.gpb = static_cast<int32_t>(kgroups);
         a.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));
         a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, a.gpb));
+        static const int env_order = getenv("OQ_RTN_ORDER") ? atoi(getenv("OQ_RTN_ORDER")) : 1;
+        static const int env_nt = getenv("OQ_RTN_NT") ? atoi(getenv("OQ_RTN_NT")) : 1;
+        a.order = env_order;
+        a.nt = env_nt;
         const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        static const int env_stream = getenv("OQ_RTN_STREAM") ? atoi(getenv("OQ_RTN_STREAM")) : 0;
+        static const int env_blocks = getenv("OQ_RTN_BLOCKS") ? atoi(getenv("OQ_RTN_BLOCKS")) : 0;
+        if (env_stream && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves) {
+            // persistent grid: every block gets the same number of units (+-1); all blocks co-resident
+            const uint32_t nunits = a.ncol_tiles * a.nrow_tiles;
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+            uint32_t cap = static_cast<uint32_t>(env_blocks > 0 ? env_blocks : 2 * cus);
+            uint32_t nblocks = nunits < cap ? nunits : cap;
+            if (nunits > cap && env_blocks <= 0) {
+                // prefer a block count that divides the work evenly (equal streams finish together)
+                const uint32_t per = static_cast<uint32_t>(ceil_div(nunits, cap));
+                nblocks = static_cast<uint32_t>(ceil_div(nunits, per));
+            }
+#define OQ_STREAM(EQ, LAY, B)                                                                                  \
+    do {                                                                                                          \
+        if (env_nt) hipLaunchKernelGGL((rtn_group_stream<EQ, LAY, B, true>), dim3(nblocks), block, 0, s, a, nunits); \
+        else hipLaunchKernelGGL((rtn_group_stream<EQ, LAY, B, false>), dim3(nblocks), block, 0, s, a, nunits);     \
+    } while (0)
+            if (!emit_q) OQ_STREAM(false, OQ_LAYOUT_KN, 8);
+            else if (layout == OQ_LAYOUT_KN) OQ_STREAM(true, OQ_LAYOUT_KN, 8);
+            else if (grid.bits == 4) OQ_STREAM(true, OQ_LAYOUT_NBITS, 4);
+            else OQ_STREAM(true, OQ_LAYOUT_NBITS, 8);
+#undef OQ_STREAM
+            st = check_launch("rtn_group_stream");
+            if (st != OQ_OK || !staged) return st;
+            hipLaunchKernelGGL(transpose_qparams, dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32))),
+                               dim3(256), 0, s, a.scale_t, a.zp_t, kgroups, N, scale_out, zp8);
+            return check_launch("transpose_qparams");
+        }
         if (vec4) {
             if (emit_q) launch_fused<true, true>(rpw, a, grid_dim, block, s);
             else launch_fused<true, false>(rpw, a, grid_dim, block, s);
@@ -530,7 +888,11 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             if (emit_q) launch_fused<false, true>(rpw, a, grid_dim, block, s);
             else launch_fused<false, false>(rpw, a, grid_dim, block, s);
         }
-        return check_launch("rtn_group_fused");
+        st = check_launch("rtn_group_fused");
+        if (st != OQ_OK || !staged) return st;
+        hipLaunchKernelGGL(transpose_qparams, dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32))),
+                           dim3(256), 0, s, a.scale_t, a.zp_t, kgroups, N, scale_out, zp8);
+        return check_launch("transpose_qparams");
     }
 
     // two-pass
@@ -581,6 +943,8 @@ size_t oq_rtn_workspace_bytes(int64_t K, int64_t N, int32_t strategy, int64_t gr
     if (oq::resolve_group(strategy, K, group_size, &g) != OQ_OK) return 0;
     if (strategy == OQ_GROUP && K % g != 0) return 0;
     size_t need = oq::twopass_ws(K, N, g);
+    const size_t st = oq::stage_ws(K, N, g);
+    if (st > need) need = st;
     if (mse) need += oq::rtn_mse_workspace(K, N, strategy, g);
     return need + 256;
 }
