@@ -157,24 +157,29 @@ int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t ac
                             int32_t* perm_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* G2  gptq.py:134-150: H += percdamp*mean(diag H) on the diagonal, then the UPPER factor U with
- *     inv(H) = U^T U, written to U_out [K, K] (strictly-lower part zeroed).  H is consumed (overwritten).
+ *     inv(H) = U^T U, written to U_out [K, K] (strictly-lower part zeroed).  H is read only.
  *     info (DEVICE int32): 0 = ok; > 0 = first non-positive pivot (1-based), in which case U_out = I
  *     (the reference's LinAlgError fallback, gptq.py:143-150).  The call itself still returns OQ_OK. */
 size_t oq_gptq_factor_workspace_bytes(int64_t K);
-int32_t oq_gptq_factor_f32(float* H, int64_t K, float percdamp, float* U_out, int32_t* info,
+int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info,
                            void* workspace, size_t workspace_bytes, void* stream);
 
-/* G3  gptq.py:153-216: the block / row loop.  W [K, N] is consumed (overwritten with the working
- *     copy).  Outputs: Q_int [K, N] one value per byte, Q_deq [K, N] fp32 (the dequantized rows the
- *     final qparams are re-derived from, gptq.py:219-231), and -- for OQ_GPTQ_CORRECTED -- the
- *     (scale, zp) actually applied per (k-group, column): used_scale/used_zp [K/g_loop, N] (may be NULL).
- *     group_size: the reference's loop value (<=0 or -1: no regrouping inside the loop).
- *     loop_strategy: OQ_TENSOR or OQ_CHANNEL (gptq.py:92-96: GROUP is mapped to CHANNEL by the caller). */
+/* G3  gptq.py:153-216: the block / row loop.  W [K, N] is the working copy (after oq_gptq_prepare_f32); it
+ *     receives the lazy batch updates of gptq.py:208 (OQ_GPTQ_CORRECTED only: in OQ_GPTQ_PARITY the update term
+ *     is structurally zero) and is otherwise left as is.
+ *     group_size: the reference's loop value; > 0 re-derives per-column (scale, zp) from rows
+ *                 [r, r+group_size) of W whenever r % group_size == 0 (gptq.py:168-184); <= 0: never.
+ *     init_scale/init_zp: the parameters computed before the loop (gptq.py:104-116), init_count = 1 (tensor) or N.
+ *     block_size: gptq.py:153; blocks taller than 128 rows are processed as 128-row blocks.
+ *     Outputs: q_int_out [K, N] one value per byte; q_deq_out [K, N] fp32 (the dequantized rows the final qparams
+ *     are re-derived from, gptq.py:219-231); used_scale/used_zp [ceil(K/group_size), N] = the parameters actually
+ *     applied per (k-group, column) (NULL to skip; only written when group_size > 0).
+ *     mse != 0 is not supported inside the loop (OQ_ERR_UNSUPPORTED). */
 size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size);
-int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype,
-                         int32_t loop_strategy, int64_t group_size, int32_t symmetric,
-                         int32_t reduce_range, float clip_ratio, int32_t mse, int64_t block_size,
-                         int32_t mode, void* q_int_out, float* q_deq_out, float* used_scale,
+int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size,
+                         int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
+                         int64_t block_size, int32_t mode, const float* init_scale, const int32_t* init_zp,
+                         int64_t init_count, void* q_int_out, float* q_deq_out, float* used_scale,
                          int32_t* used_zp, void* workspace, size_t workspace_bytes, void* stream);
 
 /* N3  qrules/_common.py:65-123: MatMulNBits zero-point packing [N, ceil(K/g / 2)] (pad nibble 0x8)

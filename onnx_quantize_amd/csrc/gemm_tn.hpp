@@ -1,0 +1,33 @@
+// fp32 "TN" GEMM on the gfx950 matrix cores, shared by the GPTQ kernels:
+//
+//     C[m, n] = beta * C[m, n] + alpha * sum_k (sa * At[k, m]) * (sb * B[k, n])
+//
+// Both operands are stored k-major (row k holds all m / all n), which is exactly the layout of
+//   * the Hessian  H += (2/n) X^T X            (At = B = X [T, K],          gptq.py:246-260)
+//   * the Cholesky trailing update A -= P^T P  (At = B = panel^T [nb, K])
+//   * the GPTQ lazy batch update W -= U_rows^T Err (At = rows of U, B = Err [nb, N], gptq.py:208)
+// so no operand is ever transposed in memory.  v_mfma_f32_32x32x2_f32 takes ONE fp32 VGPR per operand
+// per lane -- lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31] -- i.e. two
+// consecutive k-rows of 32 contiguous floats: a k-major LDS tile is read conflict-free with
+// ds_read_b32 and needs no swizzle.  Accumulation is exact fp32 (an fmaf chain), like the sgemm the
+// reference calls; only the summation order differs.
+#pragma once
+
+#include "oq_common.hpp"
+
+namespace oq {
+
+struct GemmTN {
+    const float* At;  // [Kd, M], leading dimension lda
+    const float* B;   // [Kd, N], leading dimension ldb
+    float* C;         // [M, N], leading dimension ldc
+    int64_t M, N, Kd, lda, ldb, ldc;
+    float alpha, beta;
+    float sa, sb;     // operand pre-scales applied on load (fp32 rounding each, like `sqrt(2/n) * inp`)
+    int32_t upper_only;  // compute only tiles with tile_n >= tile_m (symmetric result, At == B)
+    int32_t mirror;      // with upper_only: also store C[n, m] for off-diagonal tiles
+};
+
+int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s);
+
+}  // namespace oq

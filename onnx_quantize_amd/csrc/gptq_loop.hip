@@ -1,0 +1,181 @@
+// G3: the GPTQ block / row loop (gptq.py:153-216) for gfx950.
+//
+// Output columns are independent given U, so one lane owns one column for the whole block: the block's
+// rows of that column live in an LDS tile ([rows][256 columns], one column per lane -> conflict-free), the
+// loop over rows is the sequential part, and the coefficients of U are wave-uniform scalars.  After each
+// block the lazy batch update of the rows below (gptq.py:208) is one MFMA TN GEMM over the whole chip.
+//
+// Error-feedback indexing (oq_gptq_mode):
+//   PARITY     coefficient of row j for the error of row i = U[i1+j][i1+i]   (gptq.py:199 as written: the
+//              column of the UPPER factor below the diagonal, i.e. exact zeros -> the integers equal RTN
+//              with per-group parameters; SURVEY.md finding 1)
+//   CORRECTED  U[i1+i][i1+j]  (row of the upper factor right of the diagonal: what GPTQ intends)
+// The batch update uses U[i2:, i1:i2] (PARITY: an all-zero block, the GEMM is skipped) or U[i1:i2, i2:]^T.
+#include "gemm_tn.hpp"
+
+namespace oq {
+
+constexpr int kLoopCols = 256;
+constexpr int kLoopMaxRows = 128;
+
+struct LoopArgs {
+    float* W;          // [K, N] working copy
+    const float* U;    // [K, K]
+    int64_t K, N;
+    int64_t i1, count; // rows [i1, i1 + count) of this block
+    int64_t g;         // loop group size (<= 0: none)
+    QGrid grid;
+    int32_t mode;
+    const float* init_scale;
+    const int32_t* init_zp;
+    int64_t init_count;
+    uint8_t* q_int;    // [K, N]
+    float* q_deq;      // [K, N]
+    float* used_scale; // [ceil(K/g), N] or null
+    int32_t* used_zp;
+    float* err;        // [count, N]
+    float* carry_scale;  // [N] parameters in force at the end of the previous block (groups may span blocks)
+    int32_t* carry_zp;
+};
+
+__global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a) {
+    extern __shared__ float tile[];  // [count][kLoopCols]
+    const int c_local = threadIdx.x;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kLoopCols + c_local;
+    const bool live = c < a.N;
+    const int64_t cc = live ? c : a.N - 1;  // clamped column for loads
+
+    for (int64_t i = 0; i < a.count; ++i) tile[i * kLoopCols + c_local] = a.W[(a.i1 + i) * a.N + cc];  // W1 = copy (gptq.py:157)
+
+    float scale;
+    int32_t zp;
+    if (a.i1 == 0) {  // gptq.py:104-116
+        const int64_t pi = a.init_count == 1 ? 0 : cc;
+        scale = a.init_scale[pi];
+        zp = a.init_zp[pi];
+    } else {
+        scale = a.carry_scale[cc];
+        zp = a.carry_zp[cc];
+    }
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+
+    for (int64_t i = 0; i < a.count; ++i) {
+        const int64_t row = a.i1 + i;
+        if (a.g > 0 && row % a.g == 0) {
+            // gptq.py:168-184: per-column parameters from rows [row, row + g) of the GLOBAL working matrix
+            // (not from the block copy), channel strategy.
+            const int64_t rend = row + a.g < a.K ? row + a.g : a.K;
+            float mn = INFINITY, mx = -INFINITY;
+            for (int64_t r = row; r < rend; ++r) {
+                const float x = a.W[r * a.N + cc];
+                mn = fminf(mn, x);
+                mx = fmaxf(mx, x);
+            }
+            const QParam p = qparam_from_minmax(mn, mx, a.grid);
+            scale = p.scale;
+            zp = p.zp;
+            if (live && a.used_scale != nullptr) {
+                a.used_scale[(row / a.g) * a.N + c] = scale;
+                a.used_zp[(row / a.g) * a.N + c] = zp;
+            }
+        }
+        const float w = tile[i * kLoopCols + c_local];
+        const int32_t qi = quantize_one(w, scale, zp, qmin, qmax);   // gptq.py:186-188
+        const float q = dequantize_one(qi, scale, zp);                // :189
+        const float d = a.U[row * a.K + row];                         // :164
+        const float e = (w - q) / d;                                  // :197
+        if (live) {
+            a.q_int[row * a.N + c] = static_cast<uint8_t>(qi);
+            a.q_deq[row * a.N + c] = q;
+            a.err[i * a.N + c] = e;
+        }
+        // gptq.py:198-200  W1[i:, :] -= outer(Hinv1[i:, i], err1); row i itself is never read again
+        const float* coef = a.mode == OQ_GPTQ_PARITY ? a.U + a.i1 * a.K + row   // + j * K  (column `row`)
+                                                     : a.U + row * a.K + a.i1;  // + j      (row `row`)
+        const int64_t cstride = a.mode == OQ_GPTQ_PARITY ? a.K : 1;
+        for (int64_t j = i + 1; j < a.count; ++j) {
+            const float prod = coef[j * cstride] * e;   // the K=1 matmul of the reference: one rounding
+            tile[j * kLoopCols + c_local] = tile[j * kLoopCols + c_local] - prod;
+        }
+    }
+    if (live) {
+        a.carry_scale[c] = scale;
+        a.carry_zp[c] = zp;
+    }
+}
+
+}  // namespace oq
+
+extern "C" {
+
+using namespace oq;
+
+size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size) {
+    if (K <= 0 || N <= 0) return 0;
+    (void)block_size;
+    return static_cast<size_t>(kLoopMaxRows) * N * 4 + static_cast<size_t>(N) * 8 + 512;
+}
+
+int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size, int32_t symmetric,
+                         int32_t reduce_range, float clip_ratio, int32_t mse, int64_t block_size, int32_t mode,
+                         const float* init_scale, const int32_t* init_zp, int64_t init_count, void* q_int_out,
+                         float* q_deq_out, float* used_scale, int32_t* used_zp, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    OQ_REQUIRE(W && U && init_scale && init_zp && q_int_out && q_deq_out && K > 0 && N > 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_gptq_loop_f32: bad argument");
+    OQ_REQUIRE(init_count == 1 || init_count == N, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: init_count must be 1 or N");
+    OQ_REQUIRE(block_size > 0, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: block_size must be positive");
+    OQ_REQUIRE(mode == OQ_GPTQ_PARITY || mode == OQ_GPTQ_CORRECTED, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: bad mode %d", mode);
+    OQ_REQUIRE(!mse, OQ_ERR_UNSUPPORTED, "oq_gptq_loop_f32: mse inside the GPTQ loop is not supported");
+    OQ_REQUIRE(clip_ratio > 0.0f && clip_ratio <= 1.0f, OQ_ERR_INVALID_ARGUMENT, "clip_ratio must be in (0.0, 1.0], got %g", clip_ratio);
+    QGrid grid;
+    int32_t st = make_grid(qtype, symmetric, reduce_range, clip_ratio, &grid);
+    if (st != OQ_OK) return st;
+    const size_t need = oq_gptq_loop_workspace_bytes(K, N, block_size);
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_gptq_loop_f32: workspace of %zu bytes needed, %zu given", need,
+               workspace_bytes);
+    hipStream_t s = as_stream(stream);
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gptq_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLoopMaxRows * kLoopCols * 4) != hipSuccess)
+            return fail(OQ_ERR_LAUNCH, "oq_gptq_loop_f32: cannot reserve LDS");
+        attr_set = true;
+    }
+
+    LoopArgs a;
+    a.W = W; a.U = U; a.K = K; a.N = N; a.g = group_size > 0 ? group_size : 0; a.grid = grid; a.mode = mode;
+    a.init_scale = init_scale; a.init_zp = init_zp; a.init_count = init_count;
+    a.q_int = static_cast<uint8_t*>(q_int_out); a.q_deq = q_deq_out;
+    a.used_scale = (group_size > 0) ? used_scale : nullptr;
+    a.used_zp = used_zp;
+    if (a.used_scale != nullptr && used_zp == nullptr) return fail(OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: used_zp missing");
+    a.err = static_cast<float*>(workspace);
+    a.carry_scale = a.err + static_cast<size_t>(kLoopMaxRows) * N;
+    a.carry_zp = reinterpret_cast<int32_t*>(a.carry_scale + N);
+
+    const int64_t bs = block_size < kLoopMaxRows ? block_size : kLoopMaxRows;
+    const uint32_t nblk = static_cast<uint32_t>(ceil_div(N, kLoopCols));
+    for (int64_t i1 = 0; i1 < K; i1 += bs) {
+        const int64_t count = (K - i1) < bs ? (K - i1) : bs;
+        a.i1 = i1; a.count = count;
+        hipLaunchKernelGGL(gptq_block_kernel, dim3(nblk), dim3(kLoopCols), static_cast<size_t>(count) * kLoopCols * 4, s, a);
+        st = check_launch("gptq_block_kernel");
+        if (st != OQ_OK) return st;
+        const int64_t i2 = i1 + count;
+        if (mode == OQ_GPTQ_CORRECTED && i2 < K) {
+            // gptq.py:208 with the intended operand: W[i2:, :] -= U[i1:i2, i2:]^T @ Err1
+            GemmTN g;
+            g.At = U + i1 * K + i2; g.lda = K; g.M = K - i2;
+            g.B = a.err; g.ldb = N; g.N = N;
+            g.C = W + i2 * N; g.ldc = N;
+            g.Kd = count; g.alpha = -1.0f; g.beta = 1.0f; g.sa = 1.0f; g.sb = 1.0f; g.upper_only = 0; g.mirror = 0;
+            st = launch_gemm_tn(g, s);
+            if (st != OQ_OK) return st;
+        }
+    }
+    return OQ_OK;
+}
+
+}  // extern "C"

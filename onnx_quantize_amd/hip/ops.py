@@ -233,3 +233,113 @@ def pack_nibbles(values: torch.Tensor) -> torch.Tensor:
     out = torch.empty((v.numel() + 1) // 2, dtype=torch.uint8, device=values.device)
     L.check(L.load().oq_pack_nibbles(_ptr(v), v.numel(), _ptr(out), _stream()))
     return out
+
+
+# ----------------------------------------------------------------------------- G1 - G4
+def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
+    """gptq.py:246-260, in place on ``h`` [K, K]; ``x`` [n_add, ..., K] fp32.  Returns the new sample
+    count.  The activations are streamed through the MFMA TN GEMM; nothing is concatenated."""
+    _require_device(x, "x", torch.float32)
+    _require_device(h, "H", torch.float32)
+    n_add = int(x.shape[0])
+    x2 = x.reshape(-1, x.shape[-1])
+    x2, ldx = _row_major(x2)
+    t, k = x2.shape
+    if h.shape != (k, k) or not h.is_contiguous():
+        raise ValueError(f"H must be a contiguous [{k}, {k}] tensor")
+    L.check(L.load().oq_hessian_accumulate_f32(_ptr(x2), t, k, ldx, int(n_seen), n_add, _ptr(h), _stream()))
+    return int(n_seen) + n_add
+
+
+def gptq_prepare(w: torch.Tensor, h: torch.Tensor, actorder: bool):
+    """gptq.py:118-127 in place on the working copies ``w`` [K, N] and ``h`` [K, K]; returns perm or None."""
+    _require_device(w, "W", torch.float32)
+    _require_device(h, "H", torch.float32)
+    assert w.is_contiguous() and h.is_contiguous()
+    k, n = w.shape
+    lib = L.load()
+    perm = torch.empty(k, dtype=torch.int32, device=w.device) if actorder else None
+    ws = _workspace(lib.oq_gptq_prepare_workspace_bytes(k, n, int(actorder)), w.device)
+    L.check(lib.oq_gptq_prepare_f32(_ptr(w), k, n, _ptr(h), int(actorder), _ptr(perm), _ptr(ws), ws.numel(), _stream()))
+    return perm
+
+
+def gptq_factor(h: torch.Tensor, percdamp: float):
+    """gptq.py:134-150: returns (U [K, K] upper with inv(H + damp I) = U^T U, info int32[1] on device)."""
+    _require_device(h, "H", torch.float32)
+    assert h.is_contiguous() and h.dim() == 2 and h.shape[0] == h.shape[1]
+    k = h.shape[0]
+    lib = L.load()
+    u = torch.empty((k, k), dtype=torch.float32, device=h.device)
+    info = torch.zeros(1, dtype=torch.int32, device=h.device)
+    ws = _workspace(lib.oq_gptq_factor_workspace_bytes(k), h.device)
+    L.check(lib.oq_gptq_factor_f32(_ptr(h), k, float(percdamp), _ptr(u), _ptr(info), _ptr(ws), ws.numel(), _stream()))
+    return u, info
+
+
+def gptq_loop(w: torch.Tensor, u: torch.Tensor, qtype: str, group_size, symmetric: bool, reduce_range: bool,
+              clip_ratio: float, mse: bool, block_size: int, mode: str, init_scale: torch.Tensor,
+              init_zp: torch.Tensor, want_used: bool = False):
+    """gptq.py:153-216 on the working copy ``w`` (modified in place in corrected mode).
+    Returns (q_int [K, N], q_deq [K, N], used_scale | None, used_zp | None)."""
+    _require_device(w, "W", torch.float32)
+    _require_device(u, "U", torch.float32)
+    assert w.is_contiguous() and u.is_contiguous()
+    k, n = w.shape
+    lib = L.load()
+    g = int(group_size) if group_size else 0
+    q_int = torch.empty((k, n), dtype=container_dtype(qtype), device=w.device)
+    q_deq = torch.empty((k, n), dtype=torch.float32, device=w.device)
+    used_s = used_z = None
+    if want_used and g > 0:
+        ng = (k + g - 1) // g
+        used_s = torch.empty((ng, n), dtype=torch.float32, device=w.device)
+        used_z = torch.empty((ng, n), dtype=torch.int32, device=w.device)
+    s0 = init_scale.to(torch.float32).contiguous().reshape(-1)
+    z0 = init_zp.to(torch.int32).contiguous().reshape(-1)
+    ws = _workspace(lib.oq_gptq_loop_workspace_bytes(k, n, int(block_size)), w.device)
+    L.check(lib.oq_gptq_loop_f32(_ptr(w), k, n, _ptr(u), L.QTYPE_CODE[qtype], g, int(symmetric), int(reduce_range),
+                                 float(clip_ratio), int(mse), int(block_size),
+                                 L.OQ_GPTQ_PARITY if mode == "parity" else L.OQ_GPTQ_CORRECTED, _ptr(s0), _ptr(z0),
+                                 s0.numel(), _ptr(q_int), _ptr(q_deq), _ptr(used_s), _ptr(used_z), _ptr(ws),
+                                 ws.numel(), _stream()))
+    return q_int, q_deq, used_s, used_z
+
+
+def gptq_quantize(w: torch.Tensor, h: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
+                  reduce_range=False, clip_ratio=1.0, block_size=128, percdamp=0.01, actorder=False, mse=False,
+                  mode: str = "parity"):
+    """gptq.py:76-243 (`_gptq`) on device tensors: ``w`` [K, N] weights, ``h`` [K, K] accumulated Hessian.
+    Neither input is modified.  Returns (q_int, scale, zp, info) with the reference's output shapes."""
+    if mode not in ("parity", "corrected"):
+        raise ValueError("mode must be 'parity' or 'corrected'")
+    _require_device(w, "W", torch.float32)
+    _require_device(h, "H", torch.float32)
+    k, n = w.shape
+    used = "channel" if strategy == "group" else strategy                      # gptq.py:92-96
+    w1 = w.contiguous().clone()                                                  # :99-100
+    h1 = h.contiguous().clone()
+    # :104-116 initial parameters: per out-channel over all of K (or global)
+    _, s0, z0 = rtn_quantize(w1, qtype, used, -1, symmetric, reduce_range, clip_ratio, mse, emit_q=False)
+    perm = gptq_prepare(w1, h1, actorder)                                        # :118-127
+    u, info = gptq_factor(h1, percdamp)                                          # :134-150
+    loop_g = group_size if (group_size and group_size != -1) else 0
+    corrected_own = mode == "corrected" and not actorder
+    q_int, q_deq, us, uz = gptq_loop(w1, u, qtype, loop_g, symmetric, reduce_range, clip_ratio, mse, block_size,
+                                     mode, s0, z0, want_used=corrected_own and strategy == "group")
+    if actorder:                                                                 # :210-213
+        inv = torch.argsort(perm.to(torch.int64))
+        q_int = q_int.index_select(0, inv)
+        q_deq = q_deq.index_select(0, inv)
+    # :219-231 final parameters re-derived from the dequantized Q in the user's layout
+    _, scale, zp = rtn_quantize(q_deq, qtype, strategy, group_size if group_size is not None else -1, symmetric,
+                                reduce_range, clip_ratio, mse, emit_q=False)
+    if corrected_own:
+        g_eff = resolve_group("group", k, loop_g) if loop_g else 0
+        if strategy == "group" and loop_g and k % g_eff == 0 and us is not None:
+            # corrected mode returns the parameters the integers were produced with (see oracle/oq_oracle.py)
+            scale = us.t().contiguous().reshape(-1, 1)
+            zp = uz.t().contiguous().reshape(-1, 1).to(container_dtype(qtype))
+        elif not loop_g and strategy in ("tensor", "channel"):
+            scale, zp = s0.reshape(scale.shape), z0.reshape(zp.shape)
+    return q_int, scale, zp, info
