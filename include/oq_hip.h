@@ -97,6 +97,17 @@ int32_t oq_qparams_f32(const float* rmin, const float* rmax, int64_t count, int3
                        int32_t symmetric, int32_t reduce_range, float* scale_out, int32_t* zp_out,
                        void* stream);
 
+/* Same for float64 ranges (the reference's arithmetic follows the input dtype, utils.py:260-262; its own
+ * known-answer tests feed float64): scale is computed in double and written as fp32. */
+int32_t oq_qparams_f64(const double* rmin, const double* rmax, int64_t count, int32_t qtype,
+                       int32_t symmetric, int32_t reduce_range, float* scale_out, int32_t* zp_out,
+                       void* stream);
+
+/* R1  core/_algorithms/utils.py:60-61 with axis=1: per-row min and max of a row-major [R, C] array (the
+ *     reference's preprocessed layout, one row per (scale, zp)).  Raw extrema: no clip ratio, no zero. */
+int32_t oq_minmax_rows_f32(const float* x, int64_t R, int64_t C, int64_t ldx, float* min_out,
+                           float* max_out, void* stream);
+
 /* K1  core/_algorithms/utils.py:72-79  _quantize_array_from_qparams, and
  * K2  core/_algorithms/utils.py:102-137 _dequantize_array, on a row-major [R, C] array.
  *     The (scale, zp) entry used by element (r, c) is  (r / row_div) * row_stride + c * col_stride :

@@ -15,6 +15,28 @@ __global__ void qparams_kernel(const float* rmin, const float* rmax, int64_t cou
     zp[i] = p.zp;
 }
 
+// utils.py:242-299 evaluated in float64 (what NumPy does for float64 ranges); scale leaves as fp32.
+__global__ void qparams_kernel_f64(const double* rmin, const double* rmax, int64_t count, QGrid grid, float* scale,
+                                   int32_t* zp) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double lo = rmin[i], hi = rmax[i];
+    if (grid.symmetric) {
+        const double amax = fmax(fabs(lo), fabs(hi));
+        double s = amax / grid.levels;
+        if (s < DBL_MIN) s = 1.0;
+        scale[i] = static_cast<float>(s);
+        zp[i] = grid.zero;
+    } else {
+        double s = (hi - lo) / static_cast<double>(grid.qmax - grid.qmin);
+        if (s < DBL_MIN) s = 1.0;
+        double z = static_cast<double>(grid.qmin) - lo / s;
+        z = fmin(fmax(z, static_cast<double>(grid.qmin)), static_cast<double>(grid.qmax));
+        scale[i] = static_cast<float>(s);
+        zp[i] = static_cast<int32_t>(rint(z));
+    }
+}
+
 struct ParamIndex {
     int64_t row_div, row_stride, col_stride;
     __device__ __forceinline__ int64_t operator()(int64_t r, int64_t c) const {
@@ -105,6 +127,17 @@ int32_t oq_qparams_f32(const float* rmin, const float* rmax, int64_t count, int3
     hipLaunchKernelGGL(qparams_kernel, dim3(static_cast<uint32_t>(ceil_div(count, 256))), dim3(256), 0, as_stream(stream),
                        rmin, rmax, count, grid, scale_out, zp_out);
     return check_launch("qparams_kernel");
+}
+
+int32_t oq_qparams_f64(const double* rmin, const double* rmax, int64_t count, int32_t qtype, int32_t symmetric,
+                       int32_t reduce_range, float* scale_out, int32_t* zp_out, void* stream) {
+    OQ_REQUIRE(rmin && rmax && scale_out && zp_out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_qparams_f64: bad argument");
+    QGrid grid;
+    const int32_t st = make_grid(qtype, symmetric, reduce_range, 1.0f, &grid);
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(qparams_kernel_f64, dim3(static_cast<uint32_t>(ceil_div(count, 256))), dim3(256), 0, as_stream(stream),
+                       rmin, rmax, count, grid, scale_out, zp_out);
+    return check_launch("qparams_kernel_f64");
 }
 
 int32_t oq_quantize_f32(const float* x, int64_t R, int64_t C, int64_t ldx, const float* scale, const int32_t* zp,

@@ -188,6 +188,28 @@ __global__ __launch_bounds__(256) void absmax_rows(const float* x, int64_t R, in
     if (lane == 0) out[r] = m;
 }
 
+// per-row (min, max): one wave per row
+__global__ __launch_bounds__(256) void minmax_rows(const float* x, int64_t R, int64_t C, int64_t ldx, bool vec4, float* mn_out,
+                                                   float* mx_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* row = x + r * ldx;
+    float mn = INFINITY, mx = -INFINITY;
+    if (vec4) {
+        for (int64_t c = lane * 4; c < C; c += 256) {
+            const float4 t = *reinterpret_cast<const float4*>(row + c);
+            mn = fminf(fminf(mn, t.x), fminf(fminf(t.y, t.z), t.w));
+            mx = fmaxf(fmaxf(mx, t.x), fmaxf(fmaxf(t.y, t.z), t.w));
+        }
+    } else {
+        for (int64_t c = lane; c < C; c += 64) { mn = fminf(mn, row[c]); mx = fmaxf(mx, row[c]); }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane == 0) { mn_out[r] = mn; mx_out[r] = mx; }
+}
+
 }  // namespace oq
 
 extern "C" {
@@ -235,6 +257,14 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
     if (st != OQ_OK) return st;
     hipLaunchKernelGGL(absmax_cols_finalize, dim3(static_cast<uint32_t>(ceil_div(C, 256))), dim3(256), 0, s, partial, chunks, C, out);
     return check_launch("absmax_cols_finalize");
+}
+
+int32_t oq_minmax_rows_f32(const float* x, int64_t R, int64_t C, int64_t ldx, float* min_out, float* max_out, void* stream) {
+    OQ_REQUIRE(x && min_out && max_out && R > 0 && C > 0 && ldx >= C, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_rows_f32: bad argument");
+    const bool vec4 = (C % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+    hipLaunchKernelGGL(minmax_rows, dim3(static_cast<uint32_t>(ceil_div(R, 4))), dim3(256), 0, as_stream(stream), x, R, C, ldx,
+                       vec4, min_out, max_out);
+    return check_launch("minmax_rows");
 }
 
 }  // extern "C"

@@ -55,6 +55,8 @@ PROTOTYPES = {
     "oq_rtn_qparams_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _f32, _i32,
                                   _p, _p, _p, _sz, _p]),
     "oq_qparams_f32": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _p, _p, _p]),
+    "oq_qparams_f64": (_i32, [_p, _p, _i64, _i32, _i32, _i32, _p, _p, _p]),
+    "oq_minmax_rows_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p]),
     "oq_quantize_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "oq_dequantize_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "oq_quantize_bias_f32": (_i32, [_p, _i64, _p, _i64, _f32, _p, _p, _p]),

@@ -123,6 +123,29 @@ def qparams(rmin: torch.Tensor, rmax: torch.Tensor, qtype: str, symmetric: bool,
     return scale.reshape(rmin.shape), zp.reshape(rmin.shape)
 
 
+def qparams_f64(rmin: torch.Tensor, rmax: torch.Tensor, qtype: str, symmetric: bool, reduce_range: bool):
+    """utils.py:242-299 for float64 ranges (arithmetic in double, fp32 scale out)."""
+    _require_device(rmin, "rmin", torch.float64)
+    _require_device(rmax, "rmax", torch.float64)
+    a, b = rmin.contiguous().reshape(-1), rmax.contiguous().reshape(-1)
+    scale = torch.empty(a.numel(), dtype=torch.float32, device=a.device)
+    zp = torch.empty(a.numel(), dtype=torch.int32, device=a.device)
+    L.check(L.load().oq_qparams_f64(_ptr(a), _ptr(b), a.numel(), L.QTYPE_CODE[qtype], int(symmetric),
+                                    int(reduce_range), _ptr(scale), _ptr(zp), _stream()))
+    return scale.reshape(rmin.shape), zp.reshape(rmin.shape)
+
+
+def minmax_rows(x: torch.Tensor):
+    """utils.py:60-61 (axis=1): raw per-row (min, max) of a 2-D fp32 tensor."""
+    _require_device(x, "x", torch.float32)
+    x2, ldx = _row_major(x)
+    r, c = x2.shape
+    mn = torch.empty(r, dtype=torch.float32, device=x.device)
+    mx = torch.empty(r, dtype=torch.float32, device=x.device)
+    L.check(L.load().oq_minmax_rows_f32(_ptr(x2), r, c, ldx, _ptr(mn), _ptr(mx), _stream()))
+    return mn, mx
+
+
 # ----------------------------------------------------------------------------- K1 / K2
 def _param_index(mode: str, r: int, c: int, group: int = 1):
     if mode == "tensor":

@@ -1,0 +1,292 @@
+"""The NumPy-facing API (same names and call shapes as the reference) running on the GPU: these tests
+read like the reference's test/core/algorithms/test_rtn.py, test_gptq.py and
+test/core/calibration/test_minmax_calibrator.py, plus golden-vector checks of the small kernels."""
+import math
+
+import numpy as np
+import pytest
+
+import oq_oracle as O
+from conftest import load_json, load_npz
+from onnx_quantize_amd import QuantizationStrategy, QuantType
+
+pytestmark = pytest.mark.gpu
+
+QT = {"int4": QuantType.QInt4, "uint4": QuantType.QUInt4, "int8": QuantType.QInt8, "uint8": QuantType.QUInt8}
+KATS = load_json("scalar_kats.json")
+
+
+@pytest.fixture(scope="module")
+def F():
+    from onnx_quantize_amd.algorithms import functional
+    return functional
+
+
+@pytest.fixture(scope="module")
+def A():
+    from onnx_quantize_amd import algorithms
+    return algorithms
+
+
+# ------------------------------------------------------------------ test_rtn.py:21-72
+@pytest.mark.parametrize("vals,qtype,sym,exp_scale,exp_zp", KATS["qparams"])
+def test_get_quantization_params_scalar(F, vals, qtype, sym, exp_scale, exp_zp):
+    quant_type = QT[qtype]
+    scale, zero_point = F._compute_qparams_from_array(
+        np.array(vals), quant_type, QuantizationStrategy.TENSOR, group_size=-1, is_symmetric=sym,
+        reduce_range=False, clip_ratio=1.0, mse=False, scale_dtype=np.float32, zp_dtype=quant_type.np_dtype)
+    assert scale > 0 and scale.size == 1
+    np.testing.assert_allclose(scale, np.array(exp_scale, dtype=np.float32), rtol=1e-5)
+    assert zero_point.dtype == quant_type.np_dtype and zero_point.size == 1
+    assert int(zero_point) == exp_zp
+    qmin, qmax = quant_type.qrange(sym)
+    assert qmin <= zero_point <= qmax
+
+
+@pytest.mark.parametrize("fp_array, qtype, symmetric", [
+    (np.array([[-5.0, 0.0, 10.0], [-2.0, 5.0, 3.0]]), "int8", False),
+    (np.array([[0.0, 5.0, 10.0], [1.0, 2.0, 3.0]]), "uint8", False),
+    (np.array([[-10.0, -5.0, 5.0], [2.0, 1.0, -1.0]]), "int8", True),
+    (np.array([[0.0, 0.0, 0.0], [1.0, 2.0, 3.0]]), "int8", False),
+])
+def test_get_quantization_params_per_channel(F, fp_array, qtype, symmetric):
+    quant_type = QT[qtype]
+    scale, zero_point = F._compute_qparams_from_array(
+        fp_array, quant_type, QuantizationStrategy.CHANNEL, group_size=-1, is_symmetric=symmetric,
+        reduce_range=False, clip_ratio=1.0, mse=False, scale_dtype=np.float32, zp_dtype=quant_type.np_dtype)
+    assert scale.shape == (fp_array.shape[0], 1) and zero_point.shape == (fp_array.shape[0], 1)
+    assert np.all(scale > 0) and zero_point.dtype == quant_type.np_dtype
+    es, ez = O.qparams_from_rows(fp_array.astype(np.float32), qtype, "channel", symmetric, False)
+    np.testing.assert_allclose(scale, es, rtol=1e-6)
+    np.testing.assert_array_equal(zero_point, ez)
+
+
+@pytest.mark.parametrize("qtype, symmetric, group_size", [("int8", False, 2), ("uint8", False, 4), ("int8", True, 16),
+                                                          ("int8", False, 7)])
+def test_get_quantization_params_group(F, qtype, symmetric, group_size):
+    quant_type = QT[qtype]
+    fp_array = np.ones((32, 64), dtype=np.float32)
+    in_channels, out_channels = fp_array.shape
+    if group_size > in_channels or in_channels % group_size:       # qrules/_common.py:13-29
+        group_size = in_channels
+    rows = F._preprocess_array(fp_array, QuantizationStrategy.GROUP, group_size)
+    scale, zero_point = F._compute_qparams_from_array(
+        rows, quant_type, QuantizationStrategy.GROUP, group_size=group_size, is_symmetric=symmetric,
+        reduce_range=False, clip_ratio=1.0, mse=False, scale_dtype=np.float32, zp_dtype=quant_type.np_dtype)
+    num_groups = math.ceil(in_channels / group_size)
+    assert scale.shape == (out_channels * num_groups, 1) == zero_point.shape
+    assert np.all(scale > 0) and zero_point.dtype == quant_type.np_dtype
+
+
+def test_quantize_bias(A, rng):
+    bias = rng.random((16,)).astype(np.float32)
+    input_scale = 1.5
+    weight_scale = rng.random((16,)).astype(np.float32)
+    q_bias, scale, zero_point = A._quantize_bias(bias, input_scale, weight_scale)
+    assert q_bias.shape == bias.shape and q_bias.dtype == np.int32 and zero_point == 0
+    np.testing.assert_array_equal(scale, input_scale * weight_scale)
+    K = load_npz("kernels.npz")
+    qb, bs, _ = A._quantize_bias(K["bias"], K["bias_xscale"], K["bias_wscale"])
+    np.testing.assert_array_equal(qb, K["bias_q"])
+    assert bs.tobytes() == K["bias_scale"].tobytes()
+
+
+@pytest.mark.parametrize("strategy,group_size", [(QuantizationStrategy.TENSOR, None), (QuantizationStrategy.CHANNEL, -1),
+                                                 (QuantizationStrategy.GROUP, 16), (QuantizationStrategy.GROUP, 64)])
+@pytest.mark.parametrize("qtype", ["int4", "uint4", "int8", "uint8"])
+@pytest.mark.parametrize("symmetric", [False, True])
+def test_rtn_quantize_shapes_dtypes_error_bound(A, F, rng, strategy, group_size, qtype, symmetric):
+    """test_rtn.py:259-452: shapes, dtypes, range and |dq - w| <= 2 * scale."""
+    quant_type = QT[qtype]
+    w = rng.normal(0, 1, (64, 48)).astype(np.float32)
+    q, scale, zp = A._rtn_quantize(w, quant_type, strategy, group_size, symmetric, False, 1.0, False,
+                                   np.dtype(np.float32), quant_type.np_dtype)
+    assert q.shape == w.shape and q.dtype == quant_type.np_dtype
+    qmin, qmax = quant_type.qrange(symmetric)
+    assert q.min() >= qmin and q.max() <= qmax
+    if strategy == QuantizationStrategy.TENSOR:
+        assert scale.shape == () and zp.shape == ()
+    elif strategy == QuantizationStrategy.CHANNEL:
+        assert scale.shape == (48,) and zp.shape == (48,)
+    else:
+        assert scale.shape == (48 * 64 // group_size, 1) == zp.shape
+    assert scale.dtype == np.float32 and zp.dtype == quant_type.np_dtype
+    dq = F._dequantize_array(q, scale, zp, preprocess=True, strategy=strategy,
+                             group_size=-1 if group_size is None else group_size)
+    smax = float(np.max(scale))
+    assert np.max(np.abs(dq - w)) <= 2 * smax
+
+
+def test_rtn_all_zero_weights(A):
+    # test_rtn.py:455-479
+    for strategy, g in ((QuantizationStrategy.TENSOR, None), (QuantizationStrategy.CHANNEL, -1), (QuantizationStrategy.GROUP, 8)):
+        q, s, z = A._rtn_quantize(np.zeros((16, 8), np.float32), QuantType.QInt8, strategy, g, False, False, 1.0, False,
+                                  np.dtype(np.float32), np.dtype(np.int8))
+        assert np.all(s == 1.0) and np.all(q == z.reshape(-1)[0])
+
+
+def test_small_kernels_vs_golden(F):
+    K = load_npz("kernels.npz")
+    x = K["x"]
+    lo = np.minimum(x.min(axis=1, keepdims=True), 0)
+    hi = np.maximum(x.max(axis=1, keepdims=True), 0)
+    for qtype in ("int4", "uint4", "int8", "uint8"):
+        for sym in (False, True):
+            for red in (False, True):
+                tag = f"{qtype}_{int(sym)}{int(red)}"
+                s, z = F._compute_qparams(lo, hi, QT[qtype], sym, red, np.dtype(np.float32), QT[qtype].np_dtype)
+                assert s.tobytes() == K[f"qp_{tag}_s"].tobytes(), tag
+                np.testing.assert_array_equal(z, K[f"qp_{tag}_z"])
+                q = F._quantize_array_from_qparams(x, s, z, QT[qtype], sym, red)
+                np.testing.assert_array_equal(q, K[f"qp_{tag}_q"])
+                assert q.dtype == K[f"qp_{tag}_q"].dtype
+                assert F._dequantize_array(q, s, z).tobytes() == K[f"qp_{tag}_dq"].tobytes()
+                assert F._fake_quantize_array(x, s, z, QT[qtype], sym, red).tobytes() == K[f"qp_{tag}_dq"].tobytes()
+    for sname, g in (("tensor", -1), ("channel", -1), ("group", 16)):
+        out = F._dequantize_array(K[f"dq_{sname}_q"], K[f"dq_{sname}_s"], K[f"dq_{sname}_z"], preprocess=True,
+                                  strategy=QuantizationStrategy(sname), group_size=g)
+        assert np.ascontiguousarray(out).tobytes() == K[f"dq_{sname}_out"].tobytes()
+
+
+def test_wire_format_packers():
+    import torch
+    from onnx_quantize_amd.hip import ops
+    for vals, qtype, expected in KATS["pack"]:      # test_pack.py:11-27, :59-75
+        a = torch.tensor(vals, dtype=torch.int8 if qtype == "int4" else torch.uint8, device="cuda")
+        assert ops.pack_nibbles(a).cpu().tolist() == expected
+    r = np.random.default_rng(0)                    # test_common.py:7-31
+    z = r.integers(0, 16, size=(4 * 5, 1), dtype=np.uint8)
+    pz = ops.pack_zero_points_u4(torch.from_numpy(z).cuda(), 4, 5).cpu().numpy()
+    _, _, epz = O.matmul_nbits_layout(np.zeros((80, 4), np.uint8), np.zeros(20, np.float32), z, 16, 4)
+    np.testing.assert_array_equal(pz, epz)
+
+
+# ------------------------------------------------------------------ test_minmax_calibrator.py
+class TestMinMaxCalibrator:
+    def make(self, **kw):
+        from onnx_quantize_amd.calibration import MinMaxCalibrator
+        return MinMaxCalibrator(**kw)
+
+    def test_collect_single_batch(self):
+        c = self.make()
+        c.collect("test", np.array([1.0, 2.0, 3.0, 4.0, 5.0]))
+        assert "test" in c.data and c.data["test"].min_val == 1.0 and c.data["test"].max_val == 5.0
+        lo, hi = c.compute_range("test")
+        np.testing.assert_almost_equal(lo, 0.0)
+        np.testing.assert_almost_equal(hi, 5.0)
+        assert lo.dtype == np.float32 and lo.shape == ()
+
+    def test_negative_and_multidimensional(self):
+        c = self.make()
+        c.collect("a", np.array([-5.0, -2.0, 0.0, 3.0, 7.0]))
+        assert (c.data["a"].min_val, c.data["a"].max_val) == (-5.0, 7.0)
+        c.collect("b", np.array([-10.0, -5.0, -2.0, -1.0]))
+        lo, hi = c.compute_range("b")
+        assert (float(lo), float(hi)) == (-10.0, 0.0)
+        c.collect("c", np.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0], [0.5, 7.0, 2.5]]))
+        assert (c.data["c"].min_val, c.data["c"].max_val) == (0.5, 7.0)
+        c.collect("d", np.array([42.0]))
+        assert (c.data["d"].min_val, c.data["d"].max_val) == (42.0, 42.0)
+        c.collect("z", np.zeros(10))
+        assert (c.data["z"].min_val, c.data["z"].max_val) == (0.0, 0.0)
+        assert len(c.data) == 5
+
+    def test_multiple_batches_no_momentum(self):
+        c = self.make(momentum=0.0)
+        for b in ([1.0, 2.0, 3.0], [-0.5, 4.0, 2.5], [1.5, 3.5, 5.5]):
+            c.collect("test", np.array(b))
+        assert (c.data["test"].min_val, c.data["test"].max_val) == (-0.5, 5.5)
+
+    def test_multiple_batches_with_momentum(self):
+        c = self.make(momentum=0.8)
+        c.collect("test", np.array([-1.0, 2.0, 3.0]))
+        assert (c.data["test"].min_val, c.data["test"].max_val) == (-1.0, 3.0)
+        c.collect("test", np.array([-0.5, 2.5, 4.0]))
+        assert np.isclose(c.data["test"].min_val, -0.9) and np.isclose(c.data["test"].max_val, 3.2)
+        lo, hi = c.compute_range("test")
+        np.testing.assert_almost_equal(lo, -0.9)
+        np.testing.assert_almost_equal(hi, 3.2)
+
+    def test_golden_sequences(self):
+        """Bit-exact running state after every batch (fp32 EMA rounding included)."""
+        M = load_npz("minmax.npz")
+        for seq in load_json("minmax.json"):
+            sid = seq["id"]
+            c = self.make(momentum=seq["momentum"])
+            for b in range(seq["batches"]):
+                c.collect("t", M[f"{sid}_b{b}"])
+                assert np.float32(c.data["t"].min_val).tobytes() == M[f"{sid}_b{b}_min"].tobytes(), (sid, b)
+                assert np.float32(c.data["t"].max_val).tobytes() == M[f"{sid}_b{b}_max"].tobytes(), (sid, b)
+            lo, hi = c.compute_range("t")
+            assert lo.tobytes() == M[f"{sid}_lo"].tobytes() and hi.tobytes() == M[f"{sid}_hi"].tobytes()
+
+    def test_device_tensors_and_large_batches(self):
+        """Activations already in HBM (the on-device driver of SURVEY.md 8f-N1), gemma3-shaped batch,
+        odd element counts and unaligned views."""
+        import torch
+        c = self.make()
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        x = torch.randn((10, 512, 640), generator=gen, device="cuda")
+        c.collect("act", x)
+        assert c.data["act"].min_val == x.min().item() and c.data["act"].max_val == x.max().item()
+        y = torch.randn(1_000_003, generator=gen, device="cuda")
+        c.collect("odd", y[1:])
+        assert c.data["odd"].min_val == y[1:].min().item() and c.data["odd"].max_val == y[1:].max().item()
+        c.collect("odd", y[:7])
+        assert c.data["odd"].min_val == min(y[1:].min().item(), y[:7].min().item())
+
+
+def test_absmax_reductions():
+    """S1: smooth_quant.py:62-74 column / row absmax."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn((6, 333, 644), generator=gen, device="cuda") * 3
+    got = ops.absmax(x)
+    assert torch.equal(got, x.reshape(-1, 644).abs().amax(dim=0))
+    w = torch.randn((515, 1030), generator=gen, device="cuda")
+    assert torch.equal(ops.absmax(w, per_row=True), w.abs().amax(dim=1))
+    assert torch.equal(ops.absmax(w[:, 1:1022]), w[:, 1:1022].abs().amax(dim=0))
+    np.testing.assert_array_equal(got.cpu().numpy(), O.absmax_cols(x.cpu().numpy()))
+
+
+# ------------------------------------------------------------------ test_gptq.py
+@pytest.mark.parametrize("group_size", [8, 16, 64, -1])
+@pytest.mark.parametrize("block_size", [32, 128, 256])
+@pytest.mark.parametrize("actorder", [True, False])
+def test_gptq_quantize_grid(A, rng, block_size, group_size, actorder):
+    w = rng.normal(0, 1, (16, 32)).astype(np.float32)
+    x = rng.normal(0, 1, (32, 16)).astype(np.float32)
+    w_q, w_scale, w_zp = A._gptq_quantize(w, x, group_size=group_size, strategy=QuantizationStrategy.TENSOR,
+                                          block_size=block_size, percdamp=0.01, actorder=actorder)
+    assert w_q.shape == w.shape and w_q.dtype == np.int8
+    assert isinstance(w_scale, np.ndarray) and w_scale.dtype == np.float32 and w_zp.dtype == np.int8
+    eq, es, ez = O.gptq_quantize(w, x, "int8", "tensor", group_size, block_size=block_size, actorder=actorder)
+    np.testing.assert_array_equal(w_q, eq)
+    np.testing.assert_array_equal(w_zp, ez)
+    np.testing.assert_allclose(w_scale, es, rtol=1e-5)
+
+
+@pytest.mark.parametrize("reduce_range", [True, False])
+@pytest.mark.parametrize("clip_ratio", [0.9, 1.0])
+def test_gptq_reduce_range_clip_ratio(A, rng, reduce_range, clip_ratio):
+    w = rng.normal(0, 1, (16, 32)).astype(np.float32)
+    x = rng.normal(0, 1, (32, 16)).astype(np.float32)
+    w_q, _, _ = A._gptq_quantize(w, x, strategy=QuantizationStrategy.TENSOR, reduce_range=reduce_range,
+                                 clip_ratio=clip_ratio)
+    lim = (-64, 64) if reduce_range else (-128, 127)
+    assert w_q.min() >= lim[0] and w_q.max() <= lim[1]
+
+
+def test_gptq_streamed_batches_and_fallback_warning(A, rng, caplog):
+    w = rng.normal(0, 1, (64, 40)).astype(np.float32)
+    x = rng.normal(0, 1, (12, 9, 64)).astype(np.float32)
+    q1, s1, z1 = A._gptq_quantize(w, x, QuantType.QInt4, QuantizationStrategy.GROUP, 32)
+    q2, s2, z2 = A._gptq_quantize(w, [x[:5], x[5:]], QuantType.QInt4, QuantizationStrategy.GROUP, 32)
+    np.testing.assert_array_equal(q1, q2)
+    assert s1.shape == (40 * 2, 1) and s1.tobytes() == s2.tobytes()
+    import logging
+    with caplog.at_level(logging.WARNING):
+        logging.getLogger("onnx_quantize_amd.algorithms.gptq").propagate = True
+        A._gptq_quantize(w, x, percdamp=-2.0)          # negative damping -> not positive definite
+    assert "Falling back to round-to-nearest" in caplog.text

@@ -1,0 +1,290 @@
+"""API parity of the configuration objects with the reference (core/_qconfig.py, _dtypes.py,
+_calibration/base.py), following the expectations of the reference's test/core/test_qconfig.py,
+test_dtypes.py and test/core/calibration/test_execution_provider.py.  CPU only: importing the package and
+building configs must never touch the GPU or the HIP library."""
+import numpy as np
+import pytest
+
+import onnx_quantize_amd as oq
+from onnx_quantize_amd import (CalibrationMethod, CalibrationParams, GPTQConfig, QActivationArgs, QConfig, QFormat,
+                               QuantizationStrategy, QuantType, QWeightArgs, RTNConfig)
+from onnx_quantize_amd.calibration import ExecutionProvider, MinMaxCalibrator, get_calibrator
+from onnx_quantize_amd.config import (AlgorithmConfig, _ALGORITHM_REGISTRY, register_algorithm_config)
+from conftest import load_json
+
+
+def test_public_names():
+    for name in ("quantize", "QConfig", "QWeightArgs", "QActivationArgs", "QuantType", "QuantizationStrategy",
+                 "QFormat", "RTNConfig", "GPTQConfig", "CalibrationMethod", "CalibrationParams", "set_log_level",
+                 "AlgorithmConfig", "PreProcessingConfig", "register_algorithm_config"):
+        assert hasattr(oq, name), name
+
+
+@pytest.mark.parametrize("qtype,sym,red,expected", load_json("scalar_kats.json")["qrange"])
+def test_quant_type_qrange(qtype, sym, red, expected):
+    assert list(QuantType.from_string(qtype).qrange(sym, red)) == expected
+
+
+def test_quant_type_misc():
+    assert QuantType.from_string(" UInt4 ") is QuantType.QUInt4
+    with pytest.raises(ValueError, match="Invalid quantization type 'int3'"):
+        QuantType.from_string("int3")
+    assert QuantType.QInt8.np_dtype == np.int8 and QuantType.QUInt8.np_dtype == np.uint8
+    assert QuantType.QInt4.bitwidth == 4 and QuantType.QInt32.bitwidth == 32
+    assert [m.name for m in QuantType] == ["QInt4", "QUInt4", "QInt8", "QUInt8", "QInt32", "QUInt32"]
+
+
+class TestQConfig:
+    def test_defaults(self):
+        c = QConfig(weights=QWeightArgs())
+        assert c.format == "qdq" and c.format == QFormat.QDQ
+        assert c.weights.dtype == QuantType.QInt8
+        assert c.weights.strategy == QuantizationStrategy.TENSOR
+        assert c.weights.symmetric is False
+        assert c.input_activations is None and c.output_activations is None
+        assert c.target_op_types == ("MatMul", "Gemm")
+        assert c.preprocessors == () and c.ignore == ()
+        assert isinstance(c.weights.algorithm, RTNConfig)
+        assert c.calibration_params.num_samples == 100 and c.calibration_params.batch_size == 10
+        assert c.calibration_params.momentum == 0.0
+        assert c.calibration_params.method == CalibrationMethod.MINMAX
+        assert c.calibration_params.provider == ExecutionProvider.CPU
+
+    def test_weights_only_variants(self):
+        assert QConfig(weights=QWeightArgs(dtype=QuantType.QInt4)).weights.dtype == QuantType.QInt4
+        c = QConfig(weights=QWeightArgs(strategy=QuantizationStrategy.GROUP, group_size=32))
+        assert c.weights.strategy == QuantizationStrategy.GROUP and c.weights.group_size == 32
+
+    def test_everything_none_is_allowed(self):
+        c = QConfig()
+        assert c.weights is None
+
+    def test_format(self):
+        with pytest.raises(ValueError, match="Invalid quantization format"):
+            QConfig(weights=QWeightArgs(), format="invalid_format")
+        assert QConfig(weights=QWeightArgs(), format="QDQ").format == QFormat.QDQ
+
+    @pytest.mark.parametrize("kw", [
+        dict(weights=QWeightArgs(dtype=QuantType.QInt4), input_activations=QActivationArgs()),
+        dict(weights=QWeightArgs(dtype="uint4"), output_activations=QActivationArgs()),
+        dict(weights=QWeightArgs(dtype="int4"), input_activations=QActivationArgs(), output_activations=QActivationArgs()),
+    ])
+    def test_four_bit_needs_weights_only(self, kw):
+        with pytest.raises(NotImplementedError, match="4-bit quantization is only supported"):
+            QConfig(**kw)
+
+    @pytest.mark.parametrize("kw", [
+        dict(input_activations=QActivationArgs()),
+        dict(output_activations=QActivationArgs()),
+        dict(input_activations=QActivationArgs(), output_activations=QActivationArgs()),
+    ])
+    def test_group_needs_weights_only(self, kw):
+        with pytest.raises(NotImplementedError, match="Group quantization is only supported"):
+            QConfig(weights=QWeightArgs(group_size=32), **kw)
+
+    def test_static_dynamic_mix(self):
+        with pytest.raises(NotImplementedError, match="Both input and output activations must be either both"):
+            QConfig(weights=QWeightArgs(), input_activations=QActivationArgs(is_static=True),
+                    output_activations=QActivationArgs(dtype="uint8", is_static=False))
+
+    def test_qlinear_rules(self):
+        with pytest.raises(ValueError, match="QLinear format requires both input and output"):
+            QConfig(weights=QWeightArgs(), format="qlinear")
+        with pytest.raises(ValueError, match="QLinear format requires both input and output"):
+            QConfig(weights=QWeightArgs(), input_activations=QActivationArgs(), format="qlinear")
+        with pytest.raises(ValueError, match="QLinear format requires both input and output activations.*static"):
+            QConfig(weights=QWeightArgs(), format="qlinear",
+                    input_activations=QActivationArgs(dtype="uint8", is_static=False),
+                    output_activations=QActivationArgs(dtype="uint8", is_static=False))
+        with pytest.raises(ValueError, match="QLinear format supports only int8/uint8 for input activations"):
+            QConfig(weights=QWeightArgs(), format="qlinear", input_activations=QActivationArgs(dtype="int32"),
+                    output_activations=QActivationArgs())
+        with pytest.raises(ValueError, match="QLinear format supports only int8/uint8 for output activations"):
+            QConfig(weights=QWeightArgs(), format="qlinear", input_activations=QActivationArgs(),
+                    output_activations=QActivationArgs(dtype="int32"))
+        ok = QConfig(weights=QWeightArgs(), format="qlinear", input_activations=QActivationArgs(),
+                     output_activations=QActivationArgs(dtype="uint8"))
+        assert ok.format == QFormat.QLINEAR
+
+    @pytest.mark.parametrize("kw", [dict(input_activations=QActivationArgs()), dict(output_activations=QActivationArgs()),
+                                    dict(input_activations=QActivationArgs(), output_activations=QActivationArgs())])
+    def test_activation_only(self, kw):
+        with pytest.raises(ValueError, match="Activation only quantization is not supported"):
+            QConfig(**kw)
+
+    def test_target_op_types(self):
+        assert QConfig(weights=QWeightArgs(), target_op_types=["MatMul", "Gemm", "MatMul"]).target_op_types == ("Gemm", "MatMul")
+        assert QConfig(weights=QWeightArgs(), target_op_types=["MatMul"]).target_op_types == ("MatMul",)
+        with pytest.raises(ValueError, match="Unsupported operator type.*Conv"):
+            QConfig(weights=QWeightArgs(), target_op_types=["MatMul", "Conv"])
+
+    @pytest.mark.parametrize("value, expected", [(["lm_head", "embed"], ("lm_head", "embed")), (("lm_head",), ("lm_head",)),
+                                                 ("lm_head", ("lm_head",)), (None, ())])
+    def test_ignore_normalisation(self, value, expected):
+        assert QConfig(weights=QWeightArgs(), ignore=value).ignore == expected
+
+    def test_extra_fields_forbidden_on_qconfig_only(self):
+        with pytest.raises(ValueError):
+            QConfig(weights=QWeightArgs(), bogus=1)
+        QWeightArgs(is_symmetric=True, scale_type="x")   # silently ignored, as in the reference
+
+    def test_roundtrip_through_model_dump(self):
+        """The reference serialises the config onto every node and re-parses it (pre_passes/__init__.py:23,
+        qrules/base.py:57): plugin subtypes must survive."""
+        c = QConfig(weights=QWeightArgs(dtype="int4", group_size=128, algorithm=GPTQConfig(actorder=True, percdamp=0.05)),
+                    calibration_params={"num_samples": 8, "batch_size": 2, "provider": "cpu"})
+        c2 = QConfig(**c.model_dump())
+        assert isinstance(c2.weights.algorithm, GPTQConfig) and c2.weights.algorithm.actorder is True
+        assert c2.weights.algorithm.percdamp == 0.05 and c2.weights.group_size == 128
+        assert c2.calibration_params.num_samples == 8
+        with pytest.raises(ValueError, match="Unknown algorithm_type"):
+            QWeightArgs(algorithm={"algorithm_type": "nope"})
+
+
+class TestQWeightArgs:
+    def test_defaults(self):
+        a = QWeightArgs()
+        assert (a.dtype, a.strategy, a.symmetric, a.clip_ratio, a.mse, a.group_size) == (
+            QuantType.QInt8, QuantizationStrategy.TENSOR, False, 1.0, False, None)
+        assert a.scale_dtype == np.dtype(np.float32) and a.zp_dtype == np.dtype(np.int8)
+        assert a.reduce_range is False
+
+    @pytest.mark.parametrize("v", [0.0, -0.5, 1.5])
+    def test_clip_ratio(self, v):
+        with pytest.raises(ValueError, match="clip_ratio must be in"):
+            QWeightArgs(clip_ratio=v)
+
+    @pytest.mark.parametrize("v", [-2, -10])
+    def test_invalid_group_size(self, v):
+        with pytest.raises(ValueError, match="Invalid group size"):
+            QWeightArgs(group_size=v)
+
+    @pytest.mark.parametrize("s", [QuantizationStrategy.TENSOR, QuantizationStrategy.CHANNEL])
+    def test_group_size_needs_group_strategy(self, s):
+        with pytest.raises(ValueError, match="group_size requires strategy to be set to 'group'"):
+            QWeightArgs(group_size=128, strategy=s)
+
+    @pytest.mark.parametrize("g", [None, 0, -1])
+    def test_group_strategy_needs_group_size(self, g):
+        with pytest.raises(ValueError, match="strategy .* requires group_size"):
+            QWeightArgs(strategy=QuantizationStrategy.GROUP, group_size=g)
+
+    def test_strategy_inference_and_strings(self):
+        assert QWeightArgs(group_size=None).strategy == QuantizationStrategy.TENSOR
+        assert QWeightArgs(group_size=-1).strategy == QuantizationStrategy.CHANNEL
+        assert QWeightArgs(group_size=32).strategy == QuantizationStrategy.GROUP
+        a = QWeightArgs(dtype="int4", strategy="channel", group_size=-1)
+        assert a.dtype == QuantType.QInt4 and a.strategy == QuantizationStrategy.CHANNEL
+        assert QWeightArgs(strategy="GROUP", group_size=32).strategy == QuantizationStrategy.GROUP
+
+    @pytest.mark.parametrize("dt", [np.float16, np.int32])
+    def test_scale_dtype(self, dt):
+        with pytest.raises(ValueError, match="Only float32 scale dtype is currently supported."):
+            QWeightArgs(scale_dtype=dt)
+        assert QWeightArgs(scale_dtype=np.float32).scale_dtype == np.dtype(np.float32)
+
+    def test_algorithms(self):
+        a = QWeightArgs(algorithm=GPTQConfig(), strategy=QuantizationStrategy.GROUP, group_size=128)
+        assert isinstance(a.algorithm, GPTQConfig) and a.algorithm.requires_calibration
+        assert (a.algorithm.block_size, a.algorithm.percdamp, a.algorithm.actorder) == (128, 0.01, False)
+        assert isinstance(QWeightArgs(algorithm=None).algorithm, RTNConfig)
+        assert not RTNConfig.requires_calibration
+        assert _ALGORITHM_REGISTRY["rtn"] is RTNConfig and _ALGORITHM_REGISTRY["gptq"] is GPTQConfig
+
+    def test_plugin_registration(self):
+        from typing import Literal
+
+        @register_algorithm_config
+        class Dummy(AlgorithmConfig):
+            algorithm_type: Literal["dummy-test"] = "dummy-test"
+
+            def validate_weight_args(self, weight_args):
+                if weight_args.dtype != QuantType.QUInt4:
+                    raise ValueError("Dummy only supports uint4 weight type")
+
+        try:
+            assert isinstance(QWeightArgs(dtype="uint4", algorithm={"algorithm_type": "dummy-test"}).algorithm, Dummy)
+            with pytest.raises(ValueError, match="Dummy only supports uint4"):
+                QWeightArgs(algorithm=Dummy())
+            with pytest.raises(NotImplementedError, match="must implement quantize_weights"):
+                Dummy().quantize_weights(None, None)
+        finally:
+            _ALGORITHM_REGISTRY.pop("dummy-test")
+
+        class NoTag(AlgorithmConfig):
+            pass
+        with pytest.raises(TypeError, match="must declare an 'algorithm_type' field"):
+            register_algorithm_config(NoTag)
+
+
+class TestQActivationArgs:
+    def test_defaults(self):
+        a = QActivationArgs()
+        assert (a.dtype, a.symmetric, a.strategy, a.is_static, a.group_size) == (
+            QuantType.QInt8, False, QuantizationStrategy.TENSOR, True, None)
+        assert QActivationArgs(dtype="uint8").dtype == QuantType.QUInt8
+
+    def test_tensor_only(self):
+        with pytest.raises(NotImplementedError, match="Activation quantization only supports"):
+            QActivationArgs(strategy=QuantizationStrategy.CHANNEL)
+        with pytest.raises(NotImplementedError, match="Activation quantization only supports"):
+            QActivationArgs(strategy=QuantizationStrategy.GROUP, group_size=128)
+
+    @pytest.mark.parametrize("qt", [QuantType.QInt4, QuantType.QUInt4])
+    def test_no_four_bit(self, qt):
+        with pytest.raises(NotImplementedError, match="4-bit quantization is not supported"):
+            QActivationArgs(dtype=qt)
+
+    @pytest.mark.parametrize("qt", [QuantType.QInt32, QuantType.QInt8])
+    def test_dynamic_needs_uint8(self, qt):
+        with pytest.raises(NotImplementedError, match="Dynamic activation quantization only supports"):
+            QActivationArgs(dtype=qt, is_static=False)
+        assert QActivationArgs(dtype=QuantType.QUInt8, is_static=False).is_static is False
+
+
+class TestCalibrationParams:
+    def test_coercions_and_checks(self):
+        p = CalibrationParams(method="minmax", provider="GPU")
+        assert p.method == CalibrationMethod.MINMAX and p.provider == ExecutionProvider.CUDA
+        assert CalibrationParams(provider="CPUExecutionProvider").provider == ExecutionProvider.CPU
+        assert CalibrationParams(provider="rocm").provider == ExecutionProvider.ROCM
+        with pytest.raises(ValueError, match="Invalid execution provider 'tpu'"):
+            CalibrationParams(provider="tpu")
+        with pytest.raises(ValueError, match="Invalid calibration method 'entropy'"):
+            CalibrationParams(method="entropy")
+        with pytest.raises(ValueError, match=r"Momentum must be in \[0, 1\)"):
+            CalibrationParams(momentum=1.0)
+        with pytest.raises(ValueError, match="num_samples must be positive"):
+            CalibrationParams(num_samples=0)
+        with pytest.raises(ValueError, match="batch_size must be positive"):
+            CalibrationParams(batch_size=-3)
+        with pytest.raises(ValueError):
+            CalibrationParams(unknown=1)
+
+    def test_calibrator_factory_without_gpu(self):
+        c = get_calibrator(CalibrationMethod.MINMAX, momentum=0.5)
+        assert isinstance(c, MinMaxCalibrator) and c.momentum == 0.5 and c.data == {}
+        with pytest.raises(TypeError, match="Invalid arguments for MinMaxCalibrator"):
+            get_calibrator(CalibrationMethod.MINMAX, bogus=1)
+        for m in (1.0, 1.5, -0.1):
+            with pytest.raises(AssertionError, match="Momentum must be in"):
+                MinMaxCalibrator(momentum=m)
+        with pytest.raises(KeyError, match="No calibration data collected for 'nonexistent'"):
+            MinMaxCalibrator().compute_range("nonexistent")
+
+
+def test_quantize_entry_point_fails_loudly_without_onnx():
+    try:
+        import onnx  # noqa: F401
+        pytest.skip("onnx is installed here")
+    except ImportError:
+        pass
+    with pytest.raises(ImportError, match="needs the `onnx`"):
+        oq.quantize(object(), QConfig(weights=QWeightArgs()))
+
+
+def test_logging_entry_point():
+    import logging
+    oq.set_log_level("debug")
+    assert logging.getLogger("onnx_quantize").level == logging.DEBUG
+    oq.set_log_level(logging.INFO)
