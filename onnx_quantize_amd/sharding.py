@@ -1,0 +1,135 @@
+"""Node-level sharding of a model's MatMul weights over the GPUs of one node.
+
+Every MatMul / Gemm weight is quantized independently of every other one (the reference's rewriter calls
+the numeric seam once per node, qrules/_common.py:126-142), so the path shards by *objects*: one process
+per GPU, each quantizes the layers a cost-balanced plan assigns to it, no data-path collective while
+quantizing, and one exchange at the end that brings (q, scale, zero point) of every layer to rank 0 --
+an RCCL gather over xGMI on a GPU node (backend "nccl"), gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+import dataclasses
+from collections.abc import Callable, Sequence
+
+import numpy as np
+
+
+@dataclasses.dataclass(frozen=True)
+class LayerSpec:
+    """One weight to quantize: [K, N] = (in, out) and, for GPTQ, the number of calibration tokens."""
+
+    name: str
+    k: int
+    n: int
+    tokens: int = 0          # 0: RTN (no Hessian)
+    hessian_key: str = ""    # layers sharing the same input share one Hessian (q/k/v, gate/up)
+
+
+def layer_cost(spec: LayerSpec, hessian_cached: bool = False) -> float:
+    """Relative cost in flop-equivalents: Hessian SYRK (T K^2), inverse factor (~K^3), loop + lazy
+    updates (K^2 N / 2 for corrected GPTQ, ~K N otherwise); RTN is byte-bound: ~K N."""
+    k, n, t = spec.k, spec.n, spec.tokens
+    if t == 0:
+        return 5.0 * k * n
+    cost = 0.5 * k * k * n + 5.0 * k * n
+    if not hessian_cached:
+        cost += float(t) * k * k + (2.0 / 3.0) * k ** 3
+    return cost
+
+
+def plan_lpt(specs: Sequence[LayerSpec], world_size: int) -> list[list[int]]:
+    """Longest-processing-time greedy plan.  Layers with the same ``hessian_key`` stay on one rank so the
+    Hessian and its factor are computed once.  Returns, per rank, the indices of its layers (ascending)."""
+    assert world_size >= 1
+    bundles: dict[str, list[int]] = {}
+    for i, s in enumerate(specs):
+        bundles.setdefault(s.hessian_key or f"__solo_{i}", []).append(i)
+    weighted = []
+    for key, idx in bundles.items():
+        c = sum(layer_cost(specs[i], hessian_cached=(j > 0)) for j, i in enumerate(idx))
+        weighted.append((c, key, idx))
+    weighted.sort(key=lambda t: (-t[0], t[1]))
+    loads = [0.0] * world_size
+    plan: list[list[int]] = [[] for _ in range(world_size)]
+    for c, _, idx in weighted:
+        r = min(range(world_size), key=lambda j: (loads[j], j))
+        loads[r] += c
+        plan[r].extend(idx)
+    return [sorted(p) for p in plan]
+
+
+def _pack(result) -> np.ndarray:
+    """(q, scale, zp) -> one contiguous byte buffer with a small header."""
+    q, s, z = (np.ascontiguousarray(a) for a in result)
+    header = np.array([q.nbytes, s.nbytes, z.nbytes], dtype=np.int64).view(np.uint8)
+    return np.concatenate([header, q.view(np.uint8).reshape(-1), s.view(np.uint8).reshape(-1), z.view(np.uint8).reshape(-1)])
+
+
+def _unpack(buf: np.ndarray, like) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    nq, ns, nz = buf[:24].view(np.int64)
+    o = 24
+    q_dtype, q_shape, s_shape, z_dtype, z_shape = like
+    q = buf[o:o + nq].view(q_dtype).reshape(q_shape); o += nq
+    s = buf[o:o + ns].view(np.float32).reshape(s_shape); o += ns
+    z = buf[o:o + nz].view(z_dtype).reshape(z_shape)
+    return q, s, z
+
+
+def quantize_sharded(specs: Sequence[LayerSpec], quantize_fn: Callable[[int, LayerSpec], tuple], *, device=None,
+                     group=None):
+    """Run ``quantize_fn(index, spec) -> (q, scale, zp)`` (NumPy arrays) for this rank's share of ``specs``
+    and gather every result on rank 0.  Returns ``{name: (q, scale, zp)}`` on rank 0, ``None`` elsewhere.
+
+    Works without an initialised process group (single process: everything is local).
+    """
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    plan = plan_lpt(specs, world)
+    mine = {i: quantize_fn(i, specs[i]) for i in plan[rank]}
+    if world == 1:
+        return {specs[i].name: mine[i] for i in sorted(mine)}
+
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                             if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    # 1) everybody learns every buffer size and result signature (tiny, object all-gather)
+    meta_local = {i: (len(_pack(r)), r[0].dtype.str, r[0].shape, r[1].shape, r[2].dtype.str, r[2].shape) for i, r in mine.items()}
+    metas = [None] * world
+    dist.all_gather_object(metas, meta_local, group=group)
+    # 2) payload: one flat byte tensor per rank, gathered on rank 0 (padded to the largest)
+    flat = np.concatenate([_pack(mine[i]) for i in plan[rank]]) if plan[rank] else np.zeros(0, np.uint8)
+    sizes = [sum(m[i][0] for i in plan[r]) for r, m in enumerate(metas)]
+    cap = max(max(sizes), 1)
+    send = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    send[: flat.size] = torch.from_numpy(flat).to(dev)
+    recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, recv, dst=0, group=group)
+    if rank != 0:
+        return None
+    out = {}
+    for r in range(world):
+        buf = recv[r].cpu().numpy()
+        o = 0
+        for i in plan[r]:
+            nbytes, qd, qs, ss, zd, zs = metas[r][i]
+            out[specs[i].name] = _unpack(buf[o:o + nbytes], (np.dtype(qd), qs, ss, np.dtype(zd), zs))
+            o += nbytes
+    return {s.name: out[s.name] for s in specs}
+
+
+def llama2_7b_specs(tokens: int = 0, layers: int = 32, hidden: int = 4096, ffn: int = 11008) -> list[LayerSpec]:
+    """MatMul weights of Llama-2-7B in [K, N] layout (BASELINE.json configs 4/5); lm_head excluded like the
+    reference's examples do."""
+    specs = []
+    for l in range(layers):
+        p = f"model.layers.{l}"
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            specs.append(LayerSpec(f"{p}.self_attn.{nm}", hidden, hidden, tokens, f"{p}.attn_in"))
+        specs.append(LayerSpec(f"{p}.self_attn.o_proj", hidden, hidden, tokens, f"{p}.attn_out"))
+        for nm in ("gate_proj", "up_proj"):
+            specs.append(LayerSpec(f"{p}.mlp.{nm}", hidden, ffn, tokens, f"{p}.mlp_in"))
+        specs.append(LayerSpec(f"{p}.mlp.down_proj", ffn, hidden, tokens, f"{p}.mlp_mid"))
+    return specs
