@@ -107,10 +107,10 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
         if (t == 0) A[j][j] = d;
         __syncthreads();
         // trailing update of the lower triangle: A[i][c] -= A[i][j] * A[c][j],  j < c <= i < n
-        const int m = n - j - 1;
-        for (int idx = t; idx < m * m; idx += blockDim.x) {
-            const int i = j + 1 + idx / m, c = j + 1 + idx % m;
-            if (c <= i) A[i][c] = A[i][c] - A[i][j] * A[c][j];
+        // 16 x 16 thread grid strides over the (i, c) pairs: no integer division in the inner loop
+        for (int i = j + 1 + (t >> 4); i < n; i += 16) {
+            const float aij = A[i][j];
+            for (int c = j + 1 + (t & 15); c <= i; c += 16) A[i][c] = A[i][c] - aij * A[c][j];
         }
     }
     __syncthreads();
@@ -121,9 +121,16 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
         const int c = t;
         M[c][c] = 1.0f / A[c][c];
         for (int i = c + 1; i < n; ++i) {
-            float s = 0.f;
-            for (int k = c; k < i; ++k) s = fmaf(A[i][k], M[k][c], s);
-            M[i][c] = -s / A[i][i];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four chains: the dot product is LDS-latency bound otherwise
+            int k = c;
+            for (; k + 3 < i; k += 4) {
+                s0 = fmaf(A[i][k], M[k][c], s0);
+                s1 = fmaf(A[i][k + 1], M[k + 1][c], s1);
+                s2 = fmaf(A[i][k + 2], M[k + 2][c], s2);
+                s3 = fmaf(A[i][k + 3], M[k + 3][c], s3);
+            }
+            for (; k < i; ++k) s0 = fmaf(A[i][k], M[k][c], s0);
+            M[i][c] = -((s0 + s1) + (s2 + s3)) / A[i][i];
         }
     }
     __syncthreads();

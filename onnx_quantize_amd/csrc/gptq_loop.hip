@@ -40,12 +40,24 @@ struct LoopArgs {
 
 __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a) {
     extern __shared__ float tile[];  // [count][kLoopCols]
+    __shared__ float coef_s[2][kLoopMaxRows];  // coefficients of the current / next row step (wave-uniform values)
+    __shared__ float diag_s[kLoopMaxRows];
     const int c_local = threadIdx.x;
     const int64_t c = static_cast<int64_t>(blockIdx.x) * kLoopCols + c_local;
     const bool live = c < a.N;
     const int64_t cc = live ? c : a.N - 1;  // clamped column for loads
+    const int count = static_cast<int>(a.count);
 
-    for (int64_t i = 0; i < a.count; ++i) tile[i * kLoopCols + c_local] = a.W[(a.i1 + i) * a.N + cc];  // W1 = copy (gptq.py:157)
+    // gptq.py:199 as written (PARITY): column `i1+i` of U below the diagonal -> U[(i1+j)*K + i1+i];
+    // CORRECTED: row `i1+i` right of the diagonal -> U[(i1+i)*K + i1+j].
+    auto coef_at = [&](int j, int i) -> float {
+        return a.mode == OQ_GPTQ_PARITY ? a.U[(a.i1 + j) * a.K + a.i1 + i] : a.U[(a.i1 + i) * a.K + a.i1 + j];
+    };
+    if (c_local < count) {
+        diag_s[c_local] = a.U[(a.i1 + c_local) * a.K + a.i1 + c_local];
+        coef_s[0][c_local] = coef_at(c_local, 0);
+    }
+    for (int i = 0; i < count; ++i) tile[i * kLoopCols + c_local] = a.W[(a.i1 + i) * a.N + cc];  // W1 = copy (gptq.py:157)
 
     float scale;
     int32_t zp;
@@ -58,9 +70,15 @@ __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a)
         zp = a.carry_zp[cc];
     }
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    __syncthreads();
 
-    for (int64_t i = 0; i < a.count; ++i) {
+    for (int i = 0; i < count; ++i) {
+        const int cur = i & 1;
         const int64_t row = a.i1 + i;
+        // next step's coefficients: issued now, consumed after this step's work (latency hidden)
+        float next_coef = 0.0f;
+        if (c_local < count && i + 1 < count) next_coef = coef_at(c_local, i + 1);
+
         if (a.g > 0 && row % a.g == 0) {
             // gptq.py:168-184: per-column parameters from rows [row, row + g) of the GLOBAL working matrix
             // (not from the block copy), channel strategy.
@@ -82,21 +100,27 @@ __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a)
         const float w = tile[i * kLoopCols + c_local];
         const int32_t qi = quantize_one(w, scale, zp, qmin, qmax);   // gptq.py:186-188
         const float q = dequantize_one(qi, scale, zp);                // :189
-        const float d = a.U[row * a.K + row];                         // :164
-        const float e = (w - q) / d;                                  // :197
+        const float e = (w - q) / diag_s[i];                          // :164, :197
         if (live) {
             a.q_int[row * a.N + c] = static_cast<uint8_t>(qi);
             a.q_deq[row * a.N + c] = q;
             a.err[i * a.N + c] = e;
         }
-        // gptq.py:198-200  W1[i:, :] -= outer(Hinv1[i:, i], err1); row i itself is never read again
-        const float* coef = a.mode == OQ_GPTQ_PARITY ? a.U + a.i1 * a.K + row   // + j * K  (column `row`)
-                                                     : a.U + row * a.K + a.i1;  // + j      (row `row`)
-        const int64_t cstride = a.mode == OQ_GPTQ_PARITY ? a.K : 1;
-        for (int64_t j = i + 1; j < a.count; ++j) {
-            const float prod = coef[j * cstride] * e;   // the K=1 matmul of the reference: one rounding
-            tile[j * kLoopCols + c_local] = tile[j * kLoopCols + c_local] - prod;
+        // gptq.py:198-200  W1[i:, :] -= outer(Hinv1[i:, i], err1); row i itself is never read again.
+        // prod is the K=1 matmul of the reference: one rounding, then the subtraction (no FMA).
+        int j = i + 1;
+        for (; j + 3 < count; j += 4) {
+            const float p0 = coef_s[cur][j] * e, p1 = coef_s[cur][j + 1] * e, p2 = coef_s[cur][j + 2] * e, p3 = coef_s[cur][j + 3] * e;
+            const float t0 = tile[j * kLoopCols + c_local], t1 = tile[(j + 1) * kLoopCols + c_local];
+            const float t2 = tile[(j + 2) * kLoopCols + c_local], t3 = tile[(j + 3) * kLoopCols + c_local];
+            tile[j * kLoopCols + c_local] = t0 - p0;
+            tile[(j + 1) * kLoopCols + c_local] = t1 - p1;
+            tile[(j + 2) * kLoopCols + c_local] = t2 - p2;
+            tile[(j + 3) * kLoopCols + c_local] = t3 - p3;
         }
+        for (; j < count; ++j) tile[j * kLoopCols + c_local] = tile[j * kLoopCols + c_local] - coef_s[cur][j] * e;
+        if (c_local < count) coef_s[cur ^ 1][c_local] = next_coef;
+        __syncthreads();
     }
     if (live) {
         a.carry_scale[c] = scale;

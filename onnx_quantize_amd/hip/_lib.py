@@ -94,6 +94,12 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `python -m onnx_quantize_amd._build` "
                 "(hipcc, gfx950).  onnx_quantize_amd has no CPU fallback.")
         try:
+            # torch ships its own libamdhip64; it has to be the HIP runtime of the process, otherwise the
+            # library's launches go to a second runtime instance that never saw torch's device context
+            # ("no ROCm-capable device is detected").  Importing torch first makes the dynamic linker
+            # resolve liboq_hip's libamdhip64 dependency to the copy torch already loaded.
+            import torch  # noqa: F401
+
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # missing ROCm runtime etc.
             raise OqHipMissing(f"cannot load {LIB_PATH}: {e}") from e
