@@ -94,8 +94,27 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
         A[r][c] = P[(o + r) * K + o + c];
     }
     __syncthreads();
+    // Left-looking (dot-product) Cholesky: column j is finished from the already final columns 0..j-1,
+    //   s_i = A[i][j] - sum_{k<j} L[i][k] * L[j][k],   L[j][j] = sqrt(s_j),   L[i][j] = s_i / L[j][j]  (i > j).
+    // One thread per row (row walks are conflict-free with the 129-float pitch, row j is a broadcast);
+    // two barriers per column and no trailing-matrix sweep.
     for (int j = 0; j < n; ++j) {
-        __syncthreads();  // trailing update of step j-1 complete
+        float s = 0.f;
+        const int i = t;
+        if (i >= j && i < n) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int k = 0;
+            for (; k + 3 < j; k += 4) {
+                s0 = fmaf(A[i][k], A[j][k], s0);
+                s1 = fmaf(A[i][k + 1], A[j][k + 1], s1);
+                s2 = fmaf(A[i][k + 2], A[j][k + 2], s2);
+                s3 = fmaf(A[i][k + 3], A[j][k + 3], s3);
+            }
+            for (; k < j; ++k) s0 = fmaf(A[i][k], A[j][k], s0);
+            s = A[i][j] - ((s0 + s1) + (s2 + s3));
+            A[i][j] = s;
+        }
+        __syncthreads();
         float ajj = A[j][j];
         if (!(ajj > 0.0f)) {  // also catches NaN: LAPACK spotrf's "leading minor not positive definite"
             if (t == 0 && *info == 0) *info = static_cast<int32_t>(o + j + 1);
@@ -103,15 +122,9 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
         }
         const float d = sqrtf(ajj);
         __syncthreads();  // everyone has read the pivot before it is overwritten
-        for (int i = j + 1 + t; i < n; i += blockDim.x) A[i][j] = A[i][j] / d;
-        if (t == 0) A[j][j] = d;
-        __syncthreads();
-        // trailing update of the lower triangle: A[i][c] -= A[i][j] * A[c][j],  j < c <= i < n
-        // 16 x 16 thread grid strides over the (i, c) pairs: no integer division in the inner loop
-        for (int i = j + 1 + (t >> 4); i < n; i += 16) {
-            const float aij = A[i][j];
-            for (int c = j + 1 + (t & 15); c <= i; c += 16) A[i][c] = A[i][c] - aij * A[c][j];
-        }
+        if (i > j && i < n) A[i][j] = s / d;
+        if (i == j) A[j][j] = d;
+        // column j is only read by later columns' dot products, which start after the next barrier
     }
     __syncthreads();
     // inverse of the lower factor, one column per thread (forward substitution)

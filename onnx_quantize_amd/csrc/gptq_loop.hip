@@ -36,6 +36,10 @@ struct LoopArgs {
     float* err;        // [count, N]
     float* carry_scale;  // [N] parameters in force at the end of the previous block (groups may span blocks)
     int32_t* carry_zp;
+    const float* pre_scale;   // mse: [groups starting in this block][N] parameters found by the MSE search, else null
+    const uint8_t* pre_zp;
+    int32_t zp_signed;
+    int64_t pre_first_group;  // index (row / g) of the first group that starts in this block
 };
 
 __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a) {
@@ -82,16 +86,22 @@ __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a)
         if (a.g > 0 && row % a.g == 0) {
             // gptq.py:168-184: per-column parameters from rows [row, row + g) of the GLOBAL working matrix
             // (not from the block copy), channel strategy.
-            const int64_t rend = row + a.g < a.K ? row + a.g : a.K;
-            float mn = INFINITY, mx = -INFINITY;
-            for (int64_t r = row; r < rend; ++r) {
-                const float x = a.W[r * a.N + cc];
-                mn = fminf(mn, x);
-                mx = fmaxf(mx, x);
+            if (a.pre_scale != nullptr) {   // mse=True: searched beforehand on the same rows (utils.py:140-239)
+                const int64_t o = (row / a.g - a.pre_first_group) * a.N + cc;
+                scale = a.pre_scale[o];
+                zp = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.pre_zp[o])) : static_cast<int32_t>(a.pre_zp[o]);
+            } else {
+                const int64_t rend = row + a.g < a.K ? row + a.g : a.K;
+                float mn = INFINITY, mx = -INFINITY;
+                for (int64_t r = row; r < rend; ++r) {
+                    const float x = a.W[r * a.N + cc];
+                    mn = fminf(mn, x);
+                    mx = fmaxf(mx, x);
+                }
+                const QParam p = qparam_from_minmax(mn, mx, a.grid);
+                scale = p.scale;
+                zp = p.zp;
             }
-            const QParam p = qparam_from_minmax(mn, mx, a.grid);
-            scale = p.scale;
-            zp = p.zp;
             if (live && a.used_scale != nullptr) {
                 a.used_scale[(row / a.g) * a.N + c] = scale;
                 a.used_zp[(row / a.g) * a.N + c] = zp;
@@ -128,6 +138,10 @@ __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a)
     }
 }
 
+int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy, int64_t group_size,
+                 int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse, void* q_out, float* scale_out, void* zp_out,
+                 int32_t layout, void* workspace, size_t workspace_bytes, void* stream, bool emit_q);
+
 }  // namespace oq
 
 extern "C" {
@@ -137,7 +151,10 @@ using namespace oq;
 size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size) {
     if (K <= 0 || N <= 0) return 0;
     (void)block_size;
-    return static_cast<size_t>(kLoopMaxRows) * N * 4 + static_cast<size_t>(N) * 8 + 512;
+    // Err [128, N] + carried (scale, zp) [N] + (mse) per-group parameters of one block [128, N] x (4 + 1) B
+    // + the MSE search's own workspace for one [group, N] slice
+    return static_cast<size_t>(kLoopMaxRows) * N * 4 + static_cast<size_t>(N) * 8 + static_cast<size_t>(kLoopMaxRows) * N * 5 +
+           oq_rtn_workspace_bytes(K, N, OQ_CHANNEL, -1, 1) + 2048;
 }
 
 int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size, int32_t symmetric,
@@ -150,7 +167,6 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
     OQ_REQUIRE(init_count == 1 || init_count == N, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: init_count must be 1 or N");
     OQ_REQUIRE(block_size > 0, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: block_size must be positive");
     OQ_REQUIRE(mode == OQ_GPTQ_PARITY || mode == OQ_GPTQ_CORRECTED, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: bad mode %d", mode);
-    OQ_REQUIRE(!mse, OQ_ERR_UNSUPPORTED, "oq_gptq_loop_f32: mse inside the GPTQ loop is not supported");
     OQ_REQUIRE(clip_ratio > 0.0f && clip_ratio <= 1.0f, OQ_ERR_INVALID_ARGUMENT, "clip_ratio must be in (0.0, 1.0], got %g", clip_ratio);
     QGrid grid;
     int32_t st = make_grid(qtype, symmetric, reduce_range, clip_ratio, &grid);
@@ -179,11 +195,32 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
     a.carry_scale = a.err + static_cast<size_t>(kLoopMaxRows) * N;
     a.carry_zp = reinterpret_cast<int32_t*>(a.carry_scale + N);
 
+    float* pre_scale = reinterpret_cast<float*>(a.carry_zp + N);
+    uint8_t* pre_zp = reinterpret_cast<uint8_t*>(pre_scale + static_cast<size_t>(kLoopMaxRows) * N);
+    char* mse_ws = reinterpret_cast<char*>(pre_zp) + static_cast<size_t>(kLoopMaxRows) * N;
+    mse_ws += (256 - reinterpret_cast<uintptr_t>(mse_ws) % 256) % 256;
+    const size_t mse_ws_bytes = static_cast<size_t>(static_cast<char*>(workspace) + workspace_bytes - mse_ws);
+    a.pre_scale = nullptr; a.pre_zp = nullptr; a.pre_first_group = 0;
+    a.zp_signed = (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0;
     const int64_t bs = block_size < kLoopMaxRows ? block_size : kLoopMaxRows;
     const uint32_t nblk = static_cast<uint32_t>(ceil_div(N, kLoopCols));
     for (int64_t i1 = 0; i1 < K; i1 += bs) {
         const int64_t count = (K - i1) < bs ? (K - i1) : bs;
         a.i1 = i1; a.count = count;
+        if (mse && a.g > 0) {
+            // gptq.py:168-184 with mse=True: the MSE search (channel strategy) on rows [r, r+g) of the working
+            // matrix for every group that starts inside this block, before the sequential kernel runs.
+            const int64_t first = (i1 + a.g - 1) / a.g;   // first group index with start row >= i1
+            int64_t slot = 0;
+            for (int64_t gi = first; gi * a.g < i1 + count; ++gi, ++slot) {
+                const int64_t r0 = gi * a.g;
+                const int64_t rows = (r0 + a.g <= K) ? a.g : K - r0;
+                st = rtn_impl(W + r0 * N, rows, N, N, qtype, OQ_CHANNEL, -1, symmetric, reduce_range, clip_ratio, 1, nullptr,
+                              pre_scale + slot * N, pre_zp + slot * N, OQ_LAYOUT_KN, mse_ws, mse_ws_bytes, stream, false);
+                if (st != OQ_OK) return st;
+            }
+            a.pre_scale = pre_scale; a.pre_zp = pre_zp; a.pre_first_group = first;
+        }
         hipLaunchKernelGGL(gptq_block_kernel, dim3(nblk), dim3(kLoopCols), static_cast<size_t>(count) * kLoopCols * 4, s, a);
         st = check_launch("gptq_block_kernel");
         if (st != OQ_OK) return st;

@@ -780,6 +780,21 @@ int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QG
                      size_t workspace_bytes, hipStream_t s, bool emit_q);
 size_t rtn_mse_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
 
+// Pass 3 of the two-pass path (also the final pass of the MSE search): elementwise K1 with stored parameters.
+int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t g, int64_t kgroups, const float* scale,
+                           const uint8_t* zp, uint8_t* q, const QGrid& grid, int32_t zp_signed, bool tensor, hipStream_t s) {
+    QuantKnArgs qa;
+    qa.W = W; qa.K = K; qa.N = N; qa.ldw = ldw; qa.g = g; qa.kgroups = kgroups;
+    qa.scale = scale; qa.zp = zp; qa.q = q;
+    qa.qmin = grid.qmin; qa.qmax = grid.qmax; qa.zp_signed = zp_signed; qa.tensor = tensor;
+    const bool vec4 = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(W) && (reinterpret_cast<uintptr_t>(q) & 3u) == 0;
+    const int64_t work = vec4 ? K * (N / 4) : K * N;
+    const uint32_t blocks = static_cast<uint32_t>(work / 256 + 1 < 256 * 16 ? work / 256 + 1 : 256 * 16);
+    if (vec4) hipLaunchKernelGGL(quantize_kn<true>, dim3(blocks), dim3(256), 0, s, qa);
+    else hipLaunchKernelGGL(quantize_kn<false>, dim3(blocks), dim3(256), 0, s, qa);
+    return check_launch("quantize_kn");
+}
+
 int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
                  int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
                  void* q_out, float* scale_out, void* zp_out, int32_t layout, void* workspace,
@@ -922,15 +937,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     }
     st = check_launch("range_finalize");
     if (st != OQ_OK || !emit_q) return st;
-    QuantKnArgs qa;
-    qa.W = W; qa.K = K; qa.N = N; qa.ldw = ldw; qa.g = g; qa.kgroups = kgroups;
-    qa.scale = scale_out; qa.zp = zp8; qa.q = q8;
-    qa.qmin = grid.qmin; qa.qmax = grid.qmax; qa.zp_signed = zp_signed; qa.tensor = strategy == OQ_TENSOR;
-    const int64_t work = vec4 ? K * (N / 4) : K * N;
-    const uint32_t blocks = static_cast<uint32_t>(work / 256 + 1 < 256 * 16 ? work / 256 + 1 : 256 * 16);
-    if (vec4) hipLaunchKernelGGL(quantize_kn<true>, dim3(blocks), dim3(256), 0, s, qa);
-    else hipLaunchKernelGGL(quantize_kn<false>, dim3(blocks), dim3(256), 0, s, qa);
-    return check_launch("quantize_kn");
+    return launch_quantize_kn(W, K, N, ldw, g, kgroups, scale_out, zp8, q8, grid, zp_signed, strategy == OQ_TENSOR, s);
 }
 
 }  // namespace oq

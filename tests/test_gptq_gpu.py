@@ -161,3 +161,21 @@ def test_gptq_layer_shaped_property(ops):
         rq, rs, rz = ops.rtn_quantize(w, qtype, strategy, g)
         assert torch.equal(q, rq) and torch.equal(z, rz)
         assert torch.allclose(s, rs, rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("strategy,group_size,qtype", [("tensor", 8, "int8"), ("group", 8, "int4"), ("channel", -1, "int8"),
+                                                       ("group", 16, "uint4"), ("tensor", 64, "int8")])
+@pytest.mark.parametrize("actorder", [False, True])
+def test_gptq_with_mse_vs_oracle(ops, strategy, group_size, qtype, actorder):
+    """mse=True inside GPTQ (test_gptq.py:20-51 grid): the initial, per-group and final parameters all come
+    from the MSE search.  pow / summation-order differences can swap near-tied candidates, so the comparison
+    allows a small fraction of rows to differ (see tests/test_mse_gpu.py); in practice they are equal."""
+    w, x = GPTQ["a_w"], GPTQ["a_x"]
+    h, _ = hessian_of(ops, x)
+    q, s, z, info = ops.gptq_quantize(dev(w), h, qtype, strategy, group_size, False, False, 1.0, 128, 0.01, actorder, True)
+    eq, es, ez = O.gptq_quantize(w, x, qtype, strategy, group_size, False, False, 1.0, 128, 0.01, actorder, True)
+    q, s, z = q.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy()
+    assert q.shape == eq.shape and s.shape == es.shape and z.shape == ez.shape
+    assert np.mean(q != eq) <= 0.05
+    np.testing.assert_allclose(s, es, rtol=0.2)          # a swapped candidate moves a scale by k/100
+    assert np.mean(np.abs(s - es) > 1e-6 * np.abs(es)) <= 0.1
