@@ -27,6 +27,7 @@ struct RtnArgs {
     uint32_t ncol_tiles, nrow_tiles;
     int32_t order;    // 0: K-direction fastest + XCD strips, 1: column tiles fastest (row-sequential DRAM stream)
     int32_t nt;       // non-temporal loads of W
+    int32_t stage_q;  // NBITS: transpose the block's packed output through LDS (64/128-byte chunks per column)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -229,6 +230,69 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
         // MatMulNBits blob (qrules/_common.py:72-87): for out-channel n, k-group kg: g*bits/8 bytes,
         // k ascending, even k in the low nibble.  This wave owns bytes [wig*RPW*bits/8, +RPW*bits/8).
         const int64_t blob = a.g * a.grid.bits / 8;
+        if constexpr (RPW == 16 && VEC4) {
+            if (a.stage_q) {
+                // The 8 waves of the block own, for every column, consecutive pieces (8 B of nibbles / 16 B of
+                // bytes each) of ONE contiguous chunk of the blob (k-groups stacked in a block are adjacent in
+                // [N, K/g, g*bits/8]).  Writing them from registers is 64 lanes x 8 B to 64 different lines per
+                // instruction (2 M tiny L2 writes per matrix); instead the chunk is assembled in LDS (XOR-swizzled
+                // slots, see below) and written with 16 B per lane, 4 or 8 lanes per column.
+                __shared__ uint4 s_out[kColsPerWave * 8];   // 256 columns x 128 B
+                uint8_t* so = reinterpret_cast<uint8_t*>(s_out);
+                const bool four = a.grid.bits == 4;
+                const int chunk = four ? 64 : 128;           // bytes per column and block
+                const int sw = lane & 7;                     // swizzle key of this lane's columns ((col/4) & 7)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cl = lane * 4 + i;
+                    if (four) {
+                        const uint32_t flip = bias ? 0x88888888u : 0u;
+                        uint32_t words[2];
+#pragma unroll
+                        for (int wd = 0; wd < 2; ++wd) {
+                            uint32_t ev = 0, od = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                ev = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 8 + 2 * j][i], j, ev);
+                                od = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 8 + 2 * j + 1][i], j, od);
+                            }
+                            words[wd] = (ev | (od << 4)) ^ flip;
+                        }
+                        *reinterpret_cast<uint2*>(so + cl * 64 + ((wave ^ sw) * 8)) = make_uint2(words[0], words[1]);
+                    } else {
+                        const uint32_t flip = bias ? 0x80808080u : 0u;
+                        uint32_t words[4];
+#pragma unroll
+                        for (int wd = 0; wd < 4; ++wd) {
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 4 + j][i], j, acc);
+                            words[wd] = acc ^ flip;
+                        }
+                        *reinterpret_cast<uint4*>(so + cl * 128 + ((wave ^ sw) * 16)) = make_uint4(words[0], words[1], words[2], words[3]);
+                    }
+                }
+                __syncthreads();
+                const int lpc = chunk / 16;                  // lanes per column chunk: 4 or 8
+                const int cpi = 64 / lpc;                    // chunks per wave-instruction
+                const int64_t kg0 = static_cast<int64_t>(row_tile) * a.gpb;
+                for (int it = 0; it < 32 / cpi; ++it) {
+                    const int cl = wave * 32 + it * cpi + lane / lpc;
+                    const int part = lane % lpc;
+                    const int64_t col = tile_col0 + cl;
+                    const int key = (cl >> 2) & 7;
+                    uint4 t;
+                    if (four) {   // 16 B = slots 2*part, 2*part+1 -> swizzled pair (part ^ (key >> 1)), halves swapped if key is odd
+                        t = *reinterpret_cast<const uint4*>(so + cl * 64 + ((part ^ (key >> 1)) * 16));
+                        if (key & 1) t = make_uint4(t.z, t.w, t.x, t.y);
+                    } else {
+                        t = *reinterpret_cast<const uint4*>(so + cl * 128 + ((part ^ key) * 16));
+                    }
+                    if (col < a.N) *reinterpret_cast<uint4*>(a.q + (col * a.kgroups + kg0) * blob + part * 16) = t;
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!col_ok[i]) continue;
@@ -865,6 +929,9 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         static const int env_nt = getenv("OQ_RTN_NT") ? atoi(getenv("OQ_RTN_NT")) : 1;
         a.order = env_order;
         a.nt = env_nt;
+        static const int env_stage_q = getenv("OQ_RTN_STAGE_Q") ? atoi(getenv("OQ_RTN_STAGE_Q")) : 1;
+        a.stage_q = (env_stage_q && layout == OQ_LAYOUT_NBITS && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves &&
+                     kgroups % a.gpb == 0) ? 1 : 0;
         const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
         static const int env_stream = getenv("OQ_RTN_STREAM") ? atoi(getenv("OQ_RTN_STREAM")) : 0;
         static const int env_blocks = getenv("OQ_RTN_BLOCKS") ? atoi(getenv("OQ_RTN_BLOCKS")) : 0;
