@@ -155,10 +155,13 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *       H *= n_seen / (n_seen + n_add);  H += (2 / (n_seen + n_add)) * X^T X      (fp32, MFMA)
  *     X [T, K] row-major (ldx), H [K, K] row-major, in/out, full symmetric matrix is maintained.
  *     n_add is the LEADING dimension of the activation before flattening (gptq.py:247), i.e. the
- *     number of samples, not T.
+ *     number of samples, not T.  workspace (optional, may be NULL): partial-sum slabs that let the T
+ *     dimension be split over more workgroups when K is small (deterministic two-stage sum).
  * ------------------------------------------------------------------------------------------- */
+size_t oq_hessian_workspace_bytes(int64_t T, int64_t K);
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen,
-                                  int64_t n_add, float* H, void* stream);
+                                  int64_t n_add, float* H, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* G3 prologue  gptq.py:118-127: dead = diag(H) == 0 -> H[d,d] = 1, W[d,:] = 0 (both in place);
  *     when actorder: perm_out = argsort(diag(H)) reversed (ties: larger index first) and W, H are

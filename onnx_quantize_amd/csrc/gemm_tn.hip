@@ -46,9 +46,26 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float (*tile)[kB
     for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = r.v[p];
 }
 
-__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, const bool vec_a, const bool vec_b) {
-    const int tile_m = blockIdx.y, tile_n = blockIdx.x;
-    if (g.upper_only && tile_n < tile_m) return;
+// Partial-slab mode (slab != null): blockIdx.y = T-slice; the raw accumulator tile is stored to
+// slab[slice][m][n] and alpha / beta / mirror are left to syrk_reduce_kernel.
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, const bool vec_a, const bool vec_b,
+                                                               float* slab, const int64_t k_per_slice, const int ntiles_n) {
+    int tile_m, tile_n;
+    if (g.upper_only) {
+        // linear id over the upper triangle, row-major: row m holds (ntiles_n - m) tiles
+        const int id = blockIdx.x;
+        int m = static_cast<int>((2.0f * ntiles_n + 1.0f - sqrtf((2.0f * ntiles_n + 1.0f) * (2.0f * ntiles_n + 1.0f) - 8.0f * id)) * 0.5f);
+        auto row_start = [&](int r) { return r * ntiles_n - r * (r - 1) / 2; };
+        while (m > 0 && row_start(m) > id) --m;
+        while (row_start(m + 1) <= id) ++m;
+        tile_m = m;
+        tile_n = m + (id - row_start(m));
+    } else {
+        tile_m = blockIdx.x / ntiles_n;
+        tile_n = blockIdx.x - tile_m * ntiles_n;
+    }
+    const int64_t k_begin = slab ? static_cast<int64_t>(blockIdx.y) * k_per_slice : 0;
+    const int64_t k_end = slab ? (k_begin + k_per_slice < g.Kd ? k_begin + k_per_slice : g.Kd) : g.Kd;
     __shared__ float sA[2][kBT][kBM];
     __shared__ float sB[2][kBT][kBN];
 
@@ -65,10 +82,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, c
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int64_t nstages = (g.Kd + kBT - 1) / kBT;
+    const int64_t nstages = (k_end - k_begin + kBT - 1) / kBT;
     StageRegs ra, rb;
-    stage_load(ra, g.At, g.lda, 0, m0, g.Kd, g.M, g.sa, vec_a);
-    if (!same) stage_load(rb, g.B, g.ldb, 0, n0, g.Kd, g.N, g.sb, vec_b);
+    stage_load(ra, g.At, g.lda, k_begin, m0, k_end, g.M, g.sa, vec_a);
+    if (!same) stage_load(rb, g.B, g.ldb, k_begin, n0, k_end, g.N, g.sb, vec_b);
     stage_store(ra, sA[0]);
     if (!same) stage_store(rb, sB[0]);
     __syncthreads();
@@ -78,8 +95,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, c
         const int buf = s & 1;
         const bool more = s + 1 < nstages;
         if (more) {
-            stage_load(ra, g.At, g.lda, (s + 1) * kBT, m0, g.Kd, g.M, g.sa, vec_a);
-            if (!same) stage_load(rb, g.B, g.ldb, (s + 1) * kBT, n0, g.Kd, g.N, g.sb, vec_b);
+            stage_load(ra, g.At, g.lda, k_begin + (s + 1) * kBT, m0, k_end, g.M, g.sa, vec_a);
+            if (!same) stage_load(rb, g.B, g.ldb, k_begin + (s + 1) * kBT, n0, k_end, g.N, g.sb, vec_b);
         }
         float (*tA)[kBM] = sA[buf];
         float (*tB)[kBN] = same ? sA[buf] : sB[buf];
@@ -102,6 +119,20 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, c
     }
 
     // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
+    if (slab != nullptr) {
+        float* out = slab + static_cast<int64_t>(blockIdx.y) * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                    const int64_t col = n0 + wn * 64 + j * 32 + cl;
+                    if (row < g.M && col < g.N) out[row * g.N + col] = acc[i][j][e];
+                }
+        return;
+    }
     const bool mirror = g.mirror && g.upper_only && tile_m != tile_n;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -125,9 +156,77 @@ int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s) {
     OQ_REQUIRE(g.lda >= g.M && g.ldb >= g.N && g.ldc >= g.N, OQ_ERR_INVALID_ARGUMENT, "gemm_tn: bad leading dimension");
     const bool vec_a = (g.lda % 4 == 0) && (reinterpret_cast<uintptr_t>(g.At) & 15u) == 0;
     const bool vec_b = (g.ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(g.B) & 15u) == 0;
-    const dim3 grid(static_cast<uint32_t>(ceil_div(g.N, kBN)), static_cast<uint32_t>(ceil_div(g.M, kBM)));
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(kGemmThreads), 0, s, g, vec_a, vec_b);
+    const int tn = static_cast<int>(ceil_div(g.N, kBN)), tm = static_cast<int>(ceil_div(g.M, kBM));
+    const uint32_t ntiles = g.upper_only ? static_cast<uint32_t>(tn) * (tn + 1) / 2 : static_cast<uint32_t>(tn) * tm;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ntiles), dim3(kGemmThreads), 0, s, g, vec_a, vec_b, static_cast<float*>(nullptr),
+                       static_cast<int64_t>(0), tn);
     return check_launch("gemm_tn_kernel");
+}
+
+// Sum the T-slices of one 64 x 64 tile in slice order, apply alpha / beta, and write C[m][n] and (for
+// off-diagonal tiles) C[n][m]; the transposed copy goes through LDS so both stores are row-contiguous.
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int splits, int64_t K, float alpha, float beta, float* C) {
+    __shared__ float t[64][65];
+    const int64_t m0 = static_cast<int64_t>(blockIdx.y) * 64, n0 = static_cast<int64_t>(blockIdx.x) * 64;
+    if (n0 / kBN < m0 / kBM) return;                            // 128-tile below the diagonal: produced by the mirror
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t row = m0 + r, col = n0 + tx;
+        float v = 0.f;
+        if (row < K && col < K) {
+            // upper 128-tiles were computed in full, so every (row, col) with col-tile >= row-tile (128 granularity) is valid;
+            // elements of a diagonal 128-tile below the diagonal are valid too (the tile is computed completely)
+            for (int z = 0; z < splits; ++z) v += slab[(static_cast<int64_t>(z) * K + row) * K + col];
+            v = alpha * v;
+            if (beta != 0.0f) v = beta * C[row * K + col] + v;
+            C[row * K + col] = v;
+        }
+        t[r][tx] = v;
+    }
+    __syncthreads();
+    if ((m0 / kBM) == (n0 / kBN)) return;                        // same 128-tile: the GEMM already produced both triangles
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t row = n0 + r, col = m0 + tx;               // transposed position
+        if (row < K && col < K) C[row * K + col] = t[tx][r];
+    }
+}
+
+size_t syrk_slab_bytes(int64_t T, int64_t K) {
+    (void)T;
+    if (K <= 0) return 0;
+    return static_cast<size_t>(16) * K * K * sizeof(float);     // up to 16 slices
+}
+
+int32_t launch_syrk_tn(const float* X, int64_t T, int64_t K, int64_t ldx, float scale_x, float alpha, float beta, float* C,
+                       void* slab, size_t slab_bytes, hipStream_t s) {
+    GemmTN g;
+    g.At = X; g.B = X; g.C = C;
+    g.M = K; g.N = K; g.Kd = T; g.lda = ldx; g.ldb = ldx; g.ldc = K;
+    g.alpha = alpha; g.beta = beta; g.sa = scale_x; g.sb = scale_x;
+    g.upper_only = 1; g.mirror = 1;
+    const int tn = static_cast<int>(ceil_div(K, kBN));
+    const int64_t tiles = static_cast<int64_t>(tn) * (tn + 1) / 2;
+    // choose the number of T-slices: enough blocks for ~8 rounds of the 512 block slots, slices of >= 256 rows
+    int splits = 1;
+    if (slab != nullptr && tiles < 8 * 512) {
+        splits = static_cast<int>((8 * 512 + tiles - 1) / tiles);
+        const int64_t max_by_t = T / 256 > 0 ? T / 256 : 1;
+        if (splits > max_by_t) splits = static_cast<int>(max_by_t);
+        if (splits > 16) splits = 16;
+        while (splits > 1 && static_cast<size_t>(splits) * K * K * sizeof(float) > slab_bytes) --splits;
+    }
+    if (splits <= 1) return launch_gemm_tn(g, s);
+    const bool vec = (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
+    int64_t per = ceil_div(T, splits);
+    per = ceil_div(per, kBT) * kBT;
+    splits = static_cast<int>(ceil_div(T, per));
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(static_cast<uint32_t>(tiles), static_cast<uint32_t>(splits)), dim3(kGemmThreads), 0, s, g, vec,
+                       vec, static_cast<float*>(slab), per, tn);
+    int32_t st = check_launch("gemm_tn_kernel(split)");
+    if (st != OQ_OK) return st;
+    const uint32_t t64 = static_cast<uint32_t>(ceil_div(K, 64));
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(t64, t64), dim3(256), 0, s, static_cast<const float*>(slab), splits, K, alpha, beta, C);
+    return check_launch("syrk_reduce_kernel");
 }
 
 }  // namespace oq
@@ -137,29 +236,20 @@ extern "C" {
 using namespace oq;
 
 // G1  gptq.py:246-260.
+size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) { return syrk_slab_bytes(T, K) + 256; }
+
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen, int64_t n_add, float* H,
-                                  void* stream) {
+                                  void* workspace, size_t workspace_bytes, void* stream) {
     OQ_REQUIRE(X && H && T > 0 && K > 0 && ldx >= K, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: bad argument");
     OQ_REQUIRE(n_seen >= 0 && n_add > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: bad sample counts %lld + %lld",
                (long long)n_seen, (long long)n_add);
     const int64_t n_total = n_seen + n_add;
-    GemmTN g;
-    g.At = X; g.B = X; g.C = H;
-    g.M = K; g.N = K; g.Kd = T; g.lda = ldx; g.ldb = ldx; g.ldc = K;
-    g.alpha = 1.0f;
-    // gptq.py:254  H *= num_samples / (num_samples + num_added): a Python float applied to an fp32 array
-    g.beta = static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));
+    // gptq.py:254  H *= num_samples / (num_samples + num_added): a Python float applied to an fp32 array.
+    // The first call of the reference starts from zeros (gptq.py:304): beta = 0, nothing is read.
+    const float beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));
     // gptq.py:257  inp = math.sqrt(2 / num_samples) * inp  (double evaluated, weak scalar -> fp32 multiply)
     const float sx = static_cast<float>(std::sqrt(2.0 / static_cast<double>(n_total)));
-    g.sa = sx; g.sb = sx;
-    g.upper_only = 1;
-    g.mirror = 1;
-    if (n_seen == 0) {
-        // beta == 0 but H must still be defined for the kernel's "beta != 0" shortcut: the first call of the
-        // reference starts from zeros (gptq.py:304), so nothing is read.
-        g.beta = 0.0f;
-    }
-    return launch_gemm_tn(g, as_stream(stream));
+    return launch_syrk_tn(X, T, K, ldx, sx, 1.0f, beta, H, workspace, workspace_bytes, as_stream(stream));
 }
 
 }  // extern "C"

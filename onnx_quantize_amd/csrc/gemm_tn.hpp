@@ -30,4 +30,13 @@ struct GemmTN {
 
 int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s);
 
+// Symmetric rank-k update C = beta*C + alpha*(s*X)^T (s*X) for tall X [T, K] (the GPTQ Hessian).  When the
+// upper-triangular tile count cannot fill the chip (K = 4096: 528 tiles for 512 block slots -> a 2-round
+// tail), the T dimension is split into `splits` slices whose partial tiles go to `slab`
+// ([splits][K][K] fp32) and a second kernel sums them in a fixed order (deterministic), applies beta and
+// writes both triangles with coalesced stores.  slab may be null (splits forced to 1).
+size_t syrk_slab_bytes(int64_t T, int64_t K);
+int32_t launch_syrk_tn(const float* X, int64_t T, int64_t K, int64_t ldx, float scale_x, float alpha, float beta, float* C,
+                       void* slab, size_t slab_bytes, hipStream_t s);
+
 }  // namespace oq

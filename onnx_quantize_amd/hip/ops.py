@@ -270,7 +270,9 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
     t, k = x2.shape
     if h.shape != (k, k) or not h.is_contiguous():
         raise ValueError(f"H must be a contiguous [{k}, {k}] tensor")
-    L.check(L.load().oq_hessian_accumulate_f32(_ptr(x2), t, k, ldx, int(n_seen), n_add, _ptr(h), _stream()))
+    lib = L.load()
+    ws = _workspace(lib.oq_hessian_workspace_bytes(t, k) if k <= 8192 else 256, x.device)
+    L.check(lib.oq_hessian_accumulate_f32(_ptr(x2), t, k, ldx, int(n_seen), n_add, _ptr(h), _ptr(ws), ws.numel(), _stream()))
     return int(n_seen) + n_add
 
 
