@@ -11,49 +11,65 @@ constexpr int kBM = 128, kBN = 128, kBT = 32;  // block tile and k-rows per LDS 
 constexpr int kGemmThreads = 256;              // 4 waves, 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
 
 // One stage of one operand: kBT rows x 128 floats = 1024 float4, 4 per thread.
+// Loads are UNCONDITIONAL (clamped coordinates) and their results are not touched until stage_store: a
+// predicated or immediately-consumed load puts exec branches and vmcnt(0) waits in front of the MFMA loop
+// (cdna_hip_programming.md section 5, trap (c)) and the whole global latency is exposed every stage.
 struct StageRegs {
     float4 v[4];
+    uint32_t ok;   // 4 bits per load: which of the 4 floats are inside the matrix
 };
 
+template <bool VEC>
 __device__ __forceinline__ void stage_load(StageRegs& r, const float* __restrict__ P, int64_t ld, int64_t k0, int64_t c0,
-                                           int64_t Kd, int64_t cols, float scale, bool vec_ok) {
+                                           int64_t Kd, int64_t cols) {
     const int t = threadIdx.x;
-    const int c4 = (t & 31) * 4;
+    const int64_t c = c0 + (t & 31) * 4;
+    uint32_t ok = 0;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int64_t k = k0 + (t >> 5) + p * 8;
-        const int64_t c = c0 + c4;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < Kd) {
-            const float* src = P + k * ld + c;
-            if (vec_ok && c + 3 < cols) {
-                x = *reinterpret_cast<const float4*>(src);
-            } else {
-                if (c < cols) x.x = src[0];
-                if (c + 1 < cols) x.y = src[1];
-                if (c + 2 < cols) x.z = src[2];
-                if (c + 3 < cols) x.w = src[3];
-            }
+        const int64_t kc = k < Kd ? k : Kd - 1;
+        if constexpr (VEC) {   // cols % 4 == 0, ld % 4 == 0, 16-byte aligned base
+            const int64_t cc = c < cols ? c : cols - 4;
+            r.v[p] = *reinterpret_cast<const float4*>(P + kc * ld + cc);
+            if (k < Kd && c < cols) ok |= 0xfu << (4 * p);
+        } else {
+            const float* row = P + kc * ld;
+            const int64_t last = cols - 1;
+            r.v[p].x = row[c < cols ? c : last];
+            r.v[p].y = row[c + 1 < cols ? c + 1 : last];
+            r.v[p].z = row[c + 2 < cols ? c + 2 : last];
+            r.v[p].w = row[c + 3 < cols ? c + 3 : last];
+            if (k < Kd) ok |= ((c < cols ? 1u : 0u) | (c + 1 < cols ? 2u : 0u) | (c + 2 < cols ? 4u : 0u) | (c + 3 < cols ? 8u : 0u)) << (4 * p);
         }
-        if (scale != 1.0f) { x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale; }
-        r.v[p] = x;
     }
+    r.ok = ok;
 }
 
-__device__ __forceinline__ void stage_store(const StageRegs& r, float (*tile)[kBM]) {
+// Zero-fill of the out-of-range elements and the operand pre-scale happen on the way into LDS, i.e. after the
+// compute loop of the previous stage: the global loads have the whole stage (>= 4096 MFMA cycles) to land.
+__device__ __forceinline__ void stage_store(const StageRegs& r, float (*tile)[kBM], float scale) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = r.v[p];
+    for (int p = 0; p < 4; ++p) {
+        float4 x = r.v[p];
+        const uint32_t m = r.ok >> (4 * p);
+        x.x = (m & 1u) ? x.x : 0.f; x.y = (m & 2u) ? x.y : 0.f; x.z = (m & 4u) ? x.z : 0.f; x.w = (m & 8u) ? x.w : 0.f;
+        if (scale != 1.0f) { x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale; }
+        *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = x;
+    }
 }
 
 // Partial-slab mode (slab != null): blockIdx.y = T-slice; the raw accumulator tile is stored to
 // slab[slice][m][n] and alpha / beta / mirror are left to syrk_reduce_kernel.
-__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, const bool vec_a, const bool vec_b,
-                                                               float* slab, const int64_t k_per_slice, const int ntiles_n) {
+template <bool VA, bool VB>
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, float* slab, const int64_t k_per_slice, const int ntiles_n) {
     int tile_m, tile_n;
     if (g.upper_only) {
         // linear id over the upper triangle, row-major: row m holds (ntiles_n - m) tiles
-        const int id = blockIdx.x;
+        // XCD-contiguous ids: the 64 tiles resident on one XCD are neighbours of one tile row, walk T in step
+        // and share the A-panel stages through that XCD's L2 (speed only; see oq_common.hpp::xcd_remap)
+        const int id = static_cast<int>(xcd_remap(blockIdx.x, gridDim.x));
         int m = static_cast<int>((2.0f * ntiles_n + 1.0f - sqrtf((2.0f * ntiles_n + 1.0f) * (2.0f * ntiles_n + 1.0f) - 8.0f * id)) * 0.5f);
         auto row_start = [&](int r) { return r * ntiles_n - r * (r - 1) / 2; };
         while (m > 0 && row_start(m) > id) --m;
@@ -84,10 +100,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, c
 
     const int64_t nstages = (k_end - k_begin + kBT - 1) / kBT;
     StageRegs ra, rb;
-    stage_load(ra, g.At, g.lda, k_begin, m0, k_end, g.M, g.sa, vec_a);
-    if (!same) stage_load(rb, g.B, g.ldb, k_begin, n0, k_end, g.N, g.sb, vec_b);
-    stage_store(ra, sA[0]);
-    if (!same) stage_store(rb, sB[0]);
+    stage_load<VA>(ra, g.At, g.lda, k_begin, m0, k_end, g.M);
+    if (!same) stage_load<VB>(rb, g.B, g.ldb, k_begin, n0, k_end, g.N);
+    stage_store(ra, sA[0], g.sa);
+    if (!same) stage_store(rb, sB[0], g.sb);
     __syncthreads();
 
     const int kl = lane >> 5, cl = lane & 31;
@@ -95,25 +111,43 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, c
         const int buf = s & 1;
         const bool more = s + 1 < nstages;
         if (more) {
-            stage_load(ra, g.At, g.lda, k_begin + (s + 1) * kBT, m0, k_end, g.M, g.sa, vec_a);
-            if (!same) stage_load(rb, g.B, g.ldb, k_begin + (s + 1) * kBT, n0, k_end, g.N, g.sb, vec_b);
+            stage_load<VA>(ra, g.At, g.lda, k_begin + (s + 1) * kBT, m0, k_end, g.M);
+            if (!same) stage_load<VB>(rb, g.B, g.ldb, k_begin + (s + 1) * kBT, n0, k_end, g.N);
         }
         float (*tA)[kBM] = sA[buf];
         float (*tB)[kBN] = same ? sA[buf] : sB[buf];
+        // Two operand sets in flight: the set consumed by k-pair kk is refilled (for kk+4) right after its four
+        // MFMAs have issued, so every ds_read has two MFMA groups (~512 cycles) to land.  hipcc otherwise emits
+        // "read, lgkmcnt(0), 4 x mfma" with the read latency exposed on every k-pair.
+        auto rd = [&](int k, float& x0, float& x1, float& y0, float& y1) {
+            x0 = tA[k + kl][wm * 64 + cl];
+            x1 = tA[k + kl][wm * 64 + 32 + cl];
+            y0 = tB[k + kl][wn * 64 + cl];
+            y1 = tB[k + kl][wn * 64 + 32 + cl];
+        };
+        auto mm = [&](float x0, float x1, float y0, float y1) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+        };
+        float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+        rd(0, pa0, pa1, pb0, pb1);
+        rd(2, qa0, qa1, qb0, qb1);
 #pragma unroll
-        for (int kk = 0; kk < kBT; kk += 2) {
-            const float a0 = tA[kk + kl][wm * 64 + cl];
-            const float a1 = tA[kk + kl][wm * 64 + 32 + cl];
-            const float b0 = tB[kk + kl][wn * 64 + cl];
-            const float b1 = tB[kk + kl][wn * 64 + 32 + cl];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kk = 0; kk < kBT; kk += 4) {
+            mm(pa0, pa1, pb0, pb1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (kk + 4 < kBT) rd(kk + 4, pa0, pa1, pb0, pb1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            mm(qa0, qa1, qb0, qb1);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (kk + 6 < kBT) rd(kk + 6, qa0, qa1, qb0, qb1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         if (more) {
-            stage_store(ra, sA[buf ^ 1]);
-            if (!same) stage_store(rb, sB[buf ^ 1]);
+            stage_store(ra, sA[buf ^ 1], g.sa);
+            if (!same) stage_store(rb, sB[buf ^ 1], g.sb);
         }
         __syncthreads();
     }
@@ -151,15 +185,21 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, c
             }
 }
 
+static void launch_variant(bool va, bool vb, dim3 grid, hipStream_t s, const GemmTN& g, float* slab, int64_t per, int tn) {
+    if (va && vb) hipLaunchKernelGGL((gemm_tn_kernel<true, true>), grid, dim3(kGemmThreads), 0, s, g, slab, per, tn);
+    else if (va) hipLaunchKernelGGL((gemm_tn_kernel<true, false>), grid, dim3(kGemmThreads), 0, s, g, slab, per, tn);
+    else if (vb) hipLaunchKernelGGL((gemm_tn_kernel<false, true>), grid, dim3(kGemmThreads), 0, s, g, slab, per, tn);
+    else hipLaunchKernelGGL((gemm_tn_kernel<false, false>), grid, dim3(kGemmThreads), 0, s, g, slab, per, tn);
+}
+
 int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s) {
     OQ_REQUIRE(g.At && g.B && g.C && g.M > 0 && g.N > 0 && g.Kd >= 0, OQ_ERR_INVALID_ARGUMENT, "gemm_tn: bad argument");
     OQ_REQUIRE(g.lda >= g.M && g.ldb >= g.N && g.ldc >= g.N, OQ_ERR_INVALID_ARGUMENT, "gemm_tn: bad leading dimension");
-    const bool vec_a = (g.lda % 4 == 0) && (reinterpret_cast<uintptr_t>(g.At) & 15u) == 0;
-    const bool vec_b = (g.ldb % 4 == 0) && (reinterpret_cast<uintptr_t>(g.B) & 15u) == 0;
+    const bool vec_a = (g.lda % 4 == 0) && (g.M % 4 == 0) && (reinterpret_cast<uintptr_t>(g.At) & 15u) == 0;
+    const bool vec_b = (g.ldb % 4 == 0) && (g.N % 4 == 0) && (reinterpret_cast<uintptr_t>(g.B) & 15u) == 0;
     const int tn = static_cast<int>(ceil_div(g.N, kBN)), tm = static_cast<int>(ceil_div(g.M, kBM));
     const uint32_t ntiles = g.upper_only ? static_cast<uint32_t>(tn) * (tn + 1) / 2 : static_cast<uint32_t>(tn) * tm;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(ntiles), dim3(kGemmThreads), 0, s, g, vec_a, vec_b, static_cast<float*>(nullptr),
-                       static_cast<int64_t>(0), tn);
+    launch_variant(vec_a, vec_b, dim3(ntiles), s, g, nullptr, 0, tn);
     return check_launch("gemm_tn_kernel");
 }
 
@@ -216,12 +256,11 @@ int32_t launch_syrk_tn(const float* X, int64_t T, int64_t K, int64_t ldx, float 
         while (splits > 1 && static_cast<size_t>(splits) * K * K * sizeof(float) > slab_bytes) --splits;
     }
     if (splits <= 1) return launch_gemm_tn(g, s);
-    const bool vec = (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
+    const bool vec = (ldx % 4 == 0) && (K % 4 == 0) && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
     int64_t per = ceil_div(T, splits);
     per = ceil_div(per, kBT) * kBT;
     splits = static_cast<int>(ceil_div(T, per));
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(static_cast<uint32_t>(tiles), static_cast<uint32_t>(splits)), dim3(kGemmThreads), 0, s, g, vec,
-                       vec, static_cast<float*>(slab), per, tn);
+    launch_variant(vec, vec, dim3(static_cast<uint32_t>(tiles), static_cast<uint32_t>(splits)), s, g, static_cast<float*>(slab), per, tn);
     int32_t st = check_launch("gemm_tn_kernel(split)");
     if (st != OQ_OK) return st;
     const uint32_t t64 = static_cast<uint32_t>(ceil_div(K, 64));
