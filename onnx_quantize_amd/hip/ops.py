@@ -331,9 +331,24 @@ def gptq_loop(w: torch.Tensor, u: torch.Tensor, qtype: str, group_size, symmetri
     return q_int, q_deq, used_s, used_z
 
 
+def gptq_shared_factor(h: torch.Tensor, percdamp: float, actorder: bool):
+    """Everything of `_gptq` that depends on H only (gptq.py:118-150): the dead-channel mask, the optional
+    actorder permutation and the inverse factor.  The reference recomputes this for every node; nodes that
+    share an input (q/k/v, gate/up) share H, so one factor serves them all -- pass the result to
+    ``gptq_quantize(..., shared=...)``."""
+    _require_device(h, "H", torch.float32)
+    k = h.shape[0]
+    h1 = h.contiguous().clone()
+    dummy = torch.zeros((k, 4), dtype=torch.float32, device=h.device)
+    perm = gptq_prepare(dummy, h1, actorder)
+    u, info = gptq_factor(h1, percdamp)
+    dead = torch.diagonal(h) == 0
+    return {"u": u, "info": info, "perm": perm, "dead": dead}
+
+
 def gptq_quantize(w: torch.Tensor, h: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
                   reduce_range=False, clip_ratio=1.0, block_size=128, percdamp=0.01, actorder=False, mse=False,
-                  mode: str = "parity"):
+                  mode: str = "parity", shared=None):
     """gptq.py:76-243 (`_gptq`) on device tensors: ``w`` [K, N] weights, ``h`` [K, K] accumulated Hessian.
     Neither input is modified.  Returns (q_int, scale, zp, info) with the reference's output shapes."""
     if mode not in ("parity", "corrected"):
@@ -343,11 +358,17 @@ def gptq_quantize(w: torch.Tensor, h: torch.Tensor, qtype: str, strategy: str, g
     k, n = w.shape
     used = "channel" if strategy == "group" else strategy                      # gptq.py:92-96
     w1 = w.contiguous().clone()                                                  # :99-100
-    h1 = h.contiguous().clone()
+    h1 = h.contiguous().clone() if shared is None else None
     # :104-116 initial parameters: per out-channel over all of K (or global)
     _, s0, z0 = rtn_quantize(w1, qtype, used, -1, symmetric, reduce_range, clip_ratio, mse, emit_q=False)
-    perm = gptq_prepare(w1, h1, actorder)                                        # :118-127
-    u, info = gptq_factor(h1, percdamp)                                          # :134-150
+    if shared is None:
+        perm = gptq_prepare(w1, h1, actorder)                                    # :118-127
+        u, info = gptq_factor(h1, percdamp)                                      # :134-150
+    else:   # H-only work done once for all layers with this input
+        u, info, perm = shared["u"], shared["info"], shared["perm"]
+        w1[shared["dead"], :] = 0                                                # :121
+        if perm is not None:
+            w1 = w1.index_select(0, perm.to(torch.int64)).contiguous()          # :126
     loop_g = group_size if (group_size and group_size != -1) else 0
     corrected_own = mode == "corrected" and not actorder
     q_int, q_deq, us, uz = gptq_loop(w1, u, qtype, loop_g, symmetric, reduce_range, clip_ratio, mse, block_size,

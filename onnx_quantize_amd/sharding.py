@@ -133,3 +133,51 @@ def llama2_7b_specs(tokens: int = 0, layers: int = 32, hidden: int = 4096, ffn: 
             specs.append(LayerSpec(f"{p}.mlp.{nm}", hidden, ffn, tokens, f"{p}.mlp_in"))
         specs.append(LayerSpec(f"{p}.mlp.down_proj", ffn, hidden, tokens, f"{p}.mlp_mid"))
     return specs
+
+
+def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], mine: dict, *, group=None):
+    """End-of-run exchange for results that live in HBM: ``mine[i] = (q, scale, zp)`` torch tensors on this
+    rank's GPU.  Each rank flattens its results into ONE byte tensor, sizes are exchanged with a tiny
+    all_gather, and a single padded ``gather`` (RCCL over xGMI with backend nccl) brings everything to rank 0.
+    Returns ``({name: (q, scale, zp)} on rank 0 | None, bytes_gathered)``."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    if world == 1:
+        return {specs[i].name: mine[i] for i in sorted(mine)}, 0
+    order = plan[rank]
+    parts, meta = [], []
+    for i in order:
+        q, s, z = mine[i]
+        for t in (q, s, z):
+            parts.append(t.contiguous().view(-1).view(torch.uint8))
+        meta.append((i, str(q.dtype), tuple(q.shape), tuple(s.shape), str(z.dtype), tuple(z.shape),
+                     q.numel() * q.element_size(), s.numel() * 4, z.numel() * z.element_size()))
+    dev = parts[0].device if parts else torch.device("cuda", torch.cuda.current_device())
+    flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = flat.numel()
+    dist.all_reduce(sizes, group=group)
+    cap = int(sizes.max().item())
+    send = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+    send[: flat.numel()] = flat
+    recv = [torch.empty(max(cap, 1), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    metas = [None] * world
+    dist.all_gather_object(metas, meta, group=group)
+    dist.gather(send, recv, dst=0, group=group)
+    total = int(sizes.sum().item())
+    if rank != 0:
+        return None, total
+    out = {}
+    for r in range(world):
+        o = 0
+        for (i, qd, qs, ss, zd, zs, nq, ns, nz) in metas[r]:
+            buf = recv[r]
+            q = buf[o:o + nq].view(getattr(torch, qd.split(".")[-1])).reshape(qs); o += nq
+            s = buf[o:o + ns].view(torch.float32).reshape(ss); o += ns
+            z = buf[o:o + nz].view(getattr(torch, zd.split(".")[-1])).reshape(zs); o += nz
+            out[specs[i].name] = (q, s, z)
+    return {s.name: out[s.name] for s in specs}, total

@@ -179,3 +179,28 @@ def test_gptq_with_mse_vs_oracle(ops, strategy, group_size, qtype, actorder):
     assert np.mean(q != eq) <= 0.05
     np.testing.assert_allclose(s, es, rtol=0.2)          # a swapped candidate moves a scale by k/100
     assert np.mean(np.abs(s - es) > 1e-6 * np.abs(es)) <= 0.1
+
+
+@pytest.mark.parametrize("actorder", [False, True])
+def test_shared_factor_equals_per_layer_factor(ops, actorder):
+    """q/k/v (and gate/up) share their input: one Hessian + one inverse factor must give exactly the results of
+    the reference's per-node recomputation."""
+    import torch
+    w, x = GPTQ["b_w"], GPTQ["b_x"]
+    h, _ = hessian_of(ops, x)
+    shared = ops.gptq_shared_factor(h, 0.01, actorder)
+    for seed in (0, 1):
+        wi = dev(w + np.random.default_rng(seed).standard_normal(w.shape).astype(np.float32) * 0.01)
+        a = ops.gptq_quantize(wi, h, "int4", "group", 128, actorder=actorder)
+        b = ops.gptq_quantize(wi, h, "int4", "group", 128, actorder=actorder, shared=shared)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+def test_device_gather_single_process(ops):
+    import torch
+    from onnx_quantize_amd.sharding import LayerSpec, gather_device_results, plan_lpt
+    specs = [LayerSpec("a", 64, 32), LayerSpec("b", 128, 16)]
+    plan = plan_lpt(specs, 1)
+    mine = {i: ops.rtn_quantize(torch.randn((s.k, s.n), device="cuda"), "uint4", "group", 32) for i, s in enumerate(specs)}
+    out, nbytes = gather_device_results(specs, plan, mine)
+    assert list(out) == ["a", "b"] and nbytes == 0 and out["b"][0].shape == (128, 16)
