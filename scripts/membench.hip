@@ -87,10 +87,19 @@ __global__ __launch_bounds__(256) void copy_linear(const float4* x, float4* y, s
     }
     for (; i < n4; i += stride) y[i] = x[i];
 }
+// NOTE: rounds 1's first version of this kernel had no remainder loop and silently skipped up to 26 % of the
+// elements (its "33 us" was for 74 % of the work); the remainder loop below makes it complete.
 template <int UNROLL>
 __global__ __launch_bounds__(256) void read4_write1(const float4* x, uint32_t* y, size_t n4) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t j = i + (n4 / (UNROLL * stride)) * (UNROLL * stride); j < n4; j += stride) {
+        const float4 t = x[j];
+        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(t.x, 0, 0);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t.y, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t.z, 2, w);
+        y[j] = __builtin_amdgcn_cvt_pk_u8_f32(t.w, 3, w);
+    }
     for (; i + (UNROLL - 1) * stride < n4; i += UNROLL * stride) {
         float4 t[UNROLL];
 #pragma unroll
@@ -347,6 +356,105 @@ __global__ __launch_bounds__(WAVES * 64) void linear_oneshot(const float4* x, ui
     }
 }
 
+// N: one-shot tile kernel, 128 rows x 256 cols per block, WAVES waves x RPW rows (WAVES*RPW = 128), byte stores
+template <int WAVES, int RPW, bool NTS>
+__global__ __launch_bounds__(WAVES * 64) void tile_rw_shape(const float* W, int ncol_tiles, unsigned char* q) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row_tile = blockIdx.x / ncol_tiles, col_tile = blockIdx.x % ncol_tiles;
+    const size_t row0 = (size_t)row_tile * 128 + wave * RPW;
+    const size_t col0 = (size_t)col_tile * 256 + lane * 4;
+    const float* p = W + row0 * N + col0;
+    float4 t[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) t[r] = *reinterpret_cast<const float4*>(p + (size_t)r * N);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        uint32_t x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].x, 0, 0);
+        x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].y, 1, x);
+        x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].z, 2, x);
+        x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].w, 3, x);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(q + (row0 + r) * N + col0);
+        if (NTS) __builtin_nontemporal_store(x, dst); else *dst = x;
+    }
+}
+
+// P: looping tile kernel WITHOUT the rolling reload: per unit 16 loads, then 16 x (cvt + store), like E<16> but
+// with tile addresses (TILE=1) or linear addresses (TILE=0); 4 waves per block, grid-stride over units.
+template <int TILE, bool NTS>
+__global__ __launch_bounds__(256) void loop_units(const float* W, int ncol_tiles, int nunits, unsigned char* q) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int u = blockIdx.x; u < nunits; u += gridDim.x) {
+        size_t roff, woff, rstride, wstride;
+        if (TILE) {
+            const int row_tile = u / ncol_tiles, col_tile = u % ncol_tiles;     // unit = 64 rows x 256 cols
+            const size_t row0 = (size_t)row_tile * 64 + wave * 16, col0 = (size_t)col_tile * 256 + lane * 4;
+            roff = row0 * N + col0; woff = roff; rstride = N; wstride = N;
+        } else {
+            roff = ((size_t)u * 4 + wave) * 4096 + lane * 4; woff = roff; rstride = 256; wstride = 256;
+        }
+        float4 t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = *reinterpret_cast<const float4*>(W + roff + r * rstride);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            uint32_t x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].x, 0, 0);
+            x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].y, 1, x);
+            x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].z, 2, x);
+            x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].w, 3, x);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(q + woff + r * wstride);
+            if (NTS) __builtin_nontemporal_store(x, dst); else *dst = x;
+        }
+    }
+}
+
+// Q: one-shot tile kernel with a different wave -> sub-tile map: the 8 waves of a block take CW adjacent
+// column tiles x (8/CW) row slices of 16 rows (CW=1: the fused-kernel geometry, CW=8: 16 rows x 2048 columns)
+template <int CW, bool NTS>
+__global__ __launch_bounds__(512) void tile_rw_map(const float* W, unsigned char* q) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RS = 8 / CW;                       // row slices per block
+    const int tiles_x = N / (256 * CW);              // 43 / CW must be handled: N=11008 -> 43 tiles; use ceil + guard
+    const int bx = blockIdx.x % ((43 + CW - 1) / CW), by = blockIdx.x / ((43 + CW - 1) / CW);
+    (void)tiles_x;
+    const int col_tile = bx * CW + (wave % CW);
+    if (col_tile >= 43) return;
+    const size_t row0 = (size_t)by * (16 * RS) + (wave / CW) * 16;
+    const size_t col0 = (size_t)col_tile * 256 + lane * 4;
+    const float* p = W + row0 * N + col0;
+    float4 t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = *reinterpret_cast<const float4*>(p + (size_t)r * N);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        uint32_t x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].x, 0, 0);
+        x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].y, 1, x);
+        x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].z, 2, x);
+        x = __builtin_amdgcn_cvt_pk_u8_f32(t[r].w, 3, x);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(q + (row0 + r) * N + col0);
+        if (NTS) __builtin_nontemporal_store(x, dst); else *dst = x;
+    }
+}
+
+// R: one-shot, but with E's address map: adjacent waves take adjacent KiB, the U loads of one wave are
+// (total waves) KiB apart.  Separates "looping" from "who touches neighbouring addresses when".
+template <int U, int WAVES, bool NTS>
+__global__ __launch_bounds__(WAVES * 64) void oneshot_interleaved(const float4* x, uint32_t* y, size_t n4) {
+    const size_t lane = threadIdx.x & 63, g = (size_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const size_t wv = n4 / (64 * U);
+    float4 t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) t[u] = x[((size_t)u * wv + g) * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(t[u].x, 0, 0);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t[u].y, 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t[u].z, 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(t[u].w, 3, w);
+        uint32_t* dst = &y[((size_t)u * wv + g) * 64 + lane];
+        if (NTS) __builtin_nontemporal_store(w, dst); else *dst = w;
+    }
+}
+
 int main(int argc, char** argv) {
     const bool rnd = argc > 1 && atoi(argv[1]) == 1;
     printf("data = %s\n", rnd ? "random" : "constant");
@@ -401,6 +509,31 @@ int main(int argc, char** argv) {
     timeit("I order2 (K fastest, XCD chunks) nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_order<2, true>), dim3(nct * 32), dim3(512), 0, 0, in[b], nct, 32, (unsigned char*)outb[b]); });
     timeit("J tile kernel, block-linear output (wrong layout)", bytes * 1.25, [&](int b) { hipLaunchKernelGGL(tile_rw_linear<1>, dim3(nct * 32), dim3(512), 0, 0, in[b], nct, (unsigned char*)outb[b]); });
     timeit("J tile kernel, real layout (control)", bytes * 1.25, [&](int b) { hipLaunchKernelGGL(tile_rw_linear<2>, dim3(nct * 32), dim3(512), 0, 0, in[b], nct, (unsigned char*)outb[b]); });
+    timeit("N tile 8 waves x 16 rows, nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_shape<8, 16, true>), dim3(nct * 32), dim3(512), 0, 0, in[b], nct, (unsigned char*)outb[b]); });
+    timeit("N tile 16 waves x 8 rows, nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_shape<16, 8, true>), dim3(nct * 32), dim3(1024), 0, 0, in[b], nct, (unsigned char*)outb[b]); });
+    timeit("N tile 16 waves x 8 rows", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_shape<16, 8, false>), dim3(nct * 32), dim3(1024), 0, 0, in[b], nct, (unsigned char*)outb[b]); });
+    timeit("N tile 4 waves x 32 rows, nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_shape<4, 32, true>), dim3(nct * 32), dim3(256), 0, 0, in[b], nct, (unsigned char*)outb[b]); });
+    for (int nblk : {1024, 2048}) {
+        char nm[128];
+        snprintf(nm, 128, "P loop_units linear grid=%d", nblk);
+        timeit(nm, bytes * 1.25, [&](int b) { hipLaunchKernelGGL((loop_units<0, false>), dim3(nblk), dim3(256), 0, 0, in[b], nct, nct * 64, (unsigned char*)outb[b]); });
+        snprintf(nm, 128, "P loop_units linear nt grid=%d", nblk);
+        timeit(nm, bytes * 1.25, [&](int b) { hipLaunchKernelGGL((loop_units<0, true>), dim3(nblk), dim3(256), 0, 0, in[b], nct, nct * 64, (unsigned char*)outb[b]); });
+        snprintf(nm, 128, "P loop_units TILE grid=%d", nblk);
+        timeit(nm, bytes * 1.25, [&](int b) { hipLaunchKernelGGL((loop_units<1, false>), dim3(nblk), dim3(256), 0, 0, in[b], nct, nct * 64, (unsigned char*)outb[b]); });
+        snprintf(nm, 128, "P loop_units TILE nt grid=%d", nblk);
+        timeit(nm, bytes * 1.25, [&](int b) { hipLaunchKernelGGL((loop_units<1, true>), dim3(nblk), dim3(256), 0, 0, in[b], nct, nct * 64, (unsigned char*)outb[b]); });
+    }
+    timeit("Q map CW=1 (128 rows x 256 cols per block) nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_map<1, true>), dim3(43 * (K / 128)), dim3(512), 0, 0, in[b], (unsigned char*)outb[b]); });
+    timeit("Q map CW=2 (64 rows x 512 cols) nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_map<2, true>), dim3(22 * (K / 64)), dim3(512), 0, 0, in[b], (unsigned char*)outb[b]); });
+    timeit("Q map CW=4 (32 rows x 1024 cols) nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_map<4, true>), dim3(11 * (K / 32)), dim3(512), 0, 0, in[b], (unsigned char*)outb[b]); });
+    timeit("Q map CW=8 (16 rows x 2048 cols) nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_map<8, true>), dim3(6 * (K / 16)), dim3(512), 0, 0, in[b], (unsigned char*)outb[b]); });
+    timeit("Q map CW=8 (16 rows x 2048 cols)", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((tile_rw_map<8, false>), dim3(6 * (K / 16)), dim3(512), 0, 0, in[b], (unsigned char*)outb[b]); });
+    timeit("R oneshot_interleaved<16, 8 waves>", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((oneshot_interleaved<16, 8, false>), dim3(n4 / (64 * 16 * 8)), dim3(512), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
+    timeit("R oneshot_interleaved<16, 8 waves> nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((oneshot_interleaved<16, 8, true>), dim3(n4 / (64 * 16 * 8)), dim3(512), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
+    timeit("R oneshot_interleaved<16, 4 waves>", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((oneshot_interleaved<16, 4, false>), dim3(n4 / (64 * 16 * 4)), dim3(256), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
+    timeit("R oneshot_interleaved<4, 4 waves>", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((oneshot_interleaved<4, 4, false>), dim3(n4 / (64 * 4 * 4)), dim3(256), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
+    timeit("R oneshot_interleaved<4, 4 waves> nt", bytes * 1.25, [&](int b) { hipLaunchKernelGGL((oneshot_interleaved<4, 4, true>), dim3(n4 / (64 * 4 * 4)), dim3(256), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
     timeit("E read4_write1<1> grid=8192", bytes * 1.25, [&](int b) { hipLaunchKernelGGL(read4_write1<1>, dim3(8192), dim3(256), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
     timeit("E read4_write1<2> grid=8192", bytes * 1.25, [&](int b) { hipLaunchKernelGGL(read4_write1<2>, dim3(8192), dim3(256), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });
     timeit("E read4_write1<16> grid=2048", bytes * 1.25, [&](int b) { hipLaunchKernelGGL(read4_write1<16>, dim3(2048), dim3(256), 0, 0, (const float4*)in[b], (uint32_t*)outb[b], n4); });

@@ -1,7 +1,9 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 run() { r=$(env "$@" python bench.py --no-cpu-baseline --steps 300 --warmup 30 $MODE 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['launch_us'], d['verified_vs_reference_digest'])"); echo "$* mode='$MODE' -> launch_us,verified = $r"; }
-for MODE in "--layout nbits" ""; do
+for MODE in "" "--layout nbits"; do
   run A=default
-  run OQ_RTN_STAGE_Q=0
+  run OQ_RTN_STAGE=0
+  for gk in 1 2 4 8 16 32; do run OQ_RTN_ORDER=2 OQ_RTN_GK=$gk OQ_RTN_STAGE=0; done
+  for gk in 2 4 8; do run OQ_RTN_ORDER=2 OQ_RTN_GK=$gk OQ_RTN_STAGE=1; done
 done

@@ -178,3 +178,27 @@ def test_errors_are_loud(ops):
         ops.rtn_quantize(w, "int8", "tensor", clip_ratio=1.5)
     with pytest.raises(ValueError, match="cannot reshape"):
         ops.rtn_quantize(torch.zeros((10, 3), device="cuda"), "int8", "group", 4)
+
+
+def test_back_to_back_launches_do_not_leak_between_calls(ops):
+    """300 launches of different matrices back to back on one stream, no synchronisation in between: the
+    staged [K/g, N] parameters + transpose launch (and the workspace reuse of the caching allocator) must never
+    hand a later call the parameters of an earlier one.  Independent formula in torch (true division)."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(123)
+    shapes = [(1024, 2304, 128), (2048, 1024, 64), (512, 4352, 128), (4096, 768, 32)]
+    mats = [(torch.randn((k, n), generator=gen, device="cuda") * (0.5 + i), g) for i, (k, n, g) in enumerate(shapes * 3)]
+    outs = []
+    for rep in range(25):
+        for w, g in mats:
+            outs.append((w, g) + ops.rtn_quantize(w, "uint4", "group", g))
+    torch.cuda.synchronize()
+    for w, g, q, s, z in outs[::7] + outs[-12:]:
+        k, n = w.shape
+        wg = w.t().reshape(n, k // g, g)
+        lo = wg.amin(dim=2).clamp(max=0)
+        hi = wg.amax(dim=2).clamp(min=0)
+        es = torch.div(hi - lo, torch.full_like(hi, 15.0))      # tensor / tensor: IEEE division (x / 15.0 would multiply by 1/15)
+        ez = torch.clamp(0.0 - torch.div(lo, es), 0, 15).round()  # torch.round is half-to-even
+        assert torch.equal(s.reshape(n, k // g), es)
+        assert torch.equal(z.reshape(n, k // g).to(torch.float32), ez)
