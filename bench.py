@@ -3,9 +3,12 @@
 
     python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path (reference rtn.py:54-109, `_rtn_quantize`) over one
-4096x11008 matrix already resident in HBM: one launch of the fused HIP kernel through the C ABI
-(oq_rtn_quantize_f32).  Inputs rotate over `--rotate` distinct HBM buffers (default 4 x 180 MB,
+One "step" = one pass of the hot path over one 4096x11008 matrix already resident in HBM: one call of
+oq_rtn_quantize_f32 through the C ABI.  Default output layout "nbits" = reference rtn.py:54-109
+(`_rtn_quantize`) fused with qrules/_common.py:65-123 (`_prepare_for_matmul_nbits`), i.e. the packed int4
+MatMulNBits blob + scales + zero points the reference emits for this configuration and the layout the
+algorithmic byte count (4.539 B/param) is defined on; "kn" = the [K, N] one-value-per-byte array
+`_rtn_quantize` itself returns (timed too and reported under "other_layout").  Inputs rotate over `--rotate` distinct HBM buffers (default 4 x 180 MB,
 more than the 256 MiB Infinity Cache) so every step streams from HBM, not from cache.
 
 N > 1 is weak scaling: every rank quantizes its own matrices (independent MatMul weights shard with
@@ -78,7 +81,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rotate", type=int, default=4, help="distinct input/output buffer sets cycled through")
-    ap.add_argument("--layout", choices=["kn", "nbits"], default="kn",
+    ap.add_argument("--layout", choices=["kn", "nbits"], default="nbits",
                     help="kn: [K,N] one value per byte (what _rtn_quantize returns); "
                          "nbits: MatMulNBits blob [N,K/g,g/2] (what the emitted graph holds for this config)")
     ap.add_argument("--symmetric", action="store_true")
@@ -157,6 +160,33 @@ def main() -> None:
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream: device time of the K launches
 
+    # the other output layout, shorter run, same buffers (reported next to the headline, never as `value`)
+    other = "kn" if args.layout == "nbits" else "nbits"
+    other_us = None
+    if world == 1 and not args.qparams_only:
+        olayout = L.OQ_LAYOUT_KN if other == "kn" else L.OQ_LAYOUT_NBITS
+        oq = torch.empty(K_DIM * N_DIM if other == "kn" else K_DIM * N_DIM // 2, dtype=torch.uint8, device=dev)
+        oqp = C.c_void_p(oq.data_ptr())
+
+        def ostep(i: int) -> None:
+            wp, _, sp, zp = calls[i % len(calls)]
+            st = fn(wp, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, oqp, sp, zp, olayout, wsp, wsn, stream)
+            if st != 0:
+                L.check(st)
+        for i in range(10):
+            ostep(i)
+        torch.cuda.synchronize()
+        o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        o0.record()
+        for i in range(100):
+            ostep(i)
+        o1.record()
+        torch.cuda.synchronize()
+        other_us = o0.elapsed_time(o1) * 10.0
+        for i in range(len(calls)):          # restore the headline layout's outputs for the digest check below
+            step(i)
+        torch.cuda.synchronize()
+
     t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,9 +241,13 @@ def main() -> None:
         "config": {"workload": f"rtn_quint4_g128_{'sym' if args.symmetric else 'asym'}_4096x11008_f32",
                    "out_layout": args.layout, "rotating_buffers": len(ws), "matrices_per_step_per_gpu": 1},
         "verified_vs_reference_digest": verified,
+        "other_layout": None if other_us is None else {
+            "out_layout": other, "launch_us": round(other_us, 2),
+            "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "oq::rtn_group_fused<16,true,true>", "launch_us": round(launch_us, 2),
+                     "kernel": "oq::rtn_group_fused<16,true,true,true>" + (" + oq::transpose_qparams" if args.layout == "kn" else ""),
+                     "launch_us": round(launch_us, 2),
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -28,6 +28,7 @@ struct RtnArgs {
     int32_t order;    // 0: K-direction fastest + XCD strips, 1: column tiles fastest (row-sequential DRAM stream)
     int32_t nt;       // non-temporal loads of W
     int32_t stage_q;  // NBITS: transpose the block's packed output through LDS (64/128-byte chunks per column)
+    int32_t gk;       // order 2: row tiles per id chunk (see the block order in rtn_group_fused)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -77,9 +78,25 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
         const uint32_t id = xcd_remap(blockIdx.x, nblk);
         col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
         row_tile = id - col_tile * a.nrow_tiles;
-    } else {
+    } else if (a.order == 1) {
         row_tile = blockIdx.x / a.ncol_tiles;  // column tiles fastest: co-resident blocks stream whole rows
         col_tile = blockIdx.x - row_tile * a.ncol_tiles;
+    } else {
+        // Column tiles fastest over bands of `gk` row tiles, ids blocked as [8 column tiles] x [gk row tiles] with
+        // the column tile in the low 3 bits: blocks of one column tile and neighbouring k-groups are 8 ids apart,
+        // i.e. on one XCD at about the same time (observed round-robin placement; speed only).  Pieces of one
+        // 128-byte line that different blocks produce -- the two 64-byte halves of a MatMulNBits line, the 4-byte
+        // scales of neighbouring k-groups -- then merge in that XCD's L2 before they are written back, while a
+        // band still streams whole rows of W.
+        const uint32_t band_sz = a.ncol_tiles * a.gk;
+        const uint32_t b = blockIdx.x / band_sz;
+        uint32_t r = blockIdx.x - b * band_sz;
+        const uint32_t gk_eff = min(static_cast<uint32_t>(a.gk), a.nrow_tiles - b * a.gk);
+        const uint32_t cc = r / (8u * gk_eff);
+        r -= cc * 8u * gk_eff;
+        const uint32_t w = min(8u, a.ncol_tiles - cc * 8u);
+        row_tile = b * a.gk + r / w;
+        col_tile = cc * 8u + r % w;
     }
 
     const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + gib;
@@ -914,7 +931,8 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
         a.scale_t = nullptr; a.zp_t = nullptr;
         static const int env_stage = getenv("OQ_RTN_STAGE") ? atoi(getenv("OQ_RTN_STAGE")) : 1;
-        const bool staged = env_stage && vec4 && kgroups > 1 && workspace != nullptr && workspace_bytes >= stage_ws(K, N, g) &&
+        const bool want_stage = getenv("OQ_RTN_STAGE") ? env_stage != 0 : layout != OQ_LAYOUT_NBITS;
+        const bool staged = want_stage && vec4 && kgroups > 1 && workspace != nullptr && workspace_bytes >= stage_ws(K, N, g) &&
                             (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
         if (staged) {
             a.scale_t = static_cast<float*>(workspace);
@@ -927,7 +945,13 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, a.gpb));
         static const int env_order = getenv("OQ_RTN_ORDER") ? atoi(getenv("OQ_RTN_ORDER")) : 1;
         static const int env_nt = getenv("OQ_RTN_NT") ? atoi(getenv("OQ_RTN_NT")) : 1;
-        a.order = env_order;
+        static const int env_gk = getenv("OQ_RTN_GK") ? atoi(getenv("OQ_RTN_GK")) : 8;
+        // Tuned on 4096x11008 (profiles/r01_rtn_knob_sweep.txt): the [K,N] byte layout is fastest with plain
+        // column-fastest ids + staged parameters + transpose launch; the MatMulNBits blob is fastest with the
+        // L2-merging order (its 64-byte half lines and the 4-byte scales merge in one L2) and direct n-major stores.
+        const bool merge_order = layout == OQ_LAYOUT_NBITS;
+        a.order = getenv("OQ_RTN_ORDER") ? env_order : (merge_order ? 2 : 1);
+        a.gk = env_gk > 0 ? env_gk : 1;
         a.nt = env_nt;
         static const int env_stage_q = getenv("OQ_RTN_STAGE_Q") ? atoi(getenv("OQ_RTN_STAGE_Q")) : 1;
         a.stage_q = (env_stage_q && layout == OQ_LAYOUT_NBITS && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves &&
