@@ -86,6 +86,8 @@ def main() -> None:
                          "nbits: MatMulNBits blob [N,K/g,g/2] (what the emitted graph holds for this config)")
     ap.add_argument("--symmetric", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch-extra", type=int, default=4,
+                    help="also time oq_rtn_quantize_batched_f32 with this many matrices per launch (0/1: skip)")
     ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
     args = ap.parse_args()
 
@@ -187,6 +189,38 @@ def main() -> None:
             step(i)
         torch.cuda.synchronize()
 
+    # batched entry point: `--batch-extra` matrices per launch (stacked weights); reported separately
+    batched = None
+    if world == 1 and not args.qparams_only and args.batch_extra > 1:
+        nb = args.batch_extra
+        wb = torch.stack([w_src] * nb).contiguous()
+        qb = torch.empty(nb * q_elems, dtype=torch.uint8, device=dev)
+        sb = torch.empty(nb * groups, dtype=torch.float32, device=dev)
+        zb = torch.empty(nb * groups, dtype=torch.uint8, device=dev)
+        bws = torch.empty(lib.oq_rtn_batched_workspace_bytes(nb, K_DIM, N_DIM, GROUP) + 256, dtype=torch.uint8, device=dev)
+
+        def bstep() -> None:
+            st = lib.oq_rtn_quantize_batched_f32(C.c_void_p(wb.data_ptr()), nb, K_DIM * N_DIM, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, GROUP, sym, 0,
+                                                 1.0, C.c_void_p(qb.data_ptr()), C.c_void_p(sb.data_ptr()), C.c_void_p(zb.data_ptr()), layout,
+                                                 C.c_void_p(bws.data_ptr()), bws.numel(), stream)
+            if st != 0:
+                L.check(st)
+        for _ in range(5):
+            bstep()
+        torch.cuda.synchronize()
+        b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b0.record()
+        for _ in range(50):
+            bstep()
+        b1.record()
+        torch.cuda.synchronize()
+        per_matrix_us = b0.elapsed_time(b1) * 1e3 / 50 / nb
+        same = bool(torch.equal(qb[:q_elems], outs[0][0]) and torch.equal(sb[:groups], outs[0][1]))
+        batched = {"matrices_per_launch": nb, "us_per_matrix": round(per_matrix_us, 2),
+                   "achieved_GBs": round(algorithmic_bytes(args.layout) / (per_matrix_us * 1e-6) / 1e9, 1),
+                   "frac": round(algorithmic_bytes(args.layout) / (per_matrix_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                   "equals_single_launch_output": same}
+
     t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -241,6 +275,7 @@ def main() -> None:
         "config": {"workload": f"rtn_quint4_g128_{'sym' if args.symmetric else 'asym'}_4096x11008_f32",
                    "out_layout": args.layout, "rotating_buffers": len(ws), "matrices_per_step_per_gpu": 1},
         "verified_vs_reference_digest": verified,
+        "batched_launch": batched,
         "other_layout": None if other_us is None else {
             "out_layout": other, "launch_us": round(other_us, 2),
             "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -84,6 +84,17 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
                             float* scale_out, void* zp_out, int32_t layout, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* A1 over a strided batch of equally shaped matrices (stacked projection weights, experts, ...): matrix b is
+ *     W + b * w_stride (fp32 elements); outputs are packed back to back (q: K*N bytes resp. the blob size per
+ *     matrix; scale / zp: N*K/g entries per matrix).  Group strategy, K % group_size == 0, group_size <= 256.
+ *     One launch covers all matrices, so the tail of one matrix overlaps the head of the next. */
+size_t oq_rtn_batched_workspace_bytes(int64_t batch, int64_t K, int64_t N, int64_t group_size);
+int32_t oq_rtn_quantize_batched_f32(const float* W, int64_t batch, int64_t w_stride, int64_t K, int64_t N,
+                                    int64_t ldw, int32_t qtype, int64_t group_size, int32_t symmetric,
+                                    int32_t reduce_range, float clip_ratio, void* q_out, float* scale_out,
+                                    void* zp_out, int32_t layout, void* workspace, size_t workspace_bytes,
+                                    void* stream);
+
 /* Q2  core/_algorithms/utils.py:302-348  _compute_qparams_from_array on [K, N] weights (no integer
  *     output): same arguments and outputs as above minus q_out. */
 int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,

@@ -29,6 +29,8 @@ struct RtnArgs {
     int32_t nt;       // non-temporal loads of W
     int32_t stage_q;  // NBITS: transpose the block's packed output through LDS (64/128-byte chunks per column)
     int32_t gk;       // order 2: row tiles per id chunk (see the block order in rtn_group_fused)
+    // strided batch (oq_rtn_quantize_batched_f32): matrix b lives at base + b * stride (elements / bytes as noted)
+    int64_t w_stride, q_stride, p_stride;  // fp32 elements of W; bytes of q; entries of scale / zp (also of the staging)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -63,24 +65,33 @@ __device__ __forceinline__ void store_words(uint8_t* dst, const uint32_t (&w)[NW
 // WPG waves x RPW rows.  Registers per lane: RPW x 4 fp32 of W.
 // ---------------------------------------------------------------------------------------------
 template <int RPW, bool VEC4, bool EMIT_Q, bool NT = false>
-__global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArgs a) {
+__global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArgs a_in) {
     __shared__ float4 s_mn[kMaxWaves][kWave];
     __shared__ float4 s_mx[kMaxWaves][kWave];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wig = wave % a.wpg;   // wave inside its group
-    const int gib = wave / a.wpg;   // group inside the block
+    const int wig = wave % a_in.wpg;   // wave inside its group
+    const int gib = wave / a_in.wpg;   // group inside the block
 
-    const uint32_t nblk = a.ncol_tiles * a.nrow_tiles;
+    const uint32_t nblk = a_in.ncol_tiles * a_in.nrow_tiles;
+    // Batched launch: block ids run over all matrices, so the tail of one matrix overlaps the head of the next.
+    const uint32_t mat = blockIdx.x / nblk;
+    const uint32_t bid = blockIdx.x - mat * nblk;
+    RtnArgs a = a_in;
+    a.W += static_cast<int64_t>(mat) * a.w_stride;
+    if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
+    a.scale += static_cast<int64_t>(mat) * a.p_stride;
+    a.zp += static_cast<int64_t>(mat) * a.p_stride;
+    if (a.scale_t) { a.scale_t += static_cast<int64_t>(mat) * a.p_stride; a.zp_t += static_cast<int64_t>(mat) * a.p_stride; }
     uint32_t col_tile, row_tile;
     if (a.order == 0) {
-        const uint32_t id = xcd_remap(blockIdx.x, nblk);
+        const uint32_t id = xcd_remap(bid, nblk);
         col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
         row_tile = id - col_tile * a.nrow_tiles;
     } else if (a.order == 1) {
-        row_tile = blockIdx.x / a.ncol_tiles;  // column tiles fastest: co-resident blocks stream whole rows
-        col_tile = blockIdx.x - row_tile * a.ncol_tiles;
+        row_tile = bid / a.ncol_tiles;  // column tiles fastest: co-resident blocks stream whole rows
+        col_tile = bid - row_tile * a.ncol_tiles;
     } else {
         // Column tiles fastest over bands of `gk` row tiles, ids blocked as [8 column tiles] x [gk row tiles] with
         // the column tile in the low 3 bits: blocks of one column tile and neighbouring k-groups are 8 ids apart,
@@ -89,8 +100,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
         // scales of neighbouring k-groups -- then merge in that XCD's L2 before they are written back, while a
         // band still streams whole rows of W.
         const uint32_t band_sz = a.ncol_tiles * a.gk;
-        const uint32_t b = blockIdx.x / band_sz;
-        uint32_t r = blockIdx.x - b * band_sz;
+        const uint32_t b = bid / band_sz;
+        uint32_t r = bid - b * band_sz;
         const uint32_t gk_eff = min(static_cast<uint32_t>(a.gk), a.nrow_tiles - b * a.gk);
         const uint32_t cc = r / (8u * gk_eff);
         r -= cc * 8u * gk_eff;
@@ -766,6 +777,10 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
                                                          float* scale, uint8_t* zp) {
     __shared__ float ts[32][33];
     __shared__ uint8_t tz[32][36];
+    {   // blockIdx.z = matrix of a strided batch: every array advances by kgroups * N entries
+        const int64_t off = static_cast<int64_t>(blockIdx.z) * kgroups * N;
+        scale_t += off; zp_t += off; scale += off; zp += off;
+    }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int64_t n0 = static_cast<int64_t>(blockIdx.x) * 32, k0 = static_cast<int64_t>(blockIdx.y) * 32;
 #pragma unroll
@@ -876,6 +891,11 @@ int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, in
     return check_launch("quantize_kn");
 }
 
+// Strided batch of equally shaped matrices for the fused group kernel (set by oq_rtn_quantize_batched_f32 around
+// its call of rtn_impl; 1 matrix otherwise).
+struct BatchCtx { int64_t count = 1, w_stride = 0, q_stride = 0; };
+static thread_local BatchCtx g_batch;
+
 int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
                  int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
                  void* q_out, float* scale_out, void* zp_out, int32_t layout, void* workspace,
@@ -930,13 +950,15 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
         a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
         a.scale_t = nullptr; a.zp_t = nullptr;
+        const int64_t batch = g_batch.count;
+        a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups;
         static const int env_stage = getenv("OQ_RTN_STAGE") ? atoi(getenv("OQ_RTN_STAGE")) : 1;
         const bool want_stage = getenv("OQ_RTN_STAGE") ? env_stage != 0 : layout != OQ_LAYOUT_NBITS;
-        const bool staged = want_stage && vec4 && kgroups > 1 && workspace != nullptr && workspace_bytes >= stage_ws(K, N, g) &&
-                            (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
+        const bool staged = want_stage && vec4 && kgroups > 1 && workspace != nullptr &&
+                            workspace_bytes >= static_cast<size_t>(batch) * stage_ws(K, N, g) && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
         if (staged) {
             a.scale_t = static_cast<float*>(workspace);
-            a.zp_t = static_cast<uint8_t*>(workspace) + (kgroups * N * 4 + 255) / 256 * 256;
+            a.zp_t = static_cast<uint8_t*>(workspace) + (batch * kgroups * N * 4 + 255) / 256 * 256;
         }
         a.wpg = wpg;
         a.gpb = kMaxWaves / wpg > 0 ? kMaxWaves / wpg : 1;
@@ -956,10 +978,10 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         static const int env_stage_q = getenv("OQ_RTN_STAGE_Q") ? atoi(getenv("OQ_RTN_STAGE_Q")) : 1;
         a.stage_q = (env_stage_q && layout == OQ_LAYOUT_NBITS && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves &&
                      kgroups % a.gpb == 0) ? 1 : 0;
-        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles * static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
         static const int env_stream = getenv("OQ_RTN_STREAM") ? atoi(getenv("OQ_RTN_STREAM")) : 0;
         static const int env_blocks = getenv("OQ_RTN_BLOCKS") ? atoi(getenv("OQ_RTN_BLOCKS")) : 0;
-        if (env_stream && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves) {
+        if (env_stream && batch == 1 && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves) {
             // persistent grid: every block gets the same number of units (+-1); all blocks co-resident
             const uint32_t nunits = a.ncol_tiles * a.nrow_tiles;
             int dev = 0, cus = 256;
@@ -996,10 +1018,12 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         }
         st = check_launch("rtn_group_fused");
         if (st != OQ_OK || !staged) return st;
-        hipLaunchKernelGGL(transpose_qparams, dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32))),
+        hipLaunchKernelGGL(transpose_qparams,
+                           dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32)), static_cast<uint32_t>(batch)),
                            dim3(256), 0, s, a.scale_t, a.zp_t, kgroups, N, scale_out, zp8);
         return check_launch("transpose_qparams");
     }
+    OQ_REQUIRE(g_batch.count == 1, OQ_ERR_UNSUPPORTED, "batched call needs the fused group path");
 
     // two-pass
     const size_t need = twopass_ws(K, N, g);
@@ -1061,6 +1085,35 @@ int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, in
                            void* stream) {
     return oq::rtn_impl(W, K, N, ldw, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, mse, nullptr,
                         scale_out, zp_out, OQ_LAYOUT_KN, workspace, workspace_bytes, stream, false);
+}
+
+size_t oq_rtn_batched_workspace_bytes(int64_t batch, int64_t K, int64_t N, int64_t group_size) {
+    if (batch <= 0 || K <= 0 || N <= 0) return 0;
+    int64_t g;
+    if (oq::resolve_group(OQ_GROUP, K, group_size, &g) != OQ_OK || K % g != 0) return 0;
+    return static_cast<size_t>(batch) * oq::stage_ws(K, N, g) + 512;
+}
+
+int32_t oq_rtn_quantize_batched_f32(const float* W, int64_t batch, int64_t w_stride, int64_t K, int64_t N, int64_t ldw, int32_t qtype,
+                                    int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, void* q_out,
+                                    float* scale_out, void* zp_out, int32_t layout, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    OQ_REQUIRE(batch >= 1 && w_stride >= K * ldw, OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_batched_f32: bad batch %lld / stride %lld",
+               (long long)batch, (long long)w_stride);
+    int64_t g;
+    int32_t st = oq::resolve_group(OQ_GROUP, K, group_size, &g);
+    if (st != OQ_OK) return st;
+    OQ_REQUIRE(K % g == 0, OQ_ERR_UNSUPPORTED, "oq_rtn_quantize_batched_f32 needs K %% group_size == 0");
+    int rpw = 0, wpg = 0;
+    OQ_REQUIRE(oq::fused_shape(g, &rpw, &wpg), OQ_ERR_UNSUPPORTED, "oq_rtn_quantize_batched_f32 needs a group the fused kernel holds (<= 256 rows)");
+    const int64_t bits = (qtype == OQ_INT4 || qtype == OQ_UINT4) ? 4 : 8;
+    oq::g_batch.count = batch;
+    oq::g_batch.w_stride = w_stride;
+    oq::g_batch.q_stride = layout == OQ_LAYOUT_KN ? K * N : K * N * bits / 8;
+    st = oq::rtn_impl(W, K, N, ldw, qtype, OQ_GROUP, group_size, symmetric, reduce_range, clip_ratio, 0, q_out, scale_out, zp_out, layout,
+                      workspace, workspace_bytes, stream, true);
+    oq::g_batch = oq::BatchCtx();
+    return st;
 }
 
 }  // extern "C"

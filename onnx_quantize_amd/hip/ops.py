@@ -110,6 +110,34 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
     return q, scale.reshape(shape), zp.reshape(shape)
 
 
+def rtn_quantize_batched(w: torch.Tensor, qtype: str, group_size: int, symmetric=False, reduce_range=False,
+                         clip_ratio=1.0, layout: str = "kn", out=None):
+    """rtn.py:54-109 for a stack of equally shaped weights ``w`` [B, K, N] in ONE launch (group strategy).
+    Returns (q [B, K, N] | [B, N, K/g, g*bits/8], scale [B, N*K/g, 1], zp [B, N*K/g, 1])."""
+    _require_device(w, "w", torch.float32)
+    if w.dim() != 3 or not w.is_contiguous():
+        raise ValueError("w must be a contiguous [B, K, N] tensor")
+    b, k, n = w.shape
+    g = resolve_group("group", k, group_size)
+    if k % g:
+        raise ValueError("batched RTN needs K % group_size == 0")
+    lib = L.load()
+    cdt = container_dtype(qtype)
+    if out is not None:
+        q, scale, zp = out
+    else:
+        q = (torch.empty((b, k, n), dtype=cdt, device=w.device) if layout == "kn"
+             else torch.empty((b, n, k // g, g * BITS[qtype] // 8), dtype=torch.uint8, device=w.device))
+        scale = torch.empty((b, n * k // g, 1), dtype=torch.float32, device=w.device)
+        zp = torch.empty((b, n * k // g, 1), dtype=cdt, device=w.device)
+    ws = _workspace(lib.oq_rtn_batched_workspace_bytes(b, k, n, int(group_size)), w.device)
+    L.check(lib.oq_rtn_quantize_batched_f32(_ptr(w), b, k * n, k, n, n, L.QTYPE_CODE[qtype], int(group_size), int(symmetric),
+                                            int(reduce_range), float(clip_ratio), _ptr(q), _ptr(scale), _ptr(zp),
+                                            L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS, _ptr(ws), ws.numel(),
+                                            _stream()))
+    return q, scale, zp
+
+
 # ----------------------------------------------------------------------------- Q1
 def qparams(rmin: torch.Tensor, rmax: torch.Tensor, qtype: str, symmetric: bool, reduce_range: bool):
     """utils.py:242-299 on device ranges (any shape); returns (scale fp32, zp int32) of that shape."""

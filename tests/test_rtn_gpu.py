@@ -202,3 +202,16 @@ def test_back_to_back_launches_do_not_leak_between_calls(ops):
         ez = torch.clamp(0.0 - torch.div(lo, es), 0, 15).round()  # torch.round is half-to-even
         assert torch.equal(s.reshape(n, k // g), es)
         assert torch.equal(z.reshape(n, k // g).to(torch.float32), ez)
+
+
+@pytest.mark.parametrize("layout", ["kn", "nbits"])
+@pytest.mark.parametrize("qtype,g,sym", [("uint4", 128, False), ("int8", 64, True), ("uint8", 32, False)])
+def test_batched_equals_per_matrix(ops, layout, qtype, g, sym):
+    """One launch over a stack of matrices == the matrices quantized one by one (bit for bit)."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    w = torch.randn((5, 512, 768), generator=gen, device="cuda") * torch.tensor([0.5, 1, 2, 4, 8], device="cuda")[:, None, None]
+    bq, bs, bz = ops.rtn_quantize_batched(w, qtype, g, sym, layout=layout)
+    for b in range(w.shape[0]):
+        q, s, z = ops.rtn_quantize(w[b], qtype, "group", g, sym, layout=layout)
+        assert torch.equal(bq[b], q) and torch.equal(bs[b], s) and torch.equal(bz[b], z)
