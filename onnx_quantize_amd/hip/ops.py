@@ -238,19 +238,30 @@ def minmax_state(device, dtype=torch.float32) -> torch.Tensor:
     return torch.zeros(4, dtype=dtype, device=device)
 
 
+_MINMAX_WS: dict = {}   # (device index, stream) -> workspace reused by every collect on that stream (calls are ordered)
+
+
 def minmax_collect(x: torch.Tensor, state: torch.Tensor, momentum: float = 0.0) -> None:
-    """minmax.py:40-64: fold one activation batch into `state`, entirely on the device."""
+    """minmax.py:40-64: fold one activation batch into `state`, entirely on the device.  This sits in the
+    calibration loop (thousands of tensors per run), so the host side is kept to one ctypes call."""
     if not x.is_cuda or x.dtype not in (torch.float32, torch.float64):
         raise TypeError("activations must be fp32/fp64 tensors in GPU memory")
     if state.dtype != x.dtype:
         raise TypeError("state dtype must match the activation dtype")
-    flat = x.contiguous().reshape(-1)
-    if flat.numel() == 0:
+    flat = x if x.is_contiguous() else x.contiguous()
+    n = flat.numel()
+    if n == 0:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     lib = L.load()
-    ws = _workspace(lib.oq_minmax_workspace_bytes(flat.numel()), x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    key = (x.device.index, stream)
+    ws = _MINMAX_WS.get(key)
+    if ws is None:
+        ws = _MINMAX_WS[key] = _workspace(lib.oq_minmax_workspace_bytes(n), x.device)
     fn = lib.oq_minmax_collect_f32 if x.dtype == torch.float32 else lib.oq_minmax_collect_f64
-    L.check(fn(_ptr(flat), flat.numel(), _ptr(state), float(momentum), _ptr(ws), ws.numel(), _stream()))
+    st = fn(flat.data_ptr(), n, state.data_ptr(), float(momentum), ws.data_ptr(), ws.numel(), stream)
+    if st:
+        L.check(st)
 
 
 def absmax(x: torch.Tensor, per_row: bool = False) -> torch.Tensor:
