@@ -88,6 +88,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch-extra", type=int, default=4,
                     help="also time oq_rtn_quantize_batched_f32 with this many matrices per launch (0/1: skip)")
+    ap.add_argument("--no-extras", action="store_true", help="time only the headline configuration (used under rocprofv3)")
     ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
     args = ap.parse_args()
 
@@ -165,7 +166,7 @@ def main() -> None:
     # the other output layout, shorter run, same buffers (reported next to the headline, never as `value`)
     other = "kn" if args.layout == "nbits" else "nbits"
     other_us = None
-    if world == 1 and not args.qparams_only:
+    if world == 1 and not args.qparams_only and not args.no_extras:
         olayout = L.OQ_LAYOUT_KN if other == "kn" else L.OQ_LAYOUT_NBITS
         oq = torch.empty(K_DIM * N_DIM if other == "kn" else K_DIM * N_DIM // 2, dtype=torch.uint8, device=dev)
         oqp = C.c_void_p(oq.data_ptr())
@@ -191,7 +192,7 @@ def main() -> None:
 
     # batched entry point: `--batch-extra` matrices per launch (stacked weights); reported separately
     batched = None
-    if world == 1 and not args.qparams_only and args.batch_extra > 1:
+    if world == 1 and not args.qparams_only and not args.no_extras and args.batch_extra > 1:
         nb = args.batch_extra
         wb = torch.stack([w_src] * nb).contiguous()
         qb = torch.empty(nb * q_elems, dtype=torch.uint8, device=dev)
