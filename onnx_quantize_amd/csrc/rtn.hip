@@ -361,226 +361,6 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming variant of the fused kernel (the one the headline benchmark runs).
-//
-// The plain fused kernel runs load -> reduce -> quantize -> store as separate phases of a short-lived
-// block, so HBM idles while the VALU works and vice versa (measured: 53 us where a pure tile read
-// takes 30 us).  Here a block is persistent over a run of consecutive units (a unit = 128 rows x 256
-// columns, K direction fastest) and the register tile is recycled row by row: as soon as row r of the
-// current unit has been quantized and stored, the same registers receive row r of the NEXT unit, so
-// loads stay in flight during all of the VALU / store work.  Consecutive k-groups of a column strip
-// are handled by one block, so the 4-byte scale writes of a 128-byte line meet in one L2.
-// Requires RPW == 16, 16-byte aligned rows (VEC4) and g | 128 or g == 128.
-// ---------------------------------------------------------------------------------------------
-template <bool EMIT_Q, int LAYOUT, int BITS, bool NT>
-__global__ __launch_bounds__(kMaxWaves* kWave, 4) void rtn_group_stream(const RtnArgs a, const uint32_t nunits) {
-    constexpr int RPW = 16;
-    __shared__ float4 s_mn[2][kMaxWaves][kWave];
-    __shared__ float4 s_mx[2][kMaxWaves][kWave];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wig = wave % a.wpg;
-    const int gib = wave / a.wpg;
-
-    const uint32_t u_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * nunits / gridDim.x);
-    const uint32_t u_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * nunits / gridDim.x);
-    if (u_begin >= u_end) return;
-
-    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
-    const int32_t bias = qmin < 0 ? ((LAYOUT == OQ_LAYOUT_NBITS && BITS == 4) ? 8 : 128) : 0;
-    const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
-
-    // unit -> first row of this wave, first column of this lane, validity
-    auto locate = [&](uint32_t u, int64_t& kg, int64_t& row0, int64_t& col0, bool& ok) {
-        const uint32_t col_tile = u / a.nrow_tiles;
-        const uint32_t row_tile = u - col_tile * a.nrow_tiles;
-        kg = static_cast<int64_t>(row_tile) * a.gpb + gib;
-        row0 = kg * a.g + static_cast<int64_t>(wig) * RPW;
-        col0 = static_cast<int64_t>(col_tile) * kColsPerWave + lane * 4;
-        ok = (kg < a.kgroups) && (col0 < a.N);
-    };
-    // Loads are never predicated (see rtn_group_fused): out-of-range lanes / waves read a clamped address.
-    auto load_base = [&](int64_t kg, int64_t row0, int64_t col0) -> const float* {
-        const int64_t lrow0 = kg < a.kgroups ? row0 : static_cast<int64_t>(wig) * RPW;
-        const int64_t lcol = col0 < a.N ? col0 : a.N - 4;
-        return a.W + lrow0 * a.ldw + lcol;
-    };
-    auto load_row = [&](const float* p) -> float4 {
-        if constexpr (NT) {
-            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-            return make_float4(t[0], t[1], t[2], t[3]);
-        } else {
-            return *reinterpret_cast<const float4*>(p);
-        }
-    };
-
-    float4 v[RPW];
-    int64_t kg, row0, col0;
-    bool ok;
-    locate(u_begin, kg, row0, col0, ok);
-    {
-        const float* p = load_base(kg, row0, col0);
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) v[r] = load_row(p + r * a.ldw);
-    }
-
-    // One unit; RELOAD (compile-time) refills the register tile from unit u+1 while unit u is quantized.
-    auto unit_body = [&](const uint32_t u, auto reload_tag) {
-        constexpr bool RELOAD = decltype(reload_tag)::value;
-        const int buf = (u - u_begin) & 1;
-        // R1: lane-local column min / max of this wave's 16 rows (first use of v: waits for the loads)
-        float4 mn = v[0], mx = v[0];
-#pragma unroll
-        for (int r = 1; r < RPW; ++r) {
-            mn.x = fminf(mn.x, v[r].x); mn.y = fminf(mn.y, v[r].y); mn.z = fminf(mn.z, v[r].z); mn.w = fminf(mn.w, v[r].w);
-            mx.x = fmaxf(mx.x, v[r].x); mx.y = fmaxf(mx.y, v[r].y); mx.z = fmaxf(mx.z, v[r].z); mx.w = fmaxf(mx.w, v[r].w);
-        }
-        if (a.wpg > 1) {
-            s_mn[buf][wave][lane] = mn;
-            s_mx[buf][wave][lane] = mx;
-            __syncthreads();
-            const int w0 = gib * a.wpg;
-            for (int w = 0; w < a.wpg; ++w) {
-                const float4 tn = s_mn[buf][w0 + w][lane], tx = s_mx[buf][w0 + w][lane];
-                mn.x = fminf(mn.x, tn.x); mn.y = fminf(mn.y, tn.y); mn.z = fminf(mn.z, tn.z); mn.w = fminf(mn.w, tn.w);
-                mx.x = fmaxf(mx.x, tx.x); mx.y = fmaxf(mx.y, tx.y); mx.z = fmaxf(mx.z, tx.z); mx.w = fmaxf(mx.w, tx.w);
-            }
-        }
-        // Q1
-        ColQ cq[4];
-        {
-            const float mns[4] = {mn.x, mn.y, mn.z, mn.w}, mxs[4] = {mx.x, mx.y, mx.z, mx.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) cq[i] = make_colq(qparam_from_minmax(mns[i], mxs[i], a.grid), mns[i], mxs[i], bias);
-        }
-        if (ok && wig == 0) {
-            if (a.scale_t != nullptr) {
-                const int64_t o = kg * a.N + col0;
-                *reinterpret_cast<float4*>(a.scale_t + o) = make_float4(cq[0].scale, cq[1].scale, cq[2].scale, cq[3].scale);
-                *reinterpret_cast<uint32_t*>(a.zp_t + o) = (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 8) |
-                                                           ((static_cast<uint32_t>(cq[2].zp) & 0xffu) << 16) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 24);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int64_t o = (col0 + i) * a.kgroups + kg;
-                    a.scale[o] = cq[i].scale;
-                    a.zp[o] = static_cast<uint8_t>(cq[i].zp);
-                }
-            }
-        }
-
-        // where the next unit's rows go
-        const bool have_next = RELOAD;
-        int64_t nkg = kg, nrow0 = row0, ncol0 = col0;
-        bool nok = false;
-        if (have_next) locate(u + 1, nkg, nrow0, ncol0, nok);
-        const float* np = load_base(nkg, nrow0, ncol0);
-
-        if constexpr (!EMIT_Q) {
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);
-        } else if constexpr (LAYOUT == OQ_LAYOUT_KN) {
-            const uint32_t flip = bias ? 0x80808080u : 0u;
-            uint8_t* o = a.q + row0 * a.N + col0;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const float xs[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-                float f[4];
-                bool unsafe = false;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(xs[i], cq[i], lo_b, hi_b, unsafe);
-                if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(xs[i], cq[i], qmin, qmax, bias);
-                }
-                uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
-                w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
-                w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
-                w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
-                if (ok) {
-                    if constexpr (NT) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
-                    else *reinterpret_cast<uint32_t*>(o + r * a.N) = w ^ flip;
-                }
-                if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);   // recycle the registers
-            }
-        } else {
-            // MatMulNBits blob (qrules/_common.py:72-87): levels replace the weights in place (exact small
-            // floats); once the rows of one 32-bit word are complete (8 rows of nibbles / 4 rows of bytes) they
-            // are packed and the registers are refilled from the next unit.
-            const int64_t blob = a.g * BITS / 8;
-            uint32_t words[BITS == 4 ? 2 : 4][4];  // [word][column]
-            auto levels_row = [&](int r) {
-                const float xs[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
-                float f[4];
-                bool unsafe = false;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(xs[i], cq[i], lo_b, hi_b, unsafe);
-                if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(xs[i], cq[i], qmin, qmax, bias);
-                }
-                v[r] = make_float4(f[0], f[1], f[2], f[3]);
-            };
-            auto comp = [](const float4& t, int i) { return i == 0 ? t.x : (i == 1 ? t.y : (i == 2 ? t.z : t.w)); };
-            if constexpr (BITS == 4) {
-                const uint32_t flip = bias ? 0x88888888u : 0u;
-#pragma unroll
-                for (int wd = 0; wd < 2; ++wd) {
-#pragma unroll
-                    for (int r = wd * 8; r < wd * 8 + 8; ++r) levels_row(r);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint32_t ev = 0, od = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            ev = __builtin_amdgcn_cvt_pk_u8_f32(comp(v[wd * 8 + 2 * j], i), j, ev);
-                            od = __builtin_amdgcn_cvt_pk_u8_f32(comp(v[wd * 8 + 2 * j + 1], i), j, od);
-                        }
-                        words[wd][i] = (ev | (od << 4)) ^ flip;
-                    }
-#pragma unroll
-                    for (int r = wd * 8; r < wd * 8 + 8; ++r) if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);
-                }
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint8_t* o = a.q + ((col0 + i) * a.kgroups + kg) * blob + wig * 8;
-                        *reinterpret_cast<uint2*>(o) = make_uint2(words[0][i], words[1][i]);
-                    }
-                }
-            } else {
-                const uint32_t flip = bias ? 0x80808080u : 0u;
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) {
-#pragma unroll
-                    for (int r = wd * 4; r < wd * 4 + 4; ++r) levels_row(r);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint32_t acc = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(comp(v[wd * 4 + j], i), j, acc);
-                        words[wd][i] = acc ^ flip;
-                    }
-#pragma unroll
-                    for (int r = wd * 4; r < wd * 4 + 4; ++r) if constexpr (RELOAD) v[r] = load_row(np + r * a.ldw);
-                }
-                if (ok) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        uint8_t* o = a.q + ((col0 + i) * a.kgroups + kg) * blob + wig * 16;
-                        *reinterpret_cast<uint4*>(o) = make_uint4(words[0][i], words[1][i], words[2][i], words[3][i]);
-                    }
-                }
-            }
-        }
-        kg = nkg; row0 = nrow0; col0 = ncol0; ok = nok;
-    };
-    for (uint32_t u = u_begin; u + 1 < u_end; ++u) unit_body(u, std::true_type{});
-    unit_body(u_end - 1, std::false_type{});
-}
-
-// ---------------------------------------------------------------------------------------------
 // Two-pass path (channel, tensor, groups too tall for registers).  Pass 1: per (row chunk, column)
 // min / max.  Pass 2: fold the chunks of one group -> qparams.  Pass 3: elementwise K1.
 // ---------------------------------------------------------------------------------------------
@@ -802,6 +582,21 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
     }
 }
 
+// Experiment knobs (never needed for correctness): -1 = use the tuned default.
+struct Tuning {
+    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1;
+    static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
+    static Tuning from_env() {
+        Tuning t;
+        t.order = env_int("OQ_RTN_ORDER");      // 0 K-fastest + XCD strips, 1 column tiles fastest, 2 L2-merging blocks
+        t.gk = env_int("OQ_RTN_GK");            // row tiles per id block of order 2
+        t.nt = env_int("OQ_RTN_NT");            // bit 0 non-temporal W loads and [K,N] stores, bit 1 non-temporal blob stores
+        t.stage = env_int("OQ_RTN_STAGE");      // stage (scale, zp) as [K/g, N] + transpose launch
+        t.stage_q = env_int("OQ_RTN_STAGE_Q");  // assemble blob chunks in LDS
+        return t;
+    }
+};
+
 // ------------------------------------------------------------------------------------ dispatch
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -952,8 +747,8 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.scale_t = nullptr; a.zp_t = nullptr;
         const int64_t batch = g_batch.count;
         a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups;
-        static const int env_stage = getenv("OQ_RTN_STAGE") ? atoi(getenv("OQ_RTN_STAGE")) : 1;
-        const bool want_stage = getenv("OQ_RTN_STAGE") ? env_stage != 0 : layout != OQ_LAYOUT_NBITS;
+        static const Tuning tune_s = Tuning::from_env();
+        const bool want_stage = tune_s.stage >= 0 ? tune_s.stage != 0 : layout != OQ_LAYOUT_NBITS;
         const bool staged = want_stage && vec4 && kgroups > 1 && workspace != nullptr &&
                             workspace_bytes >= static_cast<size_t>(batch) * stage_ws(K, N, g) && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
         if (staged) {
@@ -965,50 +760,17 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         if (a.gpb > kgroups) a.gpb = static_cast<int32_t>(kgroups);
         a.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));
         a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, a.gpb));
-        static const int env_order = getenv("OQ_RTN_ORDER") ? atoi(getenv("OQ_RTN_ORDER")) : 1;
-        static const int env_nt = getenv("OQ_RTN_NT") ? atoi(getenv("OQ_RTN_NT")) : 1;
-        static const int env_gk = getenv("OQ_RTN_GK") ? atoi(getenv("OQ_RTN_GK")) : 8;
-        // Tuned on 4096x11008 (profiles/r01_rtn_knob_sweep.txt): the [K,N] byte layout is fastest with plain
-        // column-fastest ids + staged parameters + transpose launch; the MatMulNBits blob is fastest with the
-        // L2-merging order (its 64-byte half lines and the 4-byte scales merge in one L2) and direct n-major stores.
-        const bool merge_order = layout == OQ_LAYOUT_NBITS;
-        a.order = getenv("OQ_RTN_ORDER") ? env_order : (merge_order ? 2 : 1);
-        a.gk = env_gk > 0 ? env_gk : 1;
-        a.nt = env_nt;
-        static const int env_stage_q = getenv("OQ_RTN_STAGE_Q") ? atoi(getenv("OQ_RTN_STAGE_Q")) : 1;
-        a.stage_q = (env_stage_q && layout == OQ_LAYOUT_NBITS && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves &&
-                     kgroups % a.gpb == 0) ? 1 : 0;
+        // Tuned on 4096x11008 (profiles/r01_rtn_knob_sweep.txt).  [K,N] bytes: plain column-fastest ids, parameters
+        // staged [K/g, N] + transpose launch.  MatMulNBits blob: L2-merging id order (its 64-byte half lines and the
+        // 4-byte scales of neighbouring k-groups meet in one L2) + direct n-major parameter stores.  The OQ_RTN_*
+        // environment variables override these choices for experiments only.
+        static const Tuning tune = Tuning::from_env();
+        const bool blob = layout == OQ_LAYOUT_NBITS;
+        a.order = tune.order >= 0 ? tune.order : (blob ? 2 : 1);
+        a.gk = tune.gk > 0 ? tune.gk : 8;
+        a.nt = tune.nt >= 0 ? tune.nt : 1;
+        a.stage_q = ((tune.stage_q != 0) && blob && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves && kgroups % a.gpb == 0) ? 1 : 0;
         const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles * static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
-        static const int env_stream = getenv("OQ_RTN_STREAM") ? atoi(getenv("OQ_RTN_STREAM")) : 0;
-        static const int env_blocks = getenv("OQ_RTN_BLOCKS") ? atoi(getenv("OQ_RTN_BLOCKS")) : 0;
-        if (env_stream && batch == 1 && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves) {
-            // persistent grid: every block gets the same number of units (+-1); all blocks co-resident
-            const uint32_t nunits = a.ncol_tiles * a.nrow_tiles;
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-            uint32_t cap = static_cast<uint32_t>(env_blocks > 0 ? env_blocks : 2 * cus);
-            uint32_t nblocks = nunits < cap ? nunits : cap;
-            if (nunits > cap && env_blocks <= 0) {
-                // prefer a block count that divides the work evenly (equal streams finish together)
-                const uint32_t per = static_cast<uint32_t>(ceil_div(nunits, cap));
-                nblocks = static_cast<uint32_t>(ceil_div(nunits, per));
-            }
-#define OQ_STREAM(EQ, LAY, B)                                                                                  \
-    do {                                                                                                          \
-        if (env_nt) hipLaunchKernelGGL((rtn_group_stream<EQ, LAY, B, true>), dim3(nblocks), block, 0, s, a, nunits); \
-        else hipLaunchKernelGGL((rtn_group_stream<EQ, LAY, B, false>), dim3(nblocks), block, 0, s, a, nunits);     \
-    } while (0)
-            if (!emit_q) OQ_STREAM(false, OQ_LAYOUT_KN, 8);
-            else if (layout == OQ_LAYOUT_KN) OQ_STREAM(true, OQ_LAYOUT_KN, 8);
-            else if (grid.bits == 4) OQ_STREAM(true, OQ_LAYOUT_NBITS, 4);
-            else OQ_STREAM(true, OQ_LAYOUT_NBITS, 8);
-#undef OQ_STREAM
-            st = check_launch("rtn_group_stream");
-            if (st != OQ_OK || !staged) return st;
-            hipLaunchKernelGGL(transpose_qparams, dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32))),
-                               dim3(256), 0, s, a.scale_t, a.zp_t, kgroups, N, scale_out, zp8);
-            return check_launch("transpose_qparams");
-        }
         if (vec4) {
             if (emit_q) launch_fused<true, true>(rpw, a, grid_dim, block, s);
             else launch_fused<true, false>(rpw, a, grid_dim, block, s);
