@@ -459,7 +459,20 @@ __global__ void col_range_finalize(const float* pmin, const float* pmax, int64_t
     zp[col * kgroups + kg] = static_cast<uint8_t>(p.zp);
 }
 
-// Pass 2 (tensor): one block folds every partial into one (scale, zp).
+// Pass 2 (tensor), step 1: per-column fold of all chunk partials, in place into row 0.
+__global__ void col_fold_kernel(float* pmin, float* pmax, int64_t N, int64_t rows) {
+    const int64_t col = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (col >= N) return;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t r = 0; r < rows; ++r) {
+        mn = fminf(mn, pmin[r * N + col]);
+        mx = fmaxf(mx, pmax[r * N + col]);
+    }
+    pmin[col] = mn;
+    pmax[col] = mx;
+}
+
+// Pass 2 (tensor), step 2: one block folds the N column values into one (scale, zp).
 __global__ __launch_bounds__(1024) void tensor_range_finalize(const float* pmin, const float* pmax, int64_t count,
                                                               QGrid grid, float* scale, uint8_t* zp) {
     __shared__ float s_mn[16], s_mx[16];
@@ -484,39 +497,87 @@ __global__ __launch_bounds__(1024) void tensor_range_finalize(const float* pmin,
     }
 }
 
-// Pass 3: q[k, n] = K1(W[k, n]; params[(k / g) + n * kgroups])  (tensor: one entry).
+// Pass 3: q[k, n] = K1(W[k, n]; params[(k / g) + n * kgroups])  (tensor: one entry).  Same tiling as pass 1
+// (128-row chunk x 256 columns, a chunk never straddles a group), parameters fetched once per lane, and the
+// same exact-reciprocal fast path as the fused kernel (band from the worst-case |x / scale| of the grid:
+// (qmax - qmin) / clip_ratio, resp. levels / clip_ratio).
 struct QuantKnArgs {
     const float* W;
-    int64_t K, N, ldw, g, kgroups;
+    int64_t K, N, ldw, g, kgroups, chunks;
     const float* scale;
     const uint8_t* zp;
     uint8_t* q;
-    int32_t qmin, qmax, zp_signed, tensor;
+    QGrid grid;
+    int32_t zp_signed, tensor;
+    uint32_t ncol_tiles, nrow_tiles;
 };
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void quantize_kn(const QuantKnArgs a) {
-    const int64_t cols4 = VEC4 ? a.N / 4 : a.N;
-    const int64_t total = a.K * cols4;
-    for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
-         t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int64_t k = t / cols4, c = t - k * cols4;
-        if constexpr (VEC4) {
-            const float4 x = *reinterpret_cast<const float4*>(a.W + k * a.ldw + c * 4);
-            const float xs[4] = {x.x, x.y, x.z, x.w};
-            uint32_t w = 0;
+__global__ __launch_bounds__(kMaxWaves* kWave) void quantize_kn(const QuantKnArgs a) {
+    constexpr int RPW = kChunkRows / kMaxWaves;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t row_tile = blockIdx.x / a.ncol_tiles;          // column tiles fastest
+    const uint32_t col_tile = blockIdx.x - row_tile * a.ncol_tiles;
+    const int64_t kg = row_tile / a.chunks, c = row_tile % a.chunks;
+    const int64_t row_end = min(kg * a.g + a.g, a.K);
+    const int64_t row0 = kg * a.g + c * kChunkRows + wave * RPW;
+    const int64_t tile_col0 = static_cast<int64_t>(col_tile) * kColsPerWave;
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    const int32_t bias = qmin < 0 ? 128 : 0;
+    const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+    // x 1.25: the MSE search (rtn_mse.hip) hands over parameters of a range shrunk by p >= 0.81
+    const float worst = 1.25f * (a.grid.symmetric ? static_cast<float>(a.grid.levels) : static_cast<float>(qmax - qmin)) / a.grid.clip_ratio;
+
+    ColQ cq[4];
+    bool col_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t col = slot_col<VEC4>(tile_col0, lane, i);
+        col_ok[i] = col < a.N;
+        const int64_t pi = a.tensor ? 0 : (col_ok[i] ? col : a.N - 1) * a.kgroups + kg;
+        QParam p;
+        p.scale = a.scale[pi];
+        p.zp = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.zp[pi])) : static_cast<int32_t>(a.zp[pi]);
+        // raw extrema are not kept by pass 2; |x| <= worst * scale holds for every element of the group
+        cq[i] = make_colq(p, -worst * p.scale, worst * p.scale, bias);
+    }
+    const uint32_t flip = bias ? 0x80808080u : 0u;
+    if constexpr (VEC4) {
+        int64_t lcol = tile_col0 + lane * 4;
+        lcol = lcol < a.N ? lcol : a.N - 4;
+        float4 t[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int64_t row = row0 + r < row_end ? row0 + r : row_end - 1;   // clamped, never predicated
+            const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.W + row * a.ldw + lcol));
+            t[r] = make_float4(u[0], u[1], u[2], u[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const float xs[4] = {t[r].x, t[r].y, t[r].z, t[r].w};
+            float f[4];
+            bool unsafe = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(xs[i], cq[i], lo_b, hi_b, unsafe);
+            if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(xs[i], cq[i], qmin, qmax, bias);
+            }
+            uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
+            if (col_ok[0] && row0 + r < row_end)
+                __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(a.q + (row0 + r) * a.N + tile_col0 + lane * 4));
+        }
+    } else {
+        for (int r = 0; r < RPW; ++r)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int64_t pi = a.tensor ? 0 : (c * 4 + i) * a.kgroups + k / a.g;
-                const int32_t z = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.zp[pi])) : static_cast<int32_t>(a.zp[pi]);
-                w |= (static_cast<uint32_t>(quantize_one(xs[i], a.scale[pi], z, a.qmin, a.qmax)) & 0xffu) << (8 * i);
+                const int64_t col = slot_col<false>(tile_col0, lane, i);
+                if (col_ok[i] && row0 + r < row_end)
+                    a.q[(row0 + r) * a.N + col] = static_cast<uint8_t>(quantize_one(a.W[(row0 + r) * a.ldw + col], cq[i].scale, cq[i].zp, qmin, qmax));
             }
-            *reinterpret_cast<uint32_t*>(a.q + k * a.N + c * 4) = w;
-        } else {
-            const int64_t pi = a.tensor ? 0 : c * a.kgroups + k / a.g;
-            const int32_t z = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.zp[pi])) : static_cast<int32_t>(a.zp[pi]);
-            a.q[k * a.N + c] = static_cast<uint8_t>(quantize_one(a.W[k * a.ldw + c], a.scale[pi], z, a.qmin, a.qmax));
-        }
     }
 }
 
@@ -671,18 +732,20 @@ int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QG
                      size_t workspace_bytes, hipStream_t s, bool emit_q);
 size_t rtn_mse_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
 
-// Pass 3 of the two-pass path (also the final pass of the MSE search): elementwise K1 with stored parameters.
+// Pass 3 of the two-pass path (also the final pass of the MSE search): K1 with stored parameters.
 int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t g, int64_t kgroups, const float* scale,
                            const uint8_t* zp, uint8_t* q, const QGrid& grid, int32_t zp_signed, bool tensor, hipStream_t s) {
     QuantKnArgs qa;
     qa.W = W; qa.K = K; qa.N = N; qa.ldw = ldw; qa.g = g; qa.kgroups = kgroups;
+    qa.chunks = ceil_div(g, kChunkRows);
     qa.scale = scale; qa.zp = zp; qa.q = q;
-    qa.qmin = grid.qmin; qa.qmax = grid.qmax; qa.zp_signed = zp_signed; qa.tensor = tensor;
+    qa.grid = grid; qa.zp_signed = zp_signed; qa.tensor = tensor;
+    qa.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));
+    qa.nrow_tiles = static_cast<uint32_t>(kgroups * qa.chunks);
     const bool vec4 = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(W) && (reinterpret_cast<uintptr_t>(q) & 3u) == 0;
-    const int64_t work = vec4 ? K * (N / 4) : K * N;
-    const uint32_t blocks = static_cast<uint32_t>(work / 256 + 1 < 256 * 16 ? work / 256 + 1 : 256 * 16);
-    if (vec4) hipLaunchKernelGGL(quantize_kn<true>, dim3(blocks), dim3(256), 0, s, qa);
-    else hipLaunchKernelGGL(quantize_kn<false>, dim3(blocks), dim3(256), 0, s, qa);
+    const dim3 grid_dim(qa.ncol_tiles * qa.nrow_tiles), block(kMaxWaves * kWave);
+    if (vec4) hipLaunchKernelGGL(quantize_kn<true>, grid_dim, block, 0, s, qa);
+    else hipLaunchKernelGGL(quantize_kn<false>, grid_dim, block, 0, s, qa);
     return check_launch("quantize_kn");
 }
 
@@ -806,8 +869,10 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     st = check_launch("col_range_partial");
     if (st != OQ_OK) return st;
     if (strategy == OQ_TENSOR) {
-        hipLaunchKernelGGL(tensor_range_finalize, dim3(1), dim3(1024), 0, s, r.pmin, r.pmax, kgroups * r.chunks * N, grid,
-                           scale_out, zp8);
+        // fold the chunks per column in parallel (into the first row of the partial arrays), then one block folds N values
+        hipLaunchKernelGGL(col_fold_kernel, dim3(static_cast<uint32_t>(ceil_div(N, 256))), dim3(256), 0, s, r.pmin, r.pmax, N,
+                           kgroups * r.chunks);
+        hipLaunchKernelGGL(tensor_range_finalize, dim3(1), dim3(1024), 0, s, r.pmin, r.pmax, N, grid, scale_out, zp8);
     } else {
         hipLaunchKernelGGL(col_range_finalize, dim3(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups)),
                            dim3(256), 0, s, r.pmin, r.pmax, N, kgroups, r.chunks, grid, scale_out, zp8);
