@@ -282,7 +282,7 @@ def main() -> None:
             "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "oq::rtn_group_fused<16,true,true,true>" + (" + oq::transpose_qparams" if args.layout == "kn" else ""),
+                     "kernel": "oq::rtn_group_wave<8,true>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
                      "launch_us": round(launch_us, 2),
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
     }

@@ -10,6 +10,22 @@
 
 namespace oq {
 
+// Division of a block id by a launch constant without the ~30-instruction integer-divide expansion: the quotient
+// estimate float(n) * fl(1/d) is within 1 of n / d for n < 2^22 and is corrected with the exact remainder.
+struct FastDiv {
+    uint32_t d;
+    float rcp;
+};
+static inline FastDiv make_fastdiv(uint32_t d) { return FastDiv{d, 1.0f / static_cast<float>(d)}; }
+__device__ __forceinline__ uint32_t fast_divmod(uint32_t n, const FastDiv& f, uint32_t& rem) {
+    uint32_t q = static_cast<uint32_t>(static_cast<float>(n) * f.rcp);
+    int32_t r = static_cast<int32_t>(n - q * f.d);
+    if (r < 0) { --q; r += static_cast<int32_t>(f.d); }
+    else if (r >= static_cast<int32_t>(f.d)) { ++q; r -= static_cast<int32_t>(f.d); }
+    rem = static_cast<uint32_t>(r);
+    return q;
+}
+
 struct RtnArgs {
     const float* W;
     int64_t K, N, ldw;
@@ -29,11 +45,15 @@ struct RtnArgs {
     int32_t nt;       // non-temporal loads of W
     int32_t stage_q;  // NBITS: transpose the block's packed output through LDS (64/128-byte chunks per column)
     int32_t gk;       // order 2: row tiles per id chunk (see the block order in rtn_group_fused)
+    FastDiv fd_ncol, fd_band, fd_chunk;  // ncol_tiles, ncol_tiles * gk, 8 * gk (block ids < 2^22, checked by the host)
+    int32_t spb_log2;  // wave kernel: log2(strips per block)
     // strided batch (oq_rtn_quantize_batched_f32): matrix b lives at base + b * stride (elements / bytes as noted)
     int64_t w_stride, q_stride, p_stride;  // fp32 elements of W; bytes of q; entries of scale / zp (also of the staging)
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kColsPerWave = 256;  // 64 lanes x 4 columns: 1 KiB of one fp32 row per wave-instruction
 constexpr int kMaxWaves = 8;
@@ -60,6 +80,42 @@ __device__ __forceinline__ void store_words(uint8_t* dst, const uint32_t (&w)[NW
     }
 }
 
+// Block id -> (row tile, column tile).  Speed only: every order visits every tile exactly once.
+__device__ __forceinline__ void tile_of_block(const RtnArgs& a, uint32_t bid, uint32_t nblk, uint32_t& row_tile, uint32_t& col_tile) {
+    if (a.order == 0) {
+        const uint32_t id = xcd_remap(bid, nblk);
+        col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
+        row_tile = id - col_tile * a.nrow_tiles;
+    } else if (a.order == 1) {
+        row_tile = fast_divmod(bid, a.fd_ncol, col_tile);  // column tiles fastest: co-resident blocks stream whole rows
+    } else {
+        // Column tiles fastest over bands of `gk` row tiles, ids blocked as [8 column tiles] x [gk row tiles] with
+        // the column tile in the low 3 bits: blocks of one column tile and neighbouring k-groups are 8 ids apart,
+        // i.e. on one XCD at about the same time (observed round-robin placement; speed only).  Pieces of one
+        // 128-byte line that different blocks produce -- the two 64-byte halves of a MatMulNBits line, the 4-byte
+        // scales of neighbouring k-groups -- then merge in that XCD's L2 before they are written back, while a
+        // band still streams whole rows of W.
+        uint32_t r;
+        const uint32_t b = fast_divmod(bid, a.fd_band, r);
+        const uint32_t gk_eff = min(static_cast<uint32_t>(a.gk), a.nrow_tiles - b * a.gk);
+        uint32_t cc;
+        if (gk_eff == static_cast<uint32_t>(a.gk)) {
+            cc = fast_divmod(r, a.fd_chunk, r);
+        } else {  // last, shorter band
+            cc = r / (8u * gk_eff);
+            r -= cc * 8u * gk_eff;
+        }
+        const uint32_t w = min(8u, a.ncol_tiles - cc * 8u);
+        if (w == 8u) {
+            row_tile = b * a.gk + (r >> 3);
+            col_tile = cc * 8u + (r & 7u);
+        } else {  // last, narrower chunk of column tiles
+            row_tile = b * a.gk + r / w;
+            col_tile = cc * 8u + r % w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused one-pass kernel.  One block = GPB groups (stacked along K) x 256 columns; one group =
 // WPG waves x RPW rows.  Registers per lane: RPW x 4 fp32 of W.
@@ -76,8 +132,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
 
     const uint32_t nblk = a_in.ncol_tiles * a_in.nrow_tiles;
     // Batched launch: block ids run over all matrices, so the tail of one matrix overlaps the head of the next.
-    const uint32_t mat = blockIdx.x / nblk;
-    const uint32_t bid = blockIdx.x - mat * nblk;
+    const uint32_t mat = blockIdx.y;   // strided batch: x runs fastest, so the tail of one matrix overlaps the head of the next
+    const uint32_t bid = blockIdx.x;
     RtnArgs a = a_in;
     a.W += static_cast<int64_t>(mat) * a.w_stride;
     if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
@@ -85,30 +141,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     a.zp += static_cast<int64_t>(mat) * a.p_stride;
     if (a.scale_t) { a.scale_t += static_cast<int64_t>(mat) * a.p_stride; a.zp_t += static_cast<int64_t>(mat) * a.p_stride; }
     uint32_t col_tile, row_tile;
-    if (a.order == 0) {
-        const uint32_t id = xcd_remap(bid, nblk);
-        col_tile = id / a.nrow_tiles;   // K-direction fastest: an XCD owns whole column strips
-        row_tile = id - col_tile * a.nrow_tiles;
-    } else if (a.order == 1) {
-        row_tile = bid / a.ncol_tiles;  // column tiles fastest: co-resident blocks stream whole rows
-        col_tile = bid - row_tile * a.ncol_tiles;
-    } else {
-        // Column tiles fastest over bands of `gk` row tiles, ids blocked as [8 column tiles] x [gk row tiles] with
-        // the column tile in the low 3 bits: blocks of one column tile and neighbouring k-groups are 8 ids apart,
-        // i.e. on one XCD at about the same time (observed round-robin placement; speed only).  Pieces of one
-        // 128-byte line that different blocks produce -- the two 64-byte halves of a MatMulNBits line, the 4-byte
-        // scales of neighbouring k-groups -- then merge in that XCD's L2 before they are written back, while a
-        // band still streams whole rows of W.
-        const uint32_t band_sz = a.ncol_tiles * a.gk;
-        const uint32_t b = bid / band_sz;
-        uint32_t r = bid - b * band_sz;
-        const uint32_t gk_eff = min(static_cast<uint32_t>(a.gk), a.nrow_tiles - b * a.gk);
-        const uint32_t cc = r / (8u * gk_eff);
-        r -= cc * 8u * gk_eff;
-        const uint32_t w = min(8u, a.ncol_tiles - cc * 8u);
-        row_tile = b * a.gk + r / w;
-        col_tile = cc * 8u + r % w;
-    }
+    tile_of_block(a, bid, nblk, row_tile, col_tile);
 
     const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + gib;
     const bool group_ok = kg < a.kgroups;
@@ -356,6 +389,146 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                     store_words<RPW / 4>(o + wig * RPW, words);
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-owns-group kernel for the MatMulNBits blob.  One wave = one k-group of G = 16 * (64 / LPR)
+// rows x (4 * LPR) columns: LPR lanes span one row piece (LPR x 16 B), the 64 / LPR lane sets `h`
+// hold 16 consecutive rows each, so a wave-instruction loads 64 / LPR row pieces.  The group's
+// column range is folded lane-locally over 16 rows and then across the lane sets with xor
+// butterflies: no LDS, no barrier, waves never wait for each other.  In the blob a lane's 16 rows
+// of a column are 8 (4-bit) / 16 (8-bit) consecutive bytes and the lane sets of a column are
+// adjacent, so one store instruction writes whole 64 / 128-byte chunks.  G = 128 for LPR = 8.
+// ---------------------------------------------------------------------------------------------
+template <int LPR, bool EMIT_Q>
+__global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs a_in) {
+    constexpr int RS = 64 / LPR;  // lane sets (row sub-ranges) per wave
+    constexpr int G = 16 * RS;    // rows per group
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane / LPR, cl = lane % LPR;
+
+    const uint32_t nblk = a_in.ncol_tiles * a_in.nrow_tiles;
+    const uint32_t mat = blockIdx.y;   // strided batch: x runs fastest, so the tail of one matrix overlaps the head of the next
+    const uint32_t bid = blockIdx.x;
+    RtnArgs a = a_in;
+    a.W += static_cast<int64_t>(mat) * a.w_stride;
+    if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
+    a.scale += static_cast<int64_t>(mat) * a.p_stride;
+    a.zp += static_cast<int64_t>(mat) * a.p_stride;
+    uint32_t col_tile, row_tile;
+    tile_of_block(a, bid, nblk, row_tile, col_tile);
+
+    // block = gpb k-groups x spb strips of 4 * LPR columns; neighbouring strips on neighbouring waves
+    const int spb = 1 << a.spb_log2;
+    const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + (wave >> a.spb_log2);
+    const int64_t c0 = (static_cast<int64_t>(col_tile) * spb + (wave & (spb - 1))) * (4 * LPR) + cl * 4;
+    if (kg >= a.kgroups || c0 - cl * 4 >= a.N) return;  // wave-uniform; nothing below synchronises
+    const bool col_ok = c0 < a.N;                       // N % 4 == 0: a lane's four columns are in or out together
+
+    float v[16][4];
+    {
+        const float* p = a.W + (kg * G + h * 16) * a.ldw + (col_ok ? c0 : a.N - 4);  // clamped, never predicated
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + r * a.ldw));
+            v[r][0] = u[0]; v[r][1] = u[1]; v[r][2] = u[2]; v[r][3] = u[3];
+        }
+    }
+    float mn[4], mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mn[i] = mx[i] = v[0][i];
+#pragma unroll
+    for (int r = 1; r < 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], v[r][i]);
+            mx[i] = fmaxf(mx[i], v[r][i]);
+        }
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = fminf(mn[i], __shfl_xor(mn[i], off, 64));
+            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], off, 64));
+        }
+
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    const int32_t bias = qmin < 0 ? (a.grid.bits == 4 ? 8 : 128) : 0;
+    ColQ cq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const QParam p = qparam_from_minmax(mn[i], mx[i], a.grid);
+        cq[i] = make_colq(p, mn[i], mx[i], bias);
+    }
+    // rtn.py:98-109 result layout (entry n * K/g + kg)
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += RS) {
+        const int j = j0 + h;
+        if (j < 4 && col_ok) {
+            const float s = j == 0 ? cq[0].scale : j == 1 ? cq[1].scale : j == 2 ? cq[2].scale : cq[3].scale;
+            const int32_t z = j == 0 ? cq[0].zp : j == 1 ? cq[1].zp : j == 2 ? cq[2].zp : cq[3].zp;
+            const int64_t o = (c0 + j) * a.kgroups + kg;
+            a.scale[o] = s;
+            a.zp[o] = static_cast<uint8_t>(z);
+        }
+    }
+    if constexpr (!EMIT_Q) return;
+
+    const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float f[4];
+        bool unsafe = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(v[r][i], cq[i], lo_b, hi_b, unsafe);
+        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(v[r][i], cq[i], qmin, qmax, bias);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[r][i] = f[i];
+    }
+    if (!col_ok) return;
+
+    // qrules/_common.py:72-87: out-channel n, k-group kg -> G * bits / 8 bytes, k ascending, even k in the low nibble
+    if (a.grid.bits == 4) {
+        const uint32_t flip = bias ? 0x88888888u : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t words[2];
+#pragma unroll
+            for (int wd = 0; wd < 2; ++wd) {
+                uint32_t ev = 0, od = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ev = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 8 + 2 * j][i], j, ev);
+                    od = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 8 + 2 * j + 1][i], j, od);
+                }
+                words[wd] = (ev | (od << 4)) ^ flip;
+            }
+            u32x2* o = reinterpret_cast<u32x2*>(a.q + ((c0 + i) * a.kgroups + kg) * (G / 2) + h * 8);
+            const u32x2 t = {words[0], words[1]};
+            if (a.nt & 2) __builtin_nontemporal_store(t, o);
+            else *o = t;
+        }
+    } else {
+        const uint32_t flip = bias ? 0x80808080u : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t words[4];
+#pragma unroll
+            for (int wd = 0; wd < 4; ++wd) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 4 + j][i], j, acc);
+                words[wd] = acc ^ flip;
+            }
+            u32x4* o = reinterpret_cast<u32x4*>(a.q + ((c0 + i) * a.kgroups + kg) * G + h * 16);
+            const u32x4 t = {words[0], words[1], words[2], words[3]};
+            if (a.nt & 2) __builtin_nontemporal_store(t, o);
+            else *o = t;
         }
     }
 }
@@ -645,7 +818,7 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
 
 // Experiment knobs (never needed for correctness): -1 = use the tuned default.
 struct Tuning {
-    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1;
+    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1;
     static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
     static Tuning from_env() {
         Tuning t;
@@ -654,6 +827,9 @@ struct Tuning {
         t.nt = env_int("OQ_RTN_NT");            // bit 0 non-temporal W loads and [K,N] stores, bit 1 non-temporal blob stores
         t.stage = env_int("OQ_RTN_STAGE");      // stage (scale, zp) as [K/g, N] + transpose launch
         t.stage_q = env_int("OQ_RTN_STAGE_Q");  // assemble blob chunks in LDS
+        t.wavek = env_int("OQ_RTN_WAVEK");      // blob layout: wave-owns-group kernel (1) or the block kernel (0)
+        t.gpb = env_int("OQ_RTN_GPB");          // wave kernel: k-groups per block
+        t.wpb = env_int("OQ_RTN_WPB");          // wave kernel: waves per block
         return t;
     }
 };
@@ -676,6 +852,16 @@ static bool fused_shape(int64_t g, int* rpw, int* wpg) {
         return true;
     }
     return false;
+}
+
+// Fills the id-division constants of the chosen block order; ids beyond the fast-division range use order 0.
+static void set_block_order(RtnArgs& a) {
+    if (a.gk < 1) a.gk = 1;
+    const uint64_t nblk = static_cast<uint64_t>(a.ncol_tiles) * a.nrow_tiles;
+    if (nblk >= (1u << 22)) a.order = 0;
+    a.fd_ncol = make_fastdiv(a.ncol_tiles);
+    a.fd_band = make_fastdiv(a.ncol_tiles * static_cast<uint32_t>(a.gk));
+    a.fd_chunk = make_fastdiv(8u * static_cast<uint32_t>(a.gk));
 }
 
 template <bool VEC4, bool EMIT_Q>
@@ -803,6 +989,45 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
                    "NBITS layout needs group_size %% 16 == 0 and a 16-byte aligned output");
     }
 
+    // MatMulNBits blob with a group of 32 / 64 / 128 rows: wave-owns-group kernel (no LDS, no barrier)
+    {
+        static const Tuning tw = Tuning::from_env();
+        const bool wave_ok = strategy == OQ_GROUP && layout == OQ_LAYOUT_NBITS && vec4 && (g == 32 || g == 64 || g == 128) && tw.wavek != 0;
+        if (wave_ok) {
+            OQ_REQUIRE(emit_q && aligned16(q_out), OQ_ERR_UNSUPPORTED, "NBITS layout needs a 16-byte aligned output");
+            RtnArgs a;
+            a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
+            a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
+            a.scale_t = nullptr; a.zp_t = nullptr; a.wpg = 1; a.stage_q = 0;
+            const int64_t batch = g_batch.count;
+            a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups;
+            const int lpr = static_cast<int>(1024 / g);
+            int wpb = tw.wpb > 0 ? tw.wpb : 4;
+            if (wpb > kMaxWaves) wpb = kMaxWaves;
+            while (wpb & (wpb - 1)) wpb &= wpb - 1;   // power of two
+            int gpb = tw.gpb > 0 ? tw.gpb : 1;
+            while (gpb & (gpb - 1)) gpb &= gpb - 1;
+            while (gpb > 1 && (gpb > wpb || gpb > kgroups)) gpb >>= 1;
+            a.gpb = gpb;
+            a.spb_log2 = 0;
+            while ((1 << (a.spb_log2 + 1)) <= wpb / gpb) ++a.spb_log2;
+            const int64_t nstrips = ceil_div(N, 4 * lpr);
+            a.ncol_tiles = static_cast<uint32_t>(ceil_div(nstrips, wpb / gpb));
+            a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, gpb));
+            a.order = tw.order >= 0 ? tw.order : 2;
+            a.gk = tw.gk > 0 ? tw.gk : 8;
+            a.nt = tw.nt >= 0 ? tw.nt : 1;
+            set_block_order(a);
+            const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(wpb * kWave));
+            switch (lpr) {
+                case 8: hipLaunchKernelGGL((rtn_group_wave<8, true>), grid_dim, block, 0, s, a); break;
+                case 16: hipLaunchKernelGGL((rtn_group_wave<16, true>), grid_dim, block, 0, s, a); break;
+                default: hipLaunchKernelGGL((rtn_group_wave<32, true>), grid_dim, block, 0, s, a); break;
+            }
+            return check_launch("rtn_group_wave");
+        }
+    }
+
     if (fused) {
         RtnArgs a;
         a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
@@ -833,7 +1058,9 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.gk = tune.gk > 0 ? tune.gk : 8;
         a.nt = tune.nt >= 0 ? tune.nt : 1;
         a.stage_q = ((tune.stage_q != 0) && blob && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves && kgroups % a.gpb == 0) ? 1 : 0;
-        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles * static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        a.spb_log2 = 0;
+        set_block_order(a);
+        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
         if (vec4) {
             if (emit_q) launch_fused<true, true>(rpw, a, grid_dim, block, s);
             else launch_fused<true, false>(rpw, a, grid_dim, block, s);

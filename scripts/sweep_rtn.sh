@@ -1,9 +1,15 @@
 #!/bin/bash
+# Knob sweep of the headline RTN kernel (run on the GPU box through gpurun): scripts/sweep_rtn.sh > gpurun_out/sweepN.log
 cd $GRAFT_REPO_ROOT
-run() { r=$(env "$@" python bench.py --no-cpu-baseline --steps 400 --warmup 40 $MODE 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['launch_us'], d['verified_vs_reference_digest'])"); echo "$* mode='$MODE' -> launch_us,verified = $r"; }
-for MODE in "--layout nbits" ""; do
-run OQ_RTN_WAVES=16 OQ_RTN_ORDER=1 OQ_RTN_STAGE=1
-run OQ_RTN_WAVES=16 OQ_RTN_ORDER=1 OQ_RTN_STAGE=0
-for gk in 2 4 8; do run OQ_RTN_WAVES=16 OQ_RTN_ORDER=2 OQ_RTN_GK=$gk OQ_RTN_STAGE=0; done
-run OQ_RTN_WAVES=8 OQ_RTN_ORDER=2 OQ_RTN_GK=8 OQ_RTN_STAGE=0
-done
+MODE="--layout nbits"
+run() { r=$(env "$@" python bench.py --no-cpu-baseline --no-extras --steps 400 --warmup 40 $MODE 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['launch_us'], d['verified_vs_reference_digest'])"); echo "$* mode='$MODE' -> launch_us,verified = $r"; }
+run A=0
+run OQ_RTN_MINW=5
+run OQ_RTN_MINW=6
+run OQ_RTN_WPB=8
+run OQ_RTN_WPB=2
+run OQ_RTN_ORDER=1
+run OQ_RTN_WAVEK=0
+run A=0
+MODE="--layout kn"
+run A=0

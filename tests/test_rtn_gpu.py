@@ -135,17 +135,47 @@ def test_full_size_digests(ops, key):
 def test_nbits_layout_matches_reference_packing(ops):
     """OQ_LAYOUT_NBITS == qrules/_common.py:65-123 applied to the [K, N] result."""
     rng = np.random.default_rng(17)
+    # g in {32, 64, 128}: wave-owns-group kernel (ragged right edges: n % 32, n % 64, n % 128 != 0); other g: block kernel
     for (k, n, g, qtype) in [(512, 520, 128, "uint4"), (256, 36, 16, "uint4"), (512, 260, 64, "uint8"),
-                             (768, 256, 256, "uint4"), (160, 40, 32, "uint8")]:
+                             (768, 256, 256, "uint4"), (160, 40, 32, "uint8"), (384, 1100, 128, "uint8"),
+                             (1024, 172, 64, "uint4"), (96, 2052, 32, "uint4"), (128, 4, 128, "uint4"),
+                             (4096, 96, 128, "uint4")]:
         w = rng.standard_normal((k, n), dtype=np.float32)
         eq, es, ez = O.rtn_quantize(w, qtype, "group", g)
         eb, es2, epz = O.matmul_nbits_layout(eq, es, ez, g, O.BITWIDTH[qtype])
         b, s, z = ops.rtn_quantize(dev(w), qtype, "group", g, layout="nbits")
         np.testing.assert_array_equal(b.cpu().numpy(), eb)
         assert s.cpu().numpy().reshape(n, k // g).tobytes() == es2.tobytes()
+        np.testing.assert_array_equal(z.cpu().numpy().reshape(-1), ez.reshape(-1))
         if qtype == "uint4" and k // g > 1:
             pz = ops.pack_zero_points_u4(z, n, k // g)
             np.testing.assert_array_equal(pz.cpu().numpy(), epz)
+        # the same matrix as a column slice of a wider one (leading dimension > N, 16-byte aligned start)
+        wide = np.zeros((k, n + 24), np.float32)
+        wide[:, 8:8 + n] = w
+        b2, s2, z2 = ops.rtn_quantize(dev(wide)[:, 8:8 + n], qtype, "group", g, layout="nbits")
+        np.testing.assert_array_equal(b2.cpu().numpy(), eb)
+        assert s2.cpu().numpy().tobytes() == s.cpu().numpy().tobytes()
+
+
+@pytest.mark.parametrize("qtype,g,sym,rr,clip", [("int4", 128, False, False, 1.0), ("int4", 64, True, False, 0.9),
+                                                 ("int8", 128, True, True, 1.0), ("uint8", 32, True, False, 0.75),
+                                                 ("uint4", 128, True, False, 1.0), ("int8", 32, False, True, 0.5)])
+def test_nbits_layout_signed_symmetric_clipped(ops, qtype, g, sym, rr, clip):
+    """The blob kernels against the oracle for the grids MatMulNBits itself never sees (signed, symmetric, reduced,
+    clipped): same integers as the [K, N] result, packed by qrules/_common.py:72-87's rule; heavy tails + zero groups."""
+    rng = np.random.default_rng(23)
+    k, n = 512, 296
+    w = rng.standard_t(3, (k, n)).astype(np.float32)
+    w[:g, :7] = 0.0                                    # all-zero groups: the tiny-scale guard (utils.py:262-263)
+    eq, es, ez = O.rtn_quantize(w, qtype, "group", g, sym, rr, clip)
+    bits = O.BITWIDTH[qtype]
+    u = (eq.astype(np.int16) & (0xF if bits == 4 else 0xFF)).astype(np.uint8)   # two's-complement nibbles / bytes
+    eb, _, _ = O.matmul_nbits_layout(u, es, ez, g, bits)
+    b, s, z = ops.rtn_quantize(dev(w), qtype, "group", g, sym, rr, clip, layout="nbits")
+    np.testing.assert_array_equal(b.cpu().numpy(), eb)
+    assert s.cpu().numpy().tobytes() == es.tobytes()
+    np.testing.assert_array_equal(z.cpu().numpy().reshape(-1), ez.reshape(-1))
 
 
 def test_roundtrip_property_full_size(ops):
