@@ -406,7 +406,8 @@ template <int LPR, bool EMIT_Q>
 __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs a_in) {
     constexpr int RS = 64 / LPR;  // lane sets (row sub-ranges) per wave
     constexpr int G = 16 * RS;    // rows per group
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar address math below
     const int h = lane / LPR, cl = lane % LPR;
 
     const uint32_t nblk = a_in.ncol_tiles * a_in.nrow_tiles;
@@ -423,16 +424,21 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
     // block = gpb k-groups x spb strips of 4 * LPR columns; neighbouring strips on neighbouring waves
     const int spb = 1 << a.spb_log2;
     const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + (wave >> a.spb_log2);
-    const int64_t c0 = (static_cast<int64_t>(col_tile) * spb + (wave & (spb - 1))) * (4 * LPR) + cl * 4;
-    if (kg >= a.kgroups || c0 - cl * 4 >= a.N) return;  // wave-uniform; nothing below synchronises
-    const bool col_ok = c0 < a.N;                       // N % 4 == 0: a lane's four columns are in or out together
+    const int64_t strip0 = (static_cast<int64_t>(col_tile) * spb + (wave & (spb - 1))) * (4 * LPR);
+    if (kg >= a.kgroups || strip0 >= a.N) return;  // wave-uniform; nothing below synchronises
+    const int64_t c0 = strip0 + cl * 4;
+    const bool col_ok = c0 < a.N;                  // N % 4 == 0: a lane's four columns are in or out together
 
     float v[16][4];
     {
-        const float* p = a.W + (kg * G + h * 16) * a.ldw + (col_ok ? c0 : a.N - 4);  // clamped, never predicated
+        // scalar row base + one 32-bit lane offset for all 16 loads (host guarantees 112 * ldw * 4 + 4 * N < 2^32);
+        // lanes past the right edge read a clamped address, never a predicated load
+        const char* base = reinterpret_cast<const char*>(a.W + kg * G * a.ldw + strip0);
+        const uint32_t loff = static_cast<uint32_t>(h * 16 * a.ldw + (col_ok ? cl * 4 : a.N - 4 - strip0)) * 4u;
+        const int64_t row_bytes = a.ldw * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + r * a.ldw));
+            const f32x4 u = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + r * row_bytes + loff));
             v[r][0] = u[0]; v[r][1] = u[1]; v[r][2] = u[2]; v[r][3] = u[3];
         }
     }
@@ -456,22 +462,29 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
 
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
     const int32_t bias = qmin < 0 ? (a.grid.bits == 4 ? 8 : 128) : 0;
-    ColQ cq[4];
+    // per column: scale, fl(1/scale), float(zp + bias); one safety band for the four columns (the narrowest).
+    // Fewer live registers than four full ColQ records (102 VGPRs, 4 waves per SIMD; forcing 96 for a fifth wave
+    // spills 7 dwords and measured 44.7 us against 41.0).
+    float sc[4], rinv[4], zpb[4], thr;
+    {
+        ColQ c = make_colq(qparam_from_minmax(mn[0], mx[0], a.grid), mn[0], mx[0], bias);
+        sc[0] = c.scale; rinv[0] = c.rinv; zpb[0] = c.zpb; thr = c.thr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const QParam p = qparam_from_minmax(mn[i], mx[i], a.grid);
-        cq[i] = make_colq(p, mn[i], mx[i], bias);
+        for (int i = 1; i < 4; ++i) {
+            c = make_colq(qparam_from_minmax(mn[i], mx[i], a.grid), mn[i], mx[i], bias);
+            sc[i] = c.scale; rinv[i] = c.rinv; zpb[i] = c.zpb; thr = fminf(thr, c.thr);
+        }
     }
-    // rtn.py:98-109 result layout (entry n * K/g + kg)
+    // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
 #pragma unroll
     for (int j0 = 0; j0 < 4; j0 += RS) {
         const int j = j0 + h;
         if (j < 4 && col_ok) {
-            const float s = j == 0 ? cq[0].scale : j == 1 ? cq[1].scale : j == 2 ? cq[2].scale : cq[3].scale;
-            const int32_t z = j == 0 ? cq[0].zp : j == 1 ? cq[1].zp : j == 2 ? cq[2].zp : cq[3].zp;
+            const float s = j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3];
+            const float z = j == 0 ? zpb[0] : j == 1 ? zpb[1] : j == 2 ? zpb[2] : zpb[3];
             const int64_t o = (c0 + j) * a.kgroups + kg;
             a.scale[o] = s;
-            a.zp[o] = static_cast<uint8_t>(z);
+            a.zp[o] = static_cast<uint8_t>(static_cast<int32_t>(z) - bias);
         }
     }
     if constexpr (!EMIT_Q) return;
@@ -482,10 +495,16 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
         float f[4];
         bool unsafe = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(v[r][i], cq[i], lo_b, hi_b, unsafe);
-        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {
+        for (int i = 0; i < 4; ++i) {
+            const float t = v[r][i] * rinv[i];
+            const float k = rintf(t);
+            unsafe = unsafe || !(fabsf(t - k) < thr);
+            f[i] = __builtin_amdgcn_fmed3f(k + zpb[i], lo_b, hi_b);
+        }
+        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {  // wave-uniform, rare: redo this row with the IEEE divide
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(v[r][i], cq[i], qmin, qmax, bias);
+            for (int i = 0; i < 4; ++i)
+                f[i] = static_cast<float>(quantize_one(v[r][i], sc[i], static_cast<int32_t>(zpb[i]) - bias, qmin, qmax) + bias);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[r][i] = f[i];
@@ -992,7 +1011,8 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     // MatMulNBits blob with a group of 32 / 64 / 128 rows: wave-owns-group kernel (no LDS, no barrier)
     {
         static const Tuning tw = Tuning::from_env();
-        const bool wave_ok = strategy == OQ_GROUP && layout == OQ_LAYOUT_NBITS && vec4 && (g == 32 || g == 64 || g == 128) && tw.wavek != 0;
+        const bool wave_ok = strategy == OQ_GROUP && layout == OQ_LAYOUT_NBITS && vec4 && (g == 32 || g == 64 || g == 128) && tw.wavek != 0 &&
+                             ldw < (1 << 22);   // 32-bit lane offsets
         if (wave_ok) {
             OQ_REQUIRE(emit_q && aligned16(q_out), OQ_ERR_UNSUPPORTED, "NBITS layout needs a 16-byte aligned output");
             RtnArgs a;

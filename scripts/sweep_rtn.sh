@@ -5,11 +5,5 @@ MODE="--layout nbits"
 run() { r=$(env "$@" python bench.py --no-cpu-baseline --no-extras --steps 400 --warmup 40 $MODE 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['launch_us'], d['verified_vs_reference_digest'])"); echo "$* mode='$MODE' -> launch_us,verified = $r"; }
 run A=0
 run OQ_RTN_MINW=5
-run OQ_RTN_MINW=6
-run OQ_RTN_WPB=8
-run OQ_RTN_WPB=2
-run OQ_RTN_ORDER=1
-run OQ_RTN_WAVEK=0
 run A=0
-MODE="--layout kn"
-run A=0
+run OQ_RTN_MINW=5
