@@ -77,76 +77,154 @@ __global__ __launch_bounds__(1024) void damp_kernel(float* P, int64_t K, float p
     for (int64_t i = threadIdx.x; i < K; i += blockDim.x) P[i * K + i] += d;
 }
 
-// Diagonal block kb: Cholesky of the n x n block (n <= 128) in LDS, then its triangular inverse.
+// ---- 128 x 128 diagonal block in one workgroup ------------------------------------------------------------
+// Recursive blocking by 32: a 32 x 32 sub-block is factored and inverted by ONE wave out of registers (lane i
+// holds row i; the rows / columns another lane needs arrive by v_readlane, no LDS round trip, no barrier); the
+// panel below it, the trailing update and the off-diagonal blocks of the inverse are dense LDS products spread
+// over all 256 threads (2 x 2 outputs per thread).  The sequential chain is 4 x (two 32-step register loops)
+// instead of 128 barrier-separated columns plus a 127-step substitution per thread.
+constexpr int kSB = 32;
+
+__device__ __forceinline__ float lane_value(float v, int src_lane) {   // src_lane is a compile-time constant below
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+// In-place Cholesky of the 32 x 32 block whose row `lane & 31` is a[0..31]; on return a[k], k <= row, = L[row][k].
+// Returns 0 or the 1-based index of the first non-positive pivot (which is replaced by 1 like chol_diag of old).
+__device__ __forceinline__ int chol32_regs(float (&a)[kSB], int row) {
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < kSB; ++j) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            const float ljk = lane_value(a[k], j);
+            if (k & 1) s1 = fmaf(a[k], ljk, s1);
+            else s0 = fmaf(a[k], ljk, s0);
+        }
+        const float s = a[j] - (s0 + s1);
+        float piv = lane_value(s, j);
+        if (!(piv > 0.0f)) {   // also NaN: LAPACK spotrf's "leading minor not positive definite"
+            if (bad == 0) bad = j + 1;
+            piv = 1.0f;
+        }
+        const float d = sqrtf(piv);
+        a[j] = row == j ? d : s / d;   // rows above j hold garbage in column j: the upper triangle is never read
+    }
+    return bad;
+}
+
+// m[i] = inv(L)[i][col] for the lane's column `col`, from the rows of L held by the lanes (a[] as left by chol32_regs).
+__device__ __forceinline__ void inv32_regs(const float (&a)[kSB], float (&m)[kSB], int col) {
+#pragma unroll
+    for (int i = 0; i < kSB; ++i) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < i; ++k) {
+            const float lik = lane_value(a[k], i);
+            if (k & 1) s1 = fmaf(lik, m[k], s1);   // m[k] == 0 above the column's diagonal entry
+            else s0 = fmaf(lik, m[k], s0);
+        }
+        const float lii = lane_value(a[i], i);
+        m[i] = i >= col ? ((i == col ? 1.0f : 0.0f) - (s0 + s1)) / lii : 0.0f;
+    }
+}
+
+// out(r, c) = sum_{k < kd} fa(r, k) * fb(k, c) for r < mr, c < nc (mr, nc even), 2 x 2 outputs per thread and step.
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void lds_product(int mr, int nc, int kd, FA fa, FB fb, FS store) {
+    const int tc = nc >> 1;
+    const int tiles = (mr >> 1) * tc;
+    for (int t = threadIdx.x; t < tiles; t += blockDim.x) {
+        const int r = (t / tc) * 2, c = (t % tc) * 2;
+        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < kd; ++k) {
+            const float p0 = fa(r, k), p1 = fa(r + 1, k), q0 = fb(k, c), q1 = fb(k, c + 1);
+            a00 = fmaf(p0, q0, a00); a01 = fmaf(p0, q1, a01);
+            a10 = fmaf(p1, q0, a10); a11 = fmaf(p1, q1, a11);
+        }
+        store(r, c, a00); store(r, c + 1, a01); store(r + 1, c, a10); store(r + 1, c + 1, a11);
+    }
+}
+
+// Diagonal block kb: Cholesky of the n x n block (n <= 128; padded with the identity to 128) and its inverse.
 //   Lt   [K, K]: Lt[k][i] = L[i][k]  (upper triangular = L^T), diag block written here
 //   Dinv [nb][128][128]: Dinv[kb][k][c] = inv(L_kk)[c][k]  (transposed, zero above the diagonal of the inverse)
 //   info: first non-positive pivot (1-based, in reversed index space), 0 if none so far
 __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t K, int64_t kb, float* Lt, float* Dinv,
                                                         int32_t* info) {
     extern __shared__ float lds[];
-    float (*A)[kLd] = reinterpret_cast<float (*)[kLd]>(lds);
-    float (*M)[kLd] = reinterpret_cast<float (*)[kLd]>(lds + kNB * kLd);
+    float (*A)[kLd] = reinterpret_cast<float (*)[kLd]>(lds);                    // the block; lower triangle becomes L
+    float (*M)[kLd] = reinterpret_cast<float (*)[kLd]>(lds + kNB * kLd);        // inv(L), lower triangular
+    float (*S)[kLd] = reinterpret_cast<float (*)[kLd]>(lds + 2 * kNB * kLd);    // [32][129] scratch of the inverse
     const int64_t o = kb * kNB;
     const int n = static_cast<int>((K - o) < kNB ? (K - o) : kNB);
     const int t = threadIdx.x;
-    for (int idx = t; idx < n * n; idx += blockDim.x) {
-        const int r = idx / n, c = idx - r * n;
-        A[r][c] = P[(o + r) * K + o + c];
+    const int lane = t & 63, wave = t >> 6;
+    for (int idx = t; idx < kNB * kNB; idx += blockDim.x) {
+        const int r = idx / kNB, c = idx - r * kNB;
+        A[r][c] = (r < n && c < n) ? P[(o + r) * K + o + c] : (r == c ? 1.0f : 0.0f);
+        M[r][c] = 0.0f;
     }
     __syncthreads();
-    // Left-looking (dot-product) Cholesky: column j is finished from the already final columns 0..j-1,
-    //   s_i = A[i][j] - sum_{k<j} L[i][k] * L[j][k],   L[j][j] = sqrt(s_j),   L[i][j] = s_i / L[j][j]  (i > j).
-    // One thread per row (row walks are conflict-free with the 129-float pitch, row j is a broadcast);
-    // two barriers per column and no trailing-matrix sweep.
-    for (int j = 0; j < n; ++j) {
-        float s = 0.f;
-        const int i = t;
-        if (i >= j && i < n) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int k = 0;
-            for (; k + 3 < j; k += 4) {
-                s0 = fmaf(A[i][k], A[j][k], s0);
-                s1 = fmaf(A[i][k + 1], A[j][k + 1], s1);
-                s2 = fmaf(A[i][k + 2], A[j][k + 2], s2);
-                s3 = fmaf(A[i][k + 3], A[j][k + 3], s3);
+
+    for (int jb = 0; jb < kNB / kSB; ++jb) {
+        const int so = jb * kSB;
+        if (wave == 0) {   // 32 x 32 sub-block: factor + inverse out of registers
+            const int i = lane & 31;
+            float a[kSB], m[kSB];
+#pragma unroll
+            for (int k = 0; k < kSB; ++k) a[k] = A[so + i][so + k];
+            const int bad = chol32_regs(a, i);
+            inv32_regs(a, m, i);
+            if (lane < kSB) {
+#pragma unroll
+                for (int k = 0; k < kSB; ++k) {
+                    if (k <= i) A[so + i][so + k] = a[k];
+                    M[so + k][so + i] = m[k];          // column i of the inverse (zeros above the diagonal)
+                }
             }
-            for (; k < j; ++k) s0 = fmaf(A[i][k], A[j][k], s0);
-            s = A[i][j] - ((s0 + s1) + (s2 + s3));
-            A[i][j] = s;
+            if (lane == 0 && bad != 0 && so + bad <= n && *info == 0) *info = static_cast<int32_t>(o + so + bad);
         }
         __syncthreads();
-        float ajj = A[j][j];
-        if (!(ajj > 0.0f)) {  // also catches NaN: LAPACK spotrf's "leading minor not positive definite"
-            if (t == 0 && *info == 0) *info = static_cast<int32_t>(o + j + 1);
-            ajj = 1.0f;
-        }
-        const float d = sqrtf(ajj);
-        __syncthreads();  // everyone has read the pivot before it is overwritten
-        if (i > j && i < n) A[i][j] = s / d;
-        if (i == j) A[j][j] = d;
-        // column j is only read by later columns' dot products, which start after the next barrier
-    }
-    __syncthreads();
-    // inverse of the lower factor, one column per thread (forward substitution)
-    for (int idx = t; idx < n * n; idx += blockDim.x) M[idx / n][idx % n] = 0.0f;
-    __syncthreads();
-    if (t < n) {
-        const int c = t;
-        M[c][c] = 1.0f / A[c][c];
-        for (int i = c + 1; i < n; ++i) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // four chains: the dot product is LDS-latency bound otherwise
-            int k = c;
-            for (; k + 3 < i; k += 4) {
-                s0 = fmaf(A[i][k], M[k][c], s0);
-                s1 = fmaf(A[i][k + 1], M[k + 1][c], s1);
-                s2 = fmaf(A[i][k + 2], M[k + 2][c], s2);
-                s3 = fmaf(A[i][k + 3], M[k + 3][c], s3);
+        const int below = kNB - so - kSB;   // rows under the sub-block
+        if (below > 0) {
+            const int ro = so + kSB;
+            // panel: L21 = A21 * inv(L11)^T, staged in the still unused part of M under the sub-block (A21 is an input
+            // of every output of its row)
+            lds_product(below, kSB, kSB,
+                        [&](int r, int k) { return A[ro + r][so + k]; },
+                        [&](int k, int c) { return M[so + c][so + k]; },
+                        [&](int r, int c, float v) { M[ro + r][so + c] = v; });
+            __syncthreads();
+            for (int idx = t; idx < below * kSB; idx += blockDim.x) {
+                const int r = idx / kSB, c = idx - r * kSB;
+                A[ro + r][so + c] = M[ro + r][so + c];
             }
-            for (; k < i; ++k) s0 = fmaf(A[i][k], M[k][c], s0);
-            M[i][c] = -((s0 + s1) + (s2 + s3)) / A[i][i];
+            __syncthreads();
+            // trailing update (full square: both triangles stay current): A22 -= L21 * L21^T
+            lds_product(below, below, kSB,
+                        [&](int r, int k) { return A[ro + r][so + k]; },
+                        [&](int k, int c) { return A[ro + c][so + k]; },
+                        [&](int r, int c, float v) { A[ro + r][ro + c] -= v; });
+            __syncthreads();
         }
     }
-    __syncthreads();
+    // off-diagonal blocks of the inverse by block rows:  X_i,<i = -inv(L_ii) * (L_i,<i * X_<i,<i)
+    for (int ib = 1; ib < kNB / kSB; ++ib) {
+        const int ro = ib * kSB;
+        lds_product(kSB, ro, ro,
+                    [&](int r, int k) { return A[ro + r][k]; },
+                    [&](int k, int c) { return k >= c ? M[k][c] : 0.0f; },   // staging leftovers sit only below the diagonal blocks
+                    [&](int r, int c, float v) { S[r][c] = v; });
+        __syncthreads();
+        lds_product(kSB, ro, kSB,
+                    [&](int r, int k) { return M[ro + r][ro + k]; },
+                    [&](int k, int c) { return S[k][c]; },
+                    [&](int r, int c, float v) { M[ro + r][c] = -v; });
+        __syncthreads();
+    }
     for (int idx = t; idx < kNB * kNB; idx += blockDim.x) {
         const int k = idx / kNB, c = idx - k * kNB;
         // L^T diag block (zero below the diagonal of Lt) and the transposed inverse
@@ -155,13 +233,15 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
     }
 }
 
-// X diag block (lower triangular inverse block) from Dinv: X[o+c][o+k] = Dinv[kb][k][c]
-__global__ void place_diag_inverse_kernel(const float* Dinv, int64_t K, int64_t kb, float* X) {
-    const int64_t o = kb * kNB;
+// Diagonal blocks of X = L'^-1 (lower) and of Y = X^T (upper) from Dinv[kb][k][c] = inv(L_kk)[c][k]; one block per kb.
+__global__ void place_diag_inverse_kernel(const float* Dinv, int64_t K, float* X, float* Y) {
+    const int64_t kb = blockIdx.x, o = kb * kNB;
     const int n = static_cast<int>((K - o) < kNB ? (K - o) : kNB);
     for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-        const int c = idx / n, k = idx - c * n;
-        X[(o + c) * K + o + k] = Dinv[(kb * kNB + k) * kNB + c];
+        const int k = idx / n, c = idx - k * n;
+        const float v = Dinv[(kb * kNB + k) * kNB + c];
+        Y[(o + k) * K + o + c] = v;
+        X[(o + c) * K + o + k] = v;
     }
 }
 
@@ -218,8 +298,8 @@ size_t oq_gptq_factor_workspace_bytes(int64_t K) {
     if (K <= 0) return 0;
     const size_t kk = align256(static_cast<size_t>(K) * K * 4);
     const int64_t nb = ceil_div(K, kNB);
-    // P (reversed, damped, factored in place), Lt, X, Dinv, S (one block row)
-    return 3 * kk + align256(static_cast<size_t>(nb) * kNB * kNB * 4) + align256(static_cast<size_t>(kNB) * K * 4) + 256;
+    // P (reversed, damped, factored in place; later the S scratch of the inverse), Lt, X, Y = X^T, Dinv
+    return 4 * kk + align256(static_cast<size_t>(nb) * kNB * kNB * 4) + 256;
 }
 
 int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info, void* workspace,
@@ -235,17 +315,19 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
     float* P = reinterpret_cast<float*>(base);
     float* Lt = reinterpret_cast<float*>(base + kk);
     float* X = reinterpret_cast<float*>(base + 2 * kk);
-    float* Dinv = reinterpret_cast<float*>(base + 3 * kk);
-    float* S = reinterpret_cast<float*>(base + 3 * kk + align256(static_cast<size_t>(nb) * kNB * kNB * 4));
+    float* Y = reinterpret_cast<float*>(base + 3 * kk);
+    float* Dinv = reinterpret_cast<float*>(base + 4 * kk);
+    float* S = P;   // P is dead once the Cholesky loop has finished
 
-    if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess || hipMemsetAsync(X, 0, static_cast<size_t>(K) * K * 4, s) != hipSuccess)
+    if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess || hipMemsetAsync(X, 0, static_cast<size_t>(K) * K * 4, s) != hipSuccess ||
+        hipMemsetAsync(Y, 0, static_cast<size_t>(K) * K * 4, s) != hipSuccess)
         return fail(OQ_ERR_LAUNCH, "oq_gptq_factor_f32: memset failed");
     hipLaunchKernelGGL(reverse_copy_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, H, K, P);
     hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, s, P, K, percdamp);
     int32_t st = check_launch("reverse/damp");
     if (st != OQ_OK) return st;
 
-    const size_t diag_lds = 2 * kNB * kLd * sizeof(float);
+    const size_t diag_lds = (2 * kNB + kSB) * kLd * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -281,28 +363,42 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
         if (st != OQ_OK) return st;
     }
 
-    // ---- X = L'^-1 by block rows:  X_ii = inv(L_ii),  X_i,<i = -inv(L_ii) * (L_i,<i * X_<i,<i)
-    for (int64_t ib = 0; ib < nb; ++ib) {
-        const int64_t o = ib * kNB;
-        const int64_t n = (K - o) < kNB ? (K - o) : kNB;
-        hipLaunchKernelGGL(place_diag_inverse_kernel, dim3(1), dim3(256), 0, s, Dinv, K, ib, X);
-        st = check_launch("place_diag_inverse_kernel");
-        if (st != OQ_OK) return st;
-        if (ib == 0) continue;
-        GemmTN sg;  // S[r][j] = sum_k Lt[k][o+r] * X[k][j],  k, j < o
-        sg.At = Lt + o; sg.lda = K; sg.M = n;
-        sg.B = X; sg.ldb = K; sg.N = o;
-        sg.C = S; sg.ldc = o;
-        sg.Kd = o; sg.alpha = 1.0f; sg.beta = 0.0f; sg.sa = 1.0f; sg.sb = 1.0f; sg.upper_only = 0; sg.mirror = 0;
-        st = launch_gemm_tn(sg, s);
-        if (st != OQ_OK) return st;
-        GemmTN xg;  // X[o+r][j] = -sum_c inv(L_ii)[r][c] * S[c][j]
-        xg.At = Dinv + ib * kNB * kNB; xg.lda = kNB; xg.M = n;
-        xg.B = S; xg.ldb = o; xg.N = o;
-        xg.C = X + o * K; xg.ldc = K;
-        xg.Kd = n; xg.alpha = -1.0f; xg.beta = 0.0f; xg.sa = 1.0f; xg.sb = 1.0f; xg.upper_only = 0; xg.mirror = 0;
-        st = launch_gemm_tn(xg, s);
-        if (st != OQ_OK) return st;
+    // ---- X = L'^-1 by recursive doubling.  With L = [[L11, 0], [L21, L22]]:  X21 = -X22 * (L21 * X11).  At level b
+    // every pair of neighbouring b x b diagonal blocks is one problem of a strided batch (the diagonal stride is
+    // 2b * (K + 1)), so a level is two launches with K / 2b * (b / 128)^2 tiles each instead of one 128-row block
+    // row (a single tile row) at a time.  Both X and Y = X^T are kept: the TN GEMM wants its left operand k-major,
+    // i.e. X22 transposed; the second GEMM writes its result to both.
+    hipLaunchKernelGGL(place_diag_inverse_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, Dinv, K, X, Y);
+    st = check_launch("place_diag_inverse_kernel");
+    if (st != OQ_OK) return st;
+    for (int64_t b = kNB; b < K; b *= 2) {
+        const int64_t npairs = (K - b + 2 * b - 1) / (2 * b);       // pairs whose second block is not empty
+        const int64_t full = (K / (2 * b));                          // pairs with a full second block
+        for (int part = 0; part < 2; ++part) {                       // 0: the full pairs (one batch), 1: the ragged last pair
+            const int64_t first = part == 0 ? 0 : full;
+            const int64_t count = part == 0 ? full : npairs - full;
+            if (count <= 0) continue;
+            const int64_t o1 = first * 2 * b, o2 = o1 + b;
+            const int64_t b2 = part == 0 ? b : K - o2;               // rows of the second block
+            GemmTN sg;  // S[r][j] = sum_k L21[r][k] * X11[k][j] = sum_k Lt[o1+k][o2+r] * X[o1+k][o1+j]
+            sg.At = Lt + o1 * K + o2; sg.lda = K; sg.M = b2;
+            sg.B = X + o1 * K + o1; sg.ldb = K; sg.N = b;
+            sg.C = S + first * b * b; sg.ldc = b;
+            sg.Kd = b; sg.alpha = 1.0f; sg.beta = 0.0f; sg.sa = 1.0f; sg.sb = 1.0f; sg.upper_only = 0; sg.mirror = 0;
+            sg.batch = count; sg.stride_a = 2 * b * (K + 1); sg.stride_b = 2 * b * (K + 1); sg.stride_c = b * b;
+            st = launch_gemm_tn(sg, s);
+            if (st != OQ_OK) return st;
+            GemmTN xg;  // X21[r][j] = -sum_c X22[r][c] * S[c][j] = -sum_c Y[o2+c][o2+r] * S[c][j];  Y12 = X21^T
+            xg.At = Y + o2 * K + o2; xg.lda = K; xg.M = b2;
+            xg.B = S + first * b * b; xg.ldb = b; xg.N = b;
+            xg.C = X + o2 * K + o1; xg.ldc = K;
+            xg.Ct = Y + o1 * K + o2; xg.ldct = K;
+            xg.Kd = b2; xg.alpha = -1.0f; xg.beta = 0.0f; xg.sa = 1.0f; xg.sb = 1.0f; xg.upper_only = 0; xg.mirror = 0;
+            xg.batch = count; xg.stride_a = 2 * b * (K + 1); xg.stride_b = b * b; xg.stride_c = 2 * b * (K + 1);
+            xg.stride_ct = 2 * b * (K + 1);
+            st = launch_gemm_tn(xg, s);
+            if (st != OQ_OK) return st;
+        }
     }
     hipLaunchKernelGGL(finish_factor_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, X, K, info, U_out);
     return check_launch("finish_factor_kernel");

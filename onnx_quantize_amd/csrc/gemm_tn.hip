@@ -63,7 +63,13 @@ __device__ __forceinline__ void stage_store(const StageRegs& r, float (*tile)[kB
 // Partial-slab mode (slab != null): blockIdx.y = T-slice; the raw accumulator tile is stored to
 // slab[slice][m][n] and alpha / beta / mirror are left to syrk_reduce_kernel.
 template <bool VA, bool VB>
-__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, float* slab, const int64_t k_per_slice, const int ntiles_n) {
+__global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in, float* slab, const int64_t k_per_slice, const int ntiles_n) {
+    GemmTN g = g_in;
+    if (g.batch > 1) {
+        const int64_t z = blockIdx.z;
+        g.At += z * g.stride_a; g.B += z * g.stride_b; g.C += z * g.stride_c;
+        if (g.Ct) g.Ct += z * g.stride_ct;
+    }
     int tile_m, tile_n;
     if (g.upper_only) {
         // linear id over the upper triangle, row-major: row m holds (ntiles_n - m) tiles
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g, f
                     if (g.beta != 0.0f) v = g.beta * g.C[row * g.ldc + col] + v;
                     g.C[row * g.ldc + col] = v;
                     if (mirror) g.C[col * g.ldc + row] = v;
+                    if (g.Ct) g.Ct[col * g.ldct + row] = v;
                 }
             }
 }
@@ -199,7 +206,9 @@ int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s) {
     const bool vec_b = (g.ldb % 4 == 0) && (g.N % 4 == 0) && (reinterpret_cast<uintptr_t>(g.B) & 15u) == 0;
     const int tn = static_cast<int>(ceil_div(g.N, kBN)), tm = static_cast<int>(ceil_div(g.M, kBM));
     const uint32_t ntiles = g.upper_only ? static_cast<uint32_t>(tn) * (tn + 1) / 2 : static_cast<uint32_t>(tn) * tm;
-    launch_variant(vec_a, vec_b, dim3(ntiles), s, g, nullptr, 0, tn);
+    OQ_REQUIRE(g.batch >= 1 && g.batch <= 65535, OQ_ERR_INVALID_ARGUMENT, "gemm_tn: bad batch %lld", (long long)g.batch);
+    const bool vec_sa = g.batch == 1 || g.stride_a % 4 == 0, vec_sb = g.batch == 1 || g.stride_b % 4 == 0;
+    launch_variant(vec_a && vec_sa, vec_b && vec_sb, dim3(ntiles, 1, static_cast<uint32_t>(g.batch)), s, g, nullptr, 0, tn);
     return check_launch("gemm_tn_kernel");
 }
 

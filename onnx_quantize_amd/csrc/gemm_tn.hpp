@@ -26,6 +26,11 @@ struct GemmTN {
     float sa, sb;     // operand pre-scales applied on load (fp32 rounding each, like `sqrt(2/n) * inp`)
     int32_t upper_only;  // compute only tiles with tile_n >= tile_m (symmetric result, At == B)
     int32_t mirror;      // with upper_only: also store C[n, m] for off-diagonal tiles
+    // strided batch (blockIdx.z): problem z uses At + z * stride_a, B + z * stride_b, C + z * stride_c (elements)
+    int64_t batch = 1, stride_a = 0, stride_b = 0, stride_c = 0;
+    // optional second, transposed copy of the result: Ct[n * ldct + m] = C[m, n] (+ z * stride_ct)
+    float* Ct = nullptr;
+    int64_t ldct = 0, stride_ct = 0;
 };
 
 int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s);

@@ -138,6 +138,54 @@ __global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a)
     }
 }
 
+// PARITY mode without the sequential kernel.  As written in the reference (gptq.py:199, :208) the error of a row
+// reaches no other row (the coefficients are the structural zeros below the diagonal of the upper factor), so
+// every row is quantized from the untouched working matrix with the parameters of its group: the parameters of
+// group kg come from rows [kg*g, min(kg*g + g, K)) of W (gptq.py:168-184), or, without a loop group, are the
+// initial per-channel / per-tensor ones (:104-116) for every row.  One thread = one column of one row band.
+__global__ __launch_bounds__(256) void gptq_parity_kernel(const LoopArgs a, int64_t band_rows) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool live = c < a.N;
+    const int64_t cc = live ? c : a.N - 1;
+    const int64_t band = blockIdx.y;
+    const int64_t r0 = band * band_rows;
+    const int64_t r1 = r0 + band_rows < a.K ? r0 + band_rows : a.K;
+    float scale;
+    int32_t zp;
+    if (a.g > 0) {
+        float mn = INFINITY, mx = -INFINITY;
+        int64_t r = r0;
+        for (; r + 3 < r1; r += 4) {   // four loads in flight per lane
+            const float x0 = a.W[r * a.N + cc], x1 = a.W[(r + 1) * a.N + cc], x2 = a.W[(r + 2) * a.N + cc], x3 = a.W[(r + 3) * a.N + cc];
+            mn = fminf(fminf(mn, x0), fminf(x1, fminf(x2, x3)));
+            mx = fmaxf(fmaxf(mx, x0), fmaxf(x1, fmaxf(x2, x3)));
+        }
+        for (; r < r1; ++r) {
+            const float x = a.W[r * a.N + cc];
+            mn = fminf(mn, x);
+            mx = fmaxf(mx, x);
+        }
+        const QParam p = qparam_from_minmax(mn, mx, a.grid);
+        scale = p.scale;
+        zp = p.zp;
+        if (live && a.used_scale != nullptr) {
+            a.used_scale[band * a.N + c] = scale;
+            a.used_zp[band * a.N + c] = zp;
+        }
+    } else {
+        const int64_t pi = a.init_count == 1 ? 0 : cc;
+        scale = a.init_scale[pi];
+        zp = a.init_zp[pi];
+    }
+    if (!live) return;
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    for (int64_t r = r0; r < r1; ++r) {
+        const int32_t qi = quantize_one(a.W[r * a.N + c], scale, zp, qmin, qmax);   // gptq.py:186-188
+        a.q_int[r * a.N + c] = static_cast<uint8_t>(qi);
+        a.q_deq[r * a.N + c] = dequantize_one(qi, scale, zp);                       // :189
+    }
+}
+
 int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy, int64_t group_size,
                  int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse, void* q_out, float* scale_out, void* zp_out,
                  int32_t layout, void* workspace, size_t workspace_bytes, void* stream, bool emit_q);
@@ -202,6 +250,14 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
     const size_t mse_ws_bytes = static_cast<size_t>(static_cast<char*>(workspace) + workspace_bytes - mse_ws);
     a.pre_scale = nullptr; a.pre_zp = nullptr; a.pre_first_group = 0;
     a.zp_signed = (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0;
+    if (mode == OQ_GPTQ_PARITY && !(mse && a.g > 0) && ceil_div(K, a.g > 0 ? a.g : 128) <= 65535) {
+        // no row depends on another one: one elementwise launch instead of K sequential steps
+        const int64_t band_rows = a.g > 0 ? a.g : 128;
+        a.i1 = 0; a.count = 0;
+        hipLaunchKernelGGL(gptq_parity_kernel, dim3(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K, band_rows))),
+                           dim3(256), 0, s, a, band_rows);
+        return check_launch("gptq_parity_kernel");
+    }
     const int64_t bs = block_size < kLoopMaxRows ? block_size : kLoopMaxRows;
     const uint32_t nblk = static_cast<uint32_t>(ceil_div(N, kLoopCols));
     for (int64_t i1 = 0; i1 < K; i1 += bs) {
