@@ -81,18 +81,23 @@ def main() -> None:
             gen = torch.Generator(device=dev).manual_seed(zlib.crc32(key.encode()) % (2**31))
             chan = 0.1 + 3.9 * torch.rand(sp.k, generator=gen, device=dev)
             h = torch.zeros((sp.k, sp.k), device=dev)
-            e0, e1, e2 = ev(), ev(), ev()
-            e0.record()
             n = 0
             for b in range(0, n_seqs, args.batch_seqs):
                 nb = min(args.batch_seqs, n_seqs - b)
+                # synthetic activations stand in for the calibration forward pass (not part of the path): generated
+                # outside the timed events, one batch at a time (never concatenated)
                 x = torch.randn((nb, args.seq, sp.k), generator=gen, device=dev) * chan
+                e0, e1 = ev(), ev()
+                e0.record()
                 n = ops.hessian_accumulate(x, h, n)
+                e1.record()
+                timings.append(("h", e0, e1))
+            e1, e2 = ev(), ev()
             e1.record()
             shared = ops.gptq_shared_factor(h, 0.01, False)
             e2.record()
             shared_cache[key] = (h, shared)
-            timings.append(("hf", e0, e1, e2))
+            timings.append(("f", e1, e2))
         h, shared = shared_cache[key]
         genw = torch.Generator(device=dev).manual_seed(1000 + i)
         w = torch.randn((sp.k, sp.n), generator=genw, device=dev) * 0.02
@@ -105,8 +110,10 @@ def main() -> None:
     torch.cuda.synchronize()
     t_quant = time.perf_counter() - t0
     for t in timings:
-        if t[0] == "hf":
-            t_h += t[1].elapsed_time(t[2]); t_f += t[2].elapsed_time(t[3])
+        if t[0] == "h":
+            t_h += t[1].elapsed_time(t[2])
+        elif t[0] == "f":
+            t_f += t[1].elapsed_time(t[2])
         else:
             t_l += t[1].elapsed_time(t[2])
     fence()
@@ -114,9 +121,10 @@ def main() -> None:
     gathered, nbytes = gather_device_results(specs, plan, results)
     fence()
     t_gather = time.perf_counter() - t1
-    wall = time.perf_counter() - t0
+    wall_all = time.perf_counter() - t0
+    wall = (t_h + t_f + t_l) * 1e-3 + t_gather        # device time of the path + the gather; excludes the synthetic data generation
 
-    stats = torch.tensor([wall, t_quant, t_gather, t_h, t_f, t_l], dtype=torch.float64, device=dev)
+    stats = torch.tensor([wall, t_quant, t_gather, t_h, t_f, t_l, wall_all], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     if rank == 0:
@@ -129,7 +137,8 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
                        "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01},
-            "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
+            "seconds": {"path": round(wall, 3), "wall_incl_synthetic_data_generation": round(float(stats[6]), 3),
+                        "quantize_incl_datagen_max_rank": round(float(stats[1]), 3),
                         "gather": round(float(stats[2]), 4), "hessian_ms_max_rank": round(float(stats[3]), 1),
                         "factor_ms_max_rank": round(float(stats[4]), 1), "loop_ms_max_rank": round(float(stats[5]), 1)},
             "gather_bytes": nbytes,

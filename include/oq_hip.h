@@ -207,6 +207,21 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
                          int64_t init_count, void* q_int_out, float* q_deq_out, float* used_scale,
                          int32_t* used_zp, void* workspace, size_t workspace_bytes, void* stream);
 
+/* N2  core/_algorithms/hqq.py:106-213 (`_optimize_zero_point` + the final quantize of `_hqq_quantize`): uint4,
+ *     asymmetric, group strategy, float zero points.  W [K, N] fp32; scale / zero_point_in / zero_point_out
+ *     [N * K/g] fp32 in the rtn.py:98-109 order (entry n * K/g + kg); the initial scale and zero points come
+ *     from oq_rtn_qparams_f32 (hqq.py:181-192; zero points converted to fp32).  beta / kappa are float64 like
+ *     the reference's Python floats (beta *= kappa per round).  q_out [K, N] one value per byte (NULL: zero
+ *     points only); rounds_out (device int32, may be NULL) receives the number of rounds evaluated before the
+ *     early stop.  Every round, the mean-error reduction and the best / early-stop decision run on the
+ *     device; nothing synchronises with the host.  K % group_size != 0 is OQ_ERR_UNSUPPORTED. */
+size_t oq_hqq_workspace_bytes(int64_t K, int64_t N, int64_t group_size);
+int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t group_size,
+                            int32_t reduce_range, const float* scale, const float* zero_point_in,
+                            double lp_norm, double beta, double kappa, int32_t iters, int32_t early_stop,
+                            void* q_out, float* zero_point_out, int32_t* rounds_out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* N3  qrules/_common.py:65-123: MatMulNBits zero-point packing [N, ceil(K/g / 2)] (pad nibble 0x8)
  *     from the per-group zero points [N*K/g] (1 byte each).  4-bit only. */
 int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out, void* stream);

@@ -1,0 +1,276 @@
+// HQQ zero-point optimisation (core/_algorithms/hqq.py:106-213 of the reference) for gfx950 -- SURVEY.md 8f, row N2.
+//
+// The reference alternates, for up to `iters` rounds over the WHOLE preprocessed array [N*K/g, g]:
+//     w_q = clip(round(w * (1/s) + z));  w_r = (w_q - z) / (1/s);  w_e = shrink(w - w_r, beta, p)
+//     err = mean |w - w_r|  (ONE number for the whole array: it steers `best` and the early stop)
+//     z   = mean_row(w_q - (w - w_e) * (1/s))
+// Rows (one k-group of one output column) are independent inside a round, the rounds are coupled only through
+// `err`.  So a round is one elementwise kernel over W (read once per round: 4 B / element, HBM / Infinity-Cache
+// bound with a powf per element) that leaves a per-block partial of sum|w - w_r|, and a one-block kernel that
+// folds the partials in a fixed order and takes the reference's decision ON THE DEVICE (no host round trip):
+// the next round's kernel applies it.  One thread = one row; neighbouring lanes = neighbouring columns, so every
+// load of W [K, N] is coalesced and no transposed copy (utils.py:24) exists.
+//
+// Parity: np.power (fp32 powf) and NumPy's pairwise fp32 means are not bit-reproducible on a GPU, so zero points
+// agree to a few ulp and an integer may move where w / s + z lands within that distance of a tie; the row means
+// use NumPy's summation tree (8 strided partial sums per <= 128 elements, halves above) to stay as close as
+// possible.  tests/test_hqq_gpu.py states the tolerances.
+#include "oq_common.hpp"
+
+namespace oq {
+
+struct HqqCtrl {
+    double best_err;
+    int32_t improved;  // the round that was just judged lowered the error: its zero points become `best`
+    int32_t stopped;   // early stop taken (hqq.py:136-137): later rounds are no-ops
+    int32_t rounds;    // rounds actually evaluated (diagnostic)
+    int32_t pad;
+};
+
+struct HqqArgs {
+    const float* W;
+    int64_t K, N, ldw, g, kgroups;
+    const float* scale;   // [N * kgroups], entry n * kgroups + kg (rtn.py:98-109 layout)
+    float* zp_cur;        // zero points of the round being evaluated
+    float* zp_next;       // hqq.py:140 result of that round
+    float* zp_best;
+    double* partial;      // [gridDim.x * gridDim.y] sums of |w - w_r|
+    HqqCtrl* ctrl;
+    float qmin, qmax;
+    float inv_beta;       // float32(1 / beta) of this round (beta *= kappa in float64 on the host, hqq.py:128)
+    float expo;           // float32(lp_norm - 1)
+    int32_t round;
+};
+
+// NumPy's pairwise sum of a row (numpy/core/src/umath/loops_utils.h.src::pairwise_sum): `value(i)` is evaluated
+// once per element, in index order; the result is what np.add.reduce returns for the row.
+template <typename F>
+__device__ __forceinline__ float pairwise_leaf(int64_t n, int64_t base, F&& value) {
+    // n <= 128 (loops_utils: n < 8 -> plain loop; else 8 strided partial sums + tail)
+    if (n < 8) {
+        float res = 0.f;
+        for (int64_t i = 0; i < n; ++i) res += value(base + i);
+        return res;
+    }
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = value(base + j);
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += value(base + i + j);
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += value(base + i);
+    return res;
+}
+
+// Whole row of length n: recursion of loops_utils (n > 128: halves, the left one a multiple of 8) unrolled with an
+// explicit stack; -1 on the work stack means "add the two newest sub-tree sums".
+template <typename F>
+__device__ __forceinline__ float pairwise_row(int64_t n, F&& value) {
+    if (n <= 128) return pairwise_leaf(n, 0, value);
+    int64_t work[40];
+    float vals[24];
+    int wt = 0, vt = 0;
+    int64_t pos = 0;
+    work[wt++] = n;
+    while (wt > 0) {
+        const int64_t len = work[--wt];
+        if (len < 0) {
+            const float b = vals[--vt], a = vals[--vt];
+            vals[vt++] = a + b;
+        } else if (len <= 128) {
+            vals[vt++] = pairwise_leaf(len, pos, value);
+            pos += len;
+        } else {
+            int64_t n2 = len / 2;
+            n2 -= n2 % 8;
+            work[wt++] = -1;
+            work[wt++] = len - n2;
+            work[wt++] = n2;
+        }
+    }
+    return vals[0];
+}
+
+__device__ __forceinline__ float hqq_shrink(float d, float inv_beta, float expo) {
+    // hqq.py:102-103: sign(x) * relu(|x| - (1/beta) * (|x| + 1e-8)^(p - 1)), every step rounded to fp32
+    const float a = fabsf(d);
+    const float t = a - inv_beta * powf(a + 1e-8f, expo);
+    const float m = fmaxf(0.0f, t);
+    const float sg = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : d);   // np.sign keeps +-0 and NaN
+    return sg * m;
+}
+
+__global__ __launch_bounds__(256) void hqq_round_kernel(const HqqArgs a) {
+    __shared__ double s_part[4];
+    const int64_t col = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t kg = blockIdx.y;
+    const bool live = col < a.N;
+    const int64_t r = (live ? col : a.N - 1) * a.kgroups + kg;
+    double abs_sum = 0.0;
+    const HqqCtrl c = *a.ctrl;
+    bool active = live;
+    if (a.round > 0) {   // apply the decision taken on the previous round (hqq.py:132-140)
+        if (live && c.improved) a.zp_best[r] = a.zp_cur[r];
+        if (c.stopped) active = false;
+        else if (live) a.zp_cur[r] = a.zp_next[r];
+    }
+    if (active) {
+        const float z = a.zp_cur[r];
+        const float inv = 1.0f / a.scale[r];                               // hqq.py:120
+        const float* w = a.W + kg * a.g * a.ldw + col;
+        const float zmean = pairwise_row(a.g, [&](int64_t t) {
+            const float x = w[t * a.ldw];
+            const float wq = fminf(fmaxf(rintf(x * inv + z), a.qmin), a.qmax);   // :124
+            const float wr = (wq - z) / inv;                                   // :125
+            const float d = x - wr;
+            abs_sum += static_cast<double>(fabsf(d));                          // :131
+            const float we = hqq_shrink(d, a.inv_beta, a.expo);                // :126
+            return wq - (x - we) * inv;                                        // :140
+        }) / static_cast<float>(a.g);
+        a.zp_next[r] = zmean;
+    }
+    // block partial of sum |w - w_r|, folded in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) abs_sum += __shfl_xor(abs_sum, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = abs_sum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        a.partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+// hqq.py:131-137 on the device: err = float32 mean; better -> remember, else early stop.
+__global__ __launch_bounds__(1024) void hqq_decide_kernel(const double* partial, int64_t nparts, double count, int32_t early_stop,
+                                                          HqqCtrl* ctrl) {
+    __shared__ double s[16];
+    if (ctrl->stopped) {
+        if (threadIdx.x == 0) ctrl->improved = 0;
+        return;
+    }
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < nparts; i += blockDim.x) acc += partial[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < static_cast<int>(blockDim.x >> 6); ++w) t += s[w];
+        const double err = static_cast<double>(static_cast<float>(t / count));   // np.mean of an fp32 array is fp32
+        ctrl->rounds += 1;
+        if (err < ctrl->best_err) {
+            ctrl->best_err = err;
+            ctrl->improved = 1;
+        } else {
+            ctrl->improved = 0;
+            if (early_stop) ctrl->stopped = 1;
+        }
+    }
+}
+
+__global__ void hqq_init_kernel(HqqCtrl* ctrl) {
+    ctrl->best_err = INFINITY;
+    ctrl->improved = 0;
+    ctrl->stopped = 0;
+    ctrl->rounds = 0;
+    ctrl->pad = 0;
+}
+
+// After the last round: settle `best` and quantize with it (hqq.py:163-171: round(w / s + z), float zero point
+// inside the rounding, no int32 cast).  q is the [K, N] one-value-per-byte array `_post_process_array` returns.
+__global__ __launch_bounds__(256) void hqq_finish_kernel(const HqqArgs a, uint8_t* q, float* zp_out) {
+    const int64_t col = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t kg = blockIdx.y;
+    if (col >= a.N) return;
+    const int64_t r = col * a.kgroups + kg;
+    const float z = (a.round > 0 && a.ctrl->improved) ? a.zp_cur[r] : a.zp_best[r];
+    zp_out[r] = z;
+    if (q == nullptr) return;
+    const float s = a.scale[r];
+    const float* w = a.W + kg * a.g * a.ldw + col;
+    for (int64_t t = 0; t < a.g; ++t) {
+        const float v = fminf(fmaxf(rintf(w[t * a.ldw] / s + z), a.qmin), a.qmax);
+        q[(kg * a.g + t) * a.N + col] = static_cast<uint8_t>(v);
+    }
+}
+
+}  // namespace oq
+
+extern "C" {
+
+using namespace oq;
+
+size_t oq_hqq_workspace_bytes(int64_t K, int64_t N, int64_t group_size) {
+    if (K <= 0 || N <= 0) return 0;
+    int64_t g = group_size > K ? K : group_size;
+    if (g == -1) g = K;
+    if (g <= 0 || K % g != 0) return 0;
+    const int64_t rows = N * (K / g);
+    const int64_t parts = ceil_div(N, 256) * (K / g);
+    return static_cast<size_t>(rows) * 4 * 3 + static_cast<size_t>(parts) * 8 + 1024;
+}
+
+int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t group_size, int32_t reduce_range,
+                            const float* scale, const float* zero_point_in, double lp_norm, double beta, double kappa, int32_t iters,
+                            int32_t early_stop, void* q_out, float* zero_point_out, int32_t* rounds_out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(W && scale && zero_point_in && zero_point_out && K > 0 && N > 0 && ldw >= N, OQ_ERR_INVALID_ARGUMENT,
+               "oq_hqq_optimize_f32: bad argument");
+    OQ_REQUIRE(iters >= 0 && beta > 0.0, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: iters >= 0 and beta > 0 needed");
+    int64_t g = group_size > K ? K : group_size;   // utils.py:19-22
+    if (g == -1) g = K;
+    OQ_REQUIRE(g > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: bad group_size %lld", (long long)group_size);
+    OQ_REQUIRE(K % g == 0, OQ_ERR_UNSUPPORTED, "oq_hqq_optimize_f32: groups that straddle columns (K %% group_size != 0) are not supported");
+    const int64_t kgroups = K / g;
+    OQ_REQUIRE(kgroups <= 65535, OQ_ERR_UNSUPPORTED, "oq_hqq_optimize_f32: more than 65535 groups per column");
+    const size_t need = oq_hqq_workspace_bytes(K, N, group_size);
+    OQ_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, OQ_ERR_WORKSPACE,
+               "oq_hqq_optimize_f32: 8-byte aligned workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    int64_t qmin, qmax;
+    OQ_REQUIRE(qrange_host(OQ_UINT4, 0, reduce_range, &qmin, &qmax), OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: qrange");
+    hipStream_t s = as_stream(stream);
+    const int64_t rows = N * kgroups;
+    const dim3 grid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups));
+    const int64_t parts = static_cast<int64_t>(grid.x) * grid.y;
+
+    char* base = static_cast<char*>(workspace);
+    HqqArgs a;
+    a.ctrl = reinterpret_cast<HqqCtrl*>(base);
+    a.partial = reinterpret_cast<double*>(base + 64);
+    a.zp_cur = reinterpret_cast<float*>(base + 64 + parts * 8);
+    a.zp_next = a.zp_cur + rows;
+    a.zp_best = a.zp_next + rows;
+    a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups; a.scale = scale;
+    a.qmin = static_cast<float>(qmin); a.qmax = static_cast<float>(qmax);
+    a.expo = static_cast<float>(lp_norm - 1.0);
+    a.round = 0; a.inv_beta = 0.f;
+
+    // hqq.py:115-116: best = zero_point.copy(); the first round evaluates the given zero points
+    if (hipMemcpyAsync(a.zp_cur, zero_point_in, static_cast<size_t>(rows) * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(a.zp_best, zero_point_in, static_cast<size_t>(rows) * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail(OQ_ERR_LAUNCH, "oq_hqq_optimize_f32: device copy failed");
+    hipLaunchKernelGGL(hqq_init_kernel, dim3(1), dim3(1), 0, s, a.ctrl);
+    double b = beta;
+    for (int32_t it = 0; it < iters; ++it) {
+        a.round = it;
+        a.inv_beta = static_cast<float>(1.0 / b);   // (1.0 / beta) meets an fp32 array: weak scalar -> fp32
+        b *= kappa;                                 // :128
+        hipLaunchKernelGGL(hqq_round_kernel, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(hqq_decide_kernel, dim3(1), dim3(1024), 0, s, a.partial, parts, static_cast<double>(K) * static_cast<double>(N),
+                           early_stop, a.ctrl);
+    }
+    int32_t st = check_launch("hqq_round_kernel");
+    if (st != OQ_OK) return st;
+    a.round = iters;
+    hipLaunchKernelGGL(hqq_finish_kernel, grid, dim3(256), 0, s, a, static_cast<uint8_t*>(q_out), zero_point_out);
+    st = check_launch("hqq_finish_kernel");
+    if (st != OQ_OK) return st;
+    if (rounds_out != nullptr &&
+        hipMemcpyAsync(rounds_out, &a.ctrl->rounds, sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return fail(OQ_ERR_LAUNCH, "oq_hqq_optimize_f32: device copy failed");
+    return OQ_OK;
+}
+
+}  // extern "C"

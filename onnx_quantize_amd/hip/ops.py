@@ -110,6 +110,35 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
     return q, scale.reshape(shape), zp.reshape(shape)
 
 
+def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_ratio=1.0, mse=False, lp_norm=0.7, beta=1e1,
+                 kappa=1.01, iters=20, early_stop=True, emit_q: bool = True):
+    """hqq.py:147-213 on the GPU: uint4 / asymmetric / group with float zero points.  ``w`` [K, N] fp32 in HBM.
+    Returns (q [K, N] uint8 | None, scale [N*K/g, 1] fp32, zero_point [N*K/g, 1] fp32, rounds int32[1] on device)."""
+    _require_device(w, "w", torch.float32)
+    if w.dim() != 2:
+        raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
+    w, ldw = _row_major(w)
+    k, n = w.shape
+    g = resolve_group("group", k, group_size if group_size is not None else -1)
+    if g <= 0 or (k * n) % g:
+        raise ValueError(f"cannot reshape array of size {k * n} into shape (-1, {g})")
+    # hqq.py:181-192: initial parameters = the RTN ones with float zero points (integral values)
+    _, scale, zp0 = rtn_quantize(w, "uint4", "group", group_size, False, reduce_range, clip_ratio, mse, emit_q=False)
+    lib = L.load()
+    dev = w.device
+    rows = (k * n) // g
+    zp_in = zp0.reshape(-1).to(torch.float32)
+    zp = torch.empty(rows, dtype=torch.float32, device=dev)
+    q = torch.empty((k, n), dtype=torch.uint8, device=dev) if emit_q else None
+    rounds = torch.zeros(1, dtype=torch.int32, device=dev)
+    gs = -1 if group_size is None else int(group_size)
+    ws = _workspace(lib.oq_hqq_workspace_bytes(k, n, gs), dev)
+    L.check(lib.oq_hqq_optimize_f32(_ptr(w), k, n, ldw, gs, int(reduce_range), _ptr(scale), _ptr(zp_in), float(lp_norm),
+                                    float(beta), float(kappa), int(iters), int(early_stop), _ptr(q), _ptr(zp), _ptr(rounds),
+                                    _ptr(ws), ws.numel(), _stream()))
+    return q, scale.reshape(rows, 1), zp.reshape(rows, 1), rounds
+
+
 def rtn_quantize_batched(w: torch.Tensor, qtype: str, group_size: int, symmetric=False, reduce_range=False,
                          clip_ratio=1.0, layout: str = "kn", out=None):
     """rtn.py:54-109 for a stack of equally shaped weights ``w`` [B, K, N] in ONE launch (group strategy).

@@ -66,6 +66,7 @@ def _load_reference():
     mods.utils = importlib.import_module("onnx_quantize.core._algorithms.utils")
     mods.rtn = importlib.import_module("onnx_quantize.core._algorithms.rtn")
     mods.gptq = importlib.import_module("onnx_quantize.core._algorithms.gptq")
+    mods.hqq = importlib.import_module("onnx_quantize.core._algorithms.hqq")
     mods.minmax = importlib.import_module("onnx_quantize.core._calibration.minmax")
     mods.pack = importlib.import_module("onnx_quantize.core._pack")
     mods.dtypes = importlib.import_module("onnx_quantize.core._dtypes")
@@ -413,6 +414,39 @@ def gen_gptq(out):
     print("gptq:", len(cases), "cases")
 
 
+def gen_hqq(out):
+    """core/_algorithms/hqq.py::_hqq_quantize (uint4, group, float zero points) on small matrices."""
+    cases, arrays = [], {}
+    grid = [
+        # (kind, seed, k, n, g, reduce_range, clip, mse, lp_norm, beta, kappa, iters, early_stop)
+        ("normal", 42, 32, 64, 16, False, 1.0, False, 0.7, 10.0, 1.01, 20, True),
+        ("normal", 42, 32, 64, 32, False, 1.0, False, 0.7, 10.0, 1.01, 20, False),
+        ("normal", 43, 64, 48, 64, False, 1.0, True, 0.7, 10.0, 1.01, 20, True),
+        ("normal", 44, 128, 40, 32, False, 1.0, False, 0.5, 5.0, 1.05, 10, True),
+        ("normal", 45, 128, 40, 64, False, 1.0, False, 1.0, 15.0, 1.02, 15, False),
+        ("heavy", 46, 256, 36, 128, False, 1.0, False, 0.7, 10.0, 1.01, 20, True),
+        ("heavy", 47, 256, 36, 128, True, 0.9, False, 0.7, 10.0, 1.01, 20, False),
+        ("zero_groups", 48, 128, 24, 32, False, 1.0, False, 0.7, 10.0, 1.01, 20, True),
+        ("normal", 49, 96, 20, -1, False, 1.0, False, 0.7, 10.0, 1.01, 20, True),
+        ("normal", 50, 512, 16, 256, False, 1.0, False, 0.7, 10.0, 1.01, 6, False),
+    ]
+    for idx, (kind, seed, k, n, g, red, clip, mse, lp, beta, kappa, iters, es) in enumerate(grid):
+        w = weight(kind, seed, k, n)
+        q, s, z = R.hqq._hqq_quantize(w, QT["uint4"], g, reduce_range=red, clip_ratio=clip, mse=mse, lp_norm=lp, beta=beta,
+                                      kappa=kappa, iters=iters, early_stop=es)
+        assert s.dtype == np.float32 and z.dtype == np.float32
+        key = f"c{idx}"
+        arrays[key + "_q"] = np.asarray(q).astype(np.uint8)
+        arrays[key + "_s"] = np.asarray(s)
+        arrays[key + "_z"] = np.asarray(z)
+        cases.append(dict(key=key, kind=kind, seed=seed, k=k, n=n, group_size=g, reduce_range=red, clip_ratio=clip, mse=mse,
+                          lp_norm=lp, beta=beta, kappa=kappa, iters=iters, early_stop=es, w_sha=sha16(w)))
+    np.savez_compressed(os.path.join(out, "hqq.npz"), **arrays)
+    with open(os.path.join(out, "hqq.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=1)
+    print(f"hqq: {len(cases)} cases")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -456,13 +490,10 @@ def gen_digests(out):
 
 def main():
     out = HERE
-    gen_scalar_kats(out)
-    gen_rtn_small(out)
-    gen_rtn_mse(out)
-    gen_kernels(out)
-    gen_minmax(out)
-    gen_gptq(out)
-    gen_digests(out)
+    gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, digests=gen_digests)
+    for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
+        gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],
                 reference="/root/reference (AyoubMDL/onnx_quantize v0.3.0 checkout)")
     with open(os.path.join(out, "PROVENANCE.json"), "w") as f:
