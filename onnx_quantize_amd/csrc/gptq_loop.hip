@@ -1,9 +1,9 @@
 // G3: the GPTQ block / row loop (gptq.py:153-216) for gfx950.
 //
-// Output columns are independent given U, so one lane owns one column for the whole block: the block's
-// rows of that column live in an LDS tile ([rows][256 columns], one column per lane -> conflict-free), the
-// loop over rows is the sequential part, and the coefficients of U are wave-uniform scalars.  After each
-// block the lazy batch update of the rows below (gptq.py:208) is one MFMA TN GEMM over the whole chip.
+// Output columns are independent given U.  Sequential mode (CORRECTED, or PARITY with mse): gptq_block_kernel
+// below, 64 columns per workgroup, 32-row sub-blocks out of registers; after each 128-row block the lazy batch
+// update of the rows below (gptq.py:208) is one MFMA TN GEMM over the whole chip.  PARITY without mse needs no
+// sequence at all: gptq_parity_kernel.
 //
 // Error-feedback indexing (oq_gptq_mode):
 //   PARITY     coefficient of row j for the error of row i = U[i1+j][i1+i]   (gptq.py:199 as written: the
@@ -15,7 +15,6 @@
 
 namespace oq {
 
-constexpr int kLoopCols = 256;
 constexpr int kLoopMaxRows = 128;
 
 struct LoopArgs {
@@ -42,97 +41,150 @@ struct LoopArgs {
     int64_t pre_first_group;  // index (row / g) of the first group that starts in this block
 };
 
-__global__ __launch_bounds__(kLoopCols) void gptq_block_kernel(const LoopArgs a) {
-    extern __shared__ float tile[];  // [count][kLoopCols]
-    __shared__ float coef_s[2][kLoopMaxRows];  // coefficients of the current / next row step (wave-uniform values)
-    __shared__ float diag_s[kLoopMaxRows];
-    const int c_local = threadIdx.x;
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * kLoopCols + c_local;
+// One workgroup = 64 columns x one block of <= 128 rows, 4 waves.  The block is walked in sub-blocks of 32 rows:
+//   * wave 0 holds the sub-block's rows of its 64 columns in REGISTERS (one column per lane) and runs the 32
+//     sequential steps out of them -- quantize, error, update of the later rows of the sub-block -- with the
+//     coefficients of U arriving as wave-uniform LDS broadcasts;
+//   * then all four waves apply the sub-block's 32 errors to the block's remaining rows in LDS (each row receives
+//     its updates in the reference's order i = 0, 1, ... and with the reference's roundings: product, then
+//     subtraction, gptq.py:198-200 -- only later in time, which no value can observe).
+// The old formulation (one lane per column, every row step sweeping all later rows through LDS) spent ~10 k cycles
+// per row step and ran on N / 256 workgroups.
+constexpr int kSubRows = 32;
+constexpr int kLoopColsV2 = 64;
+
+__global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
+    __shared__ float tile[kLoopMaxRows][kLoopColsV2];   // working copy W1 of the block (gptq.py:157)
+    __shared__ float coef[kSubRows][kLoopMaxRows];      // coefficient of the error of sub-block row i for block row j
+    __shared__ float err_s[kSubRows][kLoopColsV2];
+    __shared__ float gp_scale[kSubRows][kLoopColsV2];   // parameters of the groups that start inside the current sub-block
+    __shared__ int32_t gp_zp[kSubRows][kLoopColsV2];
+    __shared__ float red_mn[4][kLoopColsV2], red_mx[4][kLoopColsV2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * kLoopColsV2 + lane;
     const bool live = c < a.N;
     const int64_t cc = live ? c : a.N - 1;  // clamped column for loads
     const int count = static_cast<int>(a.count);
 
-    // gptq.py:199 as written (PARITY): column `i1+i` of U below the diagonal -> U[(i1+j)*K + i1+i];
-    // CORRECTED: row `i1+i` right of the diagonal -> U[(i1+i)*K + i1+j].
-    auto coef_at = [&](int j, int i) -> float {
-        return a.mode == OQ_GPTQ_PARITY ? a.U[(a.i1 + j) * a.K + a.i1 + i] : a.U[(a.i1 + i) * a.K + a.i1 + j];
-    };
-    if (c_local < count) {
-        diag_s[c_local] = a.U[(a.i1 + c_local) * a.K + a.i1 + c_local];
-        coef_s[0][c_local] = coef_at(c_local, 0);
-    }
-    for (int i = 0; i < count; ++i) tile[i * kLoopCols + c_local] = a.W[(a.i1 + i) * a.N + cc];  // W1 = copy (gptq.py:157)
+    for (int i = wave; i < count; i += 4) tile[i][lane] = a.W[(a.i1 + i) * a.N + cc];
 
-    float scale;
-    int32_t zp;
-    if (a.i1 == 0) {  // gptq.py:104-116
-        const int64_t pi = a.init_count == 1 ? 0 : cc;
-        scale = a.init_scale[pi];
-        zp = a.init_zp[pi];
-    } else {
-        scale = a.carry_scale[cc];
-        zp = a.carry_zp[cc];
+    float scale = 1.0f;
+    int32_t zp = 0;
+    if (wave == 0) {
+        if (a.i1 == 0) {  // gptq.py:104-116
+            const int64_t pi = a.init_count == 1 ? 0 : cc;
+            scale = a.init_scale[pi];
+            zp = a.init_zp[pi];
+        } else {
+            scale = a.carry_scale[cc];
+            zp = a.carry_zp[cc];
+        }
     }
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
-    __syncthreads();
 
-    for (int i = 0; i < count; ++i) {
-        const int cur = i & 1;
-        const int64_t row = a.i1 + i;
-        // next step's coefficients: issued now, consumed after this step's work (latency hidden)
-        float next_coef = 0.0f;
-        if (c_local < count && i + 1 < count) next_coef = coef_at(c_local, i + 1);
-
-        if (a.g > 0 && row % a.g == 0) {
-            // gptq.py:168-184: per-column parameters from rows [row, row + g) of the GLOBAL working matrix
-            // (not from the block copy), channel strategy.
-            if (a.pre_scale != nullptr) {   // mse=True: searched beforehand on the same rows (utils.py:140-239)
-                const int64_t o = (row / a.g - a.pre_first_group) * a.N + cc;
-                scale = a.pre_scale[o];
-                zp = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.pre_zp[o])) : static_cast<int32_t>(a.pre_zp[o]);
-            } else {
-                const int64_t rend = row + a.g < a.K ? row + a.g : a.K;
-                float mn = INFINITY, mx = -INFINITY;
-                for (int64_t r = row; r < rend; ++r) {
-                    const float x = a.W[r * a.N + cc];
-                    mn = fminf(mn, x);
-                    mx = fmaxf(mx, x);
+    for (int s0 = 0; s0 < count; s0 += kSubRows) {
+        const int ns = count - s0 < kSubRows ? count - s0 : kSubRows;   // rows of this sub-block
+        // gptq.py:199 as written (PARITY): column i1+i of U below the diagonal -> U[(i1+j)*K + i1+i] (exact zeros);
+        // CORRECTED: row i1+i right of the diagonal -> U[(i1+i)*K + i1+j].  The diagonal entry is the divisor.
+        for (int idx = threadIdx.x; idx < ns * kLoopMaxRows; idx += blockDim.x) {
+            const int i = idx / kLoopMaxRows, j = idx - i * kLoopMaxRows;
+            float v = 0.0f;
+            if (j < count) {
+                const int64_t ri = a.i1 + s0 + i, rj = a.i1 + j;
+                v = (a.mode == OQ_GPTQ_PARITY && j != s0 + i) ? a.U[rj * a.K + ri] : a.U[ri * a.K + rj];
+            }
+            coef[i][j] = v;
+        }
+        // gptq.py:168-184: parameters of every group that starts in this sub-block, from rows [row, row + g) of the
+        // GLOBAL working matrix (not of the block copy), channel strategy -- or the ones an MSE search left.  All
+        // four waves fold the rows (8 loads in flight per lane); uniform control flow.
+        if (a.g > 0) {
+            int slot = 0;
+            for (int i = 0; i < ns; ++i) {
+                const int64_t row = a.i1 + s0 + i;
+                if (row % a.g != 0) continue;
+                if (a.pre_scale != nullptr) {   // mse=True: searched beforehand on the same rows (utils.py:140-239)
+                    if (wave == 0) {
+                        const int64_t o = (row / a.g - a.pre_first_group) * a.N + cc;
+                        gp_scale[slot][lane] = a.pre_scale[o];
+                        gp_zp[slot][lane] = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.pre_zp[o])) : static_cast<int32_t>(a.pre_zp[o]);
+                    }
+                } else {
+                    const int64_t rend = row + a.g < a.K ? row + a.g : a.K;
+                    float mn = INFINITY, mx = -INFINITY;
+                    for (int64_t r = row + wave * 8; r < rend; r += 32) {
+                        float x[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[u] = a.W[(r + u < rend ? r + u : rend - 1) * a.N + cc];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { mn = fminf(mn, x[u]); mx = fmaxf(mx, x[u]); }
+                    }
+                    red_mn[wave][lane] = mn;
+                    red_mx[wave][lane] = mx;
+                    __syncthreads();
+                    if (wave == 0) {
+                        mn = fminf(fminf(red_mn[0][lane], red_mn[1][lane]), fminf(red_mn[2][lane], red_mn[3][lane]));
+                        mx = fmaxf(fmaxf(red_mx[0][lane], red_mx[1][lane]), fmaxf(red_mx[2][lane], red_mx[3][lane]));
+                        const QParam p = qparam_from_minmax(mn, mx, a.grid);
+                        gp_scale[slot][lane] = p.scale;
+                        gp_zp[slot][lane] = p.zp;
+                    }
+                    __syncthreads();
                 }
-                const QParam p = qparam_from_minmax(mn, mx, a.grid);
-                scale = p.scale;
-                zp = p.zp;
-            }
-            if (live && a.used_scale != nullptr) {
-                a.used_scale[(row / a.g) * a.N + c] = scale;
-                a.used_zp[(row / a.g) * a.N + c] = zp;
+                ++slot;
             }
         }
-        const float w = tile[i * kLoopCols + c_local];
-        const int32_t qi = quantize_one(w, scale, zp, qmin, qmax);   // gptq.py:186-188
-        const float q = dequantize_one(qi, scale, zp);                // :189
-        const float e = (w - q) / diag_s[i];                          // :164, :197
-        if (live) {
-            a.q_int[row * a.N + c] = static_cast<uint8_t>(qi);
-            a.q_deq[row * a.N + c] = q;
-            a.err[i * a.N + c] = e;
+        __syncthreads();
+        if (wave == 0) {
+            float w[kSubRows];
+            int slot = 0;
+#pragma unroll
+            for (int i = 0; i < kSubRows; ++i) w[i] = tile[(s0 + i < count) ? s0 + i : count - 1][lane];
+#pragma unroll
+            for (int i = 0; i < kSubRows; ++i) {
+                if (i < ns) {   // uniform
+                    const int64_t row = a.i1 + s0 + i;
+                    if (a.g > 0 && row % a.g == 0) {
+                        scale = gp_scale[slot][lane];
+                        zp = gp_zp[slot][lane];
+                        ++slot;
+                        if (live && a.used_scale != nullptr) {
+                            a.used_scale[(row / a.g) * a.N + c] = scale;
+                            a.used_zp[(row / a.g) * a.N + c] = zp;
+                        }
+                    }
+                    const int32_t qi = quantize_one(w[i], scale, zp, qmin, qmax);   // gptq.py:186-188
+                    const float q = dequantize_one(qi, scale, zp);                    // :189
+                    const float e = (w[i] - q) / coef[i][s0 + i];                     // :164, :197
+                    if (live) {
+                        a.q_int[row * a.N + c] = static_cast<uint8_t>(qi);
+                        a.q_deq[row * a.N + c] = q;
+                        a.err[(s0 + i) * a.N + c] = e;
+                    }
+                    err_s[i][lane] = e;
+                    // gptq.py:198-200  W1[i:, :] -= outer(Hinv1[i:, i], err1): one rounding for the product (the K = 1
+                    // matmul of the reference), one for the subtraction (no FMA)
+#pragma unroll
+                    for (int j = i + 1; j < kSubRows; ++j) w[j] = w[j] - coef[i][s0 + j] * e;
+                }
+            }
         }
-        // gptq.py:198-200  W1[i:, :] -= outer(Hinv1[i:, i], err1); row i itself is never read again.
-        // prod is the K=1 matmul of the reference: one rounding, then the subtraction (no FMA).
-        int j = i + 1;
-        for (; j + 3 < count; j += 4) {
-            const float p0 = coef_s[cur][j] * e, p1 = coef_s[cur][j + 1] * e, p2 = coef_s[cur][j + 2] * e, p3 = coef_s[cur][j + 3] * e;
-            const float t0 = tile[j * kLoopCols + c_local], t1 = tile[(j + 1) * kLoopCols + c_local];
-            const float t2 = tile[(j + 2) * kLoopCols + c_local], t3 = tile[(j + 3) * kLoopCols + c_local];
-            tile[j * kLoopCols + c_local] = t0 - p0;
-            tile[(j + 1) * kLoopCols + c_local] = t1 - p1;
-            tile[(j + 2) * kLoopCols + c_local] = t2 - p2;
-            tile[(j + 3) * kLoopCols + c_local] = t3 - p3;
+        __syncthreads();
+        // the same updates for the block's later rows, four waves, rows interleaved
+        if (s0 + kSubRows < count) {
+            float e[kSubRows];
+#pragma unroll
+            for (int i = 0; i < kSubRows; ++i) e[i] = err_s[i][lane];
+            for (int r = s0 + kSubRows + wave; r < count; r += 4) {
+                float t = tile[r][lane];
+#pragma unroll
+                for (int i = 0; i < kSubRows; ++i) t = t - coef[i][r] * e[i];
+                tile[r][lane] = t;
+            }
         }
-        for (; j < count; ++j) tile[j * kLoopCols + c_local] = tile[j * kLoopCols + c_local] - coef_s[cur][j] * e;
-        if (c_local < count) coef_s[cur ^ 1][c_local] = next_coef;
         __syncthreads();
     }
-    if (live) {
+    if (wave == 0 && live) {
         a.carry_scale[c] = scale;
         a.carry_zp[c] = zp;
     }
@@ -224,14 +276,6 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
                workspace_bytes);
     hipStream_t s = as_stream(stream);
 
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gptq_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLoopMaxRows * kLoopCols * 4) != hipSuccess)
-            return fail(OQ_ERR_LAUNCH, "oq_gptq_loop_f32: cannot reserve LDS");
-        attr_set = true;
-    }
-
     LoopArgs a;
     a.W = W; a.U = U; a.K = K; a.N = N; a.g = group_size > 0 ? group_size : 0; a.grid = grid; a.mode = mode;
     a.init_scale = init_scale; a.init_zp = init_zp; a.init_count = init_count;
@@ -259,7 +303,7 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
         return check_launch("gptq_parity_kernel");
     }
     const int64_t bs = block_size < kLoopMaxRows ? block_size : kLoopMaxRows;
-    const uint32_t nblk = static_cast<uint32_t>(ceil_div(N, kLoopCols));
+    const uint32_t nblk = static_cast<uint32_t>(ceil_div(N, kLoopColsV2));
     for (int64_t i1 = 0; i1 < K; i1 += bs) {
         const int64_t count = (K - i1) < bs ? (K - i1) : bs;
         a.i1 = i1; a.count = count;
@@ -277,7 +321,7 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
             }
             a.pre_scale = pre_scale; a.pre_zp = pre_zp; a.pre_first_group = first;
         }
-        hipLaunchKernelGGL(gptq_block_kernel, dim3(nblk), dim3(kLoopCols), static_cast<size_t>(count) * kLoopCols * 4, s, a);
+        hipLaunchKernelGGL(gptq_block_kernel, dim3(nblk), dim3(256), 0, s, a);
         st = check_launch("gptq_block_kernel");
         if (st != OQ_OK) return st;
         const int64_t i2 = i1 + count;
