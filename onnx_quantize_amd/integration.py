@@ -13,14 +13,17 @@ def install_into_reference() -> None:
     import onnx_quantize.core._qconfig as ref_cfg
 
     from .algorithms.gptq import _gptq_quantize
+    from .algorithms.hqq import _hqq_quantize
     from .algorithms.rtn import _rtn_quantize
     from .calibration import MinMaxCalibrator
 
     import onnx_quantize.core._algorithms.gptq as ref_gptq
+    import onnx_quantize.core._algorithms.hqq as ref_hqq
     import onnx_quantize.core._algorithms.rtn as ref_rtn
 
     ref_rtn._rtn_quantize = _rtn_quantize          # rtn.py:37-51 resolves the name at call time
     ref_gptq._gptq_quantize = _gptq_quantize       # gptq.py:51-73 likewise
+    ref_hqq._hqq_quantize = _hqq_quantize          # hqq.py:80-97 likewise
     ref_factory._CALIBRATORS[ref_factory.CalibrationMethod.MINMAX] = MinMaxCalibrator
     del ref_cfg
 
