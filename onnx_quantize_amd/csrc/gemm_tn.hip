@@ -2,6 +2,7 @@
 #include "gemm_tn.hpp"
 
 #include <cmath>
+#include <type_traits>
 
 namespace oq {
 
@@ -19,45 +20,57 @@ struct StageRegs {
     uint32_t ok;   // 4 bits per load: which of the 4 floats are inside the matrix
 };
 
+// Piece p (0..3) of a stage: rows k0 + (t >> 5) + 8 p, four floats per thread.  Loads are UNCONDITIONAL (clamped
+// coordinates, branch-free): a predicated load puts an exec branch and a vmcnt(0) in front of the MFMA stream
+// (cdna_hip_programming.md section 5, trap (c)).  The validity bits of the four floats go to bits 4p..4p+3 of r.ok.
 template <bool VEC>
-__device__ __forceinline__ void stage_load(StageRegs& r, const float* __restrict__ P, int64_t ld, int64_t k0, int64_t c0,
+__device__ __forceinline__ void load_piece(StageRegs& r, int p, const float* __restrict__ P, int64_t ld, int64_t k0, int64_t c0,
                                            int64_t Kd, int64_t cols) {
     const int t = threadIdx.x;
     const int64_t c = c0 + (t & 31) * 4;
-    uint32_t ok = 0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int64_t k = k0 + (t >> 5) + p * 8;
-        const int64_t kc = k < Kd ? k : Kd - 1;
-        if constexpr (VEC) {   // cols % 4 == 0, ld % 4 == 0, 16-byte aligned base
-            const int64_t cc = c < cols ? c : cols - 4;
-            r.v[p] = *reinterpret_cast<const float4*>(P + kc * ld + cc);
-            if (k < Kd && c < cols) ok |= 0xfu << (4 * p);
-        } else {
-            const float* row = P + kc * ld;
-            const int64_t last = cols - 1;
-            r.v[p].x = row[c < cols ? c : last];
-            r.v[p].y = row[c + 1 < cols ? c + 1 : last];
-            r.v[p].z = row[c + 2 < cols ? c + 2 : last];
-            r.v[p].w = row[c + 3 < cols ? c + 3 : last];
-            if (k < Kd) ok |= ((c < cols ? 1u : 0u) | (c + 1 < cols ? 2u : 0u) | (c + 2 < cols ? 4u : 0u) | (c + 3 < cols ? 8u : 0u)) << (4 * p);
-        }
+    const int64_t k = k0 + (t >> 5) + p * 8;
+    const int64_t kc = k < Kd ? k : Kd - 1;
+    uint32_t ok;
+    if constexpr (VEC) {   // cols % 4 == 0, ld % 4 == 0, 16-byte aligned base
+        const int64_t cc = c < cols ? c : cols - 4;
+        r.v[p] = *reinterpret_cast<const float4*>(P + kc * ld + cc);
+        ok = (k < Kd && c < cols) ? 0xfu : 0u;
+    } else {
+        const float* row = P + kc * ld;
+        const int64_t last = cols - 1;
+        r.v[p].x = row[c < cols ? c : last];
+        r.v[p].y = row[c + 1 < cols ? c + 1 : last];
+        r.v[p].z = row[c + 2 < cols ? c + 2 : last];
+        r.v[p].w = row[c + 3 < cols ? c + 3 : last];
+        ok = k < Kd ? ((c < cols ? 1u : 0u) | (c + 1 < cols ? 2u : 0u) | (c + 2 < cols ? 4u : 0u) | (c + 3 < cols ? 8u : 0u)) : 0u;
     }
-    r.ok = ok;
+    r.ok = (r.ok & ~(0xfu << (4 * p))) | (ok << (4 * p));
 }
 
-// Zero-fill of the out-of-range elements and the operand pre-scale happen on the way into LDS, i.e. after the
-// compute loop of the previous stage: the global loads have the whole stage (>= 4096 MFMA cycles) to land.
-__device__ __forceinline__ void stage_store(const StageRegs& r, float (*tile)[kBM], float scale) {
+// Zero-fill of the out-of-range elements and the operand pre-scale happen on the way into LDS.
+__device__ __forceinline__ void store_piece(const StageRegs& r, int p, float (*tile)[kBM], float scale) {
     const int t = threadIdx.x;
+    float4 x = r.v[p];
+    // pins the first use of the loaded registers HERE: without it instruction selection hoists the scale multiply to
+    // right behind the load (with a vmcnt(0) in front of it) and every inlined load stalls the MFMA stream
+    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));
+    const uint32_t m = r.ok >> (4 * p);
+    x.x = (m & 1u) ? x.x * scale : 0.f; x.y = (m & 2u) ? x.y * scale : 0.f;
+    x.z = (m & 4u) ? x.z * scale : 0.f; x.w = (m & 8u) ? x.w * scale : 0.f;
+    *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = x;
+}
+
+template <bool VEC>
+__device__ __forceinline__ void stage_load(StageRegs& r, const float* __restrict__ P, int64_t ld, int64_t k0, int64_t c0,
+                                           int64_t Kd, int64_t cols) {
+    r.ok = 0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        float4 x = r.v[p];
-        const uint32_t m = r.ok >> (4 * p);
-        x.x = (m & 1u) ? x.x : 0.f; x.y = (m & 2u) ? x.y : 0.f; x.z = (m & 4u) ? x.z : 0.f; x.w = (m & 8u) ? x.w : 0.f;
-        if (scale != 1.0f) { x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale; }
-        *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = x;
-    }
+    for (int p = 0; p < 4; ++p) load_piece<VEC>(r, p, P, ld, k0, c0, Kd, cols);
+}
+
+__device__ __forceinline__ void stage_store(const StageRegs& r, float (*tile)[kBM], float scale) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) store_piece(r, p, tile, scale);
 }
 
 // Partial-slab mode (slab != null): blockIdx.y = T-slice; the raw accumulator tile is stored to
@@ -113,7 +126,6 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // wave position inside the 2 x 2 grid
     const int64_t m0 = static_cast<int64_t>(tile_m) * kBM, n0 = static_cast<int64_t>(tile_n) * kBN;
-    const bool same = g.upper_only && (g.At == g.B) && tile_m == tile_n;  // diagonal tile of a SYRK: one operand
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -126,56 +138,78 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
     const int64_t nstages = (k_end - k_begin + kBT - 1) / kBT;
     StageRegs ra, rb;
     stage_load<VA>(ra, g.At, g.lda, k_begin, m0, k_end, g.M);
-    if (!same) stage_load<VB>(rb, g.B, g.ldb, k_begin, n0, k_end, g.N);
+    stage_load<VB>(rb, g.B, g.ldb, k_begin, n0, k_end, g.N);
     stage_store(ra, sA[0], g.sa);
-    if (!same) stage_store(rb, sB[0], g.sb);
+    stage_store(rb, sB[0], g.sb);
     __syncthreads();
 
     const int kl = lane >> 5, cl = lane & 31;
-    for (int64_t s = 0; s < nstages; ++s) {
+    // One stage = 16 groups of 4 MFMAs (k-pairs 0, 2, ..., 30), two operand register sets alternating.  A wave issues
+    // in order and an MFMA occupies the matrix pipe for 64 cycles, so whatever sits BETWEEN two MFMAs in program
+    // order issues for free while the first one executes, and whatever sits in a lump outside the MFMA stream leaves
+    // the pipe idle (measured with loads / LDS refill in lumps around the stream: 62 % pipe use with one wave per
+    // SIMD, 73 % with two -- the two waves of a SIMD reach their lumps together).  sched_barrier(0) pins the order:
+    //   after the 4th MFMA of a group    refill its operand set (consumed two groups later: lgkmcnt(2) suffices)
+    //   NEXT, groups 0-2, slots 1-3      the 8 clamped global loads of the next stage, one piece per slot
+    //   NEXT, groups 12-15, slots 1-2    mask + scale + ds_write of the 8 pieces into the other LDS buffer
+    // The stream itself is branch-free (a branch inside it makes the waitcnt pass guard the inlined loads with
+    // vmcnt(0)); the last stage of a tile runs the variant without fillers.  The diagonal tiles of a SYRK load their
+    // (identical) second operand like every other tile.
+    auto stage_body = [&](auto next_tag, int64_t s) {
+        constexpr bool NEXT = decltype(next_tag)::value;
         const int buf = s & 1;
-        const bool more = s + 1 < nstages;
-        if (more) {
-            stage_load<VA>(ra, g.At, g.lda, k_begin + (s + 1) * kBT, m0, k_end, g.M);
-            if (!same) stage_load<VB>(rb, g.B, g.ldb, k_begin + (s + 1) * kBT, n0, k_end, g.N);
-        }
         float (*tA)[kBM] = sA[buf];
-        float (*tB)[kBN] = same ? sA[buf] : sB[buf];
-        // Two operand sets in flight: the set consumed by k-pair kk is refilled (for kk+4) right after its four
-        // MFMAs have issued, so every ds_read has two MFMA groups (~512 cycles) to land.  hipcc otherwise emits
-        // "read, lgkmcnt(0), 4 x mfma" with the read latency exposed on every k-pair.
+        float (*tB)[kBN] = sB[buf];
         auto rd = [&](int k, float& x0, float& x1, float& y0, float& y1) {
             x0 = tA[k + kl][wm * 64 + cl];
             x1 = tA[k + kl][wm * 64 + 32 + cl];
             y0 = tB[k + kl][wn * 64 + cl];
             y1 = tB[k + kl][wn * 64 + 32 + cl];
         };
-        auto mm = [&](float x0, float x1, float y0, float y1) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, y1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, y1, acc[1][1], 0, 0, 0);
+        float xa[2][2], yb[2][2];   // [set][half]
+        rd(0, xa[0][0], xa[0][1], yb[0][0], yb[0][1]);
+        rd(2, xa[1][0], xa[1][1], yb[1][0], yb[1][1]);
+        const int64_t kn = k_begin + (s + 1) * kBT;
+        auto filler = [&](int grp, int slot) {
+            if constexpr (NEXT) {
+                if (grp < 3) {
+                    const int q = grp * 3 + (slot - 1);
+                    if (q < 4) load_piece<VA>(ra, q, g.At, g.lda, kn, m0, k_end, g.M);
+                    else if (q < 8) load_piece<VB>(rb, q - 4, g.B, g.ldb, kn, n0, k_end, g.N);
+                } else if (grp >= 12 && slot <= 2) {
+                    const int q = (grp - 12) * 2 + (slot - 1);   // 0..7
+                    if (q < 4) store_piece(ra, q, sA[buf ^ 1], g.sa);
+                    else store_piece(rb, q - 4, sB[buf ^ 1], g.sb);
+                }
+            }
         };
-        float pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
-        rd(0, pa0, pa1, pb0, pb1);
-        rd(2, qa0, qa1, qb0, qb1);
 #pragma unroll
-        for (int kk = 0; kk < kBT; kk += 4) {
-            mm(pa0, pa1, pb0, pb1);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (kk + 4 < kBT) rd(kk + 4, pa0, pa1, pb0, pb1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            mm(qa0, qa1, qb0, qb1);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (kk + 6 < kBT) rd(kk + 6, qa0, qa1, qb0, qb1);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        for (int grp = 0; grp < kBT / 2; ++grp) {
+            const int set = grp & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[set][0], yb[set][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            filler(grp, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[set][0], yb[set][1], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            filler(grp, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[set][1], yb[set][0], acc[1][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            filler(grp, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[set][1], yb[set][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * grp + 4 < kBT) rd(2 * grp + 4, xa[set][0], xa[set][1], yb[set][0], yb[set][1]);
         }
-        if (more) {
-            stage_store(ra, sA[buf ^ 1], g.sa);
-            if (!same) stage_store(rb, sB[buf ^ 1], g.sb);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int64_t s = 0; s + 1 < nstages; ++s) {
+        stage_body(std::true_type{}, s);
         __syncthreads();
     }
+    if (nstages > 0) stage_body(std::false_type{}, nstages - 1);
 
     // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     if (slab != nullptr) {
