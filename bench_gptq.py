@@ -31,7 +31,7 @@ def main() -> None:
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--tokens", type=int, default=128 * 2048, help="calibration tokens per layer input (128 seqs x 2048)")
     ap.add_argument("--seq", type=int, default=2048)
-    ap.add_argument("--batch-seqs", type=int, default=8)
+    ap.add_argument("--batch-seqs", type=int, default=32, help="sequences per Hessian call (T = 32 x 2048 = 65536 rows: one X^T X launch without T-slabs at K = 11008)")
     ap.add_argument("--mode", choices=["parity", "corrected"], default="parity")
     ap.add_argument("--hidden", type=int, default=4096)
     ap.add_argument("--ffn", type=int, default=11008)

@@ -245,3 +245,30 @@ def test_batched_equals_per_matrix(ops, layout, qtype, g, sym):
     for b in range(w.shape[0]):
         q, s, z = ops.rtn_quantize(w[b], qtype, "group", g, sym, layout=layout)
         assert torch.equal(bq[b], q) and torch.equal(bs[b], s) and torch.equal(bz[b], z)
+
+
+@pytest.mark.parametrize("k,n", [(1, 1), (1, 7), (2, 4), (7, 3), (33, 5), (128, 1), (128, 4), (130, 64), (256, 257), (512, 36), (96, 1028)])
+def test_odd_shapes_all_strategies_against_oracle(ops, k, n):
+    """Ragged and degenerate shapes (single row / column, N % 4 != 0, K not a multiple of the tile, group == K,
+    group > K) through every strategy and both 4- and 8-bit grids: integers, zero points and scale bits equal the
+    oracle's.  Group sizes are the divisors the reference's reshape accepts (utils.py:24)."""
+    rng = np.random.default_rng(k * 1000 + n)
+    w = (rng.standard_normal((k, n)) * rng.choice([1e-3, 1.0, 50.0])).astype(np.float32)
+    configs = [("int8", "tensor", -1, True), ("uint8", "tensor", -1, False), ("int4", "channel", -1, False),
+               ("uint4", "channel", -1, True), ("int8", "group", k, False), ("uint4", "group", 4 * k, False)]
+    for g in (2, 16, 32, 64, 128):
+        if k % g == 0:
+            configs += [("uint4", "group", g, False), ("int8", "group", g, True)]
+    for qtype, strategy, g, sym in configs:
+        eq, es, ez = O.rtn_quantize(w, qtype, strategy, g, sym)
+        q, s, z = ops.rtn_quantize(dev(w), qtype, strategy, g, sym)
+        label = f"{k}x{n} {qtype} {strategy} g={g} sym={sym}"
+        assert np.array_equal(q.cpu().numpy(), eq), label
+        assert s.cpu().numpy().tobytes() == np.asarray(es, np.float32).tobytes(), label
+        assert np.array_equal(z.cpu().numpy().reshape(-1), np.asarray(ez).reshape(-1)), label
+        if strategy == "group" and k % min(g, k) == 0 and min(g, k) % 16 == 0 and min(g, k) <= 256:   # fused blob epilogue: g <= 256
+            b, s2, _ = ops.rtn_quantize(dev(w), qtype, "group", g, sym, layout="nbits")
+            u = (eq.astype(np.int16) & (0xF if O.BITWIDTH[qtype] == 4 else 0xFF)).astype(np.uint8)
+            eb, _, _ = O.matmul_nbits_layout(u, es, ez, min(g, k), O.BITWIDTH[qtype])
+            assert np.array_equal(b.cpu().numpy(), eb), label + " (blob)"
+
