@@ -73,7 +73,11 @@ int32_t oq_qrange(int32_t qtype, int32_t symmetric, int32_t reduce_range, int64_
  *   group_size GROUP only: > 0 (clamped to K), or -1 (= K).  K % group_size must be 0 (the reference's
  *              product path guarantees it, qrules/_common.py:13-29) or N*K % group_size == 0 (groups
  *              then straddle columns exactly like W.T.reshape(-1, g)).
- *   q_out      OQ_LAYOUT_KN: K*N bytes.  OQ_LAYOUT_NBITS: N*(K/g)*(g*bits/8) bytes.
+ *   q_out      OQ_LAYOUT_KN: K*N bytes.  OQ_LAYOUT_NBITS: N*(K/g)*(g*bits/8) bytes (group strategy, 4/8-bit types,
+ *              K % g == 0, g % 16 == 0, 16-byte aligned; g <= 256 in the fused kernels, larger g -- group_size -1
+ *              = the whole column is MatMulNBits-eligible, qrules/_common.py:32-62 -- needs g % 128 == 0 and
+ *              N % 4 == 0; anything else is OQ_ERR_UNSUPPORTED, never a silent fallback).  Signed types are
+ *              stored as two's-complement nibbles / bytes.
  *   scale_out  fp32: 1 (tensor) | N (channel) | N*K/g (group; entry n*(K/g)+kg)
  *   zp_out     same count, 1 byte each (the weight container dtype)
  * ------------------------------------------------------------------------------------------- */

@@ -702,6 +702,7 @@ struct QuantKnArgs {
     QGrid grid;
     int32_t zp_signed, tensor;
     uint32_t ncol_tiles, nrow_tiles;
+    int32_t layout;   // OQ_LAYOUT_NBITS: groups that are a multiple of 128 rows, VEC4 only (checked by the host)
 };
 
 template <bool VEC4>
@@ -755,12 +756,51 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void quantize_kn(const QuantKnArg
 #pragma unroll
                 for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(xs[i], cq[i], qmin, qmax, bias);
             }
+            if (a.layout == OQ_LAYOUT_NBITS) {   // keep the levels; packed per column below
+                t[r] = make_float4(f[0], f[1], f[2], f[3]);
+                continue;
+            }
             uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
             w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
             w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
             w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
             if (col_ok[0] && row0 + r < row_end)
                 __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(a.q + (row0 + r) * a.N + tile_col0 + lane * 4));
+        }
+        if (a.layout == OQ_LAYOUT_NBITS && col_ok[0]) {
+            // qrules/_common.py:72-87: out-channel n, k-group kg -> g * bits / 8 bytes, k ascending, even k in the low nibble;
+            // this wave owns rows [c * 128 + wave * 16, +16) of the group
+            const int64_t blob = a.g * a.grid.bits / 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* lv = reinterpret_cast<const float*>(t) + i;   // t[r].{x,y,z,w}: stride 4 floats
+                uint8_t* o = a.q + ((tile_col0 + lane * 4 + i) * a.kgroups + kg) * blob;
+                if (a.grid.bits == 4) {
+                    // signed levels are biased by 128 here: the low nibble of (level + 128) already is the two's-complement nibble
+                    uint32_t words[2];
+#pragma unroll
+                    for (int wd = 0; wd < 2; ++wd) {
+                        uint32_t ev = 0, od = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            ev = __builtin_amdgcn_cvt_pk_u8_f32(lv[(wd * 8 + 2 * j) * 4], j, ev);
+                            od = __builtin_amdgcn_cvt_pk_u8_f32(lv[(wd * 8 + 2 * j + 1) * 4], j, od);
+                        }
+                        words[wd] = (ev & 0x0f0f0f0fu) | ((od & 0x0f0f0f0fu) << 4);
+                    }
+                    *reinterpret_cast<uint2*>(o + c * (kChunkRows / 2) + wave * (RPW / 2)) = make_uint2(words[0], words[1]);
+                } else {
+                    uint32_t words[4];
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        uint32_t acc = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(lv[(wd * 4 + j) * 4], j, acc);
+                        words[wd] = acc ^ flip;
+                    }
+                    *reinterpret_cast<uint4*>(o + c * kChunkRows + wave * RPW) = make_uint4(words[0], words[1], words[2], words[3]);
+                }
+            }
         }
     } else {
         for (int r = 0; r < RPW; ++r)
@@ -939,8 +979,10 @@ size_t rtn_mse_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
 
 // Pass 3 of the two-pass path (also the final pass of the MSE search): K1 with stored parameters.
 int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t g, int64_t kgroups, const float* scale,
-                           const uint8_t* zp, uint8_t* q, const QGrid& grid, int32_t zp_signed, bool tensor, hipStream_t s) {
+                           const uint8_t* zp, uint8_t* q, const QGrid& grid, int32_t zp_signed, bool tensor, hipStream_t s,
+                           int32_t layout) {
     QuantKnArgs qa;
+    qa.layout = layout;
     qa.W = W; qa.K = K; qa.N = N; qa.ldw = ldw; qa.g = g; qa.kgroups = kgroups;
     qa.chunks = ceil_div(g, kChunkRows);
     qa.scale = scale; qa.zp = zp; qa.q = q;
@@ -948,6 +990,8 @@ int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, in
     qa.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));
     qa.nrow_tiles = static_cast<uint32_t>(kgroups * qa.chunks);
     const bool vec4 = (N % 4 == 0) && (ldw % 4 == 0) && aligned16(W) && (reinterpret_cast<uintptr_t>(q) & 3u) == 0;
+    OQ_REQUIRE(layout == OQ_LAYOUT_KN || (vec4 && g % kChunkRows == 0 && aligned16(q) && !tensor), OQ_ERR_UNSUPPORTED,
+               "NBITS layout with group_size > 256 needs group_size %% 128 == 0, N %% 4 == 0 and 16-byte aligned buffers");
     const dim3 grid_dim(qa.ncol_tiles * qa.nrow_tiles), block(kMaxWaves * kWave);
     if (vec4) hipLaunchKernelGGL(quantize_kn<true>, grid_dim, block, 0, s, qa);
     else hipLaunchKernelGGL(quantize_kn<false>, grid_dim, block, 0, s, qa);
@@ -1003,7 +1047,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     int rpw = 0, wpg = 0;
     const bool fused = strategy == OQ_GROUP && fused_shape(g, &rpw, &wpg);
     if (layout == OQ_LAYOUT_NBITS) {
-        OQ_REQUIRE(fused && emit_q, OQ_ERR_UNSUPPORTED, "NBITS layout needs the group strategy with group_size <= 256");
+        OQ_REQUIRE(strategy == OQ_GROUP && emit_q, OQ_ERR_UNSUPPORTED, "NBITS layout needs the group strategy");
         OQ_REQUIRE(g % 16 == 0 && aligned16(q_out), OQ_ERR_UNSUPPORTED,
                    "NBITS layout needs group_size %% 16 == 0 and a 16-byte aligned output");
     }
@@ -1126,7 +1170,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     }
     st = check_launch("range_finalize");
     if (st != OQ_OK || !emit_q) return st;
-    return launch_quantize_kn(W, K, N, ldw, g, kgroups, scale_out, zp8, q8, grid, zp_signed, strategy == OQ_TENSOR, s);
+    return launch_quantize_kn(W, K, N, ldw, g, kgroups, scale_out, zp8, q8, grid, zp_signed, strategy == OQ_TENSOR, s, layout);
 }
 
 }  // namespace oq

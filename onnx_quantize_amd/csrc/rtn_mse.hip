@@ -177,7 +177,8 @@ size_t rtn_mse_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g) {
 
 // quantize pass shared with the two-pass RTN path (rtn.hip)
 int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t g, int64_t kgroups, const float* scale,
-                           const uint8_t* zp, uint8_t* q, const QGrid& grid, int32_t zp_signed, bool tensor, hipStream_t s);
+                           const uint8_t* zp, uint8_t* q, const QGrid& grid, int32_t zp_signed, bool tensor, hipStream_t s,
+                           int32_t layout);
 
 int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid_in, int32_t strategy, int64_t g,
                      void* q_out, float* scale_out, void* zp_out, int32_t zp_signed, void* workspace, size_t workspace_bytes,
@@ -213,7 +214,7 @@ int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QG
     st = check_launch("mse_resolve_kernel");
     if (st != OQ_OK || !emit_q) return st;
     return launch_quantize_kn(W, K, N, ldw, g, kgroups, scale_out, static_cast<const uint8_t*>(zp_out), static_cast<uint8_t*>(q_out),
-                              grid, zp_signed, strategy == OQ_TENSOR, s);
+                              grid, zp_signed, strategy == OQ_TENSOR, s, OQ_LAYOUT_KN);
 }
 
 }  // namespace oq

@@ -139,7 +139,8 @@ def test_nbits_layout_matches_reference_packing(ops):
     for (k, n, g, qtype) in [(512, 520, 128, "uint4"), (256, 36, 16, "uint4"), (512, 260, 64, "uint8"),
                              (768, 256, 256, "uint4"), (160, 40, 32, "uint8"), (384, 1100, 128, "uint8"),
                              (1024, 172, 64, "uint4"), (96, 2052, 32, "uint4"), (128, 4, 128, "uint4"),
-                             (4096, 96, 128, "uint4")]:
+                             (4096, 96, 128, "uint4"), (512, 72, 512, "uint4"), (1024, 44, -1, "uint8"), (384, 256, 384, "uint4")]:
+        g = k if g == -1 else g            # group_size = -1 (whole column) is MatMulNBits-eligible (qrules/_common.py:32-62): two-pass path
         w = rng.standard_normal((k, n), dtype=np.float32)
         eq, es, ez = O.rtn_quantize(w, qtype, "group", g)
         eb, es2, epz = O.matmul_nbits_layout(eq, es, ez, g, O.BITWIDTH[qtype])
@@ -160,7 +161,8 @@ def test_nbits_layout_matches_reference_packing(ops):
 
 @pytest.mark.parametrize("qtype,g,sym,rr,clip", [("int4", 128, False, False, 1.0), ("int4", 64, True, False, 0.9),
                                                  ("int8", 128, True, True, 1.0), ("uint8", 32, True, False, 0.75),
-                                                 ("uint4", 128, True, False, 1.0), ("int8", 32, False, True, 0.5)])
+                                                 ("uint4", 128, True, False, 1.0), ("int8", 32, False, True, 0.5),
+                                                 ("int4", 512, False, False, 1.0), ("int8", 512, True, False, 0.8)])
 def test_nbits_layout_signed_symmetric_clipped(ops, qtype, g, sym, rr, clip):
     """The blob kernels against the oracle for the grids MatMulNBits itself never sees (signed, symmetric, reduced,
     clipped): same integers as the [K, N] result, packed by qrules/_common.py:72-87's rule; heavy tails + zero groups."""
@@ -266,7 +268,7 @@ def test_odd_shapes_all_strategies_against_oracle(ops, k, n):
         assert np.array_equal(q.cpu().numpy(), eq), label
         assert s.cpu().numpy().tobytes() == np.asarray(es, np.float32).tobytes(), label
         assert np.array_equal(z.cpu().numpy().reshape(-1), np.asarray(ez).reshape(-1)), label
-        if strategy == "group" and k % min(g, k) == 0 and min(g, k) % 16 == 0 and min(g, k) <= 256:   # fused blob epilogue: g <= 256
+        if strategy == "group" and k % min(g, k) == 0 and min(g, k) % 16 == 0 and (min(g, k) <= 256 or min(g, k) % 128 == 0) and n % 4 == 0:   # blob epilogues: fused (g <= 256) or two-pass (g % 128 == 0)
             b, s2, _ = ops.rtn_quantize(dev(w), qtype, "group", g, sym, layout="nbits")
             u = (eq.astype(np.int16) & (0xF if O.BITWIDTH[qtype] == 4 else 0xFF)).astype(np.uint8)
             eb, _, _ = O.matmul_nbits_layout(u, es, ez, min(g, k), O.BITWIDTH[qtype])
