@@ -60,6 +60,14 @@ __device__ __forceinline__ void store_piece(const StageRegs& r, int p, float (*t
     *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = x;
 }
 
+__device__ __forceinline__ void store_piece_plain(const StageRegs& r, int p, float (*tile)[kBM], float scale) {
+    const int t = threadIdx.x;
+    float4 x = r.v[p];
+    asm volatile("" : "+v"(x.x), "+v"(x.y), "+v"(x.z), "+v"(x.w));   // see store_piece
+    x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;             // x * 1.0f == x bit for bit
+    *reinterpret_cast<float4*>(&tile[(t >> 5) + p * 8][(t & 31) * 4]) = x;
+}
+
 template <bool VEC>
 __device__ __forceinline__ void stage_load(StageRegs& r, const float* __restrict__ P, int64_t ld, int64_t k0, int64_t c0,
                                            int64_t Kd, int64_t cols) {
@@ -144,6 +152,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
     __syncthreads();
 
     const int kl = lane >> 5, cl = lane & 31;
+    const uint32_t off_a = static_cast<uint32_t>((threadIdx.x >> 5) * g.lda + (threadIdx.x & 31) * 4) * 4u;
+    const uint32_t off_b = static_cast<uint32_t>((threadIdx.x >> 5) * g.ldb + (threadIdx.x & 31) * 4) * 4u;
+    const char* base_a = reinterpret_cast<const char*>(g.At + k_begin * g.lda + m0);
+    const char* base_b = reinterpret_cast<const char*>(g.B + k_begin * g.ldb + n0);
+    const int64_t stage_a = kBT * g.lda * 4, stage_b = kBT * g.ldb * 4, rows8_a = 8 * g.lda * 4, rows8_b = 8 * g.ldb * 4;
     // One stage = 16 groups of 4 MFMAs (k-pairs 0, 2, ..., 30), two operand register sets alternating.  A wave issues
     // in order and an MFMA occupies the matrix pipe for 64 cycles, so whatever sits BETWEEN two MFMAs in program
     // order issues for free while the first one executes, and whatever sits in a lump outside the MFMA stream leaves
@@ -155,8 +168,9 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
     // The stream itself is branch-free (a branch inside it makes the waitcnt pass guard the inlined loads with
     // vmcnt(0)); the last stage of a tile runs the variant without fillers.  The diagonal tiles of a SYRK load their
     // (identical) second operand like every other tile.
-    auto stage_body = [&](auto next_tag, int64_t s) {
+    auto stage_body = [&](auto next_tag, auto plain_tag, int64_t s) {
         constexpr bool NEXT = decltype(next_tag)::value;
+        constexpr bool PLAIN = decltype(plain_tag)::value;   // every element of the next stage lies inside both operands
         const int buf = s & 1;
         float (*tA)[kBM] = sA[buf];
         float (*tB)[kBN] = sB[buf];
@@ -174,12 +188,22 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
             if constexpr (NEXT) {
                 if (grp < 3) {
                     const int q = grp * 3 + (slot - 1);
-                    if (q < 4) load_piece<VA>(ra, q, g.At, g.lda, kn, m0, k_end, g.M);
-                    else if (q < 8) load_piece<VB>(rb, q - 4, g.B, g.ldb, kn, n0, k_end, g.N);
+                    if constexpr (PLAIN) {   // scalar stage base + constant 32-bit thread offset: no address arithmetic, no masks
+                        if (q < 4) ra.v[q] = *reinterpret_cast<const float4*>(base_a + (s + 1) * stage_a + q * rows8_a + off_a);
+                        else if (q < 8) rb.v[q - 4] = *reinterpret_cast<const float4*>(base_b + (s + 1) * stage_b + (q - 4) * rows8_b + off_b);
+                    } else {
+                        if (q < 4) load_piece<VA>(ra, q, g.At, g.lda, kn, m0, k_end, g.M);
+                        else if (q < 8) load_piece<VB>(rb, q - 4, g.B, g.ldb, kn, n0, k_end, g.N);
+                    }
                 } else if (grp >= 12 && slot <= 2) {
                     const int q = (grp - 12) * 2 + (slot - 1);   // 0..7
-                    if (q < 4) store_piece(ra, q, sA[buf ^ 1], g.sa);
-                    else store_piece(rb, q - 4, sB[buf ^ 1], g.sb);
+                    if constexpr (PLAIN) {
+                        if (q < 4) store_piece_plain(ra, q, sA[buf ^ 1], g.sa);
+                        else store_piece_plain(rb, q - 4, sB[buf ^ 1], g.sb);
+                    } else {
+                        if (q < 4) store_piece(ra, q, sA[buf ^ 1], g.sa);
+                        else store_piece(rb, q - 4, sB[buf ^ 1], g.sb);
+                    }
                 }
             }
         };
@@ -205,11 +229,20 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int64_t s = 0; s + 1 < nstages; ++s) {
-        stage_body(std::true_type{}, s);
+    // interior tile of vector-aligned operands: all stages but a ragged last one take the mask-free fillers (one uniform
+    // branch per tile selects the stream; the stages of one tile never mix streams except at that last stage)
+    const bool interior = VA && VB && m0 + kBM <= g.M && n0 + kBN <= g.N && g.lda < (1 << 22) && g.ldb < (1 << 22);
+    const int64_t nplain = interior ? (k_end - k_begin) / kBT - 1 : 0;   // stages s whose NEXT stage is full: s + 2 <= full stages
+    int64_t s = 0;
+    for (; s < nplain && s + 1 < nstages; ++s) {
+        stage_body(std::true_type{}, std::true_type{}, s);
         __syncthreads();
     }
-    if (nstages > 0) stage_body(std::false_type{}, nstages - 1);
+    for (; s + 1 < nstages; ++s) {
+        stage_body(std::true_type{}, std::false_type{}, s);
+        __syncthreads();
+    }
+    if (nstages > 0) stage_body(std::false_type{}, std::false_type{}, nstages - 1);
 
     // Epilogue.  C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).
     if (slab != nullptr) {
