@@ -385,6 +385,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             sg.B = X + o1 * K + o1; sg.ldb = K; sg.N = b;
             sg.C = S + first * b * b; sg.ldc = b;
             sg.Kd = b; sg.alpha = 1.0f; sg.beta = 0.0f; sg.sa = 1.0f; sg.sb = 1.0f; sg.upper_only = 0; sg.mirror = 0;
+            sg.k_from_n = 1;   // X11 is lower triangular
             sg.batch = count; sg.stride_a = 2 * b * (K + 1); sg.stride_b = 2 * b * (K + 1); sg.stride_c = b * b;
             st = launch_gemm_tn(sg, s);
             if (st != OQ_OK) return st;
@@ -394,6 +395,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             xg.C = X + o2 * K + o1; xg.ldc = K;
             xg.Ct = Y + o1 * K + o2; xg.ldct = K;
             xg.Kd = b2; xg.alpha = -1.0f; xg.beta = 0.0f; xg.sa = 1.0f; xg.sb = 1.0f; xg.upper_only = 0; xg.mirror = 0;
+            xg.k_to_m = 1;     // X22^T is upper triangular
             xg.batch = count; xg.stride_a = 2 * b * (K + 1); xg.stride_b = b * b; xg.stride_c = 2 * b * (K + 1);
             xg.stride_ct = 2 * b * (K + 1);
             st = launch_gemm_tn(xg, s);

@@ -126,14 +126,16 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
         tile_m = blockIdx.x / ntiles_n;
         tile_n = blockIdx.x - tile_m * ntiles_n;
     }
-    const int64_t k_begin = slab ? static_cast<int64_t>(blockIdx.y) * k_per_slice : 0;
-    const int64_t k_end = slab ? (k_begin + k_per_slice < g.Kd ? k_begin + k_per_slice : g.Kd) : g.Kd;
+    int64_t k_begin = slab ? static_cast<int64_t>(blockIdx.y) * k_per_slice : 0;
+    int64_t k_end = slab ? (k_begin + k_per_slice < g.Kd ? k_begin + k_per_slice : g.Kd) : g.Kd;
     __shared__ float sA[2][kBT][kBM];
     __shared__ float sB[2][kBT][kBN];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // wave position inside the 2 x 2 grid
     const int64_t m0 = static_cast<int64_t>(tile_m) * kBM, n0 = static_cast<int64_t>(tile_n) * kBN;
+    if (g.k_from_n && n0 > k_begin) k_begin = n0 < k_end ? n0 : k_end;          // kBN is a multiple of kBT
+    if (g.k_to_m && m0 + kBM < k_end) k_end = m0 + kBM > k_begin ? m0 + kBM : k_begin;
 
     f32x16 acc[2][2];
 #pragma unroll

@@ -31,6 +31,10 @@ struct GemmTN {
     // optional second, transposed copy of the result: Ct[n * ldct + m] = C[m, n] (+ z * stride_ct)
     float* Ct = nullptr;
     int64_t ldct = 0, stride_ct = 0;
+    // triangular operands: skip the k-range that only multiplies structural zeros
+    //   k_from_n: B[k][n] == 0 for k < n (B lower triangular)  -> a tile starts at k = its first column
+    //   k_to_m:   At[k][m] == 0 for k > m (At upper triangular) -> a tile stops behind its last row
+    int32_t k_from_n = 0, k_to_m = 0;
 };
 
 int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s);
