@@ -336,31 +336,53 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
         attr_set = true;
     }
 
-    // ---- blocked right-looking Cholesky of P (both triangles of the trailing matrix are kept current)
-    for (int64_t kb = 0; kb < nb; ++kb) {
-        const int64_t o = kb * kNB;
-        const int64_t n = (K - o) < kNB ? (K - o) : kNB;
-        const int64_t rest = K - o - n;  // rows / columns behind this block
-        hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, s, P, K, kb, Lt, Dinv, info);
-        st = check_launch("chol_diag_kernel");
-        if (st != OQ_OK) return st;
-        if (rest <= 0) break;
-        // panel (kept transposed): Lt[o+c][i] = sum_k inv(L_kk)[c][k] * P[o+k][i],  i behind the block
-        GemmTN pg;
-        pg.At = Dinv + kb * kNB * kNB; pg.lda = kNB; pg.M = n;
-        pg.B = P + o * K + o + n; pg.ldb = K; pg.N = rest;
-        pg.C = Lt + o * K + o + n; pg.ldc = K;
-        pg.Kd = n; pg.alpha = 1.0f; pg.beta = 0.0f; pg.sa = 1.0f; pg.sb = 1.0f; pg.upper_only = 0; pg.mirror = 0;
-        st = launch_gemm_tn(pg, s);
-        if (st != OQ_OK) return st;
-        // trailing update: P[i][j] -= sum_c Lt[o+c][i] * Lt[o+c][j]
-        GemmTN tg;
-        tg.At = Lt + o * K + o + n; tg.lda = K; tg.M = rest;
-        tg.B = tg.At; tg.ldb = K; tg.N = rest;
-        tg.C = P + (o + n) * K + o + n; tg.ldc = K;
-        tg.Kd = n; tg.alpha = -1.0f; tg.beta = 1.0f; tg.sa = 1.0f; tg.sb = 1.0f; tg.upper_only = 1; tg.mirror = 1;
-        st = launch_gemm_tn(tg, s);
-        if (st != OQ_OK) return st;
+    // ---- blocked right-looking Cholesky of P, two levels: inside an outer panel of kOuter rows the 128-row steps
+    // update only the panel's own rows (a strip of <= 384 rows x all columns behind); the square behind the panel gets
+    // ONE update per outer panel with Kd = kOuter instead of four with Kd = 128 (each a read-modify-write of the whole
+    // trailing matrix through 4 stages of MFMA work per tile: 27 TFLOP/s on K = 11008).
+    constexpr int64_t kOuter = 4 * kNB;
+    for (int64_t O = 0; O < K; O += kOuter) {
+        const int64_t pend = O + kOuter < K ? O + kOuter : K;
+        for (int64_t o = O; o < pend; o += kNB) {
+            const int64_t kb = o / kNB;
+            const int64_t n = (K - o) < kNB ? (K - o) : kNB;
+            const int64_t rest = K - o - n;  // columns behind this block
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, s, P, K, kb, Lt, Dinv, info);
+            st = check_launch("chol_diag_kernel");
+            if (st != OQ_OK) return st;
+            if (rest <= 0) break;
+            // panel (kept transposed): Lt[o+c][i] = sum_k inv(L_kk)[c][k] * P[o+k][i],  i behind the block
+            GemmTN pg;
+            pg.At = Dinv + kb * kNB * kNB; pg.lda = kNB; pg.M = n;
+            pg.B = P + o * K + o + n; pg.ldb = K; pg.N = rest;
+            pg.C = Lt + o * K + o + n; pg.ldc = K;
+            pg.Kd = n; pg.alpha = 1.0f; pg.beta = 0.0f; pg.sa = 1.0f; pg.sb = 1.0f; pg.upper_only = 0; pg.mirror = 0;
+            st = launch_gemm_tn(pg, s);
+            if (st != OQ_OK) return st;
+            // strip update: rows of the outer panel behind this block x all columns behind it
+            const int64_t strip = pend - (o + n);
+            if (strip > 0) {
+                GemmTN tg;
+                tg.At = Lt + o * K + o + n; tg.lda = K; tg.M = strip;
+                tg.B = Lt + o * K + o + n; tg.ldb = K; tg.N = rest;
+                tg.C = P + (o + n) * K + o + n; tg.ldc = K;
+                tg.Kd = n; tg.alpha = -1.0f; tg.beta = 1.0f; tg.sa = 1.0f; tg.sb = 1.0f; tg.upper_only = 0; tg.mirror = 0;
+                st = launch_gemm_tn(tg, s);
+                if (st != OQ_OK) return st;
+            }
+        }
+        const int64_t rest2 = K - pend;
+        if (rest2 > 0) {
+            // deferred update of the square behind the outer panel (both triangles stay current):
+            // P[i][j] -= sum_{c in panel} Lt[c][i] * Lt[c][j]
+            GemmTN tg;
+            tg.At = Lt + O * K + pend; tg.lda = K; tg.M = rest2;
+            tg.B = tg.At; tg.ldb = K; tg.N = rest2;
+            tg.C = P + pend * K + pend; tg.ldc = K;
+            tg.Kd = pend - O; tg.alpha = -1.0f; tg.beta = 1.0f; tg.sa = 1.0f; tg.sb = 1.0f; tg.upper_only = 1; tg.mirror = 1;
+            st = launch_gemm_tn(tg, s);
+            if (st != OQ_OK) return st;
+        }
     }
 
     // ---- X = L'^-1 by recursive doubling.  With L = [[L11, 0], [L21, L22]]:  X21 = -X22 * (L21 * X11).  At level b
