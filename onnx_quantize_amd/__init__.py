@@ -22,6 +22,7 @@ from .config import (  # noqa: F401
     register_preprocessing_config,
 )
 from .dtypes import QuantType  # noqa: F401
+from .preprocessing import AwqConfig, SmoothQuantConfig  # noqa: F401
 from .quantize import quantize  # noqa: F401
 
 __version__ = "0.1.0"

@@ -307,6 +307,84 @@ def absmax(x: torch.Tensor, per_row: bool = False) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- N2: AWQ / SmoothQuant searches
+def _flat_inputs(x: torch.Tensor) -> torch.Tensor:
+    _require_device(x, "inputs", torch.float32)
+    return x.reshape(-1, x.shape[-1])
+
+
+def _strategy_mode(strategy: str, k: int, group_size):
+    if strategy == "group":
+        return "group", resolve_group("group", k, group_size)
+    return ("col" if strategy == "channel" else "tensor"), 1      # oq_dequantize_f32 addressing: per column / one entry
+
+
+def awq_weight_scale(w: torch.Tensor, strategy: str, group_size) -> torch.Tensor:
+    """pre_passes/awq.py:52-72 on W [K, N] in HBM: |w| / absmax of its quantization group, mean over the
+    output channels -> [K]."""
+    k, n = w.shape
+    a = w.abs()
+    if strategy == "tensor":
+        return (a / a.max()).mean(dim=1)
+    if strategy == "group":
+        g = int(group_size)
+        amax = a.t().reshape(n, k // g, g).amax(dim=2, keepdim=True)                 # [N, K/g, 1]
+        return (a.t().reshape(n, k // g, g) / amax).reshape(n, k).mean(dim=0)
+    return (a / a.amax(dim=0, keepdim=True)).mean(dim=1)                            # channel: per output column
+
+
+def awq_scale_search(x: torch.Tensor, w: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
+                     reduce_range=False, n_grid: int = 20):
+    """pre_passes/awq.py:114-184, device resident: 20 x {scale -> RTN (oq_rtn_quantize_f32) -> dequantize ->
+    X @ W^ (rocBLAS through torch) -> MSE}; nothing leaves the GPU until the 20 losses are read.
+    Returns (best_scale [K] on device, losses float64[n_grid] on host)."""
+    x2 = _flat_inputs(x)
+    _require_device(w, "w", torch.float32)
+    k, n = w.shape
+    mode, g = _strategy_mode(strategy, k, group_size)
+    act = x2.abs().mean(dim=0)
+    ws = awq_weight_scale(w, strategy, group_size)
+    ref_out = x2 @ w
+    losses, scales = [], []
+    for i in range(n_grid):
+        ratio = i * 1 / n_grid
+        scale = torch.clamp(torch.pow(act, ratio) / torch.pow(ws, 1 - ratio), min=1e-4)
+        scale = scale / torch.sqrt(scale.max() * scale.min())
+        col = scale.reshape(-1, 1)
+        q, s, z = rtn_quantize(w * col, qtype, strategy, group_size, symmetric, reduce_range)
+        w_hat = dequantize(q, s, z, qtype, mode=mode, group=g) / col
+        d = (ref_out - x2 @ w_hat).reshape(-1)
+        losses.append(torch.dot(d, d) / d.numel())
+        scales.append(scale)
+    lv = torch.stack(losses).double().cpu().numpy()
+    best = int(lv.argmin())                      # first minimum, like `loss < best_error` in awq.py:178
+    return scales[best], lv
+
+
+def awq_clip_search(x: torch.Tensor, w: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
+                    reduce_range=False):
+    """pre_passes/awq.py:207-259: (best clip_ratio, losses[10])."""
+    x2 = _flat_inputs(x)
+    _require_device(w, "w", torch.float32)
+    mode, g = _strategy_mode(strategy, w.shape[0], group_size)
+    ref_out = x2 @ w
+    losses = []
+    for i in range(10):
+        ratio = 1 - i / 100
+        q, s, z = rtn_quantize(w, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio=ratio)
+        d = (ref_out - x2 @ dequantize(q, s, z, qtype, mode=mode, group=g)).reshape(-1)
+        losses.append(torch.dot(d, d) / d.numel())
+    lv = torch.stack(losses).double().cpu().numpy()
+    return 1 - int(lv.argmin()) / 100, lv
+
+
+def smooth_quant_scale(x: torch.Tensor, w: torch.Tensor, alpha: float) -> torch.Tensor:
+    """pre_passes/smooth_quant.py:62-74, :111-113 with the column / row absmax kernels (oq_absmax_f32)."""
+    act = torch.clamp(absmax(_flat_inputs(x)), min=1e-5)
+    wsc = absmax(w, per_row=True)
+    return torch.pow(act, alpha) / torch.pow(wsc + 1e-9, 1 - alpha)
+
+
 # ----------------------------------------------------------------------------- N3
 def pack_zero_points_u4(zp: torch.Tensor, n: int, blocks: int) -> torch.Tensor:
     """_common.py:96-121: [N*blocks] 4-bit zero points -> [N, ceil(blocks/2)] (pad nibble 0x8)."""

@@ -25,6 +25,16 @@ def install_into_reference() -> None:
     ref_gptq._gptq_quantize = _gptq_quantize       # gptq.py:51-73 likewise
     ref_hqq._hqq_quantize = _hqq_quantize          # hqq.py:80-97 likewise
     ref_factory._CALIBRATORS[ref_factory.CalibrationMethod.MINMAX] = MinMaxCalibrator
+    # the AWQ pass binds the two helpers by name at import time (pre_passes/awq.py:10-11): rebind them in its namespace
+    try:
+        import onnx_quantize.pre_passes.awq as ref_awq
+
+        from .algorithms.functional import _dequantize_array
+
+        ref_awq._rtn_quantize = _rtn_quantize
+        ref_awq._dequantize_array = _dequantize_array
+    except ImportError:
+        pass
     del ref_cfg
 
 

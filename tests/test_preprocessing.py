@@ -1,0 +1,70 @@
+"""AWQ / SmoothQuant numeric cores (reference pre_passes/awq.py, smooth_quant.py).
+
+PARITY UNPINNED for these two passes: their modules import onnx_ir.passes / onnxscript, which the build container
+does not have, so no golden vectors could be produced by the reference itself; the oracle restates the source as
+read, on top of the (pinned) RTN / dequantize functions, and the GPU composition is checked against that oracle.
+Tolerances: reductions run in a different order on the device, so the search scale differs by a few ulp, an RTN
+integer may flip, and the 20 / 10 losses agree to 2e-3 relative; the chosen grid point must be the oracle's or one
+whose oracle loss is within that tolerance of the oracle's minimum."""
+import numpy as np
+import pytest
+
+import oq_oracle as O
+from onnx_quantize_amd import AwqConfig, QConfig, QWeightArgs, QuantType, SmoothQuantConfig
+
+
+def test_configs_mirror_the_reference():
+    a, s = AwqConfig(), SmoothQuantConfig()
+    assert (a.preprocessing_type, a.clip_search) == ("awq", False)
+    assert (s.preprocessing_type, s.alpha) == ("smooth_quant", 0.5)
+    q = QConfig(weights=QWeightArgs(dtype="uint4", strategy="group", group_size=32), preprocessors=[{"preprocessing_type": "awq", "clip_search": True}],
+                calibration_data=np.zeros((2, 4), np.float32))
+    assert isinstance(q.preprocessors[0], AwqConfig) and q.preprocessors[0].clip_search
+    with pytest.raises(ImportError, match="delegated to the reference package"):
+        a.build_pass(q)
+
+
+def test_oracle_search_properties(rng):
+    """awq.py:143-184: ratio 0 leaves only the weight term; the winning scale is normalised (sqrt(max * min) == 1);
+    the clip search returns a ratio of its grid; SmoothQuant with alpha = 1 is the activation absmax."""
+    x = rng.standard_normal((3, 8, 32)).astype(np.float32) * rng.uniform(0.1, 4, 32).astype(np.float32)
+    w = rng.standard_normal((32, 24)).astype(np.float32)
+    scale, losses = O.awq_scale_search(x, w, "uint4", "group", 16)
+    assert losses.shape == (20,) and np.isclose(np.sqrt(scale.max() * scale.min()), 1.0, rtol=1e-6)
+    ratio, l2 = O.awq_clip_search(x, w, "uint4", "group", 16)
+    assert ratio in [1 - i / 100 for i in range(10)] and l2.shape == (10,)
+    np.testing.assert_allclose(O.smooth_quant_scale(x, w, 1.0), np.maximum(np.abs(x.reshape(-1, 32)).max(0), 1e-5), rtol=1e-6)
+
+
+def _inputs(seed, t, k, n):
+    r = np.random.default_rng(seed)
+    x = r.standard_normal((4, t // 4, k)).astype(np.float32) * r.uniform(0.1, 4, k).astype(np.float32)
+    w = (r.standard_normal((k, n)) * 0.05).astype(np.float32)
+    return x, w
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qtype,strategy,g,sym", [("uint4", "group", 32, False), ("int8", "channel", -1, True), ("uint8", "tensor", -1, False),
+                                                  ("int4", "group", 128, False)])
+def test_gpu_awq_searches_follow_the_oracle(qtype, strategy, g, sym):
+    from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search
+    x, w = _inputs(3, 512, 256, 192)
+    es, el = O.awq_scale_search(x, w, qtype, strategy, g, sym)
+    s, l = awq_scale_search(x, w, QuantType.from_string(qtype), strategy, g, sym)
+    np.testing.assert_allclose(l, el, rtol=2e-3)
+    assert el[int(np.argmin(l))] <= el.min() * (1 + 2e-3)
+    if int(np.argmin(l)) == int(np.argmin(el)):
+        np.testing.assert_allclose(s, es, rtol=1e-5)
+    er, ecl = O.awq_clip_search(x, w, qtype, strategy, g, sym)
+    r, cl = awq_clip_search(x, w, QuantType.from_string(qtype), strategy, g, sym)
+    np.testing.assert_allclose(cl, ecl, rtol=2e-3)
+    assert ecl[int(round((1 - r) * 100))] <= ecl.min() * (1 + 2e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_smooth_quant_scale_matches_oracle():
+    from onnx_quantize_amd.preprocessing import smooth_quant_scale
+    x, w = _inputs(4, 1024, 384, 128)
+    x[..., 7] = 0.0                                   # a dead activation channel: clamped to 1e-5 (smooth_quant.py:66-67)
+    for alpha in (0.5, 0.25, 1.0):
+        np.testing.assert_allclose(smooth_quant_scale(x, w, alpha), O.smooth_quant_scale(x, w, alpha), rtol=2e-6)
