@@ -66,7 +66,18 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
     const int64_t cc = live ? c : a.N - 1;  // clamped column for loads
     const int count = static_cast<int>(a.count);
 
-    for (int i = wave; i < count; i += 4) tile[i][lane] = a.W[(a.i1 + i) * a.N + cc];
+    // 8 loads in flight per lane (a load -> LDS store chain per row would pay the memory latency 32 times)
+    for (int i0 = wave; i0 < count; i0 += 32) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 4 * u;
+            x[u] = a.W[(a.i1 + (i < count ? i : count - 1)) * a.N + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 4 * u < count) tile[i0 + 4 * u][lane] = x[u];
+    }
 
     float scale = 1.0f;
     int32_t zp = 0;
@@ -86,14 +97,23 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
         const int ns = count - s0 < kSubRows ? count - s0 : kSubRows;   // rows of this sub-block
         // gptq.py:199 as written (PARITY): column i1+i of U below the diagonal -> U[(i1+j)*K + i1+i] (exact zeros);
         // CORRECTED: row i1+i right of the diagonal -> U[(i1+i)*K + i1+j].  The diagonal entry is the divisor.
-        for (int idx = threadIdx.x; idx < ns * kLoopMaxRows; idx += blockDim.x) {
-            const int i = idx / kLoopMaxRows, j = idx - i * kLoopMaxRows;
-            float v = 0.0f;
-            if (j < count) {
-                const int64_t ri = a.i1 + s0 + i, rj = a.i1 + j;
-                v = (a.mode == OQ_GPTQ_PARITY && j != s0 + i) ? a.U[rj * a.K + ri] : a.U[ri * a.K + rj];
+        {   // 32 x 128 coefficients, 16 per thread, all loads in flight before the first LDS store
+            constexpr int kPer = kSubRows * kLoopMaxRows / 256;
+            float cv[kPer];
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int idx = threadIdx.x + u * 256;
+                const int i = idx / kLoopMaxRows, j = idx - i * kLoopMaxRows;
+                const int ic = i < ns ? i : ns - 1, jc = j < count ? j : count - 1;   // clamped loads, masked stores
+                const int64_t ri = a.i1 + s0 + ic, rj = a.i1 + jc;
+                cv[u] = (a.mode == OQ_GPTQ_PARITY && jc != s0 + ic) ? a.U[rj * a.K + ri] : a.U[ri * a.K + rj];
             }
-            coef[i][j] = v;
+#pragma unroll
+            for (int u = 0; u < kPer; ++u) {
+                const int idx = threadIdx.x + u * 256;
+                const int i = idx / kLoopMaxRows, j = idx - i * kLoopMaxRows;
+                if (i < ns) coef[i][j] = j < count ? cv[u] : 0.0f;
+            }
         }
         // gptq.py:168-184: parameters of every group that starts in this sub-block, from rows [row, row + g) of the
         // GLOBAL working matrix (not of the block copy), channel strategy -- or the ones an MSE search left.  All
