@@ -162,10 +162,23 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
     const int n = static_cast<int>((K - o) < kNB ? (K - o) : kNB);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    for (int idx = t; idx < kNB * kNB; idx += blockDim.x) {
-        const int r = idx / kNB, c = idx - r * kNB;
-        A[r][c] = (r < n && c < n) ? P[(o + r) * K + o + c] : (r == c ? 1.0f : 0.0f);
-        M[r][c] = 0.0f;
+    // the block arrives with 16 loads in flight per thread (a load -> LDS store chain per element would pay the
+    // memory latency 64 times); clamped coordinates, identity padding applied on the way into LDS
+    for (int b0 = 0; b0 < kNB * kNB; b0 += 16 * 256) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = b0 + u * 256 + t;
+            const int r = idx / kNB, c = idx - r * kNB;
+            x[u] = P[(o + (r < n ? r : n - 1)) * K + o + (c < n ? c : n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = b0 + u * 256 + t;
+            const int r = idx / kNB, c = idx - r * kNB;
+            A[r][c] = (r < n && c < n) ? x[u] : (r == c ? 1.0f : 0.0f);
+            M[r][c] = 0.0f;
+        }
     }
     __syncthreads();
 
