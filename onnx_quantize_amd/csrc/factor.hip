@@ -81,9 +81,10 @@ __global__ __launch_bounds__(1024) void damp_kernel(float* P, int64_t K, float p
 // Recursive blocking by 32: a 32 x 32 sub-block is factored and inverted by ONE wave out of registers (lane i
 // holds row i; the rows / columns another lane needs arrive by v_readlane, no LDS round trip, no barrier); the
 // panel below it, the trailing update and the off-diagonal blocks of the inverse are dense LDS products spread
-// over all 256 threads (2 x 2 outputs per thread).  The sequential chain is 4 x (two 32-step register loops)
+// over all 512 threads (2 x 2 outputs per thread).  The sequential chain is 4 x (two 32-step register loops)
 // instead of 128 barrier-separated columns plus a 127-step substitution per thread.
 constexpr int kSB = 32;
+constexpr int kDiagThreads = 512;   // 8 waves: the dense LDS phases are latency-bound with one wave per SIMD (1024 threads cap the VGPRs at 128 and spill the register loops: same time)
 
 __device__ __forceinline__ float lane_value(float v, int src_lane) {   // src_lane is a compile-time constant below
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
@@ -152,7 +153,7 @@ __device__ __forceinline__ void lds_product(int mr, int nc, int kd, FA fa, FB fb
 //   Lt   [K, K]: Lt[k][i] = L[i][k]  (upper triangular = L^T), diag block written here
 //   Dinv [nb][128][128]: Dinv[kb][k][c] = inv(L_kk)[c][k]  (transposed, zero above the diagonal of the inverse)
 //   info: first non-positive pivot (1-based, in reversed index space), 0 if none so far
-__global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t K, int64_t kb, float* Lt, float* Dinv,
+__global__ __launch_bounds__(kDiagThreads) void chol_diag_kernel(const float* P, int64_t K, int64_t kb, float* Lt, float* Dinv,
                                                         int32_t* info) {
     extern __shared__ float lds[];
     float (*A)[kLd] = reinterpret_cast<float (*)[kLd]>(lds);                    // the block; lower triangle becomes L
@@ -164,17 +165,17 @@ __global__ __launch_bounds__(256) void chol_diag_kernel(const float* P, int64_t 
     const int lane = t & 63, wave = t >> 6;
     // the block arrives with 16 loads in flight per thread (a load -> LDS store chain per element would pay the
     // memory latency 64 times); clamped coordinates, identity padding applied on the way into LDS
-    for (int b0 = 0; b0 < kNB * kNB; b0 += 16 * 256) {
+    for (int b0 = 0; b0 < kNB * kNB; b0 += 16 * kDiagThreads) {
         float x[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int idx = b0 + u * 256 + t;
+            const int idx = b0 + u * kDiagThreads + t;
             const int r = idx / kNB, c = idx - r * kNB;
             x[u] = P[(o + (r < n ? r : n - 1)) * K + o + (c < n ? c : n - 1)];
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const int idx = b0 + u * 256 + t;
+            const int idx = b0 + u * kDiagThreads + t;
             const int r = idx / kNB, c = idx - r * kNB;
             A[r][c] = (r < n && c < n) ? x[u] : (r == c ? 1.0f : 0.0f);
             M[r][c] = 0.0f;
@@ -360,7 +361,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             const int64_t kb = o / kNB;
             const int64_t n = (K - o) < kNB ? (K - o) : kNB;
             const int64_t rest = K - o - n;  // columns behind this block
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), diag_lds, s, P, K, kb, Lt, Dinv, info);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(kDiagThreads), diag_lds, s, P, K, kb, Lt, Dinv, info);
             st = check_launch("chol_diag_kernel");
             if (st != OQ_OK) return st;
             if (rest <= 0) break;
