@@ -163,6 +163,18 @@ def main() -> None:
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream: device time of the K launches
 
+    # per-launch distribution (median, p10 / p90): 100 more launches, one event pair each
+    pct = None
+    if world == 1 and not args.no_extras:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            step(i)
+            b.record()
+        torch.cuda.synchronize()
+        d = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+        pct = [round(d[10], 2), round(d[50], 2), round(d[90], 2)]
+
     # the other output layout, shorter run, same buffers (reported next to the headline, never as `value`)
     other = "kn" if args.layout == "nbits" else "nbits"
     other_us = None
@@ -283,7 +295,7 @@ def main() -> None:
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel": "oq::rtn_group_wave<8,true>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
-                     "launch_us": round(launch_us, 2),
+                     "launch_us": round(launch_us, 2), "launch_us_p10_p50_p90": pct,
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
     }
     if world == 1 and not args.no_cpu_baseline:
