@@ -3,8 +3,9 @@
 a gemma-3-270m-shaped model.  gemma-3-270m itself is not obtainable offline, so the activation population is
 synthetic with the same shapes: per batch of 10 samples, 18 layers x { [10,512,640] x 2 (attention
 and MLP inputs), [10,512,1024] (o_proj input), [10,512,2048] (down_proj input) } fp32; 51 batches (the reference
-drops the 2 remaining samples, calibrate.py:161-170).  Every tensor goes through MinMaxCalibrator.collect on the
-GPU (one HBM-bound reduction, running state on the device), then compute_range + _compute_qparams per tensor.
+drops the 2 remaining samples, calibrate.py:161-170).  Every batch goes through MinMaxCalibrator.collect_many on the GPU (ONE launch pair per batch of 72 tensors, running
+state on the device; the per-tensor `collect` loop of calibrate.py:264-266 is timed next to it), then compute_range +
+_compute_qparams per tensor.
 Prints one JSON line: tensors/s, GB/s of activation bytes reduced, and the large-tensor reduction rate.
 """
 import json
@@ -43,7 +44,19 @@ def main():
         for name, t in acts.items():
             cal.collect(name, t)
     torch.cuda.synchronize()
+    t_per_tensor = time.perf_counter() - t0
+    # the same statistics with one launch pair per batch (oq_minmax_collect_many_f32): what an on-device driver calls
+    cal_many = MinMaxCalibrator()
+    cal_many.collect_many(acts)
+    torch.cuda.synchronize()
+    cal_many = MinMaxCalibrator()
+    t0 = time.perf_counter()
+    for b in range(batches):
+        cal_many.collect_many(acts)
+    torch.cuda.synchronize()
     t_collect = time.perf_counter() - t0
+    for name in list(acts)[:8]:
+        assert cal_many.data[name].min_val == cal.data[name].min_val and cal_many.data[name].max_val == cal.data[name].max_val
     t1 = time.perf_counter()
     qparams = {}
     for name in acts:
@@ -71,8 +84,11 @@ def main():
         "value": round(nbytes * batches / t_collect / 1e9, 1), "unit": "GB/s", "n_gpus": 1,
         "config": {"workload": "calibration_minmax_gemma3_270m_shapes", "layers": layers, "batches": batches,
                    "tensors_per_batch": len(acts), "bytes_per_batch": nbytes},
-        "seconds": {"collect": round(t_collect, 4), "ranges_and_qparams": round(t_params, 4)},
+        "seconds": {"collect": round(t_collect, 4), "ranges_and_qparams": round(t_params, 4),
+                    "collect_per_tensor_calls": round(t_per_tensor, 4)},
         "tensors_per_s": round(len(acts) * batches / t_collect, 1),
+        "per_tensor_calls": {"GBs": round(nbytes * batches / t_per_tensor / 1e9, 1),
+                             "tensors_per_s": round(len(acts) * batches / t_per_tensor, 1)},
         "roofline": {"bound": "hbm", "achieved": round(big_gbs, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(big_gbs / 8000.0, 4), "kernel": "oq::minmax_partial<float> (1.3 GB tensor)"},
     }))

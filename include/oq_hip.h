@@ -143,6 +143,18 @@ int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, co
 int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale,
                              float x_scale, int32_t* q_out, float* bias_scale_out, void* stream);
 
+/* C1 for a whole calibration batch: n tensors in ONE launch pair (calibrate.py:264-266 calls collect once per
+ *     tensor and batch; dozens of 10-40 MB tensors per batch make that loop launch-bound).  `desc` is a DEVICE
+ *     array of n oq_minmax_desc {x, count, state}; every count > 0; each state as in oq_minmax_collect_f32. */
+typedef struct {
+    const float* x;
+    int64_t count;
+    float* state;
+} oq_minmax_desc;
+size_t oq_minmax_many_workspace_bytes(int64_t n);
+int32_t oq_minmax_collect_many_f32(const void* desc, int64_t n, double momentum, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * C1  core/_calibration/minmax.py:40-64  MinMaxCalibrator.collect for one activation tensor:
  *     cur = (min(x), max(x)); first sight: state = cur; momentum > 0: state = m*state + (1-m)*cur

@@ -156,6 +156,27 @@ class MinMaxCalibrator(Calibrator):
             x = x.to(entry._state.dtype)
         ops.minmax_collect(x, entry._state, self.momentum)
 
+    def collect_many(self, arrays) -> None:
+        """``collect`` for a whole calibration batch ({name: fp32 torch tensor in HBM}) in one launch pair -- what an
+        on-device calibration driver calls once per batch instead of calibrate.py:264-266's per-tensor loop.  Same
+        statistics as calling ``collect`` for every item (first sight / EMA / running min-max per name)."""
+        import torch
+
+        from .hip import ops
+
+        names, xs = [], []
+        for name, t in arrays.items():
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32) or (
+                    name in self.data and self.data[name]._state.dtype != torch.float32):
+                self.collect(name, t)            # anything else takes the per-tensor path
+                continue
+            if name not in self.data:
+                self.data[name] = CalibrationData(ops.minmax_state(t.device, torch.float32), np.dtype(np.float32))
+            names.append(name)
+            xs.append(t)
+        if xs:
+            ops.minmax_collect_many(xs, [self.data[n]._state for n in names], self.momentum)
+
     def compute_range(self, name: str) -> tuple[np.ndarray, np.ndarray]:
         if name not in self.data:
             raise KeyError(f"No calibration data collected for '{name}'")

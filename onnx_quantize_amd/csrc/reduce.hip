@@ -115,6 +115,83 @@ static int32_t minmax_collect(const T* x, int64_t count, T* state, double moment
     return check_launch("minmax_update");
 }
 
+// ---------------------------------------------------------------------------------- C1 for a list of tensors
+// One calibration batch hands over dozens of activation tensors (gemma-3-270m: 72 per batch of 13-42 MB each): at
+// 2 launches per tensor the loop is launch-bound (2.0 TB/s end to end against 5.5 TB/s for the reduction itself).
+// Here ONE launch pair serves the whole list: blockIdx.y = tensor, blockIdx.x = slice of it.
+struct ManyDesc {   // device-resident, 24 bytes per tensor (oq_hip.h: oq_minmax_desc)
+    const float* x;
+    int64_t count;
+    float* state;
+};
+
+__global__ __launch_bounds__(kRedBlock) void minmax_many_partial(const ManyDesc* desc, float* partial /* [n][gridDim.x][2] */) {
+    __shared__ float s_mn[kRedBlock / 64], s_mx[kRedBlock / 64];
+    const ManyDesc d = desc[blockIdx.y];
+    const float* x = d.x;
+    const int64_t count = d.count;
+    // peel to 16-byte alignment: [head | float4 body | tail]
+    int64_t vec_off = static_cast<int64_t>(((16 - reinterpret_cast<uintptr_t>(x) % 16) % 16) / 4);
+    if (vec_off > count) vec_off = count;
+    const int64_t nvec = (count - vec_off) / 4;
+    const float4* xv = reinterpret_cast<const float4*>(x + vec_off);
+    const int64_t tid = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    float mn = INFINITY, mx = -INFINITY;
+    int64_t i = tid;
+    for (; i + stride < nvec; i += 2 * stride) {   // two independent 16-byte loads in flight per lane and iteration
+        const float4 a = xv[i], b = xv[i + stride];
+        mn = fminf(fminf(fminf(mn, a.x), fminf(a.y, a.z)), fminf(fminf(a.w, b.x), fminf(b.y, fminf(b.z, b.w))));
+        mx = fmaxf(fmaxf(fmaxf(mx, a.x), fmaxf(a.y, a.z)), fmaxf(fmaxf(a.w, b.x), fmaxf(b.y, fmaxf(b.z, b.w))));
+    }
+    for (; i < nvec; i += stride) {
+        const float4 a = xv[i];
+        mn = fminf(fminf(mn, a.x), fminf(fminf(a.y, a.z), a.w));
+        mx = fmaxf(fmaxf(mx, a.x), fmaxf(fmaxf(a.y, a.z), a.w));
+    }
+    for (int64_t j = tid; j < vec_off; j += stride) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
+    for (int64_t j = vec_off + nvec * 4 + tid; j < count; j += stride) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
+    block_minmax(mn, mx, s_mn, s_mx);
+    if (threadIdx.x == 0) {
+        float* o = partial + (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 2;
+        o[0] = mn;
+        o[1] = mx;
+    }
+}
+
+// one wave per tensor: fold its slices and apply minmax.py:50-64 to its state
+__global__ __launch_bounds__(64) void minmax_many_update(const ManyDesc* desc, const float* partial, int slices, double momentum) {
+    const float* p = partial + static_cast<int64_t>(blockIdx.x) * slices * 2;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = threadIdx.x; i < slices; i += 64) {
+        mn = fminf(mn, p[2 * i]);
+        mx = fmaxf(mx, p[2 * i + 1]);
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (threadIdx.x != 0) return;
+    float* state = desc[blockIdx.x].state;
+    if (state[2] == 0.0f) {
+        state[0] = mn;
+        state[1] = mx;
+        state[2] = 1.0f;
+    } else if (momentum > 0.0) {
+        const float m = static_cast<float>(momentum), om = static_cast<float>(1.0 - momentum);
+        state[0] = m * state[0] + om * mn;
+        state[1] = m * state[1] + om * mx;
+    } else {
+        state[0] = fminf(state[0], mn);
+        state[1] = fmaxf(state[1], mx);
+    }
+}
+
+static int many_slices(int64_t n) {   // ~4096 blocks in total, 4..64 slices per tensor
+    int64_t s = 4096 / (n > 0 ? n : 1);
+    if (s < 4) s = 4;
+    if (s > 64) s = 64;
+    return static_cast<int>(s);
+}
+
 // ------------------------------------------------------------------------------------- absmax
 constexpr int kAbsChunkRows = 128;
 
@@ -229,6 +306,28 @@ int32_t oq_minmax_collect_f32(const float* x, int64_t count, float* state, doubl
 int32_t oq_minmax_collect_f64(const double* x, int64_t count, double* state, double momentum, void* workspace,
                               size_t workspace_bytes, void* stream) {
     return minmax_collect<double>(x, count, state, momentum, workspace, workspace_bytes, stream);
+}
+
+size_t oq_minmax_many_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return static_cast<size_t>(n) * many_slices(n) * 2 * sizeof(float) + 256;
+}
+
+int32_t oq_minmax_collect_many_f32(const void* desc, int64_t n, double momentum, void* workspace, size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(desc && n > 0 && n <= 65535, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_collect_many_f32: bad argument (1 <= n <= 65535)");
+    OQ_REQUIRE(momentum >= 0.0 && momentum < 1.0, OQ_ERR_INVALID_ARGUMENT, "Momentum must be in the range [0, 1).");
+    const size_t need = oq_minmax_many_workspace_bytes(n);
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_minmax_collect_many_f32: workspace of %zu bytes needed, %zu given",
+               need, workspace_bytes);
+    const int slices = many_slices(n);
+    hipStream_t s = as_stream(stream);
+    const ManyDesc* d = static_cast<const ManyDesc*>(desc);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(minmax_many_partial, dim3(static_cast<uint32_t>(slices), static_cast<uint32_t>(n)), dim3(kRedBlock), 0, s, d, partial);
+    int32_t st = check_launch("minmax_many_partial");
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(minmax_many_update, dim3(static_cast<uint32_t>(n)), dim3(64), 0, s, d, partial, slices, momentum);
+    return check_launch("minmax_many_update");
 }
 
 size_t oq_absmax_workspace_bytes(int64_t R, int64_t C, int32_t transposed) {

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "oq_minmax_workspace_bytes": (_sz, [_i64]),
     "oq_minmax_collect_f32": (_i32, [_p, _i64, _p, _f64, _p, _sz, _p]),
     "oq_minmax_collect_f64": (_i32, [_p, _i64, _p, _f64, _p, _sz, _p]),
+    "oq_minmax_many_workspace_bytes": (_sz, [_i64]),
+    "oq_minmax_collect_many_f32": (_i32, [_p, _i64, _f64, _p, _sz, _p]),
     "oq_absmax_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oq_absmax_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "oq_hessian_workspace_bytes": (_sz, [_i64, _i64]),

@@ -293,6 +293,27 @@ def minmax_collect(x: torch.Tensor, state: torch.Tensor, momentum: float = 0.0) 
         L.check(st)
 
 
+def minmax_collect_many(xs, states, momentum: float = 0.0) -> None:
+    """minmax.py:40-64 for a list of fp32 tensors in ONE launch pair (oq_minmax_collect_many_f32): ``xs[i]`` is folded
+    into ``states[i]``.  The 24-byte descriptors travel in one small host-to-device copy per call."""
+    if len(xs) != len(states) or not xs:
+        raise ValueError("minmax_collect_many needs equally long, non-empty lists")
+    flats = []
+    for x, st in zip(xs, states):
+        if not x.is_cuda or x.dtype != torch.float32 or st.dtype != torch.float32:
+            raise TypeError("minmax_collect_many takes fp32 tensors in GPU memory (use minmax_collect for fp64)")
+        f = x if x.is_contiguous() else x.contiguous()
+        if f.numel() == 0:
+            raise ValueError("zero-size array to reduction operation minimum which has no identity")
+        flats.append(f)
+    dev = flats[0].device
+    table = torch.tensor([[f.data_ptr(), f.numel(), st.data_ptr()] for f, st in zip(flats, states)], dtype=torch.int64)
+    desc = table.to(dev, non_blocking=False)
+    lib = L.load()
+    ws = _workspace(lib.oq_minmax_many_workspace_bytes(len(flats)), dev)
+    L.check(lib.oq_minmax_collect_many_f32(_ptr(desc), len(flats), float(momentum), _ptr(ws), ws.numel(), _stream()))
+
+
 def absmax(x: torch.Tensor, per_row: bool = False) -> torch.Tensor:
     """smooth_quant.py:62-74: max |x| per last-axis channel ([..., C] -> [C]); per_row=True gives the
     per-row absmax of a 2-D matrix (weights [K, N] -> [K])."""

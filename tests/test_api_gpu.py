@@ -235,6 +235,33 @@ class TestMinMaxCalibrator:
         c.collect("odd", y[:7])
         assert c.data["odd"].min_val == min(y[1:].min().item(), y[:7].min().item())
 
+    @pytest.mark.parametrize("momentum", [0.0, 0.8])
+    def test_collect_many_equals_per_tensor_collect(self, momentum):
+        """One launch pair per calibration batch (oq_minmax_collect_many_f32) leaves exactly the state that per-tensor
+        collect calls leave -- first sight, running min / max and the fp32 EMA -- for ragged sizes, unaligned views
+        and names that appear only in some batches."""
+        import torch
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        a, b = self.make(momentum=momentum), self.make(momentum=momentum)
+        base = torch.randn(3_000_011, generator=gen, device="cuda")
+        for batch in range(4):
+            tensors = {"act0": torch.randn((10, 512, 640), generator=gen, device="cuda") * (batch + 1),
+                       "act1": torch.randn((7, 333), generator=gen, device="cuda") - batch,
+                       "odd": base[1 + batch: 1 + batch + 1_000_001],
+                       "tiny": torch.randn(3, generator=gen, device="cuda")}
+            if batch % 2:
+                tensors["sometimes"] = torch.randn((64, 1024), generator=gen, device="cuda")
+            a.collect_many(tensors)
+            for name, t in tensors.items():
+                b.collect(name, t)
+            for name in tensors:
+                assert np.float32(a.data[name].min_val).tobytes() == np.float32(b.data[name].min_val).tobytes(), (batch, name)
+                assert np.float32(a.data[name].max_val).tobytes() == np.float32(b.data[name].max_val).tobytes(), (batch, name)
+        assert set(a.data) == set(b.data)
+        # host arrays and fp64 tensors fall back to the per-tensor path inside collect_many
+        a.collect_many({"host": np.array([1.0, -2.0, 3.0]), "f64": torch.tensor([4.0, -5.0], dtype=torch.float64, device="cuda")})
+        assert (a.data["host"].min_val, a.data["host"].max_val) == (-2.0, 3.0) and a.data["f64"].min_val == -5.0
+
 
 def test_absmax_reductions():
     """S1: smooth_quant.py:62-74 column / row absmax."""
