@@ -150,13 +150,20 @@ def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], min
         return {specs[i].name: mine[i] for i in sorted(mine)}, 0
     order = plan[rank]
     parts, meta = [], []
+    pad16 = lambda nbytes: (nbytes + 15) // 16 * 16   # noqa: E731  every tensor starts 16-byte aligned in the flat buffer
     for i in order:
         q, s, z = mine[i]
         for t in (q, s, z):
-            parts.append(t.contiguous().view(-1).view(torch.uint8))
+            b = t.contiguous().view(-1).view(torch.uint8)
+            parts.append(b)
+            if pad16(b.numel()) != b.numel():
+                parts.append(torch.zeros(pad16(b.numel()) - b.numel(), dtype=torch.uint8, device=b.device))
         meta.append((i, str(q.dtype), tuple(q.shape), tuple(s.shape), str(z.dtype), tuple(z.shape),
                      q.numel() * q.element_size(), s.numel() * 4, z.numel() * z.element_size()))
-    dev = parts[0].device if parts else torch.device("cuda", torch.cuda.current_device())
+    if parts:
+        dev = parts[0].device
+    else:   # a rank without work still takes part in the exchange, on the backend's device
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     flat = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.uint8, device=dev)
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     sizes[rank] = flat.numel()
@@ -176,8 +183,8 @@ def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], min
         o = 0
         for (i, qd, qs, ss, zd, zs, nq, ns, nz) in metas[r]:
             buf = recv[r]
-            q = buf[o:o + nq].view(getattr(torch, qd.split(".")[-1])).reshape(qs); o += nq
-            s = buf[o:o + ns].view(torch.float32).reshape(ss); o += ns
-            z = buf[o:o + nz].view(getattr(torch, zd.split(".")[-1])).reshape(zs); o += nz
+            q = buf[o:o + nq].view(getattr(torch, qd.split(".")[-1])).reshape(qs); o += (nq + 15) // 16 * 16
+            s = buf[o:o + ns].view(torch.float32).reshape(ss); o += (ns + 15) // 16 * 16
+            z = buf[o:o + nz].view(getattr(torch, zd.split(".")[-1])).reshape(zs); o += (nz + 15) // 16 * 16
             out[specs[i].name] = (q, s, z)
     return {s.name: out[s.name] for s in specs}, total

@@ -94,6 +94,54 @@ def test_two_rank_gather_gloo():
     assert q.get(timeout=5) is True
 
 
+def _worker_device_gather(rank, world, port, q):
+    """gather_device_results (the exchange bench_gptq.py uses with RCCL) over gloo with CPU tensors: odd byte counts,
+    a rank with nothing to send, dtypes and shapes restored on rank 0."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from onnx_quantize_amd.sharding import LayerSpec, gather_device_results
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [LayerSpec(f"m{i}", 8 + i, 5 + 2 * i) for i in range(5)]
+    plan = [[0, 2, 3, 4], [1]] if world == 2 else [[0, 1, 2, 3, 4], [], []][:world]
+
+    def result(i):
+        g = torch.Generator().manual_seed(100 + i)
+        k, n = specs[i].k, specs[i].n
+        return (torch.randint(0, 255, ((k * n + 1) // 2,), generator=g, dtype=torch.uint8),     # odd byte counts
+                torch.rand((n * 3, 1), generator=g), torch.randint(-8, 7, (n * 3, 1), generator=g, dtype=torch.int8))
+    mine = {i: result(i) for i in plan[rank]}
+    out, nbytes = gather_device_results(specs, plan, mine)
+    if rank == 0:
+        ok = list(out) == [s.name for s in specs] and nbytes > 0
+        for i, s in enumerate(specs):
+            e = result(i)
+            ok = ok and all(torch.equal(a, b) and a.dtype == b.dtype and a.shape == b.shape for a, b in zip(out[s.name], e))
+        q.put(bool(ok))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_result_gather_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_device_gather, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_single_process_path():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oq_oracle as O
