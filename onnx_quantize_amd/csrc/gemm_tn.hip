@@ -177,10 +177,12 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
         float (*tA)[kBM] = sA[buf];
         float (*tB)[kBN] = sB[buf];
         auto rd = [&](int k, float& x0, float& x1, float& y0, float& y1) {
-            x0 = tA[k + kl][wm * 64 + cl];
-            x1 = tA[k + kl][wm * 64 + 32 + cl];
-            y0 = tB[k + kl][wn * 64 + cl];
-            y1 = tB[k + kl][wn * 64 + 32 + cl];
+            // a wave owns rows / columns {w*32 .. w*32+31} and {64 + w*32 ..} of the block tile: its two operand halves
+            // sit 256 B apart in LDS, so each pair is ONE ds_read2st64_b32 with immediate offsets for every k-pair
+            x0 = tA[k + kl][wm * 32 + cl];
+            x1 = tA[k + kl][wm * 32 + 64 + cl];
+            y0 = tB[k + kl][wn * 32 + cl];
+            y1 = tB[k + kl][wn * 32 + 64 + cl];
         };
         float xa[2][2], yb[2][2];   // [set][half]
         rd(0, xa[0][0], xa[0][1], yb[0][0], yb[0][1]);
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
-                    const int64_t col = n0 + wn * 64 + j * 32 + cl;
+                    const int64_t row = m0 + wm * 32 + i * 64 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                    const int64_t col = n0 + wn * 32 + j * 64 + cl;
                     if (row < g.M && col < g.N) out[row * g.N + col] = acc[i][j][e];
                 }
         return;
@@ -268,8 +270,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
-                const int64_t col = n0 + wn * 64 + j * 32 + cl;
+                const int64_t row = m0 + wm * 32 + i * 64 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int64_t col = n0 + wn * 32 + j * 64 + cl;
                 if (row < g.M && col < g.N) {
                     float v = g.alpha * acc[i][j][e];
                     if (g.beta != 0.0f) v = g.beta * g.C[row * g.ldc + col] + v;
