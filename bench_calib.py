@@ -58,11 +58,29 @@ def main():
     for name in list(acts)[:8]:
         assert cal_many.data[name].min_val == cal.data[name].min_val and cal_many.data[name].max_val == cal.data[name].max_val
     t1 = time.perf_counter()
-    qparams = {}
-    for name in acts:
+    qparams_ref = {}
+    for name in acts:                      # the reference's call pattern: one round trip per name (calibrate.py:268-285)
         lo, hi = cal.compute_range(name)
-        qparams[name] = _compute_qparams(lo, hi, QuantType.QInt8, False, False, "float32", QuantType.QInt8.np_dtype)
+        qparams_ref[name] = _compute_qparams(lo, hi, QuantType.QInt8, False, False, "float32", QuantType.QInt8.np_dtype)
+    t_params_per_name = time.perf_counter() - t1
+    cal_many.compute_qparams_many(list(acts)[:2], QuantType.QInt8)
+    t1 = time.perf_counter()
+    qparams = cal_many.compute_qparams_many(list(acts), QuantType.QInt8)     # one kernel, one copy
     t_params = time.perf_counter() - t1
+    for name in acts:
+        assert qparams[name][0].tobytes() == qparams_ref[name][0].tobytes() and int(qparams[name][1]) == int(qparams_ref[name][1])
+    # the weight side of the same configuration (static QInt8, per-tensor symmetric like BASELINE config 1) on the
+    # gemma-3-270m MatMul shapes: 18 layers x {q 640x1024, k / v 640x256, o 1024x640, gate / up 640x2048, down 2048x640}
+    wshapes = [(640, 1024), (640, 256), (640, 256), (1024, 640), (640, 2048), (640, 2048), (2048, 640)]
+    weights = [torch.randn(kn, generator=gen, device=dev) * 0.05 for _ in range(layers) for kn in wshapes]
+    for w in weights[:7]:
+        ops.rtn_quantize(w, "int8", "tensor", -1, True)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    wq = [ops.rtn_quantize(w, "int8", "tensor", -1, True) for w in weights]
+    torch.cuda.synchronize()
+    t_weights = time.perf_counter() - t2
+    wparams = sum(w.numel() for w in weights)
     # correctness spot check against torch
     for name in list(acts)[:6]:
         assert cal.data[name].min_val == acts[name].min().item() and cal.data[name].max_val == acts[name].max().item()
@@ -85,7 +103,9 @@ def main():
         "config": {"workload": "calibration_minmax_gemma3_270m_shapes", "layers": layers, "batches": batches,
                    "tensors_per_batch": len(acts), "bytes_per_batch": nbytes},
         "seconds": {"collect": round(t_collect, 4), "ranges_and_qparams": round(t_params, 4),
-                    "collect_per_tensor_calls": round(t_per_tensor, 4)},
+                    "collect_per_tensor_calls": round(t_per_tensor, 4), "ranges_and_qparams_per_name_calls": round(t_params_per_name, 4),
+                    "weights_rtn_int8_per_tensor": round(t_weights, 4)},
+        "weights": {"matrices": len(weights), "params": wparams, "M_params_per_s": round(wparams / t_weights / 1e6, 1)},
         "tensors_per_s": round(len(acts) * batches / t_collect, 1),
         "per_tensor_calls": {"GBs": round(nbytes * batches / t_per_tensor / 1e9, 1),
                              "tensors_per_s": round(len(acts) * batches / t_per_tensor, 1)},

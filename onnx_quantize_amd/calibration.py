@@ -187,6 +187,33 @@ class MinMaxCalibrator(Calibrator):
         return np.array(np.minimum(lo, 0), dtype=np.float32), np.array(np.maximum(hi, 0), dtype=np.float32)
 
 
+    def compute_qparams_many(self, names, quant_type, is_symmetric: bool = False, reduce_range: bool = False):
+        """``compute_range`` + ``_compute_qparams`` (calibrate.py:268-285) for a list of fp32 names with ONE kernel and
+        ONE device-to-host copy instead of a round trip per name.  Returns {name: (scale fp32 0-d, zero_point 0-d in the
+        activation dtype)}; unseen names raise KeyError like ``compute_range``."""
+        import torch
+
+        from .hip import ops
+
+        names = list(names)
+        for n in names:
+            if n not in self.data:
+                raise KeyError(f"No calibration data collected for '{n}'")
+        if not names:
+            return {}
+        if any(self.data[n]._state.dtype != torch.float32 for n in names):     # float64 names: the per-name path
+            from .algorithms.functional import _compute_qparams
+            return {n: _compute_qparams(*self.compute_range(n), quant_type, is_symmetric, reduce_range, np.float32, quant_type.np_dtype)
+                    for n in names}
+        st = torch.stack([self.data[n]._state for n in names])               # [n, 4] on the device
+        zero = torch.zeros((), dtype=torch.float32, device=st.device)
+        lo, hi = torch.minimum(st[:, 0], zero), torch.maximum(st[:, 1], zero)  # minmax.py:83-87 zero is part of the range
+        scale, zp = ops.qparams(lo.contiguous(), hi.contiguous(), quant_type.key, bool(is_symmetric), bool(reduce_range))
+        both = torch.stack([scale, zp.to(torch.float32)]).cpu().numpy()       # zero points of 8-bit grids are exact in fp32
+        return {n: (np.array(both[0, i], dtype=np.float32), np.array(both[1, i]).astype(quant_type.np_dtype))
+                for i, n in enumerate(names)}
+
+
 _CALIBRATORS: dict[CalibrationMethod, type[Calibrator]] = {CalibrationMethod.MINMAX: MinMaxCalibrator}
 
 

@@ -262,6 +262,24 @@ class TestMinMaxCalibrator:
         a.collect_many({"host": np.array([1.0, -2.0, 3.0]), "f64": torch.tensor([4.0, -5.0], dtype=torch.float64, device="cuda")})
         assert (a.data["host"].min_val, a.data["host"].max_val) == (-2.0, 3.0) and a.data["f64"].min_val == -5.0
 
+    def test_compute_qparams_many_equals_per_name_path(self):
+        """One kernel + one copy for all names == compute_range + _compute_qparams per name (calibrate.py:268-285)."""
+        import torch
+        from onnx_quantize_amd import QuantType
+        from onnx_quantize_amd.algorithms.functional import _compute_qparams
+        c = self.make()
+        gen = torch.Generator(device="cuda").manual_seed(8)
+        data = {f"t{i}": torch.randn(1000 + 37 * i, generator=gen, device="cuda") * (i + 0.5) + (i - 3) for i in range(9)}
+        data["positive"] = torch.rand(500, generator=gen, device="cuda") + 2.0      # zero must still be inside the range
+        c.collect_many(data)
+        for qt, sym in ((QuantType.QInt8, False), (QuantType.QUInt8, False), (QuantType.QInt8, True)):
+            many = c.compute_qparams_many(list(data), qt, sym)
+            for name in data:
+                es, ez = _compute_qparams(*c.compute_range(name), qt, sym, False, np.float32, qt.np_dtype)
+                assert many[name][0].tobytes() == es.tobytes() and int(many[name][1]) == int(ez) and many[name][1].dtype == ez.dtype
+        with pytest.raises(KeyError):
+            c.compute_qparams_many(["nope"], QuantType.QInt8)
+
 
 def test_absmax_reductions():
     """S1: smooth_quant.py:62-74 column / row absmax."""
