@@ -38,8 +38,12 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert lib.oq_abi_version() == 1
 
 
-def test_code_object_is_gfx950(lib_path):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", lib_path], capture_output=True, text=True)
+def test_code_object_is_gfx950(lib_path, tmp_path):
+    # llvm-objdump --offloading drops the extracted code objects next to its input: work on a copy outside the tree
+    import shutil
+    copy = shutil.copy(lib_path, tmp_path / "liboq_hip.so")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(copy)], capture_output=True, text=True,
+                         cwd=tmp_path)
     assert "gfx950" in out.stdout + out.stderr
 
 
