@@ -47,6 +47,26 @@ def test_code_object_is_gfx950(lib_path, tmp_path):
     assert "gfx950" in out.stdout + out.stderr
 
 
+def test_header_is_plain_c_and_links(lib_path, tmp_path):
+    """tests/c/abi_check.c: include/oq_hip.h compiles as C99, every declared entry point resolves against the library
+    and the host-only calls answer; the list of symbols in the C file must be the header's."""
+    src = os.path.join(ROOT, "tests", "c", "abi_check.c")
+    text = open(src).read()
+    assert sorted(set(re.findall(r"TAKE\((oq_[a-z0-9_]+)\)", text))) == declared_symbols()
+    exe = tmp_path / "abi_check"
+    libdir = os.path.dirname(lib_path)
+    cc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", str(exe),
+                         "-L", libdir, "-loq_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"],
+                        capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stdout + cc.stderr
+    env = dict(os.environ)
+    import torch
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(os.path.dirname(torch.__file__), "lib"), "/opt/rocm/lib",
+                                               env.get("LD_LIBRARY_PATH", "")])
+    run = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert run.returncode == 0 and run.stdout.startswith("ok "), (run.returncode, run.stdout, run.stderr)
+
+
 def test_host_only_entry_points(lib_path):
     """oq_qrange / status strings / argument validation run on the host and need no device."""
     from onnx_quantize_amd.hip import _lib
