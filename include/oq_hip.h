@@ -227,16 +227,17 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
  *     asymmetric, group strategy, float zero points.  W [K, N] fp32; scale / zero_point_in / zero_point_out
  *     [N * K/g] fp32 in the rtn.py:98-109 order (entry n * K/g + kg); the initial scale and zero points come
  *     from oq_rtn_qparams_f32 (hqq.py:181-192; zero points converted to fp32).  beta / kappa are float64 like
- *     the reference's Python floats (beta *= kappa per round).  q_out [K, N] one value per byte (NULL: zero
- *     points only); rounds_out (device int32, may be NULL) receives the number of rounds evaluated before the
+ *     the reference's Python floats (beta *= kappa per round).  q_out: OQ_LAYOUT_KN [K, N] one value per byte, or
+ *     OQ_LAYOUT_NBITS the MatMulNBits blob [N, K/g, g/2] HQQ is meant for (qrules/_common.py:65-87; float zero
+ *     points stay unpacked [N, K/g], :96-99); NULL: zero points only.  rounds_out (device int32, may be NULL) receives the number of rounds evaluated before the
  *     early stop.  Every round, the mean-error reduction and the best / early-stop decision run on the
  *     device; nothing synchronises with the host.  K % group_size != 0 is OQ_ERR_UNSUPPORTED. */
 size_t oq_hqq_workspace_bytes(int64_t K, int64_t N, int64_t group_size);
 int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t group_size,
                             int32_t reduce_range, const float* scale, const float* zero_point_in,
                             double lp_norm, double beta, double kappa, int32_t iters, int32_t early_stop,
-                            void* q_out, float* zero_point_out, int32_t* rounds_out, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            void* q_out, int32_t layout, float* zero_point_out, int32_t* rounds_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* N3  qrules/_common.py:65-123: MatMulNBits zero-point packing [N, ceil(K/g / 2)] (pad nibble 0x8)
  *     from the per-group zero points [N*K/g] (1 byte each).  4-bit only. */

@@ -180,7 +180,7 @@ __global__ void hqq_init_kernel(HqqCtrl* ctrl) {
 
 // After the last round: settle `best` and quantize with it (hqq.py:163-171: round(w / s + z), float zero point
 // inside the rounding, no int32 cast).  q is the [K, N] one-value-per-byte array `_post_process_array` returns.
-__global__ __launch_bounds__(256) void hqq_finish_kernel(const HqqArgs a, uint8_t* q, float* zp_out) {
+__global__ __launch_bounds__(256) void hqq_finish_kernel(const HqqArgs a, uint8_t* q, float* zp_out, int32_t layout) {
     const int64_t col = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const int64_t kg = blockIdx.y;
     if (col >= a.N) return;
@@ -190,6 +190,20 @@ __global__ __launch_bounds__(256) void hqq_finish_kernel(const HqqArgs a, uint8_
     if (q == nullptr) return;
     const float s = a.scale[r];
     const float* w = a.W + kg * a.g * a.ldw + col;
+    if (layout == OQ_LAYOUT_NBITS) {
+        // qrules/_common.py:72-87: the (column, k-group) chunk is g / 2 consecutive bytes, even k in the low nibble
+        uint8_t* o = q + r * (a.g / 2);
+        for (int64_t t = 0; t < a.g; t += 8) {   // g is a power of two >= 16 for HQQ (hqq.py:66-70): whole 4-byte words
+            uint32_t word = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = fminf(fmaxf(rintf(w[(t + j) * a.ldw] / s + z), a.qmin), a.qmax);
+                word |= (static_cast<uint32_t>(v) & 0xfu) << (4 * j);
+            }
+            *reinterpret_cast<uint32_t*>(o + t / 2) = word;
+        }
+        return;
+    }
     for (int64_t t = 0; t < a.g; ++t) {
         const float v = fminf(fmaxf(rintf(w[t * a.ldw] / s + z), a.qmin), a.qmax);
         q[(kg * a.g + t) * a.N + col] = static_cast<uint8_t>(v);
@@ -214,11 +228,12 @@ size_t oq_hqq_workspace_bytes(int64_t K, int64_t N, int64_t group_size) {
 
 int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t group_size, int32_t reduce_range,
                             const float* scale, const float* zero_point_in, double lp_norm, double beta, double kappa, int32_t iters,
-                            int32_t early_stop, void* q_out, float* zero_point_out, int32_t* rounds_out, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+                            int32_t early_stop, void* q_out, int32_t layout, float* zero_point_out, int32_t* rounds_out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
     OQ_REQUIRE(W && scale && zero_point_in && zero_point_out && K > 0 && N > 0 && ldw >= N, OQ_ERR_INVALID_ARGUMENT,
                "oq_hqq_optimize_f32: bad argument");
     OQ_REQUIRE(iters >= 0 && beta > 0.0, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: iters >= 0 and beta > 0 needed");
+    OQ_REQUIRE(layout == OQ_LAYOUT_KN || layout == OQ_LAYOUT_NBITS, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: bad layout %d", layout);
     int64_t g = group_size > K ? K : group_size;   // utils.py:19-22
     if (g == -1) g = K;
     OQ_REQUIRE(g > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: bad group_size %lld", (long long)group_size);
@@ -264,7 +279,9 @@ int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
     int32_t st = check_launch("hqq_round_kernel");
     if (st != OQ_OK) return st;
     a.round = iters;
-    hipLaunchKernelGGL(hqq_finish_kernel, grid, dim3(256), 0, s, a, static_cast<uint8_t*>(q_out), zero_point_out);
+    OQ_REQUIRE(layout == OQ_LAYOUT_KN || q_out == nullptr || (g % 8 == 0 && (reinterpret_cast<uintptr_t>(q_out) & 3u) == 0), OQ_ERR_UNSUPPORTED,
+               "oq_hqq_optimize_f32: NBITS layout needs group_size %% 8 == 0 and a 4-byte aligned output");
+    hipLaunchKernelGGL(hqq_finish_kernel, grid, dim3(256), 0, s, a, static_cast<uint8_t*>(q_out), zero_point_out, layout);
     st = check_launch("hqq_finish_kernel");
     if (st != OQ_OK) return st;
     if (rounds_out != nullptr &&

@@ -80,7 +80,7 @@ PROTOTYPES = {
     "oq_gptq_loop_f32": (_i32, [_p, _i64, _i64, _p, _i32, _i64, _i32, _i32, _f32, _i32, _i64, _i32,
                                 _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
     "oq_hqq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "oq_hqq_optimize_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _f64, _f64, _f64, _i32, _i32, _p, _p, _p,
+    "oq_hqq_optimize_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _f64, _f64, _f64, _i32, _i32, _p, _i32, _p, _p,
                                    _p, _sz, _p]),
     "oq_pack_zero_points_u4": (_i32, [_p, _i64, _i64, _p, _p]),
     "oq_pack_nibbles": (_i32, [_p, _i64, _p, _p]),

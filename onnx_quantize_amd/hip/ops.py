@@ -111,9 +111,10 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
 
 
 def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_ratio=1.0, mse=False, lp_norm=0.7, beta=1e1,
-                 kappa=1.01, iters=20, early_stop=True, emit_q: bool = True):
+                 kappa=1.01, iters=20, early_stop=True, emit_q: bool = True, layout: str = "kn"):
     """hqq.py:147-213 on the GPU: uint4 / asymmetric / group with float zero points.  ``w`` [K, N] fp32 in HBM.
-    Returns (q [K, N] uint8 | None, scale [N*K/g, 1] fp32, zero_point [N*K/g, 1] fp32, rounds int32[1] on device)."""
+    Returns (q [K, N] uint8 | MatMulNBits blob [N, K/g, g/2] for layout="nbits" | None, scale [N*K/g, 1] fp32,
+    zero_point [N*K/g, 1] fp32, rounds int32[1] on device)."""
     _require_device(w, "w", torch.float32)
     if w.dim() != 2:
         raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
@@ -129,12 +130,18 @@ def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_rati
     rows = (k * n) // g
     zp_in = zp0.reshape(-1).to(torch.float32)
     zp = torch.empty(rows, dtype=torch.float32, device=dev)
-    q = torch.empty((k, n), dtype=torch.uint8, device=dev) if emit_q else None
+    if not emit_q:
+        q = None
+    elif layout == "kn":
+        q = torch.empty((k, n), dtype=torch.uint8, device=dev)
+    else:
+        q = torch.empty((n, k // g, g // 2), dtype=torch.uint8, device=dev)
     rounds = torch.zeros(1, dtype=torch.int32, device=dev)
     gs = -1 if group_size is None else int(group_size)
     ws = _workspace(lib.oq_hqq_workspace_bytes(k, n, gs), dev)
     L.check(lib.oq_hqq_optimize_f32(_ptr(w), k, n, ldw, gs, int(reduce_range), _ptr(scale), _ptr(zp_in), float(lp_norm),
-                                    float(beta), float(kappa), int(iters), int(early_stop), _ptr(q), _ptr(zp), _ptr(rounds),
+                                    float(beta), float(kappa), int(iters), int(early_stop), _ptr(q),
+                                    L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS, _ptr(zp), _ptr(rounds),
                                     _ptr(ws), ws.numel(), _stream()))
     return q, scale.reshape(rows, 1), zp.reshape(rows, 1), rounds
 

@@ -143,6 +143,21 @@ def test_gpu_plugin_seam_and_medium_matrix():
 
 
 @pytest.mark.gpu
+def test_gpu_matmul_nbits_blob_equals_packed_kn_result():
+    """layout="nbits": the blob HQQ's only consumer (MatMulNBits) takes, qrules/_common.py:65-99 -- the same integers as
+    the [K, N] result, packed two per byte along k; float zero points stay one per group."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    w = torch.from_numpy(np.random.default_rng(12).standard_normal((512, 200), dtype=np.float32)).cuda()
+    for g in (16, 64, 128):
+        q, s, z, _ = ops.hqq_quantize(w, g)
+        b, s2, z2, _ = ops.hqq_quantize(w, g, layout="nbits")
+        eb, es, ez = O.matmul_nbits_layout(q.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy(), g, 4, zp_is_float=True)
+        np.testing.assert_array_equal(b.cpu().numpy(), eb)
+        assert torch.equal(s, s2) and torch.equal(z, z2) and ez.shape == (200, 512 // g) and ez.dtype == np.float32
+
+
+@pytest.mark.gpu
 def test_gpu_errors_are_loud():
     import torch
     from onnx_quantize_amd.hip import ops
