@@ -1,0 +1,170 @@
+"""the on-device calibration driver against the reference's hold-everything flow
+(core/_calibration/calibrate.py:204-385), restated in oracle/oq_oracle.py (`calibrate_flow`, `gptq_inputs`)."""
+import numpy as np
+import pytest
+
+from oracle import oq_oracle as O
+from onnx_quantize_amd import calibration_driver as D
+from onnx_quantize_amd.config import QActivationArgs
+from onnx_quantize_amd.dtypes import QuantType
+
+
+# ----------------------------------------------------------------------------- host logic (no GPU)
+@pytest.mark.parametrize("total,batch,num,shape", [(10, 2, 10, (5, 2)), (10, 5, 10, (2, 5)), (10, 10, 10, (1, 10)),
+                                                   (10, 20, 10, (1, 10)), (10, 3, 10, (3, 3)), (10, 4, 100, (2, 4)),
+                                                   (12, 4, 7, (1, 4)), (3, 1, 2, (2, 1))])
+def test_prepare_calibration_data_batches_like_the_reference(total, batch, num, shape):
+    """test_calibrate.py:139-176: the (batch_size, num_samples) grid, incl. 'drops excess samples' (10 // 3 = 3)."""
+    data = np.arange(total * 6, dtype=np.float32).reshape(total, 2, 3)
+    got = D.prepare_calibration_data(data, batch, num)
+    exp = O.prepare_calibration_data(data, batch, num)
+    assert got.shape == shape + (2, 3)
+    np.testing.assert_array_equal(got, exp)
+    assert np.shares_memory(got, data)                                  # a view, never a copy
+    import torch
+    t = D.prepare_calibration_data(torch.from_numpy(data), batch, num)
+    np.testing.assert_array_equal(t.numpy(), exp)
+
+
+def test_random_calibration_data_matches_the_reference_recipe():
+    """calibrate.py:127-147: default_rng(0), symbolic dims -> 1, ints in [0, 100), one generator for all inputs."""
+    one = D.generate_random_calibration_data(12, [("X", ("N", 32), np.float32)])
+    np.testing.assert_array_equal(one, np.random.default_rng(0).standard_normal((12, 32)).astype(np.float32))
+    ids = D.generate_random_calibration_data(4, [("input_ids", ("N", "S"), np.int32)])
+    assert ids.shape == (4, 1) and ids.dtype == np.int32 and ids.min() >= 0 and ids.max() < 100
+    rng = np.random.default_rng(0)
+    a, b = rng.standard_normal((5, 8)).astype(np.float32), rng.integers(0, 100, size=(5, 1, 3), dtype=np.int64)
+    both = D.generate_random_calibration_data(5, [("a", (None, 8), np.float32), ("b", ("N", "S", 3), np.int64)])
+    np.testing.assert_array_equal(both["a"], a)
+    np.testing.assert_array_equal(both["b"], b)
+
+
+def test_multi_input_model_needs_a_dict():
+    """calibrate.py:228-233 / test_calibrate.py:229-238."""
+    with pytest.raises(ValueError, match="Calibration data must be a dict"):
+        D.run_calibration(lambda f: {}, np.zeros((4, 3), np.float32), D.ActivationStream(), input_names=["X", "Y"])
+
+
+def test_stream_rejects_host_arrays():
+    import torch
+    with pytest.raises(TypeError, match="not a tensor in GPU memory"):
+        D.ActivationStream(input_names=["a"]).feed({"a": torch.zeros(3)})
+
+
+# ----------------------------------------------------------------------------- GPU
+def _mlp(seed=0):
+    import torch
+    torch.manual_seed(seed)
+    m = torch.nn.Sequential()
+    m.add_module("fc1", torch.nn.Linear(32, 64, bias=True))
+    m.add_module("act", torch.nn.ReLU())
+    m.add_module("fc2", torch.nn.Linear(64, 128, bias=False))
+    m.add_module("fc3", torch.nn.Linear(128, 32, bias=True))
+    return m.cuda()
+
+
+_TAPS = {"X": ("fc1", "input"), "h1": ("fc1", "output"), "a1": ("fc2", "input"), "h2": ("fc2", "output"),
+         "h3": ("fc3", "output")}          # fc3's input IS h2: one value, two roles, like an ONNX graph
+
+
+def _reference_activations(model, data, batch, num):
+    """What calibrate.py:244-251 would hold: a list of per-batch {name: NumPy array} (computed with the same model)."""
+    import torch
+    runner = D.TorchRunner(model, _TAPS)
+    out = []
+    for b in O.prepare_calibration_data(data, batch, num):
+        out.append({k: v.cpu().numpy() for k, v in runner(torch.from_numpy(b).cuda()).items()})
+    runner.close()
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("momentum", [0.0, 0.9])
+@pytest.mark.parametrize("kinds", ["input", "output", "both"])
+def test_static_activation_parameters_equal_the_hold_everything_flow(momentum, kinds):
+    from onnx_quantize_amd.calibration import MinMaxCalibrator
+    model = _mlp()
+    data = (np.random.default_rng(3).standard_normal((23, 32)) * 2).astype(np.float32)
+    in_names = ["X", "a1", "h2"] if kinds != "output" else []
+    out_names = ["h1", "h2", "h3"] if kinds != "input" else []
+    in_args = QActivationArgs(dtype=QuantType.QUInt8, is_static=True)
+    out_args = QActivationArgs(dtype=QuantType.QInt8, symmetric=True, is_static=True)
+    stream = D.ActivationStream(calibrator=MinMaxCalibrator(momentum), input_names=in_names, output_names=out_names)
+    runner = D.TorchRunner(model, _TAPS)
+    D.run_calibration(runner, data, stream, num_samples=23, batch_size=4, input_names=["X"])
+    runner.close()
+    assert stream.batches == 5                                          # 23 // 4, three samples dropped
+    acts = _reference_activations(model, data, 4, 23)
+    exp = O.calibrate_flow(acts, in_names, out_names, momentum,
+                           ("uint8", False, False) if in_names else None, ("int8", True, False) if out_names else None)
+    got = {}
+    if in_names:
+        got.update({("input", n): v for n, v in stream.input_qparams(in_args).items()})
+    if out_names:
+        got.update({("output", n): v for n, v in stream.output_qparams(out_args).items()})
+    assert got.keys() == exp.keys() and len(got) == len(in_names) + len(out_names)
+    for key, (scale, zp) in exp.items():
+        s, z = got[key]
+        assert s.dtype == np.float32 and s.shape == () and z.dtype == zp.dtype and z.shape == ()
+        np.testing.assert_allclose(s, scale, rtol=1e-6, atol=0), key     # EMA: fused vs two-step multiply-add
+        assert abs(int(z) - int(zp)) <= (1 if momentum else 0), key
+    if momentum == 0.0:
+        for key, (scale, zp) in exp.items():
+            assert got[key][0] == scale and got[key][1] == zp, key         # running min / max: bit-exact
+
+
+@pytest.mark.gpu
+def test_two_walk_ema_differs_from_one_walk_and_is_reproduced():
+    """With both kinds and momentum > 0 the reference's output ranges see the batch sequence twice; a driver that
+    collected once would give different numbers -- make sure the case is real and the stream follows the reference."""
+    import torch
+    from onnx_quantize_amd.calibration import MinMaxCalibrator
+    rng = np.random.default_rng(5)
+    batches = [{"a": rng.standard_normal((4, 8)).astype(np.float32) * (i + 1),
+                "b": rng.standard_normal((4, 8)).astype(np.float32)} for i in range(4)]
+    args = QActivationArgs(dtype=QuantType.QUInt8, is_static=True)
+    stream = D.ActivationStream(calibrator=MinMaxCalibrator(0.5), input_names=["a"], output_names=["b", "a"])
+    for b in batches:
+        stream.feed({k: torch.from_numpy(v).cuda() for k, v in b.items()})
+    exp = O.calibrate_flow(batches, ["a"], ["b", "a"], 0.5, ("uint8", False, False), ("uint8", False, False))
+    once = O.calibrate_flow(batches, [], ["b", "a"], 0.5, None, ("uint8", False, False))
+    assert exp[("output", "a")][0] != once[("output", "a")][0]
+    out, inp = stream.output_qparams(args), stream.input_qparams(args)     # order of the two reads must not matter
+    np.testing.assert_allclose(inp["a"][0], exp[("input", "a")][0], rtol=1e-6)
+    np.testing.assert_allclose(out["a"][0], exp[("output", "a")][0], rtol=1e-6)
+    np.testing.assert_allclose(out["b"][0], exp[("output", "b")][0], rtol=1e-6)
+    assert not np.isclose(out["a"][0], once[("output", "a")][0], rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_streamed_hessian_and_gptq_equal_the_concatenated_flow():
+    """calibrate.py:288-307 + gptq.py:304-305: H from all batches at once == H streamed batch by batch; then `_gptq`
+    with the factor shared by the two layers that read the same value."""
+    import torch
+    model = _mlp(1)
+    data = np.random.default_rng(7).standard_normal((24, 6, 32)).astype(np.float32)       # [samples, seq, K]
+    stream = D.ActivationStream(hessian_names=["X", "a1", "h2"], absmax_names=["a1"], keep_names=["a1"])
+    runner = D.TorchRunner(model, _TAPS)
+    D.run_calibration(runner, data, stream, num_samples=24, batch_size=8)
+    runner.close()
+    acts = _reference_activations(model, data, 8, 24)
+    whole = O.gptq_inputs(acts)
+    for name in ("X", "a1", "h2"):
+        k = whole[name].shape[-1]
+        h, n = O.accumulate_hessian(whole[name], np.zeros((k, k), np.float32), 0)
+        assert stream.hessians[name].n == n == 24                         # samples, not tokens (gptq.py:247)
+        np.testing.assert_allclose(stream.hessians[name].h.cpu().numpy(), h, rtol=2e-4, atol=2e-5 * np.abs(h).max())
+    np.testing.assert_array_equal(stream.absmax["a1"].cpu().numpy(), O.absmax_cols(whole["a1"]))
+    np.testing.assert_array_equal(stream.kept("a1").cpu().numpy(), whole["a1"])
+    # the weights in the ONNX MatMul layout [K, N]
+    layers = {"fc2": (model.fc2.weight.detach().t().contiguous(), "a1"),
+              "fc3": (model.fc3.weight.detach().t().contiguous(), "h2")}
+    res = D.quantize_weights_gptq(layers, stream.hessians, "int4", "group", 32)
+    for name, (w, value) in layers.items():
+        q, s, z, _ = res[name]
+        eq, es, ez = O.gptq_quantize(w.cpu().numpy(), whole[value], "int4", "group", 32)
+        assert q.shape == eq.shape and s.shape == es.shape
+        np.testing.assert_allclose(s.cpu().numpy(), es, rtol=1e-5)
+        assert (q.cpu().numpy() != eq).mean() <= 1e-3 and (z.cpu().numpy() != ez).mean() <= 1e-3
+    with pytest.raises(KeyError, match="no Hessian accumulated"):
+        D.quantize_weights_gptq({"x": (layers["fc2"][0], "nope")}, stream.hessians, "int4", "group", 32)
