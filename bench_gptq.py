@@ -158,7 +158,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
                        "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
-                       "streams": 1 if args.no_overlap else 2},
+                       "streams": 1 if args.no_overlap else 2, "hessian_method": ops.hessian_method()},
             "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
                         "gather": round(float(stats[2]), 4),
                         # per-phase device time (with two streams the phases overlap: their sum exceeds the wall time)

@@ -182,9 +182,22 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *       H *= n_seen / (n_seen + n_add);  H += (2 / (n_seen + n_add)) * X^T X      (fp32, MFMA)
  *     X [T, K] row-major (ldx), H [K, K] row-major, in/out, full symmetric matrix is maintained.
  *     n_add is the LEADING dimension of the activation before flattening (gptq.py:247), i.e. the
- *     number of samples, not T.  workspace (optional, may be NULL): partial-sum slabs that let the T
- *     dimension be split over more workgroups when K is small (deterministic two-stage sum).
+ *     number of samples, not T.  workspace (oq_hessian_workspace_bytes; optional for OQ_HESSIAN_F32, where
+ *     it may be NULL): the bf16 operand pieces of the split methods (6 B per element of X) and partial-sum
+ *     slabs that let the T dimension be split over more workgroups (deterministic two-stage sum).
+ *     Method (process-wide, oq_hessian_set_method; environment OQ_HESSIAN_METHOD = 0..3 sets the initial value):
+ *       OQ_HESSIAN_F32     v_mfma_f32_32x32x2_f32 on the operands scaled by sqrt(2/n) as gptq.py:257 does;
+ *       OQ_HESSIAN_BF16X6  every fp32 element split EXACTLY into three bf16 pieces (x = hi + mid + lo), the six piece
+ *                          products down to 2^-16 |x y| on v_mfma_f32_32x32x16_bf16, fp32 accumulation; what is left
+ *                          out is <= 2^-23 |x y| per product (one fp32 rounding); 2 / n applied to the sum;
+ *       OQ_HESSIAN_BF16X9  all nine piece products (no product rounding at all);
+ *       OQ_HESSIAN_AUTO    BF16X6 for K >= 1024 (its block tile is 256 x 256) when the workspace holds the pieces,
+ *                          else F32.  An explicit split method with too small a workspace is OQ_ERR_WORKSPACE.
+ *     The reference's own H goes through sgemm in BLAS order: parity is to a tolerance for every method.
  * ------------------------------------------------------------------------------------------- */
+enum { OQ_HESSIAN_AUTO = 0, OQ_HESSIAN_F32 = 1, OQ_HESSIAN_BF16X6 = 2, OQ_HESSIAN_BF16X9 = 3 };
+int32_t oq_hessian_set_method(int32_t method);
+int32_t oq_hessian_method(void);
 size_t oq_hessian_workspace_bytes(int64_t T, int64_t K);
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen,
                                   int64_t n_add, float* H, void* workspace, size_t workspace_bytes,

@@ -2,6 +2,7 @@
 #include "gemm_tn.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace oq {
@@ -97,31 +98,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
         // row-major inside one) and XCD-contiguous ids (oq_common.hpp::xcd_remap): the ~64 tiles resident on one XCD
         // then share 8 A-panels and 8 B-panels per k-stage through that XCD's L2, instead of 1 + 64 panels for 64
         // neighbours of one tile row -- a quarter of the L2 fill traffic.  Speed only; every tile is visited once.
-        int rem = static_cast<int>(xcd_remap(blockIdx.x, gridDim.x));
-        const int ns = (ntiles_n + 7) >> 3;
-        int R = 0, C = 0, nr = 0, nc = 0;
-        bool found = false;
-        for (R = 0; R < ns && !found; ++R) {
-            nr = min(8, ntiles_n - 8 * R);
-            for (C = R; C < ns; ++C) {
-                nc = min(8, ntiles_n - 8 * C);
-                const int cnt = C == R ? nr * (nr + 1) / 2 : nr * nc;
-                if (rem < cnt) { found = true; break; }
-                rem -= cnt;
-            }
-            if (found) break;
-        }
-        int r, c;
-        if (C == R) {
-            r = 0;
-            while (rem >= nr - r) { rem -= nr - r; ++r; }
-            c = r + rem;
-        } else {
-            r = rem / nc;
-            c = rem - r * nc;
-        }
-        tile_m = 8 * R + r;
-        tile_n = 8 * C + c;
+        upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles_n, tile_m, tile_n);
     } else {
         tile_m = blockIdx.x / ntiles_n;
         tile_n = blockIdx.x - tile_m * ntiles_n;
@@ -304,17 +281,17 @@ int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s) {
 
 // Sum the T-slices of one 64 x 64 tile in slice order, apply alpha / beta, and write C[m][n] and (for
 // off-diagonal tiles) C[n][m]; the transposed copy goes through LDS so both stores are row-contiguous.
-__global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int splits, int64_t K, float alpha, float beta, float* C) {
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile) {
     __shared__ float t[64][65];
     const int64_t m0 = static_cast<int64_t>(blockIdx.y) * 64, n0 = static_cast<int64_t>(blockIdx.x) * 64;
-    if (n0 / kBN < m0 / kBM) return;                            // 128-tile below the diagonal: produced by the mirror
+    if (n0 < m0) return;                                        // below the diagonal: written as the mirror of block (n0, m0)
+    (void)tile;                                                 // every 64-block on or above the diagonal lies in a computed GEMM tile
+    const bool diag = n0 == m0;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 x 4
     for (int r = ty; r < 64; r += 4) {
         const int64_t row = m0 + r, col = n0 + tx;
         float v = 0.f;
-        if (row < K && col < K) {
-            // upper 128-tiles were computed in full, so every (row, col) with col-tile >= row-tile (128 granularity) is valid;
-            // elements of a diagonal 128-tile below the diagonal are valid too (the tile is computed completely)
+        if (row < K && col < K && (!diag || tx >= r)) {
             for (int z = 0; z < splits; ++z) v += slab[(static_cast<int64_t>(z) * K + row) * K + col];
             v = alpha * v;
             if (beta != 0.0f) v = beta * C[row * K + col] + v;
@@ -323,11 +300,18 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int
         t[r][tx] = v;
     }
     __syncthreads();
-    if ((m0 / kBM) == (n0 / kBN)) return;                        // same 128-tile: the GEMM already produced both triangles
+    // the lower triangle is the mirror of the upper one bit for bit (a GEMM that computes both halves of a diagonal
+    // tile may have summed them in different orders)
     for (int r = ty; r < 64; r += 4) {
         const int64_t row = n0 + r, col = m0 + tx;               // transposed position
-        if (row < K && col < K) C[row * K + col] = t[tx][r];
+        if (row < K && col < K && (!diag || tx < r)) C[row * K + col] = t[tx][r];
     }
+}
+
+int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile, hipStream_t s) {
+    const uint32_t t64 = static_cast<uint32_t>(ceil_div(K, 64));
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(t64, t64), dim3(256), 0, s, slab, splits, K, alpha, beta, C, tile);
+    return check_launch("syrk_reduce_kernel");
 }
 
 size_t syrk_slab_bytes(int64_t T, int64_t K) {
@@ -362,9 +346,7 @@ int32_t launch_syrk_tn(const float* X, int64_t T, int64_t K, int64_t ldx, float 
     launch_variant(vec, vec, dim3(static_cast<uint32_t>(tiles), static_cast<uint32_t>(splits)), s, g, static_cast<float*>(slab), per, tn);
     int32_t st = check_launch("gemm_tn_kernel(split)");
     if (st != OQ_OK) return st;
-    const uint32_t t64 = static_cast<uint32_t>(ceil_div(K, 64));
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(t64, t64), dim3(256), 0, s, static_cast<const float*>(slab), splits, K, alpha, beta, C);
-    return check_launch("syrk_reduce_kernel");
+    return launch_syrk_reduce(static_cast<const float*>(slab), splits, K, alpha, beta, C, kBM, s);
 }
 
 }  // namespace oq
@@ -374,7 +356,32 @@ extern "C" {
 using namespace oq;
 
 // G1  gptq.py:246-260.
-size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) { return syrk_slab_bytes(T, K) + 256; }
+// slab slices the workspace query budgets for: 16 for K <= 8192 (1 GB at 4096), 4 above (1.9 GB at 11008)
+static size_t hessian_slab_budget(int64_t K) { return K <= 0 ? 0 : static_cast<size_t>(K <= 8192 ? 16 : 4) * K * K * sizeof(float); }
+
+size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) {
+    if (T <= 0 || K <= 0) return 256;
+    const size_t f32 = K <= 8192 ? syrk_slab_bytes(T, K) : 0;
+    const size_t split = syrk_bf16x3_pieces_bytes(T, K) + hessian_slab_budget(K);
+    return (f32 > split ? f32 : split) + 512;
+}
+
+static int32_t g_hessian_method = -1;   // -1: not set yet (environment OQ_HESSIAN_METHOD, else OQ_HESSIAN_AUTO)
+
+int32_t oq_hessian_set_method(int32_t method) {
+    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_BF16X9, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_set_method: unknown method %d", method);
+    g_hessian_method = method;
+    return OQ_OK;
+}
+
+int32_t oq_hessian_method(void) {
+    if (g_hessian_method < 0) {
+        const char* e = std::getenv("OQ_HESSIAN_METHOD");
+        const int v = e ? std::atoi(e) : OQ_HESSIAN_AUTO;
+        g_hessian_method = (v >= OQ_HESSIAN_AUTO && v <= OQ_HESSIAN_BF16X9) ? v : OQ_HESSIAN_AUTO;
+    }
+    return g_hessian_method;
+}
 
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen, int64_t n_add, float* H,
                                   void* workspace, size_t workspace_bytes, void* stream) {
@@ -385,6 +392,18 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
     // gptq.py:254  H *= num_samples / (num_samples + num_added): a Python float applied to an fp32 array.
     // The first call of the reference starts from zeros (gptq.py:304): beta = 0, nothing is read.
     const float beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));
+    int32_t method = oq_hessian_method();
+    // auto: the split-operand kernels where their 256-wide tiles are worth it and the caller's workspace holds the
+    // pieces; small problems stay on the fp32 MFMA
+    if (method == OQ_HESSIAN_AUTO)
+        method = (K >= 1024 && workspace != nullptr && workspace_bytes >= syrk_bf16x3_pieces_bytes(T, K) + 256) ? OQ_HESSIAN_BF16X6 : OQ_HESSIAN_F32;
+    if (method != OQ_HESSIAN_F32) {
+        // gptq.py:257 scales the operand by sqrt(2 / n); here the factor 2 / n goes onto the sum (one rounding per
+        // element of H instead of one per element of X)
+        const float alpha = static_cast<float>(2.0 / static_cast<double>(n_total));
+        return launch_syrk_bf16x3(X, T, K, ldx, alpha, beta, H, workspace, workspace_bytes, method == OQ_HESSIAN_BF16X9 ? 9 : 6,
+                                  as_stream(stream));
+    }
     // gptq.py:257  inp = math.sqrt(2 / num_samples) * inp  (double evaluated, weak scalar -> fp32 multiply)
     const float sx = static_cast<float>(std::sqrt(2.0 / static_cast<double>(n_total)));
     return launch_syrk_tn(X, T, K, ldx, sx, 1.0f, beta, H, workspace, workspace_bytes, as_stream(stream));

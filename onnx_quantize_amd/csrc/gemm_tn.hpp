@@ -39,13 +39,48 @@ struct GemmTN {
 
 int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s);
 
-// Symmetric rank-k update C = beta*C + alpha*(s*X)^T (s*X) for tall X [T, K] (the GPTQ Hessian).  When the
-// upper-triangular tile count cannot fill the chip (K = 4096: 528 tiles for 512 block slots -> a 2-round
-// tail), the T dimension is split into `splits` slices whose partial tiles go to `slab`
-// ([splits][K][K] fp32) and a second kernel sums them in a fixed order (deterministic), applies beta and
-// writes both triangles with coalesced stores.  slab may be null (splits forced to 1).
-size_t syrk_slab_bytes(int64_t T, int64_t K);
-int32_t launch_syrk_tn(const float* X, int64_t T, int64_t K, int64_t ldx, float scale_x, float alpha, float beta, float* C,
-                       void* slab, size_t slab_bytes, hipStream_t s);
+// Upper-triangle tiles of an ntiles x ntiles grid enumerated by 8 x 8 SUPER-TILES (row-major over the upper triangle
+// of super-tiles, tiles row-major inside one).  With XCD-contiguous ids (oq_common.hpp::xcd_remap) the tiles resident
+// on one XCD then share 8 A-panels and 8 B-panels per k-stage through that XCD's L2, instead of 1 + 64 panels for 64
+// neighbours of one tile row -- a quarter of the L2 fill traffic.  Speed only; every tile is visited once.
+__device__ __forceinline__ void upper_tile_of(int rem, int ntiles, int& tile_m, int& tile_n) {
+    const int ns = (ntiles + 7) >> 3;
+    int R = 0, C = 0, nr = 0, nc = 0;
+    bool found = false;
+    for (R = 0; R < ns && !found; ++R) {
+        nr = min(8, ntiles - 8 * R);
+        for (C = R; C < ns; ++C) {
+            nc = min(8, ntiles - 8 * C);
+            const int cnt = C == R ? nr * (nr + 1) / 2 : nr * nc;
+            if (rem < cnt) { found = true; break; }
+            rem -= cnt;
+        }
+        if (found) break;
+    }
+    int r, c;
+    if (C == R) {
+        r = 0;
+        while (rem >= nr - r) { rem -= nr - r; ++r; }
+        c = r + rem;
+    } else {
+        r = rem / nc;
+        c = rem - r * nc;
+    }
+    tile_m = 8 * R + r;
+    tile_n = 8 * C + c;
+}
+
+// Sums the `splits` partial results slab[z][K][K] (valid where the GEMM's `tile` x `tile` block tiles lie on or above the
+// diagonal) in slice order, applies alpha / beta and writes both triangles of C.
+int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile, hipStream_t s);
+
+// The same update on the bf16 matrix cores with fp32-exact operands (syrk_bf16x3.hip): every fp32 element is split
+// into three bf16 pieces whose sum is the element exactly; `terms` = 6 (piece products down to 2^-16, the dropped
+// ones are below fp32 rounding of a product) or 9 (all of them).  workspace = the pieces (syrk_bf16x3_pieces_bytes)
+// followed by optional T-slice slabs of K x K floats.
+bool syrk_bf16x3_applicable(const float* X, int64_t T, int64_t K, int64_t ldx);
+size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K);
+int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C,
+                           void* workspace, size_t workspace_bytes, int terms, hipStream_t s);
 
 }  // namespace oq

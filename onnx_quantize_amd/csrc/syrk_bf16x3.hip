@@ -1,0 +1,321 @@
+// G1 on the bf16 matrix cores with fp32-exact operands:  C = beta C + alpha X^T X  for tall X [T, K]  (gptq.py:246-260).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate (157 vs 2 500 TFLOP/s dense), and the Hessian is 90 % of a GPTQ
+// run.  An fp32 number is the exact sum of three bf16 numbers: hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (8 + 8
+// + 8 significand bits; the subtractions are exact).  So x y = sum over the nine piece products, each of which is EXACT
+// in fp32 (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Relative to x y the products weigh
+//   hi.hi 1 | hi.mid, mid.hi 2^-8 | mid.mid, hi.lo, lo.hi 2^-16 | mid.lo, lo.mid 2^-24 | lo.lo 2^-32.
+// terms = 6 keeps everything down to 2^-16 (what is dropped is <= 2^-23 |x y|, the size of ONE fp32 rounding of the
+// product, and of either sign because the pieces are rounded to nearest); terms = 9 keeps all and is then MORE exact
+// than an fp32 fma chain (no product rounding at all).  6 MFMAs at 16 x the fp32 rate = 2.7 x the fp32 peak.
+//
+// Two kernels.
+//  1. split_bf16x3_kernel: X -> pieces P, once (HBM-bound: 4 B read + 6 B written per element).  The MFMA wants, per
+//     lane, 8 consecutive k (= rows t of X) of ONE column, so a thread takes one column x 8 rows (coalesced dword loads
+//     across the wave), splits them in registers and writes three 16-byte vectors {t0..t7}:
+//         P[chunk = t / 8][piece][column (padded to 256)] x 16 B,   zero rows / columns behind T / K.
+//     Splitting inside the GEMM was measured first: every block re-splits its two panels (K / 256 times each element),
+//     and ~100 dependent VALU instructions per wave and stage do not hide under 48 MFMAs -- 212 against 336 TFLOP/s
+//     (fp32-equivalent) with the split compiled out.
+//  2. syrk_pieces_kernel: 256 x 256 tile of C per block, 8 waves (4 x 2), each 64 x 128 = 2 x 4 MFMA tiles (128
+//     accumulator registers).  A stage = 16 rows = [operand A|B][piece][chunk 0|1][256 columns] x 16 B = 48 KB of LDS, in
+//     exactly the order P holds them, so staging is 48 global_load_lds_dwordx4 (1 KB each, 6 per wave): no staging
+//     registers, no ds_write, no VALU.  LDS is a ring of three stages (144 KB, one block per CU).
+#include "gemm_tn.hpp"
+
+#include <cstdlib>
+#include <type_traits>
+
+namespace oq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kST = 256;                          // block tile edge
+constexpr int kSK = 16;                           // rows of X per stage = k of one MFMA
+constexpr int kSThreads = 512;
+constexpr int kPlaneBytes = 2 * kST * 16;         // [t-chunk][position] x 16 B
+constexpr int kOperandBytes = 3 * kPlaneBytes;    // hi | mid | lo
+constexpr int kStageBytes = 2 * kOperandBytes;    // A | B
+constexpr int kSyrkLdsBytes = 3 * kStageBytes;    // ring of three stages: 147 456 B
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    const bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};   // v_cvt_pk_bf16_f32: round to nearest even
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// two consecutive rows of one column -> the three packed piece pairs
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    hi = pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);      // exact
+    mid = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);    // exact, <= 8 bits
+    lo = pk_bf16(s0, s1);
+}
+
+// ---- 1. X -> pieces
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                           const int64_t Kp, const int64_t nchunks, u32x4* __restrict__ P) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool col_ok = k < K;
+    const float* src = X + (col_ok ? k : K - 1);
+#pragma unroll 1
+    for (int64_t c = static_cast<int64_t>(blockIdx.y) * 4; c < nchunks && c < static_cast<int64_t>(blockIdx.y) * 4 + 4; ++c) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t t = c * 8 + r;
+            const float x = src[(t < T ? t : T - 1) * ldx];
+            v[r] = (t < T && col_ok) ? x : 0.f;
+        }
+        u32x4 hi, mid, lo;
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            uint32_t h, m, l;
+            split_pair(v[2 * rp], v[2 * rp + 1], h, m, l);
+            hi[rp] = h; mid[rp] = m; lo[rp] = l;
+        }
+        u32x4* o = P + (c * 3) * Kp + k;
+        __builtin_nontemporal_store(hi, o);
+        __builtin_nontemporal_store(mid, o + Kp);
+        __builtin_nontemporal_store(lo, o + 2 * Kp);
+    }
+}
+
+// ---- 2. C += pieces^T pieces
+// Stream of one stage (sched_barrier(0) pins it; what sits BETWEEN two MFMAs issues while the first one runs):
+//   slots 0-23  this wave's six global_load_lds of stage s + 2 into ring slot (s + 2) % 3 (free since the last barrier),
+//               one every fourth slot
+//   per j       the B operand of tile column j + 1 while the MFMAs of column j run
+//   tail        stage s + 1 landed before the last barrier, so its first operands are fetched behind the last MFMAs of
+//               this stage: no wave starts a stage by waiting for LDS while all eight queue 9 KB each on it
+//   end         vmcnt(0) (the DMAs were issued ~40 MFMAs ago), lgkmcnt(0), s_barrier.
+template <int TERMS>
+__global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
+                                                                const float alpha, const float beta, float* __restrict__ C,
+                                                                float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int tile_m, tile_n;
+    upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles, tile_m, tile_n);
+    const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
+    const int64_t s_begin = static_cast<int64_t>(blockIdx.y) * stages_per_slice;
+    const int64_t s_end = s_begin + stages_per_slice < nstages_all ? s_begin + stages_per_slice : nstages_all;
+    const int64_t nstages = s_end - s_begin;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = lane >> 5, cl = lane & 31;
+
+    // ---- loader role: pieces q = 6 wave .. 6 wave + 5 of the 48 KB stage; piece q = 1 KB =
+    // (operand, piece, chunk, quarter of 64 columns) in LDS order [operand][piece][chunk][256 columns]
+    const char* gsrc[6];
+    uint32_t ldst[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int q = wave * 6 + i;
+        const int quarter = q & 3, cc = (q >> 2) & 1, pc = (q >> 3) % 3, op = q / 24;
+        ldst[i] = static_cast<uint32_t>(q) * 1024u;
+        const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
+        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * 2 + cc) * 3 + pc) * Kp + colq);
+    }
+    const int64_t stage_bytes = 2 * 3 * Kp * 16;
+    auto stage_dma = [&](int64_t s_rel, int slot3, int i) {
+        __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes,
+                                         (__attribute__((address_space(3))) void*)(lds + slot3 * kStageBytes + ldst[i]), 16, 0, 0);
+    };
+
+    // prologue: stages 0 and 1 (clamped to the last stage of the slice when the slice is shorter: harmless re-reads)
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) stage_dma(st < nstages ? st : nstages - 1, st, i);
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    constexpr int kSlots = 8 * TERMS;
+    static_assert(kSlots >= 2 + 6 * 4, "the DMAs must fit into the stream");
+    const uint32_t rd_a = static_cast<uint32_t>((kc * kST + wm * 64 + cl) * 16);
+    const uint32_t rd_b = static_cast<uint32_t>(kOperandBytes + (kc * kST + wn * 128 + cl) * 16);
+    bf16x8 a[2][3], b[2][3];
+    auto read_a = [&](int slot3, int i) {
+#pragma unroll
+        for (int p = 2; p >= 0; --p) a[i][p] = *reinterpret_cast<const bf16x8*>(lds + slot3 * kStageBytes + rd_a + p * kPlaneBytes + i * 32 * 16);
+    };
+    auto read_b = [&](int slot3, int j, int which) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[which][p] = *reinterpret_cast<const bf16x8*>(lds + slot3 * kStageBytes + rd_b + p * kPlaneBytes + j * 32 * 16);
+    };
+    auto stage_body = [&](auto phase_tag, int64_t s, int cur3, int nxt3, int wr3) {
+        constexpr int STRIDE = 4;                                        // one DMA every fourth MFMA
+        constexpr int DMA0 = decltype(phase_tag)::value ? 2 : 0;         // first slot of this wave's six DMAs
+        read_a(cur3, 1);                                       // a[0], b[0] came with the previous stage
+        const int64_t s_dma = s + 2 < nstages ? s + 2 : nstages - 1;   // behind the slice: re-read its last stage into a slot nobody reads
+        int slot = 0;
+        auto mm = [&](const bf16x8& x, const bf16x8& y, f32x16& c) {
+            __builtin_amdgcn_sched_barrier(0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (slot >= DMA0 && slot < DMA0 + 6 * STRIDE && (slot - DMA0) % STRIDE == 0) stage_dma(s_dma, wr3, (slot - DMA0) / STRIDE);
+            ++slot;
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cur = j & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 c = acc[i][j];
+                if constexpr (TERMS == 9) {
+                    mm(a[i][2], b[cur][2], c);
+                    mm(a[i][2], b[cur][1], c);
+                    mm(a[i][1], b[cur][2], c);
+                }
+                mm(a[i][2], b[cur][0], c);     // small terms first
+                mm(a[i][0], b[cur][2], c);
+                mm(a[i][1], b[cur][1], c);
+                if (i == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 3) read_b(cur3, j + 1, cur ^ 1);
+                    else read_b(nxt3, 0, 0);
+                }
+                mm(a[i][1], b[cur][0], c);
+                mm(a[i][0], b[cur][1], c);
+                mm(a[i][0], b[cur][0], c);
+                acc[i][j] = c;
+                if (i == 0 && j == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_a(nxt3, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    read_b(0, 0, 0);
+    read_a(0, 0);
+    int cur3 = 0, nxt3 = 1, wr3 = 2;
+    // Neighbouring waves (the two of a SIMD, and neighbouring SIMDs) run the same stream with their DMAs two slots apart,
+    // so that they do not all pay the issue cost of a global_load_lds -- M0, address, ~100 cycles on a busy CU -- in the
+    // same MFMA gap (measured: all in slots 0-5 199, half a stage apart 213-219, one every fourth slot and two slots
+    // apart 225 TFLOP/s fp32-equivalent, K = 11008).  Two copies of the loop: a branch inside it would cost the
+    // accumulators their registers.
+    const int phase = __builtin_amdgcn_readfirstlane((wave >> 2) ^ (wave & 1));
+    if (phase) {
+        for (int64_t s = 0; s < nstages; ++s) {
+            stage_body(std::true_type{}, s, cur3, nxt3, wr3);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_barrier();
+            const int t3 = cur3; cur3 = nxt3; nxt3 = wr3; wr3 = t3;
+        }
+    } else {
+        for (int64_t s = 0; s < nstages; ++s) {
+            stage_body(std::false_type{}, s, cur3, nxt3, wr3);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_barrier();
+            const int t3 = cur3; cur3 = nxt3; nxt3 = wr3; wr3 = t3;
+        }
+    }
+
+    // ---- epilogue.  C/D map of a 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).
+    float* out = slab ? slab + static_cast<int64_t>(blockIdx.y) * K * K : C;
+    const bool direct = slab == nullptr;
+    const bool diag = tile_m == tile_n;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t colj = n0 + wn * 128 + j * 32 + cl;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kc;
+                if (row < K && colj < K) {
+                    float val = acc[i][j][e];
+                    if (direct) {
+                        // a diagonal tile holds both (r, c) and (c, r), summed in different orders: keep the upper one
+                        // and mirror it, so that C is symmetric bit for bit
+                        if (diag && colj < row) continue;
+                        val = alpha * val;
+                        if (beta != 0.0f) val = beta * out[row * K + colj] + val;
+                        if (colj != row) out[colj * K + row] = val;
+                    }
+                    out[row * K + colj] = val;
+                }
+            }
+        }
+}
+
+bool syrk_bf16x3_applicable(const float* X, int64_t T, int64_t K, int64_t ldx) {
+    return X != nullptr && T > 0 && K >= 1 && ldx >= K;
+}
+
+static int64_t padded_k(int64_t K) { return ceil_div(K, kST) * kST; }
+static int64_t stages_of(int64_t T) { return ceil_div(T, kSK); }
+
+size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K) {
+    if (T <= 0 || K <= 0) return 0;
+    return static_cast<size_t>(stages_of(T)) * 2 * 3 * padded_k(K) * 16;
+}
+
+int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, void* workspace,
+                           size_t workspace_bytes, int terms, hipStream_t s) {
+    OQ_REQUIRE(syrk_bf16x3_applicable(X, T, K, ldx), OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: bad argument");
+    OQ_REQUIRE(terms == 6 || terms == 9, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: terms must be 6 or 9");
+    const size_t pieces = syrk_bf16x3_pieces_bytes(T, K);
+    OQ_REQUIRE(workspace != nullptr && workspace_bytes >= pieces + 256, OQ_ERR_WORKSPACE,
+               "syrk_bf16x3: workspace of %zu bytes needed for the operand pieces, %zu given", pieces + 256, workspace_bytes);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    base += (256 - (reinterpret_cast<uintptr_t>(base) & 255u)) & 255u;
+    u32x4* P = reinterpret_cast<u32x4*>(base);
+    float* slab = reinterpret_cast<float*>(base + pieces);
+    const size_t slab_bytes = workspace_bytes - pieces - 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_pieces_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLdsBytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_pieces_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLdsBytes);
+        OQ_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", kSyrkLdsBytes);
+        attr_set = true;
+    }
+    const int64_t Kp = padded_k(K), nstages = stages_of(T), nchunks = nstages * 2;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<uint32_t>(Kp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s,
+                       X, T, K, ldx, Kp, nchunks, P);
+    int32_t st = check_launch("split_bf16x3_kernel");
+    if (st != OQ_OK) return st;
+
+    const int tn = static_cast<int>(Kp / kST);
+    const int64_t tiles = static_cast<int64_t>(tn) * (tn + 1) / 2;
+    // T-slices: one block per CU (144 KB of LDS), 256 CUs.  Choose the slice count (<= 16, slices of >= 32 stages, slab
+    // permitting) whose block count fills whole rounds of 256 best; ties go to fewer slices.
+    int splits = 1;
+    {
+        const int64_t by_rows = nstages / 32 > 0 ? nstages / 32 : 1;
+        int64_t cap = by_rows < 16 ? by_rows : 16;
+        while (cap > 1 && static_cast<size_t>(cap) * K * K * sizeof(float) > slab_bytes) --cap;
+        double best = -1.0;
+        for (int c = 1; c <= cap; ++c) {
+            const int64_t blocks = tiles * c;
+            const double fill = static_cast<double>(blocks) / static_cast<double>(ceil_div(blocks, 256) * 256);
+            if (fill > best + 0.02) { best = fill; splits = c; }      // more slices only for a real gain (each costs a K x K pass)
+        }
+    }
+    int64_t per = ceil_div(nstages, splits);
+    splits = static_cast<int>(ceil_div(nstages, per));
+    float* slab_f = splits > 1 ? slab : nullptr;
+    const dim3 grid(static_cast<uint32_t>(tiles), static_cast<uint32_t>(splits));
+    if (terms == 9)
+        hipLaunchKernelGGL(syrk_pieces_kernel<9>, grid, dim3(kSThreads), kSyrkLdsBytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn);
+    else
+        hipLaunchKernelGGL(syrk_pieces_kernel<6>, grid, dim3(kSThreads), kSyrkLdsBytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn);
+    st = check_launch("syrk_pieces_kernel");
+    if (st != OQ_OK || splits == 1) return st;
+    return launch_syrk_reduce(slab_f, splits, K, alpha, beta, C, kST, s);
+}
+
+}  // namespace oq

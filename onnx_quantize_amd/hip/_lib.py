@@ -20,6 +20,7 @@ OQ_TENSOR, OQ_CHANNEL, OQ_GROUP = range(3)
 OQ_LAYOUT_KN, OQ_LAYOUT_NBITS = range(2)
 OQ_GPTQ_PARITY, OQ_GPTQ_CORRECTED = range(2)
 OQ_ABI_VERSION = 1
+OQ_ERR_INVALID_ARGUMENT, OQ_ERR_UNSUPPORTED, OQ_ERR_WORKSPACE, OQ_ERR_LAUNCH, OQ_ERR_NOT_SPD = -1, -2, -3, -4, -5
 
 QTYPE_CODE = {"int4": OQ_INT4, "uint4": OQ_UINT4, "int8": OQ_INT8, "uint8": OQ_UINT8,
               "int32": OQ_INT32, "uint32": OQ_UINT32}
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "oq_minmax_collect_many_f32": (_i32, [_p, _i64, _f64, _p, _sz, _p]),
     "oq_absmax_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oq_absmax_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "oq_hessian_set_method": (_i32, [_i32]),
+    "oq_hessian_method": (_i32, []),
     "oq_hessian_workspace_bytes": (_sz, [_i64, _i64]),
     "oq_hessian_accumulate_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "oq_gptq_prepare_workspace_bytes": (_sz, [_i64, _i64, _i32]),

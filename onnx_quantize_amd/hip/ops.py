@@ -445,9 +445,22 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
     if h.shape != (k, k) or not h.is_contiguous():
         raise ValueError(f"H must be a contiguous [{k}, {k}] tensor")
     lib = L.load()
-    ws = _workspace(lib.oq_hessian_workspace_bytes(t, k) if k <= 8192 else 256, x.device)
+    ws = _workspace(lib.oq_hessian_workspace_bytes(t, k), x.device)
     L.check(lib.oq_hessian_accumulate_f32(_ptr(x2), t, k, ldx, int(n_seen), n_add, _ptr(h), _ptr(ws), ws.numel(), _stream()))
     return int(n_seen) + n_add
+
+
+HESSIAN_METHODS = {"auto": 0, "f32": 1, "bf16x6": 2, "bf16x9": 3}
+
+
+def hessian_set_method(method: str) -> None:
+    """Process-wide choice of the X^T X kernel (include/oq_hip.h, G1): "auto" | "f32" | "bf16x6" | "bf16x9"."""
+    L.check(L.load().oq_hessian_set_method(HESSIAN_METHODS[method]))
+
+
+def hessian_method() -> str:
+    code = L.load().oq_hessian_method()
+    return next(k for k, v in HESSIAN_METHODS.items() if v == code)
 
 
 def gptq_prepare(w: torch.Tensor, h: torch.Tensor, actorder: bool):

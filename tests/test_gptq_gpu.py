@@ -73,6 +73,80 @@ def test_hessian_shapes_vs_float64(ops, t, k):
     np.testing.assert_allclose(h.cpu().numpy(), ref, rtol=0, atol=2e-5 * float(np.abs(ref).max()))
 
 
+@pytest.fixture
+def restore_hessian_method(ops):
+    before = ops.hessian_method()
+    yield
+    ops.hessian_set_method(before)
+
+
+@pytest.mark.parametrize("method", ["f32", "bf16x6", "bf16x9"])
+@pytest.mark.parametrize("t,k,ld", [(4096, 1024, 1024), (1000, 384, 384), (333, 200, 256), (2050, 1301, 1301), (16, 1, 1)])
+def test_hessian_methods_vs_float64(ops, restore_hessian_method, method, t, k, ld):
+    """Every X^T X kernel (include/oq_hip.h, G1 methods): fp32-grade against float64, exactly symmetric, exact zeros for
+    dead channels, rows of X with a leading dimension, T and K that are no multiples of the 16-row stage / 256 tile."""
+    import torch
+    rng = np.random.default_rng(t + k)
+    x = rng.standard_normal((t, ld), dtype=np.float32) * rng.uniform(0.1, 3, size=ld).astype(np.float32) + 0.25
+    if k > 8:
+        x[:, 5] = 0
+    xd = dev(x)[:, :k]                                               # a strided view when ld > k
+    ops.hessian_set_method(method)
+    assert ops.hessian_method() == method
+    h = torch.zeros((k, k), dtype=torch.float32, device="cuda")
+    n = ops.hessian_accumulate(xd.reshape(2, t // 2, k) if ld == k else xd, h, 0)
+    n_add = 2 if ld == k else t
+    assert n == n_add
+    x2 = x[:, :k].astype(np.float64)
+    ref = (2.0 / n_add) * x2.T @ x2
+    got = h.cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5 * float(np.abs(ref).max()))
+    np.testing.assert_array_equal(got, got.T)
+    if k > 8:
+        assert np.all(got[5] == 0) and np.all(got[:, 5] == 0)
+    # second batch: the running average H n/(n+b) + (2/(n+b)) X^T X
+    n2 = ops.hessian_accumulate(xd.reshape(2, t // 2, k) if ld == k else xd, h, n)
+    assert n2 == 2 * n_add
+    np.testing.assert_allclose(h.cpu().numpy(), ref, rtol=0, atol=1e-5 * float(np.abs(ref).max()))   # same X twice: same mean
+
+
+def test_hessian_auto_picks_the_split_kernel_for_wide_inputs_only(ops, restore_hessian_method):
+    import torch
+    ops.hessian_set_method("auto")
+    x = torch.randn((2, 512, 1024), device="cuda")
+    outs = {}
+    for m in ("auto", "bf16x6", "f32"):
+        ops.hessian_set_method(m)
+        h = torch.zeros((1024, 1024), device="cuda")
+        ops.hessian_accumulate(x, h, 0)
+        outs[m] = h
+    assert torch.equal(outs["auto"], outs["bf16x6"]) and not torch.equal(outs["auto"], outs["f32"])
+    xs = x[..., :512].contiguous()
+    for m in ("auto", "f32"):
+        ops.hessian_set_method(m)
+        h = torch.zeros((512, 512), device="cuda")
+        ops.hessian_accumulate(xs, h, 0)
+        outs[m] = h
+    assert torch.equal(outs["auto"], outs["f32"])
+
+
+def test_hessian_method_errors_are_loud(ops, restore_hessian_method):
+    import torch
+    from onnx_quantize_amd.hip import _lib as L
+    lib = L.load()
+    assert lib.oq_hessian_set_method(7) == L.OQ_ERR_INVALID_ARGUMENT and b"unknown method" in lib.oq_last_error()
+    ops.hessian_set_method("bf16x6")
+    x = torch.randn((64, 256), device="cuda")
+    h = torch.zeros((256, 256), device="cuda")
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")         # far too small for the pieces
+    st = lib.oq_hessian_accumulate_f32(x.data_ptr(), 64, 256, 256, 0, 64, h.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert st == L.OQ_ERR_WORKSPACE and b"workspace" in lib.oq_last_error()
+    assert float(h.abs().max()) == 0.0                               # nothing was written
+    ops.hessian_set_method("auto")                                   # auto never fails for lack of workspace: fp32 kernel
+    st = lib.oq_hessian_accumulate_f32(x.data_ptr(), 64, 256, 256, 0, 64, h.data_ptr(), None, 0, None)
+    assert st == 0 and float(h.abs().max()) > 0
+
+
 @pytest.mark.parametrize("k", [96, 128, 200, 256, 515, 1024])
 def test_factor_vs_float64(ops, k):
     """U upper, zero below the diagonal, U^T U = inv(H + damp I)."""
