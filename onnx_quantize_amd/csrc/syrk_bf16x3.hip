@@ -276,14 +276,12 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     u32x4* P = reinterpret_cast<u32x4*>(base);
     float* slab = reinterpret_cast<float*>(base + pieces);
     const size_t slab_bytes = workspace_bytes - pieces - 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_pieces_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLdsBytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_pieces_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLdsBytes);
-        OQ_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", kSyrkLdsBytes);
-        attr_set = true;
-    }
+    // per launch, not once: the attribute belongs to the current device's copy of the kernel
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(terms == 9 ? &syrk_pieces_kernel<9> : &syrk_pieces_kernel<6>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLdsBytes);
+    OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", kSyrkLdsBytes);
     const int64_t Kp = padded_k(K), nstages = stages_of(T), nchunks = nstages * 2;
+    OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "syrk_bf16x3: at most 2 097 120 rows per call, %lld given", (long long)T);
     hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<uint32_t>(Kp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s,
                        X, T, K, ldx, Kp, nchunks, P);
     int32_t st = check_launch("split_bf16x3_kernel");
