@@ -78,7 +78,6 @@ int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha
 // into three bf16 pieces whose sum is the element exactly; `terms` = 6 (piece products down to 2^-16, the dropped
 // ones are below fp32 rounding of a product) or 9 (all of them).  workspace = the pieces (syrk_bf16x3_pieces_bytes)
 // followed by optional T-slice slabs of K x K floats.
-bool syrk_bf16x3_applicable(const float* X, int64_t T, int64_t K, int64_t ldx);
 size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K);
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C,
                            void* workspace, size_t workspace_bytes, int terms, hipStream_t s);

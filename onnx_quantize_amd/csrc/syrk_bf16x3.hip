@@ -8,6 +8,7 @@
 // terms = 6 keeps everything down to 2^-16 (what is dropped is <= 2^-23 |x y|, the size of ONE fp32 rounding of the
 // product, and of either sign because the pieces are rounded to nearest); terms = 9 keeps all and is then MORE exact
 // than an fp32 fma chain (no product rounding at all).  6 MFMAs at 16 x the fp32 rate = 2.7 x the fp32 peak.
+// (bf16 has fp32's exponent range, so the split needs no scaling; inf / NaN inputs give NaN where fp32 gives inf / NaN.)
 //
 // Two kernels.
 //  1. split_bf16x3_kernel: X -> pieces P, once (HBM-bound: 4 B read + 6 B written per element).  The MFMA wants, per
@@ -23,7 +24,6 @@
 //     registers, no ds_write, no VALU.  LDS is a ring of three stages (144 KB, one block per CU).
 #include "gemm_tn.hpp"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace oq {
@@ -252,10 +252,6 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
         }
 }
 
-bool syrk_bf16x3_applicable(const float* X, int64_t T, int64_t K, int64_t ldx) {
-    return X != nullptr && T > 0 && K >= 1 && ldx >= K;
-}
-
 static int64_t padded_k(int64_t K) { return ceil_div(K, kST) * kST; }
 static int64_t stages_of(int64_t T) { return ceil_div(T, kSK); }
 
@@ -266,7 +262,7 @@ size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K) {
 
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, void* workspace,
                            size_t workspace_bytes, int terms, hipStream_t s) {
-    OQ_REQUIRE(syrk_bf16x3_applicable(X, T, K, ldx), OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: bad argument");
+    OQ_REQUIRE(X != nullptr && C != nullptr && T > 0 && K >= 1 && ldx >= K, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: bad argument");
     OQ_REQUIRE(terms == 6 || terms == 9, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: terms must be 6 or 9");
     const size_t pieces = syrk_bf16x3_pieces_bytes(T, K);
     OQ_REQUIRE(workspace != nullptr && workspace_bytes >= pieces + 256, OQ_ERR_WORKSPACE,
