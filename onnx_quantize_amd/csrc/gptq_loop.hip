@@ -118,14 +118,20 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
         // gptq.py:168-184: parameters of every group that starts in this sub-block, from rows [row, row + g) of the
         // GLOBAL working matrix (not of the block copy), channel strategy -- or the ones an MSE search left.  All
         // four waves fold the rows (8 loads in flight per lane); uniform control flow.
+        // position of the sub-block's first row inside its group: ONE 64-bit division per sub-block instead of two per
+        // row step (a runtime 64-bit `%` / `/` is ~100 instructions, and the row steps are the critical chain)
+        const int64_t grp0 = a.g > 0 ? (a.i1 + s0) / a.g : 0;
+        const int64_t rem0 = a.g > 0 ? (a.i1 + s0) - grp0 * a.g : 1;
         if (a.g > 0) {
             int slot = 0;
-            for (int i = 0; i < ns; ++i) {
+            int64_t rem = rem0, grp = grp0;
+            for (int i = 0; i < ns; ++i, ++rem) {
                 const int64_t row = a.i1 + s0 + i;
-                if (row % a.g != 0) continue;
+                if (rem == a.g) { rem = 0; ++grp; }
+                if (rem != 0) continue;
                 if (a.pre_scale != nullptr) {   // mse=True: searched beforehand on the same rows (utils.py:140-239)
                     if (wave == 0) {
-                        const int64_t o = (row / a.g - a.pre_first_group) * a.N + cc;
+                        const int64_t o = (grp - a.pre_first_group) * a.N + cc;
                         gp_scale[slot][lane] = a.pre_scale[o];
                         gp_zp[slot][lane] = a.zp_signed ? static_cast<int32_t>(static_cast<int8_t>(a.pre_zp[o])) : static_cast<int32_t>(a.pre_zp[o]);
                     }
@@ -158,19 +164,21 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
         if (wave == 0) {
             float w[kSubRows];
             int slot = 0;
+            int64_t rem = rem0, grp = grp0;
 #pragma unroll
             for (int i = 0; i < kSubRows; ++i) w[i] = tile[(s0 + i < count) ? s0 + i : count - 1][lane];
 #pragma unroll
-            for (int i = 0; i < kSubRows; ++i) {
+            for (int i = 0; i < kSubRows; ++i, ++rem) {
                 if (i < ns) {   // uniform
                     const int64_t row = a.i1 + s0 + i;
-                    if (a.g > 0 && row % a.g == 0) {
+                    if (rem == a.g) { rem = 0; ++grp; }
+                    if (rem == 0) {   // a.g <= 0: rem0 = 1 and `rem == a.g` never holds, so rem only grows
                         scale = gp_scale[slot][lane];
                         zp = gp_zp[slot][lane];
                         ++slot;
                         if (live && a.used_scale != nullptr) {
-                            a.used_scale[(row / a.g) * a.N + c] = scale;
-                            a.used_zp[(row / a.g) * a.N + c] = zp;
+                            a.used_scale[grp * a.N + c] = scale;
+                            a.used_zp[grp * a.N + c] = zp;
                         }
                     }
                     const int32_t qi = quantize_one(w[i], scale, zp, qmin, qmax);   // gptq.py:186-188
