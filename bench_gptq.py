@@ -13,8 +13,9 @@ calibration forward pass, which is not part of the path), streamed batch by batc
 collective while quantizing; one RCCL gather of (packed int4, scales, zero points) to rank 0 at the end.
 Strong scaling: the model is fixed.
 
-Two HIP streams per rank: the Hessian of input i+1 (chip-filling MFMA GEMMs) runs next to the inverse factor and
-the loop of input i (latency-bound chains of small launches); `--no-overlap` serialises them.  `value` is
+HIP streams per rank: one for the Hessians (chip-filling MFMA GEMMs) and `--factor-streams` (4) that take the inverse
+factor + loop of successive inputs in turn (latency-bound chains of small launches, side by side and next to the
+Hessian of the following inputs); `--no-overlap` serialises everything on one stream.  `value` is
 parameters / wall time of the timed region (first Hessian launch to the end of the gather, max over ranks).
 Prints one JSON line on rank 0.
 """
@@ -42,6 +43,9 @@ def main() -> None:
     ap.add_argument("--hidden", type=int, default=4096)
     ap.add_argument("--ffn", type=int, default=11008)
     ap.add_argument("--no-overlap", action="store_true", help="one stream: Hessian, factor and loop strictly in sequence")
+    ap.add_argument("--factor-streams", type=int, default=4,
+                    help="streams that take the factor + loop chains of successive inputs in turn (chains of small launches: "
+                         "several of them side by side hide each other's launch and diagonal-block latency)")
     args = ap.parse_args()
 
     import torch
@@ -100,11 +104,12 @@ def main() -> None:
         groups[seen[key]][1].append(i)
 
     s_h = torch.cuda.Stream(device=dev)
-    s_q = s_h if args.no_overlap else torch.cuda.Stream(device=dev)
+    q_streams = [s_h] if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
     results, timings = {}, []
     fence()
     t0 = time.perf_counter()
-    for key, members in groups:
+    for gi, (key, members) in enumerate(groups):
+        s_q = q_streams[gi % len(q_streams)]
         k = specs[members[0]].k
         with torch.cuda.stream(s_h):
             h = torch.zeros((k, k), device=dev)
@@ -158,7 +163,7 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
                        "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
-                       "streams": 1 if args.no_overlap else 2, "hessian_method": ops.hessian_method()},
+                       "streams": 1 if args.no_overlap else 1 + len(q_streams), "hessian_method": ops.hessian_method()},
             "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
                         "gather": round(float(stats[2]), 4),
                         # per-phase device time (with two streams the phases overlap: their sum exceeds the wall time)
