@@ -80,6 +80,14 @@ def main():
     wq = [ops.rtn_quantize(w, "int8", "tensor", -1, True) for w in weights]
     torch.cuda.synchronize()
     t_weights = time.perf_counter() - t2
+    # the same 126 matrices through the many-tensor entry point (three launches for the whole model)
+    ops.rtn_quantize_tensor_many(weights, "int8", True)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    wq_many = ops.rtn_quantize_tensor_many(weights, "int8", True)
+    torch.cuda.synchronize()
+    t_weights_many = time.perf_counter() - t3
+    assert all(torch.equal(a[0], b[0]) and float(a[1]) == float(b[1]) for a, b in zip(wq[:5], wq_many[:5]))
     wparams = sum(w.numel() for w in weights)
     # correctness spot check against torch
     for name in list(acts)[:6]:
@@ -104,8 +112,9 @@ def main():
                    "tensors_per_batch": len(acts), "bytes_per_batch": nbytes},
         "seconds": {"collect": round(t_collect, 4), "ranges_and_qparams": round(t_params, 4),
                     "collect_per_tensor_calls": round(t_per_tensor, 4), "ranges_and_qparams_per_name_calls": round(t_params_per_name, 4),
-                    "weights_rtn_int8_per_tensor": round(t_weights, 4)},
-        "weights": {"matrices": len(weights), "params": wparams, "M_params_per_s": round(wparams / t_weights / 1e6, 1)},
+                    "weights_rtn_int8_per_tensor": round(t_weights, 4), "weights_rtn_int8_per_tensor_one_call": round(t_weights_many, 5)},
+        "weights": {"matrices": len(weights), "params": wparams, "M_params_per_s": round(wparams / t_weights / 1e6, 1),
+                    "M_params_per_s_one_call": round(wparams / t_weights_many / 1e6, 1)},
         "tensors_per_s": round(len(acts) * batches / t_collect, 1),
         "per_tensor_calls": {"GBs": round(nbytes * batches / t_per_tensor / 1e9, 1),
                              "tensors_per_s": round(len(acts) * batches / t_per_tensor, 1)},

@@ -143,6 +143,22 @@ int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, co
 int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale,
                              float x_scale, int32_t* q_out, float* bias_scale_out, void* stream);
 
+/* A1 with strategy = tensor for n weight tensors in three launches (a model of many small MatMul weights makes a
+ *     loop over oq_rtn_quantize_f32 launch-bound).  `desc` is a DEVICE array of n oq_rtn_tensor_desc: w = `count`
+ *     contiguous fp32 values, q_out = `count` bytes (4-bit values one per byte, signed ones as two's complement),
+ *     scale_out / zp_out = one entry each.  4- and 8-bit types only.  Same bits as oq_rtn_quantize_f32 per tensor. */
+typedef struct {
+    const float* w;
+    int64_t count;
+    void* q_out;
+    float* scale_out;
+    void* zp_out;
+} oq_rtn_tensor_desc;
+size_t oq_rtn_tensor_many_workspace_bytes(int64_t n);
+int32_t oq_rtn_tensor_many_f32(const void* desc, int64_t n, int32_t qtype, int32_t symmetric,
+                               int32_t reduce_range, float clip_ratio, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* C1 for a whole calibration batch: n tensors in ONE launch pair (calibrate.py:264-266 calls collect once per
  *     tensor and batch; dozens of 10-40 MB tensors per batch make that loop launch-bound).  `desc` is a DEVICE
  *     array of n oq_minmax_desc {x, count, state}; every count > 0; each state as in oq_minmax_collect_f32. */

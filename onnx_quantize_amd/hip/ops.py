@@ -146,6 +146,39 @@ def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_rati
     return q, scale.reshape(rows, 1), zp.reshape(rows, 1), rounds
 
 
+def rtn_quantize_tensor_many(ws, qtype: str, symmetric=False, reduce_range=False, clip_ratio=1.0):
+    """rtn.py:54-109 with strategy "tensor" for a list of contiguous fp32 weights of any shapes in THREE launches
+    (oq_rtn_tensor_many_f32): a model of many small matrices makes a per-matrix loop launch-bound.  4- / 8-bit types.
+    Returns [(q like w in the container dtype, scale 0-d fp32, zp 0-d)], views of three shared buffers."""
+    if not ws:
+        return []
+    if BITS[qtype] > 8:
+        raise NotImplementedError("rtn_quantize_tensor_many: 4- and 8-bit types only")
+    flats = []
+    for w in ws:
+        _require_device(w, "w", torch.float32)
+        flats.append(w if w.is_contiguous() else w.contiguous())
+    dev = flats[0].device
+    cdt = container_dtype(qtype)
+    counts = [f.numel() for f in flats]
+    if min(counts) == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    offs = [0]
+    for c in counts:
+        offs.append(offs[-1] + (c + 15) // 16 * 16)                 # every q slice starts 16-byte aligned
+    q_all = torch.empty(offs[-1], dtype=cdt, device=dev)
+    s_all = torch.empty(len(flats), dtype=torch.float32, device=dev)
+    z_all = torch.empty(len(flats), dtype=cdt, device=dev)
+    qb, sb, zb = q_all.data_ptr(), s_all.data_ptr(), z_all.data_ptr()
+    table = torch.tensor([[f.data_ptr(), c, qb + o, sb + 4 * i, zb + i] for i, (f, c, o) in enumerate(zip(flats, counts, offs))],
+                         dtype=torch.int64).to(dev)
+    lib = L.load()
+    wsb = _workspace(lib.oq_rtn_tensor_many_workspace_bytes(len(flats)), dev)
+    L.check(lib.oq_rtn_tensor_many_f32(_ptr(table), len(flats), L.QTYPE_CODE[qtype], int(symmetric), int(reduce_range),
+                                       float(clip_ratio), _ptr(wsb), wsb.numel(), _stream()))
+    return [(q_all[o:o + c].view(f.shape), s_all[i], z_all[i]) for i, (f, c, o) in enumerate(zip(flats, counts, offs))]
+
+
 def rtn_quantize_batched(w: torch.Tensor, qtype: str, group_size: int, symmetric=False, reduce_range=False,
                          clip_ratio=1.0, layout: str = "kn", out=None):
     """rtn.py:54-109 for a stack of equally shaped weights ``w`` [B, K, N] in ONE launch (group strategy).

@@ -274,3 +274,41 @@ def test_odd_shapes_all_strategies_against_oracle(ops, k, n):
             eb, _, _ = O.matmul_nbits_layout(u, es, ez, min(g, k), O.BITWIDTH[qtype])
             assert np.array_equal(b.cpu().numpy(), eb), label + " (blob)"
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qtype,symmetric,reduce_range,clip", [("int8", True, False, 1.0), ("uint8", False, False, 1.0), ("int4", False, False, 0.9),
+                                                                ("uint4", False, True, 1.0), ("int8", False, True, 0.75), ("int4", True, False, 1.0)])
+def test_tensor_strategy_for_many_weights_in_one_call(qtype, symmetric, reduce_range, clip):
+    """oq_rtn_tensor_many_f32: every tensor gets exactly what `_rtn_quantize(strategy=tensor)` gives it (rtn.py:54-109),
+    whatever the mix of shapes, incl. a 1-element tensor, odd sizes (scalar head / tail paths) and an all-zero one."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    rng = np.random.default_rng(11)
+    shapes = [(640, 2048), (2048, 640), (640, 1024), (1, 1), (7, 13), (333, 129), (64, 64), (5, 4099)]
+    hosts = [(rng.standard_normal(s) * rng.uniform(0.01, 3)).astype(np.float32) for s in shapes]
+    hosts.append(np.zeros((16, 16), np.float32))
+    hosts.append(np.abs(rng.standard_normal((31, 17))).astype(np.float32) + 1)          # strictly positive: zero joins the range
+    res = ops.rtn_quantize_tensor_many([torch.from_numpy(h).cuda() for h in hosts], qtype, symmetric, reduce_range, clip)
+    assert len(res) == len(hosts)
+    for h, (q, s, z) in zip(hosts, res):
+        eq, es, ez = O.rtn_quantize(h, qtype, "tensor", -1, symmetric, reduce_range, clip)
+        assert q.shape == h.shape and s.shape == () and z.shape == ()
+        np.testing.assert_array_equal(q.cpu().numpy(), eq)
+        assert s.cpu().numpy().tobytes() == np.asarray(es, np.float32).tobytes() and int(z.cpu()) == int(ez)
+    # and equals the one-tensor entry point bit for bit
+    q1, s1, z1 = ops.rtn_quantize(torch.from_numpy(hosts[0]).cuda(), qtype, "tensor", -1, symmetric, reduce_range, clip)
+    assert torch.equal(q1, res[0][0]) and torch.equal(s1.reshape(()), res[0][1]) and torch.equal(z1.reshape(()), res[0][2])
+
+
+@pytest.mark.gpu
+def test_tensor_many_errors_are_loud():
+    import torch
+    from onnx_quantize_amd.hip import ops
+    assert ops.rtn_quantize_tensor_many([], "int8") == []
+    with pytest.raises(NotImplementedError):
+        ops.rtn_quantize_tensor_many([torch.zeros(4, device="cuda")], "int32")
+    with pytest.raises(TypeError):
+        ops.rtn_quantize_tensor_many([torch.zeros(4)], "int8")
+    with pytest.raises(ValueError, match="zero-size"):
+        ops.rtn_quantize_tensor_many([torch.zeros(0, device="cuda")], "int8")
