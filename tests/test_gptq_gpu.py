@@ -314,3 +314,28 @@ def test_full_size_layer_properties(ops):
         dq = ops.dequantize(qq, ss, zz, "int4", mode="group", group=128)
         return float(((xs[0].reshape(-1, k)[:2048] @ (dq - w)) ** 2).mean())
     assert out_err(qc, sc, zc) < 0.9 * out_err(rq, rs, rz)
+
+
+def test_hessian_widest_llama_input_properties(ops):
+    """K = 11008 (Llama-2-7B down_proj input, config 4): 43 x 43 tiles of the split-operand kernel, several T-slices.
+    Exactly symmetric, the diagonal = (2/n) sum x^2 and a 256-column strip = the float64 product within the Hessian
+    tolerance, a zero channel stays exactly zero, a second batch continues the running average."""
+    import torch
+    k = 11008
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    chan = 0.1 + 3.9 * torch.rand(k, generator=gen, device="cuda")
+    chan[777] = 0
+    xs = [torch.randn((2, 1024, k), generator=gen, device="cuda") * chan + 0.1 * (chan > 0) for _ in range(2)]
+    assert ops.hessian_method() == "auto"
+    h = torch.zeros((k, k), device="cuda")
+    n = 0
+    for x in xs:
+        n = ops.hessian_accumulate(x, h, n)
+    assert n == 4 and torch.equal(h, h.T)
+    x64 = torch.cat([x.reshape(-1, k) for x in xs]).double()
+    top = float((2.0 / n) * (x64 * x64).sum(0).max())
+    diag = (2.0 / n) * (x64 * x64).sum(0)
+    assert float((torch.diagonal(h).double() - diag).abs().max()) <= 1e-5 * top
+    strip = (2.0 / n) * (x64[:, 10752:].T @ x64)                     # the last, ragged-free tile column
+    assert float((h[10752:].double() - strip).abs().max()) <= 1e-5 * top
+    assert float(h[777].abs().max()) == 0.0 and float(h[:, 777].abs().max()) == 0.0
