@@ -38,7 +38,18 @@ def hessian_of(ops, x):
     return h, n
 
 
-def test_hessian_vs_golden(ops):
+@pytest.mark.parametrize("method", ["auto", "f32", "bf16x6", "bf16x9"])
+def test_hessian_vs_golden(ops, method):
+    """H as the reference itself produced it (tests/golden/make_golden.py ran gptq.py:246-260), for every kernel."""
+    before = ops.hessian_method()
+    ops.hessian_set_method(method)
+    try:
+        _hessian_vs_golden(ops)
+    finally:
+        ops.hessian_set_method(before)
+
+
+def _hessian_vs_golden(ops):
     x = GPTQ["b_x"]
     h, n = hessian_of(ops, x)
     assert n == int(GPTQ["b_nsamples"])
