@@ -149,6 +149,25 @@ def main() -> None:
     t_f = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "f")
     t_l = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "l")
 
+    # outside the timed region: the Hessian kernel that just ran against float64 (a 256-column strip of one input)
+    hcheck = None
+    if rank == 0:
+        kc = min(acts)
+        hc = torch.zeros((kc, kc), device=dev)
+        ref = torch.zeros((256, kc), dtype=torch.float64, device=dev)
+        nc = 0
+        for x in acts[kc]:
+            nc = ops.hessian_accumulate(x, hc, nc)
+            x2 = x.reshape(-1, kc)
+            for i in range(0, x2.shape[0], 16384):
+                blk = x2[i:i + 16384].double()
+                ref += blk[:, :256].t() @ blk
+        ref *= 2.0 / nc
+        hcheck = {"k": kc, "rows": int(sum(x.shape[0] * x.shape[1] for x in acts[kc])),
+                  "max_abs_err_over_max_abs_h": float((hc[:256].double() - ref).abs().max() / ref.abs().max()),
+                  "exactly_symmetric": bool(torch.equal(hc, hc.T))}
+        del hc, ref
+
     stats = torch.tensor([wall, t_quant, t_gather, t_h, t_f, t_l], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
@@ -171,6 +190,7 @@ def main() -> None:
                         "factor_ms_max_rank": round(float(stats[4]), 1), "loop_ms_max_rank": round(float(stats[5]), 1)},
             "gather_bytes": nbytes,
             "hessian_flops_executed": flops_exec,
+            "hessian_check_vs_float64": hcheck,
         }))
     if world > 1:
         dist.destroy_process_group()
