@@ -6,7 +6,7 @@
 //     z   = mean_row(w_q - (w - w_e) * (1/s))
 // Rows (one k-group of one output column) are independent inside a round, the rounds are coupled only through
 // `err`.  So a round is one elementwise kernel over W (read once per round: 4 B / element, HBM / Infinity-Cache
-// bound with a powf per element) that leaves a per-block partial of sum|w - w_r|, and a one-block kernel that
+// bound with a division and a power per element) that leaves a per-block partial of sum|w - w_r|, and a one-block kernel that
 // folds the partials in a fixed order and takes the reference's decision ON THE DEVICE (no host round trip):
 // the next round's kernel applies it.  One thread = one row; neighbouring lanes = neighbouring columns, so every
 // load of W [K, N] is coalesced and no transposed copy (utils.py:24) exists.
@@ -97,7 +97,9 @@ __device__ __forceinline__ float pairwise_row(int64_t n, F&& value) {
 __device__ __forceinline__ float hqq_shrink(float d, float inv_beta, float expo) {
     // hqq.py:102-103: sign(x) * relu(|x| - (1/beta) * (|x| + 1e-8)^(p - 1)), every step rounded to fp32
     const float a = fabsf(d);
-    const float t = a - inv_beta * powf(a + 1e-8f, expo);
+    // (|x| + 1e-8)^(p - 1) = 2^((p - 1) log2(.)) on the hardware log / exp units (~2e-6 relative; np.power is not
+    // reproduced bit for bit either way, see the header)
+    const float t = a - inv_beta * __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf(a + 1e-8f));
     const float m = fmaxf(0.0f, t);
     const float sg = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : d);   // np.sign keeps +-0 and NaN
     return sg * m;

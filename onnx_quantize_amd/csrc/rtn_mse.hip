@@ -9,11 +9,12 @@
 // Here every row records a 20-bit mask of the iterations in which it would improve (rows are independent
 // until the stop), the masks are OR-ed into one device word, and a resolve kernel derives the stop
 // iteration from that word and picks, per row, the last improving iteration not after it.  The search is
-// ALU-bound (an IEEE divide and a powf per element and candidate, 20 candidates); W is re-read from
-// L2 / Infinity Cache per candidate instead of being tiled: 20 x 45 M powf's dominate everything else.
+// ALU-bound (an IEEE divide and |d|^2.4 per element and candidate, 20 candidates); W is re-read from
+// L2 / Infinity Cache per candidate instead of being tiled.  The power runs on the hardware log / exp units (the library
+// powf was 3/4 of the kernel: 4.6 -> 1.2 ms on the 4096 x 11008 matrix).
 //
 // Numerics: per-element arithmetic follows the reference (divide, rint, clamp, (q - zp) * s, subtract, abs,
-// powf(., 2.4f)), but NumPy's pow kernel and its pairwise summation order cannot be reproduced bit for bit,
+// |.|^2.4), but NumPy's pow kernel and its pairwise summation order cannot be reproduced bit for bit,
 // so two candidates whose errors differ in the last bits can swap; tests/test_mse_gpu.py is tolerance-aware.
 #include "oq_common.hpp"
 
@@ -29,7 +30,9 @@ __device__ __forceinline__ float shrink_factor(int i) { return static_cast<float
 __device__ __forceinline__ float fake_quant_error(float x, const QParam& p, const QGrid& g) {
     const int32_t q = quantize_one(x, p.scale, p.zp, g.qmin, g.qmax);
     const float d = dequantize_one(q, p.scale, p.zp) - x;
-    return powf(fabsf(d), kMseNorm);
+    // |d|^2.4 = 2^(2.4 log2 |d|) on the hardware log / exp units (~2e-6 relative; the library powf costs several times
+    // the rest of the candidate, and NumPy's own float32 pow is not reproduced bit for bit either way, see above)
+    return __builtin_amdgcn_exp2f(kMseNorm * __builtin_amdgcn_logf(fabsf(d)));
 }
 
 struct MseRow {
