@@ -180,12 +180,34 @@ __global__ void pack_zp_u4_kernel(const uint8_t* zp, int64_t N, int64_t blocks, 
     out[t] = static_cast<uint8_t>(lo | (hi << 4));
 }
 
-__global__ void pack_nibbles_kernel(const uint8_t* v, int64_t count, uint8_t* out) {
+// _pack.py:8-22: out[t] = v[2t] & 15 | (v[2t+1] & 15) << 4, zero pad.  A thread takes 16 values (one 16-byte load) and
+// writes 8 bytes when the pointers allow it; the ragged end and unaligned calls go one output byte per thread.
+__global__ void pack_nibbles_kernel(const uint8_t* v, int64_t count, uint8_t* out, int64_t vec16) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (t >= (count + 1) / 2) return;
-    const uint32_t lo = v[2 * t] & 0x0fu;
-    const uint32_t hi = (2 * t + 1 < count) ? (v[2 * t + 1] & 0x0fu) : 0u;  // _pack.py:15-17 zero pad
-    out[t] = static_cast<uint8_t>(lo | (hi << 4));
+    if (t < vec16) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        const u32x4 a = *reinterpret_cast<const u32x4*>(v + 16 * t);
+        u32x2 o;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const uint32_t x = a[2 * h + e] & 0x0f0f0f0fu;              // four values, one per byte
+                const uint32_t y = (x | (x >> 4)) & 0x00ff00ffu;            // bytes 0 and 2: neighbours joined
+                w |= ((y & 0xffu) | ((y >> 8) & 0xff00u)) << (16 * e);
+            }
+            o[h] = w;
+        }
+        *reinterpret_cast<u32x2*>(out + 8 * t) = o;
+        return;
+    }
+    const int64_t j = vec16 * 8 + (t - vec16);                              // output byte index behind the vector part
+    if (j >= (count + 1) / 2) return;
+    const uint32_t lo = v[2 * j] & 0x0fu;
+    const uint32_t hi = (2 * j + 1 < count) ? (v[2 * j + 1] & 0x0fu) : 0u;  // _pack.py:15-17 zero pad
+    out[j] = static_cast<uint8_t>(lo | (hi << 4));
 }
 
 static uint32_t grid_for(int64_t work, int block = 256) {
@@ -311,8 +333,11 @@ int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uin
 
 int32_t oq_pack_nibbles(const void* values, int64_t count, uint8_t* out, void* stream) {
     OQ_REQUIRE(values && out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_nibbles: bad argument");
-    hipLaunchKernelGGL(pack_nibbles_kernel, dim3(static_cast<uint32_t>(ceil_div((count + 1) / 2, 256))), dim3(256), 0,
-                       as_stream(stream), static_cast<const uint8_t*>(values), count, out);
+    const bool aligned = (reinterpret_cast<uintptr_t>(values) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
+    const int64_t vec16 = aligned ? count / 16 : 0;
+    const int64_t threads = vec16 + ((count + 1) / 2 - vec16 * 8);
+    hipLaunchKernelGGL(pack_nibbles_kernel, dim3(static_cast<uint32_t>(ceil_div(threads, 256))), dim3(256), 0,
+                       as_stream(stream), static_cast<const uint8_t*>(values), count, out, vec16);
     return check_launch("pack_nibbles_kernel");
 }
 
