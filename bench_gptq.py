@@ -167,6 +167,35 @@ def main() -> None:
                   "max_abs_err_over_max_abs_h": float((hc[:256].double() - ref).abs().max() / ref.abs().max()),
                   "exactly_symmetric": bool(torch.equal(hc, hc.T))}
         del hc, ref
+    # and its rate alone (no other stream active): one batch of the widest input, events on the current stream
+    roof = None
+    if rank == 0:
+        kw = max(acts)
+        xw = acts[kw][0]
+        hw = torch.zeros((kw, kw), device=dev)
+        ops.hessian_accumulate(xw, hw, 0)
+        torch.cuda.synchronize()
+        e0, e1 = ev(), ev()
+        e0.record()
+        reps = 3
+        for _ in range(reps):
+            ops.hessian_accumulate(xw, hw, xw.shape[0])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        t_rows = xw.shape[0] * xw.shape[1]
+        tiles = (kw + 255) // 256
+        fp32_equiv = 2.0 * t_rows * (tiles * (tiles + 1) // 2) * 256 * 256          # upper 256 x 256 tiles, as executed
+        method = ops.hessian_method()
+        split = method != "f32" and kw >= 1024
+        terms = 9 if method == "bf16x9" else 6
+        roof = {"bound": "mfma", "kernel": "oq::syrk_pieces_kernel<%d>" % terms if split else "oq::gemm_tn_kernel",
+                "achieved": round(fp32_equiv * (terms if split else 1) / ms / 1e9, 1), "peak": 2500.0 if split else 157.3,
+                "unit": "TFLOP/s", "dtype": "bf16 pieces, fp32 accumulate" if split else "f32",
+                "fp32_equivalent_TFLOPs": round(fp32_equiv / ms / 1e9, 1), "call_ms": round(ms, 2), "k": kw, "rows": t_rows,
+                "traffic": None}
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        del hw
 
     stats = torch.tensor([wall, t_quant, t_gather, t_h, t_f, t_l], dtype=torch.float64, device=dev)
     if world > 1:
@@ -191,6 +220,7 @@ def main() -> None:
             "gather_bytes": nbytes,
             "hessian_flops_executed": flops_exec,
             "hessian_check_vs_float64": hcheck,
+            "roofline": roof,
         }))
     if world > 1:
         dist.destroy_process_group()
