@@ -342,13 +342,10 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
     if (st != OQ_OK) return st;
 
     const size_t diag_lds = (2 * kNB + kSB) * kLd * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(diag_lds)) != hipSuccess)
-            return fail(OQ_ERR_LAUNCH, "oq_gptq_factor_f32: cannot reserve %zu bytes of LDS", diag_lds);
-        attr_set = true;
-    }
+    // once per call, not once per process: the attribute belongs to the current device's copy of the kernel
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(diag_lds)) != hipSuccess)
+        return fail(OQ_ERR_LAUNCH, "oq_gptq_factor_f32: cannot reserve %zu bytes of LDS", diag_lds);
 
     // ---- blocked right-looking Cholesky of P, two levels: inside an outer panel of kOuter rows the 128-row steps
     // update only the panel's own rows (a strip of <= 384 rows x all columns behind); the square behind the panel gets
