@@ -90,12 +90,15 @@ class ActivationStream:
     extrema (two floats per name and batch, kept on the device) instead of from the activations."""
 
     def __init__(self, *, calibrator=None, input_names: Iterable[str] = (), output_names: Iterable[str] = (),
-                 hessian_names: Iterable[str] = (), absmax_names: Iterable[str] = (), keep_names: Iterable[str] = ()):
+                 hessian_names: Iterable[str] = (), absmax_names: Iterable[str] = (), keep_names: Iterable[str] = (),
+                 hessian_streams: int = 4):
         self.calibrator = calibrator if calibrator is not None else MinMaxCalibrator()
         self.input_names, self.output_names = list(dict.fromkeys(input_names)), list(dict.fromkeys(output_names))
         self.hessian_names, self.absmax_names = set(hessian_names), set(absmax_names)
         self.keep_names = set(keep_names)
         self.hessians: dict[str, HessianAccumulator] = {}
+        self.hessian_streams = max(0, int(hessian_streams))      # side streams for the Hessian updates of one batch (0: none)
+        self._side = None
         self.absmax: dict = {}
         self._kept: dict[str, list] = {}
         self._ranged = bool(self.input_names or self.output_names)
@@ -124,13 +127,27 @@ class ActivationStream:
                 self.calibrator.collect_many({n: st[:2] for n, st in per_batch.items()})
             else:
                 self.calibrator.collect_many(activations)
-        for name in self.hessian_names & activations.keys():
-            x = activations[name]
-            x = x if x.dtype == torch.float32 else x.to(torch.float32)
-            acc = self.hessians.get(name)
-            if acc is None:
-                acc = self.hessians[name] = HessianAccumulator(x.shape[-1], x.device)
-            acc.add(x)
+        wanted = sorted(self.hessian_names & activations.keys())
+        if wanted:
+            # The updates of different names are independent and, for small models, launch-bound (a few tens of
+            # microseconds of GEMM each): spread them over a few side streams so that they overlap, fork / join by events.
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = [torch.cuda.Stream(device=activations[wanted[0]].device) for _ in range(self.hessian_streams)]
+            fork = cur.record_event()
+            for i, name in enumerate(wanted):
+                x = activations[name]
+                side = self._side[i % len(self._side)] if self._side else cur
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    x32 = x if x.dtype == torch.float32 else x.to(torch.float32)
+                    acc = self.hessians.get(name)
+                    if acc is None:
+                        acc = self.hessians[name] = HessianAccumulator(x32.shape[-1], x32.device)
+                    acc.add(x32)
+                x.record_stream(side)
+            for side in self._side:
+                cur.wait_stream(side)
         for name in self.absmax_names & activations.keys():
             x = activations[name]
             cur = ops.absmax(x if x.dtype == torch.float32 else x.to(torch.float32))
