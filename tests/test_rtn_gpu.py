@@ -312,3 +312,44 @@ def test_tensor_many_errors_are_loud():
         ops.rtn_quantize_tensor_many([torch.zeros(4)], "int8")
     with pytest.raises(ValueError, match="zero-size"):
         ops.rtn_quantize_tensor_many([torch.zeros(0, device="cuda")], "int8")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qtype", ["int4", "uint4", "int8", "uint8"])
+@pytest.mark.parametrize("r,c,mode,group", [(64, 256, "tensor", 1), (33, 1028, "row", 1), (70, 260, "col", 1), (96, 132, "group", 32),
+                                            (256, 1024, "group", 128), (40, 8, "group", 8), (129, 516, "group", 43), (1, 4096, "tensor", 1),
+                                            (37, 63, "col", 1), (50, 1030, "row", 1)])
+def test_elementwise_quantize_dequantize_every_parameter_mode(qtype, r, c, mode, group):
+    """oq_quantize_f32 / oq_dequantize_f32 (utils.py:72-79, :130-132) with parameters per tensor / row / column / row
+    group, on shapes that take the tiled fast path (C % 4 == 0) and on ones that take the per-element kernel, row
+    counts that are no multiple of the 32-row tile, groups that straddle tiles: bit-equal to the oracle's arithmetic."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    rng = np.random.default_rng(r * 1000 + c)
+    x = (rng.standard_normal((r, c)) * 3).astype(np.float32)
+    qmin, qmax = O.qrange(qtype, False, False)
+    nparam = {"tensor": 1, "row": r, "col": c, "group": (r // group) * c}[mode]
+    scale = rng.uniform(0.01, 0.3, size=nparam).astype(np.float32)
+    zp = rng.integers(qmin, qmax + 1, size=nparam).astype(np.int32)
+    if mode == "tensor":
+        s_full, z_full = np.full((r, c), scale[0], np.float32), np.full((r, c), zp[0], np.int32)
+    elif mode == "row":
+        s_full, z_full = np.repeat(scale[:, None], c, 1), np.repeat(zp[:, None], c, 1)
+    elif mode == "col":
+        s_full, z_full = np.repeat(scale[None, :], r, 0), np.repeat(zp[None, :], r, 0)
+    else:   # entry n * (R / g) + kg
+        kg = np.arange(r) // group
+        idx = np.arange(c)[None, :] * (r // group) + kg[:, None]
+        s_full, z_full = scale[idx], zp[idx]
+    eq = np.clip(np.rint(x / s_full).astype(np.int32) + z_full, qmin, qmax)
+    edq = (eq.astype(np.float32) - z_full.astype(np.float32)) * s_full
+    xd, sd, zd = torch.from_numpy(x).cuda(), torch.from_numpy(scale).cuda(), torch.from_numpy(zp).cuda()
+    q = ops.quantize(xd, sd, zd, qtype, False, False, mode, group)
+    np.testing.assert_array_equal(q.cpu().numpy().astype(np.int32), eq)
+    dq = ops.dequantize(q, sd, zd, qtype, mode, group)
+    assert dq.cpu().numpy().tobytes() == edq.astype(np.float32).tobytes()
+    # a row-strided input (leading dimension > C) goes through the same kernels
+    if c % 4 == 0:
+        wide = torch.zeros((r, c + 8), device="cuda")
+        wide[:, :c] = xd
+        assert torch.equal(ops.quantize(wide[:, :c], sd, zd, qtype, False, False, mode, group), q)
