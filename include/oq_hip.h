@@ -207,7 +207,8 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *                          products down to 2^-16 |x y| on v_mfma_f32_32x32x16_bf16, fp32 accumulation; what is left
  *                          out is <= 2^-23 |x y| per product (one fp32 rounding); 2 / n applied to the sum;
  *       OQ_HESSIAN_BF16X9  all nine piece products (no product rounding at all);
- *       OQ_HESSIAN_AUTO    BF16X6 for K >= 1024 (its block tile is 256 x 256) when the workspace holds the pieces,
+ *       OQ_HESSIAN_AUTO    BF16X6 for K >= 1024 (its block tile is 256 x 256; K < 2048 also needs T >= 2048) when the
+ *                          workspace holds the pieces,
  *                          else F32.  An explicit split method with too small a workspace is OQ_ERR_WORKSPACE.
  *     The reference's own H goes through sgemm in BLAS order: parity is to a tolerance for every method.
  * ------------------------------------------------------------------------------------------- */

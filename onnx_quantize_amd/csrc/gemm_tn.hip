@@ -396,7 +396,8 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
     // auto: the split-operand kernels where their 256-wide tiles are worth it and the caller's workspace holds the
     // pieces; small problems stay on the fp32 MFMA
     if (method == OQ_HESSIAN_AUTO)
-        method = (K >= 1024 && workspace != nullptr && workspace_bytes >= syrk_bf16x3_pieces_bytes(T, K) + 256) ? OQ_HESSIAN_BF16X6 : OQ_HESSIAN_F32;
+        method = (K >= 1024 && (T >= 2048 || K >= 2048) && workspace != nullptr && workspace_bytes >= syrk_bf16x3_pieces_bytes(T, K) + 256)
+                     ? OQ_HESSIAN_BF16X6 : OQ_HESSIAN_F32;   // measured cross-over: K = 1024-1536 with ~1000 rows is faster on the fp32 kernel
     if (method != OQ_HESSIAN_F32) {
         // gptq.py:257 scales the operand by sqrt(2 / n); here the factor 2 / n goes onto the sum (one rounding per
         // element of H instead of one per element of X)

@@ -124,7 +124,7 @@ def test_hessian_methods_vs_float64(ops, restore_hessian_method, method, t, k, l
 def test_hessian_auto_picks_the_split_kernel_for_wide_inputs_only(ops, restore_hessian_method):
     import torch
     ops.hessian_set_method("auto")
-    x = torch.randn((2, 512, 1024), device="cuda")
+    x = torch.randn((2, 1024, 1024), device="cuda")                  # K = 1024 needs T >= 2048 rows for the split kernel
     outs = {}
     for m in ("auto", "bf16x6", "f32"):
         ops.hessian_set_method(m)
@@ -137,6 +137,13 @@ def test_hessian_auto_picks_the_split_kernel_for_wide_inputs_only(ops, restore_h
         ops.hessian_set_method(m)
         h = torch.zeros((512, 512), device="cuda")
         ops.hessian_accumulate(xs, h, 0)
+        outs[m] = h
+    assert torch.equal(outs["auto"], outs["f32"])
+    xt = x[:, :256].contiguous()                                     # same width, only 512 rows: below the measured cross-over
+    for m in ("auto", "f32"):
+        ops.hessian_set_method(m)
+        h = torch.zeros((1024, 1024), device="cuda")
+        ops.hessian_accumulate(xt, h, 0)
         outs[m] = h
     assert torch.equal(outs["auto"], outs["f32"])
 
