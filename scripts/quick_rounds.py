@@ -2,7 +2,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from onnx_quantize_amd.hip import ops
 K = 4096
-for N in (4096, 6144, 8192, 9216, 10240, 11008, 12288, 13312, 14336, 16384):
+import sys as _s
+for N in ([int(v) for v in _s.argv[1:]] or (4096, 6144, 8192, 9216, 10240, 11008, 12288, 13312, 14336, 16384)):
     ws = [torch.randn((K, N), device="cuda") for _ in range(max(2, int(1.2e9 / (K * N * 4))))]
     outs = [ops.rtn_quantize(w, "uint4", "group", 128, layout="nbits") for w in ws[:1]]
     out = outs[0]
