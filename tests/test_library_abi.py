@@ -98,3 +98,52 @@ def test_ops_refuse_host_tensors():
         ops.rtn_quantize(torch.zeros(4, 4), "int8", "tensor")
     with pytest.raises(TypeError):
         ops.minmax_collect(torch.zeros(4), torch.zeros(4), 0.0)
+
+
+def _fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for byte in b:
+        h = ((h ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.gpu
+def test_c_program_quantizes_on_the_gpu(tmp_path):
+    """The boundary is a C ABI, not a torch extension: a C99 program that links liboq_hip.so and the HIP runtime only
+    (tests/c/rtn_direct.c) quantizes a matrix on the GPU; its output digests equal the oracle's on the same data, its
+    error path returns a status and a text."""
+    import shutil
+    import subprocess
+    import numpy as np
+    from oracle import oq_oracle as O
+    from onnx_quantize_amd import _build
+
+    gcc, rocm = shutil.which("gcc"), "/opt/rocm"
+    if gcc is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("gcc or the ROCm headers are not on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "rtn_direct")
+    lib_dir = os.path.dirname(_build.LIB)
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(rocm, "include"), os.path.join(root, "tests", "c", "rtn_direct.c"), "-L", lib_dir, "-loq_hip",
+                    "-L", os.path.join(rocm, "lib"), "-lamdhip64", f"-Wl,-rpath,{lib_dir}", f"-Wl,-rpath,{rocm}/lib", "-o", exe],
+                   check=True, capture_output=True, text=True)
+    k, n = 512, 384
+    out = subprocess.run([exe, str(k), str(n)], check=True, capture_output=True, text=True, timeout=120).stdout.splitlines()
+    # the same LCG as the C program
+    x, vals = 12345, np.empty(k * n, np.float32)
+    state = np.uint32(x)
+    seq = np.empty(k * n, np.uint32)
+    with np.errstate(over="ignore"):
+        for i in range(k * n):
+            state = np.uint32(state * np.uint32(1664525) + np.uint32(1013904223))
+            seq[i] = state
+    vals = ((seq >> np.uint32(8)).astype(np.float32) / np.float32(16777216.0) - np.float32(0.5)) * np.float32(4.0)
+    w = vals.reshape(k, n)
+    q, s, z = O.rtn_quantize(w, "uint4", "group", 128)
+    blob, _, _ = O.matmul_nbits_layout(q, s, z, 128, 4)
+    kn = dict(item.split("=") for item in out[0].split()[1:])
+    assert int(kn["q"], 16) == _fnv1a(q.tobytes()) and int(kn["scale"], 16) == _fnv1a(np.ascontiguousarray(s, np.float32).tobytes())
+    assert int(kn["zp"], 16) == _fnv1a(np.ascontiguousarray(z, np.uint8).tobytes())
+    assert int(out[1].split("=")[1], 16) == _fnv1a(blob.tobytes())
+    assert out[2].startswith("error status=-2") and "NBITS layout needs the group strategy" in out[2]
