@@ -357,3 +357,32 @@ def test_hessian_widest_llama_input_properties(ops):
     strip = (2.0 / n) * (x64[:, 10752:].T @ x64)                     # the last, ragged-free tile column
     assert float((h[10752:].double() - strip).abs().max()) <= 1e-5 * top
     assert float(h[777].abs().max()) == 0.0 and float(h[:, 777].abs().max()) == 0.0
+
+
+def test_results_are_deterministic(ops):
+    """No atomics on floating point anywhere on the path: T-slices are summed in slice order, reductions fold in a fixed
+    order -- the same call gives the same bits, for every Hessian kernel, the factor and both loop modes."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((4, 2048, 1280), generator=gen, device="cuda")
+    w = torch.randn((1280, 768), generator=gen, device="cuda") * 0.05
+    before = ops.hessian_method()
+    try:
+        for m in ("f32", "bf16x6", "bf16x9"):
+            ops.hessian_set_method(m)
+            hs = []
+            for _ in range(2):
+                h = torch.zeros((1280, 1280), device="cuda")
+                n = ops.hessian_accumulate(x, h, 0)
+                ops.hessian_accumulate(x, h, n)
+                hs.append(h)
+            assert torch.equal(hs[0], hs[1]), m
+    finally:
+        ops.hessian_set_method(before)
+    u1, _ = ops.gptq_factor(hs[0], 0.01)
+    u2, _ = ops.gptq_factor(hs[0], 0.01)
+    assert torch.equal(u1, u2)
+    for mode in ("parity", "corrected"):
+        a = ops.gptq_quantize(w, hs[0], "int4", "group", 128, mode=mode)
+        b = ops.gptq_quantize(w, hs[0], "int4", "group", 128, mode=mode)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), mode
