@@ -386,3 +386,28 @@ def test_results_are_deterministic(ops):
         a = ops.gptq_quantize(w, hs[0], "int4", "group", 128, mode=mode)
         b = ops.gptq_quantize(w, hs[0], "int4", "group", 128, mode=mode)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), mode
+
+
+def test_calls_on_side_streams_do_not_interfere(ops):
+    """Every entry point takes the stream it runs on and owns its workspace for the call: two streams working at the
+    same time (a Hessian on one, RTN + calibration on the other) give what they give alone."""
+    import torch
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn((4, 4096, 1024), generator=gen, device="cuda")
+    w = torch.randn((2048, 1536), generator=gen, device="cuda")
+    h_ref = torch.zeros((1024, 1024), device="cuda")
+    ops.hessian_accumulate(x, h_ref, 0)
+    q_ref, s_ref, z_ref = ops.rtn_quantize(w, "uint4", "group", 128, layout="nbits")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    hs, qs = [], []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            h = torch.zeros((1024, 1024), device="cuda")
+            ops.hessian_accumulate(x, h, 0)
+            hs.append(h)
+        with torch.cuda.stream(s2):
+            qs.append(ops.rtn_quantize(w, "uint4", "group", 128, layout="nbits"))
+    torch.cuda.synchronize()
+    assert all(torch.equal(h, h_ref) for h in hs)
+    assert all(torch.equal(q, q_ref) and torch.equal(s, s_ref) and torch.equal(z, z_ref) for q, s, z in qs)
