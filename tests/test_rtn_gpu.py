@@ -353,3 +353,32 @@ def test_elementwise_quantize_dequantize_every_parameter_mode(qtype, r, c, mode,
         wide = torch.zeros((r, c + 8), device="cuda")
         wide[:, :c] = xd
         assert torch.equal(ops.quantize(wide[:, :c], sd, zd, qtype, False, False, mode, group), q)
+
+
+@pytest.mark.gpu
+def test_more_than_2_31_elements():
+    """Indexing is 64-bit wherever a flat offset can pass 2^31: a 32768 x 69632 weight (2.28e9 elements, 9.1 GB) through
+    the blob and the [K, N] kernels; sampled column strips (incl. the last one) against the oracle."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    k, n, g = 32768, 69632, 128
+    assert k * n > 2**31
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    w = torch.empty((k, n), device="cuda")
+    for r0 in range(0, k, 4096):                                    # generated in slabs: no 9 GB temporaries
+        w[r0:r0 + 4096].normal_(generator=gen)
+    blob, s, z = ops.rtn_quantize(w, "uint4", "group", g, layout="nbits")
+    q, s2, z2 = ops.rtn_quantize(w, "uint4", "group", g)
+    assert torch.equal(s, s2) and torch.equal(z, z2)
+    kg = k // g
+    for c0 in (0, 32768, 65536 - 32, n - 32):
+        strip = w[:, c0:c0 + 32].cpu().numpy()
+        eq, es, ez = O.rtn_quantize(strip, "uint4", "group", g)
+        np.testing.assert_array_equal(q[:, c0:c0 + 32].cpu().numpy(), eq)
+        got_s = s.reshape(n, kg)[c0:c0 + 32].cpu().numpy().reshape(-1, 1)
+        got_z = z.reshape(n, kg)[c0:c0 + 32].cpu().numpy().reshape(-1, 1)
+        assert got_s.tobytes() == es.tobytes() and np.array_equal(got_z, ez)
+        eb, _, _ = O.matmul_nbits_layout(eq, es, ez, g, 4)
+        np.testing.assert_array_equal(blob[c0:c0 + 32].cpu().numpy(), eb)
+    del w, blob, q
+    torch.cuda.empty_cache()
