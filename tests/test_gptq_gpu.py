@@ -411,3 +411,19 @@ def test_calls_on_side_streams_do_not_interfere(ops):
     torch.cuda.synchronize()
     assert all(torch.equal(h, h_ref) for h in hs)
     assert all(torch.equal(q, q_ref) and torch.equal(s, s_ref) and torch.equal(z, z_ref) for q, s, z in qs)
+
+
+def test_hessian_of_a_very_wide_input(ops):
+    """K = 16384 (a 1 GiB Hessian, 2080 upper tiles): last-tile strip and diagonal against float64, exact symmetry."""
+    import torch
+    k = 16384
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    x = torch.randn((2, 2048, k), generator=gen, device="cuda")
+    h = torch.zeros((k, k), device="cuda")
+    assert ops.hessian_accumulate(x, h, 0) == 2
+    assert torch.equal(h, h.T)
+    x64 = x.reshape(-1, k).double()
+    strip = x64[:, k - 256:].T @ x64                                 # (2 / n) = 1
+    top = float(strip.abs().max())
+    assert float((h[k - 256:].double() - strip).abs().max()) <= 1e-5 * top
+    assert float((torch.diagonal(h).double() - (x64 * x64).sum(0)).abs().max()) <= 1e-5 * top
