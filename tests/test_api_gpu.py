@@ -335,3 +335,25 @@ def test_gptq_streamed_batches_and_fallback_warning(A, rng, caplog):
         logging.getLogger("onnx_quantize_amd.algorithms.gptq").propagate = True
         A._gptq_quantize(w, x, percdamp=-2.0)          # negative damping -> not positive definite
     assert "Falling back to round-to-nearest" in caplog.text
+
+
+def test_calibration_of_a_tensor_with_more_than_2_31_elements():
+    """minmax.py:40-64 on 2.2e9 activations (8.8 GB): extremes planted at the very first and very last element, one
+    tensor through `collect` and through `collect_many` together with a small one."""
+    import torch
+    from onnx_quantize_amd.calibration import MinMaxCalibrator
+    n = 2**31 + 2**26 + 12345
+    x = torch.empty(n, device="cuda")
+    for i in range(0, n, 2**28):
+        x[i:i + 2**28].uniform_(-1.0, 1.0)
+    x[0], x[-1], x[2**31 + 7] = -7.25, 9.5, 3.0
+    cal = MinMaxCalibrator()
+    cal.collect("big", x)
+    assert cal.data["big"].min_val == np.float32(-7.25) and cal.data["big"].max_val == np.float32(9.5)
+    small = torch.linspace(-2, 11, 1000, device="cuda")
+    many = MinMaxCalibrator()
+    many.collect_many({"big": x, "small": small})
+    assert many.data["big"].min_val == np.float32(-7.25) and many.data["big"].max_val == np.float32(9.5)
+    assert many.data["small"].min_val == np.float32(-2) and many.data["small"].max_val == np.float32(11)
+    del x
+    torch.cuda.empty_cache()
