@@ -447,6 +447,175 @@ def gen_hqq(out):
     print(f"hqq: {len(cases)} cases")
 
 
+def _load_passes():
+    """The AWQ / SmoothQuant passes (pre_passes/awq.py, smooth_quant.py) are methods on graph nodes.  Their arithmetic is
+    run UNMODIFIED; what the image lacks (onnx_ir's graph objects) is replaced by the barest carriers: a tensor that
+    returns its array, a value that has a name and a constant, a node / model made of namespaces.  The two methods that
+    only edit the graph (`is_valid_node`, `_insert_mul_node_before`) are overridden to accept the node and to record
+    the scale the pass computed."""
+    ir = sys.modules["onnx_ir"]
+
+    class Tensor:
+        def __init__(self, a):
+            self._a = np.asarray(a)
+
+        def numpy(self):
+            return self._a
+
+    class Value:
+        def __init__(self, name, const_value=None):
+            self.name, self.const_value = name, const_value
+
+    ir.passes = types.SimpleNamespace(InPlacePass=object, PassResult=lambda model, modified: (model, modified))
+    ir.tensor = Tensor
+    ir.val = lambda name, const_value=None: Value(name, const_value)
+    ir.convenience = types.SimpleNamespace(get_const_tensor=lambda v: v.const_value, replace_all_uses_with=lambda a, b: None)
+    pre = types.ModuleType("onnx_quantize.pre_passes")
+    pre.__path__ = [os.path.join(REF, "pre_passes")]
+    sys.modules["onnx_quantize.pre_passes"] = pre
+    awq = importlib.import_module("onnx_quantize.pre_passes.awq")
+    sq = importlib.import_module("onnx_quantize.pre_passes.smooth_quant")
+
+    def node_and_model(x, w, qconfig):
+        node = types.SimpleNamespace(op_type="MatMul", domain="", attributes={}, meta={"qconfig": qconfig.model_dump(), "input": x.copy()},
+                                     inputs=[Value("x"), Value("w", Tensor(w.copy()))], outputs=[Value("y")])
+        model = types.SimpleNamespace(graph=types.SimpleNamespace(initializers={}))
+        return node, model
+
+    class Awq(awq.AwqPass):
+        def is_valid_node(self, node):
+            return True
+
+        def _insert_mul_node_before(self, node, model, scale_initializer):
+            self.recorded = scale_initializer.const_value.numpy()
+
+    class Sq(sq.SmoothQuantPass):
+        def _insert_mul_node_before(self, node, model, scale_initializer):
+            self.recorded = scale_initializer.const_value.numpy()
+
+    return types.SimpleNamespace(awq=awq, sq=sq, Awq=Awq, Sq=Sq, node_and_model=node_and_model)
+
+
+def gen_awq(out):
+    """pre_passes/awq.py::_apply_awq / _apply_awq_clip and smooth_quant.py::_smooth_quant_node on small layers."""
+    P = _load_passes()
+    Q = R.qconfig
+    cases, arrays = [], {}
+    grid = [
+        # (seed, t, k, n, qtype, strategy, group, symmetric)
+        (1, 48, 64, 40, "uint4", "group", 16, False),
+        (2, 48, 64, 40, "uint4", "group", 32, True),
+        (3, 40, 32, 24, "int8", "channel", None, False),
+        (4, 40, 32, 24, "uint8", "tensor", None, False),
+        (5, 64, 128, 16, "int4", "group", 64, False),
+        (6, 30, 48, 20, "int8", "channel", None, True),
+    ]
+    for idx, (seed, t, k, n, qtype, strategy, g, sym) in enumerate(grid):
+        rng = np.random.default_rng(seed)
+        x = (rng.standard_normal((t, k)) * rng.uniform(0.2, 4.0, size=k)).astype(np.float32)
+        w = (rng.standard_normal((k, n)) * 0.1).astype(np.float32)
+        wargs = Q.QWeightArgs(dtype=QT[qtype], symmetric=sym, group_size=g, strategy=strategy)
+        qcfg = Q.QConfig(weights=wargs, preprocessors=[P.awq.AwqConfig(clip_search=True)])
+        key = f"c{idx}"
+        node, model = P.node_and_model(x, w, qcfg)
+        pas = P.Awq(clip_search=True, target_op_types={"MatMul"})
+        assert pas._apply_awq(node, model)
+        arrays[key + "_x"], arrays[key + "_w"] = x, w
+        arrays[key + "_awq_inv_scale"] = np.asarray(pas.recorded)                       # 1 / best_scale, as emitted
+        arrays[key + "_awq_w"] = model.graph.initializers["w"].const_value.numpy()      # W * best_scale
+        arrays[key + "_awq_x"] = node.meta["input"]                                     # X / best_scale
+        node2, _ = P.node_and_model(x, w, qcfg)
+        assert pas._apply_awq_clip(node2)
+        clip = float(node2.meta["qconfig"]["weights"]["clip_ratio"])
+        for alpha in (0.5, 0.8):
+            qs = Q.QConfig(weights=wargs, preprocessors=[P.sq.SmoothQuantConfig(alpha=alpha)])
+            node3, model3 = P.node_and_model(x, w, qs)
+            sp = P.Sq(alpha=alpha, target_op_types={"MatMul"})
+            assert sp._smooth_quant_node(node3, model3)
+            arrays[key + f"_sq{int(alpha * 10)}_inv_scale"] = np.asarray(sp.recorded)
+            arrays[key + f"_sq{int(alpha * 10)}_w"] = model3.graph.initializers["w"].const_value.numpy()
+        cases.append(dict(key=key, seed=seed, t=t, k=k, n=n, qtype=qtype, strategy=strategy, group_size=g, symmetric=sym, clip_ratio=clip))
+    np.savez_compressed(os.path.join(out, "awq.npz"), **arrays)
+    with open(os.path.join(out, "awq.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=1)
+    print(f"awq / smooth_quant: {len(cases)} cases")
+
+
+def gen_calibrate(out):
+    """core/_calibration/calibrate.py::calibrate_model -- the ORDER in which the activation list is walked (one calibrator,
+    the input kind first, every tapped name collected in both walks) -- with only the onnxruntime session replaced:
+    `_collect_activations` returns a prepared list of per-batch dicts.  `ml_dtypes` (one entry of a dtype table) and the
+    graph objects are the barest stand-ins, as in `_load_passes`."""
+    _load_passes()                                     # installs the graph-object carriers on the onnx_ir stand-in
+    ir = sys.modules["onnx_ir"]
+    ir.Model = ir.Node = ir.Value = object             # names in (evaluated) annotations only
+    sys.modules.setdefault("ml_dtypes", types.SimpleNamespace(bfloat16=np.float16))
+    cal = importlib.import_module("onnx_quantize.core._calibration.calibrate")
+    base = importlib.import_module("onnx_quantize.core._calibration.base")
+    Q = R.qconfig
+
+    class Node:                                        # hashable (get_target_nodes builds a set)
+        def __init__(self, name, x, y):
+            self.op_type, self.name, self.meta = "MatMul", name, {}
+            self.inputs = [ir.val(x), ir.val(name + "_w", ir.tensor(np.zeros((2, 2), np.float32)))]
+            self.outputs = [ir.val(y)]
+
+    def chain():
+        nodes = [Node("fc1", "X", "h1"), Node("fc2", "h1", "h2"), Node("fc3", "h2", "Y")]
+        return types.SimpleNamespace(graph=nodes), nodes
+
+    cases, arrays = [], {}
+    grid = [(0.0, "input"), (0.0, "output"), (0.0, "both"), (0.9, "input"), (0.9, "both"), (0.5, "both"), (0.3, "output")]
+    for idx, (momentum, kinds) in enumerate(grid):
+        rng = np.random.default_rng(100 + idx)
+        names = ["X", "h1", "h2"] if kinds == "input" else ["h1", "h2", "Y"] if kinds == "output" else ["X", "h1", "h2", "Y"]
+        acts = [{n: (rng.standard_normal((4, 6)) * (b + 1) * (1 + names.index(n))).astype(np.float32) for n in names} for b in range(5)]
+        model, nodes = chain()
+        qc = Q.QConfig(
+            weights=Q.QWeightArgs(dtype=QT["uint8"]),
+            input_activations=Q.QActivationArgs(dtype=QT["uint8"], is_static=True) if kinds != "output" else None,
+            output_activations=Q.QActivationArgs(dtype=QT["int8"], symmetric=True, is_static=True) if kinds != "input" else None,
+            calibration_params=base.CalibrationParams(momentum=momentum, num_samples=20, batch_size=4))
+        cal._collect_activations = lambda *a, _acts=acts, **k: _acts          # the ONLY replaced step: no onnxruntime here
+        cal.calibrate_model(model, qc)
+        key = f"c{idx}"
+        for b, act in enumerate(acts):
+            for n, a in act.items():
+                arrays[f"{key}_b{b}_{n}"] = a
+        got = {}
+        for node in nodes:
+            for kind in ("input", "output"):
+                if f"{kind}_scale" in node.meta:
+                    nm = node.inputs[0].name if kind == "input" else node.outputs[0].name
+                    arrays[f"{key}_{kind}_{nm}_scale"] = np.asarray(node.meta[f"{kind}_scale"])
+                    arrays[f"{key}_{kind}_{nm}_zp"] = np.asarray(node.meta[f"{kind}_zero_point"])
+                    got.setdefault(kind, []).append(nm)
+        cases.append(dict(key=key, momentum=momentum, kinds=kinds, names=names, batches=len(acts), set=got))
+    # the GPTQ branch: inputs of every node concatenated over the batches (calibrate.py:288-307)
+    model, nodes = chain()
+    rng = np.random.default_rng(7)
+    acts = [{n: rng.standard_normal((3, 5, 8)).astype(np.float32) for n in ("X", "h1", "h2")} for _ in range(4)]
+    qc = Q.QConfig(weights=Q.QWeightArgs(dtype=QT["uint8"], algorithm=R.gptq.GPTQConfig()))
+    cal._collect_activations = lambda *a, **k: acts
+    cal.calibrate_model(model, qc)
+    for b, act in enumerate(acts):
+        for n, a in act.items():
+            arrays[f"gptq_b{b}_{n}"] = a
+    for node in nodes:
+        arrays[f"gptq_input_{node.inputs[0].name}"] = node.meta["input"]
+    # batching rule (calibrate.py:150-172)
+    data = np.arange(10 * 3, dtype=np.float32).reshape(10, 3)
+    prep = []
+    for bs, ns in ((2, 10), (5, 10), (10, 10), (20, 10), (3, 10), (4, 100), (4, 7)):
+        o = cal._prepare_calibration_data(data, bs, ns)
+        arrays[f"prep_{bs}_{ns}"] = np.asarray(o)
+        prep.append([bs, ns])
+    np.savez_compressed(os.path.join(out, "calibrate.npz"), **arrays)
+    with open(os.path.join(out, "calibrate.json"), "w") as f:
+        json.dump({"cases": cases, "gptq_batches": 4, "prepare": prep}, f, indent=1)
+    print(f"calibrate: {len(cases)} walk-order cases + the GPTQ branch + {len(prep)} batching cases")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -491,7 +660,7 @@ def gen_digests(out):
 def main():
     out = HERE
     gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
-                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, digests=gen_digests)
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, digests=gen_digests)
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],

@@ -26,6 +26,37 @@ def test_prepare_calibration_data_batches_like_the_reference(total, batch, num, 
     np.testing.assert_array_equal(t.numpy(), exp)
 
 
+def test_oracle_walk_order_equals_the_reference_calibrate_model():
+    """tests/golden/calibrate.*: the reference's own `calibrate_model` (calibrate.py:310-385) run on prepared activation
+    lists (make_golden.py::gen_calibrate replaces only the onnxruntime session).  The oracle's `calibrate_flow` gives the
+    same (scale, zero point) for every node and kind -- including the cases where input AND output kinds are calibrated
+    with momentum > 0, i.e. the output ranges are an EMA over the batch sequence seen twice -- bit for bit; `gptq_inputs`
+    and `prepare_calibration_data` likewise."""
+    from conftest import load_json, load_npz
+    G, meta = load_npz("calibrate.npz"), load_json("calibrate.json")
+    assert len(meta["cases"]) == 7
+    chain_in, chain_out = ["X", "h1", "h2"], ["h1", "h2", "Y"]
+    for c in meta["cases"]:
+        key = c["key"]
+        acts = [{n: G[f"{key}_b{b}_{n}"] for n in c["names"]} for b in range(c["batches"])]
+        in_names = chain_in if c["kinds"] != "output" else []
+        out_names = chain_out if c["kinds"] != "input" else []
+        res = O.calibrate_flow(acts, in_names, out_names, c["momentum"], ("uint8", False, False) if in_names else None,
+                               ("int8", True, False) if out_names else None)
+        assert {k: sorted(v) for k, v in c["set"].items()} == {kind: sorted(n for (kd, n) in res if kd == kind) for kind in c["set"]}
+        for (kind, name), (scale, zp) in res.items():
+            assert np.asarray(scale).tobytes() == G[f"{key}_{kind}_{name}_scale"].tobytes(), (key, kind, name)
+            assert int(zp) == int(G[f"{key}_{kind}_{name}_zp"]) and np.asarray(zp).dtype == G[f"{key}_{kind}_{name}_zp"].dtype
+    acts = [{n: G[f"gptq_b{b}_{n}"] for n in chain_in} for b in range(meta["gptq_batches"])]
+    whole = O.gptq_inputs(acts)
+    for n in chain_in:
+        np.testing.assert_array_equal(whole[n], G[f"gptq_input_{n}"])
+    data = np.arange(10 * 3, dtype=np.float32).reshape(10, 3)
+    for bs, ns in meta["prepare"]:
+        np.testing.assert_array_equal(O.prepare_calibration_data(data, bs, ns), G[f"prep_{bs}_{ns}"])
+        np.testing.assert_array_equal(D.prepare_calibration_data(data, bs, ns), G[f"prep_{bs}_{ns}"])
+
+
 def test_random_calibration_data_matches_the_reference_recipe():
     """calibrate.py:127-147: default_rng(0), symbolic dims -> 1, ints in [0, 100), one generator for all inputs."""
     one = D.generate_random_calibration_data(12, [("X", ("N", 32), np.float32)])

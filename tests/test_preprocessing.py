@@ -1,8 +1,8 @@
 """AWQ / SmoothQuant numeric cores (reference pre_passes/awq.py, smooth_quant.py).
 
-PARITY UNPINNED for these two passes: their modules import onnx_ir.passes / onnxscript, which the build container
-does not have, so no golden vectors could be produced by the reference itself; the oracle restates the source as
-read, on top of the (pinned) RTN / dequantize functions, and the GPU composition is checked against that oracle.
+The oracle's restatements are pinned by tests/golden/awq.* -- the reference's own `_apply_awq`, `_apply_awq_clip` and
+`_smooth_quant_node` run on six small layers (make_golden.py::gen_awq) -- and the GPU composition is checked against
+that oracle.
 Tolerances: reductions run in a different order on the device, so the search scale differs by a few ulp, an RTN
 integer may flip, and the 20 / 10 losses agree to 2e-3 relative; the chosen grid point must be the oracle's or one
 whose oracle loss is within that tolerance of the oracle's minimum."""
@@ -22,6 +22,30 @@ def test_configs_mirror_the_reference():
     assert isinstance(q.preprocessors[0], AwqConfig) and q.preprocessors[0].clip_search
     with pytest.raises(ImportError, match="delegated to the reference package"):
         a.build_pass(q)
+
+
+def test_oracle_reproduces_what_the_reference_passes_computed():
+    """tests/golden/awq.*: `_apply_awq`, `_apply_awq_clip` (pre_passes/awq.py:114-259) and `_smooth_quant_node`
+    (smooth_quant.py:91-129) run unmodified on small layers (make_golden.py::gen_awq); the oracle's restatements give the
+    same chosen scale (as the emitted Mul constant 1 / scale), the same rescaled weights and activations, the same clip
+    ratio -- bit for bit."""
+    from conftest import load_json, load_npz
+    G, cases = load_npz("awq.npz"), load_json("awq.json")["cases"]
+    assert len(cases) == 6
+    for c in cases:
+        key, g = c["key"], c["group_size"]
+        x, w = G[key + "_x"], G[key + "_w"]
+        best, losses = O.awq_scale_search(x, w, c["qtype"], c["strategy"], g, c["symmetric"])
+        assert best.dtype == np.float32 and len(losses) == 20
+        np.testing.assert_array_equal(1.0 / best, G[key + "_awq_inv_scale"])
+        np.testing.assert_array_equal(w * best.reshape(-1, 1), G[key + "_awq_w"])
+        np.testing.assert_array_equal(x / best.reshape(1, -1), G[key + "_awq_x"])
+        ratio, _ = O.awq_clip_search(x, w, c["qtype"], c["strategy"], g, c["symmetric"])
+        assert ratio == c["clip_ratio"]
+        for alpha in (0.5, 0.8):
+            sc = O.smooth_quant_scale(x, w, alpha)
+            np.testing.assert_array_equal(1.0 / sc, G[key + f"_sq{int(alpha * 10)}_inv_scale"])
+            np.testing.assert_array_equal(np.multiply(sc.reshape(-1, 1), w), G[key + f"_sq{int(alpha * 10)}_w"])
 
 
 def test_oracle_search_properties(rng):
