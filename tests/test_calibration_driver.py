@@ -199,3 +199,46 @@ def test_streamed_hessian_and_gptq_equal_the_concatenated_flow():
         assert (q.cpu().numpy() != eq).mean() <= 1e-3 and (z.cpu().numpy() != ez).mean() <= 1e-3
     with pytest.raises(KeyError, match="no Hessian accumulated"):
         D.quantize_weights_gptq({"x": (layers["fc2"][0], "nope")}, stream.hessians, "int4", "group", 32)
+
+
+@pytest.mark.gpu
+def test_stream_reproduces_the_reference_calibrate_model_outputs():
+    """The streamed driver against what the reference's `calibrate_model` itself wrote into node.meta
+    (tests/golden/calibrate.*): running min / max cases bit for bit, EMA cases (incl. both kinds = two walks) to 1e-6."""
+    import torch
+    from conftest import load_json, load_npz
+    from onnx_quantize_amd.calibration import MinMaxCalibrator
+    G, meta = load_npz("calibrate.npz"), load_json("calibrate.json")
+    chain_in, chain_out = ["X", "h1", "h2"], ["h1", "h2", "Y"]
+    in_args = QActivationArgs(dtype=QuantType.QUInt8, is_static=True)
+    out_args = QActivationArgs(dtype=QuantType.QInt8, symmetric=True, is_static=True)
+    for c in meta["cases"]:
+        key = c["key"]
+        in_names = chain_in if c["kinds"] != "output" else []
+        out_names = chain_out if c["kinds"] != "input" else []
+        stream = D.ActivationStream(calibrator=MinMaxCalibrator(c["momentum"]), input_names=in_names, output_names=out_names)
+        for b in range(c["batches"]):
+            stream.feed({n: torch.from_numpy(G[f"{key}_b{b}_{n}"]).cuda() for n in c["names"]})
+        got = {}
+        if in_names:
+            got.update({("input", n): v for n, v in stream.input_qparams(in_args).items()})
+        if out_names:
+            got.update({("output", n): v for n, v in stream.output_qparams(out_args).items()})
+        assert len(got) == len(in_names) + len(out_names)
+        for (kind, name), (s, z) in got.items():
+            es, ez = G[f"{key}_{kind}_{name}_scale"], G[f"{key}_{kind}_{name}_zp"]
+            if c["momentum"] == 0.0:
+                assert s.tobytes() == es.tobytes() and int(z) == int(ez), (key, kind, name)
+            else:
+                np.testing.assert_allclose(s, es, rtol=1e-6)
+                assert abs(int(z) - int(ez)) <= 1
+            assert z.dtype == ez.dtype
+    # the GPTQ branch: streamed Hessians of the concatenated inputs the reference stored
+    stream = D.ActivationStream(hessian_names=chain_in)
+    for b in range(meta["gptq_batches"]):
+        stream.feed({n: torch.from_numpy(G[f"gptq_b{b}_{n}"]).cuda() for n in chain_in})
+    for n in chain_in:
+        whole = G[f"gptq_input_{n}"]
+        h, cnt = O.accumulate_hessian(whole, np.zeros((8, 8), np.float32), 0)
+        assert stream.hessians[n].n == cnt == whole.shape[0]
+        np.testing.assert_allclose(stream.hessians[n].h.cpu().numpy(), h, rtol=2e-4, atol=2e-5 * np.abs(h).max())
