@@ -92,3 +92,29 @@ def test_gpu_smooth_quant_scale_matches_oracle():
     x[..., 7] = 0.0                                   # a dead activation channel: clamped to 1e-5 (smooth_quant.py:66-67)
     for alpha in (0.5, 0.25, 1.0):
         np.testing.assert_allclose(smooth_quant_scale(x, w, alpha), O.smooth_quant_scale(x, w, alpha), rtol=2e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_searches_against_the_reference_passes_outputs():
+    """The GPU searches on the six golden layers (tests/golden/awq.*): the SmoothQuant scale to 1e-6; the AWQ scale
+    equals the one the reference's `_apply_awq` emitted whenever the same grid point wins, and the winning grid point is
+    the reference's or one whose (oracle) loss is within 2e-3 of it; the clip ratio likewise."""
+    from conftest import load_json, load_npz
+    from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search, smooth_quant_scale
+    G, cases = load_npz("awq.npz"), load_json("awq.json")["cases"]
+    for c in cases:
+        key, g = c["key"], c["group_size"]
+        x, w = G[key + "_x"], G[key + "_w"]
+        qt = QuantType.from_string(c["qtype"])
+        s, losses = awq_scale_search(x, w, qt, c["strategy"], g, c["symmetric"])
+        _, el = O.awq_scale_search(x, w, c["qtype"], c["strategy"], g, c["symmetric"])
+        assert el[int(np.argmin(losses))] <= el.min() * (1 + 2e-3)
+        if int(np.argmin(losses)) == int(np.argmin(el)):
+            np.testing.assert_allclose(1.0 / s, G[key + "_awq_inv_scale"], rtol=2e-5)
+        r, cl = awq_clip_search(x, w, qt, c["strategy"], g, c["symmetric"])
+        _, ecl = O.awq_clip_search(x, w, c["qtype"], c["strategy"], g, c["symmetric"])
+        assert ecl[int(round((1 - r) * 100))] <= ecl.min() * (1 + 2e-3)
+        if int(np.argmin(cl)) == int(np.argmin(ecl)):
+            assert r == c["clip_ratio"]
+        for alpha in (0.5, 0.8):
+            np.testing.assert_allclose(1.0 / smooth_quant_scale(x, w, alpha), G[key + f"_sq{int(alpha * 10)}_inv_scale"], rtol=2e-6)
