@@ -616,6 +616,44 @@ def gen_calibrate(out):
     print(f"calibrate: {len(cases)} walk-order cases + the GPTQ branch + {len(prep)} batching cases")
 
 
+def gen_nbits(out):
+    """qrules/_common.py::_prepare_for_matmul_nbits (the MatMulNBits wire format: B blob, scales, packed zero points) on
+    what `_rtn_quantize` / `_hqq_quantize` return, for the uint4 / uint8 group cases MatMulNBits accepts."""
+    _load_passes()
+    ir = sys.modules["onnx_ir"]
+    ir.Model = ir.Node = ir.Value = object
+    ir.tape = types.SimpleNamespace(Tape=object)
+    qr = types.ModuleType("onnx_quantize.qrules")      # bypass qrules/__init__.py (it pulls in onnxscript)
+    qr.__path__ = [os.path.join(REF, "qrules")]
+    sys.modules["onnx_quantize.qrules"] = qr
+    common = importlib.import_module("onnx_quantize.qrules._common")
+    Q = R.qconfig
+    cases, arrays = [], {}
+    grid = [  # (seed, k, n, qtype, g, hqq)
+        (1, 64, 12, "uint4", 16, False), (2, 80, 9, "uint4", 16, False), (3, 128, 7, "uint4", 32, False), (4, 128, 10, "uint4", 128, False),
+        (5, 96, 5, "uint8", 32, False), (6, 64, 6, "uint8", 64, False), (7, 96, 8, "uint4", 32, True), (8, 48, 4, "uint4", 16, True),
+    ]
+    for idx, (seed, k, n, qtype, g, hqq) in enumerate(grid):
+        w = weight("normal", seed, k, n)
+        if hqq:
+            wargs = Q.QWeightArgs(dtype=QT[qtype], group_size=g, strategy="group", algorithm=R.hqq.HqqConfig())
+            q, sc, zp = R.hqq._hqq_quantize(w, QT[qtype], g)
+        else:
+            wargs = Q.QWeightArgs(dtype=QT[qtype], group_size=g, strategy="group")
+            q, sc, zp = rtn_call(w, qtype, "group", g, False, False, 1.0, False)
+        qc = Q.QConfig(weights=wargs)
+        assert common.is_matmul_nbits_compatible(qc)
+        b, s2, pz = common._prepare_for_matmul_nbits(np.asarray(q).astype(np.uint8), np.asarray(sc), np.asarray(zp), qc)
+        key = f"c{idx}"
+        arrays[key + "_q"], arrays[key + "_s"], arrays[key + "_z"] = np.asarray(q).astype(np.uint8), np.asarray(sc), np.asarray(zp)
+        arrays[key + "_blob"], arrays[key + "_scale"], arrays[key + "_zp"] = np.asarray(b), np.asarray(s2), np.asarray(pz)
+        cases.append(dict(key=key, seed=seed, k=k, n=n, qtype=qtype, group_size=g, float_zero_points=hqq))
+    np.savez_compressed(os.path.join(out, "nbits.npz"), **arrays)
+    with open(os.path.join(out, "nbits.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=1)
+    print(f"nbits: {len(cases)} cases")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -660,7 +698,7 @@ def gen_digests(out):
 def main():
     out = HERE
     gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
-                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, digests=gen_digests)
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, digests=gen_digests)
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],

@@ -240,3 +240,20 @@ def test_config2_digest(key):
     assert s[0].tobytes().hex() == d["scale0_hex"]
     assert z[:4, 0].tolist() == d["zp_head"] and q[:4, 0].tolist() == d["q_head"]
     assert s.shape == (d["n"] * d["k"] // 128, 1)
+
+
+def test_matmul_nbits_layout_vs_the_reference_function():
+    """tests/golden/nbits.*: `_prepare_for_matmul_nbits` (qrules/_common.py:65-123) itself on RTN / HQQ results -- B blob,
+    [N, K/g] scales, packed (or float, for HQQ) zero points -- reproduced byte for byte."""
+    G, cases = load_npz("nbits.npz"), load_json("nbits.json")["cases"]
+    assert len(cases) == 8
+    for c in cases:
+        key = c["key"]
+        bits = 4 if c["qtype"] == "uint4" else 8
+        b, s, z = O.matmul_nbits_layout(G[key + "_q"], G[key + "_s"], G[key + "_z"], c["group_size"], bits,
+                                        zp_is_float=c["float_zero_points"])
+        assert b.dtype == G[key + "_blob"].dtype and b.shape == G[key + "_blob"].shape
+        np.testing.assert_array_equal(b, G[key + "_blob"])
+        assert s.shape == G[key + "_scale"].shape and s.tobytes() == G[key + "_scale"].tobytes()
+        assert z.dtype == G[key + "_zp"].dtype and z.shape == G[key + "_zp"].shape
+        np.testing.assert_array_equal(z, G[key + "_zp"])

@@ -382,3 +382,35 @@ def test_more_than_2_31_elements():
         np.testing.assert_array_equal(blob[c0:c0 + 32].cpu().numpy(), eb)
     del w, blob, q
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_kernel_emitted_wire_format_equals_the_reference_function_output():
+    """tests/golden/nbits.*: what `_prepare_for_matmul_nbits` (qrules/_common.py:65-123) made of the reference's own RTN /
+    HQQ results, against what the kernels write directly (layout="nbits") + the zero-point packing kernel."""
+    import torch
+    from conftest import load_json, load_npz, synth_weight
+    from onnx_quantize_amd.hip import ops
+    G, cases = load_npz("nbits.npz"), load_json("nbits.json")["cases"]
+    for c in cases:
+        key, g, k, n = c["key"], c["group_size"], c["k"], c["n"]
+        w = torch.from_numpy(synth_weight("normal", c["seed"], k, n)).cuda()
+        blocks = k // g
+        if c["float_zero_points"]:
+            blob, s, z, _ = ops.hqq_quantize(w, g, layout="nbits")
+            # HQQ parity is tolerance-based (DESIGN.md 4.7): compare through the unpacked integers
+            eb = G[key + "_blob"]
+            lo, hi = (blob.cpu().numpy() & 15).astype(np.int32), (blob.cpu().numpy() >> 4).astype(np.int32)
+            elo, ehi = (eb & 15).astype(np.int32), (eb >> 4).astype(np.int32)
+            assert blob.shape == eb.shape and max(np.abs(lo - elo).max(), np.abs(hi - ehi).max()) <= 1
+            assert (np.count_nonzero(lo != elo) + np.count_nonzero(hi != ehi)) <= 2e-3 * 2 * eb.size
+            np.testing.assert_allclose(z.reshape(n, blocks).cpu().numpy(), G[key + "_zp"], atol=2e-5)
+            assert s.reshape(n, blocks).cpu().numpy().tobytes() == G[key + "_scale"].tobytes()
+            continue
+        blob, s, z = ops.rtn_quantize(w, c["qtype"], "group", g, layout="nbits")
+        np.testing.assert_array_equal(blob.cpu().numpy(), G[key + "_blob"])
+        assert s.reshape(n, blocks).cpu().numpy().tobytes() == G[key + "_scale"].tobytes()
+        if c["qtype"] == "uint4" and blocks > 1:
+            np.testing.assert_array_equal(ops.pack_zero_points_u4(z, n, blocks).cpu().numpy(), G[key + "_zp"])
+        else:
+            np.testing.assert_array_equal(z.reshape(n, -1).cpu().numpy(), G[key + "_zp"])
