@@ -654,6 +654,72 @@ def gen_nbits(out):
     print(f"nbits: {len(cases)} cases")
 
 
+def _describe(obj, fields):
+    d = {}
+    for f in fields:
+        v = getattr(obj, f)
+        if hasattr(v, "algorithm_type"):
+            v = v.algorithm_type
+        elif isinstance(v, enum.Enum):
+            v = v.name if f == "dtype" else v.value
+        elif isinstance(v, np.dtype):
+            v = v.name
+        d[f] = v
+    return d
+
+
+def _attempt(fn, fields):
+    try:
+        return dict(ok=True, fields=_describe(fn(), fields))
+    except Exception as e:  # noqa: BLE001 -- the class of what the reference raises IS the datum
+        return dict(ok=False, error=type(e).__name__)
+
+
+def gen_config(out):
+    """core/_qconfig.py: what QWeightArgs / QActivationArgs / QConfig accept, infer and reject, over a grid of arguments
+    (the resolved fields, or the class of the exception)."""
+    _load_passes()
+    Q = R.qconfig
+    algos = {"rtn": lambda: None, "gptq": lambda: R.gptq.GPTQConfig(), "hqq": lambda: R.hqq.HqqConfig()}
+    wf = ["dtype", "symmetric", "group_size", "strategy", "scale_dtype", "zp_dtype", "reduce_range", "clip_ratio", "mse", "algorithm"]
+    af = ["dtype", "symmetric", "group_size", "strategy", "scale_dtype", "zp_dtype", "reduce_range", "is_static"]
+    weights, acts, confs = [], [], []
+    for dt, sym, gs, st, red, al in itertools.product(list(QT), (False, True), (None, -1, 0, 16, 64), (None, "tensor", "channel", "group"),
+                                                      (False, True), list(algos)):
+        kw = dict(dtype=dt, symmetric=sym, group_size=gs, strategy=st, reduce_range=red)
+        def make(kw=kw, al=al):
+            a = algos[al]()
+            return Q.QWeightArgs(**{**kw, "dtype": QT[kw["dtype"]]}, **({} if a is None else {"algorithm": a}))
+        weights.append(dict(kw=kw, algorithm=al, **_attempt(make, wf)))
+    for extra in (dict(clip_ratio=0.5), dict(clip_ratio=0.0), dict(clip_ratio=1.5), dict(clip_ratio=1.0, mse=True), dict(group_size=-2),
+                  dict(scale_dtype="float16"), dict(scale_dtype="float32"), dict(dtype="uint4", group_size=32), dict(dtype="QInt4"), dict(strategy="GROUP", group_size=8)):
+        weights.append(dict(kw=extra, algorithm="rtn", **_attempt(lambda e=extra: Q.QWeightArgs(**e), wf)))
+    for dt, sym, static, st, gs in itertools.product(list(QT), (False, True), (False, True), (None, "tensor", "channel", "group"), (None, -1, 32)):
+        kw = dict(dtype=dt, symmetric=sym, is_static=static, strategy=st, group_size=gs)
+        acts.append(dict(kw=kw, **_attempt(lambda kw=kw: Q.QActivationArgs(**{**kw, "dtype": QT[kw["dtype"]]}), af)))
+    wopts = {"none": None, "w8": dict(dtype="uint8"), "w8c": dict(dtype="int8", group_size=-1), "w4g": dict(dtype="uint4", group_size=32),
+             "w8g": dict(dtype="uint8", group_size=32), "w4t": dict(dtype="int4")}
+    aopts = {"none": None, "static_u8": dict(dtype="uint8", is_static=True), "dynamic_u8": dict(dtype="uint8", is_static=False),
+             "static_i8": dict(dtype="int8", is_static=True, symmetric=True)}
+    for wk, ik, ok, fmt in itertools.product(wopts, aopts, aopts, (None, "qdq", "qlinear")):
+        def make(wk=wk, ik=ik, ok=ok, fmt=fmt):
+            kw = {}
+            if wopts[wk] is not None:
+                kw["weights"] = Q.QWeightArgs(**wopts[wk])
+            if aopts[ik] is not None:
+                kw["input_activations"] = Q.QActivationArgs(**aopts[ik])
+            if aopts[ok] is not None:
+                kw["output_activations"] = Q.QActivationArgs(**aopts[ok])
+            if fmt is not None:
+                kw["format"] = fmt
+            return Q.QConfig(**kw)
+        confs.append(dict(weights=wk, inputs=ik, outputs=ok, format=fmt, **_attempt(make, ["format"])))
+    with open(os.path.join(out, "config.json"), "w") as f:
+        json.dump(dict(weight_options=wopts, activation_options=aopts, weights=weights, activations=acts, configs=confs), f)
+    print(f"config: {len(weights)} QWeightArgs, {len(acts)} QActivationArgs, {len(confs)} QConfig combinations "
+          f"({sum(not w['ok'] for w in weights)} / {sum(not a['ok'] for a in acts)} / {sum(not c['ok'] for c in confs)} rejected)")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -698,7 +764,7 @@ def gen_digests(out):
 def main():
     out = HERE
     gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
-                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, digests=gen_digests)
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, digests=gen_digests)
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],

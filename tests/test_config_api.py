@@ -288,3 +288,74 @@ def test_logging_entry_point():
     oq.set_log_level("debug")
     assert logging.getLogger("onnx_quantize").level == logging.DEBUG
     oq.set_log_level(logging.INFO)
+
+
+def _describe(obj, fields):
+    import enum
+    d = {}
+    for f in fields:
+        v = getattr(obj, f)
+        if hasattr(v, "algorithm_type"):
+            v = v.algorithm_type
+        elif isinstance(v, enum.Enum):
+            v = v.name if f == "dtype" else v.value
+        elif isinstance(v, np.dtype):
+            v = v.name
+        d[f] = v
+    return d
+
+
+def _attempt(fn, fields):
+    try:
+        return dict(ok=True, fields=_describe(fn(), fields))
+    except Exception as e:  # noqa: BLE001
+        return dict(ok=False, error=type(e).__name__)
+
+
+def test_argument_grid_behaves_like_the_reference_classes():
+    """tests/golden/config.json: 1450 QWeightArgs, 288 QActivationArgs and 288 QConfig argument combinations through the
+    reference's own pydantic models (make_golden.py::gen_config): this package's mirrors accept, infer (strategy, zero-point
+    dtype, ...) and reject (same exception class) exactly the same."""
+    from conftest import load_json
+    from onnx_quantize_amd import GPTQConfig, HqqConfig, QActivationArgs, QConfig, QWeightArgs
+    G = load_json("config.json")
+    QT = {"int4": QuantType.QInt4, "uint4": QuantType.QUInt4, "int8": QuantType.QInt8, "uint8": QuantType.QUInt8,
+          "int32": QuantType.QInt32, "uint32": QuantType.QUInt32}
+    algos = {"rtn": lambda: None, "gptq": GPTQConfig, "hqq": HqqConfig}
+    wf = ["dtype", "symmetric", "group_size", "strategy", "scale_dtype", "zp_dtype", "reduce_range", "clip_ratio", "mse", "algorithm"]
+    af = ["dtype", "symmetric", "group_size", "strategy", "scale_dtype", "zp_dtype", "reduce_range", "is_static"]
+    bad = []
+    for c in G["weights"]:
+        def make(c=c):
+            kw = dict(c["kw"])
+            if kw.get("dtype") in QT:
+                kw["dtype"] = QT[kw["dtype"]]
+            a = algos[c["algorithm"]]()
+            return QWeightArgs(**kw, **({} if a is None else {"algorithm": a}))
+        got = _attempt(make, wf)
+        exp = {k: c[k] for k in ("ok", "fields", "error") if k in c}
+        if got != exp:
+            bad.append(("weights", c["kw"], c["algorithm"], exp, got))
+    for c in G["activations"]:
+        got = _attempt(lambda c=c: QActivationArgs(**{**c["kw"], "dtype": QT[c["kw"]["dtype"]]}), af)
+        exp = {k: c[k] for k in ("ok", "fields", "error") if k in c}
+        if got != exp:
+            bad.append(("activations", c["kw"], None, exp, got))
+    wopts, aopts = G["weight_options"], G["activation_options"]
+    for c in G["configs"]:
+        def make(c=c):
+            kw = {}
+            if wopts[c["weights"]] is not None:
+                kw["weights"] = QWeightArgs(**wopts[c["weights"]])
+            if aopts[c["inputs"]] is not None:
+                kw["input_activations"] = QActivationArgs(**aopts[c["inputs"]])
+            if aopts[c["outputs"]] is not None:
+                kw["output_activations"] = QActivationArgs(**aopts[c["outputs"]])
+            if c["format"] is not None:
+                kw["format"] = c["format"]
+            return QConfig(**kw)
+        got = _attempt(make, ["format"])
+        exp = {k: c[k] for k in ("ok", "fields", "error") if k in c}
+        if got != exp:
+            bad.append(("configs", (c["weights"], c["inputs"], c["outputs"], c["format"]), None, exp, got))
+    assert not bad, f"{len(bad)} differences, first: {bad[:5]}"
