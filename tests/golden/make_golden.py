@@ -714,9 +714,28 @@ def gen_config(out):
                 kw["format"] = fmt
             return Q.QConfig(**kw)
         confs.append(dict(weights=wk, inputs=ik, outputs=ok, format=fmt, **_attempt(make, ["format"])))
+    # the small parameter models: algorithm / pre-pass / calibration settings
+    base = importlib.import_module("onnx_quantize.core._calibration.base")
+    P = sys.modules["onnx_quantize.pre_passes.awq"], sys.modules["onnx_quantize.pre_passes.smooth_quant"]
+    params = []
+    def add(model, cls, fields, grid):
+        for kw in grid:
+            params.append(dict(model=model, kw=kw, **_attempt(lambda kw=kw: cls(**kw), fields)))
+    add("gptq", R.gptq.GPTQConfig, ["algorithm_type", "block_size", "percdamp", "actorder"],
+        [dict()] + [dict(block_size=b) for b in (-1, 0, 1, 64, "128", 1.5)] + [dict(percdamp=p) for p in (-0.1, 0, 0.5, 1, 2, "0.1")] +
+        [dict(actorder=a) for a in (True, 1, "yes", None)] + [dict(unknown=1), dict(algorithm_type="rtn")])
+    add("hqq", R.hqq.HqqConfig, ["algorithm_type", "lp_norm", "beta", "kappa", "iters", "early_stop"],
+        [dict()] + [dict(lp_norm=v) for v in (0, 0.5, 1, 2, -1)] + [dict(beta=v) for v in (0, -1, 5)] + [dict(kappa=v) for v in (1, 0.5, 2)] +
+        [dict(iters=v) for v in (0, -1, 5, 2.5)] + [dict(early_stop=False), dict(nope=1)])
+    add("awq", P[0].AwqConfig, ["preprocessing_type", "clip_search"], [dict(), dict(clip_search=True), dict(clip_search="no"), dict(x=1)])
+    add("smooth_quant", P[1].SmoothQuantConfig, ["preprocessing_type", "alpha"], [dict()] + [dict(alpha=a) for a in (-0.1, 0, 0.5, 1, 1.1, "0.3")])
+    add("calibration", base.CalibrationParams, ["method", "num_samples", "batch_size", "momentum", "provider"],
+        [dict()] + [dict(momentum=m) for m in (-0.1, 0, 0.5, 0.99, 1, 1.2)] + [dict(num_samples=n) for n in (0, 1, -5, 7)] +
+        [dict(batch_size=b) for b in (0, 1, -1)] + [dict(method=m) for m in ("minmax", "MinMax", "entropy", 3)] +
+        [dict(provider=p) for p in ("cpu", "CPU", "cuda", "gpu", "rocm", "CPUExecutionProvider", "CUDAExecutionProvider", "tpu", "")] + [dict(extra=1)])
     with open(os.path.join(out, "config.json"), "w") as f:
-        json.dump(dict(weight_options=wopts, activation_options=aopts, weights=weights, activations=acts, configs=confs), f)
-    print(f"config: {len(weights)} QWeightArgs, {len(acts)} QActivationArgs, {len(confs)} QConfig combinations "
+        json.dump(dict(weight_options=wopts, activation_options=aopts, weights=weights, activations=acts, configs=confs, params=params), f)
+    print(f"config: {len(params)} parameter-model cases; {len(weights)} QWeightArgs, {len(acts)} QActivationArgs, {len(confs)} QConfig combinations "
           f"({sum(not w['ok'] for w in weights)} / {sum(not a['ok'] for a in acts)} / {sum(not c['ok'] for c in confs)} rejected)")
 
 

@@ -358,4 +358,22 @@ def test_argument_grid_behaves_like_the_reference_classes():
         exp = {k: c[k] for k in ("ok", "fields", "error") if k in c}
         if got != exp:
             bad.append(("configs", (c["weights"], c["inputs"], c["outputs"], c["format"]), None, exp, got))
+    from onnx_quantize_amd import AwqConfig, SmoothQuantConfig
+    from onnx_quantize_amd.calibration import CalibrationParams
+    models = {"gptq": (GPTQConfig, ["algorithm_type", "block_size", "percdamp", "actorder"]),
+              "hqq": (HqqConfig, ["algorithm_type", "lp_norm", "beta", "kappa", "iters", "early_stop"]),
+              "awq": (AwqConfig, ["preprocessing_type", "clip_search"]),
+              "smooth_quant": (SmoothQuantConfig, ["preprocessing_type", "alpha"]),
+              "calibration": (CalibrationParams, ["method", "num_samples", "batch_size", "momentum", "provider"])}
+    # the ONE deliberate extension of the mirror: ROCm / MIGraphX execution providers next to the reference's CPU / CUDA
+    extensions = [("calibration", {"provider": "rocm"})]
+    for c in G["params"]:
+        if (c["model"], c["kw"]) in extensions:
+            assert not c["ok"] and CalibrationParams(**c["kw"]).provider.value == "ROCMExecutionProvider"
+            continue
+        cls, fields = models[c["model"]]
+        got = _attempt(lambda c=c, cls=cls: cls(**c["kw"]), fields)
+        exp = {k: c[k] for k in ("ok", "fields", "error") if k in c}
+        if got != exp:
+            bad.append((c["model"], c["kw"], None, exp, got))
     assert not bad, f"{len(bad)} differences, first: {bad[:5]}"
