@@ -272,6 +272,11 @@ int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
 /* N3  qrules/_common.py:65-123: MatMulNBits zero-point packing [N, ceil(K/g / 2)] (pad nibble 0x8)
  *     from the per-group zero points [N*K/g] (1 byte each).  4-bit only. */
 int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out, void* stream);
+/* N3  qrules/_common.py:72-87: the MatMulNBits B blob [N, K/g, g*bits/8] from a [K, N] array of 4- / 8-bit values stored
+ *     one per byte (what `_rtn_quantize` / `_gptq_quantize` / `_hqq_quantize` return): even k in the low nibble.  The RTN
+ *     and HQQ entry points write the blob directly with OQ_LAYOUT_NBITS; this is for integers that already exist. */
+int32_t oq_pack_matmul_nbits(const void* q, int64_t K, int64_t N, int64_t group_size, int32_t bits, uint8_t* out,
+                             void* stream);
 /* N3  core/_pack.py:8-22: flat nibble packing (element 2j -> low nibble of byte j) of `count` 4-bit
  *     values stored one per byte; out has (count+1)/2 bytes. */
 int32_t oq_pack_nibbles(const void* values, int64_t count, uint8_t* out, void* stream);

@@ -210,6 +210,38 @@ __global__ void pack_nibbles_kernel(const uint8_t* v, int64_t count, uint8_t* ou
     out[j] = static_cast<uint8_t>(lo | (hi << 4));
 }
 
+// qrules/_common.py:72-87: B[n][kg][j] = q[kg*g + 2j][n] | q[kg*g + 2j + 1][n] << 4 (4 bits) or q[kg*g + j][n] (8 bits) from the
+// [K, N] byte array the algorithms return.  A block transposes a tile of 64 rows x 64 columns through LDS: coalesced row
+// reads, and per output column 32 (4 bits) / 64 (8 bits) consecutive blob bytes.  g % 64 == 0 or 64 % g == 0 (g >= 16, even).
+__global__ __launch_bounds__(256) void pack_blob_kernel(const uint8_t* __restrict__ q, int64_t K, int64_t N, int64_t g, int32_t bits,
+                                                        uint8_t* __restrict__ out) {
+    __shared__ uint8_t t[64][65];
+    const int64_t k0 = static_cast<int64_t>(blockIdx.y) * 64, n0 = static_cast<int64_t>(blockIdx.x) * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t k = k0 + r, n = n0 + tx;
+        t[r][tx] = (k < K && n < N) ? q[k * N + n] : 0;
+    }
+    __syncthreads();
+    const int64_t kgroups = K / g;
+    if (bits == 4) {   // thread = (column c, byte pair index j2 in 0..31 of this 64-row slab)
+        for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+            const int c = idx >> 5, j = idx & 31;
+            const int64_t n = n0 + c, k = k0 + 2 * j;
+            if (n < N && k < K) {
+                const uint8_t b = static_cast<uint8_t>((t[2 * j][c] & 0x0f) | ((t[2 * j + 1][c] & 0x0f) << 4));
+                out[(n * kgroups + k / g) * (g / 2) + (k % g) / 2] = b;
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < 64 * 64; idx += 256) {
+            const int c = idx >> 6, j = idx & 63;
+            const int64_t n = n0 + c, k = k0 + j;
+            if (n < N && k < K) out[(n * kgroups + k / g) * g + k % g] = t[j][c];
+        }
+    }
+}
+
 static uint32_t grid_for(int64_t work, int block = 256) {
     const int64_t b = ceil_div(work, block);
     return static_cast<uint32_t>(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
@@ -329,6 +361,17 @@ int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uin
     hipLaunchKernelGGL(pack_zp_u4_kernel, dim3(static_cast<uint32_t>(ceil_div(work, 256))), dim3(256), 0, as_stream(stream), zp,
                        N, blocks, out);
     return check_launch("pack_zp_u4_kernel");
+}
+
+int32_t oq_pack_matmul_nbits(const void* q, int64_t K, int64_t N, int64_t group_size, int32_t bits, uint8_t* out, void* stream) {
+    OQ_REQUIRE(q && out && K > 0 && N > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_matmul_nbits: bad argument");
+    OQ_REQUIRE(bits == 4 || bits == 8, OQ_ERR_UNSUPPORTED, "oq_pack_matmul_nbits: 4- or 8-bit values only");
+    OQ_REQUIRE(group_size >= 2 && group_size % 2 == 0 && K % group_size == 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_pack_matmul_nbits: group_size must be even and divide K (%lld, %lld)", (long long)group_size, (long long)K);
+    const dim3 grid(static_cast<uint32_t>(ceil_div(N, 64)), static_cast<uint32_t>(ceil_div(K, 64)));
+    OQ_REQUIRE(grid.y <= 65535, OQ_ERR_UNSUPPORTED, "oq_pack_matmul_nbits: K up to 4 194 240");
+    hipLaunchKernelGGL(pack_blob_kernel, grid, dim3(256), 0, as_stream(stream), static_cast<const uint8_t*>(q), K, N, group_size, bits, out);
+    return check_launch("pack_blob_kernel");
 }
 
 int32_t oq_pack_nibbles(const void* values, int64_t count, uint8_t* out, void* stream) {

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "oq_absmax_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "oq_rtn_tensor_many_workspace_bytes": (_sz, [_i64]),
     "oq_rtn_tensor_many_f32": (_i32, [_p, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
+    "oq_pack_matmul_nbits": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p]),
     "oq_hessian_set_method": (_i32, [_i32]),
     "oq_hessian_method": (_i32, []),
     "oq_hessian_workspace_bytes": (_sz, [_i64, _i64]),

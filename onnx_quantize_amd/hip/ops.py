@@ -456,6 +456,18 @@ def pack_zero_points_u4(zp: torch.Tensor, n: int, blocks: int) -> torch.Tensor:
     return out
 
 
+def pack_matmul_nbits(q: torch.Tensor, group_size: int, bits: int) -> torch.Tensor:
+    """_common.py:72-87: [K, N] 4- / 8-bit values (one per byte) -> the MatMulNBits blob [N, K/g, g*bits/8]."""
+    _require_device(q, "q")
+    if q.dim() != 2:
+        raise ValueError("q must be [K, N]")
+    k, n = q.shape
+    v = q.contiguous().view(torch.uint8)
+    out = torch.empty((n, k // group_size, group_size * bits // 8), dtype=torch.uint8, device=q.device)
+    L.check(L.load().oq_pack_matmul_nbits(_ptr(v), k, n, int(group_size), int(bits), _ptr(out), _stream()))
+    return out
+
+
 def pack_nibbles(values: torch.Tensor) -> torch.Tensor:
     """_pack.py:8-22: flat 4-bit packing, element 2j in the low nibble."""
     _require_device(values, "values")

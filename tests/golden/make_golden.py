@@ -648,10 +648,26 @@ def gen_nbits(out):
         arrays[key + "_q"], arrays[key + "_s"], arrays[key + "_z"] = np.asarray(q).astype(np.uint8), np.asarray(sc), np.asarray(zp)
         arrays[key + "_blob"], arrays[key + "_scale"], arrays[key + "_zp"] = np.asarray(b), np.asarray(s2), np.asarray(pz)
         cases.append(dict(key=key, seed=seed, k=k, n=n, qtype=qtype, group_size=g, float_zero_points=hqq))
+    # the two host-side decisions next to it: _resolve_group_size (:13-29) and is_matmul_nbits_compatible (:32-62)
+    resolve = []
+    for in_ch, gs in itertools.product((64, 100, 128), (None, 0, -1, 16, 32, 48, 128, 256)):
+        v = ir.val("w", ir.tensor(np.zeros((in_ch, 4), np.float32)))
+        resolve.append([in_ch, gs, common._resolve_group_size(v, gs)])
+    compat = []
+    for dt, gs, st, has_in, has_out in itertools.product(("uint4", "int4", "uint8", "int8"), (None, -1, 8, 16, 24, 32, 128),
+                                                        (None, "group", "channel"), (False, True), (False, True)):
+        try:
+            qc = Q.QConfig(weights=Q.QWeightArgs(dtype=QT[dt], group_size=gs, strategy=st),
+                           input_activations=Q.QActivationArgs(dtype=QT["uint8"], is_static=True) if has_in else None,
+                           output_activations=Q.QActivationArgs(dtype=QT["uint8"], is_static=True) if has_out else None)
+        except Exception:  # noqa: BLE001 -- combinations the config classes reject are not part of this table
+            continue
+        compat.append(dict(dtype=dt, group_size=gs, strategy=st, inputs=has_in, outputs=has_out,
+                           compatible=bool(common.is_matmul_nbits_compatible(qc))))
     np.savez_compressed(os.path.join(out, "nbits.npz"), **arrays)
     with open(os.path.join(out, "nbits.json"), "w") as f:
-        json.dump({"cases": cases}, f, indent=1)
-    print(f"nbits: {len(cases)} cases")
+        json.dump({"cases": cases, "resolve_group_size": resolve, "compatible": compat}, f, indent=1)
+    print(f"nbits: {len(cases)} cases, {len(resolve)} group-size resolutions, {len(compat)} compatibility decisions")
 
 
 def _describe(obj, fields):

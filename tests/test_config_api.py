@@ -377,3 +377,20 @@ def test_argument_grid_behaves_like_the_reference_classes():
         if got != exp:
             bad.append((c["model"], c["kw"], None, exp, got))
     assert not bad, f"{len(bad)} differences, first: {bad[:5]}"
+
+
+def test_matmul_nbits_decisions_equal_the_reference():
+    """tests/golden/nbits.json: `_resolve_group_size` and `is_matmul_nbits_compatible` (qrules/_common.py:13-62) on grids
+    of arguments, from the reference's own functions."""
+    from conftest import load_json
+    from onnx_quantize_amd import QActivationArgs, QConfig, QWeightArgs
+    from onnx_quantize_amd.wire_format import _resolve_group_size, is_matmul_nbits_compatible
+    G = load_json("nbits.json")
+    assert len(G["resolve_group_size"]) == 24 and len(G["compatible"]) == 80
+    for in_ch, gs, expected in G["resolve_group_size"]:
+        assert _resolve_group_size(in_ch, gs) == expected, (in_ch, gs)
+    for c in G["compatible"]:
+        act = QActivationArgs(dtype=QuantType.QUInt8, is_static=True)
+        qc = QConfig(weights=QWeightArgs(dtype=QuantType.from_string(c["dtype"]), group_size=c["group_size"], strategy=c["strategy"]),
+                     input_activations=act if c["inputs"] else None, output_activations=act if c["outputs"] else None)
+        assert is_matmul_nbits_compatible(qc) == c["compatible"], c

@@ -414,3 +414,29 @@ def test_kernel_emitted_wire_format_equals_the_reference_function_output():
             np.testing.assert_array_equal(ops.pack_zero_points_u4(z, n, blocks).cpu().numpy(), G[key + "_zp"])
         else:
             np.testing.assert_array_equal(z.reshape(n, -1).cpu().numpy(), G[key + "_zp"])
+
+
+@pytest.mark.gpu
+def test_prepare_for_matmul_nbits_mirror_equals_the_reference_function():
+    """`wire_format._prepare_for_matmul_nbits` (NumPy in / out through oq_pack_matmul_nbits + oq_pack_zero_points_u4) on
+    the very inputs the reference function got (tests/golden/nbits.*): identical outputs, dtypes and shapes; and the
+    stand-alone blob kernel on shapes with ragged 64 x 64 tiles."""
+    import torch
+    from conftest import load_json, load_npz
+    from onnx_quantize_amd import HqqConfig, QConfig, QWeightArgs, QuantType
+    from onnx_quantize_amd.hip import ops
+    from onnx_quantize_amd.wire_format import _prepare_for_matmul_nbits
+    G, cases = load_npz("nbits.npz"), load_json("nbits.json")["cases"]
+    for c in cases:
+        key = c["key"]
+        extra = {"algorithm": HqqConfig()} if c["float_zero_points"] else {}
+        qc = QConfig(weights=QWeightArgs(dtype=QuantType.from_string(c["qtype"]), group_size=c["group_size"], strategy="group", **extra))
+        b, s, z = _prepare_for_matmul_nbits(G[key + "_q"], G[key + "_s"], G[key + "_z"], qc)
+        for got, name in ((b, "_blob"), (s, "_scale"), (z, "_zp")):
+            exp = G[key + name]
+            assert got.dtype == exp.dtype and got.shape == exp.shape and got.tobytes() == exp.tobytes(), (key, name)
+    rng = np.random.default_rng(0)
+    for k, n, g, bits in ((96, 70, 16, 4), (130 * 2, 33, 26, 4), (192, 129, 64, 8), (80, 5, 80, 8), (2048, 300, 128, 4)):
+        q = rng.integers(0, 2**bits, size=(k, n), dtype=np.uint8)
+        eb, _, _ = O.matmul_nbits_layout(q, np.ones(n * k // g, np.float32), np.zeros((n * k // g, 1), np.uint8), g, bits)
+        np.testing.assert_array_equal(ops.pack_matmul_nbits(torch.from_numpy(q).cuda(), g, bits).cpu().numpy(), eb)
