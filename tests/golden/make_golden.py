@@ -755,6 +755,48 @@ def gen_config(out):
           f"({sum(not w['ok'] for w in weights)} / {sum(not a['ok'] for a in acts)} / {sum(not c['ok'] for c in confs)} rejected)")
 
 
+def gen_seam(out):
+    """The plugin seam itself: `qconfig.weights.algorithm.quantize_weights(w, qconfig, out=out)` (qrules/_common.py:133) of the
+    reference's RTNConfig / GPTQConfig / HqqConfig, called with carrier values (a weight value whose constant returns its
+    array, an output value whose producer node carries the calibration inputs in `meta["input"]`)."""
+    _load_passes()
+    ir = sys.modules["onnx_ir"]
+    Q = R.qconfig
+    cases, arrays = [], {}
+    grid = [  # (algorithm, seed, k, n, kwargs of QWeightArgs, kwargs of the algorithm config)
+        ("rtn", 1, 64, 48, dict(dtype="int8", symmetric=True), {}),
+        ("rtn", 2, 96, 40, dict(dtype="uint8", group_size=-1), {}),
+        ("rtn", 3, 128, 24, dict(dtype="uint4", group_size=32), {}),
+        ("rtn", 4, 128, 24, dict(dtype="int4", group_size=64, symmetric=True, clip_ratio=0.9), {}),
+        ("gptq", 5, 64, 32, dict(dtype="int4", group_size=32), dict(block_size=32)),
+        ("gptq", 6, 96, 20, dict(dtype="int8", group_size=-1), dict(percdamp=0.05)),
+        ("gptq", 7, 64, 16, dict(dtype="uint8"), dict(actorder=True)),
+        ("hqq", 8, 128, 20, dict(dtype="uint4", group_size=32, strategy="group"), dict(iters=10)),
+    ]
+    algos = {"rtn": None, "gptq": R.gptq.GPTQConfig, "hqq": R.hqq.HqqConfig}
+    for idx, (al, seed, k, n, wkw, akw) in enumerate(grid):
+        w = weight("normal", seed, k, n) * np.float32(0.1)
+        rng = np.random.default_rng(seed + 100)
+        x = (rng.standard_normal((6, 10, k)) * rng.uniform(0.3, 3.0, size=k)).astype(np.float32)
+        kw = {**wkw, "dtype": QT[wkw["dtype"]]}
+        if algos[al] is not None:
+            kw["algorithm"] = algos[al](**akw)
+        qc = Q.QConfig(weights=Q.QWeightArgs(**kw))
+        node = types.SimpleNamespace(meta={"input": x})
+        outv = types.SimpleNamespace(producer=lambda node=node: node)
+        q, sc, zp = qc.weights.algorithm.quantize_weights(ir.val("w", ir.tensor(w)), qc, out=outv)
+        key = f"c{idx}"
+        arrays[key + "_w"], arrays[key + "_x"] = w, x
+        arrays[key + "_q"] = np.asarray(q).astype(np.int8 if wkw["dtype"].startswith("int") else np.uint8)
+        arrays[key + "_s"], arrays[key + "_z"] = np.asarray(sc), np.asarray(zp).astype(np.float32 if al == "hqq" else np.int32)
+        cases.append(dict(key=key, algorithm=al, weights=wkw, config=akw, q_shape=list(np.shape(q)), s_shape=list(np.shape(sc)),
+                          z_shape=list(np.shape(zp)), s_dtype=str(np.asarray(sc).dtype), z_dtype=str(np.asarray(zp).dtype)))
+    np.savez_compressed(os.path.join(out, "seam.npz"), **arrays)
+    with open(os.path.join(out, "seam.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=1)
+    print(f"seam: {len(cases)} cases")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -799,7 +841,7 @@ def gen_digests(out):
 def main():
     out = HERE
     gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
-                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, digests=gen_digests)
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, seam=gen_seam, digests=gen_digests)
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],

@@ -357,3 +357,38 @@ def test_calibration_of_a_tensor_with_more_than_2_31_elements():
     assert many.data["small"].min_val == np.float32(-2) and many.data["small"].max_val == np.float32(11)
     del x
     torch.cuda.empty_cache()
+
+
+def test_plugin_seam_against_the_reference_plugins():
+    """tests/golden/seam.*: `qconfig.weights.algorithm.quantize_weights(w, qconfig, out=out)` -- the one call through which the
+    reference reaches the path (qrules/_common.py:133) -- of the reference's RTNConfig / GPTQConfig / HqqConfig on carrier
+    values, against the same call on this package's configs: shapes, dtypes, integers and zero points identical, scales
+    bit-equal (RTN, GPTQ parity mode) or within the HQQ tolerance."""
+    import types
+    from onnx_quantize_amd import GPTQConfig, HqqConfig, QConfig, QWeightArgs
+    G, cases = load_npz("seam.npz"), load_json("seam.json")["cases"]
+    assert len(cases) == 8
+    algos = {"rtn": None, "gptq": GPTQConfig, "hqq": HqqConfig}
+    for c in cases:
+        key = c["key"]
+        kw = {**c["weights"], "dtype": QuantType.from_string(c["weights"]["dtype"])}
+        if algos[c["algorithm"]] is not None:
+            kw["algorithm"] = algos[c["algorithm"]](**c["config"])
+        qc = QConfig(weights=QWeightArgs(**kw))
+        w = types.SimpleNamespace(name="w", const_value=types.SimpleNamespace(numpy=lambda a=G[key + "_w"]: a))
+        node = types.SimpleNamespace(meta={"input": G[key + "_x"].copy()})
+        out = types.SimpleNamespace(producer=lambda node=node: node)
+        q, s, z = qc.weights.algorithm.quantize_weights(w, qc, out=out)
+        assert list(np.shape(q)) == c["q_shape"] and list(np.shape(s)) == c["s_shape"] and list(np.shape(z)) == c["z_shape"], key
+        assert str(np.asarray(s).dtype) == c["s_dtype"] and str(np.asarray(z).dtype) == c["z_dtype"], key
+        eq, es, ez = G[key + "_q"], G[key + "_s"], G[key + "_z"]
+        if c["algorithm"] == "hqq":
+            assert np.asarray(s).tobytes() == es.tobytes()
+            np.testing.assert_allclose(np.asarray(z, np.float32), ez, atol=2e-5)
+            d = np.abs(np.asarray(q).astype(np.int32) - eq.astype(np.int32))
+            assert d.max() <= 1 and np.count_nonzero(d) <= 2e-3 * d.size
+        else:
+            np.testing.assert_array_equal(np.asarray(q).astype(eq.dtype), eq)
+            np.testing.assert_array_equal(np.asarray(z).astype(np.int32), ez)
+            np.testing.assert_allclose(np.asarray(s), es, rtol=1e-5, atol=0)
+        np.testing.assert_array_equal(node.meta["input"], G[key + "_x"])          # inputs are never mutated
