@@ -845,7 +845,17 @@ def main():
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],
-                reference="/root/reference (AyoubMDL/onnx_quantize v0.3.0 checkout)")
+                reference="/root/reference (AyoubMDL/onnx_quantize v0.3.0 checkout)",
+                stand_ins=["onnx_ir: DataType enum; for the pass methods, calibrate_model, the wire-format helpers and the plugin-seam "
+                           "call also Tensor (returns its array), Value (name + constant), passes.InPlacePass = object, "
+                           "convenience.get_const_tensor / replace_all_uses_with, tape.Tape / Model / Node / Value names for annotations",
+                           "ml_dtypes: bfloat16 entry of calibrate.py's dtype table",
+                           "package objects with __path__ for onnx_quantize, onnx_quantize.pre_passes, onnx_quantize.qrules "
+                           "(their __init__ pull in onnx / onnxscript)"],
+                replaced_or_overridden=["calibrate._collect_activations (the onnxruntime session) -> a prepared list of per-batch dicts",
+                                        "AwqPass.is_valid_node -> True; AwqPass / SmoothQuantPass._insert_mul_node_before -> records the "
+                                        "scale initializer (graph edits only)"],
+                note="every arithmetic statement of the reference runs unmodified; only data leaves the script")
     with open(os.path.join(out, "PROVENANCE.json"), "w") as f:
         json.dump(meta, f, indent=1)
 
