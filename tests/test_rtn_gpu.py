@@ -440,3 +440,69 @@ def test_prepare_for_matmul_nbits_mirror_equals_the_reference_function():
         q = rng.integers(0, 2**bits, size=(k, n), dtype=np.uint8)
         eb, _, _ = O.matmul_nbits_layout(q, np.ones(n * k // g, np.float32), np.zeros((n * k // g, 1), np.uint8), g, bits)
         np.testing.assert_array_equal(ops.pack_matmul_nbits(torch.from_numpy(q).cuda(), g, bits).cpu().numpy(), eb)
+
+
+@pytest.mark.gpu
+def test_random_configurations_against_the_oracle():
+    """Property test (hypothesis, fixed seed): random shapes, types, strategies, group sizes, symmetric / reduce_range /
+    clip_ratio, value distributions with planted zeros, ties and huge / tiny magnitudes -- every output of
+    `ops.rtn_quantize` (both layouts where the blob applies) equals the oracle's bit for bit."""
+    import torch
+    from hypothesis import HealthCheck, given, seed, settings, strategies as st
+    from onnx_quantize_amd.hip import ops
+
+    @st.composite
+    def case(draw):
+        qtype = draw(st.sampled_from(["int4", "uint4", "int8", "uint8"]))
+        strategy = draw(st.sampled_from(["tensor", "channel", "group"]))
+        if strategy == "group":
+            g = draw(st.sampled_from([2, 8, 16, 24, 32, 64, 96, 128, 200, 256]))
+            k = g * draw(st.integers(1, 6))
+        else:
+            g, k = -1, draw(st.integers(1, 400))
+        n = draw(st.integers(1, 300))
+        sym, red = draw(st.booleans()), draw(st.booleans())
+        clip = draw(st.sampled_from([1.0, 0.9, 0.5, 0.999]))
+        kind = draw(st.sampled_from(["normal", "wide", "tiny", "ties", "zeros", "positive"]))
+        return qtype, strategy, g, k, n, sym, red, clip, kind, draw(st.integers(0, 2**31 - 1))
+
+    def make(kind, k, n, rs):
+        r = np.random.default_rng(rs)
+        w = r.standard_normal((k, n)).astype(np.float32)
+        if kind == "wide":
+            w *= np.float32(10.0) ** r.integers(-6, 7, size=(1, n)).astype(np.float32)
+        elif kind == "tiny":
+            w *= np.float32(1e-30)
+        elif kind == "ties":
+            w = (r.integers(-40, 41, size=(k, n)) * 0.5).astype(np.float32)
+        elif kind == "zeros":
+            w[r.random((k, n)) < 0.7] = 0
+            w[:, ::3] = 0
+        elif kind == "positive":
+            w = np.abs(w) + 1
+        return w
+
+    @seed(20240601)
+    @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(case())
+    def run(c):
+        qtype, strategy, g, k, n, sym, red, clip, kind, rs = c
+        w = make(kind, k, n, rs)
+        eq, es, ez = O.rtn_quantize(w, qtype, strategy, g, sym, red, clip)
+        wd = torch.from_numpy(w).cuda()
+        q, s, z = ops.rtn_quantize(wd, qtype, strategy, g, sym, red, clip)
+        np.testing.assert_array_equal(q.cpu().numpy(), eq, err_msg=str(c))
+        assert s.cpu().numpy().reshape(np.shape(es)).tobytes() == np.asarray(es, np.float32).tobytes(), c
+        np.testing.assert_array_equal(z.cpu().numpy().reshape(np.shape(ez)), ez, err_msg=str(c))
+        if strategy == "group" and g % 16 == 0 and n % 4 == 0 and qtype in ("uint4", "uint8", "int4", "int8"):
+            try:
+                blob, s2, z2 = ops.rtn_quantize(wd, qtype, strategy, g, sym, red, clip, layout="nbits")
+            except Exception as e:  # noqa: BLE001 -- shapes the blob path declines must say so, never answer wrongly
+                assert "NBITS" in str(e) or "unsupported" in str(e).lower(), (c, e)
+                return
+            bits = 4 if "4" in qtype else 8
+            eb, _, _ = O.matmul_nbits_layout(eq.view(np.uint8) & (15 if bits == 4 else 255), es, ez, g, bits)
+            np.testing.assert_array_equal(blob.cpu().numpy(), eb, err_msg=str(c))
+            assert torch.equal(s2.reshape(-1), s.reshape(-1)) and torch.equal(z2.reshape(-1), z.reshape(-1))
+
+    run()
