@@ -427,3 +427,42 @@ def test_hessian_of_a_very_wide_input(ops):
     top = float(strip.abs().max())
     assert float((h[k - 256:].double() - strip).abs().max()) <= 1e-5 * top
     assert float((torch.diagonal(h).double() - (x64 * x64).sum(0)).abs().max()) <= 1e-5 * top
+
+
+def test_random_gptq_configurations_against_the_oracle(ops):
+    """Property test (hypothesis, fixed seed) of the whole `_gptq_quantize` composition in parity mode: random shapes,
+    types, strategies, group / block sizes, actorder, dead channels, symmetric / reduce_range / clip_ratio.  Integers and
+    zero points equal the oracle's (which equals the reference on 104 golden cases), scales to 1e-5."""
+    import torch
+    from hypothesis import HealthCheck, given, seed, settings, strategies as st
+
+    @st.composite
+    def case(draw):
+        qtype = draw(st.sampled_from(["int4", "uint4", "int8", "uint8"]))
+        strategy = draw(st.sampled_from(["tensor", "channel", "group"]))
+        k = draw(st.sampled_from([16, 32, 48, 64, 96, 128, 160, 256]))
+        g = draw(st.sampled_from([d for d in (8, 16, 32, 64, 128) if k % d == 0])) if strategy == "group" else draw(st.sampled_from([32, -1]))
+        n = draw(st.integers(1, 70))
+        block = draw(st.sampled_from([16, 32, 64, 128]))
+        return (qtype, strategy, k, g, n, block, draw(st.booleans()), draw(st.booleans()), draw(st.booleans()),
+                draw(st.sampled_from([1.0, 0.9])), draw(st.integers(0, 3)), draw(st.integers(0, 2**31 - 1)))
+
+    @seed(20240602)
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(case())
+    def run(c):
+        qtype, strategy, k, g, n, block, actorder, sym, red, clip, dead, rs = c
+        r = np.random.default_rng(rs)
+        w = (r.standard_normal((k, n)) * 0.2).astype(np.float32)
+        x = (r.standard_normal((3, 24, k)) * r.uniform(0.2, 3.0, size=k)).astype(np.float32)
+        for d in r.choice(k, size=min(dead, k), replace=False):
+            x[..., d] = 0                                                   # dead input channels (gptq.py:118-123)
+        eq, es, ez = O.gptq_quantize(w, x, qtype, strategy, g, sym, red, clip, block, 0.01, actorder)
+        h = torch.zeros((k, k), device="cuda")
+        ops.hessian_accumulate(dev(x), h, 0)
+        q, s, z, _ = ops.gptq_quantize(dev(w), h, qtype, strategy, g, sym, red, clip, block, 0.01, actorder)
+        np.testing.assert_array_equal(q.cpu().numpy(), eq, err_msg=str(c))
+        np.testing.assert_array_equal(z.cpu().numpy().reshape(np.shape(ez)), ez, err_msg=str(c))
+        np.testing.assert_allclose(s.cpu().numpy().reshape(np.shape(es)), es, rtol=1e-5, atol=0, err_msg=str(c))
+
+    run()
