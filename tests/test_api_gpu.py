@@ -392,3 +392,44 @@ def test_plugin_seam_against_the_reference_plugins():
             np.testing.assert_array_equal(np.asarray(z).astype(np.int32), ez)
             np.testing.assert_allclose(np.asarray(s), es, rtol=1e-5, atol=0)
         np.testing.assert_array_equal(node.meta["input"], G[key + "_x"])          # inputs are never mutated
+
+
+def test_random_calibration_sequences_against_the_oracle():
+    """Property test (hypothesis, fixed seed): random sequences of activation tensors (ranks, sizes incl. unaligned odd ones,
+    float32 / float64, several names, momentum 0 or not) through `collect` and `collect_many`: the running state and the
+    range handed out equal the oracle's (= minmax.py:40-87) bit for bit, EMA included."""
+    import torch
+    from hypothesis import HealthCheck, given, seed, settings, strategies as st
+    from onnx_quantize_amd.calibration import MinMaxCalibrator
+
+    @st.composite
+    def case(draw):
+        momentum = draw(st.sampled_from([0.0, 0.0, 0.9, 0.5, 0.01]))
+        steps = draw(st.lists(st.tuples(st.sampled_from(["a", "b", "c"]), st.lists(st.integers(1, 40), min_size=1, max_size=3),
+                                        st.sampled_from(["f32", "f32", "f64"]), st.integers(0, 3)), min_size=1, max_size=8))
+        return momentum, steps, draw(st.booleans()), draw(st.integers(0, 2**31 - 1))
+
+    @seed(20240603)
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(case())
+    def run(c):
+        momentum, steps, many, rs = c
+        r = np.random.default_rng(rs)
+        cal, ref = MinMaxCalibrator(momentum), O.MinMaxOracle(momentum)
+        dtypes = {}
+        for name, shape, dt, off in steps:
+            dt = dtypes.setdefault(name, dt)                      # one dtype per name, like a real graph value
+            x = (r.standard_normal(shape) * r.uniform(0.1, 50)).astype(np.float32 if dt == "f32" else np.float64)
+            ref.collect(name, x)
+            t = torch.from_numpy(np.concatenate([np.zeros(off, x.dtype), x.ravel()])).cuda()[off:].reshape(shape)   # unaligned base
+            if many and dt == "f32":
+                cal.collect_many({name: t})
+            else:
+                cal.collect(name, t)
+        for name in dtypes:
+            lo, hi = ref.data[name]
+            assert cal.data[name].min_val == lo and cal.data[name].max_val == hi, (c, name)
+            a, b = cal.compute_range(name), ref.compute_range(name)
+            assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+    run()
