@@ -466,3 +466,32 @@ def test_random_gptq_configurations_against_the_oracle(ops):
         np.testing.assert_allclose(s.cpu().numpy().reshape(np.shape(es)), es, rtol=1e-5, atol=0, err_msg=str(c))
 
     run()
+
+
+def test_random_hessian_shapes_and_methods(ops, restore_hessian_method):
+    """Property test (hypothesis, fixed seed): random T, K (not multiples of anything), batch counts, leading dimensions
+    and kernels; every Hessian within 1e-5 max|H| of float64, exactly symmetric, counts right."""
+    import torch
+    from hypothesis import HealthCheck, given, seed, settings, strategies as st
+
+    @seed(20240604)
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.sampled_from(["f32", "bf16x6", "bf16x9", "auto"]), st.integers(1, 700), st.integers(1, 9), st.integers(1, 300),
+           st.integers(1, 3), st.integers(0, 5), st.integers(0, 2**31 - 1))
+    def run(method, k, samples, seq, batches, pad, rs):
+        ops.hessian_set_method(method)
+        r = np.random.default_rng(rs)
+        h = torch.zeros((k, k), device="cuda")
+        n, xs = 0, []
+        for _ in range(batches):
+            x = (r.standard_normal((samples, seq, k + pad)) * r.uniform(0.1, 5)).astype(np.float32)
+            xs.append(x[..., :k])
+            n = ops.hessian_accumulate(dev(x)[..., :k], h, n)        # a strided view when pad > 0
+        assert n == batches * samples
+        x64 = np.concatenate([x.reshape(-1, k) for x in xs]).astype(np.float64)
+        ref = (2.0 / n) * x64.T @ x64
+        got = h.cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-5 * max(np.abs(ref).max(), 1e-30))
+        np.testing.assert_array_equal(got, got.T)
+
+    run()
