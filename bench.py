@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: group-128 uint4 RTN quantization of a 4096x11008 fp32 weight on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]           (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+With --gpus N > 1 and no WORLD_SIZE in the environment bench.py launches the N ranks ITSELF (a
+`python -m torch.distributed.run` child, started before this process touches a GPU); under torch.distributed.run it is
+one of the ranks.  Either way `n_gpus` in the JSON line is the number of ranks that joined, and a mismatch with --gpus is
+an error, never a silent one-GPU run.
 
 One "step" = one pass of the hot path over one 4096x11008 matrix already resident in HBM: one call of
 oq_rtn_quantize_f32 through the C ABI.  Default output layout "nbits" = reference rtn.py:54-109
 (`_rtn_quantize`) fused with qrules/_common.py:65-123 (`_prepare_for_matmul_nbits`), i.e. the packed int4
 MatMulNBits blob + scales + zero points the reference emits for this configuration and the layout the
 algorithmic byte count (4.539 B/param) is defined on; "kn" = the [K, N] one-value-per-byte array
-`_rtn_quantize` itself returns (timed too and reported under "other_layout").  Inputs rotate over `--rotate` distinct HBM buffers (default 4 x 180 MB,
-more than the 256 MiB Infinity Cache) so every step streams from HBM, not from cache.
+`_rtn_quantize` itself returns (timed too and reported under "other_layout").  Inputs rotate over `--rotate` distinct
+HBM buffers (default 4 x 180 MB, more than the 256 MiB Infinity Cache) so every step streams from HBM, not from cache.
 
 N > 1 is weak scaling: every rank quantizes its own matrices (independent MatMul weights shard with
-no data-path collective); `value` = params of all ranks / max-over-ranks time.
+no data-path collective); `value` = params of all ranks / max-over-ranks time.  After the timed steps
+every rank's last result travels to rank 0 through `sharding.gather_device_results` (one padded RCCL gather over xGMI),
+reported as the `gather` object.
 
-Prints ONE JSON line (contract in the task description) with two extra objects:
+Prints ONE JSON line (contract in the task description) with these extra objects:
   roofline      algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak
   cpu_baseline  the NumPy oracle (oracle/oq_oracle.py) timed on the host, rank 0 at N=1 only
+  seam          host -> host throughput through the plugin seam (qrules/_common.py:126-142) on the same configuration:
+                round-1 route ([K,N] kernel, 45 MB download, second round trip for the packer) vs the device-resident
+                seam with pinned, prefetched uploads (seam.py, staging.py), digest-checked
+  gptq          BASELINE configs 4 / 5 from the same run: GPTQ QInt4 g128 of all Llama-2-7B MatMul weights
+                (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`
+  gather        N > 1: seconds, bytes and ranks of the end-of-run RCCL gather
 """
 from __future__ import annotations
 
@@ -25,6 +38,8 @@ import ctypes as C
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -54,8 +69,81 @@ def sha16(a) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
 
 
-def cpu_baseline(w: np.ndarray, budget_s: float = 20.0) -> dict:
+# ------------------------------------------------------------------------------------------------ launch plumbing
+def self_launch(script: str, gpus: int, argv: list[str]) -> int:
+    """Start `gpus` ranks of `script` under torch.distributed.run and relay their output.  Runs in a process that has not
+    touched a GPU (nothing before this imports torch.cuda state), and never replaces the running program: a child process
+    is started and its exit code returned."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script, *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(gpus: int, backend: str = "nccl"):
+    """(device, rank, world) of this rank; the process group is up when world > 1.  --gpus must equal WORLD_SIZE."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {gpus}` (it spawns the ranks) or "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {gpus} --master-addr 127.0.0.1 bench.py --gpus {gpus}`")
+    if backend == "gloo":                       # CPU plumbing test only (tests/test_bench_launch.py)
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    return dev, rank, world
+
+
+def stub_main(args) -> None:
+    """`--stub`: the launch / barrier / max-over-ranks / one-JSON-line plumbing with a no-op step on gloo, no GPU.  Exists
+    for the CPU test of the multi-rank path; its line says so and carries no measurement."""
+    import torch
+    import torch.distributed as dist
+
+    dev, rank, world = init_ranks(args.gpus, backend="gloo")
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = torch.ones(1, dtype=torch.int32)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing test (no measurement)", "value": None, "unit": None, "n_gpus": world,
+                          "ranks_seen": int(seen.item()), "steps": args.steps, "warmup": args.warmup, "data": "stub",
+                          "scaling": "weak", "higher_is_better": True}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(w: np.ndarray, budget_s: float = 20.0):
     """Time the oracle (checker, never the product) on the host cores: kind = "port"."""
+    from bench_gptq import cpu_info
+
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oq_oracle as O
     t_best, runs = float("inf"), 0
@@ -69,12 +157,87 @@ def cpu_baseline(w: np.ndarray, budget_s: float = 20.0) -> dict:
         "value": round(K_DIM * N_DIM / t_best / 1e6, 2), "unit": "M-param/s", "cores": 1,
         "kind": "port",
         "sample": f"full workload (one 4096x11008 matrix), best of {runs} runs, {t_best:.3f} s each; "
-                  f"NumPy {np.__version__} elementwise path is single-threaded; host has {os.cpu_count()} CPUs",
+                  f"NumPy {np.__version__} elementwise path is single-threaded (as the reference runs it)",
         "seconds": round(t_best, 4),
-        "digest_ok": None,
+        "digest_ok": None, **cpu_info(),
     }, (q, s, z)
 
 
+# ------------------------------------------------------------------------------------------------ the seam, host to host
+class _Tensor:
+    def __init__(self, a):
+        self._a = a
+
+    def numpy(self):
+        return self._a
+
+
+class _Value:
+    def __init__(self, name, a):
+        self.name, self.const_value = name, _Tensor(a)
+
+
+def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
+    """Host -> host through the plugin seam on `count` config-2 weights (NumPy in, the three MatMulNBits arrays out)."""
+    import torch
+
+    from onnx_quantize_amd import QConfig, QuantType, QWeightArgs, seam
+    from onnx_quantize_amd.algorithms.rtn import _rtn_quantize
+    from onnx_quantize_amd.staging import default_stager
+    from onnx_quantize_amd.wire_format import _prepare_for_matmul_nbits
+
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=GROUP))
+    a = qc.weights
+    mats = [w_host] + [w_host.copy() for _ in range(count - 1)]
+    params = K_DIM * N_DIM * count
+
+    def check(blob, scale, zp) -> bool:
+        full = np.empty((N_DIM, K_DIM // GROUP, GROUP), np.uint8)
+        full[..., 0::2] = blob & 0x0F
+        full[..., 1::2] = blob >> 4
+        z = np.empty((N_DIM, K_DIM // GROUP), np.uint8)
+        z[:, 0::2] = zp & 0x0F
+        z[:, 1::2] = zp >> 4
+        return bool(sha16(np.ascontiguousarray(full.reshape(N_DIM, K_DIM).T)) == digest["q_sha"] and
+                    sha16(scale.reshape(-1, 1)) == digest["s_sha"] and sha16(z.reshape(-1, 1)) == digest["z_sha"])
+
+    # round-1 route: the algorithm plugin NumPy -> NumPy ([K,N] kernel, 45 MB back), then the packer as a second round trip
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for w in mats:
+        q, s, z = _rtn_quantize(w, a.dtype, a.strategy, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse, a.scale_dtype, a.zp_dtype)
+        last = _prepare_for_matmul_nbits(q, s, z, qc)
+    t_before = time.perf_counter() - t0
+    ok_before = check(*last)
+    # device-resident seam, uploads on demand through pinned staging
+    st = default_stager()
+    t0 = time.perf_counter()
+    for i, w in enumerate(mats):
+        last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
+    t_demand = time.perf_counter() - t0
+    # ... and with the model's weights prefetched from the worker thread while the previous one is quantized
+    hits0 = st.stats["hits"]
+    t0 = time.perf_counter()
+    st.prefetch([(f"w{i}", w) for i, w in enumerate(mats)])
+    for i, w in enumerate(mats):
+        last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
+    t_after = time.perf_counter() - t0
+    ok_after = check(*last)
+    rate = lambda t: round(params / t / 1e6, 1)  # noqa: E731
+    return {"what": "host->host through quantize_weights' arrays (qrules/_common.py:133-137), uint4 g128 4096x11008, "
+                    f"{count} weights in sequence, NumPy in / MatMulNBits arrays out, PCIe included",
+            "unit": "M-param/s",
+            "before": {"route": "_rtn_quantize ([K,N] kernel + 45 MB download) + _prepare_for_matmul_nbits (second round trip)",
+                       "value": rate(t_before), "ms_per_weight": round(t_before * 1e3 / count, 2), "digest_ok": ok_before},
+            "after_on_demand": {"route": "seam.weight_arrays, pinned upload per call", "value": rate(t_demand),
+                                "ms_per_weight": round(t_demand * 1e3 / count, 2)},
+            "after": {"route": "seam.weight_arrays + WeightStager.prefetch (worker thread, side stream)", "value": rate(t_after),
+                      "ms_per_weight": round(t_after * 1e3 / count, 2), "digest_ok": ok_after,
+                      "prefetch_hits": st.stats["hits"] - hits0},
+            "speedup": round(t_before / t_after, 2)}
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,24 +252,23 @@ def main() -> None:
     ap.add_argument("--batch-extra", type=int, default=4,
                     help="also time oq_rtn_quantize_batched_f32 with this many matrices per launch (0/1: skip)")
     ap.add_argument("--no-extras", action="store_true", help="time only the headline configuration (used under rocprofv3)")
+    ap.add_argument("--no-gptq", action="store_true", help="skip the `gptq` object (configs 4 / 5)")
+    ap.add_argument("--no-seam", action="store_true", help="skip the `seam` object")
+    ap.add_argument("--gptq-layers", type=int, default=32)
+    ap.add_argument("--gptq-tokens", type=int, default=128 * 2048)
     ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
+    ap.add_argument("--stub", action="store_true", help="plumbing test on gloo without a GPU (tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # before anything touches a GPU
+        raise SystemExit(self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+    if args.stub:
+        return stub_main(args)
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dev, rank, world = init_ranks(args.gpus)
 
     from onnx_quantize_amd.hip import _lib as L
     lib = L.load()
@@ -201,6 +363,7 @@ def main() -> None:
         for i in range(len(calls)):          # restore the headline layout's outputs for the digest check below
             step(i)
         torch.cuda.synchronize()
+        del oq
 
     # batched entry point: `--batch-extra` matrices per launch (stacked weights); reported separately
     batched = None
@@ -233,30 +396,72 @@ def main() -> None:
                    "achieved_GBs": round(algorithmic_bytes(args.layout) / (per_matrix_us * 1e-6) / 1e9, 1),
                    "frac": round(algorithmic_bytes(args.layout) / (per_matrix_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                    "equals_single_launch_output": same}
+        del wb, qb, sb, zb, bws
 
     t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+    ranks_seen = torch.ones(1, dtype=torch.int32, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks_seen)
     wall, dev_ms = float(t[0]), float(t[1])
+    if int(ranks_seen.item()) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {int(ranks_seen.item())} ranks joined")
+
+    # ---- N > 1: every rank's last result to rank 0 through the RCCL gather north_star names
+    gather = None
+    if world > 1:
+        from onnx_quantize_amd.sharding import LayerSpec, gather_device_results
+
+        specs = [LayerSpec(f"rank{r}.w", K_DIM, N_DIM) for r in range(world)]
+        plan = [[r] for r in range(world)]
+        q, s, z = outs[(args.steps - 1) % len(outs)] if args.steps else outs[0]
+        fence()
+        tg = time.perf_counter()
+        got, nbytes = gather_device_results(specs, plan, {rank: (q, s, z)})
+        fence()
+        tg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        gather = {"collective": "one padded gather to rank 0 (RCCL over xGMI, backend nccl) + a size all_reduce",
+                  "gather_s": round(float(tg[0]), 5), "gather_bytes": int(nbytes), "ranks_seen": int(ranks_seen.item()),
+                  "GBs_into_rank0": round(nbytes * (world - 1) / world / float(tg[0]) / 1e9, 1),
+                  "rank0_result_intact": None if got is None else bool(torch.equal(got["rank0.w"][0], q))}
 
     # ---- verify rank 0's last outputs against the reference digests (asymmetric / symmetric KAT2)
     verified = None
+    digest = None
     if rank == 0:
         with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
-            d = json.load(f)["config2_sym" if args.symmetric else "config2_asym"]
+            digests = json.load(f)
+        digest = digests["config2_sym" if args.symmetric else "config2_asym"]
         q, s, z = outs[(args.steps - 1) % len(outs)] if args.steps else outs[0]
-        ok = sha16(s.cpu().numpy()) == d["s_sha"] and sha16(z.cpu().numpy()) == d["z_sha"]
+        ok = sha16(s.cpu().numpy()) == digest["s_sha"] and sha16(z.cpu().numpy()) == digest["z_sha"]
         if args.qparams_only:
             pass
         elif args.layout == "kn":
-            ok = ok and sha16(q.cpu().numpy()) == d["q_sha"]
+            ok = ok and sha16(q.cpu().numpy()) == digest["q_sha"]
         else:   # unpack the blob back to [K, N] and compare with the same digest
             b = q.cpu().numpy().reshape(N_DIM, K_DIM // GROUP, GROUP // 2)
             full = np.empty((N_DIM, K_DIM // GROUP, GROUP), np.uint8)
             full[..., 0::2] = b & 0x0F
             full[..., 1::2] = b >> 4
-            ok = ok and sha16(np.ascontiguousarray(full.reshape(N_DIM, K_DIM).T)) == d["q_sha"]
+            ok = ok and sha16(np.ascontiguousarray(full.reshape(N_DIM, K_DIM).T)) == digest["q_sha"]
         verified = bool(ok)
+
+    # ---- the seam (host to host) on the same configuration, rank 0 at N = 1
+    seam = None
+    if world == 1 and not args.no_seam and not args.no_extras and not args.symmetric:
+        seam = seam_bench(w_host, digests["config2_asym"])
+
+    # ---- configs 4 / 5: GPTQ of a Llama-2-7B-shaped model from the same run (all ranks take part)
+    del ws, outs, calls, w_src
+    torch.cuda.empty_cache()
+    gptq = None
+    if not args.no_gptq and not args.no_extras:
+        import bench_gptq
+
+        gargs = bench_gptq.build_parser().parse_args(["--gpus", str(world), "--layers", str(args.gptq_layers),
+                                                      "--tokens", str(args.gptq_tokens)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+        gptq = bench_gptq.run(gargs, dev, rank, world)
 
     if rank != 0:
         if world > 1:
@@ -268,11 +473,14 @@ def main() -> None:
     launch_us = dev_ms * 1e3 / max(args.steps, 1)
     alg = algorithmic_bytes(args.layout)
     achieved = alg / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "rtn_pmc_traffic.json")
     if os.path.exists(pmc):
         with open(pmc) as f:
-            traffic = json.load(f).get(args.layout)
+            pj = json.load(f)
+        traffic = pj.get(args.layout)
+        traffic_source = ("stored profile, not measured in this run: " + pj.get("source", "profiles/rtn_pmc_traffic.json (separate rocprofv3 "
+                          "--pmc passes of this command, FETCH_SIZE x2 correction)"))
 
     result = {
         "metric": "M-params quantized/sec, group-128 uint4 RTN on 4096x11008 fp32",
@@ -286,23 +494,24 @@ def main() -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"rtn_quint4_g128_{'sym' if args.symmetric else 'asym'}_4096x11008_f32",
-                   "out_layout": args.layout, "rotating_buffers": len(ws), "matrices_per_step_per_gpu": 1},
+                   "out_layout": args.layout, "rotating_buffers": max(1, args.rotate), "matrices_per_step_per_gpu": 1},
         "verified_vs_reference_digest": verified,
         "batched_launch": batched,
         "other_layout": None if other_us is None else {
             "out_layout": other, "launch_us": round(other_us, 2),
             "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "oq::rtn_group_wave<8,true>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
                      "launch_us": round(launch_us, 2), "launch_us_p10_p50_p90": pct,
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
+        "seam": seam,
+        "gather": gather,
+        "gptq": gptq,
     }
     if world == 1 and not args.no_cpu_baseline:
         base, (cq, cs, cz) = cpu_baseline(w_host)
-        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
-            d = json.load(f)["config2_asym"]
-        base["digest_ok"] = bool(sha16(cq) == d["q_sha"] and sha16(cs) == d["s_sha"])
+        base["digest_ok"] = bool(sha16(cq) == digests["config2_asym"]["q_sha"] and sha16(cs) == digests["config2_asym"]["s_sha"])
         result["cpu_baseline"] = base
     else:
         result["cpu_baseline"] = None

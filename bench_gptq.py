@@ -3,7 +3,9 @@
 QInt4 group 128, on 1..8 MI355X.
 
     python bench_gptq.py [--layers 32 --tokens 262144 --mode parity]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench_gptq.py --gpus N
+    python bench_gptq.py --gpus N            (spawns N ranks itself; or launch it with torch.distributed.run)
+
+`bench.py` runs the same `run()` and reports it as the `gptq` object of its JSON line.
 
 Synthetic data (no network): weights normal(0, 0.02); activations normal * per-channel scale, one set per
 distinct input width generated BEFORE the timed region and reused for every layer (they stand in for the
@@ -17,13 +19,22 @@ HIP streams per rank: one for the Hessians (chip-filling MFMA GEMMs) and `--fact
 factor + loop of successive inputs in turn (latency-bound chains of small launches, side by side and next to the
 Hessian of the following inputs); `--no-overlap` serialises everything on one stream.  `value` is
 parameters / wall time of the timed region (first Hessian launch to the end of the gather, max over ranks).
+
+Correctness of the timed outputs (`verified`): the reference's GPTQ as written emits the RTN integers of the untouched
+weight (SURVEY.md finding 1, pinned by the 104 reference goldens of tests/test_gptq_gpu.py), so for the first layer of
+every distinct shape the integers that were gathered are compared with the fused RTN kernel's on the same weight, and
+one 4096 x 4096 known-answer weight goes through the same GPTQ call and must give the SHA-256 digest the reference's own
+`_rtn_quantize` produced (tests/golden/digests.json, `int4_g128_4096`).
+
 Prints one JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import platform
 import sys
 import time
 
@@ -31,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main() -> None:
+def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--layers", type=int, default=32)
@@ -46,19 +57,60 @@ def main() -> None:
     ap.add_argument("--factor-streams", type=int, default=4,
                     help="streams that take the factor + loop chains of successive inputs in turn (chains of small launches: "
                          "several of them side by side hide each other's launch and diagonal-block latency)")
-    args = ap.parse_args()
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hessian-methods", default="auto,f32",
+                    help="comma list of X^T X kernels to time alone for the roofline objects (auto = split-operand bf16 MFMA)")
+    return ap
 
+
+def cpu_info() -> dict:
+    model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(),
+            "OPENBLAS_NUM_THREADS": os.environ.get("OPENBLAS_NUM_THREADS"), "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")}
+
+
+def cpu_baseline(k: int = 2048, n: int = 2048, tokens: int = 8192) -> dict:
+    """The oracle's `gptq_quantize` (gptq.py:263-324 restated: sgemm Hessian, LAPACK factor, K-step NumPy loop) on a
+    down-scaled layer, timed on the host as the reference would run: one process, NumPy defaults (BLAS threads = all
+    cores, elementwise ops single-threaded).  kind = "port"."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oq_oracle as O
+
+    rng = np.random.default_rng(4)
+    w = (rng.standard_normal((k, n)) * 0.02).astype(np.float32)
+    x = (rng.standard_normal((tokens // 512, 512, k)) * rng.uniform(0.1, 4.0, size=k)).astype(np.float32)
+    t0 = time.perf_counter()
+    q, s, z = O.gptq_quantize(w, x, "int4", "group", 128)
+    dt = time.perf_counter() - t0
+    rq, _, _ = O.rtn_quantize(w, "int4", "group", 128)
+    return {"value": round(k * n / dt / 1e6, 3), "unit": "M-param/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"one {k}x{n} layer, {tokens} calibration tokens (full workload: 224 layers of 4096..11008 wide inputs, "
+                      f"262144 tokens), oracle gptq_quantize once, {dt:.2f} s; BLAS / LAPACK parts multi-threaded, the K-step loop "
+                      f"single-threaded NumPy",
+            "seconds": round(dt, 3), "integers_equal_rtn": bool(np.array_equal(q, rq)), **cpu_info()}
+
+
+def _sha16(a) -> str:
+    import numpy as np
+
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+def run(args, dev, rank: int, world: int):
+    """The timed model run on an initialised rank (process group up when world > 1).  Returns the result dict on rank 0."""
+    import numpy as np
     import torch
     import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
     from onnx_quantize_amd.hip import ops
     from onnx_quantize_amd.sharding import gather_device_results, llama2_7b_specs, plan_lpt
@@ -105,7 +157,7 @@ def main() -> None:
 
     s_h = torch.cuda.Stream(device=dev)
     q_streams = [s_h] if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
-    results, timings = {}, []
+    results, timings, samples = {}, [], {}
     fence()
     t0 = time.perf_counter()
     for gi, (key, members) in enumerate(groups):
@@ -137,6 +189,8 @@ def main() -> None:
                 results[i] = (ops.pack_nibbles(q), s, z)               # 0.5 B / param on the wire
                 e5.record()
                 timings.append(("l", e4, e5))
+                if (sp.k, sp.n) not in samples:                         # first layer of every shape: verified after the clock stops
+                    samples[(sp.k, sp.n)] = (i, w)
     torch.cuda.synchronize()
     t_quant = time.perf_counter() - t0
     fence()
@@ -149,7 +203,37 @@ def main() -> None:
     t_f = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "f")
     t_l = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "l")
 
-    # outside the timed region: the Hessian kernel that just ran against float64 (a 256-column strip of one input)
+    # ---- outside the timed region: what was emitted against the fused RTN kernel and the reference's digest
+    verify = {"mode": args.mode, "shapes": [], "kat_4096_digest_ok": None}
+    ok = True
+    for (k, n), (i, w) in sorted(samples.items()):
+        packed = results[i][0]
+        rq, rs, rz = ops.rtn_quantize(w, "int4", "group", 128)
+        same_q = bool(torch.equal(packed, ops.pack_nibbles(rq)))
+        same_z = bool(torch.equal(results[i][2].reshape(-1), rz.reshape(-1)))
+        rel = float(((results[i][1].reshape(-1) - rs.reshape(-1)).abs() / rs.reshape(-1)).max())
+        verify["shapes"].append({"k": k, "n": n, "layer": specs[i].name, "integers_equal_rtn": same_q, "zero_points_equal_rtn": same_z,
+                                 "scale_max_rel_diff_vs_rtn": rel})
+        if args.mode == "parity":
+            ok = ok and same_q and rel <= 1e-5
+    if rank == 0 and args.mode == "parity" and args.hidden == 4096:
+        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+            d = json.load(f)["int4_g128_4096"]
+        wk = torch.from_numpy(np.random.default_rng(d["seed"]).standard_normal((4096, 4096), dtype=np.float32)).to(dev)
+        hk = torch.zeros((4096, 4096), device=dev)
+        xk = torch.randn((8, 512, 4096), device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+        ops.hessian_accumulate(xk, hk, 0)
+        qk, sk, zk, _ = ops.gptq_quantize(wk, hk, "int4", "group", 128, mode="parity")
+        verify["kat_4096_digest_ok"] = bool(_sha16(qk.cpu().numpy()) == d["q_sha"])
+        verify["kat_4096_zero_point_digest_ok"] = bool(_sha16(zk.cpu().numpy()) == d["z_sha"])
+        ok = ok and verify["kat_4096_digest_ok"]
+        del wk, hk, xk
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    verify["verified"] = bool(int(flag.item())) if args.mode == "parity" else None
+
+    # the Hessian kernel that just ran against float64 (a 256-column strip of one input)
     hcheck = None
     if rank == 0:
         kc = min(acts)
@@ -167,62 +251,90 @@ def main() -> None:
                   "max_abs_err_over_max_abs_h": float((hc[:256].double() - ref).abs().max() / ref.abs().max()),
                   "exactly_symmetric": bool(torch.equal(hc, hc.T))}
         del hc, ref
-    # and its rate alone (no other stream active): one batch of the widest input, events on the current stream
-    roof = None
+    # and its rate alone (no other stream active): one batch of the widest input, per requested kernel
+    roofs = []
     if rank == 0:
         kw = max(acts)
         xw = acts[kw][0]
         hw = torch.zeros((kw, kw), device=dev)
-        ops.hessian_accumulate(xw, hw, 0)
-        torch.cuda.synchronize()
-        e0, e1 = ev(), ev()
-        e0.record()
-        reps = 3
-        for _ in range(reps):
-            ops.hessian_accumulate(xw, hw, xw.shape[0])
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        t_rows = xw.shape[0] * xw.shape[1]
-        tiles = (kw + 255) // 256
-        fp32_equiv = 2.0 * t_rows * (tiles * (tiles + 1) // 2) * 256 * 256          # upper 256 x 256 tiles, as executed
-        method = ops.hessian_method()
-        split = method != "f32" and kw >= 1024
-        terms = 9 if method == "bf16x9" else 6
-        roof = {"bound": "mfma", "kernel": "oq::syrk_pieces_kernel<%d>" % terms if split else "oq::gemm_tn_kernel",
-                "achieved": round(fp32_equiv * (terms if split else 1) / ms / 1e9, 1), "peak": 2500.0 if split else 157.3,
-                "unit": "TFLOP/s", "dtype": "bf16 pieces, fp32 accumulate" if split else "f32",
-                "fp32_equivalent_TFLOPs": round(fp32_equiv / ms / 1e9, 1), "call_ms": round(ms, 2), "k": kw, "rows": t_rows,
-                "traffic": None}
-        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        saved = ops.hessian_method()
+        for method in [m for m in args.hessian_methods.split(",") if m]:
+            ops.hessian_set_method(method)
+            ops.hessian_accumulate(xw, hw, 0)
+            torch.cuda.synchronize()
+            e0, e1 = ev(), ev()
+            e0.record()
+            reps = 3
+            for _ in range(reps):
+                ops.hessian_accumulate(xw, hw, xw.shape[0])
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            t_rows = xw.shape[0] * xw.shape[1]
+            split = method != "f32" and kw >= 1024
+            tiles = (kw + (255 if split else 127)) // (256 if split else 128)
+            edge = 256 if split else 128
+            fp32_equiv = 2.0 * t_rows * (tiles * (tiles + 1) // 2) * edge * edge          # upper tiles, as executed
+            terms = 9 if method == "bf16x9" else 6
+            roof = {"bound": "mfma", "method": method,
+                    "kernel": "oq::syrk_pieces_kernel<%d> (+ split / reduce)" % terms if split else "oq::gemm_tn_kernel",
+                    "achieved": round(fp32_equiv * (terms if split else 1) / ms / 1e9, 1), "peak": 2500.0 if split else 157.3,
+                    "unit": "TFLOP/s", "dtype": "bf16 pieces of fp32 operands, fp32 accumulate" if split else "f32",
+                    "fp32_equivalent_TFLOPs": round(fp32_equiv / ms / 1e9, 1), "call_ms": round(ms, 2), "k": kw, "rows": t_rows,
+                    "traffic": None}
+            roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+            roofs.append(roof)
+        ops.hessian_set_method(saved)
         del hw
 
     stats = torch.tensor([wall, t_quant, t_gather, t_h, t_f, t_l], dtype=torch.float64, device=dev)
+    ranks_seen = torch.ones(1, dtype=torch.int32, device=dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ranks_seen)
+    if rank != 0:
+        return None
+    params = sum(s.k * s.n for s in specs)
+    assert gathered is not None and len(gathered) == len(specs)
+    wall = float(stats[0])
+    flops_exec = float(sum(args.tokens * specs[i].k ** 2 for i in {specs[j].hessian_key: j for j in range(len(specs))}.values()))
+    out = {
+        "metric": "M-params quantized/sec, GPTQ QInt4 group-128, Llama-2-7B MatMul weights",
+        "value": round(params / wall / 1e6, 2), "unit": "M-param/s", "n_gpus": world, "ranks_seen": int(ranks_seen.item()),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
+                   "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
+                   "streams": 1 if args.no_overlap else 1 + len(q_streams), "hessian_method": ops.hessian_method()},
+        "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
+                    "gather": round(float(stats[2]), 4),
+                    # per-phase device time (with several streams the phases overlap: their sum exceeds the wall time)
+                    "hessian_ms_max_rank": round(float(stats[3]), 1),
+                    "factor_ms_max_rank": round(float(stats[4]), 1), "loop_ms_max_rank": round(float(stats[5]), 1)},
+        "gather_bytes": nbytes,
+        "hessian_flops_executed": flops_exec,
+        "hessian_check_vs_float64": hcheck,
+        "verified": verify["verified"], "verification": verify,
+        "roofline": roofs[0] if roofs else None,
+        "roofline_by_method": roofs,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    return out
+
+
+def main() -> None:
+    args = build_parser().parse_args()
+    from bench import init_ranks, self_launch
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+    dev, rank, world = init_ranks(args.gpus)
+    res = run(args, dev, rank, world)
     if rank == 0:
-        params = sum(s.k * s.n for s in specs)
-        assert gathered is not None and len(gathered) == len(specs)
-        wall = float(stats[0])
-        flops_exec = float(sum(args.tokens * specs[i].k ** 2 for i in {specs[j].hessian_key: j for j in range(len(specs))}.values()))
-        print(json.dumps({
-            "metric": "M-params quantized/sec, GPTQ QInt4 group-128, Llama-2-7B MatMul weights",
-            "value": round(params / wall / 1e6, 2), "unit": "M-param/s", "n_gpus": world,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
-                       "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
-                       "streams": 1 if args.no_overlap else 1 + len(q_streams), "hessian_method": ops.hessian_method()},
-            "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
-                        "gather": round(float(stats[2]), 4),
-                        # per-phase device time (with two streams the phases overlap: their sum exceeds the wall time)
-                        "hessian_ms_max_rank": round(float(stats[3]), 1),
-                        "factor_ms_max_rank": round(float(stats[4]), 1), "loop_ms_max_rank": round(float(stats[5]), 1)},
-            "gather_bytes": nbytes,
-            "hessian_flops_executed": flops_exec,
-            "hessian_check_vs_float64": hcheck,
-            "roofline": roof,
-        }))
+        print(json.dumps(res))
     if world > 1:
+        import torch.distributed as dist
+
         dist.destroy_process_group()
 
 

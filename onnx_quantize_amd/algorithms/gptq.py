@@ -91,7 +91,9 @@ def _gptq_quantize(weights, inputs, quant_type=QuantType.QInt8, strategy=Quantiz
                                       bool(actorder), bool(mse), mode=mode)
     if int(info.item()) != 0:                                              # :143-150
         logger.warning(_FALLBACK_WARNING)
-    q_np = q.cpu().numpy().astype(quant_type.np_dtype, copy=False)
+    from ..staging import download
+
+    q_np = download(q).astype(quant_type.np_dtype, copy=False)
     scale = s.cpu().numpy().astype(np.float32, copy=False)                 # :238
     zp = z.cpu().numpy().astype(q_np.dtype, copy=False)                    # :239
     return q_np, scale, zp

@@ -73,5 +73,7 @@ def _hqq_quantize(w_f: np.ndarray, quant_type: QuantType, group_size: int, reduc
     wd = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).cuda()
     q, s, z, _ = ops.hqq_quantize(wd, -1 if group_size is None else group_size, bool(reduce_range), float(clip_ratio), bool(mse),
                                   float(lp_norm), float(beta), float(kappa), int(iters), bool(early_stop))
-    q_np = q.cpu().numpy().astype(quant_type.np_dtype, copy=False)
+    from ..staging import download
+
+    q_np = download(q).astype(quant_type.np_dtype, copy=False)
     return q_np, s.cpu().numpy().astype(scale_dtype, copy=False), z.cpu().numpy().astype(zp_dtype, copy=False)

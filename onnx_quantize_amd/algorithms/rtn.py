@@ -44,9 +44,11 @@ def _rtn_quantize(array: np.ndarray, quant_type: QuantType, strategy: Quantizati
     if w.ndim != 2:
         w = w.reshape(1, -1) if strategy == QuantizationStrategy.TENSOR else w.reshape(w.shape[0], -1)
     wd = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).cuda()
+    from ..staging import download
+
     q, s, z = ops.rtn_quantize(wd, quant_type.key, strategy.value, -1 if group_size is None else group_size,
                                bool(is_symmetric), bool(reduce_range), float(clip_ratio), bool(mse))
-    q_np = q.cpu().numpy().reshape(np.shape(array)).astype(quant_type.np_dtype, copy=False)
+    q_np = download(q).reshape(np.shape(array)).astype(quant_type.np_dtype, copy=False)
     scale = s.cpu().numpy().astype(scale_dtype, copy=False)
     zp = z.cpu().numpy().astype(zp_dtype, copy=False)
     return q_np, scale, zp

@@ -1,0 +1,178 @@
+"""The reference's single call site of the numeric hot path, device resident (reference: qrules/_common.py:126-142).
+
+``quantize_weights(op, w, qconfig, out, is_matmul_nbits_compatible)`` is what every rewrite rule of the reference calls
+(qrules/_qdq/matmul_to_qmatmul.py:41,59,93,108; _qdq/gemm_to_qgemm.py; _qlinear/*.py).  As written it runs the algorithm
+plugin NumPy -> NumPy and then, for MatMulNBits, repacks the result in NumPy (`_prepare_for_matmul_nbits`, :65-123).
+Behind the same signature this module keeps the weight in HBM from upload to the final wire format:
+
+    upload once (on demand or prefetched from a worker thread, staging.py)
+      -> RTN | GPTQ | HQQ kernels on the device
+      -> MatMulNBits blob written by the kernel epilogue (RTN, HQQ) or by oq_pack_matmul_nbits (GPTQ, RTN + mse)
+      -> zero points nibble-packed by oq_pack_zero_points_u4
+      -> ONE download of exactly the three arrays the reference would have handed to `op.initializer`.
+
+`weight_arrays` returns those three arrays; `quantize_weights` wraps them into initializers like the reference.  It works
+on this package's config classes and, after `integration.install_into_reference()`, on the reference's own (same field
+names); an algorithm plugin this package does not know keeps the reference's NumPy route.
+"""
+from __future__ import annotations
+
+import logging
+
+import numpy as np
+
+__all__ = ["quantize_weights", "weight_arrays", "prefetch_model_weights"]
+
+logger = logging.getLogger(__name__)
+
+_GPTQ_FALLBACK_WARNING = (
+    "Failed to invert hessian due to numerical instability. Consider increasing percdamp, increasing the "
+    "number of calibration samples, or shuffling the calibration dataset. Falling back to round-to-nearest "
+    "for this module.")
+
+
+def _key(qtype) -> str:
+    """"QUInt4" -> "uint4" for this package's QuantType and the reference's alike."""
+    return qtype.name[1:].lower()
+
+
+def _strategy(s) -> str:
+    return s.value if hasattr(s, "value") else str(s)
+
+
+def _upload(name, array):
+    from .staging import default_stager
+
+    return default_stager().take(name, array)
+
+
+def _host(t, dtype=None):
+    from .staging import download
+
+    return download(t, dtype)
+
+
+def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool):
+    """Run the configured algorithm on the device.  Returns (q, scale, zp, is_blob) as device tensors -- q is the
+    MatMulNBits blob when the algorithm's kernel wrote it directly -- or None for an algorithm this package has no
+    kernels for."""
+    import torch
+
+    from .hip import ops
+
+    a = qconfig.weights
+    algo = a.algorithm
+    tag = getattr(algo, "algorithm_type", None)
+    qt, st = _key(a.dtype), _strategy(a.strategy)
+    g = -1 if a.group_size is None else a.group_size
+    k = w_dev.shape[0]
+    if tag == "rtn":
+        blob = want_blob and not a.mse and k % ops.resolve_group(st, k, g) == 0
+        q, s, z = ops.rtn_quantize(w_dev, qt, st, g, bool(a.symmetric), bool(a.reduce_range), float(a.clip_ratio), bool(a.mse),
+                                   layout="nbits" if blob else "kn")
+        return q, s, z, blob
+    if tag == "hqq":
+        assert a.zp_dtype == a.scale_dtype                                          # hqq.py:175
+        if qt != "uint4":
+            raise ValueError("the GPU HQQ path implements the reference's only legal configuration: uint4")
+        blob = want_blob and k % ops.resolve_group("group", k, g) == 0
+        q, s, z, _ = ops.hqq_quantize(w_dev, g, bool(a.reduce_range), float(a.clip_ratio), bool(a.mse), float(algo.lp_norm),
+                                      float(algo.beta), float(algo.kappa), int(algo.iters), bool(algo.early_stop),
+                                      layout="nbits" if blob else "kn")
+        return q, s, z, blob
+    if tag == "gptq":
+        assert out is not None, "Output value is required for GPTQ quantization."      # gptq.py:54
+        node = out.producer()
+        assert "input" in node.meta, "GPTQ requires calibration data in node meta."    # gptq.py:56
+        x = node.meta["input"]
+        h = torch.zeros((k, k), dtype=torch.float32, device=w_dev.device)
+        n = 0
+        batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
+        for b in batches:
+            xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
+            n = ops.hessian_accumulate(xb.to(w_dev.device, torch.float32), h, n)
+        q, s, z, info = ops.gptq_quantize(w_dev, h, qt, st, a.group_size, bool(a.symmetric), bool(a.reduce_range),
+                                          float(a.clip_ratio), int(algo.block_size), float(algo.percdamp), bool(algo.actorder),
+                                          bool(a.mse), mode=getattr(algo, "mode", "parity"))
+        if int(info.item()) != 0:                                                     # gptq.py:143-150
+            logger.warning(_GPTQ_FALLBACK_WARNING)
+        return q, s, z, False
+    return None
+
+
+def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False):
+    """The three NumPy arrays `qrules/_common.py:133-137` produces for weight value ``w``: what
+    ``algorithm.quantize_weights`` returns (rtn.py:106-109 shapes: q [K, N]; scale / zero point 0-d | [N] | [N*K/g, 1]) or,
+    with ``is_matmul_nbits_compatible``, what `_prepare_for_matmul_nbits` makes of it (B uint8 [N, K/g, g*bits/8], scales
+    [N, K/g], zero points uint8 [N, ceil(K/g / 2)] nibble-packed | [N, K/g])."""
+    from .hip import ops
+
+    a = qconfig.weights
+    w_np = w.const_value.numpy()
+    res = None
+    if w_np.ndim == 2 and getattr(a.algorithm, "algorithm_type", None) in ("rtn", "hqq", "gptq"):
+        res = _device_algorithm(_upload(w.name, w_np), w.name, qconfig, out, is_matmul_nbits_compatible)
+    if res is None:        # an algorithm plugin without kernels here: its own NumPy route, then the wire format on the GPU
+        w_q, w_scale, w_zp = a.algorithm.quantize_weights(w, qconfig, out=out)
+        if is_matmul_nbits_compatible:
+            from .wire_format import _prepare_for_matmul_nbits
+
+            w_q, w_scale, w_zp = _prepare_for_matmul_nbits(w_q, w_scale, w_zp, qconfig)
+        return w_q, w_scale, w_zp
+
+    q, s, z, is_blob = res
+    qdt = a.dtype.np_dtype
+    if not is_matmul_nbits_compatible:
+        return _host(q, qdt), _host(s, a.scale_dtype), _host(z, a.zp_dtype)
+
+    # qrules/_common.py:65-123 on the device
+    k, n = w_np.shape
+    bits = a.dtype.bitwidth
+    g = a.group_size
+    assert k % g == 0                                                                 # _common.py:72
+    blocks = k // g
+    if not is_blob:
+        q = ops.pack_matmul_nbits(q, g, bits)
+    float_zp = np.dtype(a.zp_dtype) == np.dtype(a.scale_dtype)                        # HQQ: zero points stay floats (:96-99)
+    if bits == 4 and blocks > 1 and not float_zp:
+        z = ops.pack_zero_points_u4(z.reshape(-1), n, blocks)
+    blob = _host(q)
+    scale = _host(s, a.scale_dtype).reshape(-1, blocks)
+    zp = _host(z).reshape(n, -1).astype(a.zp_dtype if float_zp else np.uint8, copy=False)
+    if bits != 4:
+        blob = blob.astype(qdt, copy=False)
+    return blob, scale, zp
+
+
+def quantize_weights(op, w, qconfig, out=None, is_matmul_nbits_compatible: bool = False):
+    """qrules/_common.py:126-142, same signature and same three initializers (`w`, `w/scale`, `w/zero_point`)."""
+    import onnx_ir as ir
+
+    w_q, w_scale, w_zero_point = weight_arrays(w, qconfig, out, is_matmul_nbits_compatible)
+    w_q = op.initializer(ir.tensor(w_q), name=w.name)
+    w_scale = op.initializer(ir.tensor(w_scale), name=f"{w.name}/scale")
+    w_zero_point = op.initializer(ir.tensor(w_zero_point), name=f"{w.name}/zero_point")
+    return w_q, w_scale, w_zero_point
+
+
+def prefetch_model_weights(model, op_types=("MatMul", "Gemm")) -> int:
+    """Start uploading every constant weight the rewrite rules are going to quantize (nodes stamped with a `qconfig` by the
+    pre-passes, pre_passes/__init__.py:17-26; weight = input 1 with a constant 2-D fp32 value) in graph order.  Returns the
+    number of weights queued.  Called between the pre-passes and the rewrite (integration.py)."""
+    from .staging import default_stager
+
+    items, seen = [], set()
+    for node in model.graph:
+        if node.op_type not in op_types or node.meta.get("qconfig") is None or len(node.inputs) < 2:
+            continue
+        v = node.inputs[1]
+        c = getattr(v, "const_value", None)
+        if c is None or v.name in seen:
+            continue
+        a = c.numpy()
+        if a.ndim == 2 and a.dtype == np.float32:
+            seen.add(v.name)
+            items.append((v.name, a))
+    if items:
+        default_stager().prefetch(items)
+    return len(items)

@@ -1,0 +1,184 @@
+"""Host <-> HBM staging for the plugin seam (reference: qrules/_common.py:126-142, which hands the algorithm a NumPy
+weight and takes NumPy results back).
+
+The fused RTN kernel needs 42 us for a 4096 x 11008 weight; moving the same weight over PCIe needs 3.2 ms (56 GB/s on
+the MI355X host, `scripts/quick_staging.py`: pageable NumPy memory already moves at the pinned rate there and
+`hipHostRegister` is free, so no staging copy is made -- a page-locked bounce buffer costs a 0.7-9.6 ms memcpy on top and
+17 ms per allocation).  What is left to remove is the SERIALISATION of upload, kernels and download:
+
+* :meth:`WeightStager.prefetch` takes the whole list of weights a model is going to hand to the seam -- known as soon as
+  the pre-passes are done -- and uploads them from a worker thread on a side stream while the main thread quantizes, so
+  weight i+1 travels while weight i is being computed / downloaded.  288 GB of HBM hold every weight of a 7B model
+  (26 GB); the in-flight budget is bounded by ``max_ahead_bytes`` anyway.
+* downloads are cut into pieces of 16 MB (:func:`download`): one 45 MB pageable device-to-host copy runs at 8.5 GB/s on
+  that host, 22.5 MB and smaller ones at 53 GB/s.
+
+Nothing here computes anything: torch is used for device memory, streams and events only.
+"""
+from __future__ import annotations
+
+import threading
+from collections import OrderedDict
+
+import numpy as np
+
+__all__ = ["WeightStager", "default_stager", "upload", "download"]
+
+
+def _identity(a: np.ndarray):
+    """What has to be unchanged for a prefetched copy to still stand for the array: shape, dtype and a strided sample of
+    512 elements (a pass that rescales or replaces a weight between `prefetch` and `take` changes the sample; the sample
+    costs microseconds, a full comparison would cost more than the upload it saves)."""
+    flat = a.reshape(-1) if a.flags.c_contiguous else np.ascontiguousarray(a).reshape(-1)
+    step = max(1, flat.size // 512)
+    return (a.shape, a.dtype.str, flat[::step][:512].tobytes(), flat[-1:].tobytes())
+
+
+class WeightStager:
+    """Uploads of fp32 weights on a side stream, optionally ahead of time from a worker thread."""
+
+    def __init__(self, device=None, max_ahead_bytes: int = 16 << 30):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("WeightStager needs a GPU: the HIP path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_ahead_bytes = int(max_ahead_bytes)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._ready: "OrderedDict[str, tuple]" = OrderedDict()      # name -> (identity, device tensor, event)
+        self._cv = threading.Condition()
+        self._ahead = 0
+        self._pending: set = set()                                   # names the worker has not uploaded yet
+        self._worker = None
+        self._stop = False
+        self.stats = {"prefetched": 0, "hits": 0, "misses": 0, "stale": 0}
+
+    # ------------------------------------------------------------------ one upload
+    def _upload(self, a: np.ndarray, stream):
+        """fp32 C-contiguous copy of `a` in HBM, issued on `stream`; the event marks its arrival."""
+        import torch
+
+        src = np.ascontiguousarray(a, dtype=np.float32)
+        with torch.cuda.stream(stream):
+            dev = torch.from_numpy(src).to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return dev, ev
+
+    def upload(self, a: np.ndarray):
+        """Upload now, ordered on the CURRENT stream (no prefetch)."""
+        import torch
+
+        dev, _ = self._upload(a, torch.cuda.current_stream(self.device))
+        return dev
+
+    # ------------------------------------------------------------------ prefetch
+    def prefetch(self, named_arrays) -> None:
+        """Start uploading ``[(name, ndarray), ...]`` in order from a worker thread.  Returns immediately."""
+        items = [(str(k), v) for k, v in named_arrays]
+        self.cancel()
+        self._stop = False
+        self._pending = {k for k, _ in items}
+        self._worker = threading.Thread(target=self._run, args=(items,), name="oq-weight-stager", daemon=True)
+        self._worker.start()
+
+    def _run(self, items) -> None:
+        import torch
+
+        torch.cuda.set_device(self.device)
+        for name, a in items:
+            nbytes = int(np.prod(a.shape)) * 4
+            with self._cv:
+                while not self._stop and self._ahead > 0 and self._ahead + nbytes > self.max_ahead_bytes:
+                    self._cv.wait(0.05)
+                if self._stop:
+                    return
+            ident = _identity(a)
+            dev, ev = self._upload(a, self._stream)
+            with self._cv:
+                self._ready[name] = (ident, dev, ev)
+                self._pending.discard(name)
+                self._ahead += nbytes
+                self.stats["prefetched"] += 1
+                self._cv.notify_all()
+
+    def take(self, name: str, a: np.ndarray):
+        """The HBM copy of weight `name`: the prefetched one when it is (still) about the same array, else a fresh
+        upload.  The returned tensor is ready on the current stream."""
+        import torch
+
+        hit = None
+        with self._cv:
+            # a prefetch that is still on its way to this name: wait for the worker instead of uploading twice
+            while name in self._pending and name not in self._ready and self._worker is not None and self._worker.is_alive():
+                self._cv.wait(0.05)
+            hit = self._ready.pop(name, None)
+            if hit is not None:
+                self._ahead -= hit[1].numel() * 4
+                self._cv.notify_all()
+        if hit is not None:
+            ident, dev, ev = hit
+            if ident == _identity(a):
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                dev.record_stream(cur)                   # allocated on the worker's stream, consumed on this one
+                self.stats["hits"] += 1
+                return dev
+            self.stats["stale"] += 1
+        self.stats["misses"] += 1
+        return self.upload(a)
+
+    def cancel(self) -> None:
+        """Stop a running prefetch and drop what it uploaded."""
+        w = self._worker
+        if w is not None and w.is_alive():
+            with self._cv:
+                self._stop = True
+                self._cv.notify_all()
+            w.join()
+        self._worker = None
+        with self._cv:
+            self._ready.clear()
+            self._pending = set()
+            self._ahead = 0
+
+
+_DEFAULT: dict = {}
+_DEFAULT_LOCK = threading.Lock()
+
+
+def default_stager() -> WeightStager:
+    """Process-wide stager of the current device (created on first use)."""
+    import torch
+
+    idx = torch.cuda.current_device()
+    with _DEFAULT_LOCK:
+        st = _DEFAULT.get(idx)
+        if st is None:
+            st = _DEFAULT[idx] = WeightStager(torch.device("cuda", idx))
+        return st
+
+
+def upload(a: np.ndarray):
+    """fp32 C-contiguous copy of `a` in HBM on the current stream."""
+    return default_stager().upload(a)
+
+
+_CHUNK = 16 << 20
+
+
+def download(t, dtype=None) -> np.ndarray:
+    """Device tensor -> NumPy array, in pieces of 16 MB (see the module docstring), optionally viewed as `dtype`."""
+    import torch
+
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes <= 2 * _CHUNK:
+        a = t.cpu().numpy()
+    else:
+        a = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+        dst = torch.from_numpy(a).view(-1).view(torch.uint8)
+        src = t.view(-1).view(torch.uint8)
+        for o in range(0, nbytes, _CHUNK):
+            dst[o:o + _CHUNK].copy_(src[o:o + _CHUNK])
+    return a if dtype is None else a.astype(dtype, copy=False)

@@ -797,6 +797,96 @@ def gen_seam(out):
     print(f"seam: {len(cases)} cases")
 
 
+def _load_common():
+    """qrules/_common.py with the carriers of `_load_passes` (its package __init__ pulls in onnxscript and is bypassed)."""
+    _load_passes()
+    ir = sys.modules["onnx_ir"]
+    ir.Model = ir.Node = ir.Value = object
+    ir.tape = types.SimpleNamespace(Tape=object)
+    if "onnx_quantize.qrules" not in sys.modules:
+        qr = types.ModuleType("onnx_quantize.qrules")
+        qr.__path__ = [os.path.join(REF, "qrules")]
+        sys.modules["onnx_quantize.qrules"] = qr
+    return importlib.import_module("onnx_quantize.qrules._common")
+
+
+class RecordingTape:
+    """The `op` a rewrite rule receives, reduced to what the seam touches: `initializer(tensor, name=)` records the array."""
+
+    def __init__(self):
+        self.initializers = []
+
+    def initializer(self, tensor, name=None):
+        ir = sys.modules["onnx_ir"]
+        self.initializers.append((name, np.asarray(tensor.numpy())))
+        return ir.val(name, tensor)
+
+
+def gen_seam_qw(out):
+    """The ONE function every rewrite rule calls: qrules/_common.py::quantize_weights(op, w, qconfig, out,
+    is_matmul_nbits_compatible) -- algorithm plugin + `_prepare_for_matmul_nbits` + the three `op.initializer` calls --
+    run unmodified on a recording tape; `is_matmul_nbits_compatible` is decided by the reference's own predicate and
+    the group size resolved by its `_resolve_group_size`, as `QRewriter._rewrite` / `_rewrite_weights_only` do
+    (qrules/base.py:72, _qdq/matmul_to_qmatmul.py:84-88)."""
+    common = _load_common()
+    ir = sys.modules["onnx_ir"]
+    Q = R.qconfig
+    cases, arrays = [], {}
+    grid = [  # (algorithm, seed, k, n, kwargs of QWeightArgs, kwargs of the algorithm config)
+        ("rtn", 1, 128, 24, dict(dtype="uint4", group_size=32), {}),
+        ("rtn", 2, 80, 9, dict(dtype="uint4", group_size=16), {}),                      # odd number of blocks: 0x8 pad nibble
+        ("rtn", 3, 128, 10, dict(dtype="uint4", group_size=128), {}),                   # one block: zero points not packed
+        ("rtn", 4, 128, 6, dict(dtype="uint8", group_size=64), {}),
+        ("rtn", 5, 96, 8, dict(dtype="uint4", group_size=256), {}),                     # resolved to K = 96: not a power of two, still flagged by the caller's predicate on the ORIGINAL size
+        ("rtn", 6, 100, 12, dict(dtype="uint4", group_size=32), {}),                    # 32 does not divide 100 -> K
+        ("rtn", 7, 64, 16, dict(dtype="uint4", group_size=-1), {}),                     # -1 passes the predicate and breaks the packer
+        ("rtn", 8, 128, 24, dict(dtype="int4", group_size=64, symmetric=True, clip_ratio=0.9), {}),
+        ("rtn", 9, 96, 40, dict(dtype="int8", strategy="channel"), {}),
+        ("rtn", 10, 64, 48, dict(dtype="uint8"), {}),
+        ("rtn", 11, 256, 16, dict(dtype="uint4", group_size=64, symmetric=True), {}),
+        ("gptq", 12, 64, 32, dict(dtype="uint4", group_size=32), dict(block_size=32)),
+        ("gptq", 13, 96, 20, dict(dtype="int4", group_size=32), {}),
+        ("hqq", 14, 128, 20, dict(dtype="uint4", group_size=32, strategy="group"), dict(iters=10)),
+        ("hqq", 15, 64, 12, dict(dtype="uint4", group_size=64, strategy="group"), {}),
+        ("rtn", 17, 64, 8, dict(dtype="uint4", group_size=128), {}),                     # oversize group resolved to K = 64, a power of two
+        ("rtn", 18, 64, 8, dict(dtype="uint8", group_size=16, reduce_range=True), {}),
+    ]
+    algos = {"rtn": None, "gptq": R.gptq.GPTQConfig, "hqq": R.hqq.HqqConfig}
+    for idx, (al, seed, k, n, wkw, akw) in enumerate(grid):
+        w = weight("normal", seed, k, n) * np.float32(0.1)
+        rng = np.random.default_rng(seed + 100)
+        x = (rng.standard_normal((6, 10, k)) * rng.uniform(0.3, 3.0, size=k)).astype(np.float32)
+        kw = {**wkw, "dtype": QT[wkw["dtype"]]}
+        if algos[al] is not None:
+            kw["algorithm"] = algos[al](**akw)
+        qc = Q.QConfig(weights=Q.QWeightArgs(**kw))
+        wv = ir.val("fc.weight", ir.tensor(w))
+        qc.weights.group_size = common._resolve_group_size(wv, qc.weights.group_size)        # qrules/base.py:72
+        flagged = bool(common.is_matmul_nbits_compatible(qc, wv.name))
+        node = types.SimpleNamespace(meta={"input": x})
+        outv = types.SimpleNamespace(producer=lambda node=node: node)
+        tape = RecordingTape()
+        key = f"c{idx}"
+        arrays[key + "_w"], arrays[key + "_x"] = w, x
+        case = dict(key=key, algorithm=al, weights=wkw, config=akw, k=k, n=n, resolved_group_size=qc.weights.group_size, flagged=flagged)
+        try:
+            common.quantize_weights(tape, wv, qc, outv, is_matmul_nbits_compatible=flagged)
+        except Exception as e:  # noqa: BLE001 -- the exception class is the recorded behaviour
+            case["raises"] = type(e).__name__
+            cases.append(case)
+            continue
+        case["initializers"] = []
+        for j, (name, a) in enumerate(tape.initializers):
+            store = a.astype(np.float32) if a.dtype.kind == "f" else a.astype(np.int32)
+            arrays[f"{key}_i{j}"] = store
+            case["initializers"].append(dict(name=name, shape=list(a.shape), dtype=str(a.dtype)))
+        cases.append(case)
+    np.savez_compressed(os.path.join(out, "seam_qw.npz"), **arrays)
+    with open(os.path.join(out, "seam_qw.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=1)
+    print(f"seam_qw: {len(cases)} cases ({sum('raises' in c for c in cases)} raising)")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -841,7 +931,7 @@ def gen_digests(out):
 def main():
     out = HERE
     gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
-                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, seam=gen_seam, digests=gen_digests)
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, seam=gen_seam, seam_qw=gen_seam_qw, digests=gen_digests)
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],

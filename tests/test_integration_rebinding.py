@@ -94,3 +94,54 @@ def test_signatures_of_the_swapped_functions_match(reference_modules):
     for name in ("_compute_qparams", "_quantize_array_from_qparams", "_dequantize_array", "_fake_quantize_array", "_compute_min_max",
                  "_compute_qparams_from_array", "_preprocess_array", "_post_process_array"):
         assert [p for p, _ in params(getattr(F, name))] == [p for p, _ in params(getattr(ref_utils, name))], name
+
+
+def test_install_rebinds_the_seam_function_and_keeps_extensions(reference_modules):
+    """`qrules/_common.py::quantize_weights` (the function every rule module imports by name) is replaced by the device
+    resident seam; the GPTQ `mode` extension survives the dump -> registry round trip of `quantize()`
+    (pre_passes/__init__.py:23, qrules/base.py:57); the ROCm execution providers are accepted by the reference's
+    CalibrationParams after the install."""
+    import inspect
+
+    import onnx_quantize.core._calibration.base as ref_base
+    import onnx_quantize.core._qconfig as ref_cfg
+
+    from onnx_quantize_amd import integration, seam
+
+    common = reference_modules._load_common()
+    original = common.quantize_weights
+    assert original.__module__ == "onnx_quantize.qrules._common"
+    rebound = integration.install_into_reference()
+    assert "onnx_quantize.qrules._common" in rebound["quantize_weights"]
+    assert common.quantize_weights is seam.quantize_weights
+    assert list(inspect.signature(seam.quantize_weights).parameters) == list(inspect.signature(original).parameters)
+    assert [p.default for p in inspect.signature(seam.quantize_weights).parameters.values()] == \
+           [p.default for p in inspect.signature(original).parameters.values()]
+    # every rule module the reference ships imports that name: the list in integration.py is complete
+    import os
+    import re
+    users = []
+    for root, _, files in os.walk(os.path.join(REF, "qrules")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"import .*\bquantize_weights\b|^def quantize_weights", open(os.path.join(root, f)).read(), re.M):
+                rel = os.path.relpath(os.path.join(root, f), os.path.dirname(REF))[:-3].replace(os.sep, ".")
+                users.append(rel)
+    assert sorted(users) == sorted(integration._RULE_MODULES)
+
+    # GPTQ `mode` through model_dump() -> QConfig(**dict) as quantize() does
+    from onnx_quantize_amd import GPTQConfig, QConfig, QuantType, QWeightArgs
+    ours = QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=32, algorithm=GPTQConfig(mode="corrected", block_size=64)))
+    theirs = ref_cfg.QConfig(**ours.model_dump())
+    assert theirs.weights.algorithm.mode == "corrected" and theirs.weights.algorithm.block_size == 64
+    again = ref_cfg._resolve_algorithm_config(theirs.model_dump()["weights"]["algorithm"])      # the per-node re-parse (_qconfig.py:131-149)
+    assert again.mode == "corrected" and again.block_size == 64 and isinstance(again, reference_modules.R.gptq.GPTQConfig)
+
+    # ROCm providers
+    from onnx_quantize_amd.calibration import ExecutionProvider
+    p = ref_base.CalibrationParams(provider="rocm")          # held as the provider string; calibrate.py:340 re-parses it by name
+    assert getattr(p.provider, "value", p.provider) == "ROCMExecutionProvider"
+    assert ref_base.ExecutionProvider(p.model_dump()["provider"]) is ExecutionProvider.ROCM
+    c = ref_base.CalibrationParams(provider="cpu").provider
+    assert getattr(c, "value", c) == "CPUExecutionProvider"
+    with pytest.raises(ValueError, match="Invalid execution provider"):
+        ref_base.CalibrationParams(provider="tpu")

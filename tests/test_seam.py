@@ -1,0 +1,154 @@
+"""The seam every rewrite rule of the reference calls: qrules/_common.py::quantize_weights (:126-142).
+
+tests/golden/seam_qw.* were recorded by running that function UNMODIFIED on a recording tape
+(make_golden.py::gen_seam_qw): initializer names, shapes, dtypes and values for RTN / GPTQ / HQQ weights, MatMulNBits
+compatible or not, with the group size resolved and the compatibility decided by the reference's own helpers.
+
+* CPU: the oracle's restatement (`seam_arrays`, `resolve_group_size`, `matmul_nbits_compatible`) reproduces them bit for bit.
+* GPU: `onnx_quantize_amd.seam.quantize_weights` -- upload once, fused kernels, blob written by the kernel epilogue, one
+  download -- emits the same three initializers.
+"""
+import sys
+import types
+
+import numpy as np
+import pytest
+
+import oq_oracle as O
+from conftest import load_json, load_npz
+
+CASES = load_json("seam_qw.json")["cases"]
+
+
+def _strategy(c):
+    w = c["weights"]
+    if "strategy" in w:
+        return w["strategy"]
+    g = w.get("group_size")
+    return "tensor" if g is None else ("channel" if g == -1 else "group")
+
+
+def test_oracle_reproduces_the_reference_seam():
+    G = load_npz("seam_qw.npz")
+    assert len(CASES) == 17 and not any("raises" in c for c in CASES)
+    for c in CASES:
+        w, x, wk = G[c["key"] + "_w"], G[c["key"] + "_x"], c["weights"]
+        st = _strategy(c)
+        g = O.resolve_group_size(c["k"], wk.get("group_size"))
+        assert g == c["resolved_group_size"], c["key"]
+        flagged = O.matmul_nbits_compatible(wk["dtype"], st, g)
+        assert flagged == c["flagged"], c["key"]
+        got = O.seam_arrays(w, c["algorithm"], wk["dtype"], st, g, wk.get("symmetric", False), wk.get("reduce_range", False),
+                            wk.get("clip_ratio", 1.0), False, x=x, nbits=flagged, **c["config"])
+        for j, (a, meta) in enumerate(zip(got, c["initializers"])):
+            exp = G[f"{c['key']}_i{j}"]
+            assert list(np.shape(a)) == meta["shape"], (c["key"], j)
+            if exp.dtype.kind == "f":
+                assert np.asarray(a, np.float32).tobytes() == exp.tobytes(), (c["key"], j)
+            else:
+                np.testing.assert_array_equal(np.asarray(a).astype(np.int32), exp, err_msg=f"{c['key']} {j}")
+
+
+class _Tensor:
+    def __init__(self, a):
+        self._a = np.asarray(a)
+
+    def numpy(self):
+        return self._a
+
+
+class _Value:
+    def __init__(self, name, const_value=None):
+        self.name, self.const_value = name, const_value
+
+
+class _Tape:
+    def __init__(self):
+        self.initializers = []
+
+    def initializer(self, tensor, name=None):
+        self.initializers.append((name, tensor.numpy()))
+        return _Value(name, tensor)
+
+
+@pytest.fixture
+def onnx_ir_tensor(monkeypatch):
+    """`seam.quantize_weights` wraps its arrays with `onnx_ir.tensor` like the reference; where the package is absent the
+    test supplies that one name (a tensor that returns its array)."""
+    try:
+        import onnx_ir  # noqa: F401
+    except ImportError:
+        monkeypatch.setitem(sys.modules, "onnx_ir", types.SimpleNamespace(tensor=_Tensor))
+
+
+@pytest.mark.gpu
+def test_seam_emits_the_reference_initializers(onnx_ir_tensor):
+    from onnx_quantize_amd import GPTQConfig, HqqConfig, QConfig, QuantType, QWeightArgs, seam
+    from onnx_quantize_amd.wire_format import _resolve_group_size, is_matmul_nbits_compatible
+
+    G = load_npz("seam_qw.npz")
+    algos = {"rtn": None, "gptq": GPTQConfig, "hqq": HqqConfig}
+    for c in CASES:
+        key = c["key"]
+        kw = {**c["weights"], "dtype": QuantType.from_string(c["weights"]["dtype"])}
+        if algos[c["algorithm"]] is not None:
+            kw["algorithm"] = algos[c["algorithm"]](**c["config"])
+        qc = QConfig(weights=QWeightArgs(**kw))
+        qc.weights.group_size = _resolve_group_size(c["k"], qc.weights.group_size, "fc.weight")
+        assert qc.weights.group_size == c["resolved_group_size"], key
+        flagged = is_matmul_nbits_compatible(qc, "fc.weight")
+        assert flagged == c["flagged"], key
+        x = G[key + "_x"].copy()
+        node = types.SimpleNamespace(meta={"input": x})
+        out = types.SimpleNamespace(producer=lambda node=node: node)
+        tape = _Tape()
+        res = seam.quantize_weights(tape, _Value("fc.weight", _Tensor(G[key + "_w"])), qc, out, is_matmul_nbits_compatible=flagged)
+        assert [v.name for v in res] == [m["name"] for m in c["initializers"]]
+        assert len(tape.initializers) == 3
+        for j, ((name, a), meta) in enumerate(zip(tape.initializers, c["initializers"])):
+            exp = G[f"{key}_i{j}"]
+            assert name == meta["name"] and list(a.shape) == meta["shape"] and str(a.dtype) == meta["dtype"], (key, j, a.shape, a.dtype)
+            if c["algorithm"] == "hqq" and j == 0:          # HQQ: tolerance-based parity: <= 0.2 % of the nibbles one level off
+                lo = np.abs((a & 0xF).astype(np.int32) - (exp & 0xF)), np.abs((a >> 4).astype(np.int32) - (exp >> 4))
+                assert max(v.max() for v in lo) <= 1 and sum(np.count_nonzero(v) for v in lo) <= 2e-3 * 2 * a.size, key
+            elif c["algorithm"] == "hqq" and j == 2:
+                np.testing.assert_allclose(a, exp, atol=2e-5, err_msg=key)
+            elif exp.dtype.kind == "f":
+                assert a.astype(np.float32).tobytes() == exp.tobytes(), (key, j)
+            else:
+                np.testing.assert_array_equal(a.astype(np.int32), exp, err_msg=f"{key} {j}")
+        np.testing.assert_array_equal(node.meta["input"], G[key + "_x"])          # inputs are never mutated
+
+
+@pytest.mark.gpu
+def test_seam_fused_blob_at_full_size_matches_the_reference_digest(onnx_ir_tensor):
+    """BASELINE config 2 through the seam: the fused kernel's blob, unpacked, has the reference's KAT2 digest; scales and
+    (unpacked) zero points too; a prefetched upload gives the same bytes as an on-demand one."""
+    import hashlib
+
+    from onnx_quantize_amd import QConfig, QuantType, QWeightArgs, seam
+    from onnx_quantize_amd.staging import default_stager
+
+    d = load_json("digests.json")["config2_asym"]
+    w = np.random.default_rng(0).standard_normal((4096, 11008), dtype=np.float32)
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=128))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]  # noqa: E731
+    outs = []
+    for prefetch in (False, True):
+        st = default_stager()
+        if prefetch:
+            st.prefetch([("w", w)])
+        blob, scale, zp = seam.weight_arrays(_Value("w", _Tensor(w)), qc, None, True)
+        assert (st.stats["hits"] > 0) == prefetch
+        assert blob.shape == (11008, 32, 64) and scale.shape == (11008, 32) and zp.shape == (11008, 16)
+        full = np.empty((11008, 32, 128), np.uint8)
+        full[..., 0::2] = blob & 0x0F
+        full[..., 1::2] = blob >> 4
+        assert sha(full.reshape(11008, 4096).T) == d["q_sha"]
+        assert sha(scale.reshape(-1, 1)) == d["s_sha"]
+        z = np.empty((11008, 32), np.uint8)
+        z[:, 0::2] = zp & 0x0F
+        z[:, 1::2] = zp >> 4
+        assert sha(z.reshape(-1, 1)) == d["z_sha"]
+        outs.append((blob, scale, zp))
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
