@@ -188,8 +188,8 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
 
     qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=GROUP))
     a = qc.weights
-    mats = [w_host] + [w_host.copy() for _ in range(count - 1)]
     params = K_DIM * N_DIM * count
+    fresh = lambda: [w_host.copy() for _ in range(count)]   # noqa: E731 -- every route gets arrays the GPU has never touched, like a model's
 
     def check(blob, scale, zp) -> bool:
         full = np.empty((N_DIM, K_DIM // GROUP, GROUP), np.uint8)
@@ -201,21 +201,42 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
         return bool(sha16(np.ascontiguousarray(full.reshape(N_DIM, K_DIM).T)) == digest["q_sha"] and
                     sha16(scale.reshape(-1, 1)) == digest["s_sha"] and sha16(z.reshape(-1, 1)) == digest["z_sha"])
 
-    # round-1 route: the algorithm plugin NumPy -> NumPy ([K,N] kernel, 45 MB back), then the packer as a second round trip
+    def round1_route(w):
+        """What round 1 shipped behind the seam: pageable upload, [K,N] kernel, 45 MB pageable download, then the packer as
+        a second round trip (upload q, pack, download)."""
+        wd = torch.from_numpy(w).cuda()
+        q, s, z = ops.rtn_quantize(wd, "uint4", "group", GROUP)
+        q, s, z = q.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy()
+        blob = ops.pack_matmul_nbits(torch.from_numpy(q).cuda(), GROUP, 4).cpu().numpy()
+        pz = ops.pack_zero_points_u4(torch.from_numpy(z.reshape(-1)).cuda(), N_DIM, K_DIM // GROUP).cpu().numpy()
+        return blob, s.reshape(-1, K_DIM // GROUP), pz
+
+    from onnx_quantize_amd.hip import ops
+
+    st = default_stager()
+    st.warm(K_DIM * N_DIM * 4)                                 # one-time: the page-locked bounce buffers of this process
+    mats = fresh()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for w in mats:
+        last = round1_route(w)
+    t_before = time.perf_counter() - t0
+    ok_before = check(*last)
+    # the reference-compatible NumPy functions of this round (bounce-buffer upload, chunked download), still two round trips
+    mats = fresh()
     t0 = time.perf_counter()
     for w in mats:
         q, s, z = _rtn_quantize(w, a.dtype, a.strategy, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse, a.scale_dtype, a.zp_dtype)
         last = _prepare_for_matmul_nbits(q, s, z, qc)
-    t_before = time.perf_counter() - t0
-    ok_before = check(*last)
-    # device-resident seam, uploads on demand through pinned staging
-    st = default_stager()
+    t_plugin = time.perf_counter() - t0
+    # device-resident seam, uploads on demand
+    mats = fresh()
     t0 = time.perf_counter()
     for i, w in enumerate(mats):
         last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
     t_demand = time.perf_counter() - t0
     # ... and with the model's weights prefetched from the worker thread while the previous one is quantized
+    mats = fresh()
     hits0 = st.stats["hits"]
     t0 = time.perf_counter()
     st.prefetch([(f"w{i}", w) for i, w in enumerate(mats)])
@@ -227,14 +248,17 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
     return {"what": "host->host through quantize_weights' arrays (qrules/_common.py:133-137), uint4 g128 4096x11008, "
                     f"{count} weights in sequence, NumPy in / MatMulNBits arrays out, PCIe included",
             "unit": "M-param/s",
-            "before": {"route": "_rtn_quantize ([K,N] kernel + 45 MB download) + _prepare_for_matmul_nbits (second round trip)",
+            "before": {"route": "round 1: pageable upload, [K,N] kernel, 45 MB pageable download, packer as a second round trip",
                        "value": rate(t_before), "ms_per_weight": round(t_before * 1e3 / count, 2), "digest_ok": ok_before},
-            "after_on_demand": {"route": "seam.weight_arrays, pinned upload per call", "value": rate(t_demand),
+            "plugin_functions": {"route": "_rtn_quantize + _prepare_for_matmul_nbits of this round (bounce-buffer transfers, two round trips)",
+                                 "value": rate(t_plugin), "ms_per_weight": round(t_plugin * 1e3 / count, 2)},
+            "after_on_demand": {"route": "seam.weight_arrays, upload per call", "value": rate(t_demand),
                                 "ms_per_weight": round(t_demand * 1e3 / count, 2)},
             "after": {"route": "seam.weight_arrays + WeightStager.prefetch (worker thread, side stream)", "value": rate(t_after),
                       "ms_per_weight": round(t_after * 1e3 / count, 2), "digest_ok": ok_after,
                       "prefetch_hits": st.stats["hits"] - hits0},
-            "speedup": round(t_before / t_after, 2)}
+            "speedup": round(t_before / t_after, 2), "staging_buffers_one_time_ms": round(st.init_ms, 1),
+            "note": "every route is timed on fresh host arrays (memory the GPU has not mapped yet), as a model's weights are"}
 
 
 # ------------------------------------------------------------------------------------------------ main

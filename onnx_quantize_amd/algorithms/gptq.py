@@ -79,7 +79,9 @@ def _gptq_quantize(weights, inputs, quant_type=QuantType.QInt8, strategy=Quantiz
 
     from ..hip import ops
 
-    w = torch.from_numpy(np.ascontiguousarray(weights, dtype=np.float32)).cuda()
+    from ..staging import upload
+
+    w = upload(np.asarray(weights))
     k = w.shape[0]
     h = torch.zeros((k, k), dtype=torch.float32, device=w.device)          # gptq.py:304
     n = 0

@@ -70,7 +70,9 @@ def _hqq_quantize(w_f: np.ndarray, quant_type: QuantType, group_size: int, reduc
     if quant_type != QuantType.QUInt4:
         raise ValueError("the GPU HQQ path implements the reference's only legal configuration: uint4")
     w = np.asarray(w_f)
-    wd = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).cuda()
+    from ..staging import upload
+
+    wd = upload(w)
     q, s, z, _ = ops.hqq_quantize(wd, -1 if group_size is None else group_size, bool(reduce_range), float(clip_ratio), bool(mse),
                                   float(lp_norm), float(beta), float(kappa), int(iters), bool(early_stop))
     from ..staging import download

@@ -43,8 +43,9 @@ def _rtn_quantize(array: np.ndarray, quant_type: QuantType, strategy: Quantizati
     w = np.asarray(array)
     if w.ndim != 2:
         w = w.reshape(1, -1) if strategy == QuantizationStrategy.TENSOR else w.reshape(w.shape[0], -1)
-    wd = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).cuda()
-    from ..staging import download
+    from ..staging import download, upload
+
+    wd = upload(w)
 
     q, s, z = ops.rtn_quantize(wd, quant_type.key, strategy.value, -1 if group_size is None else group_size,
                                bool(is_symmetric), bool(reduce_range), float(clip_ratio), bool(mse))
