@@ -214,7 +214,6 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
     from onnx_quantize_amd.hip import ops
 
     st = default_stager()
-    st.warm(K_DIM * N_DIM * 4)                                 # one-time: the page-locked bounce buffers of this process
     mats = fresh()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -222,7 +221,7 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
         last = round1_route(w)
     t_before = time.perf_counter() - t0
     ok_before = check(*last)
-    # the reference-compatible NumPy functions of this round (bounce-buffer upload, chunked download), still two round trips
+    # the reference-compatible NumPy functions of this round, still two round trips
     mats = fresh()
     t0 = time.perf_counter()
     for w in mats:
@@ -250,14 +249,14 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
             "unit": "M-param/s",
             "before": {"route": "round 1: pageable upload, [K,N] kernel, 45 MB pageable download, packer as a second round trip",
                        "value": rate(t_before), "ms_per_weight": round(t_before * 1e3 / count, 2), "digest_ok": ok_before},
-            "plugin_functions": {"route": "_rtn_quantize + _prepare_for_matmul_nbits of this round (bounce-buffer transfers, two round trips)",
+            "plugin_functions": {"route": "_rtn_quantize + _prepare_for_matmul_nbits of this round (NumPy in / NumPy out, two round trips)",
                                  "value": rate(t_plugin), "ms_per_weight": round(t_plugin * 1e3 / count, 2)},
             "after_on_demand": {"route": "seam.weight_arrays, upload per call", "value": rate(t_demand),
                                 "ms_per_weight": round(t_demand * 1e3 / count, 2)},
             "after": {"route": "seam.weight_arrays + WeightStager.prefetch (worker thread, side stream)", "value": rate(t_after),
                       "ms_per_weight": round(t_after * 1e3 / count, 2), "digest_ok": ok_after,
                       "prefetch_hits": st.stats["hits"] - hits0},
-            "speedup": round(t_before / t_after, 2), "staging_buffers_one_time_ms": round(st.init_ms, 1),
+            "speedup": round(t_before / t_after, 2),
             "note": "every route is timed on fresh host arrays (memory the GPU has not mapped yet), as a model's weights are"}
 
 

@@ -1,36 +1,29 @@
 """Host <-> HBM staging for the plugin seam (reference: qrules/_common.py:126-142, which hands the algorithm a NumPy
 weight and takes NumPy results back).
 
-The fused RTN kernel needs 42 us for a 4096 x 11008 weight; getting the same 180 MB over PCIe is what the seam costs.
-Measured on the MI355X host (`scripts/quick_staging.py`, `quick_staging2.py`):
-
-* memory the GPU has never touched moves at 7 GB/s (26 ms for that weight: the driver maps 45 000 pages on the way);
-  every weight of a model is such memory, it is uploaded exactly once.  The same copy from memory that is already
-  mapped -- a page-locked buffer that is reused -- takes 3.2 ms (56 GB/s), and the CPU copy into that buffer 0.7-2 ms.
-* a device-to-host copy into a fresh NumPy array is the mirror image (2.4 ms for 22.5 MB against 0.4 ms into page-locked
-  memory + 0.3-0.7 ms for the CPU copy out), and one 45 MB pageable download runs at 8.5 GB/s where three of 15 MB run
-  at 43 GB/s.
-
-So every transfer goes through a small ring of page-locked bounce buffers that live as long as the process, and
+The fused RTN kernel needs 42 us for a 4096 x 11008 weight; moving the same 180 MB over PCIe is what the seam costs.
+Measured on the MI355X host (`scripts/quick_staging*.py`): a pageable upload of that weight takes 3.7 ms the first time
+and 3.2 ms from memory the GPU has seen before (56 GB/s: pageable memory already moves at the PCIe rate there); a
+download into a fresh NumPy array 1.5 ms for the 22.5 MB blob and 2.9 ms for 45 MB (`np.empty` + one copy; `Tensor.cpu()`
+needs 4.1 / 8.5 ms for the same bytes, transparent huge pages make it worse, a page-locked bounce buffer adds a CPU copy
+that costs more than it saves).  What is left to remove is the SERIALISATION of upload, kernels and download:
 :meth:`WeightStager.prefetch` takes the whole list of weights a model is going to hand to the seam -- known as soon as
-the pre-passes are done -- and uploads them from a worker thread on a side stream while the main thread quantizes:
-weight i+1 travels while weight i is computed and downloaded.  288 GB of HBM hold every weight of a 7B model (26 GB);
-the in-flight budget is bounded by ``max_ahead_bytes`` anyway.
+the pre-passes are done -- and uploads them from a worker thread on a side stream while the main thread quantizes and
+downloads, so weight i+1 travels while weight i is in the kernels or on its way back.  The worker page-locks each source
+array in place for the time of its copy (`hipHostRegister`, microseconds on that host), which is what lets the upload run
+beside the main thread's download: 3.7 ms per weight for upload + download against 5.6 ms without it and 8.4 ms in
+sequence.  288 GB of HBM hold every weight of a 7B model (26 GB); the in-flight budget is bounded by ``max_ahead_bytes``.
 
-Nothing here computes anything: torch is used for page-locked memory, device memory, streams and events only.
+Nothing here computes anything: torch is used for device memory, streams and events only.
 """
 from __future__ import annotations
 
 import threading
-import time
 from collections import OrderedDict
 
 import numpy as np
 
 __all__ = ["WeightStager", "default_stager", "upload", "download"]
-
-_CHUNK = 16 << 20
-
 
 def _identity(a: np.ndarray):
     """What has to be unchanged for a prefetched copy to still stand for the array: shape, dtype and a strided sample of
@@ -41,47 +34,18 @@ def _identity(a: np.ndarray):
     return (a.shape, a.dtype.str, flat[::step][:512].tobytes(), flat[-1:].tobytes())
 
 
-class _PinnedRing:
-    """`slots` page-locked byte buffers, grown on demand and touched once when they are made (a fresh page-locked buffer
-    pays for its page faults on the first write); a slot is reusable once the copy that last used it has completed."""
-
-    def __init__(self, slots: int):
-        self.slots = [None] * slots
-        self.events = [None] * slots
-        self.next = 0
-        self.lock = threading.Lock()
-        self.init_ms = 0.0
-
-    def acquire(self, nbytes: int):
-        import torch
-
-        i = self.next
-        self.next = (i + 1) % len(self.slots)
-        if self.events[i] is not None:
-            self.events[i].synchronize()
-            self.events[i] = None
-        buf = self.slots[i]
-        if buf is None or buf.numel() < nbytes:
-            t0 = time.perf_counter()
-            self.slots[i] = buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
-            buf.zero_()
-            self.init_ms += (time.perf_counter() - t0) * 1e3
-        return i, buf
-
-
 class WeightStager:
-    """Uploads of fp32 weights through page-locked bounce buffers, optionally ahead of time from a worker thread, and the
-    matching downloads."""
+    """Uploads of fp32 weights, optionally ahead of time from a worker thread on a side stream, and the matching
+    downloads."""
 
-    def __init__(self, device=None, slots: int = 3, max_ahead_bytes: int = 16 << 30):
+    def __init__(self, device=None, max_ahead_bytes: int = 16 << 30):
         import torch
 
         if not torch.cuda.is_available():
             raise RuntimeError("WeightStager needs a GPU: the HIP path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.max_ahead_bytes = int(max_ahead_bytes)
-        self._up = _PinnedRing(slots)
-        self._down = _PinnedRing(2)
+        self._registered: list = []                                  # (event, array) page-locked until the copy is done
         self._stream = torch.cuda.Stream(device=self.device)
         self._ready: "OrderedDict[str, tuple]" = OrderedDict()      # name -> (identity, device tensor, event)
         self._cv = threading.Condition()
@@ -91,41 +55,37 @@ class WeightStager:
         self._stop = False
         self.stats = {"prefetched": 0, "hits": 0, "misses": 0, "stale": 0}
 
-    @property
-    def init_ms(self) -> float:
-        """One-time cost of the page-locked buffers so far."""
-        return self._up.init_ms + self._down.init_ms
+    # ------------------------------------------------------------------ transfers
+    def _sweep(self, wait: bool = False) -> None:
+        """Release the page locks of source arrays whose copy has completed."""
+        import torch
 
-    def warm(self, nbytes: int) -> None:
-        """Make every upload buffer at least `nbytes` large (and the download pieces) now; otherwise they grow on first use."""
-        for ring, size in ((self._up, nbytes), (self._down, _CHUNK)):
-            with ring.lock:
-                for _ in ring.slots:
-                    ring.acquire(size)
+        rt = torch.cuda.cudart()
+        keep = []
+        for ev, src in self._registered:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                rt.cudaHostUnregister(src.ctypes.data)
+            else:
+                keep.append((ev, src))
+        self._registered = keep
 
-    # ------------------------------------------------------------------ one upload
-    def _upload(self, a: np.ndarray, stream):
-        """fp32 C-contiguous copy of `a` in HBM, asynchronous on `stream`; the event marks its arrival (and frees the slot)."""
+    def _upload(self, a: np.ndarray, stream, lock_pages: bool = False):
+        """fp32 C-contiguous copy of `a` in HBM issued on `stream`; the event marks its arrival."""
         import torch
 
         src = np.ascontiguousarray(a, dtype=np.float32)
-        n = src.size
-        if n * 4 < (1 << 20):                                            # small: the bounce is not worth two copies
-            with torch.cuda.stream(stream):
-                dev = torch.from_numpy(src).to(self.device)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-            return dev, ev
-        with self._up.lock:
-            i, buf = self._up.acquire(n * 4)
-            host = buf[: n * 4].view(torch.float32)
-            host.copy_(torch.from_numpy(src.reshape(-1)))            # CPU copy into page-locked memory (multi-threaded)
-            with torch.cuda.stream(stream):
-                dev = torch.empty(src.shape, dtype=torch.float32, device=self.device)
-                dev.view(-1).copy_(host, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(stream)
-            self._up.events[i] = ev
+        locked = False
+        if lock_pages and src.nbytes >= (1 << 20):
+            self._sweep()
+            locked = int(torch.cuda.cudart().cudaHostRegister(src.ctypes.data, src.nbytes, 0)) == 0
+        with torch.cuda.stream(stream):
+            dev = torch.from_numpy(src).to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        if locked:
+            self._registered.append((ev, src))
         return dev, ev
 
     def upload(self, a: np.ndarray):
@@ -136,36 +96,13 @@ class WeightStager:
         return dev
 
     def download(self, t, dtype=None) -> np.ndarray:
-        """Device tensor -> fresh NumPy array through the page-locked ring, in pieces of 16 MB: piece i+1 travels while
-        piece i is copied out."""
+        """Device tensor -> fresh NumPy array (`np.empty` + one copy, see the module docstring)."""
         import torch
 
         t = t.contiguous()
-        nbytes = t.numel() * t.element_size()
-        if nbytes < (1 << 20):                                           # small: the bounce is not worth two copies
-            out = t.cpu().numpy()
-            return out if dtype is None else out.astype(dtype, copy=False)
         out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
-        dst = torch.from_numpy(out).view(-1).view(torch.uint8)
-        src = t.view(-1).view(torch.uint8)
-        cur = torch.cuda.current_stream(self.device)
-        with self._down.lock:
-            pend = None
-            for o in range(0, nbytes, _CHUNK):
-                m = min(_CHUNK, nbytes - o)
-                i, buf = self._down.acquire(_CHUNK)
-                buf[:m].copy_(src[o:o + m], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self._down.events[i] = ev
-                if pend is not None:
-                    po, pm, pbuf, pev = pend
-                    pev.synchronize()
-                    dst[po:po + pm].copy_(pbuf[:pm])
-                pend = (o, m, buf, ev)
-            po, pm, pbuf, pev = pend
-            pev.synchronize()
-            dst[po:po + pm].copy_(pbuf[:pm])
+        if t.numel():
+            torch.from_numpy(out.reshape(-1) if out.ndim else out.reshape(1)).copy_(t.reshape(-1))
         return out if dtype is None else out.astype(dtype, copy=False)
 
     # ------------------------------------------------------------------ prefetch
@@ -190,7 +127,7 @@ class WeightStager:
                 if self._stop:
                     return
             ident = _identity(a)
-            dev, ev = self._upload(a, self._stream)
+            dev, ev = self._upload(a, self._stream, lock_pages=True)
             with self._cv:
                 self._ready[name] = (ident, dev, ev)
                 self._pending.discard(name)
@@ -237,6 +174,7 @@ class WeightStager:
             self._ready.clear()
             self._pending = set()
             self._ahead = 0
+        self._sweep(wait=True)
 
 
 _DEFAULT: dict = {}
