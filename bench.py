@@ -177,7 +177,7 @@ class _Value:
         self.name, self.const_value = name, _Tensor(a)
 
 
-def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
+def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
     """Host -> host through the plugin seam on `count` config-2 weights (NumPy in, the three MatMulNBits arrays out)."""
     import torch
 
@@ -214,6 +214,14 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 6) -> dict:
     from onnx_quantize_amd.hip import ops
 
     st = default_stager()
+    # one untimed call per route: first launches of a kernel / first use of a stream carry 0.1 s of one-time set-up
+    warm = w_host.copy()
+    round1_route(warm)
+    _prepare_for_matmul_nbits(*_rtn_quantize(warm, a.dtype, a.strategy, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse,
+                                             a.scale_dtype, a.zp_dtype), qc)
+    seam.weight_arrays(_Value("warm", warm), qc, None, True)
+    st.prefetch([("warm", warm)])
+    seam.weight_arrays(_Value("warm", warm), qc, None, True)
     mats = fresh()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

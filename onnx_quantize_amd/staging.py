@@ -18,6 +18,7 @@ Nothing here computes anything: torch is used for device memory, streams and eve
 """
 from __future__ import annotations
 
+import os
 import threading
 from collections import OrderedDict
 
@@ -46,6 +47,7 @@ class WeightStager:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.max_ahead_bytes = int(max_ahead_bytes)
         self._registered: list = []                                  # (event, array) page-locked until the copy is done
+        self.lock_pages = os.environ.get("OQ_STAGER_LOCK_PAGES", "1") != "0"
         self._stream = torch.cuda.Stream(device=self.device)
         self._ready: "OrderedDict[str, tuple]" = OrderedDict()      # name -> (identity, device tensor, event)
         self._cv = threading.Condition()
@@ -127,7 +129,7 @@ class WeightStager:
                 if self._stop:
                     return
             ident = _identity(a)
-            dev, ev = self._upload(a, self._stream, lock_pages=True)
+            dev, ev = self._upload(a, self._stream, lock_pages=self.lock_pages)
             with self._cv:
                 self._ready[name] = (ident, dev, ev)
                 self._pending.discard(name)
