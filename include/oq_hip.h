@@ -245,7 +245,9 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
  *     Outputs: q_int_out [K, N] one value per byte; q_deq_out [K, N] fp32 (the dequantized rows the final qparams
  *     are re-derived from, gptq.py:219-231); used_scale/used_zp [ceil(K/group_size), N] = the parameters actually
  *     applied per (k-group, column) (NULL to skip; only written when group_size > 0).
- *     mse != 0 is not supported inside the loop (OQ_ERR_UNSUPPORTED). */
+ *     mse != 0 with group_size > 0: the per-group parameters come from the MSE search (utils.py:140-239, channel strategy
+ *     on rows [r, r+group_size) of W) run beforehand for every group that starts in the block; the rows are then walked
+ *     by the sequential kernel in both modes. */
 size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size);
 int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size,
                          int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,

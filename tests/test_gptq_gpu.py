@@ -255,22 +255,91 @@ def test_gptq_layer_shaped_property(ops):
         assert torch.allclose(s, rs, rtol=1e-5, atol=0)
 
 
+def _mse_tables(rows, qtype, strategy, sym=False, red=False):
+    """The oracle's error table [iterations, rows] of utils.py:140-239 on `rows` and the (scale, zp) of every candidate."""
+    trace = []
+    O.min_max_mse(rows, qtype, strategy, sym, red, trace=trace)
+    errs = np.stack([np.asarray(e, dtype=np.float32).reshape(-1) for _, e in trace], axis=0)
+    lo0, hi0 = O.min_max(rows, strategy, 1.0)
+    cands = []
+    for i in range(len(trace)):
+        p = 1 - i / 100.0
+        s, z = O.qparams(p * lo0, p * hi0, qtype, sym, red)
+        cands.append((np.asarray(s, np.float32).reshape(-1), np.asarray(z).reshape(-1)))
+    return errs, cands
+
+
 @pytest.mark.parametrize("strategy,group_size,qtype", [("tensor", 8, "int8"), ("group", 8, "int4"), ("channel", -1, "int8"),
                                                        ("group", 16, "uint4"), ("tensor", 64, "int8")])
 @pytest.mark.parametrize("actorder", [False, True])
 def test_gptq_with_mse_vs_oracle(ops, strategy, group_size, qtype, actorder):
-    """mse=True inside GPTQ (test_gptq.py:20-51 grid): the initial, per-group and final parameters all come
-    from the MSE search.  pow / summation-order differences can swap near-tied candidates, so the comparison
-    allows a small fraction of rows to differ (see tests/test_mse_gpu.py); in practice they are equal."""
+    """mse=True inside GPTQ (test_gptq.py:20-51 grid): the initial, per-group and final parameters all come from the MSE
+    search, whose float32 pow / summation order cannot be reproduced bit for bit.  Same tolerance-aware contract as
+    tests/test_mse_gpu.py, stage by stage:
+
+    * integers: every block of rows that shares parameters (a loop group, gptq.py:168-184, else the initial per-channel /
+      per-tensor ones, :104-116) must carry the integers of ONE of the reference's candidate ranges, and that candidate
+      must be optimal for the oracle's own error table up to 1e-4;
+    * returned (scale, zp): re-derived by the same search from the dequantized Q (:219-231) -- checked against the
+      oracle's table on the Q the GPU itself produced, for every row whose Q is unambiguous;
+    * and in practice nearly everything equals the oracle outright (>= 95 % of the integers, >= 90 % of the rows)."""
     w, x = GPTQ["a_w"], GPTQ["a_x"]
+    k, n = w.shape
     h, _ = hessian_of(ops, x)
     q, s, z, info = ops.gptq_quantize(dev(w), h, qtype, strategy, group_size, False, False, 1.0, 128, 0.01, actorder, True)
-    eq, es, ez = O.gptq_quantize(w, x, qtype, strategy, group_size, False, False, 1.0, 128, 0.01, actorder, True)
+    he, _ = O.accumulate_hessian(x, np.zeros((k, k), np.float32), 0)
+    eq, es, ez, dbg = O.gptq(w, he, qtype, strategy, group_size, False, False, 1.0, 128, 0.01, actorder, True, return_debug=True)
     q, s, z = q.cpu().numpy(), s.cpu().numpy(), z.cpu().numpy()
-    assert q.shape == eq.shape and s.shape == es.shape and z.shape == ez.shape
-    assert np.mean(q != eq) <= 0.05
-    np.testing.assert_allclose(s, es, rtol=0.2)          # a swapped candidate moves a scale by k/100
-    assert np.mean(np.abs(s - es) > 1e-6 * np.abs(es)) <= 0.1
+    assert q.shape == eq.shape and s.shape == es.shape and z.shape == ez.shape and q.dtype == eq.dtype
+    perm = dbg["perm"] if actorder else np.arange(k)
+    wp = w.copy()
+    wp[dbg["dead"], :] = 0
+    wp, qp = wp[perm, :], q[perm, :]
+    used = "channel" if strategy == "group" else strategy
+    loop_g = group_size if (group_size and group_size != -1) else 0
+    blocks = ([(r, min(r + loop_g, k), wp[r:r + loop_g, :].T, "channel") for r in range(0, k, loop_g)] if loop_g
+              else [(0, k, w.T, used)])                                   # initial parameters see the untouched W (:104-116)
+    qd = np.zeros_like(wp)
+    unambiguous = np.ones((k, n), bool)
+    for r0, r1, rows, st in blocks:
+        errs, cands = _mse_tables(rows, qtype, st)
+        best = errs.min(axis=0)
+        data = wp[r0:r1, :].T if st == "channel" else wp[r0:r1, :].reshape(1, -1)
+        got = qp[r0:r1, :].T if st == "channel" else qp[r0:r1, :].reshape(1, -1)
+        nrows = data.shape[0]
+        chosen = np.full(nrows, -1)
+        matches = np.zeros(nrows, int)
+        for i, (cs, cz) in enumerate(cands):
+            ints = O.quantize(data, cs.reshape(-1, 1), cz.reshape(-1, 1), qtype, False, False)
+            hit = np.all(ints == got, axis=1) & (errs[i] <= best * (1 + 1e-4) + 1e-30)
+            matches += hit
+            chosen[(chosen < 0) & hit] = i
+        assert np.all(chosen >= 0), f"rows {r0}:{r1}: integers that belong to no near-optimal candidate of the reference's grid"
+        cs = np.stack([c[0] for c in cands])[chosen, np.arange(nrows)].reshape(-1, 1)
+        cz = np.stack([c[1] for c in cands])[chosen, np.arange(nrows)].reshape(-1, 1)
+        deq = O.dequantize(got, cs, cz)
+        if st == "channel":
+            qd[r0:r1, :] = deq.T
+            unambiguous[r0:r1, :] &= (matches == 1)[None, :]
+        else:
+            qd[r0:r1, :] = deq.reshape(r1 - r0, n)
+            unambiguous[r0:r1, :] &= bool(matches[0] == 1)
+    inv = np.argsort(perm)
+    qd, unambiguous = qd[inv, :], unambiguous[inv, :]
+    # final parameters: the search on the GPU's own dequantized Q in the user's layout
+    rows = O.to_rows(qd, strategy, group_size)
+    clear = np.all(O.to_rows(unambiguous, strategy, group_size), axis=-1).reshape(-1) if strategy != "tensor" else np.array([unambiguous.all()])
+    errs, cands = _mse_tables(rows, qtype, strategy)
+    sg, zg = s.reshape(-1), z.reshape(-1)
+    idx = np.full(sg.size, -1)
+    for i, (cs, cz) in enumerate(cands):
+        hit = (idx < 0) & (cs.view(np.uint32) == sg.view(np.uint32)) & (cz == zg)
+        idx[hit] = i
+    ok = (idx >= 0) & (errs[np.maximum(idx, 0), np.arange(sg.size)] <= errs.min(axis=0) * (1 + 1e-4) + 1e-30)
+    assert clear.mean() >= 0.9 and np.all(ok[clear]), f"{(~ok[clear]).sum()} returned (scale, zp) off the candidate grid / not optimal"
+    assert np.mean(q == eq) >= 0.95
+    same = (sg.view(np.uint32) == es.reshape(-1).view(np.uint32)) & (zg == ez.reshape(-1))
+    assert same.mean() >= 0.9
 
 
 @pytest.mark.parametrize("actorder", [False, True])
@@ -332,6 +401,45 @@ def test_full_size_layer_properties(ops):
         dq = ops.dequantize(qq, ss, zz, "int4", mode="group", group=128)
         return float(((xs[0].reshape(-1, k)[:2048] @ (dq - w)) ** 2).mean())
     assert out_err(qc, sc, zc) < 0.9 * out_err(rq, rs, rz)
+
+
+def test_down_proj_full_size_factor_and_parity_loop(ops):
+    """BASELINE config 4's widest layer, Llama-2-7B down_proj: K = 11008, N = 4096 (VERDICT r01, weak spot: nothing under
+    `-m gpu` factored K = 11008 or ran its loop).  (a) the inverse factor of the 11008 x 11008 Hessian: U upper, positive
+    diagonal, U^T U (H + damp I) = I through random float64 probe vectors; (b) the parity loop over 86 blocks of 128 rows
+    returns exactly the fused RTN kernel's integers and zero points (the reference's error feedback is a no-op,
+    SURVEY.md finding 1), scales within the north-star tolerance; (c) the dead-channel rule (gptq.py:119-121) at this
+    size: an input channel the calibration never excites quantizes a ZERO row, not the weight row."""
+    import torch
+    k, n = 11008, 4096
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    chan = 0.1 + 3.9 * torch.rand(k, generator=gen, device="cuda")
+    chan[4321] = 0
+    h = torch.zeros((k, k), device="cuda")
+    cnt = 0
+    for _ in range(2):
+        cnt = ops.hessian_accumulate(torch.randn((8, 1024, k), generator=gen, device="cuda") * chan, h, cnt)
+    assert cnt == 16 and float(h[4321, 4321]) == 0.0
+    h1 = h.clone()
+    h1[4321, 4321] = 1.0                                               # what gptq.py:119-120 factors
+    u, info = ops.gptq_factor(h1, 0.01)
+    assert int(info.item()) == 0 and float(torch.tril(u, -1).abs().max()) == 0.0 and bool((torch.diagonal(u) > 0).all())
+    damp = 0.01 * torch.diagonal(h1).double().mean()
+    probe = torch.randn((k, 8), generator=gen, device="cuda", dtype=torch.float64)
+    hp = h1.double() @ probe + damp * probe
+    back = u.double().T @ (u.double() @ hp)
+    assert float((back - probe).abs().max()) <= 5e-3 * float(probe.abs().max())
+    del hp, back, u, h1
+    w = torch.randn((k, n), generator=gen, device="cuda") * 0.02
+    q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128)
+    assert int(info.item()) == 0
+    w0 = w.clone()
+    w0[4321, :] = 0                                                    # gptq.py:121
+    rq, rs, rz = ops.rtn_quantize(w0, "int4", "group", 128)
+    assert torch.equal(q, rq) and torch.equal(z, rz)
+    torch.testing.assert_close(s, rs, rtol=1e-5, atol=0)
+    pq, _, _ = ops.rtn_quantize(w, "int4", "group", 128)
+    assert not torch.equal(q[4321], pq[4321])                          # the dead row really differs from plain RTN
 
 
 def test_hessian_widest_llama_input_properties(ops):
