@@ -138,6 +138,12 @@ int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, co
                           const int32_t* zp, int64_t row_div, int64_t row_stride, int64_t col_stride,
                           float* x_out, int64_t ldo, void* stream);
 
+/* K2 with FLOAT zero points (core/_algorithms/hqq.py:77-78 keeps zero points in the scale dtype; utils.py:130-132 then
+ *     subtracts them as they are): (f32(q) - zp) * scale, same addressing as oq_dequantize_f32.  4- / 8-bit containers. */
+int32_t oq_dequantize_fzp_f32(const void* q, int64_t R, int64_t C, int32_t qtype, const float* scale,
+                              const float* zp, int64_t row_div, int64_t row_stride, int64_t col_stride,
+                              float* x_out, int64_t ldo, void* stream);
+
 /* A3  core/_algorithms/rtn.py:112-138  _quantize_bias: bias_scale = w_scale * x_scale (fp32),
  *     q = clip(int32(rint(bias / bias_scale))).  w_scale has 1 or n entries. */
 int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale,

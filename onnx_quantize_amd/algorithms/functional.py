@@ -178,21 +178,22 @@ def _dequantize_array(q_array, scale, zero_point, *, preprocess=False, strategy=
     import torch
 
     qd = torch.from_numpy(np.ascontiguousarray(q)).cuda()
+    zdt = np.float32 if z.dtype.kind == "f" else np.int32          # HQQ's float zero points stay floats (utils.py:131)
     if preprocess:
         assert strategy is not None, "strategy must be provided if preprocess is True"
         sname = _sname(strategy)
         if sname == "tensor":
-            out = ops.dequantize(qd, _dev(s), _dev(z, np.int32), kind, mode="tensor")
+            out = ops.dequantize(qd, _dev(s), _dev(z, zdt), kind, mode="tensor")
         elif sname == "channel":
-            out = ops.dequantize(qd, _dev(s), _dev(z, np.int32), kind, mode="col")
+            out = ops.dequantize(qd, _dev(s), _dev(z, zdt), kind, mode="col")
         else:
             k = q.shape[0]
             g = min(group_size, k)
             g = g if g != -1 else k
-            out = ops.dequantize(qd, _dev(s), _dev(z, np.int32), kind, mode="group", group=g)
+            out = ops.dequantize(qd, _dev(s), _dev(z, zdt), kind, mode="group", group=g)   # ragged groups: flat addressing
         return out.cpu().numpy()
     mode = _param_mode(q, s)
-    return ops.dequantize(qd, _dev(s), _dev(z, np.int32), kind, mode=mode).cpu().numpy()
+    return ops.dequantize(qd, _dev(s), _dev(z, zdt), kind, mode=mode).cpu().numpy()
 
 
 def _fake_quantize_array(array, scale, zero_point, quant_type, is_symmetric, reduce_range):

@@ -22,7 +22,7 @@ __global__ void qparams_kernel_f64(const double* rmin, const double* rmax, int64
     if (i >= count) return;
     const double lo = rmin[i], hi = rmax[i];
     if (grid.symmetric) {
-        const double amax = fmax(fabs(lo), fabs(hi));
+        const double amax = nmax(fabs(lo), fabs(hi));
         double s = amax / grid.levels;
         if (s < DBL_MIN) s = 1.0;
         scale[i] = static_cast<float>(s);
@@ -31,7 +31,7 @@ __global__ void qparams_kernel_f64(const double* rmin, const double* rmax, int64
         double s = (hi - lo) / static_cast<double>(grid.qmax - grid.qmin);
         if (s < DBL_MIN) s = 1.0;
         double z = static_cast<double>(grid.qmin) - lo / s;
-        z = fmin(fmax(z, static_cast<double>(grid.qmin)), static_cast<double>(grid.qmax));
+        z = nmin(nmax(z, static_cast<double>(grid.qmin)), static_cast<double>(grid.qmax));
         scale[i] = static_cast<float>(s);
         zp[i] = static_cast<int32_t>(rint(z));
     }
@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* x, int64_t R
     }
 }
 
-template <typename InT>
+template <typename InT, typename ZpT = int32_t>
 __global__ __launch_bounds__(256) void dequantize_kernel(const InT* q, int64_t R, int64_t C, const float* scale,
-                                                         const int32_t* zp, ParamIndex pi, float* out, int64_t ldo) {
+                                                         const ZpT* zp, ParamIndex pi, float* out, int64_t ldo) {
     const int64_t total = R * C;
     for (int64_t t = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < total;
          t += static_cast<int64_t>(gridDim.x) * blockDim.x) {
@@ -343,6 +343,22 @@ int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, co
             break;
     }
     return check_launch("dequantize_kernel");
+}
+
+int32_t oq_dequantize_fzp_f32(const void* q, int64_t R, int64_t C, int32_t qtype, const float* scale, const float* zp,
+                              int64_t row_div, int64_t row_stride, int64_t col_stride, float* x_out, int64_t ldo,
+                              void* stream) {
+    OQ_REQUIRE(q && scale && zp && x_out && R > 0 && C > 0 && ldo >= C && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_dequantize_fzp_f32: bad argument");
+    OQ_REQUIRE(qtype >= OQ_INT4 && qtype <= OQ_UINT8, OQ_ERR_UNSUPPORTED, "oq_dequantize_fzp_f32: 4- and 8-bit containers only, got type %d", qtype);
+    const ParamIndex pi{row_div, row_stride, col_stride};
+    const dim3 grid(grid_for(R * C)), block(256);
+    hipStream_t s = as_stream(stream);
+    if (qtype == OQ_INT4 || qtype == OQ_INT8)
+        hipLaunchKernelGGL((dequantize_kernel<int8_t, float>), grid, block, 0, s, static_cast<const int8_t*>(q), R, C, scale, zp, pi, x_out, ldo);
+    else
+        hipLaunchKernelGGL((dequantize_kernel<uint8_t, float>), grid, block, 0, s, static_cast<const uint8_t*>(q), R, C, scale, zp, pi, x_out, ldo);
+    return check_launch("dequantize_kernel (float zero points)");
 }
 
 int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale, float x_scale,

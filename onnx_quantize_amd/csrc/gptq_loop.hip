@@ -143,14 +143,14 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) x[u] = a.W[(r + u < rend ? r + u : rend - 1) * a.N + cc];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { mn = fminf(mn, x[u]); mx = fmaxf(mx, x[u]); }
+                        for (int u = 0; u < 8; ++u) { mn = nmin(mn, x[u]); mx = nmax(mx, x[u]); }
                     }
                     red_mn[wave][lane] = mn;
                     red_mx[wave][lane] = mx;
                     __syncthreads();
                     if (wave == 0) {
-                        mn = fminf(fminf(red_mn[0][lane], red_mn[1][lane]), fminf(red_mn[2][lane], red_mn[3][lane]));
-                        mx = fmaxf(fmaxf(red_mx[0][lane], red_mx[1][lane]), fmaxf(red_mx[2][lane], red_mx[3][lane]));
+                        mn = nmin(nmin(red_mn[0][lane], red_mn[1][lane]), nmin(red_mn[2][lane], red_mn[3][lane]));
+                        mx = nmax(nmax(red_mx[0][lane], red_mx[1][lane]), nmax(red_mx[2][lane], red_mx[3][lane]));
                         const QParam p = qparam_from_minmax(mn, mx, a.grid);
                         gp_scale[slot][lane] = p.scale;
                         gp_zp[slot][lane] = p.zp;
@@ -237,13 +237,13 @@ __global__ __launch_bounds__(256) void gptq_parity_kernel(const LoopArgs a, int6
         int64_t r = r0;
         for (; r + 3 < r1; r += 4) {   // four loads in flight per lane
             const float x0 = a.W[r * a.N + cc], x1 = a.W[(r + 1) * a.N + cc], x2 = a.W[(r + 2) * a.N + cc], x3 = a.W[(r + 3) * a.N + cc];
-            mn = fminf(fminf(mn, x0), fminf(x1, fminf(x2, x3)));
-            mx = fmaxf(fmaxf(mx, x0), fmaxf(x1, fmaxf(x2, x3)));
+            mn = nmin(nmin(mn, x0), nmin(x1, nmin(x2, x3)));
+            mx = nmax(nmax(mx, x0), nmax(x1, nmax(x2, x3)));
         }
         for (; r < r1; ++r) {
             const float x = a.W[r * a.N + cc];
-            mn = fminf(mn, x);
-            mx = fmaxf(mx, x);
+            mn = nmin(mn, x);
+            mx = nmax(mx, x);
         }
         const QParam p = qparam_from_minmax(mn, mx, a.grid);
         scale = p.scale;

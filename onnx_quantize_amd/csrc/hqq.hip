@@ -100,7 +100,7 @@ __device__ __forceinline__ float hqq_shrink(float d, float inv_beta, float expo)
     // (|x| + 1e-8)^(p - 1) = 2^((p - 1) log2(.)) on the hardware log / exp units (~2e-6 relative; np.power is not
     // reproduced bit for bit either way, see the header)
     const float t = a - inv_beta * __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf(a + 1e-8f));
-    const float m = fmaxf(0.0f, t);
+    const float m = nmax(0.0f, t);
     const float sg = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : d);   // np.sign keeps +-0 and NaN
     return sg * m;
 }
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void hqq_round_kernel(const HqqArgs a) {
         const float* w = a.W + kg * a.g * a.ldw + col;
         const float zmean = pairwise_row(a.g, [&](int64_t t) {
             const float x = w[t * a.ldw];
-            const float wq = fminf(fmaxf(rintf(x * inv + z), a.qmin), a.qmax);   // :124
+            const float wq = nmin(nmax(rintf(x * inv + z), a.qmin), a.qmax);   // :124
             const float wr = (wq - z) / inv;                                   // :125
             const float d = x - wr;
             abs_sum += static_cast<double>(fabsf(d));                          // :131
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void hqq_finish_kernel(const HqqArgs a, uint8_
             uint32_t word = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float v = fminf(fmaxf(rintf(w[(t + j) * a.ldw] / s + z), a.qmin), a.qmax);
+                const float v = nmin(nmax(rintf(w[(t + j) * a.ldw] / s + z), a.qmin), a.qmax);
                 word |= (static_cast<uint32_t>(v) & 0xfu) << (4 * j);
             }
             *reinterpret_cast<uint32_t*>(o + t / 2) = word;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void hqq_finish_kernel(const HqqArgs a, uint8_
         return;
     }
     for (int64_t t = 0; t < a.g; ++t) {
-        const float v = fminf(fmaxf(rintf(w[t * a.ldw] / s + z), a.qmin), a.qmax);
+        const float v = nmin(nmax(rintf(w[t * a.ldw] / s + z), a.qmin), a.qmax);
         q[(kg * a.g + t) * a.N + col] = static_cast<uint8_t>(v);
     }
 }

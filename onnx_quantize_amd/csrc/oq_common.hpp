@@ -45,6 +45,14 @@ int32_t make_grid(int32_t qtype, int32_t symmetric, int32_t reduce_range, float 
 // All of this file is compiled with -ffp-contract=off: the reference rounds every product and sum
 // separately, a fused multiply-add would change results.
 
+// np.min / np.max / np.minimum / np.maximum / np.clip propagate NaN; fminf / fmaxf (IEEE minNum / maxNum) drop it and
+// would turn a corrupted tensor into plausible finite ranges.  gfx950 has the IEEE-754-2019 forms as single instructions
+// (v_minimum3_f32 / v_maximum3_f32), so NaN-propagating reductions cost the same as the dropping ones.
+__host__ __device__ __forceinline__ float nmin(float a, float b) { return __builtin_elementwise_minimum(a, b); }
+__host__ __device__ __forceinline__ float nmax(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+__host__ __device__ __forceinline__ double nmin(double a, double b) { return __builtin_elementwise_minimum(a, b); }
+__host__ __device__ __forceinline__ double nmax(double a, double b) { return __builtin_elementwise_maximum(a, b); }
+
 struct QParam {
     float scale;
     int32_t zp;
@@ -56,7 +64,7 @@ struct QParam {
 __device__ __forceinline__ QParam qparam_from_range(float lo, float hi, const QGrid& g) {
     QParam p;
     if (g.symmetric) {
-        float amax = fmaxf(fabsf(lo), fabsf(hi));
+        float amax = nmax(fabsf(lo), fabsf(hi));
         double s = static_cast<double>(amax) / g.levels;
         if (s < static_cast<double>(FLT_MIN)) s = 1.0;
         p.scale = static_cast<float>(s);
@@ -65,7 +73,7 @@ __device__ __forceinline__ QParam qparam_from_range(float lo, float hi, const QG
         float s = (hi - lo) / static_cast<float>(g.qmax - g.qmin);
         if (s < FLT_MIN) s = 1.0f;
         float z = static_cast<float>(g.qmin) - lo / s;
-        z = fminf(fmaxf(z, static_cast<float>(g.qmin)), static_cast<float>(g.qmax));
+        z = nmin(nmax(z, static_cast<float>(g.qmin)), static_cast<float>(g.qmax));
         p.scale = s;
         p.zp = static_cast<int32_t>(rintf(z));
     }
@@ -73,8 +81,8 @@ __device__ __forceinline__ QParam qparam_from_range(float lo, float hi, const QG
 }
 
 __device__ __forceinline__ QParam qparam_from_minmax(float mn, float mx, const QGrid& g) {
-    float lo = fminf(mn * g.clip_ratio, 0.0f);
-    float hi = fmaxf(mx * g.clip_ratio, 0.0f);
+    float lo = nmin(mn * g.clip_ratio, 0.0f);
+    float hi = nmax(mx * g.clip_ratio, 0.0f);
     return qparam_from_range(lo, hi, g);
 }
 
@@ -107,7 +115,7 @@ __device__ __forceinline__ ColQ make_colq(const QParam& p, float raw_min, float 
     c.zp = p.zp;
     c.rinv = 1.0f / p.scale;
     c.zpb = static_cast<float>(p.zp + bias);
-    const float bound = fmaxf(fabsf(raw_min), fabsf(raw_max)) * c.rinv * 1.0001f;
+    const float bound = nmax(fabsf(raw_min), fabsf(raw_max)) * c.rinv * 1.0001f;
     float thr = 0.5f - bound * 4.76837158203125e-07f /* 2^-21 */ - 1e-30f;
     if (!(p.scale < 1e30f) || !(bound < 4194304.0f /* 2^22: k + zp must stay exact in fp32 */)) thr = -1.0f;
     c.thr = thr;
@@ -135,22 +143,22 @@ __device__ __forceinline__ float dequantize_one(int32_t q, float scale, int32_t 
 // 64-lane butterfly reductions (no LDS).
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) v = nmin(v, __shfl_xor(v, off, 64));
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) v = nmax(v, __shfl_xor(v, off, 64));
     return v;
 }
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) v = nmin(v, __shfl_xor(v, off, 64));
     return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    for (int off = 32; off > 0; off >>= 1) v = nmax(v, __shfl_xor(v, off, 64));
     return v;
 }
 

@@ -46,14 +46,14 @@ __device__ __forceinline__ void stream_minmax(const typename Vec4<T>::type* xv, 
         for (int u = 0; u < kDepth; ++u) a[u] = __builtin_nontemporal_load(xv + i + u * stride);
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
-            mn = fmin(fmin(fmin(mn, a[u].x), fmin(a[u].y, a[u].z)), a[u].w);
-            mx = fmax(fmax(fmax(mx, a[u].x), fmax(a[u].y, a[u].z)), a[u].w);
+            mn = nmin(nmin(nmin(mn, a[u].x), nmin(a[u].y, a[u].z)), a[u].w);
+            mx = nmax(nmax(nmax(mx, a[u].x), nmax(a[u].y, a[u].z)), a[u].w);
         }
     }
     for (; i < nvec; i += stride) {
         const V a = __builtin_nontemporal_load(xv + i);
-        mn = fmin(fmin(mn, a.x), fmin(fmin(a.y, a.z), a.w));
-        mx = fmax(fmax(mx, a.x), fmax(fmax(a.y, a.z), a.w));
+        mn = nmin(nmin(mn, a.x), nmin(nmin(a.y, a.z), a.w));
+        mx = nmax(nmax(mx, a.x), nmax(nmax(a.y, a.z), a.w));
     }
 }
 
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(kRedBlock) void minmax_partial(const T* x, int64_t 
     const V* xv = reinterpret_cast<const V*>(x + vec_off);
     stream_minmax<T>(xv, nvec, tid, stride, mn, mx);
     // head and tail scalars
-    for (int64_t j = tid; j < vec_off; j += stride) { mn = fmin(mn, x[j]); mx = fmax(mx, x[j]); }
-    for (int64_t j = vec_off + nvec * 4 + tid; j < count; j += stride) { mn = fmin(mn, x[j]); mx = fmax(mx, x[j]); }
+    for (int64_t j = tid; j < vec_off; j += stride) { mn = nmin(mn, x[j]); mx = nmax(mx, x[j]); }
+    for (int64_t j = vec_off + nvec * 4 + tid; j < count; j += stride) { mn = nmin(mn, x[j]); mx = nmax(mx, x[j]); }
     block_minmax(mn, mx, s_mn, s_mx);
     if (threadIdx.x == 0) {
         partial[2 * blockIdx.x] = mn;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(kRedBlock) void minmax_update(const T* partial, int
     __shared__ T s_mn[kRedBlock / 64], s_mx[kRedBlock / 64];
     T mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
-        mn = fmin(mn, partial[2 * i]);
-        mx = fmax(mx, partial[2 * i + 1]);
+        mn = nmin(mn, partial[2 * i]);
+        mx = nmax(mx, partial[2 * i + 1]);
     }
     block_minmax(mn, mx, s_mn, s_mx);
     if (threadIdx.x != 0) return;
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(kRedBlock) void minmax_update(const T* partial, int
         state[0] = m * state[0] + om * mn;
         state[1] = m * state[1] + om * mx;
     } else {                           // minmax.py:63-64
-        state[0] = fmin(state[0], mn);
-        state[1] = fmax(state[1], mx);
+        state[0] = nmin(state[0], mn);
+        state[1] = nmax(state[1], mx);
     }
 }
 
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(kRedBlock) void minmax_many_partial(const ManyDesc*
     const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
     float mn = INFINITY, mx = -INFINITY;
     stream_minmax<float>(xv, nvec, tid, stride, mn, mx);
-    for (int64_t j = tid; j < vec_off; j += stride) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
-    for (int64_t j = vec_off + nvec * 4 + tid; j < count; j += stride) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
+    for (int64_t j = tid; j < vec_off; j += stride) { mn = nmin(mn, x[j]); mx = nmax(mx, x[j]); }
+    for (int64_t j = vec_off + nvec * 4 + tid; j < count; j += stride) { mn = nmin(mn, x[j]); mx = nmax(mx, x[j]); }
     block_minmax(mn, mx, s_mn, s_mx);
     if (threadIdx.x == 0) {
         float* o = partial + (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 2;
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(64) void minmax_many_update(const ManyDesc* desc, c
     const float* p = partial + static_cast<int64_t>(blockIdx.x) * slices * 2;
     float mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < slices; i += 64) {
-        mn = fminf(mn, p[2 * i]);
-        mx = fmaxf(mx, p[2 * i + 1]);
+        mn = nmin(mn, p[2 * i]);
+        mx = nmax(mx, p[2 * i + 1]);
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64) void minmax_many_update(const ManyDesc* desc, c
         state[0] = m * state[0] + om * mn;
         state[1] = m * state[1] + om * mx;
     } else {
-        state[0] = fminf(state[0], mn);
-        state[1] = fmaxf(state[1], mx);
+        state[0] = nmin(state[0], mn);
+        state[1] = nmax(state[1], mx);
     }
 }
 
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(512) void absmax_cols_partial(const float* x, int64
                 t[r] = (row0 + r < R) ? *reinterpret_cast<const float4*>(x + (row0 + r) * ldx + c) : make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                mx[0] = fmaxf(mx[0], fabsf(t[r].x)); mx[1] = fmaxf(mx[1], fabsf(t[r].y));
-                mx[2] = fmaxf(mx[2], fabsf(t[r].z)); mx[3] = fmaxf(mx[3], fabsf(t[r].w));
+                mx[0] = nmax(mx[0], fabsf(t[r].x)); mx[1] = nmax(mx[1], fabsf(t[r].y));
+                mx[2] = nmax(mx[2], fabsf(t[r].z)); mx[3] = nmax(mx[3], fabsf(t[r].w));
             }
         }
     } else {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(512) void absmax_cols_partial(const float* x, int64
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t c = col0 + i * 64 + lane;
-                if (c < C && row0 + r < R) mx[i] = fmaxf(mx[i], fabsf(x[(row0 + r) * ldx + c]));
+                if (c < C && row0 + r < R) mx[i] = nmax(mx[i], fabsf(x[(row0 + r) * ldx + c]));
             }
     }
     s_mx[wave][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void absmax_cols_partial(const float* x, int64
     if (wave != 0) return;
     for (int w = 1; w < 8; ++w) {
         const float4 t = s_mx[w][lane];
-        mx[0] = fmaxf(mx[0], t.x); mx[1] = fmaxf(mx[1], t.y); mx[2] = fmaxf(mx[2], t.z); mx[3] = fmaxf(mx[3], t.w);
+        mx[0] = nmax(mx[0], t.x); mx[1] = nmax(mx[1], t.y); mx[2] = nmax(mx[2], t.z); mx[3] = nmax(mx[3], t.w);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -246,7 +246,7 @@ __global__ void absmax_cols_finalize(const float* partial, int64_t chunks, int64
     const int64_t c = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float m = 0.f;
-    for (int64_t k = 0; k < chunks; ++k) m = fmaxf(m, partial[k * C + c]);
+    for (int64_t k = 0; k < chunks; ++k) m = nmax(m, partial[k * C + c]);
     out[c] = m;
 }
 
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256) void absmax_rows(const float* x, int64_t R, in
     if (vec4) {
         for (int64_t c = lane * 4; c < C; c += 256) {
             const float4 t = *reinterpret_cast<const float4*>(row + c);
-            m = fmaxf(fmaxf(m, fabsf(t.x)), fmaxf(fmaxf(fabsf(t.y), fabsf(t.z)), fabsf(t.w)));
+            m = nmax(nmax(m, fabsf(t.x)), nmax(nmax(fabsf(t.y), fabsf(t.z)), fabsf(t.w)));
         }
     } else {
-        for (int64_t c = lane; c < C; c += 64) m = fmaxf(m, fabsf(row[c]));
+        for (int64_t c = lane; c < C; c += 64) m = nmax(m, fabsf(row[c]));
     }
     m = wave_max(m);
     if (lane == 0) out[r] = m;
@@ -280,11 +280,11 @@ __global__ __launch_bounds__(256) void minmax_rows(const float* x, int64_t R, in
     if (vec4) {
         for (int64_t c = lane * 4; c < C; c += 256) {
             const float4 t = *reinterpret_cast<const float4*>(row + c);
-            mn = fminf(fminf(mn, t.x), fminf(fminf(t.y, t.z), t.w));
-            mx = fmaxf(fmaxf(mx, t.x), fmaxf(fmaxf(t.y, t.z), t.w));
+            mn = nmin(nmin(mn, t.x), nmin(nmin(t.y, t.z), t.w));
+            mx = nmax(nmax(mx, t.x), nmax(nmax(t.y, t.z), t.w));
         }
     } else {
-        for (int64_t c = lane; c < C; c += 64) { mn = fminf(mn, row[c]); mx = fmaxf(mx, row[c]); }
+        for (int64_t c = lane; c < C; c += 64) { mn = nmin(mn, row[c]); mx = nmax(mx, row[c]); }
     }
     mn = wave_min(mn);
     mx = wave_max(mx);

@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     for (int r = 1; r < RPW; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            mn[i] = fminf(mn[i], v[r][i]);
-            mx[i] = fmaxf(mx[i], v[r][i]);
+            mn[i] = nmin(mn[i], v[r][i]);
+            mx[i] = nmax(mx[i], v[r][i]);
         }
 
     if (a.wpg > 1) {  // uniform over the block: cross-wave combine of the group's partials in LDS
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
         for (int w = 0; w < a.wpg; ++w) {
             const float4 tn = s_mn[w0 + w][lane];
             const float4 tx = s_mx[w0 + w][lane];
-            mn[0] = fminf(mn[0], tn.x); mn[1] = fminf(mn[1], tn.y);
-            mn[2] = fminf(mn[2], tn.z); mn[3] = fminf(mn[3], tn.w);
-            mx[0] = fmaxf(mx[0], tx.x); mx[1] = fmaxf(mx[1], tx.y);
-            mx[2] = fmaxf(mx[2], tx.z); mx[3] = fmaxf(mx[3], tx.w);
+            mn[0] = nmin(mn[0], tn.x); mn[1] = nmin(mn[1], tn.y);
+            mn[2] = nmin(mn[2], tn.z); mn[3] = nmin(mn[3], tn.w);
+            mx[0] = nmax(mx[0], tx.x); mx[1] = nmax(mx[1], tx.y);
+            mx[2] = nmax(mx[2], tx.z); mx[3] = nmax(mx[3], tx.w);
         }
     }
     if (!group_ok) return;
@@ -449,15 +449,15 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
     for (int r = 1; r < 16; ++r)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            mn[i] = fminf(mn[i], v[r][i]);
-            mx[i] = fmaxf(mx[i], v[r][i]);
+            mn[i] = nmin(mn[i], v[r][i]);
+            mx[i] = nmax(mx[i], v[r][i]);
         }
 #pragma unroll
     for (int off = LPR; off < 64; off <<= 1)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            mn[i] = fminf(mn[i], __shfl_xor(mn[i], off, 64));
-            mx[i] = fmaxf(mx[i], __shfl_xor(mx[i], off, 64));
+            mn[i] = nmin(mn[i], __shfl_xor(mn[i], off, 64));
+            mx[i] = nmax(mx[i], __shfl_xor(mx[i], off, 64));
         }
 
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
 #pragma unroll
         for (int i = 1; i < 4; ++i) {
             c = make_colq(qparam_from_minmax(mn[i], mx[i], a.grid), mn[i], mx[i], bias);
-            sc[i] = c.scale; rinv[i] = c.rinv; zpb[i] = c.zpb; thr = fminf(thr, c.thr);
+            sc[i] = c.scale; rinv[i] = c.rinv; zpb[i] = c.zpb; thr = nmin(thr, c.thr);
         }
     }
     // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
@@ -596,11 +596,11 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void col_range_partial(const Rang
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const bool live = ok && row0 + r < row_end;
-            mn[0] = fminf(mn[0], t[r].x); mn[1] = fminf(mn[1], t[r].y);
-            mn[2] = fminf(mn[2], t[r].z); mn[3] = fminf(mn[3], t[r].w);
+            mn[0] = nmin(mn[0], t[r].x); mn[1] = nmin(mn[1], t[r].y);
+            mn[2] = nmin(mn[2], t[r].z); mn[3] = nmin(mn[3], t[r].w);
             if (live) {
-                mx[0] = fmaxf(mx[0], t[r].x); mx[1] = fmaxf(mx[1], t[r].y);
-                mx[2] = fmaxf(mx[2], t[r].z); mx[3] = fmaxf(mx[3], t[r].w);
+                mx[0] = nmax(mx[0], t[r].x); mx[1] = nmax(mx[1], t[r].y);
+                mx[2] = nmax(mx[2], t[r].z); mx[3] = nmax(mx[3], t[r].w);
             }
         }
     } else {
@@ -611,8 +611,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void col_range_partial(const Rang
                 const int64_t col = slot_col<false>(tile_col0, lane, i);
                 if (col < a.N && row0 + r < row_end) {
                     const float x = a.W[(row0 + r) * a.ldw + col];
-                    mn[i] = fminf(mn[i], x);
-                    mx[i] = fmaxf(mx[i], x);
+                    mn[i] = nmin(mn[i], x);
+                    mx[i] = nmax(mx[i], x);
                 }
             }
     }
@@ -622,8 +622,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void col_range_partial(const Rang
     if (wave != 0) return;
     for (int w = 1; w < kMaxWaves; ++w) {
         const float4 tn = s_mn[w][lane], tx = s_mx[w][lane];
-        mn[0] = fminf(mn[0], tn.x); mn[1] = fminf(mn[1], tn.y); mn[2] = fminf(mn[2], tn.z); mn[3] = fminf(mn[3], tn.w);
-        mx[0] = fmaxf(mx[0], tx.x); mx[1] = fmaxf(mx[1], tx.y); mx[2] = fmaxf(mx[2], tx.z); mx[3] = fmaxf(mx[3], tx.w);
+        mn[0] = nmin(mn[0], tn.x); mn[1] = nmin(mn[1], tn.y); mn[2] = nmin(mn[2], tn.z); mn[3] = nmin(mn[3], tn.w);
+        mx[0] = nmax(mx[0], tx.x); mx[1] = nmax(mx[1], tx.y); mx[2] = nmax(mx[2], tx.z); mx[3] = nmax(mx[3], tx.w);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -643,8 +643,8 @@ __global__ void col_range_finalize(const float* pmin, const float* pmax, int64_t
     if (col >= N) return;
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t c = 0; c < chunks; ++c) {
-        mn = fminf(mn, pmin[(kg * chunks + c) * N + col]);
-        mx = fmaxf(mx, pmax[(kg * chunks + c) * N + col]);
+        mn = nmin(mn, pmin[(kg * chunks + c) * N + col]);
+        mx = nmax(mx, pmax[(kg * chunks + c) * N + col]);
     }
     const QParam p = qparam_from_minmax(mn, mx, grid);
     scale[col * kgroups + kg] = p.scale;
@@ -657,8 +657,8 @@ __global__ void col_fold_kernel(float* pmin, float* pmax, int64_t N, int64_t row
     if (col >= N) return;
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t r = 0; r < rows; ++r) {
-        mn = fminf(mn, pmin[r * N + col]);
-        mx = fmaxf(mx, pmax[r * N + col]);
+        mn = nmin(mn, pmin[r * N + col]);
+        mx = nmax(mx, pmax[r * N + col]);
     }
     pmin[col] = mn;
     pmax[col] = mx;
@@ -670,8 +670,8 @@ __global__ __launch_bounds__(1024) void tensor_range_finalize(const float* pmin,
     __shared__ float s_mn[16], s_mx[16];
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
-        mn = fminf(mn, pmin[i]);
-        mx = fmaxf(mx, pmax[i]);
+        mn = nmin(mn, pmin[i]);
+        mx = nmax(mx, pmax[i]);
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
@@ -680,8 +680,8 @@ __global__ __launch_bounds__(1024) void tensor_range_finalize(const float* pmin,
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w) {
-            mn = fminf(mn, s_mn[w]);
-            mx = fmaxf(mx, s_mx[w]);
+            mn = nmin(mn, s_mn[w]);
+            mx = nmax(mx, s_mx[w]);
         }
         const QParam p = qparam_from_minmax(mn, mx, grid);
         scale[0] = p.scale;
@@ -828,8 +828,8 @@ __global__ __launch_bounds__(256) void rtn_flat_groups(const float* W, int64_t K
     for (int64_t t = lane; t < g; t += 64) {
         const int64_t f = grp * g + t, n = f / K, k = f - n * K;
         const float x = W[k * ldw + n];
-        mn = fminf(mn, x);
-        mx = fmaxf(mx, x);
+        mn = nmin(mn, x);
+        mx = nmax(mx, x);
     }
     mn = wave_min(mn);
     mx = wave_max(mx);

@@ -42,17 +42,17 @@ __global__ __launch_bounds__(kManyBlock) void rtn_many_partial(const RtnTensorDe
         for (int u = 0; u < 4; ++u) a[u] = xv[i + u * stride];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            mn = fminf(fminf(fminf(mn, a[u].x), fminf(a[u].y, a[u].z)), a[u].w);
-            mx = fmaxf(fmaxf(fmaxf(mx, a[u].x), fmaxf(a[u].y, a[u].z)), a[u].w);
+            mn = nmin(nmin(nmin(mn, a[u].x), nmin(a[u].y, a[u].z)), a[u].w);
+            mx = nmax(nmax(nmax(mx, a[u].x), nmax(a[u].y, a[u].z)), a[u].w);
         }
     }
     for (; i < nvec; i += stride) {
         const f32x4 a = xv[i];
-        mn = fminf(fminf(mn, a.x), fminf(fminf(a.y, a.z), a.w));
-        mx = fmaxf(fmaxf(mx, a.x), fmaxf(fmaxf(a.y, a.z), a.w));
+        mn = nmin(nmin(mn, a.x), nmin(nmin(a.y, a.z), a.w));
+        mx = nmax(nmax(mx, a.x), nmax(nmax(a.y, a.z), a.w));
     }
-    for (int64_t j = tid; j < head; j += stride) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
-    for (int64_t j = head + nvec * 4 + tid; j < count; j += stride) { mn = fminf(mn, x[j]); mx = fmaxf(mx, x[j]); }
+    for (int64_t j = tid; j < head; j += stride) { mn = nmin(mn, x[j]); mx = nmax(mx, x[j]); }
+    for (int64_t j = head + nvec * 4 + tid; j < count; j += stride) { mn = nmin(mn, x[j]); mx = nmax(mx, x[j]); }
     mn = wave_min(mn);
     mx = wave_max(mx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kManyBlock) void rtn_many_partial(const RtnTensorDe
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int w = 1; w < kManyBlock / 64; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        for (int w = 1; w < kManyBlock / 64; ++w) { mn = nmin(mn, s_mn[w]); mx = nmax(mx, s_mx[w]); }
         float* o = partial + (static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 2;
         o[0] = mn;
         o[1] = mx;
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(64) void rtn_many_finalize(const RtnTensorDesc* des
     const float* p = partial + static_cast<int64_t>(blockIdx.x) * slices * 2;
     float mn = INFINITY, mx = -INFINITY;
     for (int i = threadIdx.x; i < slices; i += 64) {
-        mn = fminf(mn, p[2 * i]);
-        mx = fmaxf(mx, p[2 * i + 1]);
+        mn = nmin(mn, p[2 * i]);
+        mx = nmax(mx, p[2 * i + 1]);
     }
     mn = wave_min(mn);
     mx = wave_max(mx);

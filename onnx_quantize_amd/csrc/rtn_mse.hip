@@ -51,10 +51,10 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(const float* W, int64_t K
     float mn = INFINITY, mx = -INFINITY;
     for (int64_t r = 0; r < g; ++r) {
         const float x = col[r * ldw];
-        mn = fminf(mn, x);
-        mx = fmaxf(mx, x);
+        mn = nmin(mn, x);
+        mx = nmax(mx, x);
     }
-    const float lo0 = fminf(mn, 0.0f), hi0 = fmaxf(mx, 0.0f);
+    const float lo0 = nmin(mn, 0.0f), hi0 = nmax(mx, 0.0f);
     float best = FLT_MAX;   // np.finfo(float32).max, utils.py:190
     uint32_t mask = 0;
     for (int i = 0; i < kMseSteps; ++i) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(const float* W, int64_t K
 __global__ __launch_bounds__(256) void mse_tensor_partial(const float* W, int64_t K, int64_t N, int64_t ldw, const float* range,
                                                           QGrid grid, float* partial /* [blocks][20] */) {
     __shared__ float s_sum[4][kMseSteps];
-    const float lo0 = fminf(range[0], 0.0f), hi0 = fmaxf(range[1], 0.0f);
+    const float lo0 = nmin(range[0], 0.0f), hi0 = nmax(range[1], 0.0f);
     QParam qp[kMseSteps];
 #pragma unroll
     for (int i = 0; i < kMseSteps; ++i) qp[i] = qparam_from_range(shrink_factor(i) * lo0, shrink_factor(i) * hi0, grid);
@@ -121,8 +121,8 @@ __global__ void mse_tensor_mask(const float* partial, int nblocks, const float* 
         for (int b = 0; b < nblocks; ++b) err += partial[b * kMseSteps + i];
         if (err < best) { best = err; mask |= 1u << i; }
     }
-    row->lo0 = fminf(range[0], 0.0f);
-    row->hi0 = fmaxf(range[1], 0.0f);
+    row->lo0 = nmin(range[0], 0.0f);
+    row->hi0 = nmax(range[1], 0.0f);
     row->mask = mask;
     *any_mask = mask;
 }
@@ -135,15 +135,15 @@ __global__ __launch_bounds__(1024) void tensor_minmax_kernel(const float* W, int
     for (int64_t t = threadIdx.x; t < total; t += blockDim.x) {
         const int64_t k = t / N, n = t - k * N;
         const float x = W[k * ldw + n];
-        mn = fminf(mn, x);
-        mx = fmaxf(mx, x);
+        mn = nmin(mn, x);
+        mx = nmax(mx, x);
     }
     mn = wave_min(mn);
     mx = wave_max(mx);
     if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+        for (int w = 1; w < 16; ++w) { mn = nmin(mn, s_mn[w]); mx = nmax(mx, s_mx[w]); }
         range[0] = mn;
         range[1] = mx;
     }

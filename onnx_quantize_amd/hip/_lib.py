@@ -63,6 +63,7 @@ PROTOTYPES = {
     "oq_minmax_rows_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p]),
     "oq_quantize_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _i64, _i64, _i64, _i32, _i32, _i32, _p, _p]),
     "oq_dequantize_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p, _i64, _i64, _i64, _p, _i64, _p]),
+    "oq_dequantize_fzp_f32": (_i32, [_p, _i64, _i64, _i32, _p, _p, _i64, _i64, _i64, _p, _i64, _p]),
     "oq_quantize_bias_f32": (_i32, [_p, _i64, _p, _i64, _f32, _p, _p, _p]),
     "oq_minmax_workspace_bytes": (_sz, [_i64]),
     "oq_minmax_collect_f32": (_i32, [_p, _i64, _p, _f64, _p, _sz, _p]),

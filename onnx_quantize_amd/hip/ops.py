@@ -256,11 +256,24 @@ def _param_index(mode: str, r: int, c: int, group: int = 1):
     raise ValueError(mode)
 
 
+def _ragged_group(r: int, c: int, mode: str, group: int) -> bool:
+    """Groups of `group` rows that do not divide K: the reference then forms them on `W.T.reshape(-1, g)` (utils.py:24),
+    i.e. element (k, n) belongs to group (n*K + k) // g and groups straddle columns."""
+    if mode != "group" or r % group == 0:
+        return False
+    if (r * c) % group:
+        raise ValueError(f"cannot reshape array of size {r * c} into shape (-1, {group})")
+    return True
+
+
 def quantize(x: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, qtype: str, symmetric: bool,
              reduce_range: bool, mode: str = "tensor", group: int = 1) -> torch.Tensor:
     """utils.py:72-79.  x [R, C] fp32; (scale, zp) indexed per `mode` (see oq_quantize_f32)."""
     _require_device(x, "x", torch.float32)
     x2 = x.reshape(1, -1) if x.dim() != 2 else x
+    if _ragged_group(x2.shape[0], x2.shape[1], mode, group):      # the reference's own row layout, one parameter per row
+        rows = x2.t().contiguous().reshape(-1, group)
+        return quantize(rows, scale, zp, qtype, symmetric, reduce_range, mode="row").reshape(x2.shape[1], x2.shape[0]).t().contiguous()
     x2, ldx = _row_major(x2)
     r, c = x2.shape
     s = scale.to(torch.float32).contiguous().reshape(-1)
@@ -274,17 +287,26 @@ def quantize(x: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, qtype: str,
 
 def dequantize(q: torch.Tensor, scale: torch.Tensor, zp: torch.Tensor, qtype: str, mode: str = "tensor",
                group: int = 1) -> torch.Tensor:
-    """utils.py:102-137 (without the layout shuffles: `mode` addresses the parameters in place)."""
+    """utils.py:102-137 (without the layout shuffles: `mode` addresses the parameters in place).  Floating-point zero
+    points (HQQ, hqq.py:77-78) are subtracted as they are, like `zero_point.astype(float32)` in utils.py:131."""
     _require_device(q, "q", container_dtype(qtype))
     q2 = q.reshape(1, -1) if q.dim() != 2 else q
+    if _ragged_group(q2.shape[0], q2.shape[1], mode, group):
+        rows = q2.t().contiguous().reshape(-1, group)
+        return dequantize(rows, scale, zp, qtype, mode="row").reshape(q2.shape[1], q2.shape[0]).t().contiguous()
     q2 = q2.contiguous()
     r, c = q2.shape
     s = scale.to(torch.float32).contiguous().reshape(-1)
-    z = zp.to(torch.int32).contiguous().reshape(-1)
     out = torch.empty((r, c), dtype=torch.float32, device=q.device)
     rd, rs, cs = _param_index(mode, r, c, group)
-    L.check(L.load().oq_dequantize_f32(_ptr(q2), r, c, L.QTYPE_CODE[qtype], _ptr(s), _ptr(z), rd, rs, cs,
-                                       _ptr(out), c, _stream()))
+    if zp.dtype.is_floating_point:
+        z = zp.to(torch.float32).contiguous().reshape(-1)
+        L.check(L.load().oq_dequantize_fzp_f32(_ptr(q2), r, c, L.QTYPE_CODE[qtype], _ptr(s), _ptr(z), rd, rs, cs,
+                                               _ptr(out), c, _stream()))
+    else:
+        z = zp.to(torch.int32).contiguous().reshape(-1)
+        L.check(L.load().oq_dequantize_f32(_ptr(q2), r, c, L.QTYPE_CODE[qtype], _ptr(s), _ptr(z), rd, rs, cs,
+                                           _ptr(out), c, _stream()))
     return out.reshape(q.shape)
 
 

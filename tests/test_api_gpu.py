@@ -359,6 +359,28 @@ def test_calibration_of_a_tensor_with_more_than_2_31_elements():
     torch.cuda.empty_cache()
 
 
+def test_calibrator_propagates_nan_like_numpy():
+    """minmax.py:47-48 uses np.min / np.max: one NaN activation makes the tensor's range NaN (and keeps it NaN through the
+    running min / max and the EMA).  ADVICE r01: the reductions used to drop NaN and hide the corruption."""
+    from onnx_quantize_amd.calibration import MinMaxCalibrator
+    rng = np.random.default_rng(12)
+    clean = rng.standard_normal((4, 33, 65)).astype(np.float32)
+    dirty = clean.copy()
+    dirty[2, 17, 40] = np.nan
+    for momentum in (0.0, 0.5):
+        cal, ref = MinMaxCalibrator(momentum), O.MinMaxOracle(momentum)
+        for x in (clean, dirty, clean):
+            cal.collect("x", x)
+            cal.collect_many({"y": x})
+            ref.collect("x", x)
+        assert np.isnan(ref.data["x"][0]) and np.isnan(ref.data["x"][1])          # what NumPy (the reference) ends up with
+        for name in ("x", "y"):
+            assert np.isnan(cal.data[name].min_val) and np.isnan(cal.data[name].max_val), (momentum, name)
+        ok = MinMaxCalibrator(momentum)
+        ok.collect("x", clean)
+        assert np.isfinite(ok.data["x"].min_val)
+
+
 def test_plugin_seam_against_the_reference_plugins():
     """tests/golden/seam.*: `qconfig.weights.algorithm.quantize_weights(w, qconfig, out=out)` -- the one call through which the
     reference reaches the path (qrules/_common.py:133) -- of the reference's RTNConfig / GPTQConfig / HqqConfig on carrier

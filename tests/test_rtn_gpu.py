@@ -356,6 +356,83 @@ def test_elementwise_quantize_dequantize_every_parameter_mode(qtype, r, c, mode,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,n,g", [(6, 4, 4), (20, 12, 16), (100, 12, 32), (96, 40, 64)])
+def test_ragged_groups_roundtrip_against_the_oracle(k, n, g):
+    """Groups that do not divide K straddle columns exactly like `W.T.reshape(-1, g)` (utils.py:24): element (k, n) belongs
+    to group (n*K + k) // g.  `_dequantize_array(preprocess=True, GROUP)` / `ops.dequantize(mode="group")` /
+    `ops.quantize(mode="group")` must address the parameters that way (K=6, N=4, g=4, element (2, 1) uses
+    parameter 1, not 2, when addressed as (k // g) + n * (K // g))."""
+    import torch
+    from onnx_quantize_amd import QuantizationStrategy
+    from onnx_quantize_amd.algorithms import functional as F
+    from onnx_quantize_amd.hip import ops
+    w = (np.random.default_rng(k * n + g).standard_normal((k, n)) * 2).astype(np.float32)
+    eq, es, ez = O.rtn_quantize(w, "uint8", "group", g)
+    rows = O.to_rows(eq, "group", g)
+    edq = O.from_rows(O.dequantize(rows, es, ez), eq, "group")
+    q, s, z = ops.rtn_quantize(torch.from_numpy(w).cuda(), "uint8", "group", g)
+    np.testing.assert_array_equal(q.cpu().numpy(), eq)
+    got = F._dequantize_array(eq, es, ez, preprocess=True, strategy=QuantizationStrategy.GROUP, group_size=g)
+    assert got.tobytes() == np.ascontiguousarray(edq, np.float32).tobytes()
+    dq = ops.dequantize(q, s, z, "uint8", mode="group", group=g)
+    assert dq.cpu().numpy().tobytes() == np.ascontiguousarray(edq, np.float32).tobytes()
+    rq = ops.quantize(torch.from_numpy(w).cuda(), s, z, "uint8", False, False, mode="group", group=g)
+    np.testing.assert_array_equal(rq.cpu().numpy(), eq)
+    assert (k * n) % 7 and k % 7
+    with pytest.raises(ValueError, match="cannot reshape array"):
+        ops.dequantize(q, s, z, "uint8", mode="group", group=7)
+
+
+@pytest.mark.gpu
+def test_dequantize_keeps_float_zero_points():
+    """HQQ's zero points are floats (hqq.py:77-78) and utils.py:131 subtracts them as they are: 7.4 must not become 7."""
+    import torch
+    from onnx_quantize_amd import QuantizationStrategy
+    from onnx_quantize_amd.algorithms import functional as F
+    from onnx_quantize_amd.hip import ops
+    rng = np.random.default_rng(9)
+    k, n, g = 64, 24, 16
+    q = rng.integers(0, 16, size=(k, n)).astype(np.uint8)
+    s = rng.uniform(0.01, 0.2, size=(n * k // g, 1)).astype(np.float32)
+    z = rng.uniform(0, 15, size=(n * k // g, 1)).astype(np.float32)
+    exp = O.from_rows((O.to_rows(q, "group", g).astype(np.float32) - z) * s, q, "group")
+    got = F._dequantize_array(q, s, z, preprocess=True, strategy=QuantizationStrategy.GROUP, group_size=g)
+    assert got.tobytes() == np.ascontiguousarray(exp, np.float32).tobytes()
+    dq = ops.dequantize(torch.from_numpy(q).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(z).cuda(), "uint4", mode="group", group=g)
+    assert dq.cpu().numpy().tobytes() == np.ascontiguousarray(exp, np.float32).tobytes()
+    trunc = O.from_rows((O.to_rows(q, "group", g).astype(np.float32) - np.trunc(z)) * s, q, "group")
+    assert not np.array_equal(trunc, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strategy,g,layout", [("group", 128, "kn"), ("group", 128, "nbits"), ("group", 32, "kn"), ("channel", -1, "kn"),
+                                               ("tensor", -1, "kn")])
+def test_nan_weights_poison_their_range_like_numpy(strategy, g, layout):
+    """np.min / np.max propagate NaN (utils.py:60-61): a NaN weight gives its group (channel, tensor) a NaN scale in the
+    reference.  The kernels' reductions are NaN-propagating too (v_minimum3_f32 / v_maximum3_f32), so the corruption shows
+    up in the same scales; every group without a NaN stays bit-exact.  (What integer a NaN itself becomes is
+    implementation-defined in NumPy and outside the parity claim.)"""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    w = np.random.default_rng(77).standard_normal((256, 96)).astype(np.float32)
+    w[130, 5] = np.nan
+    w[3, 40] = np.nan
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            eq, es, ez = O.rtn_quantize(w, "uint4", strategy, g)
+    q, s, z = ops.rtn_quantize(torch.from_numpy(w).cuda(), "uint4", strategy, g, layout=layout)
+    s, z = s.cpu().numpy(), z.cpu().numpy()
+    bad = np.isnan(es)
+    assert bad.any() and np.array_equal(np.isnan(s), bad)
+    assert s[~bad].tobytes() == es[~bad].tobytes() and np.array_equal(z[~bad], ez[~bad])
+    if layout == "kn" and strategy == "group":
+        rows_ok = ~bad.reshape(-1)
+        np.testing.assert_array_equal(O.to_rows(q.cpu().numpy(), "group", g)[rows_ok], O.to_rows(eq, "group", g)[rows_ok])
+
+
+@pytest.mark.gpu
 def test_more_than_2_31_elements():
     """Indexing is 64-bit wherever a flat offset can pass 2^31: a 32768 x 69632 weight (2.28e9 elements, 9.1 GB) through
     the blob and the [K, N] kernels; sampled column strips (incl. the last one) against the oracle."""
