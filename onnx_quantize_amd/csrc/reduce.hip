@@ -15,7 +15,7 @@ template <> struct Vec4<float> { typedef float type __attribute__((ext_vector_ty
 template <> struct Vec4<double> { typedef double type __attribute__((ext_vector_type(4))); };
 
 template <typename T>
-__device__ __forceinline__ T t_min(T a, T b) { return a < b ? a : b; }
+__device__ __forceinline__ T t_min(T a, T b) { return nmin(a, b); }
 
 template <typename T>
 __device__ __forceinline__ void block_minmax(T& mn, T& mx, T* s_mn, T* s_mx) {
@@ -26,8 +26,8 @@ __device__ __forceinline__ void block_minmax(T& mn, T& mx, T* s_mn, T* s_mx) {
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w) {
-            mn = mn < s_mn[w] ? mn : s_mn[w];
-            mx = mx > s_mx[w] ? mx : s_mx[w];
+            mn = nmin(mn, s_mn[w]);
+            mx = nmax(mx, s_mx[w]);
         }
     }
 }

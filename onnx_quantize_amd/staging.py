@@ -83,7 +83,10 @@ class WeightStager:
             self._sweep()
             locked = int(torch.cuda.cudart().cudaHostRegister(src.ctypes.data, src.nbytes, 0)) == 0
         with torch.cuda.stream(stream):
-            dev = torch.from_numpy(src).to(self.device, non_blocking=True)
+            # asynchronous only from page-locked memory that `_registered` keeps alive until the event has passed: an
+            # asynchronous copy from pageable memory may still be reading `src` after this function has returned (and a
+            # temporary `src` has been freed): a GPU page fault.  The blocking form returns when the bytes have left.
+            dev = torch.from_numpy(src).to(self.device, non_blocking=locked)
             ev = torch.cuda.Event()
             ev.record(stream)
         if locked:
