@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void tile_kernel(const float* __restrict__ xin
                     }
                     *reinterpret_cast<f32x4*>(xout + (r + u) * ldx + c) = o;
                 }
-                if (rp.next()) load_params();                   // uniform over the block
+                // uniform over the block; not after the tile's last row: the next parameter row may not exist (one entry
+                // past the end of scale / zp for the matrix' last rows: a page fault when the array ends its mapping)
+                if (rp.next() && r + u + 1 < r1) load_params();
             }
         }
     }
