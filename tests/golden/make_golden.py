@@ -41,13 +41,17 @@ def _load_reference():
         UINT8 = 2
         INT8 = 3
         INT32 = 6
+        INT64 = 7
         UINT32 = 12
         UINT4 = 21
         INT4 = 22
 
+        def __str__(self):                      # onnx_ir.DataType prints its name; the config serialiser relies on it
+            return self.name
+
         def numpy(self):
             return {
-                2: np.dtype(np.uint8), 3: np.dtype(np.int8), 6: np.dtype(np.int32),
+                2: np.dtype(np.uint8), 3: np.dtype(np.int8), 6: np.dtype(np.int32), 7: np.dtype(np.int64),
                 12: np.dtype(np.uint32), 21: np.dtype(np.uint8), 22: np.dtype(np.int8),
             }[int(self)]
 
@@ -456,8 +460,8 @@ def _load_passes():
     ir = sys.modules["onnx_ir"]
 
     class Tensor:
-        def __init__(self, a):
-            self._a = np.asarray(a)
+        def __init__(self, a, dtype=None):
+            self._a = np.asarray(a) if dtype is None else np.asarray(a, dtype=dtype.numpy())
 
         def numpy(self):
             return self._a
@@ -887,6 +891,144 @@ def gen_seam_qw(out):
     print(f"seam_qw: {len(cases)} cases ({sum('raises' in c for c in cases)} raising)")
 
 
+def _load_rules():
+    """The rewrite rules (qrules/_qdq/*.py, qrules/_qlinear/*.py, qrules/base.py) and the function-name factories
+    (qfunctions/factory.py) need `onnxscript` only for (a) the base class of a rule, whose `rule()` is called once at
+    import, (b) `MatchResult` inside `check` (not run here), (c) the `@script` decorator of the emitted functions, whose
+    bodies are never executed at quantize time.  Those three names are stood in for; every `_rewrite*` method, the
+    `_common` helpers and the factories run unmodified."""
+    common = _load_common()
+    ir = sys.modules["onnx_ir"]
+    if "onnxscript" not in sys.modules:
+        osc = types.ModuleType("onnxscript")
+
+        class RewriteRuleClassBase:
+            def rule(self):
+                return self
+
+        class Opset:
+            def __init__(self, domain, version):
+                self.domain, self.version = domain, version
+
+        def script(opset=None, **_):
+            def deco(fn):
+                fn.to_function_proto = lambda: fn.__name__
+                return fn
+            return deco
+
+        osc.rewriter = types.SimpleNamespace(RewriteRuleClassBase=RewriteRuleClassBase, MatchResult=object)
+        osc.values = types.SimpleNamespace(Opset=Opset)
+        osc.script = script
+        osc.opset21 = types.SimpleNamespace()
+        sys.modules["onnxscript"] = osc
+        ir.AttrInt64 = lambda name, value: types.SimpleNamespace(name=name, value=value)
+        qf = types.ModuleType("onnx_quantize.qfunctions")        # its __init__ deserialises function protos: bypassed
+        qf.__path__ = [os.path.join(REF, "qfunctions")]
+        sys.modules["onnx_quantize.qfunctions"] = qf
+        reg = importlib.import_module("onnx_quantize.qfunctions.register")
+        fac = importlib.import_module("onnx_quantize.qfunctions.factory")
+        qf.MS_OPSET, qf.QUANT_OPSET, qf.get_qfunction = reg.MS_OPSET, reg.QUANT_OPSET, fac.get_qfunction
+        qf.factory = fac
+    mods = types.SimpleNamespace(common=common)
+    mods.qdq_matmul = importlib.import_module("onnx_quantize.qrules._qdq.matmul_to_qmatmul")
+    mods.qdq_gemm = importlib.import_module("onnx_quantize.qrules._qdq.gemm_to_qgemm")
+    mods.ql_matmul = importlib.import_module("onnx_quantize.qrules._qlinear.matmul_to_qmatmul")
+    mods.ql_gemm = importlib.import_module("onnx_quantize.qrules._qlinear.gemm_to_qgemm")
+    return mods
+
+
+class RecordingOp(RecordingTape):
+    """The rewriter's `op`: initializers are recorded, any other attribute is an operator / function call whose name,
+    input value names and attributes are recorded."""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def __getattr__(self, name):
+        ir = sys.modules["onnx_ir"]
+
+        def call(*args, **kw):
+            self.calls.append((name, [None if a is None else a.name for a in args], dict(kw)))
+            return ir.val(f"{name}/out")
+        return call
+
+
+def gen_emit(out):
+    """The emission contract without the ONNX stack: every rule class's `_rewrite` (qrules/base.py:51-81
+    dispatch -> `_rewrite_weights_only[_standard|_matmul_nbits]` / `_rewrite_static` / `_rewrite_dynamic`,
+    `_get_activation_qparams` :15-40) run on a recording `op` for the rule paths of the five BASELINE configurations and
+    the Gemm / QLinear variants next to them: initializer names, shapes, dtypes and values, the emitted function or
+    operator name, its input order, attributes, domain and version."""
+    M = _load_rules()
+    ir = sys.modules["onnx_ir"]
+    Q = R.qconfig
+    act = lambda dt, **kw: Q.QActivationArgs(dtype=QT[dt], **kw)      # noqa: E731
+    grid = [  # (id, rule class, has bias, k, n, QWeightArgs kwargs, algorithm, QConfig kwargs)
+        ("config1_int8_sym_tensor", M.qdq_matmul.MatMulToQMatMul, False, 256, 512, dict(dtype="int8", symmetric=True), None, {}),
+        ("config2_uint4_g128_nbits", M.qdq_matmul.MatMulToQMatMul, False, 256, 24, dict(dtype="uint4", group_size=128), None, {}),
+        ("config3_static_qdq", M.qdq_matmul.MatMulToQMatMul, False, 64, 48, dict(dtype="int8"), None,
+         dict(input_activations=act("int8", is_static=True), output_activations=act("int8", is_static=True))),
+        ("config3_static_qlinear", M.ql_matmul.MatMulToQLinearMatMul, False, 64, 48, dict(dtype="int8", symmetric=True), None,
+         dict(format="qlinear", input_activations=act("uint8", is_static=True), output_activations=act("uint8", is_static=True))),
+        ("config4_gptq_int4_g128", M.qdq_matmul.MatMulToQMatMul, False, 256, 16, dict(dtype="int4", group_size=128), "gptq", {}),
+        ("matmul_int8_group32", M.qdq_matmul.MatMulToQMatMul, False, 64, 12, dict(dtype="int8", group_size=32), None, {}),
+        ("matmul_dynamic_input", M.qdq_matmul.MatMulToQMatMul, False, 64, 12, dict(dtype="int8", strategy="channel"), None,
+         dict(input_activations=act("uint8", is_static=False))),
+        ("matmul_static_input_only", M.qdq_matmul.MatMulToQMatMul, False, 64, 12, dict(dtype="uint8"), None,
+         dict(input_activations=act("uint8", is_static=True))),
+        ("gemm_bias_uint4_g32_nbits", M.qdq_gemm.GemmBiasToQGemmBias, True, 64, 12, dict(dtype="uint4", group_size=32), None, {}),
+        ("gemm_bias_int4_g32_grouped", M.qdq_gemm.GemmBiasToQGemmBias, True, 64, 12, dict(dtype="int4", group_size=32), None, {}),
+        ("gemm_bias_static_qdq", M.qdq_gemm.GemmBiasToQGemmBias, True, 64, 12, dict(dtype="int8", symmetric=True, strategy="channel"), None,
+         dict(input_activations=act("int8", is_static=True), output_activations=act("int8", is_static=True))),
+        ("gemm_bias_dynamic_qdq", M.qdq_gemm.GemmBiasToQGemmBias, True, 64, 12, dict(dtype="int8"), None,
+         dict(input_activations=act("uint8", is_static=False))),
+        ("gemm_nobias_int8_channel", M.qdq_gemm.GemmToQGemm, False, 64, 12, dict(dtype="int8", strategy="channel"), None, {}),
+        ("gemm_bias_static_qlinear", M.ql_gemm.GemmBiasToQLinearGemmBias, True, 64, 12, dict(dtype="int8", symmetric=True), None,
+         dict(format="qlinear", input_activations=act("uint8", is_static=True), output_activations=act("uint8", is_static=True))),
+    ]
+    cases, arrays = [], {}
+    for idx, (cid, rule_cls, has_bias, k, n, wkw, algo, ckw) in enumerate(grid):
+        rng = np.random.default_rng(500 + idx)
+        w = (rng.standard_normal((k, n)) * 0.1).astype(np.float32)
+        b = (rng.standard_normal(n) * 0.05).astype(np.float32)
+        x = (rng.standard_normal((4, 8, k)) * rng.uniform(0.3, 3.0, size=k)).astype(np.float32)
+        kw = {**wkw, "dtype": QT[wkw["dtype"]]}
+        if algo == "gptq":
+            kw["algorithm"] = R.gptq.GPTQConfig()
+        qc = Q.QConfig(weights=Q.QWeightArgs(**kw), **ckw)
+        meta = {"qconfig": qc.model_dump(), "input": x}
+        for kind, aargs in (("input", qc.input_activations), ("output", qc.output_activations)):
+            if aargs is not None and aargs.is_static:
+                meta[f"{kind}_scale"] = np.array(0.02 + 0.01 * idx + (0.005 if kind == "output" else 0), dtype=np.float32)
+                meta[f"{kind}_zero_point"] = np.array(3 if kind == "input" else 5).astype(aargs.dtype.np_dtype)
+        node = types.SimpleNamespace(meta=meta, outputs=[ir.val("fc/out")], attributes={})
+        outv = ir.val("fc/out")
+        outv.producer = lambda node=node: node
+        op = RecordingOp()
+        args = [ir.val("X"), ir.val("fc.weight", ir.tensor(w))] + ([ir.val("fc.bias", ir.tensor(b))] if has_bias else []) + [outv]
+        rule = rule_cls()
+        rule._rewrite(op, *args)
+        key = f"e{idx}"
+        arrays[key + "_w"], arrays[key + "_b"], arrays[key + "_x"] = w, b, x
+        inits = []
+        for j, (name, a) in enumerate(op.initializers):
+            arrays[f"{key}_i{j}"] = a.astype(np.float32) if a.dtype.kind == "f" else a.astype(np.int64)
+            inits.append(dict(name=name, shape=list(a.shape), dtype=str(a.dtype)))
+        assert len(op.calls) == 1
+        cname, cin, ckw2 = op.calls[0]
+        cases.append(dict(id=cid, key=key, rule=rule_cls.__name__, op_type=rule.op_type, has_bias=has_bias, k=k, n=n, weights=wkw, algorithm=algo,
+                          format=qc.format.value,
+                          input_activations=None if qc.input_activations is None else dict(dtype=_describe(qc.input_activations, ["dtype"])["dtype"], is_static=qc.input_activations.is_static),
+                          output_activations=None if qc.output_activations is None else dict(dtype=_describe(qc.output_activations, ["dtype"])["dtype"], is_static=qc.output_activations.is_static),
+                          meta={m: (float(v) if m.endswith("scale") else int(v)) for m, v in meta.items() if m not in ("qconfig", "input")},
+                          initializers=inits, call=dict(name=cname, inputs=cin, attrs={a: v for a, v in ckw2.items()})))
+    np.savez_compressed(os.path.join(out, "emit.npz"), **arrays)
+    with open(os.path.join(out, "emit.json"), "w") as f:
+        json.dump({"cases": cases}, f, indent=1)
+    print(f"emit: {len(cases)} rule paths")
+
+
 def gen_digests(out):
     """Digests of the BASELINE.json configurations (inputs are regenerated from seeds)."""
     d = {}
@@ -931,7 +1073,7 @@ def gen_digests(out):
 def main():
     out = HERE
     gens = dict(scalar_kats=gen_scalar_kats, rtn_small=gen_rtn_small, rtn_mse=gen_rtn_mse, kernels=gen_kernels,
-                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, seam=gen_seam, seam_qw=gen_seam_qw, digests=gen_digests)
+                minmax=gen_minmax, gptq=gen_gptq, hqq=gen_hqq, awq=gen_awq, calibrate=gen_calibrate, nbits=gen_nbits, config=gen_config, seam=gen_seam, seam_qw=gen_seam_qw, emit=gen_emit, digests=gen_digests)
     for name in (sys.argv[1:] or list(gens)):     # python make_golden.py [hqq ...] regenerates only the named sets
         gens[name](out)
     meta = dict(numpy=np.__version__, python=sys.version.split()[0],
@@ -940,8 +1082,13 @@ def main():
                            "call also Tensor (returns its array), Value (name + constant), passes.InPlacePass = object, "
                            "convenience.get_const_tensor / replace_all_uses_with, tape.Tape / Model / Node / Value names for annotations",
                            "ml_dtypes: bfloat16 entry of calibrate.py's dtype table",
-                           "package objects with __path__ for onnx_quantize, onnx_quantize.pre_passes, onnx_quantize.qrules "
-                           "(their __init__ pull in onnx / onnxscript)"],
+                           "package objects with __path__ for onnx_quantize, onnx_quantize.pre_passes, onnx_quantize.qrules, "
+                           "onnx_quantize.qfunctions (their __init__ pull in onnx / onnxscript)",
+                           "onnxscript (emit set only): rewriter.RewriteRuleClassBase (a base class with rule()), rewriter.MatchResult, "
+                           "values.Opset (domain + version), script (a decorator that returns the function: the emitted functions' "
+                           "bodies are never executed at quantize time), opset21; onnx_ir.AttrInt64 name",
+                           "recording tapes for the rewriter's `op`: initializer(tensor, name=) and operator / function calls are "
+                           "recorded (seam_qw and emit sets)"],
                 replaced_or_overridden=["calibrate._collect_activations (the onnxruntime session) -> a prepared list of per-batch dicts",
                                         "AwqPass.is_valid_node -> True; AwqPass / SmoothQuantPass._insert_mul_node_before -> records the "
                                         "scale initializer (graph edits only)"],
