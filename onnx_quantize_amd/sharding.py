@@ -188,3 +188,151 @@ def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], min
             z = buf[o:o + nz].view(getattr(torch, zd.split(".")[-1])).reshape(zs); o += (nz + 15) // 16 * 16
             out[specs[i].name] = (q, s, z)
     return {s.name: out[s.name] for s in specs}, total
+
+
+# ------------------------------------------------------------------------------------------------ inside one matrix
+# groups run along K for a fixed output channel, so a matrix also shards by COLUMNS: group / channel RTN
+# and the GPTQ loop need no exchange at all (every output channel is independent given the inverse factor); per-tensor RTN
+# needs the global range -- one all_reduce of two floats (utils.py:42-69 over the whole array); the Hessian of one input
+# can be accumulated over disjoint SAMPLES on different ranks and summed with one all_reduce of [K, K] floats
+# (gptq.py:246-260: H = (2 / n) sum X^T X, n = samples).  This is what lets ONE wide layer use several GPUs.
+
+def column_ranges(n: int, world_size: int, align: int = 32) -> list[tuple[int, int]]:
+    """Contiguous column ranges [n0, n1) per rank, boundaries on multiples of `align` (32 = one wave strip of the fused
+    kernels, 2 = a zero-point byte of the MatMulNBits layout); trailing ranks may be empty for narrow matrices."""
+    units = -(-n // align)
+    out, start = [], 0
+    for r in range(world_size):
+        cnt = units // world_size + (1 if r < units % world_size else 0)
+        end = min(n, start + cnt * align)
+        out.append((start, end))
+        start = end
+    return out
+
+
+class HipKernels:
+    """The device kernels the column-sharded drivers call (torch tensors in HBM)."""
+
+    @staticmethod
+    def rtn(w, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio):
+        from .hip import ops
+        return ops.rtn_quantize(w, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio)
+
+    @staticmethod
+    def minmax(w):
+        """Raw (min, max) of a tensor as a 2-element fp32 tensor on its device (the calibration reduction kernel)."""
+        from .hip import ops
+        st = ops.minmax_state(w.device)
+        ops.minmax_collect(w, st)
+        return st[:2].clone()
+
+    @staticmethod
+    def quantize_tensor(w, lo, hi, qtype, symmetric, reduce_range):
+        from .hip import ops
+        scale, zp = ops.qparams(lo.reshape(1), hi.reshape(1), qtype, symmetric, reduce_range)
+        q = ops.quantize(w, scale, zp, qtype, symmetric, reduce_range, mode="tensor")
+        return q, scale.reshape(()), zp.reshape(()).to(ops.container_dtype(qtype))
+
+    @staticmethod
+    def hessian(x, h, n_seen):
+        from .hip import ops
+        return ops.hessian_accumulate(x, h, n_seen)
+
+    @staticmethod
+    def gptq(w, h, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, block_size, percdamp, actorder, mode):
+        from .hip import ops
+        q, s, z, _ = ops.gptq_quantize(w, h, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, block_size, percdamp,
+                                       actorder, False, mode=mode)
+        return q, s, z
+
+
+def _dist(group):
+    import torch.distributed as dist
+
+    on = dist.is_available() and dist.is_initialized()
+    return dist, on, (dist.get_world_size(group) if on else 1), (dist.get_rank(group) if on else 0)
+
+
+def rtn_quantize_column_shard(w_cols, qtype: str, strategy: str, group_size=-1, symmetric=False, reduce_range=False,
+                              clip_ratio: float = 1.0, *, group=None, kernels=HipKernels):
+    """rtn.py:54-109 for this rank's COLUMNS ``w_cols`` [K, n_local] of a matrix whose other columns live on other ranks.
+    group / channel: purely local.  tensor: the raw (min, max) are combined with ONE all_reduce of two floats
+    ((-min, max) under MAX), then every rank derives the same (scale, zp) and quantizes its columns.
+    Returns the local (q [K, n_local], scale, zp); scale / zp are the global 0-d ones for "tensor"."""
+    import torch
+
+    dist, on, world, _ = _dist(group)
+    if strategy != "tensor":
+        return kernels.rtn(w_cols, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio)
+    mm = kernels.minmax(w_cols) if w_cols.numel() else torch.tensor([float("inf"), float("-inf")], dtype=torch.float32, device=w_cols.device)
+    both = torch.stack([-mm[0], mm[1]])
+    if on and world > 1:
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    zero = torch.zeros((), dtype=torch.float32, device=both.device)
+    lo = torch.minimum(-both[0] * clip_ratio, zero)                       # utils.py:63-69
+    hi = torch.maximum(both[1] * clip_ratio, zero)
+    return kernels.quantize_tensor(w_cols, lo, hi, qtype, symmetric, reduce_range)
+
+
+def hessian_all_reduce(h_local, n_local: int, *, group=None):
+    """Hessians accumulated on disjoint samples (gptq.py:246-260 on each rank's batches: H_r = (2 / n_r) sum X^T X) ->
+    the Hessian of all samples, H = sum_r (n_r / n) H_r, on every rank: one all_reduce(sum) of [K, K] floats (plus one of
+    the sample counts).  Returns (H, n)."""
+    import torch
+
+    dist, on, world, _ = _dist(group)
+    if not on or world == 1:
+        return h_local, int(n_local)
+    n = torch.tensor([float(n_local)], dtype=torch.float64, device=h_local.device)
+    dist.all_reduce(n, group=group)
+    total = int(n.item())
+    h = h_local * (float(n_local) / total) if total else h_local.clone()
+    dist.all_reduce(h, group=group)
+    return h, total
+
+
+def gptq_quantize_column_shard(w_cols, x_batches, qtype: str, strategy: str, group_size, symmetric=False, reduce_range=False,
+                               clip_ratio: float = 1.0, block_size: int = 128, percdamp: float = 0.01, actorder: bool = False,
+                               mode: str = "parity", *, group=None, kernels=HipKernels):
+    """gptq.py:263-324 with the layer spread over the ranks of `group`: every rank holds the columns ``w_cols``
+    [K, n_local] and accumulates the Hessian of ITS calibration batches ``x_batches`` (disjoint samples, each
+    [n_b, ..., K]); one all_reduce gives every rank the full Hessian, the factor is computed redundantly (it is a serial
+    chain) and the loop runs on the local columns without any exchange.  Strategies channel / group (tensor would need
+    the global range twice: use `rtn_quantize_column_shard` for per-tensor weights)."""
+    import torch
+
+    if strategy == "tensor":
+        raise NotImplementedError("column-sharded GPTQ supports the channel and group strategies")
+    k = w_cols.shape[0]
+    h = torch.zeros((k, k), dtype=torch.float32, device=w_cols.device)
+    n = 0
+    for x in x_batches:
+        n = kernels.hessian(x, h, n)
+    h, _ = hessian_all_reduce(h, n, group=group)
+    if w_cols.shape[1] == 0:
+        return None
+    return kernels.gptq(w_cols, h, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, block_size, percdamp, actorder, mode)
+
+
+def gather_column_shards(local, ranges, strategy: str, *, group=None):
+    """Bring the column shards of ONE matrix to rank 0 and put them together: q [K, N] along the columns, channel
+    parameters [N] and group parameters [N*K/g, 1] (out-channel major, rtn.py:98-109) along their first axis, per-tensor
+    parameters as they are.  ``local`` = (q, scale, zp) of this rank or None for an empty range.  Returns (q, scale, zp) on
+    rank 0, None elsewhere.  One padded gather (RCCL with backend nccl), like `gather_device_results`."""
+    import torch
+
+    dist, on, world, rank = _dist(group)
+    if world == 1:
+        return local
+    nonempty = [r for r in range(world) if ranges[r][1] > ranges[r][0]]
+    index = {r: i for i, r in enumerate(nonempty)}
+    specs = [LayerSpec(f"cols[{ranges[r][0]}:{ranges[r][1]}]", 0, ranges[r][1] - ranges[r][0]) for r in nonempty]
+    plan = [[index[r]] if r in index else [] for r in range(world)]
+    got, _ = gather_device_results(specs, plan, {index[rank]: local} if rank in index else {}, group=group)
+    if rank != 0:
+        return None
+    parts = [got[s.name] for s in specs]
+    q = torch.cat([p[0] for p in parts], dim=1)
+    if strategy == "tensor":
+        return q, parts[0][1], parts[0][2]
+    return q, torch.cat([p[1] for p in parts], dim=0), torch.cat([p[2] for p in parts], dim=0)

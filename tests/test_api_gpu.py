@@ -381,6 +381,45 @@ def test_calibrator_propagates_nan_like_numpy():
         assert np.isfinite(ok.data["x"].min_val)
 
 
+def test_column_shard_kernels_equal_the_whole_matrix_path():
+    """sharding.HipKernels on one GPU: the per-tensor path built from the calibration min / max
+    kernel + oq_qparams_f32 + oq_quantize_f32 gives the bits of the fused two-pass kernel, also when the matrix is cut into
+    column shards whose ranges are combined the way the all_reduce combines them; group / channel shards equal the
+    corresponding columns of the whole result; column-sharded GPTQ equals GPTQ of the whole matrix."""
+    import torch
+    from onnx_quantize_amd import sharding as S
+    from onnx_quantize_amd.hip import ops
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn((512, 320), generator=gen, device="cuda")
+    w[:, 300:] *= 4
+    ranges = S.column_ranges(320, 3, 32)
+    assert ranges == [(0, 128), (128, 224), (224, 320)]
+    for qtype, sym, clip in (("uint8", False, 1.0), ("int8", True, 0.9), ("uint4", False, 0.95)):
+        q, s, z = ops.rtn_quantize(w, qtype, "tensor", -1, sym, False, clip)
+        lq, ls, lz = S.rtn_quantize_column_shard(w, qtype, "tensor", -1, sym, False, clip)
+        assert torch.equal(lq, q) and torch.equal(ls, s) and torch.equal(lz, z) and ls.shape == s.shape == ()
+        # what the exchange does: (-min, max) of every shard under MAX
+        mm = torch.stack([torch.stack([-m[0], m[1]]) for m in (S.HipKernels.minmax(w[:, a:b].contiguous()) for a, b in ranges)]).amax(0)
+        zero = torch.zeros((), device="cuda")
+        lo, hi = torch.minimum(-mm[0] * clip, zero), torch.maximum(mm[1] * clip, zero)
+        for a, b in ranges:
+            sq, ss, sz = S.HipKernels.quantize_tensor(w[:, a:b].contiguous(), lo, hi, qtype, sym, False)
+            assert torch.equal(sq, q[:, a:b]) and torch.equal(ss, s) and torch.equal(sz, z)
+    q, s, z = ops.rtn_quantize(w, "uint4", "group", 128)
+    for a, b in ranges:
+        sq, ss, sz = S.rtn_quantize_column_shard(w[:, a:b].contiguous(), "uint4", "group", 128)
+        assert torch.equal(sq, q[:, a:b]) and torch.equal(ss, s[a * 4:b * 4]) and torch.equal(sz, z[a * 4:b * 4])
+    x = [torch.randn((2, 64, 512), generator=gen, device="cuda") for _ in range(2)]
+    h = torch.zeros((512, 512), device="cuda")
+    n = 0
+    for xb in x:
+        n = ops.hessian_accumulate(xb, h, n)
+    gq, gs, gz, _ = ops.gptq_quantize(w, h, "int4", "group", 128)
+    for a, b in ranges:
+        sq, ss, sz = S.gptq_quantize_column_shard(w[:, a:b].contiguous(), x, "int4", "group", 128)
+        assert torch.equal(sq, gq[:, a:b]) and torch.equal(sz, gz[a * 4:b * 4]) and torch.equal(ss, gs[a * 4:b * 4])
+
+
 def test_plugin_seam_against_the_reference_plugins():
     """tests/golden/seam.*: `qconfig.weights.algorithm.quantize_weights(w, qconfig, out=out)` -- the one call through which the
     reference reaches the path (qrules/_common.py:133) -- of the reference's RTNConfig / GPTQConfig / HqqConfig on carrier

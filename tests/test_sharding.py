@@ -149,3 +149,118 @@ def test_single_process_path():
     specs = [LayerSpec("x", 32, 16), LayerSpec("y", 64, 8)]
     res = quantize_sharded(specs, lambda i, s: O.rtn_quantize(np.ones((s.k, s.n), np.float32) * (i + 1), "int8", "channel"))
     assert list(res) == ["x", "y"] and res["y"][1].shape == (8,)
+
+
+# ------------------------------------------------------------------------------------------------ inside one matrix
+def test_column_ranges_are_aligned_contiguous_and_complete():
+    from onnx_quantize_amd.sharding import column_ranges
+    for n, world, align in ((11008, 8, 32), (4096, 3, 32), (100, 4, 32), (24, 8, 2), (33, 2, 32)):
+        r = column_ranges(n, world, align)
+        assert len(r) == world and r[0][0] == 0 and r[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:])) and all(a % align == 0 for a, _ in r if a < n)
+        sizes = [b - a for a, b in r]
+        assert max(sizes) - min(s for s in sizes if s or True) <= align or min(sizes) == 0
+
+
+class _OracleKernels:
+    """The kernels interface of sharding.HipKernels on CPU torch tensors through the oracle: what is under test is the
+    orchestration (who reduces what, when), exactly as with `quantize_sharded` above."""
+
+    @staticmethod
+    def _t(*arrs):
+        import torch
+        return tuple(torch.from_numpy(np.array(a)) for a in arrs)        # np.array keeps 0-d parameters 0-d
+
+    @classmethod
+    def rtn(cls, w, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio):
+        import oq_oracle as O
+        return cls._t(*O.rtn_quantize(w.numpy(), qtype, strategy, group_size, symmetric, reduce_range, clip_ratio))
+
+    @staticmethod
+    def minmax(w):
+        import torch
+        return torch.stack([w.min(), w.max()])
+
+    @classmethod
+    def quantize_tensor(cls, w, lo, hi, qtype, symmetric, reduce_range):
+        import oq_oracle as O
+        s, z = O.qparams(lo.numpy(), hi.numpy(), qtype, symmetric, reduce_range)
+        q = O.quantize(w.numpy(), s, z, qtype, symmetric, reduce_range)
+        return cls._t(q, np.asarray(s, np.float32), np.asarray(z))
+
+    @staticmethod
+    def hessian(x, h, n_seen):
+        import torch
+        import oq_oracle as O
+        hn, n = O.accumulate_hessian(x.numpy(), h.numpy().copy(), n_seen)
+        h.copy_(torch.from_numpy(hn))
+        return n
+
+    @classmethod
+    def gptq(cls, w, h, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, block_size, percdamp, actorder, mode):
+        import oq_oracle as O
+        return cls._t(*O.gptq(w.numpy(), h.numpy(), qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, block_size, percdamp,
+                              actorder, False, mode=mode))
+
+
+def _worker_columns(rank, world, port, q):
+    """One 96 x 80 matrix spread by columns over the ranks: RTN group / channel (no exchange), RTN tensor (one all_reduce of
+    two floats) and GPTQ with the Hessian accumulated on disjoint samples per rank (one all_reduce of K x K floats),
+    gathered on rank 0 and compared with the UNSHARDED oracle."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+
+    import oq_oracle as O
+    from onnx_quantize_amd import sharding as S
+    from test_sharding import _OracleKernels as KER
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, n = 96, 80
+    rng = np.random.default_rng(11)
+    w = rng.standard_normal((k, n)).astype(np.float32)
+    w[:, 70:] *= 5                                                  # the global range lives on the last rank only
+    x = (rng.standard_normal((6, 7, k)) * rng.uniform(0.3, 3, size=k)).astype(np.float32)
+    ranges = S.column_ranges(n, world, 32)
+    a, b = ranges[rank]
+    w_cols = torch.from_numpy(np.ascontiguousarray(w[:, a:b]))
+    ok = True
+    for qtype, strategy, g, sym in (("uint4", "group", 32, False), ("int8", "channel", -1, True), ("uint8", "tensor", -1, False),
+                                    ("int8", "tensor", -1, True)):
+        local = S.rtn_quantize_column_shard(w_cols, qtype, strategy, g, sym, False, 0.9, kernels=KER) if b > a or strategy == "tensor" else None
+        whole = S.gather_column_shards(local if b > a else None, ranges, strategy)
+        if rank == 0:
+            eq, es, ez = O.rtn_quantize(w, qtype, strategy, g, sym, False, 0.9)
+            ok = ok and np.array_equal(whole[0].numpy(), eq) and whole[1].numpy().tobytes() == np.asarray(es).tobytes()
+            ok = ok and np.array_equal(whole[2].numpy(), ez) and whole[1].shape == np.shape(es)
+    # GPTQ: samples 0..5 dealt round robin, columns as above
+    mine = [torch.from_numpy(x[i:i + 1]) for i in range(rank, 6, world)]
+    local = S.gptq_quantize_column_shard(w_cols, mine, "int4", "group", 32, block_size=32, kernels=KER)
+    whole = S.gather_column_shards(local, ranges, "group")
+    h_all, n_all = S.hessian_all_reduce(torch.zeros((k, k)), 0)      # ranks without samples still take part
+    if rank == 0:
+        eq, es, ez = O.gptq_quantize(w, x, "int4", "group", 32, block_size=32)
+        ok = ok and np.array_equal(whole[0].numpy(), eq) and np.array_equal(whole[2].numpy(), ez)
+        ok = ok and np.allclose(whole[1].numpy(), es, rtol=1e-6) and n_all == 0
+        q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_one_matrix_sharded_by_columns_gloo(world):
+    """SURVEY.md 8e (2).  World 4 leaves the last rank without columns (80 columns = 3 strips of 32)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_columns, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(150)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
