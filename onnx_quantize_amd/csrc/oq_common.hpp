@@ -53,6 +53,27 @@ __host__ __device__ __forceinline__ float nmax(float a, float b) { return __buil
 __host__ __device__ __forceinline__ double nmin(double a, double b) { return __builtin_elementwise_minimum(a, b); }
 __host__ __device__ __forceinline__ double nmax(double a, double b) { return __builtin_elementwise_maximum(a, b); }
 
+// Exchange with lane (l ^ OFF) for OFF = 8 / 16 / 32 without the LDS crossbar (`__shfl_xor` becomes ds_bpermute_b32):
+// a DPP rotate inside the rows of 16 lanes, and gfx950's v_permlane16_swap / v_permlane32_swap, which exchange the odd
+// rows (halves) of one register with the even rows (halves) of another -- fed the same value twice, the two results hold
+// "mine" and "my partner's" in one order or the other, which is all a min / max fold needs.
+template <int OFF, typename F>
+__device__ __forceinline__ float xor_fold(float v, F f) {
+    static_assert(OFF == 8 || OFF == 16 || OFF == 32, "lane distance");
+    if constexpr (OFF == 8) {
+        const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128 /* row_ror:8 */, 0xf, 0xf, false);
+        return f(v, __int_as_float(t));
+    } else if constexpr (OFF == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+}
+template <int OFF> __device__ __forceinline__ float xor_min(float v) { return xor_fold<OFF>(v, [](float a, float b) { return nmin(a, b); }); }
+template <int OFF> __device__ __forceinline__ float xor_max(float v) { return xor_fold<OFF>(v, [](float a, float b) { return nmax(a, b); }); }
+
 struct QParam {
     float scale;
     int32_t zp;

@@ -47,6 +47,7 @@ struct RtnArgs {
     int32_t gk;       // order 2: row tiles per id chunk (see the block order in rtn_group_fused)
     FastDiv fd_ncol, fd_band, fd_chunk;  // ncol_tiles, ncol_tiles * gk, 8 * gk (block ids < 2^22, checked by the host)
     int32_t spb_log2;  // wave kernel: log2(strips per block)
+    uint32_t pair_owner;  // fused kernel, direct parameter stores: wave (inside its group) that stores pair p, 3 bits each
     // strided batch (oq_rtn_quantize_batched_f32): matrix b lives at base + b * stride (elements / bytes as noted)
     int64_t w_stride, q_stride, p_stride;  // fp32 elements of W; bytes of q; entries of scale / zp (also of the staging)
 };
@@ -55,6 +56,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kDefaultWps = 5;     // wave kernel build used when OQ_RTN_WPS is unset (see Tuning)
 constexpr int kColsPerWave = 256;  // 64 lanes x 4 columns: 1 KiB of one fp32 row per wave-instruction
 constexpr int kMaxWaves = 8;
 
@@ -235,14 +237,20 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                 *reinterpret_cast<uint32_t*>(a.zp_t + o) = (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 8) |
                                                            ((static_cast<uint32_t>(cq[2].zp) & 0xffu) << 16) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 24);
             }
-        } else {  // rtn.py:98-109 result layout: row n*(K/g)+kg of the [N*K/g, 1] arrays
+        }
+    }
+    if (!(VEC4 && a.scale_t != nullptr)) {
+        // rtn.py:98-109 result layout: row n*(K/g)+kg of the [N*K/g, 1] arrays.  Every wave of the group holds the same
+        // parameters, so the 256 scattered 4-byte + 1-byte stores of a group (128-byte stride) are dealt over its waves:
+        // eight (column slot, half wave) pairs, the owner of pair p (= p % wpg, three bits each in `pair_owner`) stores it.
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (col_ok[i]) {
-                    const int64_t o = slot_col<VEC4>(tile_col0, lane, i) * a.kgroups + kg;
-                    a.scale[o] = cq[i].scale;
-                    a.zp[o] = static_cast<uint8_t>(cq[i].zp);
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int own_lo = static_cast<int>((a.pair_owner >> (6 * i)) & 7u), own_hi = static_cast<int>((a.pair_owner >> (6 * i + 3)) & 7u);
+            if (((lane < 32) ? own_lo : own_hi) == wig && col_ok[i]) {
+                const int64_t o = slot_col<VEC4>(tile_col0, lane, i) * a.kgroups + kg;
+                a.scale[o] = cq[i].scale;
+                a.zp[o] = static_cast<uint8_t>(cq[i].zp);
+            }
         }
     }
     if constexpr (!EMIT_Q) return;
@@ -402,10 +410,14 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
 // of a column are 8 (4-bit) / 16 (8-bit) consecutive bytes and the lane sets of a column are
 // adjacent, so one store instruction writes whole 64 / 128-byte chunks.  G = 128 for LPR = 8.
 // ---------------------------------------------------------------------------------------------
-template <int LPR, bool EMIT_Q>
-__global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs a_in) {
+template <int LPR, bool EMIT_Q, int WPS = 0>
+__global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void rtn_group_wave(const RtnArgs a_in) {
     constexpr int RS = 64 / LPR;  // lane sets (row sub-ranges) per wave
     constexpr int G = 16 * RS;    // rows per group
+    // WPS > 0: built for WPS waves per SIMD (blocks of <= 4 waves).  The four scales of a lane are only needed again by
+    // the rare exact-division fallback: they are parked in LDS (4 * LPR floats per wave, written and read by the same wave:
+    // no barrier) instead of four registers, which is what separates 100 registers from the 96 that five waves allow.
+    __shared__ float s_scale[WPS ? 4 : 1][WPS ? 4 * LPR : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar address math below
     const int h = lane / LPR, cl = lane % LPR;
@@ -426,8 +438,12 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
     const int64_t kg = static_cast<int64_t>(row_tile) * a.gpb + (wave >> a.spb_log2);
     const int64_t strip0 = (static_cast<int64_t>(col_tile) * spb + (wave & (spb - 1))) * (4 * LPR);
     if (kg >= a.kgroups || strip0 >= a.N) return;  // wave-uniform; nothing below synchronises
-    const int64_t c0 = strip0 + cl * 4;
-    const bool col_ok = c0 < a.N;                  // N % 4 == 0: a lane's four columns are in or out together
+    // WPS > 0: 32-bit output indices (the host checks N * K/g * G/2 < 2^32): scalar base + 32-bit lane offset addressing
+    // instead of 64-bit address pairs held across the kernel
+    using idx_t = std::conditional_t<(WPS > 0), uint32_t, int64_t>;
+    const idx_t c0 = static_cast<idx_t>(strip0 + cl * 4);
+    const idx_t kgroups_i = static_cast<idx_t>(a.kgroups), kg_i = static_cast<idx_t>(kg);
+    const bool col_ok = strip0 + cl * 4 < a.N;     // N % 4 == 0: a lane's four columns are in or out together
 
     float v[16][4];
     {
@@ -452,13 +468,22 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
             mn[i] = nmin(mn[i], v[r][i]);
             mx[i] = nmax(mx[i], v[r][i]);
         }
-#pragma unroll
-    for (int off = LPR; off < 64; off <<= 1)
+    if constexpr (WPS > 0) {   // butterflies over the lane sets on DPP / permlane swaps instead of ds_bpermute
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            mn[i] = nmin(mn[i], __shfl_xor(mn[i], off, 64));
-            mx[i] = nmax(mx[i], __shfl_xor(mx[i], off, 64));
+            if constexpr (LPR <= 8) { mn[i] = xor_min<8>(mn[i]); mx[i] = xor_max<8>(mx[i]); }
+            if constexpr (LPR <= 16) { mn[i] = xor_min<16>(mn[i]); mx[i] = xor_max<16>(mx[i]); }
+            mn[i] = xor_min<32>(mn[i]); mx[i] = xor_max<32>(mx[i]);
         }
+    } else {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                mn[i] = nmin(mn[i], __shfl_xor(mn[i], off, 64));
+                mx[i] = nmax(mx[i], __shfl_xor(mx[i], off, 64));
+            }
+    }
 
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
     const int32_t bias = qmin < 0 ? (a.grid.bits == 4 ? 8 : 128) : 0;
@@ -466,7 +491,33 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
     // Fewer live registers than four full ColQ records (102 VGPRs, 4 waves per SIMD; forcing 96 for a fifth wave
     // spills 7 dwords and measured 44.7 us against 41.0).
     float sc[4], rinv[4], zpb[4], thr;
-    {
+    [[maybe_unused]] float own_scale = 0.f;
+    constexpr bool ONECOL = WPS > 0 && RS >= 4;
+    if constexpr (ONECOL) {
+        // Every lane set holds the ranges of all four column slots after the butterflies; deriving all four parameter sets
+        // in every lane set is 8 x redundant (three IEEE divisions per column) and its temporaries are the register peak of
+        // the kernel.  Lane set h derives column slot h & 3 only, the other three arrive by ds_bpermute from lane sets 0-3.
+        const int j = h & 3;
+        const float mnj = j == 0 ? mn[0] : j == 1 ? mn[1] : j == 2 ? mn[2] : mn[3];
+        const float mxj = j == 0 ? mx[0] : j == 1 ? mx[1] : j == 2 ? mx[2] : mx[3];
+        const ColQ c = make_colq(qparam_from_minmax(mnj, mxj, a.grid), mnj, mxj, bias);
+        own_scale = c.scale;
+        if (h < 4) s_scale[wave][j * LPR + cl] = c.scale;      // for the fallback: slot i of strip column cl at [i * LPR + cl]
+        if (h < 4 && col_ok) {   // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
+            const idx_t o = (c0 + j) * kgroups_i + kg_i;
+            a.scale[o] = c.scale;
+            a.zp[o] = static_cast<uint8_t>(static_cast<int32_t>(c.zpb) - bias);
+        }
+        float t = c.thr;
+        if constexpr (LPR == 8) { t = xor_min<8>(t); thr = xor_min<16>(t); }
+        else { t = xor_min<16>(t); thr = xor_min<32>(t); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rinv[i] = __shfl(c.rinv, i * LPR + cl, 64);
+            zpb[i] = __shfl(c.zpb, i * LPR + cl, 64);
+            sc[i] = 0.f;
+        }
+    } else {
         ColQ c = make_colq(qparam_from_minmax(mn[0], mx[0], a.grid), mn[0], mx[0], bias);
         sc[0] = c.scale; rinv[0] = c.rinv; zpb[0] = c.zpb; thr = c.thr;
 #pragma unroll
@@ -474,20 +525,23 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
             c = make_colq(qparam_from_minmax(mn[i], mx[i], a.grid), mn[i], mx[i], bias);
             sc[i] = c.scale; rinv[i] = c.rinv; zpb[i] = c.zpb; thr = nmin(thr, c.thr);
         }
-    }
-    // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
+        // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
 #pragma unroll
-    for (int j0 = 0; j0 < 4; j0 += RS) {
-        const int j = j0 + h;
-        if (j < 4 && col_ok) {
-            const float s = j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3];
-            const float z = j == 0 ? zpb[0] : j == 1 ? zpb[1] : j == 2 ? zpb[2] : zpb[3];
-            const int64_t o = (c0 + j) * a.kgroups + kg;
-            a.scale[o] = s;
-            a.zp[o] = static_cast<uint8_t>(static_cast<int32_t>(z) - bias);
+        for (int j0 = 0; j0 < 4; j0 += RS) {
+            const int j = j0 + h;
+            if (j < 4 && col_ok) {
+                const float s = j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3];
+                const float z = j == 0 ? zpb[0] : j == 1 ? zpb[1] : j == 2 ? zpb[2] : zpb[3];
+                const idx_t o = (c0 + j) * kgroups_i + kg_i;
+                a.scale[o] = s;
+                a.zp[o] = static_cast<uint8_t>(static_cast<int32_t>(z) - bias);
+            }
         }
     }
     if constexpr (!EMIT_Q) return;
+    if constexpr (WPS > 0 && !ONECOL) {
+        if (h == 0) *reinterpret_cast<float4*>(&s_scale[wave][cl * 4]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+    }
 
     const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
 #pragma unroll
@@ -502,9 +556,19 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
             f[i] = __builtin_amdgcn_fmed3f(k + zpb[i], lo_b, hi_b);
         }
         if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {  // wave-uniform, rare: redo this row with the IEEE divide
+            float se[4];
+            if constexpr (ONECOL) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) se[i] = s_scale[wave][i * LPR + cl];
+            } else if constexpr (WPS > 0) {
+                const float4 t4 = *reinterpret_cast<const float4*>(&s_scale[wave][cl * 4]);
+                se[0] = t4.x; se[1] = t4.y; se[2] = t4.z; se[3] = t4.w;
+            } else {
+                se[0] = sc[0]; se[1] = sc[1]; se[2] = sc[2]; se[3] = sc[3];
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                f[i] = static_cast<float>(quantize_one(v[r][i], sc[i], static_cast<int32_t>(zpb[i]) - bias, qmin, qmax) + bias);
+                f[i] = static_cast<float>(quantize_one(v[r][i], se[i], static_cast<int32_t>(zpb[i]) - bias, qmin, qmax) + bias);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[r][i] = f[i];
@@ -527,7 +591,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
                 }
                 words[wd] = (ev | (od << 4)) ^ flip;
             }
-            u32x2* o = reinterpret_cast<u32x2*>(a.q + ((c0 + i) * a.kgroups + kg) * (G / 2) + h * 8);
+            u32x2* o = reinterpret_cast<u32x2*>(a.q + (((c0 + i) * kgroups_i + kg_i) * (G / 2) + h * 8));
             const u32x2 t = {words[0], words[1]};
             if (a.nt & 2) __builtin_nontemporal_store(t, o);
             else *o = t;
@@ -544,7 +608,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_wave(const RtnArgs
                 for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_cvt_pk_u8_f32(v[wd * 4 + j][i], j, acc);
                 words[wd] = acc ^ flip;
             }
-            u32x4* o = reinterpret_cast<u32x4*>(a.q + ((c0 + i) * a.kgroups + kg) * G + h * 16);
+            u32x4* o = reinterpret_cast<u32x4*>(a.q + (((c0 + i) * kgroups_i + kg_i) * G + h * 16));
             const u32x4 t = {words[0], words[1], words[2], words[3]};
             if (a.nt & 2) __builtin_nontemporal_store(t, o);
             else *o = t;
@@ -877,7 +941,7 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
 
 // Experiment knobs (never needed for correctness): -1 = use the tuned default.
 struct Tuning {
-    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1;
+    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1, wps = -1;
     static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
     static Tuning from_env() {
         Tuning t;
@@ -889,6 +953,7 @@ struct Tuning {
         t.wavek = env_int("OQ_RTN_WAVEK");      // blob layout: wave-owns-group kernel (1) or the block kernel (0)
         t.gpb = env_int("OQ_RTN_GPB");          // wave kernel: k-groups per block
         t.wpb = env_int("OQ_RTN_WPB");          // wave kernel: waves per block
+        t.wps = env_int("OQ_RTN_WPS");          // wave kernel: 0 = the 4-waves-per-SIMD build, 5 = the 92-register build (5 per SIMD)
         return t;
     }
 };
@@ -1062,7 +1127,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             RtnArgs a;
             a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
             a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
-            a.scale_t = nullptr; a.zp_t = nullptr; a.wpg = 1; a.stage_q = 0;
+            a.scale_t = nullptr; a.zp_t = nullptr; a.wpg = 1; a.stage_q = 0; a.pair_owner = 0;
             const int64_t batch = g_batch.count;
             a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups;
             const int lpr = static_cast<int>(1024 / g);
@@ -1079,10 +1144,18 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.ncol_tiles = static_cast<uint32_t>(ceil_div(nstrips, wpb / gpb));
             a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, gpb));
             a.order = tw.order >= 0 ? tw.order : 2;
-            a.gk = tw.gk > 0 ? tw.gk : 8;
+            a.gk = tw.gk > 0 ? tw.gk : 4;
             a.nt = tw.nt >= 0 ? tw.nt : 1;
             set_block_order(a);
             const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(wpb * kWave));
+            // the 5-waves-per-SIMD build addresses its outputs with 32-bit offsets and needs blocks of <= 4 waves
+            const bool small_idx = static_cast<uint64_t>(N) * static_cast<uint64_t>(K) * static_cast<uint64_t>(grid.bits) / 8u < (1ull << 32);
+            const int wps = tw.wps >= 0 ? tw.wps : kDefaultWps;
+            if (wps > 0 && small_idx && wpb <= 4 && lpr <= 16) {   // g = 32 (two lane sets) does not fit 96 registers: plain build
+                if (lpr == 8) hipLaunchKernelGGL((rtn_group_wave<8, true, 5>), grid_dim, block, 0, s, a);
+                else hipLaunchKernelGGL((rtn_group_wave<16, true, 5>), grid_dim, block, 0, s, a);
+                return check_launch("rtn_group_wave<5 waves per SIMD>");
+            }
             switch (lpr) {
                 case 8: hipLaunchKernelGGL((rtn_group_wave<8, true>), grid_dim, block, 0, s, a); break;
                 case 16: hipLaunchKernelGGL((rtn_group_wave<16, true>), grid_dim, block, 0, s, a); break;
@@ -1108,6 +1181,8 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.zp_t = static_cast<uint8_t*>(workspace) + (batch * kgroups * N * 4 + 255) / 256 * 256;
         }
         a.wpg = wpg;
+        a.pair_owner = 0;
+        for (uint32_t pr = 0; pr < 8; ++pr) a.pair_owner |= (pr % static_cast<uint32_t>(wpg)) << (3 * pr);
         a.gpb = kMaxWaves / wpg > 0 ? kMaxWaves / wpg : 1;
         if (a.gpb > kgroups) a.gpb = static_cast<int32_t>(kgroups);
         a.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kColsPerWave));

@@ -32,6 +32,10 @@ def _stream() -> C.c_void_p:
 def _require_device(t: torch.Tensor, name: str, dtype=None) -> None:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError(f"{name} must be a torch tensor in GPU memory (the HIP path has no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # the library launches on the CURRENT device's current stream and never switches devices itself
+        raise RuntimeError(f"{name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                           f"call inside `with torch.cuda.device({t.device.index}):`")
     if dtype is not None and t.dtype != dtype:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
 
