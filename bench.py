@@ -533,7 +533,7 @@ def main() -> None:
             "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "oq::rtn_group_wave<8,true>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
+                     "kernel": "oq::rtn_group_wave<8,true,5>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
                      "launch_us": round(launch_us, 2), "launch_us_p10_p50_p90": pct,
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
         "seam": seam,
