@@ -58,8 +58,8 @@ def build_parser() -> argparse.ArgumentParser:
                     help="streams that take the factor + loop chains of successive inputs in turn (chains of small launches: "
                          "several of them side by side hide each other's launch and diagonal-block latency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hessian-methods", default="auto,f32",
-                    help="comma list of X^T X kernels to time alone for the roofline objects (auto = split-operand bf16 MFMA)")
+    ap.add_argument("--hessian-methods", default="auto,bf16x6,f32",
+                    help="comma list of X^T X kernels to time alone for the roofline objects (auto = the fp16-piece split-operand kernel for K >= 1024)")
     return ap
 
 
@@ -275,11 +275,12 @@ def run(args, dev, rank: int, world: int):
             tiles = (kw + (255 if split else 127)) // (256 if split else 128)
             edge = 256 if split else 128
             fp32_equiv = 2.0 * t_rows * (tiles * (tiles + 1) // 2) * edge * edge          # upper tiles, as executed
-            terms = 9 if method == "bf16x9" else 6
+            terms = {"bf16x9": 9, "bf16x6": 6}.get(method, 3)           # "auto" is the fp16-piece kernel for K >= 1024
             roof = {"bound": "mfma", "method": method,
                     "kernel": "oq::syrk_pieces_kernel<%d> (+ split / reduce)" % terms if split else "oq::gemm_tn_kernel",
                     "achieved": round(fp32_equiv * (terms if split else 1) / ms / 1e9, 1), "peak": 2500.0 if split else 157.3,
-                    "unit": "TFLOP/s", "dtype": "bf16 pieces of fp32 operands, fp32 accumulate" if split else "f32",
+                    "unit": "TFLOP/s",
+                    "dtype": ("%s pieces of fp32 operands, fp32 accumulate" % ("fp16" if terms == 3 else "bf16")) if split else "f32",
                     "fp32_equivalent_TFLOPs": round(fp32_equiv / ms / 1e9, 1), "call_ms": round(ms, 2), "k": kw, "rows": t_rows,
                     "traffic": None}
             roof["frac"] = round(roof["achieved"] / roof["peak"], 4)

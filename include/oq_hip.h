@@ -207,18 +207,24 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *     number of samples, not T.  workspace (oq_hessian_workspace_bytes; optional for OQ_HESSIAN_F32, where
  *     it may be NULL): the bf16 operand pieces of the split methods (6 B per element of X) and partial-sum
  *     slabs that let the T dimension be split over more workgroups (deterministic two-stage sum).
- *     Method (process-wide, oq_hessian_set_method; environment OQ_HESSIAN_METHOD = 0..3 sets the initial value):
+ *     Method (process-wide, oq_hessian_set_method; environment OQ_HESSIAN_METHOD = 0..4 sets the initial value):
  *       OQ_HESSIAN_F32     v_mfma_f32_32x32x2_f32 on the operands scaled by sqrt(2/n) as gptq.py:257 does;
  *       OQ_HESSIAN_BF16X6  every fp32 element split EXACTLY into three bf16 pieces (x = hi + mid + lo), the six piece
  *                          products down to 2^-16 |x y| on v_mfma_f32_32x32x16_bf16, fp32 accumulation; what is left
  *                          out is <= 2^-23 |x y| per product (one fp32 rounding); 2 / n applied to the sum;
  *       OQ_HESSIAN_BF16X9  all nine piece products (no product rounding at all);
- *       OQ_HESSIAN_AUTO    BF16X6 for K >= 1024 (its block tile is 256 x 256; K < 2048 also needs T >= 2048) when the
+ *       OQ_HESSIAN_F16X3   two fp16 pieces of every element after scaling the call's X by a power of two (max |x| in
+ *                          [2^14, 2^15)): x = hi + lo to 22 bits (fewer below 2^-17 max |x|, where fp16 runs out of
+ *                          exponent; a sample whose fp32 square is still positive never vanishes entirely, so a channel
+ *                          is dead here exactly when it is dead for gptq.py:284), products hi.hi + hi.lo + lo.hi on
+ *                          v_mfma_f32_32x32x16_f16, 2 / (n s^2) applied to the sum: half the matrix-core work of
+ *                          BF16X6, measured error against float64 not larger (8e-7 vs 2e-6 of max |H|, K = 11008);
+ *       OQ_HESSIAN_AUTO    F16X3 for K >= 1024 (its block tile is 256 x 256; K < 2048 also needs T >= 2048) when the
  *                          workspace holds the pieces,
  *                          else F32.  An explicit split method with too small a workspace is OQ_ERR_WORKSPACE.
  *     The reference's own H goes through sgemm in BLAS order: parity is to a tolerance for every method.
  * ------------------------------------------------------------------------------------------- */
-enum { OQ_HESSIAN_AUTO = 0, OQ_HESSIAN_F32 = 1, OQ_HESSIAN_BF16X6 = 2, OQ_HESSIAN_BF16X9 = 3 };
+enum { OQ_HESSIAN_AUTO = 0, OQ_HESSIAN_F32 = 1, OQ_HESSIAN_BF16X6 = 2, OQ_HESSIAN_BF16X9 = 3, OQ_HESSIAN_F16X3 = 4 };
 int32_t oq_hessian_set_method(int32_t method);
 int32_t oq_hessian_method(void);
 size_t oq_hessian_workspace_bytes(int64_t T, int64_t K);

@@ -281,8 +281,10 @@ int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s) {
 
 // Sum the T-slices of one 64 x 64 tile in slice order, apply alpha / beta, and write C[m][n] and (for
 // off-diagonal tiles) C[n][m]; the transposed copy goes through LDS so both stores are row-contiguous.
-__global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile) {
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int splits, int64_t K, float alpha_in, float beta, float* C, int tile,
+                                                          const float* post_scale) {
     __shared__ float t[64][65];
+    const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;   // fp16-piece GEMM: 1 / s^2, a power of two
     const int64_t m0 = static_cast<int64_t>(blockIdx.y) * 64, n0 = static_cast<int64_t>(blockIdx.x) * 64;
     if (n0 < m0) return;                                        // below the diagonal: written as the mirror of block (n0, m0)
     (void)tile;                                                 // every 64-block on or above the diagonal lies in a computed GEMM tile
@@ -308,9 +310,10 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const float* slab, int
     }
 }
 
-int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile, hipStream_t s) {
+int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile, hipStream_t s,
+                           const float* post_scale) {
     const uint32_t t64 = static_cast<uint32_t>(ceil_div(K, 64));
-    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(t64, t64), dim3(256), 0, s, slab, splits, K, alpha, beta, C, tile);
+    hipLaunchKernelGGL(syrk_reduce_kernel, dim3(t64, t64), dim3(256), 0, s, slab, splits, K, alpha, beta, C, tile, post_scale);
     return check_launch("syrk_reduce_kernel");
 }
 
@@ -369,7 +372,7 @@ size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) {
 static int32_t g_hessian_method = -1;   // -1: not set yet (environment OQ_HESSIAN_METHOD, else OQ_HESSIAN_AUTO)
 
 int32_t oq_hessian_set_method(int32_t method) {
-    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_BF16X9, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_set_method: unknown method %d", method);
+    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_set_method: unknown method %d", method);
     g_hessian_method = method;
     return OQ_OK;
 }
@@ -378,7 +381,7 @@ int32_t oq_hessian_method(void) {
     if (g_hessian_method < 0) {
         const char* e = std::getenv("OQ_HESSIAN_METHOD");
         const int v = e ? std::atoi(e) : OQ_HESSIAN_AUTO;
-        g_hessian_method = (v >= OQ_HESSIAN_AUTO && v <= OQ_HESSIAN_BF16X9) ? v : OQ_HESSIAN_AUTO;
+        g_hessian_method = (v >= OQ_HESSIAN_AUTO && v <= OQ_HESSIAN_F16X3) ? v : OQ_HESSIAN_AUTO;
     }
     return g_hessian_method;
 }
@@ -397,13 +400,13 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
     // pieces; small problems stay on the fp32 MFMA
     if (method == OQ_HESSIAN_AUTO)
         method = (K >= 1024 && (T >= 2048 || K >= 2048) && workspace != nullptr && workspace_bytes >= syrk_bf16x3_pieces_bytes(T, K) + 256)
-                     ? OQ_HESSIAN_BF16X6 : OQ_HESSIAN_F32;   // measured cross-over: K = 1024-1536 with ~1000 rows is faster on the fp32 kernel
+                     ? OQ_HESSIAN_F16X3 : OQ_HESSIAN_F32;   // measured cross-over: K = 1024-1536 with ~1000 rows is faster on the fp32 kernel
     if (method != OQ_HESSIAN_F32) {
         // gptq.py:257 scales the operand by sqrt(2 / n); here the factor 2 / n goes onto the sum (one rounding per
         // element of H instead of one per element of X)
         const float alpha = static_cast<float>(2.0 / static_cast<double>(n_total));
-        return launch_syrk_bf16x3(X, T, K, ldx, alpha, beta, H, workspace, workspace_bytes, method == OQ_HESSIAN_BF16X9 ? 9 : 6,
-                                  as_stream(stream));
+        return launch_syrk_bf16x3(X, T, K, ldx, alpha, beta, H, workspace, workspace_bytes,
+                                  method == OQ_HESSIAN_BF16X9 ? 9 : (method == OQ_HESSIAN_F16X3 ? 3 : 6), as_stream(stream));
     }
     // gptq.py:257  inp = math.sqrt(2 / num_samples) * inp  (double evaluated, weak scalar -> fp32 multiply)
     const float sx = static_cast<float>(std::sqrt(2.0 / static_cast<double>(n_total)));

@@ -72,11 +72,13 @@ __device__ __forceinline__ void upper_tile_of(int rem, int ntiles, int& tile_m, 
 
 // Sums the `splits` partial results slab[z][K][K] (valid where the GEMM's `tile` x `tile` block tiles lie on or above the
 // diagonal) in slice order, applies alpha / beta and writes both triangles of C.
-int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile, hipStream_t s);
+// `post_scale` (device, optional): alpha is multiplied by post_scale[1] (the fp16-piece kernel's exact 1 / s^2).
+int32_t launch_syrk_reduce(const float* slab, int splits, int64_t K, float alpha, float beta, float* C, int tile, hipStream_t s,
+                           const float* post_scale = nullptr);
 
 // The same update on the bf16 matrix cores with fp32-exact operands (syrk_bf16x3.hip): every fp32 element is split
 // into three bf16 pieces whose sum is the element exactly; `terms` = 6 (piece products down to 2^-16, the dropped
-// ones are below fp32 rounding of a product) or 9 (all of them).  workspace = the pieces (syrk_bf16x3_pieces_bytes)
+// ones are below fp32 rounding of a product), 9 (all of them) or 3 (two fp16 pieces of the scaled element, three products).  workspace = the pieces (syrk_bf16x3_pieces_bytes)
 // followed by optional T-slice slabs of K x K floats.
 size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K);
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C,

@@ -544,6 +544,100 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
     }
 
     const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+    // the scales of the four column slots for the exact-division fallback
+    auto fallback_scales = [&](float (&se)[4]) {
+        if constexpr (ONECOL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) se[i] = s_scale[wave][i * LPR + cl];
+        } else if constexpr (WPS > 0) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&s_scale[wave][cl * 4]);
+            se[0] = t4.x; se[1] = t4.y; se[2] = t4.z; se[3] = t4.w;
+        } else {
+            se[0] = sc[0]; se[1] = sc[1]; se[2] = sc[2]; se[3] = sc[3];
+        }
+    };
+
+    if constexpr (WPS > 0) {
+        // K1 in the "magic number" domain, two elements per instruction.  With M = 1.5 * 2^23 the fp32 grid around M + k
+        // has spacing 1, so u = fma(x, rinv, zp + bias + M) IS M + rint(x * rinv + zp + bias): the product, the zero point
+        // and the rounding in ONE correctly rounded operation (round-half-even on the sum).  The residual
+        // r = fma(x, rinv, (zp + bias + M) - u) is the exact distance of x * rinv + zp from that integer (one rounding of
+        // <= 2^-25); whenever |r| < thr = 0.5 - B * 2^-21 (the band of oq_common.hpp: B >= max |x / s| of the group bounds
+        // the distance between x * fl(1/s) and fl(x / s)) no half-integer separates the two and the integer is the
+        // reference's rint(fl(x / s)) + zp; ties and everything inside the band (and NaN / inf) are redone with the IEEE
+        // division.  Clamping happens on M + level as well and the level is the low byte of the float's bits:
+        // v_pk_fma, v_pk_add, v_pk_fma, 2 compares, 2 v_med3 per PAIR of elements and 7 bit operations per packed word
+        // instead of 6 scalar operations per element and 10 per word.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr float kMagic = 12582912.0f;          // 1.5 * 2^23, bits 0x4B400000
+        const f32x2 rv[2] = {{rinv[0], rinv[1]}, {rinv[2], rinv[3]}};
+        const f32x2 zm[2] = {{zpb[0] + kMagic, zpb[1] + kMagic}, {zpb[2] + kMagic, zpb[3] + kMagic}};
+        const float lo_m = lo_b + kMagic, hi_m = hi_b + kMagic;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float f[4];
+            bool unsafe = false;
+#pragma unroll
+            for (int p2 = 0; p2 < 2; ++p2) {
+                const f32x2 x = {v[r][2 * p2], v[r][2 * p2 + 1]};
+                const f32x2 u = __builtin_elementwise_fma(x, rv[p2], zm[p2]);
+                const f32x2 res = __builtin_elementwise_fma(x, rv[p2], zm[p2] - u);
+                unsafe = unsafe || !(fabsf(res.x) < thr) || !(fabsf(res.y) < thr);
+                f[2 * p2] = __builtin_amdgcn_fmed3f(u.x, lo_m, hi_m);
+                f[2 * p2 + 1] = __builtin_amdgcn_fmed3f(u.y, lo_m, hi_m);
+            }
+            if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {  // wave-uniform, rare: redo this row with the IEEE divide
+                float se[4];
+                fallback_scales(se);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    f[i] = __uint_as_float(0x4B400000u + static_cast<uint32_t>(quantize_one(v[r][i], se[i], static_cast<int32_t>(zpb[i]) - bias, qmin, qmax) + bias));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[r][i] = f[i];
+        }
+        if (!col_ok) return;
+        // qrules/_common.py:72-87: out-channel n, k-group kg -> G * bits / 8 bytes, k ascending, even k in the low nibble.
+        // v[r][i] holds M + level: the level is byte 0 of its bits (the other three bytes are those of M).
+        auto low_bytes = [](uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {   // [b0.0, b1.0, b2.0, b3.0]
+            return __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
+        };
+        if (a.grid.bits == 4) {
+            const uint32_t flip = bias ? 0x88888888u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t words[2];
+#pragma unroll
+                for (int wd = 0; wd < 2; ++wd) {
+                    uint32_t pr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)   // byte 0 = odd row << 4 | even row (levels < 16, M's low byte is 0)
+                        pr[j] = (__float_as_uint(v[wd * 8 + 2 * j + 1][i]) << 4) | __float_as_uint(v[wd * 8 + 2 * j][i]);
+                    words[wd] = low_bytes(pr[0], pr[1], pr[2], pr[3]) ^ flip;
+                }
+                u32x2* o = reinterpret_cast<u32x2*>(a.q + (((c0 + i) * kgroups_i + kg_i) * (G / 2) + h * 8));
+                const u32x2 t = {words[0], words[1]};
+                if (a.nt & 2) __builtin_nontemporal_store(t, o);
+                else *o = t;
+            }
+        } else {
+            const uint32_t flip = bias ? 0x80808080u : 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t words[4];
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd)
+                    words[wd] = low_bytes(__float_as_uint(v[wd * 4][i]), __float_as_uint(v[wd * 4 + 1][i]), __float_as_uint(v[wd * 4 + 2][i]),
+                                          __float_as_uint(v[wd * 4 + 3][i])) ^ flip;
+                u32x4* o = reinterpret_cast<u32x4*>(a.q + (((c0 + i) * kgroups_i + kg_i) * G + h * 16));
+                const u32x4 t = {words[0], words[1], words[2], words[3]};
+                if (a.nt & 2) __builtin_nontemporal_store(t, o);
+                else *o = t;
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float f[4];
@@ -557,15 +651,7 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
         }
         if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {  // wave-uniform, rare: redo this row with the IEEE divide
             float se[4];
-            if constexpr (ONECOL) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) se[i] = s_scale[wave][i * LPR + cl];
-            } else if constexpr (WPS > 0) {
-                const float4 t4 = *reinterpret_cast<const float4*>(&s_scale[wave][cl * 4]);
-                se[0] = t4.x; se[1] = t4.y; se[2] = t4.z; se[3] = t4.w;
-            } else {
-                se[0] = sc[0]; se[1] = sc[1]; se[2] = sc[2]; se[3] = sc[3];
-            }
+            fallback_scales(se);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 f[i] = static_cast<float>(quantize_one(v[r][i], se[i], static_cast<int32_t>(zpb[i]) - bias, qmin, qmax) + bias);

@@ -22,6 +22,14 @@
 //     accumulator registers).  A stage = 16 rows = [operand A|B][piece][chunk 0|1][256 columns] x 16 B = 48 KB of LDS, in
 //     exactly the order P holds them, so staging is 48 global_load_lds_dwordx4 (1 KB each, 6 per wave): no staging
 //     registers, no ds_write, no VALU.  LDS is a ring of three stages (144 KB, one block per CU).
+//
+// Round 2, `terms` = 3 ("f16x3"): the same machinery on v_mfma_f32_32x32x16_f16 with TWO fp16 pieces per element,
+// hi = f16(x s), lo = f16(x s - hi): 11 + 11 significand bits, i.e. operands rounded to 22 bits (relative 2^-23), and the
+// three products hi.hi, hi.lo, lo.hi (what is dropped -- lo.lo and the operand roundings -- is <= 3 * 2^-23 |x y|, the
+// size of the product roundings of an fp32 fma chain and of either sign).  HALF the matrix-core work of terms = 6.
+// fp16 has five exponent bits, so the batch is scaled by a power of two s that puts max |x| into [2^14, 2^15) (one extra
+// read of X for the absmax: 3 % of the call) and 1 / s^2 -- exact -- goes onto alpha on the device.  Elements below
+// 2^-29 max |x| lose low-order bits of their lo piece to fp16's subnormal spacing: an ABSOLUTE error below 2^-39 max |x|.
 #include "gemm_tn.hpp"
 
 #include <type_traits>
@@ -37,9 +45,12 @@ constexpr int kST = 256;                          // block tile edge
 constexpr int kSK = 16;                           // rows of X per stage = k of one MFMA
 constexpr int kSThreads = 512;
 constexpr int kPlaneBytes = 2 * kST * 16;         // [t-chunk][position] x 16 B
-constexpr int kOperandBytes = 3 * kPlaneBytes;    // hi | mid | lo
-constexpr int kStageBytes = 2 * kOperandBytes;    // A | B
-constexpr int kSyrkLdsBytes = 3 * kStageBytes;    // ring of three stages: 147 456 B
+// PIECES = 3 (bf16: hi | mid | lo) or 2 (fp16: hi | lo)
+constexpr int operand_bytes(int pieces) { return pieces * kPlaneBytes; }
+constexpr int stage_bytes_of(int pieces) { return 2 * operand_bytes(pieces); }     // A | B
+constexpr int syrk_lds_bytes(int pieces) { return 3 * stage_bytes_of(pieces); }    // ring of three stages: 147 456 / 98 304 B
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
     const bf16x2 v = {static_cast<__bf16>(a), static_cast<__bf16>(b)};   // v_cvt_pk_bf16_f32: round to nearest even
@@ -84,6 +95,97 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
     }
 }
 
+// ---- 1b. fp16 pieces: scale, then hi = f16(x s), lo = f16(x s - hi)
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                             float* __restrict__ partial) {
+    float m = 0.f;
+    const int64_t rows_per = (T + static_cast<int64_t>(gridDim.x) - 1) / static_cast<int64_t>(gridDim.x);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * rows_per, t1 = t0 + rows_per < T ? t0 + rows_per : T;
+    for (int64_t t = t0; t < t1; ++t)
+        for (int64_t k = threadIdx.x; k < K; k += 256) m = nmax(m, fabsf(X[t * ldx + k]));
+    m = wave_max(m);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+}
+
+// partial maxima -> scale[0] = s = 2^(15 - exponent of max) (1 for an all-zero or non-finite batch), scale[1] = 1 / s^2
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = nmax(m, partial[i]);
+    m = wave_max(m);
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+        int ex = 0;
+        float s = 1.0f, inv2 = 1.0f;
+        if (m > 0.0f && m < INFINITY) {
+            (void)frexpf(m, &ex);                      // m = f * 2^ex, f in [0.5, 1)
+            int e = 15 - ex;
+            e = e > 60 ? 60 : (e < -60 ? -60 : e);     // 1 / s^2 must stay a normal float
+            s = ldexpf(1.0f, e);
+            inv2 = ldexpf(1.0f, -2 * e);
+        }
+        scale[0] = s;
+        scale[1] = inv2;
+    }
+}
+
+__device__ __forceinline__ uint32_t pk_f16(float a, float b) {
+    const f16x2 v = {static_cast<_Float16>(a), static_cast<_Float16>(b)};   // v_cvt_f16_f32: round to nearest even
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                          const int64_t Kp, const int64_t nchunks, const float* __restrict__ scale,
+                                                          const float alpha, u32x4* __restrict__ P) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool col_ok = k < K;
+    const float* src = X + (col_ok ? k : K - 1);
+    const float sc = scale[0];
+#pragma unroll 1
+    for (int64_t c = static_cast<int64_t>(blockIdx.y) * 4; c < nchunks && c < static_cast<int64_t>(blockIdx.y) * 4 + 4; ++c) {
+        float v[8];
+        uint32_t alive = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t t = c * 8 + r;
+            const float x = src[(t < T ? t : T - 1) * ldx];
+            v[r] = (t < T && col_ok) ? x * sc : 0.f;                       // a power of two: exact
+            // a sample whose square the fp32 path still sees (H[k][k] > 0: the channel is NOT dead, gptq.py:284-286) must not
+            // vanish below fp16's last subnormal (|x| < 2^-40 max|x|): it keeps one unit there
+            alive |= ((x * x) * alpha > 0.0f && t < T && col_ok) ? (1u << r) : 0u;
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const f16x2 h2 = {static_cast<_Float16>(v[2 * rp]), static_cast<_Float16>(v[2 * rp + 1])};
+            uint32_t hb = __builtin_bit_cast(uint32_t, h2);
+            if ((hb & 0x7fffu) == 0 && (alive >> (2 * rp) & 1u)) hb |= 1u;
+            if ((hb & 0x7fff0000u) == 0 && (alive >> (2 * rp + 1) & 1u)) hb |= 0x10000u;
+            hi[rp] = hb;
+            lo[rp] = pk_f16(v[2 * rp] - static_cast<float>(h2[0]), v[2 * rp + 1] - static_cast<float>(h2[1]));   // differences exact
+        }
+        u32x4* o = P + (c * 2) * Kp + k;
+        __builtin_nontemporal_store(hi, o);
+        __builtin_nontemporal_store(lo, o + Kp);
+    }
+}
+
+// one matrix-core instruction on a piece pair, chosen by the piece type
+__device__ __forceinline__ void mfma_pieces(const bf16x8& x, const bf16x8& y, f32x16& c) { c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); }
+__device__ __forceinline__ void mfma_pieces(const f16x8& x, const f16x8& y, f32x16& c) { c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); }
+
+// The piece products of one output tile, small terms first, and the slot in front of which the B operand of the next
+// tile column is fetched.  bf16: 0 = hi, 1 = mid, 2 = lo; fp16: 0 = hi, 1 = lo.
+template <int TERMS> struct TermSeq;
+template <> struct TermSeq<3> { static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0}, PF = 1; };
+template <> struct TermSeq<6> { static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0}, PF = 3; };
+template <> struct TermSeq<9> { static constexpr int A[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}, B[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, PF = 6; };
+
 // ---- 2. C += pieces^T pieces
 // Stream of one stage (sched_barrier(0) pins it; what sits BETWEEN two MFMAs issues while the first one runs):
 //   slots 0-23  this wave's six global_load_lds of stage s + 2 into ring slot (s + 2) % 3 (free since the last barrier),
@@ -94,8 +196,15 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 //   end         vmcnt(0) (the DMAs were issued ~40 MFMAs ago), lgkmcnt(0), s_barrier.
 template <int TERMS>
 __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
-                                                                const float alpha, const float beta, float* __restrict__ C,
-                                                                float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles) {
+                                                                const float alpha_in, const float beta, float* __restrict__ C,
+                                                                float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
+                                                                const float* __restrict__ post_scale) {
+    constexpr bool F16 = TERMS == 3;
+    constexpr int PIECES = F16 ? 2 : 3;
+    constexpr int NDMA = 8 * 2 * PIECES / 8;          // 1 KB pieces of a stage per wave: 6 (bf16) / 4 (fp16)
+    constexpr int kOperandBytes = operand_bytes(PIECES), kStageBytes = stage_bytes_of(PIECES);
+    using frag = std::conditional_t<F16, f16x8, bf16x8>;
+    const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;      // fp16 pieces: 1 / s^2, a power of two
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int tile_m, tile_n;
     upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles, tile_m, tile_n);
@@ -108,19 +217,21 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
     const int wm = wave >> 1, wn = wave & 1;
     const int kc = lane >> 5, cl = lane & 31;
 
-    // ---- loader role: pieces q = 6 wave .. 6 wave + 5 of the 48 KB stage; piece q = 1 KB =
+    // ---- loader role: pieces q = NDMA wave .. NDMA wave + NDMA - 1 of the 48 / 32 KB stage; piece q = 1 KB =
     // (operand, piece, chunk, quarter of 64 columns) in LDS order [operand][piece][chunk][256 columns]
+    // bounds are the bf16 maxima, not NDMA / PIECES: a dependent-size array captured by a lambda silently invalidates the host
+    // side of this kernel (clang 22, HIP: no stub is emitted and the library does not load)
     const char* gsrc[6];
     uint32_t ldst[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int q = wave * 6 + i;
-        const int quarter = q & 3, cc = (q >> 2) & 1, pc = (q >> 3) % 3, op = q / 24;
+    for (int i = 0; i < NDMA; ++i) {
+        const int q = wave * NDMA + i;
+        const int quarter = q & 3, cc = (q >> 2) & 1, pc = (q >> 3) % PIECES, op = q / (8 * PIECES);
         ldst[i] = static_cast<uint32_t>(q) * 1024u;
         const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
-        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * 2 + cc) * 3 + pc) * Kp + colq);
+        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * 2 + cc) * PIECES + pc) * Kp + colq);
     }
-    const int64_t stage_bytes = 2 * 3 * Kp * 16;
+    const int64_t stage_bytes = 2 * PIECES * Kp * 16;
     auto stage_dma = [&](int64_t s_rel, int slot3, int i) {
         __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes,
                                          (__attribute__((address_space(3))) void*)(lds + slot3 * kStageBytes + ldst[i]), 16, 0, 0);
@@ -130,7 +241,7 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
 #pragma unroll
     for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) stage_dma(st < nstages ? st : nstages - 1, st, i);
+        for (int i = 0; i < NDMA; ++i) stage_dma(st < nstages ? st : nstages - 1, st, i);
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
     __builtin_amdgcn_s_barrier();
 
@@ -143,17 +254,17 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     constexpr int kSlots = 8 * TERMS;
-    static_assert(kSlots >= 2 + 6 * 4, "the DMAs must fit into the stream");
+    static_assert(kSlots >= 2 + NDMA * 4, "the DMAs must fit into the stream");
     const uint32_t rd_a = static_cast<uint32_t>((kc * kST + wm * 64 + cl) * 16);
     const uint32_t rd_b = static_cast<uint32_t>(kOperandBytes + (kc * kST + wn * 128 + cl) * 16);
-    bf16x8 a[2][3], b[2][3];
+    frag a[2][3], b[2][3];
     auto read_a = [&](int slot3, int i) {
 #pragma unroll
-        for (int p = 2; p >= 0; --p) a[i][p] = *reinterpret_cast<const bf16x8*>(lds + slot3 * kStageBytes + rd_a + p * kPlaneBytes + i * 32 * 16);
+        for (int p = PIECES - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const frag*>(lds + slot3 * kStageBytes + rd_a + p * kPlaneBytes + i * 32 * 16);
     };
     auto read_b = [&](int slot3, int j, int which) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[which][p] = *reinterpret_cast<const bf16x8*>(lds + slot3 * kStageBytes + rd_b + p * kPlaneBytes + j * 32 * 16);
+        for (int p = 0; p < PIECES; ++p) b[which][p] = *reinterpret_cast<const frag*>(lds + slot3 * kStageBytes + rd_b + p * kPlaneBytes + j * 32 * 16);
     };
     auto stage_body = [&](auto phase_tag, int64_t s, int cur3, int nxt3, int wr3) {
         constexpr int STRIDE = 4;                                        // one DMA every fourth MFMA
@@ -161,35 +272,29 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
         read_a(cur3, 1);                                       // a[0], b[0] came with the previous stage
         const int64_t s_dma = s + 2 < nstages ? s + 2 : nstages - 1;   // behind the slice: re-read its last stage into a slot nobody reads
         int slot = 0;
-        auto mm = [&](const bf16x8& x, const bf16x8& y, f32x16& c) {
+        auto mm = [&](const frag& x, const frag& y, f32x16& c) {
             __builtin_amdgcn_sched_barrier(0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+            mfma_pieces(x, y, c);
             __builtin_amdgcn_sched_barrier(0);
-            if (slot >= DMA0 && slot < DMA0 + 6 * STRIDE && (slot - DMA0) % STRIDE == 0) stage_dma(s_dma, wr3, (slot - DMA0) / STRIDE);
+            if (slot >= DMA0 && slot < DMA0 + NDMA * STRIDE && (slot - DMA0) % STRIDE == 0) stage_dma(s_dma, wr3, (slot - DMA0) / STRIDE);
             ++slot;
         };
+        using seq = TermSeq<TERMS>;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cur = j & 1;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 f32x16 c = acc[i][j];
-                if constexpr (TERMS == 9) {
-                    mm(a[i][2], b[cur][2], c);
-                    mm(a[i][2], b[cur][1], c);
-                    mm(a[i][1], b[cur][2], c);
+#pragma unroll
+                for (int t = 0; t < TERMS; ++t) {
+                    if (t == seq::PF && i == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (j < 3) read_b(cur3, j + 1, cur ^ 1);
+                        else read_b(nxt3, 0, 0);
+                    }
+                    mm(a[i][seq::A[t]], b[cur][seq::B[t]], c);
                 }
-                mm(a[i][2], b[cur][0], c);     // small terms first
-                mm(a[i][0], b[cur][2], c);
-                mm(a[i][1], b[cur][1], c);
-                if (i == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (j < 3) read_b(cur3, j + 1, cur ^ 1);
-                    else read_b(nxt3, 0, 0);
-                }
-                mm(a[i][1], b[cur][0], c);
-                mm(a[i][0], b[cur][1], c);
-                mm(a[i][0], b[cur][0], c);
                 acc[i][j] = c;
                 if (i == 0 && j == 3) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -252,35 +357,52 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
         }
 }
 
+constexpr int kAbsmaxBlocks = 2048;
+constexpr size_t kScaleHeaderBytes = 16384;   // fp16 pieces: [scale, 1 / scale^2, -, -] + the absmax partials, in front of P
 static int64_t padded_k(int64_t K) { return ceil_div(K, kST) * kST; }
 static int64_t stages_of(int64_t T) { return ceil_div(T, kSK); }
 
 size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K) {
     if (T <= 0 || K <= 0) return 0;
-    return static_cast<size_t>(stages_of(T)) * 2 * 3 * padded_k(K) * 16;
+    return static_cast<size_t>(stages_of(T)) * 2 * 3 * padded_k(K) * 16 + kScaleHeaderBytes;   // three bf16 pieces, or the header + two fp16 pieces
 }
 
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, void* workspace,
                            size_t workspace_bytes, int terms, hipStream_t s) {
     OQ_REQUIRE(X != nullptr && C != nullptr && T > 0 && K >= 1 && ldx >= K, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: bad argument");
-    OQ_REQUIRE(terms == 6 || terms == 9, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: terms must be 6 or 9");
+    OQ_REQUIRE(terms == 3 || terms == 6 || terms == 9, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: terms must be 3 (fp16 pieces), 6 or 9");
+    const bool f16 = terms == 3;
     const size_t pieces = syrk_bf16x3_pieces_bytes(T, K);
     OQ_REQUIRE(workspace != nullptr && workspace_bytes >= pieces + 256, OQ_ERR_WORKSPACE,
                "syrk_bf16x3: workspace of %zu bytes needed for the operand pieces, %zu given", pieces + 256, workspace_bytes);
     unsigned char* base = static_cast<unsigned char*>(workspace);
     base += (256 - (reinterpret_cast<uintptr_t>(base) & 255u)) & 255u;
-    u32x4* P = reinterpret_cast<u32x4*>(base);
+    // fp16 pieces take 2/3 of the bf16 pieces' room: the scale header lives in the spare third
+    float* scale = f16 ? reinterpret_cast<float*>(base) : nullptr;
+    u32x4* P = reinterpret_cast<u32x4*>(base + (f16 ? kScaleHeaderBytes : 0));
     float* slab = reinterpret_cast<float*>(base + pieces);
     const size_t slab_bytes = workspace_bytes - pieces - 256;
     // per launch, not once: the attribute belongs to the current device's copy of the kernel
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(terms == 9 ? &syrk_pieces_kernel<9> : &syrk_pieces_kernel<6>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kSyrkLdsBytes);
-    OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", kSyrkLdsBytes);
+    const void* kfn = terms == 9 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<9>)
+                                 : (terms == 6 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<6>) : reinterpret_cast<const void*>(&syrk_pieces_kernel<3>));
+    const int lds_bytes = syrk_lds_bytes(f16 ? 2 : 3);
+    hipError_t e1 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", lds_bytes);
     const int64_t Kp = padded_k(K), nstages = stages_of(T), nchunks = nstages * 2;
     OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "syrk_bf16x3: at most 2 097 120 rows per call, %lld given", (long long)T);
-    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<uint32_t>(Kp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s,
-                       X, T, K, ldx, Kp, nchunks, P);
-    int32_t st = check_launch("split_bf16x3_kernel");
+    int32_t st;
+    if (f16) {
+        const int nb = static_cast<int>(T < kAbsmaxBlocks ? T : kAbsmaxBlocks);
+        hipLaunchKernelGGL(absmax_partial_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, X, T, K, ldx, scale + 4);
+        hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
+        hipLaunchKernelGGL(split_f16x2_kernel, dim3(static_cast<uint32_t>(Kp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s,
+                           X, T, K, ldx, Kp, nchunks, scale, alpha, P);
+        st = check_launch("split_f16x2_kernel");
+    } else {
+        hipLaunchKernelGGL(split_bf16x3_kernel, dim3(static_cast<uint32_t>(Kp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s,
+                           X, T, K, ldx, Kp, nchunks, P);
+        st = check_launch("split_bf16x3_kernel");
+    }
     if (st != OQ_OK) return st;
 
     const int tn = static_cast<int>(Kp / kST);
@@ -303,13 +425,17 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     splits = static_cast<int>(ceil_div(nstages, per));
     float* slab_f = splits > 1 ? slab : nullptr;
     const dim3 grid(static_cast<uint32_t>(tiles), static_cast<uint32_t>(splits));
+    const float* no_scale = nullptr;
     if (terms == 9)
-        hipLaunchKernelGGL(syrk_pieces_kernel<9>, grid, dim3(kSThreads), kSyrkLdsBytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn);
+        hipLaunchKernelGGL(syrk_pieces_kernel<9>, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn, no_scale);
+    else if (terms == 6)
+        hipLaunchKernelGGL(syrk_pieces_kernel<6>, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn, no_scale);
     else
-        hipLaunchKernelGGL(syrk_pieces_kernel<6>, grid, dim3(kSThreads), kSyrkLdsBytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn);
+        hipLaunchKernelGGL(syrk_pieces_kernel<3>, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn,
+                           static_cast<const float*>(scale));
     st = check_launch("syrk_pieces_kernel");
     if (st != OQ_OK || splits == 1) return st;
-    return launch_syrk_reduce(slab_f, splits, K, alpha, beta, C, kST, s);
+    return launch_syrk_reduce(slab_f, splits, K, alpha, beta, C, kST, s, f16 ? scale : nullptr);
 }
 
 }  // namespace oq

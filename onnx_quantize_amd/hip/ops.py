@@ -521,11 +521,11 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
     return int(n_seen) + n_add
 
 
-HESSIAN_METHODS = {"auto": 0, "f32": 1, "bf16x6": 2, "bf16x9": 3}
+HESSIAN_METHODS = {"auto": 0, "f32": 1, "bf16x6": 2, "bf16x9": 3, "f16x3": 4}
 
 
 def hessian_set_method(method: str) -> None:
-    """Process-wide choice of the X^T X kernel (include/oq_hip.h, G1): "auto" | "f32" | "bf16x6" | "bf16x9"."""
+    """Process-wide choice of the X^T X kernel (include/oq_hip.h, G1): "auto" | "f32" | "bf16x6" | "bf16x9" | "f16x3"."""
     L.check(L.load().oq_hessian_set_method(HESSIAN_METHODS[method]))
 
 

@@ -38,7 +38,7 @@ def hessian_of(ops, x):
     return h, n
 
 
-@pytest.mark.parametrize("method", ["auto", "f32", "bf16x6", "bf16x9"])
+@pytest.mark.parametrize("method", ["auto", "f32", "bf16x6", "bf16x9", "f16x3"])
 def test_hessian_vs_golden(ops, method):
     """H as the reference itself produced it (tests/golden/make_golden.py ran gptq.py:246-260), for every kernel."""
     before = ops.hessian_method()
@@ -91,7 +91,7 @@ def restore_hessian_method(ops):
     ops.hessian_set_method(before)
 
 
-@pytest.mark.parametrize("method", ["f32", "bf16x6", "bf16x9"])
+@pytest.mark.parametrize("method", ["f32", "bf16x6", "bf16x9", "f16x3"])
 @pytest.mark.parametrize("t,k,ld", [(4096, 1024, 1024), (1000, 384, 384), (333, 200, 256), (2050, 1301, 1301), (16, 1, 1)])
 def test_hessian_methods_vs_float64(ops, restore_hessian_method, method, t, k, ld):
     """Every X^T X kernel (include/oq_hip.h, G1 methods): fp32-grade against float64, exactly symmetric, exact zeros for
@@ -121,17 +121,50 @@ def test_hessian_methods_vs_float64(ops, restore_hessian_method, method, t, k, l
     np.testing.assert_allclose(h.cpu().numpy(), ref, rtol=0, atol=1e-5 * float(np.abs(ref).max()))   # same X twice: same mean
 
 
+@pytest.mark.parametrize("magnitude", [1e-17, 1e-12, 1.0, 3e4, 1e15])
+def test_hessian_f16_pieces_are_scale_free(ops, restore_hessian_method, magnitude):
+    """OQ_HESSIAN_F16X3 scales the batch by a power of two into fp16's range and undoes it exactly: the result relative to
+    max |H| does not depend on the magnitude of the activations (H from 1e-30 to 1e37, i.e. wherever fp32 can hold it), channels 1e5 x
+    apart keep their own precision where fp16's subnormals allow, an all-zero batch gives exact zeros, and the error
+    against float64 is of the size of the bf16x6 kernel's (<= 1e-5 max |H|; measured 1-3e-6)."""
+    import torch
+    t, k = 2048, 1024
+    rng = np.random.default_rng(17)
+    chan = np.exp(rng.uniform(np.log(1e-3), np.log(1e2), size=k)).astype(np.float32)     # outlier channels 1e5 apart
+    base = rng.standard_normal((t, k)).astype(np.float32) * chan
+    base[:, 7] = 0
+    x = (base.astype(np.float64) * magnitude).astype(np.float32)
+    ops.hessian_set_method("f16x3")
+    h = torch.zeros((k, k), device="cuda")
+    n = ops.hessian_accumulate(dev(x).reshape(4, t // 4, k), h, 0)
+    assert n == 4
+    x64 = x.astype(np.float64)
+    ref = (2.0 / 4) * x64.T @ x64
+    got = h.cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    np.testing.assert_array_equal(got, got.T)
+    assert np.all(got[7] == 0) and np.all(got[:, 7] == 0)
+    # a mid-sized channel pair (both ~1e-2 of the largest) keeps fp32-grade RELATIVE accuracy
+    mid = np.argsort(chan)[k // 2: k // 2 + 8]
+    sub_ref, sub = ref[np.ix_(mid, mid)], got[np.ix_(mid, mid)]
+    assert np.abs(sub - sub_ref).max() <= 2e-5 * np.abs(sub_ref).max()
+    z = torch.zeros((k, k), device="cuda")
+    ops.hessian_accumulate(torch.zeros((2, 64, k), device="cuda"), z, 0)
+    assert float(z.abs().max()) == 0.0
+
+
 def test_hessian_auto_picks_the_split_kernel_for_wide_inputs_only(ops, restore_hessian_method):
     import torch
     ops.hessian_set_method("auto")
     x = torch.randn((2, 1024, 1024), device="cuda")                  # K = 1024 needs T >= 2048 rows for the split kernel
     outs = {}
-    for m in ("auto", "bf16x6", "f32"):
+    for m in ("auto", "f16x3", "f32"):
         ops.hessian_set_method(m)
         h = torch.zeros((1024, 1024), device="cuda")
         ops.hessian_accumulate(x, h, 0)
         outs[m] = h
-    assert torch.equal(outs["auto"], outs["bf16x6"]) and not torch.equal(outs["auto"], outs["f32"])
+    assert torch.equal(outs["auto"], outs["f16x3"]) and not torch.equal(outs["auto"], outs["f32"])
     xs = x[..., :512].contiguous()
     for m in ("auto", "f32"):
         ops.hessian_set_method(m)
