@@ -8,12 +8,14 @@ from onnx_quantize_amd.hip import ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 out = []
-for K, T in ((4096, 65536), (11008, 65536)):
+METHODS = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f32", "bf16x6", "bf16x9", "f16x3"]
+SHAPES = [(int(a), 65536) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else [(4096, 65536), (11008, 65536)]
+for K, T in SHAPES:
     X = torch.randn(T, K, device=dev, dtype=torch.float32)
     X[:, : K // 8] *= 30.0          # outlier channels, like LLM activations
     Xs = X[:8192].double()
     ref = (2.0 / 8192) * (Xs.T @ Xs)
-    for m in ("f32", "bf16x6", "bf16x9", "f16x3"):
+    for m in METHODS:
         ops.hessian_set_method(m)
         H = torch.zeros(K, K, device=dev, dtype=torch.float32)
         n = ops.hessian_accumulate(X[:8192], H, 0)

@@ -154,6 +154,29 @@ def test_hessian_f16_pieces_are_scale_free(ops, restore_hessian_method, magnitud
     assert float(z.abs().max()) == 0.0
 
 
+def test_hessian_f16_pieces_keep_dead_channels_the_reference_s(ops, restore_hessian_method):
+    """gptq.py:284-286 calls a channel dead when H[k][k] == 0.  A channel 2^-45 below the batch maximum lies under fp16's
+    last subnormal after the scaling: its samples keep one unit there, so H[k][k] > 0 as on the fp32 path; an all-zero
+    channel stays exactly zero, and so does one whose squares vanish in fp32 too."""
+    import torch
+    t, k = 2048, 1024
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((t, k)).astype(np.float32)
+    x[:, 3] *= np.float32(2.0 ** -45)          # alive in fp32 (x^2 ~ 2^-90), below 2^-24 after the fp16 scaling
+    x[:, 4] = 0                                # dead
+    x[:, 5] *= np.float32(1e-30)               # x^2 underflows in fp32 as well: dead for the reference too
+    xd = torch.from_numpy(x).cuda().reshape(4, t // 4, k)
+    diag = {}
+    for m in ("f32", "f16x3"):
+        ops.hessian_set_method(m)
+        h = torch.zeros((k, k), device="cuda")
+        ops.hessian_accumulate(xd, h, 0)
+        diag[m] = torch.diagonal(h).cpu().numpy()
+    for m in diag:
+        assert diag[m][3] > 0 and diag[m][4] == 0 and diag[m][5] == 0, m
+    np.testing.assert_array_equal(diag["f32"] == 0, diag["f16x3"] == 0)
+
+
 def test_hessian_auto_picks_the_split_kernel_for_wide_inputs_only(ops, restore_hessian_method):
     import torch
     ops.hessian_set_method("auto")
