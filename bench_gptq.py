@@ -57,6 +57,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--factor-streams", type=int, default=4,
                     help="streams that take the factor + loop chains of successive inputs in turn (chains of small launches: "
                          "several of them side by side hide each other's launch and diagonal-block latency)")
+    ap.add_argument("--overlap", action="store_true", help="with --factor-wave > 0: factor + loop on side streams all the same")
+    ap.add_argument("--factor-wave", type=int, default=8,
+                    help="layers per wave whose Hessians of one width are factored as ONE batch (0: a factor chain per input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hessian-methods", default="auto,bf16x6,f32",
                     help="comma list of X^T X kernels to time alone for the roofline objects (auto = the fp16-piece split-operand kernel for K >= 1024)")
@@ -156,41 +159,88 @@ def run(args, dev, rank: int, world: int):
         groups[seen[key]][1].append(i)
 
     s_h = torch.cuda.Stream(device=dev)
-    q_streams = [s_h] if args.no_overlap else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
+    # batched factors (factor_wave > 0) run on the Hessian's stream unless --overlap: side by side the two kinds of
+    # matrix-core kernels only slow each other down (measured: 4.88 s in sequence, 5.2-5.6 s on 1 + 2..4 streams)
+    one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
+    q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
     results, timings, samples = {}, [], {}
     fence()
     t0 = time.perf_counter()
-    for gi, (key, members) in enumerate(groups):
-        s_q = q_streams[gi % len(q_streams)]
-        k = specs[members[0]].k
-        with torch.cuda.stream(s_h):
-            h = torch.zeros((k, k), device=dev)
-            e0, e1 = ev(), ev()
-            e0.record()
-            n = 0
-            for x in acts[k]:
-                n = ops.hessian_accumulate(x, h, n)
-            e1.record()
-            timings.append(("h", e0, e1))
-        with torch.cuda.stream(s_q):
-            s_q.wait_event(e1)
-            h.record_stream(s_q)
-            e2, e3 = ev(), ev()
-            e2.record()
-            shared = ops.gptq_shared_factor(h, 0.01, False)
-            e3.record()
-            timings.append(("f", e2, e3))
-            for j, i in enumerate(members):
-                sp = specs[i]
-                w = wpool[(sp.k, sp.n)][(i + j) % 3]
-                e4, e5 = ev(), ev()
-                e4.record()
-                q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128, mode=args.mode, shared=shared)
-                results[i] = (ops.pack_nibbles(q), s, z)               # 0.5 B / param on the wire
-                e5.record()
-                timings.append(("l", e4, e5))
-                if (sp.k, sp.n) not in samples:                         # first layer of every shape: verified after the clock stops
-                    samples[(sp.k, sp.n)] = (i, w)
+    def quantize_members(members, h, shared):
+        for j, i in enumerate(members):
+            sp = specs[i]
+            w = wpool[(sp.k, sp.n)][(i + j) % 3]
+            e4, e5 = ev(), ev()
+            e4.record()
+            q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128, mode=args.mode, shared=shared)
+            results[i] = (ops.pack_nibbles(q), s, z)               # 0.5 B / param on the wire
+            e5.record()
+            timings.append(("l", e4, e5))
+            if (sp.k, sp.n) not in samples:                         # first layer of every shape: verified after the clock stops
+                samples[(sp.k, sp.n)] = (i, w)
+
+    if args.factor_wave <= 0:
+        # one factor chain per input, as soon as its Hessian is complete
+        for gi, (key, members) in enumerate(groups):
+            s_q = q_streams[gi % len(q_streams)]
+            k = specs[members[0]].k
+            with torch.cuda.stream(s_h):
+                h = torch.zeros((k, k), device=dev)
+                e0, e1 = ev(), ev()
+                e0.record()
+                n = 0
+                for x in acts[k]:
+                    n = ops.hessian_accumulate(x, h, n)
+                e1.record()
+                timings.append(("h", e0, e1))
+            with torch.cuda.stream(s_q):
+                s_q.wait_event(e1)
+                h.record_stream(s_q)
+                e2, e3 = ev(), ev()
+                e2.record()
+                shared = ops.gptq_shared_factor(h, 0.01, False)
+                e3.record()
+                timings.append(("f", e2, e3))
+                quantize_members(members, h, shared)
+    else:
+        # waves of `factor_wave` layers: the Hessians of a wave accumulate into one stack per input width, and each stack
+        # is factored in lock-step (oq_gptq_factor_batched_f32: the latency of ONE chain of diagonal blocks for the whole
+        # stack) while the Hessian stream is already on the next wave
+        per_wave = max(1, args.factor_wave * max(1, len(groups) // max(1, args.layers)))
+        for w0 in range(0, len(groups), per_wave):
+            wave = groups[w0:w0 + per_wave]
+            s_q = q_streams[(w0 // per_wave) % len(q_streams)]
+            slots, last = {}, {}
+            for gi, (key, members) in enumerate(wave):
+                k = specs[members[0]].k
+                slots.setdefault(k, []).append(gi)
+                last[k] = gi
+            with torch.cuda.stream(s_h):
+                stacks = {k: torch.zeros((len(g), k, k), device=dev) for k, g in slots.items()}
+                done = {}
+                for gi, (key, members) in enumerate(wave):
+                    k = specs[members[0]].k
+                    h = stacks[k][slots[k].index(gi)]
+                    e0, e1 = ev(), ev()
+                    e0.record()
+                    n = 0
+                    for x in acts[k]:
+                        n = ops.hessian_accumulate(x, h, n)
+                    e1.record()
+                    timings.append(("h", e0, e1))
+                    if last[k] == gi:
+                        done[k] = e1
+            with torch.cuda.stream(s_q):
+                for k in sorted(slots, key=lambda kk: last[kk]):           # widths in the order their stacks complete
+                    s_q.wait_event(done[k])
+                    stacks[k].record_stream(s_q)
+                    e2, e3 = ev(), ev()
+                    e2.record()
+                    shared_list = ops.gptq_shared_factors(stacks[k], 0.01)
+                    e3.record()
+                    timings.append(("f", e2, e3))
+                    for j, gi in enumerate(slots[k]):
+                        quantize_members(wave[gi][1], stacks[k][j], shared_list[j])
     torch.cuda.synchronize()
     t_quant = time.perf_counter() - t0
     fence()
@@ -305,7 +355,8 @@ def run(args, dev, rank: int, world: int):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
                    "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
-                   "streams": 1 if args.no_overlap else 1 + len(q_streams), "hessian_method": ops.hessian_method()},
+                   "streams": 1 if one_stream else 1 + len(q_streams), "factor_wave_layers": args.factor_wave,
+                   "hessian_method": ops.hessian_method()},
         "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
                     "gather": round(float(stats[2]), 4),
                     # per-phase device time (with several streams the phases overlap: their sum exceeds the wall time)

@@ -246,6 +246,18 @@ int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t ac
 size_t oq_gptq_factor_workspace_bytes(int64_t K);
 int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info,
                            void* workspace, size_t workspace_bytes, void* stream);
+/*     The same for `count` matrices of one width in lock-step (the inputs of a model that share K: the reference
+ *     factors each node's H by itself, gptq.py:134-150 once per `_gptq` call).  Matrix i is H + i * h_stride, its
+ *     factor U_out + i * u_stride (strides in floats, >= K * K), its status info[i].  The chain of a factorisation is
+ *     ceil(K / 128) strictly sequential diagonal blocks; every launch of that chain here carries all `count` matrices,
+ *     so a batch costs the latency of ONE chain plus the matrix-core work of `count`.  Per matrix the operations and
+ *     their order are those of oq_gptq_factor_f32: the results are bit-identical.
+ *     fix_dead != 0: a zero diagonal entry of H counts as 1 (gptq.py:119-120; for an H that did not pass
+ *     oq_gptq_prepare_f32 -- the weights' dead rows remain the caller's business, gptq.py:121). */
+size_t oq_gptq_factor_batched_workspace_bytes(int64_t K, int64_t count);
+int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, int64_t count, float percdamp,
+                                   int32_t fix_dead, float* U_out, int64_t u_stride, int32_t* info,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* G3  gptq.py:153-216: the block / row loop.  W [K, N] is the working copy (after oq_gptq_prepare_f32); it
  *     receives the lazy batch updates of gptq.py:208 (OQ_GPTQ_CORRECTED only: in OQ_GPTQ_PARITY the update term

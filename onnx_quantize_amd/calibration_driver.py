@@ -256,11 +256,14 @@ def run_calibration(runner: Callable, calibration_data, stream: ActivationStream
 
 def quantize_weights_gptq(layers: Mapping, hessians: Mapping[str, HessianAccumulator], quant_type: str, strategy: str,
                           group_size, *, symmetric=False, reduce_range=False, clip_ratio=1.0, block_size=128,
-                          percdamp=0.01, actorder=False, mse=False, mode: str = "parity") -> dict:
+                          percdamp=0.01, actorder=False, mse=False, mode: str = "parity",
+                          factor_batch_bytes: int = 24 << 30) -> dict:
     """`_gptq` (gptq.py:76-243) for every ``{layer name: (W [K, N] in HBM, input value name)}``, with everything that
     depends on H alone (dead channels, permutation, inverse factor) computed once per distinct input: the reference
     repeats it per node, nodes that share an input (q/k/v, gate/up) share it here.  Returns
     {layer name: (q, scale, zero_point, info)} on the device."""
+    import torch
+
     from .hip import ops
 
     by_input: dict[str, list[str]] = {}
@@ -269,10 +272,23 @@ def quantize_weights_gptq(layers: Mapping, hessians: Mapping[str, HessianAccumul
             raise KeyError(f"quantize_weights_gptq: no Hessian accumulated for input '{value}' of '{name}'")
         by_input.setdefault(value, []).append(name)
     out = {}
-    for value, names in by_input.items():
-        h = hessians[value].h
-        shared = ops.gptq_shared_factor(h, percdamp, actorder)
-        for name in names:
-            out[name] = ops.gptq_quantize(layers[name][0], h, quant_type, strategy, group_size, symmetric, reduce_range,
-                                          clip_ratio, block_size, percdamp, actorder, mse, mode=mode, shared=shared)
-    return out
+    # Inputs of one width are factored in lock-step (oq_gptq_factor_batched_f32: the latency of one chain of diagonal
+    # blocks for the whole batch), in batches bounded by `factor_batch_bytes` of workspace + stacked copies.
+    by_width: dict[int, list[str]] = {}
+    for value in by_input:
+        by_width.setdefault(int(hessians[value].h.shape[0]), []).append(value)
+    for k, values in by_width.items():
+        per_matrix = 7 * k * k * 4                       # stacked H, U, and the factor's P, Lt, X, Y (+ Dinv)
+        step = 1 if actorder else max(1, min(len(values), factor_batch_bytes // per_matrix))
+        for b0 in range(0, len(values), step):
+            chunk = values[b0:b0 + step]
+            if len(chunk) == 1:
+                shared_list = [ops.gptq_shared_factor(hessians[chunk[0]].h, percdamp, actorder)]
+            else:
+                shared_list = ops.gptq_shared_factors(torch.stack([hessians[v].h for v in chunk]).contiguous(), percdamp)
+            for value, shared in zip(chunk, shared_list):
+                h = hessians[value].h
+                for name in by_input[value]:
+                    out[name] = ops.gptq_quantize(layers[name][0], h, quant_type, strategy, group_size, symmetric, reduce_range,
+                                                  clip_ratio, block_size, percdamp, actorder, mse, mode=mode, shared=shared)
+    return {name: out[name] for name in layers}

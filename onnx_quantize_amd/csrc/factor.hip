@@ -52,15 +52,24 @@ __global__ void gather_sym_kernel(const float* H, int64_t K, const int32_t* perm
 }
 
 // ------------------------------------------------------------------------------------ factor
-__global__ void reverse_copy_kernel(const float* src, int64_t K, float* dst) {
+// blockIdx.y = matrix of the batch.  fix_dead: a zero diagonal entry becomes 1 on the way (gptq.py:119-120, for callers
+// that did not run oq_gptq_prepare_f32 on this H).
+__global__ void reverse_copy_kernel(const float* src, int64_t K, float* dst, int64_t src_stride, int64_t dst_stride, int fix_dead) {
     const int64_t r = blockIdx.x;
-    for (int64_t c = threadIdx.x; c < K; c += blockDim.x) dst[r * K + c] = src[(K - 1 - r) * K + (K - 1 - c)];
+    src += static_cast<int64_t>(blockIdx.y) * src_stride;
+    dst += static_cast<int64_t>(blockIdx.y) * dst_stride;
+    for (int64_t c = threadIdx.x; c < K; c += blockDim.x) {
+        float v = src[(K - 1 - r) * K + (K - 1 - c)];
+        if (fix_dead && c == r && v == 0.0f) v = 1.0f;
+        dst[r * K + c] = v;
+    }
 }
 
 // gptq.py:135-138: damp = percdamp * mean(diag(H)); H[diag] += damp.  One block.
-__global__ __launch_bounds__(1024) void damp_kernel(float* P, int64_t K, float percdamp) {
+__global__ __launch_bounds__(1024) void damp_kernel(float* P, int64_t K, float percdamp, int64_t stride) {
     __shared__ float s_part[16];
     __shared__ float s_damp;
+    P += static_cast<int64_t>(blockIdx.x) * stride;
     float acc = 0.f;
     for (int64_t i = threadIdx.x; i < K; i += blockDim.x) acc += P[i * K + i];
 #pragma unroll
@@ -153,9 +162,14 @@ __device__ __forceinline__ void lds_product(int mr, int nc, int kd, FA fa, FB fb
 //   Lt   [K, K]: Lt[k][i] = L[i][k]  (upper triangular = L^T), diag block written here
 //   Dinv [nb][128][128]: Dinv[kb][k][c] = inv(L_kk)[c][k]  (transposed, zero above the diagonal of the inverse)
 //   info: first non-positive pivot (1-based, in reversed index space), 0 if none so far
+//   blockIdx.x = matrix of the batch (P, Lt advance by `stride`, Dinv by `dinv_stride` floats, info by one)
 __global__ __launch_bounds__(kDiagThreads) void chol_diag_kernel(const float* P, int64_t K, int64_t kb, float* Lt, float* Dinv,
-                                                        int32_t* info) {
+                                                        int32_t* info, int64_t stride, int64_t dinv_stride) {
     extern __shared__ float lds[];
+    P += static_cast<int64_t>(blockIdx.x) * stride;
+    Lt += static_cast<int64_t>(blockIdx.x) * stride;
+    Dinv += static_cast<int64_t>(blockIdx.x) * dinv_stride;
+    info += blockIdx.x;
     float (*A)[kLd] = reinterpret_cast<float (*)[kLd]>(lds);                    // the block; lower triangle becomes L
     float (*M)[kLd] = reinterpret_cast<float (*)[kLd]>(lds + kNB * kLd);        // inv(L), lower triangular
     float (*S)[kLd] = reinterpret_cast<float (*)[kLd]>(lds + 2 * kNB * kLd);    // [32][129] scratch of the inverse
@@ -248,8 +262,11 @@ __global__ __launch_bounds__(kDiagThreads) void chol_diag_kernel(const float* P,
 }
 
 // Diagonal blocks of X = L'^-1 (lower) and of Y = X^T (upper) from Dinv[kb][k][c] = inv(L_kk)[c][k]; one block per kb.
-__global__ void place_diag_inverse_kernel(const float* Dinv, int64_t K, float* X, float* Y) {
+__global__ void place_diag_inverse_kernel(const float* Dinv, int64_t K, float* X, float* Y, int64_t stride, int64_t dinv_stride) {
     const int64_t kb = blockIdx.x, o = kb * kNB;
+    Dinv += static_cast<int64_t>(blockIdx.y) * dinv_stride;
+    X += static_cast<int64_t>(blockIdx.y) * stride;
+    Y += static_cast<int64_t>(blockIdx.y) * stride;
     const int n = static_cast<int>((K - o) < kNB ? (K - o) : kNB);
     for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
         const int k = idx / n, c = idx - k * n;
@@ -260,9 +277,11 @@ __global__ void place_diag_inverse_kernel(const float* Dinv, int64_t K, float* X
 }
 
 // U[a][b] = X[K-1-a][K-1-b] when the factorisation succeeded, identity otherwise (gptq.py:143-150).
-__global__ void finish_factor_kernel(const float* X, int64_t K, const int32_t* info, float* U) {
+__global__ void finish_factor_kernel(const float* X, int64_t K, const int32_t* info, float* U, int64_t x_stride, int64_t u_stride) {
     const int64_t r = blockIdx.x;
-    const bool ok = *info == 0;
+    X += static_cast<int64_t>(blockIdx.y) * x_stride;
+    U += static_cast<int64_t>(blockIdx.y) * u_stride;
+    const bool ok = info[blockIdx.y] == 0;
     for (int64_t c = threadIdx.x; c < K; c += blockDim.x) {
         float v;
         if (ok) v = (c >= r) ? X[(K - 1 - r) * K + (K - 1 - c)] : 0.0f;
@@ -308,36 +327,45 @@ int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t ac
     return OQ_OK;
 }
 
-size_t oq_gptq_factor_workspace_bytes(int64_t K) {
-    if (K <= 0) return 0;
-    const size_t kk = align256(static_cast<size_t>(K) * K * 4);
-    const int64_t nb = ceil_div(K, kNB);
-    // P (reversed, damped, factored in place; later the S scratch of the inverse), Lt, X, Y = X^T, Dinv
-    return 4 * kk + align256(static_cast<size_t>(nb) * kNB * kNB * 4) + 256;
+// Workspace of a batch: [P x count][Lt x count][X x count][Y x count][Dinv x count] -- P is reversed, damped and factored in
+// place (later the S scratch of the inverse), Y = X^T, Dinv the inverted diagonal blocks.  One region per role, so the
+// matrices of a role are a strided batch (stride kk) and X, Y are cleared by one memset.
+static size_t factor_matrix_bytes(int64_t K) { return align256(static_cast<size_t>(K) * K * 4); }
+static size_t factor_dinv_bytes(int64_t K) { return align256(static_cast<size_t>(ceil_div(K, kNB)) * kNB * kNB * 4); }
+
+size_t oq_gptq_factor_batched_workspace_bytes(int64_t K, int64_t count) {
+    if (K <= 0 || count <= 0) return 0;
+    return static_cast<size_t>(count) * (4 * factor_matrix_bytes(K) + factor_dinv_bytes(K)) + 256;
 }
 
-int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info, void* workspace,
-                           size_t workspace_bytes, void* stream) {
-    OQ_REQUIRE(H && U_out && info && K > 0, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_factor_f32: bad argument");
-    const size_t need = oq_gptq_factor_workspace_bytes(K);
-    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_gptq_factor_f32: workspace of %zu bytes needed, %zu given",
-               need, workspace_bytes);
-    hipStream_t s = as_stream(stream);
-    const size_t kk = align256(static_cast<size_t>(K) * K * 4);
+size_t oq_gptq_factor_workspace_bytes(int64_t K) { return oq_gptq_factor_batched_workspace_bytes(K, 1); }
+
+// `count` independent K x K matrices in lock-step: every launch of the chain (diagonal block, panel, strip, deferred
+// square, the levels of the inverse) carries all of them -- blockIdx of the small kernels, the outer batch of the TN
+// GEMM -- so a batch costs the LATENCY of one chain (nb sequential diagonal blocks) and the GEMM work of `count`.
+static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64_t count, float percdamp, float* U_out, int64_t u_stride,
+                              int32_t* info, int32_t fix_dead, void* workspace, size_t workspace_bytes, hipStream_t s, const char* who) {
+    OQ_REQUIRE(H && U_out && info && K > 0 && count > 0 && count <= 65535, OQ_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
+    OQ_REQUIRE(count == 1 || (h_stride >= K * K && u_stride >= K * K), OQ_ERR_INVALID_ARGUMENT, "%s: matrices of the batch overlap", who);
+    const size_t need = oq_gptq_factor_batched_workspace_bytes(K, count);
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, workspace_bytes);
+    const size_t kk = factor_matrix_bytes(K);
+    const int64_t ms = static_cast<int64_t>(kk / 4);                      // floats between the matrices of one role
+    const int64_t ds = static_cast<int64_t>(factor_dinv_bytes(K) / 4);
     const int64_t nb = ceil_div(K, kNB);
+    const uint32_t cnt = static_cast<uint32_t>(count);
     char* base = static_cast<char*>(workspace);
     float* P = reinterpret_cast<float*>(base);
-    float* Lt = reinterpret_cast<float*>(base + kk);
-    float* X = reinterpret_cast<float*>(base + 2 * kk);
-    float* Y = reinterpret_cast<float*>(base + 3 * kk);
-    float* Dinv = reinterpret_cast<float*>(base + 4 * kk);
+    float* Lt = reinterpret_cast<float*>(base + count * kk);
+    float* X = reinterpret_cast<float*>(base + 2 * count * kk);
+    float* Y = reinterpret_cast<float*>(base + 3 * count * kk);
+    float* Dinv = reinterpret_cast<float*>(base + 4 * count * kk);
     float* S = P;   // P is dead once the Cholesky loop has finished
 
-    if (hipMemsetAsync(info, 0, sizeof(int32_t), s) != hipSuccess || hipMemsetAsync(X, 0, static_cast<size_t>(K) * K * 4, s) != hipSuccess ||
-        hipMemsetAsync(Y, 0, static_cast<size_t>(K) * K * 4, s) != hipSuccess)
-        return fail(OQ_ERR_LAUNCH, "oq_gptq_factor_f32: memset failed");
-    hipLaunchKernelGGL(reverse_copy_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, H, K, P);
-    hipLaunchKernelGGL(damp_kernel, dim3(1), dim3(1024), 0, s, P, K, percdamp);
+    if (hipMemsetAsync(info, 0, sizeof(int32_t) * count, s) != hipSuccess || hipMemsetAsync(X, 0, 2 * count * kk, s) != hipSuccess)
+        return fail(OQ_ERR_LAUNCH, "%s: memset failed", who);
+    hipLaunchKernelGGL(reverse_copy_kernel, dim3(static_cast<uint32_t>(K), cnt), dim3(256), 0, s, H, K, P, h_stride, ms, fix_dead);
+    hipLaunchKernelGGL(damp_kernel, dim3(cnt), dim3(1024), 0, s, P, K, percdamp, ms);
     int32_t st = check_launch("reverse/damp");
     if (st != OQ_OK) return st;
 
@@ -345,7 +373,10 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
     // once per call, not once per process: the attribute belongs to the current device's copy of the kernel
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_diag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             static_cast<int>(diag_lds)) != hipSuccess)
-        return fail(OQ_ERR_LAUNCH, "oq_gptq_factor_f32: cannot reserve %zu bytes of LDS", diag_lds);
+        return fail(OQ_ERR_LAUNCH, "%s: cannot reserve %zu bytes of LDS", who, diag_lds);
+    auto outer = [&](GemmTN& g, int64_t a, int64_t b, int64_t c, int64_t ct) {
+        g.outer = count; g.outer_a = a; g.outer_b = b; g.outer_c = c; g.outer_ct = ct;
+    };
 
     // ---- blocked right-looking Cholesky of P, two levels: inside an outer panel of kOuter rows the 128-row steps
     // update only the panel's own rows (a strip of <= 384 rows x all columns behind); the square behind the panel gets
@@ -358,7 +389,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             const int64_t kb = o / kNB;
             const int64_t n = (K - o) < kNB ? (K - o) : kNB;
             const int64_t rest = K - o - n;  // columns behind this block
-            hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(kDiagThreads), diag_lds, s, P, K, kb, Lt, Dinv, info);
+            hipLaunchKernelGGL(chol_diag_kernel, dim3(cnt), dim3(kDiagThreads), diag_lds, s, P, K, kb, Lt, Dinv, info, ms, ds);
             st = check_launch("chol_diag_kernel");
             if (st != OQ_OK) return st;
             if (rest <= 0) break;
@@ -368,6 +399,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             pg.B = P + o * K + o + n; pg.ldb = K; pg.N = rest;
             pg.C = Lt + o * K + o + n; pg.ldc = K;
             pg.Kd = n; pg.alpha = 1.0f; pg.beta = 0.0f; pg.sa = 1.0f; pg.sb = 1.0f; pg.upper_only = 0; pg.mirror = 0;
+            outer(pg, ds, ms, ms, 0);
             st = launch_gemm_tn(pg, s);
             if (st != OQ_OK) return st;
             // strip update: rows of the outer panel behind this block x all columns behind it
@@ -378,6 +410,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
                 tg.B = Lt + o * K + o + n; tg.ldb = K; tg.N = rest;
                 tg.C = P + (o + n) * K + o + n; tg.ldc = K;
                 tg.Kd = n; tg.alpha = -1.0f; tg.beta = 1.0f; tg.sa = 1.0f; tg.sb = 1.0f; tg.upper_only = 0; tg.mirror = 0;
+                outer(tg, ms, ms, ms, 0);
                 st = launch_gemm_tn(tg, s);
                 if (st != OQ_OK) return st;
             }
@@ -391,6 +424,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             tg.B = tg.At; tg.ldb = K; tg.N = rest2;
             tg.C = P + pend * K + pend; tg.ldc = K;
             tg.Kd = pend - O; tg.alpha = -1.0f; tg.beta = 1.0f; tg.sa = 1.0f; tg.sb = 1.0f; tg.upper_only = 1; tg.mirror = 1;
+            outer(tg, ms, ms, ms, 0);
             st = launch_gemm_tn(tg, s);
             if (st != OQ_OK) return st;
         }
@@ -401,7 +435,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
     // 2b * (K + 1)), so a level is two launches with K / 2b * (b / 128)^2 tiles each instead of one 128-row block
     // row (a single tile row) at a time.  Both X and Y = X^T are kept: the TN GEMM wants its left operand k-major,
     // i.e. X22 transposed; the second GEMM writes its result to both.
-    hipLaunchKernelGGL(place_diag_inverse_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, Dinv, K, X, Y);
+    hipLaunchKernelGGL(place_diag_inverse_kernel, dim3(static_cast<uint32_t>(nb), cnt), dim3(256), 0, s, Dinv, K, X, Y, ms, ds);
     st = check_launch("place_diag_inverse_kernel");
     if (st != OQ_OK) return st;
     for (int64_t b = kNB; b < K; b *= 2) {
@@ -409,8 +443,8 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
         const int64_t full = (K / (2 * b));                          // pairs with a full second block
         for (int part = 0; part < 2; ++part) {                       // 0: the full pairs (one batch), 1: the ragged last pair
             const int64_t first = part == 0 ? 0 : full;
-            const int64_t count = part == 0 ? full : npairs - full;
-            if (count <= 0) continue;
+            const int64_t pairs = part == 0 ? full : npairs - full;
+            if (pairs <= 0) continue;
             const int64_t o1 = first * 2 * b, o2 = o1 + b;
             const int64_t b2 = part == 0 ? b : K - o2;               // rows of the second block
             GemmTN sg;  // S[r][j] = sum_k L21[r][k] * X11[k][j] = sum_k Lt[o1+k][o2+r] * X[o1+k][o1+j]
@@ -419,7 +453,8 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             sg.C = S + first * b * b; sg.ldc = b;
             sg.Kd = b; sg.alpha = 1.0f; sg.beta = 0.0f; sg.sa = 1.0f; sg.sb = 1.0f; sg.upper_only = 0; sg.mirror = 0;
             sg.k_from_n = 1;   // X11 is lower triangular
-            sg.batch = count; sg.stride_a = 2 * b * (K + 1); sg.stride_b = 2 * b * (K + 1); sg.stride_c = b * b;
+            sg.batch = pairs; sg.stride_a = 2 * b * (K + 1); sg.stride_b = 2 * b * (K + 1); sg.stride_c = b * b;
+            outer(sg, ms, ms, ms, 0);
             st = launch_gemm_tn(sg, s);
             if (st != OQ_OK) return st;
             GemmTN xg;  // X21[r][j] = -sum_c X22[r][c] * S[c][j] = -sum_c Y[o2+c][o2+r] * S[c][j];  Y12 = X21^T
@@ -429,14 +464,26 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
             xg.Ct = Y + o1 * K + o2; xg.ldct = K;
             xg.Kd = b2; xg.alpha = -1.0f; xg.beta = 0.0f; xg.sa = 1.0f; xg.sb = 1.0f; xg.upper_only = 0; xg.mirror = 0;
             xg.k_to_m = 1;     // X22^T is upper triangular
-            xg.batch = count; xg.stride_a = 2 * b * (K + 1); xg.stride_b = b * b; xg.stride_c = 2 * b * (K + 1);
+            xg.batch = pairs; xg.stride_a = 2 * b * (K + 1); xg.stride_b = b * b; xg.stride_c = 2 * b * (K + 1);
             xg.stride_ct = 2 * b * (K + 1);
+            outer(xg, ms, ms, ms, ms);
             st = launch_gemm_tn(xg, s);
             if (st != OQ_OK) return st;
         }
     }
-    hipLaunchKernelGGL(finish_factor_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, X, K, info, U_out);
+    hipLaunchKernelGGL(finish_factor_kernel, dim3(static_cast<uint32_t>(K), cnt), dim3(256), 0, s, X, K, info, U_out, ms, u_stride);
     return check_launch("finish_factor_kernel");
+}
+
+int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    return factor_batched(H, K, 0, 1, percdamp, U_out, 0, info, 0, workspace, workspace_bytes, as_stream(stream), "oq_gptq_factor_f32");
+}
+
+int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, int64_t count, float percdamp, int32_t fix_dead,
+                                   float* U_out, int64_t u_stride, int32_t* info, void* workspace, size_t workspace_bytes, void* stream) {
+    return factor_batched(H, K, h_stride, count, percdamp, U_out, u_stride, info, fix_dead, workspace, workspace_bytes, as_stream(stream),
+                          "oq_gptq_factor_batched_f32");
 }
 
 }  // extern "C"

@@ -92,6 +92,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_tn_kernel(const GemmTN g_in
         g.At += z * g.stride_a; g.B += z * g.stride_b; g.C += z * g.stride_c;
         if (g.Ct) g.Ct += z * g.stride_ct;
     }
+    if (g.outer > 1) {
+        const int64_t y = blockIdx.y;
+        g.At += y * g.outer_a; g.B += y * g.outer_b; g.C += y * g.outer_c;
+        if (g.Ct) g.Ct += y * g.outer_ct;
+    }
     int tile_m, tile_n;
     if (g.upper_only) {
         // Upper-triangle tiles enumerated by 8 x 8 SUPER-TILES (row-major over the upper triangle of super-tiles, tiles
@@ -274,8 +279,11 @@ int32_t launch_gemm_tn(const GemmTN& g, hipStream_t s) {
     const int tn = static_cast<int>(ceil_div(g.N, kBN)), tm = static_cast<int>(ceil_div(g.M, kBM));
     const uint32_t ntiles = g.upper_only ? static_cast<uint32_t>(tn) * (tn + 1) / 2 : static_cast<uint32_t>(tn) * tm;
     OQ_REQUIRE(g.batch >= 1 && g.batch <= 65535, OQ_ERR_INVALID_ARGUMENT, "gemm_tn: bad batch %lld", (long long)g.batch);
-    const bool vec_sa = g.batch == 1 || g.stride_a % 4 == 0, vec_sb = g.batch == 1 || g.stride_b % 4 == 0;
-    launch_variant(vec_a && vec_sa, vec_b && vec_sb, dim3(ntiles, 1, static_cast<uint32_t>(g.batch)), s, g, nullptr, 0, tn);
+    OQ_REQUIRE(g.outer >= 1 && g.outer <= 65535, OQ_ERR_INVALID_ARGUMENT, "gemm_tn: bad outer batch %lld", (long long)g.outer);
+    const bool vec_sa = (g.batch == 1 || g.stride_a % 4 == 0) && (g.outer == 1 || g.outer_a % 4 == 0);
+    const bool vec_sb = (g.batch == 1 || g.stride_b % 4 == 0) && (g.outer == 1 || g.outer_b % 4 == 0);
+    launch_variant(vec_a && vec_sa, vec_b && vec_sb, dim3(ntiles, static_cast<uint32_t>(g.outer), static_cast<uint32_t>(g.batch)), s, g, nullptr, 0,
+                   tn);
     return check_launch("gemm_tn_kernel");
 }
 

@@ -28,6 +28,8 @@ struct GemmTN {
     int32_t mirror;      // with upper_only: also store C[n, m] for off-diagonal tiles
     // strided batch (blockIdx.z): problem z uses At + z * stride_a, B + z * stride_b, C + z * stride_c (elements)
     int64_t batch = 1, stride_a = 0, stride_b = 0, stride_c = 0;
+    // second batch level (blockIdx.y, not with T-slice slabs): `outer` independent matrices, each with its own strided batch
+    int64_t outer = 1, outer_a = 0, outer_b = 0, outer_c = 0, outer_ct = 0;
     // optional second, transposed copy of the result: Ct[n * ldct + m] = C[m, n] (+ z * stride_ct)
     float* Ct = nullptr;
     int64_t ldct = 0, stride_ct = 0;

@@ -83,6 +83,8 @@ PROTOTYPES = {
     "oq_gptq_prepare_f32": (_i32, [_p, _i64, _i64, _p, _i32, _p, _p, _sz, _p]),
     "oq_gptq_factor_workspace_bytes": (_sz, [_i64]),
     "oq_gptq_factor_f32": (_i32, [_p, _i64, _f32, _p, _p, _p, _sz, _p]),
+    "oq_gptq_factor_batched_workspace_bytes": (_sz, [_i64, _i64]),
+    "oq_gptq_factor_batched_f32": (_i32, [_p, _i64, _i64, _i64, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
     "oq_gptq_loop_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "oq_gptq_loop_f32": (_i32, [_p, _i64, _i64, _p, _i32, _i64, _i32, _i32, _f32, _i32, _i64, _i32,
                                 _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),

@@ -560,6 +560,31 @@ def gptq_factor(h: torch.Tensor, percdamp: float):
     return u, info
 
 
+def gptq_factor_batched(h: torch.Tensor, percdamp: float, fix_dead: bool = False):
+    """gptq.py:134-150 for a stack ``h`` [B, K, K] of Hessians of one width, factored in lock-step (one chain of
+    launches for all of them).  Returns (U [B, K, K], info int32[B] on the device); matrix by matrix bit-identical to
+    `gptq_factor`.  ``fix_dead``: zero diagonal entries count as 1 (gptq.py:119-120)."""
+    _require_device(h, "H", torch.float32)
+    if h.dim() != 3 or h.shape[1] != h.shape[2] or not h.is_contiguous():
+        raise ValueError("H must be a contiguous [B, K, K] tensor")
+    b, k = int(h.shape[0]), int(h.shape[1])
+    lib = L.load()
+    u = torch.empty((b, k, k), dtype=torch.float32, device=h.device)
+    info = torch.zeros(b, dtype=torch.int32, device=h.device)
+    ws = _workspace(lib.oq_gptq_factor_batched_workspace_bytes(k, b), h.device)
+    L.check(lib.oq_gptq_factor_batched_f32(_ptr(h), k, k * k, b, float(percdamp), int(bool(fix_dead)), _ptr(u), k * k, _ptr(info),
+                                           _ptr(ws), ws.numel(), _stream()))
+    return u, info
+
+
+def gptq_shared_factors(h: torch.Tensor, percdamp: float):
+    """`gptq_shared_factor` (no actorder) for a stack of Hessians [B, K, K]: one batched factor chain; returns the list
+    of per-input dictionaries ``gptq_quantize(..., shared=...)`` takes (views into the batched results)."""
+    u, info = gptq_factor_batched(h, percdamp, fix_dead=True)
+    dead = torch.diagonal(h, dim1=1, dim2=2) == 0
+    return [{"u": u[i], "info": info[i:i + 1], "perm": None, "dead": dead[i]} for i in range(h.shape[0])]
+
+
 def gptq_loop(w: torch.Tensor, u: torch.Tensor, qtype: str, group_size, symmetric: bool, reduce_range: bool,
               clip_ratio: float, mse: bool, block_size: int, mode: str, init_scale: torch.Tensor,
               init_zp: torch.Tensor, want_used: bool = False):

@@ -19,7 +19,7 @@ int main(void) {
     TAKE(oq_hessian_set_method); TAKE(oq_hessian_method);
     TAKE(oq_rtn_tensor_many_workspace_bytes); TAKE(oq_rtn_tensor_many_f32); TAKE(oq_pack_matmul_nbits);
     TAKE(oq_gptq_prepare_workspace_bytes); TAKE(oq_gptq_prepare_f32); TAKE(oq_gptq_factor_workspace_bytes);
-    TAKE(oq_gptq_factor_f32); TAKE(oq_gptq_loop_workspace_bytes); TAKE(oq_gptq_loop_f32);
+    TAKE(oq_gptq_factor_f32); TAKE(oq_gptq_factor_batched_workspace_bytes); TAKE(oq_gptq_factor_batched_f32); TAKE(oq_gptq_loop_workspace_bytes); TAKE(oq_gptq_loop_f32);
     TAKE(oq_hqq_workspace_bytes); TAKE(oq_hqq_optimize_f32); TAKE(oq_pack_zero_points_u4); TAKE(oq_pack_nibbles);
 
     int64_t lo = 0, hi = 0;

@@ -193,6 +193,18 @@ def test_streamed_hessian_and_gptq_equal_the_concatenated_flow():
         assert q.shape == eq.shape and s.shape == es.shape
         np.testing.assert_allclose(s.cpu().numpy(), es, rtol=1e-5)
         assert (q.cpu().numpy() != eq).mean() <= 1e-3 and (z.cpu().numpy() != ez).mean() <= 1e-3
+    # inputs of one width are factored as one batch: same results as one factor chain per input
+    hs = dict(stream.hessians)
+    hs["a1_again"] = stream.hessians["a1"]                                 # a second input of fc2's width
+    more = dict(layers, fc2b=(layers["fc2"][0] * 0.5, "a1_again"))
+    batched = D.quantize_weights_gptq(more, hs, "int4", "group", 32)
+    one_by_one = D.quantize_weights_gptq(more, hs, "int4", "group", 32, factor_batch_bytes=1)
+    assert list(batched) == list(more)
+    for name in more:
+        for a, b in zip(batched[name], one_by_one[name]):
+            assert torch.equal(a, b)
+    for a, b in zip(batched["fc2"], res["fc2"]):
+        assert torch.equal(a, b)
     with pytest.raises(KeyError, match="no Hessian accumulated"):
         D.quantize_weights_gptq({"x": (layers["fc2"][0], "nope")}, stream.hessians, "int4", "group", 32)
 

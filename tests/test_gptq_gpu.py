@@ -250,6 +250,52 @@ def test_factor_not_spd_falls_back_to_identity(ops):
     np.testing.assert_array_equal(u.cpu().numpy(), np.eye(200, dtype=np.float32))
 
 
+@pytest.mark.parametrize("k,count", [(96, 3), (200, 5), (515, 4), (1024, 3), (1536, 2)])
+def test_batched_factor_is_the_single_factor_matrix_by_matrix(ops, k, count):
+    """oq_gptq_factor_batched_f32: one chain of launches for `count` Hessians of one width.  Per matrix the operations are
+    those of oq_gptq_factor_f32, so U and info are bit-identical -- including a member that is not positive definite
+    (identity + info > 0, gptq.py:143-150) without disturbing its neighbours."""
+    import torch
+    rng = np.random.default_rng(k + count)
+    hs = []
+    for i in range(count):
+        x = rng.standard_normal((3 * k, k)).astype(np.float32) * rng.uniform(0.2, 2, size=k).astype(np.float32)
+        hs.append(((2.0 / (3 * k)) * x.T @ x).astype(np.float32))
+    hs[1] = -hs[1]                                     # not SPD
+    hb = dev(np.stack(hs))
+    ub, ib = ops.gptq_factor_batched(hb, 0.01)
+    assert ub.shape == (count, k, k) and ib.shape == (count,)
+    for i in range(count):
+        u1, i1 = ops.gptq_factor(dev(hs[i]), 0.01)
+        assert torch.equal(ub[i], u1), i
+        assert int(ib[i].cpu()) == int(i1.cpu()), i
+    assert int(ib[1].cpu()) > 0 and int(ib[0].cpu()) == 0
+    np.testing.assert_array_equal(ub[1].cpu().numpy(), np.eye(k, dtype=np.float32))
+
+
+def test_batched_shared_factors_equal_the_per_input_ones(ops):
+    """`gptq_shared_factors` (dead diagonal fixed inside the factor) against `gptq_shared_factor` per input, through a
+    whole `gptq_quantize` call, with a dead channel in one of the inputs."""
+    import torch
+    w, x = GPTQ["b_w"], GPTQ["b_x"]
+    k = w.shape[0]
+    x2 = np.array(x, copy=True)
+    x2[..., 5] = 0                                     # dead input channel
+    h_a, _ = hessian_of(ops, x)
+    h_b, _ = hessian_of(ops, x2)
+    stack = torch.stack([h_a, h_b]).contiguous()
+    batched = ops.gptq_shared_factors(stack, 0.01)
+    for h, sh in zip((h_a, h_b), batched):
+        single = ops.gptq_shared_factor(h, 0.01, False)
+        assert torch.equal(sh["u"], single["u"]) and torch.equal(sh["dead"], single["dead"])
+        assert int(sh["info"].cpu()) == int(single["info"].cpu())
+        a = ops.gptq_quantize(dev(w), h, "int4", "group", 128)
+        b = ops.gptq_quantize(dev(w), h, "int4", "group", 128, shared=sh)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert bool(batched[1]["dead"][5]) and not bool(batched[0]["dead"][5])
+    assert int(batched[1]["dead"].sum()) == int(batched[0]["dead"].sum()) + 1      # the fixture has dead channels of its own
+
+
 @pytest.mark.parametrize("case", GPTQ_CASES, ids=[c["id"] for c in GPTQ_CASES])
 def test_gptq_parity_mode_vs_golden(ops, case):
     cid, d = case["id"], case["data"]
