@@ -34,6 +34,14 @@
 
 #include <type_traits>
 
+#ifndef OQ_SYRK_F16_STRIDE
+#define OQ_SYRK_F16_STRIDE 3   /* measured on K = 11008: stride 5 21.7, 4 21.4, 3 21.1, 2 21.1, 1 21.3 ms per 65 536 rows */
+#endif
+#define OQ_SYRK_F16_STRIDE_EXPR (F16 ? OQ_SYRK_F16_STRIDE : 4)
+#ifndef OQ_SYRK_F16_DEEP
+#define OQ_SYRK_F16_DEEP 1
+#endif
+
 namespace oq {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,13 +50,22 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kST = 256;                          // block tile edge
-constexpr int kSK = 16;                           // rows of X per stage = k of one MFMA
 constexpr int kSThreads = 512;
-constexpr int kPlaneBytes = 2 * kST * 16;         // [t-chunk][position] x 16 B
-// PIECES = 3 (bf16: hi | mid | lo) or 2 (fp16: hi | lo)
-constexpr int operand_bytes(int pieces) { return pieces * kPlaneBytes; }
-constexpr int stage_bytes_of(int pieces) { return 2 * operand_bytes(pieces); }     // A | B
-constexpr int syrk_lds_bytes(int pieces) { return 3 * stage_bytes_of(pieces); }    // ring of three stages: 147 456 / 98 304 B
+// Geometry of a stage by piece kind.  bf16: three pieces, 16 rows (two 8-row chunks = the k of one MFMA) per stage, ring of
+// three stages = 144 KB.  fp16: two pieces and half the MFMAs per row, so a stage holds 32 rows (four chunks, two MFMA
+// k-steps) to keep 48 MFMAs per wave between two barriers, and the ring has two stages = 128 KB.
+template <int TERMS> struct StageGeom {
+    static constexpr bool F16 = TERMS == 3;
+    static constexpr int PIECES = F16 ? 2 : 3;
+    static constexpr int CH = (F16 && OQ_SYRK_F16_DEEP) ? 4 : 2;                     // 8-row chunks per stage
+    static constexpr int RING = (F16 && OQ_SYRK_F16_DEEP) ? 2 : 3;
+    static constexpr int ROWS = 8 * CH;
+    static constexpr int PLANE = CH * kST * 16;                // one piece of one operand: [chunk][256 columns] x 16 B
+    static constexpr int OPERAND = PIECES * PLANE;
+    static constexpr int STAGE = 2 * OPERAND;                  // A | B
+    static constexpr int LDS = RING * STAGE;
+    static constexpr int NDMA = STAGE / 1024 / 8;              // 1 KB pieces of a stage per wave: 6 (bf16) / 8 (fp16)
+};
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
@@ -199,10 +216,10 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
                                                                 const float alpha_in, const float beta, float* __restrict__ C,
                                                                 float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
                                                                 const float* __restrict__ post_scale) {
-    constexpr bool F16 = TERMS == 3;
-    constexpr int PIECES = F16 ? 2 : 3;
-    constexpr int NDMA = 8 * 2 * PIECES / 8;          // 1 KB pieces of a stage per wave: 6 (bf16) / 4 (fp16)
-    constexpr int kOperandBytes = operand_bytes(PIECES), kStageBytes = stage_bytes_of(PIECES);
+    using G = StageGeom<TERMS>;
+    constexpr bool F16 = G::F16;
+    constexpr int PIECES = G::PIECES, CH = G::CH, RING = G::RING, NDMA = G::NDMA;
+    constexpr int kPlaneBytes = G::PLANE, kOperandBytes = G::OPERAND, kStageBytes = G::STAGE;
     using frag = std::conditional_t<F16, f16x8, bf16x8>;
     const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;      // fp16 pieces: 1 / s^2, a power of two
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -217,29 +234,29 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
     const int wm = wave >> 1, wn = wave & 1;
     const int kc = lane >> 5, cl = lane & 31;
 
-    // ---- loader role: pieces q = NDMA wave .. NDMA wave + NDMA - 1 of the 48 / 32 KB stage; piece q = 1 KB =
+    // ---- loader role: pieces q = NDMA wave .. NDMA wave + NDMA - 1 of the stage; piece q = 1 KB =
     // (operand, piece, chunk, quarter of 64 columns) in LDS order [operand][piece][chunk][256 columns]
-    // bounds are the bf16 maxima, not NDMA / PIECES: a dependent-size array captured by a lambda silently invalidates the host
-    // side of this kernel (clang 22, HIP: no stub is emitted and the library does not load)
-    const char* gsrc[6];
-    uint32_t ldst[6];
+    // bounds are the maxima over both piece kinds, not NDMA / PIECES: a dependent-size array captured by a lambda silently
+    // invalidates the host side of this kernel (clang 22, HIP: no stub is emitted and the library does not load)
+    const char* gsrc[8];
+    uint32_t ldst[8];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
         const int q = wave * NDMA + i;
-        const int quarter = q & 3, cc = (q >> 2) & 1, pc = (q >> 3) % PIECES, op = q / (8 * PIECES);
+        const int quarter = q & 3, cc = (q >> 2) % CH, pc = (q / (4 * CH)) % PIECES, op = q / (4 * CH * PIECES);
         ldst[i] = static_cast<uint32_t>(q) * 1024u;
         const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
-        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * 2 + cc) * PIECES + pc) * Kp + colq);
+        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * CH + cc) * PIECES + pc) * Kp + colq);
     }
-    const int64_t stage_bytes = 2 * PIECES * Kp * 16;
+    const int64_t stage_bytes = static_cast<int64_t>(CH) * PIECES * Kp * 16;
     auto stage_dma = [&](int64_t s_rel, int slot3, int i) {
         __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes,
                                          (__attribute__((address_space(3))) void*)(lds + slot3 * kStageBytes + ldst[i]), 16, 0, 0);
     };
 
-    // prologue: stages 0 and 1 (clamped to the last stage of the slice when the slice is shorter: harmless re-reads)
+    // prologue: the first RING - 1 stages (clamped to the last stage of the slice when the slice is shorter: harmless re-reads)
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < RING - 1; ++st)
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) stage_dma(st < nstages ? st : nstages - 1, st, i);
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) expcnt(0) lgkmcnt(0)
@@ -253,24 +270,26 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    constexpr int kSlots = 8 * TERMS;
-    static_assert(kSlots >= 2 + NDMA * 4, "the DMAs must fit into the stream");
+    constexpr int kSlots = 8 * TERMS * (CH / 2);
+    static_assert(kSlots >= 2 + (NDMA - 1) * (OQ_SYRK_F16_STRIDE_EXPR) + 1, "the DMAs must fit into the stream");
     const uint32_t rd_a = static_cast<uint32_t>((kc * kST + wm * 64 + cl) * 16);
     const uint32_t rd_b = static_cast<uint32_t>(kOperandBytes + (kc * kST + wn * 128 + cl) * 16);
+    constexpr int kStepBytes = 2 * kST * 16;            // the two chunks of one MFMA k-step
     frag a[2][3], b[2][3];
-    auto read_a = [&](int slot3, int i) {
+    auto read_a = [&](int slot3, int h, int i) {
 #pragma unroll
-        for (int p = PIECES - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const frag*>(lds + slot3 * kStageBytes + rd_a + p * kPlaneBytes + i * 32 * 16);
+        for (int p = PIECES - 1; p >= 0; --p)
+            a[i][p] = *reinterpret_cast<const frag*>(lds + slot3 * kStageBytes + rd_a + p * kPlaneBytes + h * kStepBytes + i * 32 * 16);
     };
-    auto read_b = [&](int slot3, int j, int which) {
+    auto read_b = [&](int slot3, int h, int j, int which) {
 #pragma unroll
-        for (int p = 0; p < PIECES; ++p) b[which][p] = *reinterpret_cast<const frag*>(lds + slot3 * kStageBytes + rd_b + p * kPlaneBytes + j * 32 * 16);
+        for (int p = 0; p < PIECES; ++p)
+            b[which][p] = *reinterpret_cast<const frag*>(lds + slot3 * kStageBytes + rd_b + p * kPlaneBytes + h * kStepBytes + j * 32 * 16);
     };
     auto stage_body = [&](auto phase_tag, int64_t s, int cur3, int nxt3, int wr3) {
-        constexpr int STRIDE = 4;                                        // one DMA every fourth MFMA
-        constexpr int DMA0 = decltype(phase_tag)::value ? 2 : 0;         // first slot of this wave's six DMAs
-        read_a(cur3, 1);                                       // a[0], b[0] came with the previous stage
-        const int64_t s_dma = s + 2 < nstages ? s + 2 : nstages - 1;   // behind the slice: re-read its last stage into a slot nobody reads
+        constexpr int STRIDE = OQ_SYRK_F16_STRIDE_EXPR;                  // one DMA every fourth MFMA
+        constexpr int DMA0 = decltype(phase_tag)::value ? 2 : 0;         // first slot of this wave's DMAs
+        const int64_t s_dma = s + RING - 1 < nstages ? s + RING - 1 : nstages - 1;   // behind the slice: re-read its last stage into a slot nobody reads
         int slot = 0;
         auto mm = [&](const frag& x, const frag& y, f32x16& c) {
             __builtin_amdgcn_sched_barrier(0);
@@ -281,51 +300,67 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
         };
         using seq = TermSeq<TERMS>;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cur = j & 1;
+        for (int h = 0; h < CH / 2; ++h) {
+            constexpr bool kLookAhead = RING >= 3;        // stage s + 1 landed before the last barrier only with a ring of three
+            const bool last_step = h == CH / 2 - 1;
+            read_a(cur3, h, 1);                           // a[0], b[0] came with the previous k-step
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f32x16 c = acc[i][j];
+            for (int j = 0; j < 4; ++j) {
+                const int cur = j & 1;
 #pragma unroll
-                for (int t = 0; t < TERMS; ++t) {
-                    if (t == seq::PF && i == 0) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (j < 3) read_b(cur3, j + 1, cur ^ 1);
-                        else read_b(nxt3, 0, 0);
+                for (int i = 0; i < 2; ++i) {
+                    f32x16 c = acc[i][j];
+#pragma unroll
+                    for (int t = 0; t < TERMS; ++t) {
+                        if (t == seq::PF && i == 0) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (j < 3) read_b(cur3, h, j + 1, cur ^ 1);
+                            else if (!last_step) read_b(cur3, h + 1, 0, 0);
+                            else if (kLookAhead) read_b(nxt3, 0, 0, 0);
+                        }
+                        mm(a[i][seq::A[t]], b[cur][seq::B[t]], c);
                     }
-                    mm(a[i][seq::A[t]], b[cur][seq::B[t]], c);
-                }
-                acc[i][j] = c;
-                if (i == 0 && j == 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    read_a(nxt3, 0);
+                    acc[i][j] = c;
+                    if (i == 0 && j == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!last_step) read_a(cur3, h + 1, 0);
+                        else if (kLookAhead) read_a(nxt3, 0, 0);
+                    }
                 }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    read_b(0, 0, 0);
-    read_a(0, 0);
-    int cur3 = 0, nxt3 = 1, wr3 = 2;
+    read_b(0, 0, 0, 0);
+    read_a(0, 0, 0);
+    int cur3 = 0, nxt3 = RING >= 3 ? 1 : 1, wr3 = RING - 1;
     // Neighbouring waves (the two of a SIMD, and neighbouring SIMDs) run the same stream with their DMAs two slots apart,
     // so that they do not all pay the issue cost of a global_load_lds -- M0, address, ~100 cycles on a busy CU -- in the
     // same MFMA gap (measured: all in slots 0-5 199, half a stage apart 213-219, one every fourth slot and two slots
     // apart 225 TFLOP/s fp32-equivalent, K = 11008).  Two copies of the loop: a branch inside it would cost the
     // accumulators their registers.
+    auto rotate = [&]() {
+        if (RING >= 3) { const int t3 = cur3; cur3 = nxt3; nxt3 = wr3; wr3 = t3; }
+        else {           // ring of two: the stage just filled becomes current, and its first operands are fetched now
+            const int t3 = cur3; cur3 = wr3; nxt3 = t3; wr3 = t3;
+            read_b(cur3, 0, 0, 0);
+            read_a(cur3, 0, 0);
+        }
+    };
     const int phase = __builtin_amdgcn_readfirstlane((wave >> 2) ^ (wave & 1));
     if (phase) {
         for (int64_t s = 0; s < nstages; ++s) {
             stage_body(std::true_type{}, s, cur3, nxt3, wr3);
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_s_barrier();
-            const int t3 = cur3; cur3 = nxt3; nxt3 = wr3; wr3 = t3;
+            rotate();
         }
     } else {
         for (int64_t s = 0; s < nstages; ++s) {
             stage_body(std::false_type{}, s, cur3, nxt3, wr3);
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_s_barrier();
-            const int t3 = cur3; cur3 = nxt3; nxt3 = wr3; wr3 = t3;
+            rotate();
         }
     }
 
@@ -360,11 +395,14 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
 constexpr int kAbsmaxBlocks = 2048;
 constexpr size_t kScaleHeaderBytes = 16384;   // fp16 pieces: [scale, 1 / scale^2, -, -] + the absmax partials, in front of P
 static int64_t padded_k(int64_t K) { return ceil_div(K, kST) * kST; }
-static int64_t stages_of(int64_t T) { return ceil_div(T, kSK); }
+static int64_t stages_of(int64_t T, int rows) { return ceil_div(T, rows); }
 
 size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K) {
     if (T <= 0 || K <= 0) return 0;
-    return static_cast<size_t>(stages_of(T)) * 2 * 3 * padded_k(K) * 16 + kScaleHeaderBytes;   // three bf16 pieces, or the header + two fp16 pieces
+    // room for either kind: three bf16 pieces of 16-row stages, or the scale header + two fp16 pieces of 32-row stages
+    const size_t b16 = static_cast<size_t>(stages_of(T, StageGeom<6>::ROWS)) * StageGeom<6>::CH * StageGeom<6>::PIECES;
+    const size_t f16 = static_cast<size_t>(stages_of(T, StageGeom<3>::ROWS)) * StageGeom<3>::CH * StageGeom<3>::PIECES;
+    return (b16 > f16 ? b16 : f16) * padded_k(K) * 16 + kScaleHeaderBytes;
 }
 
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, void* workspace,
@@ -385,10 +423,11 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     // per launch, not once: the attribute belongs to the current device's copy of the kernel
     const void* kfn = terms == 9 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<9>)
                                  : (terms == 6 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<6>) : reinterpret_cast<const void*>(&syrk_pieces_kernel<3>));
-    const int lds_bytes = syrk_lds_bytes(f16 ? 2 : 3);
+    const int lds_bytes = f16 ? StageGeom<3>::LDS : StageGeom<6>::LDS;
+    const int stage_rows = f16 ? StageGeom<3>::ROWS : StageGeom<6>::ROWS, stage_chunks = stage_rows / 8;
     hipError_t e1 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", lds_bytes);
-    const int64_t Kp = padded_k(K), nstages = stages_of(T), nchunks = nstages * 2;
+    const int64_t Kp = padded_k(K), nstages = stages_of(T, stage_rows), nchunks = nstages * stage_chunks;
     OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "syrk_bf16x3: at most 2 097 120 rows per call, %lld given", (long long)T);
     int32_t st;
     if (f16) {
@@ -411,7 +450,8 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     // permitting) whose block count fills whole rounds of 256 best; ties go to fewer slices.
     int splits = 1;
     {
-        const int64_t by_rows = nstages / 32 > 0 ? nstages / 32 : 1;
+        const int64_t min_stages = 512 / stage_rows;                 // slices of >= 512 rows
+        const int64_t by_rows = nstages / min_stages > 0 ? nstages / min_stages : 1;
         int64_t cap = by_rows < 16 ? by_rows : 16;
         while (cap > 1 && static_cast<size_t>(cap) * K * K * sizeof(float) > slab_bytes) --cap;
         double best = -1.0;
