@@ -503,8 +503,9 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
         const ColQ c = make_colq(qparam_from_minmax(mnj, mxj, a.grid), mnj, mxj, bias);
         own_scale = c.scale;
         if (h < 4) s_scale[wave][j * LPR + cl] = c.scale;      // for the fallback: slot i of strip column cl at [i * LPR + cl]
-        if (h < 4 && col_ok) {   // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
-            const idx_t o = (c0 + j) * kgroups_i + kg_i;
+        if (h < 4 && col_ok && !(a.nt & 8)) {   // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j  [nt bit 3: attribution runs only]
+            idx_t o = (c0 + j) * kgroups_i + kg_i;
+            if (a.nt & 32) o = static_cast<idx_t>((kg * (a.N / (4 * LPR)) + strip0 / (4 * LPR)) * (4 * LPR) + lane);   // attribution runs only: wave-contiguous (wrong) layout
             a.scale[o] = c.scale;
             a.zp[o] = static_cast<uint8_t>(static_cast<int32_t>(c.zpb) - bias);
         }
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[r][i] = f[i];
         }
-        if (!col_ok) return;
+        if (!col_ok || (a.nt & 16)) return;   // nt bit 4: attribution runs only
         // qrules/_common.py:72-87: out-channel n, k-group kg -> G * bits / 8 bytes, k ascending, even k in the low nibble.
         // v[r][i] holds M + level: the level is byte 0 of its bits (the other three bytes are those of M).
         auto low_bytes = [](uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {   // [b0.0, b1.0, b2.0, b3.0]
@@ -616,6 +617,8 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
                     words[wd] = low_bytes(pr[0], pr[1], pr[2], pr[3]) ^ flip;
                 }
                 u32x2* o = reinterpret_cast<u32x2*>(a.q + (((c0 + i) * kgroups_i + kg_i) * (G / 2) + h * 8));
+                if (a.nt & 32)   // attribution runs only: every store instruction writes 512 contiguous bytes (wrong layout)
+                    o = reinterpret_cast<u32x2*>(a.q + ((kg * (a.N / (4 * LPR)) + strip0 / (4 * LPR)) * (2 * G * LPR) + i * 512 + lane * 8));
                 const u32x2 t = {words[0], words[1]};
                 if (a.nt & 2) __builtin_nontemporal_store(t, o);
                 else *o = t;
