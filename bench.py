@@ -95,18 +95,24 @@ def init_ranks(gpus: int, backend: str = "nccl"):
     if world != gpus:
         raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {gpus}` (it spawns the ranks) or "
                          f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {gpus} --master-addr 127.0.0.1 bench.py --gpus {gpus}`")
+    # OQ_BENCH_REHEARSAL=1: the N-rank flow on ONE GPU (ranks share cuda:0, collectives on gloo with host staging): a way to
+    # execute the multi-rank code path -- plans, sharded GPTQ, the gather, max-over-ranks -- on a 1-GPU box.  Its line says so;
+    # it is not a scaling measurement.
+    rehearsal = backend == "nccl" and os.environ.get("OQ_BENCH_REHEARSAL", "0") == "1"
     if backend == "gloo":                       # CPU plumbing test only (tests/test_bench_launch.py)
         dev = torch.device("cpu")
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        if rehearsal:
+            local_rank = local_rank % torch.cuda.device_count()
         if torch.cuda.device_count() <= local_rank:
             raise SystemExit(f"rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "gloo":
+        if backend == "gloo" or rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
@@ -453,9 +459,10 @@ def main() -> None:
         tg = torch.tensor([time.perf_counter() - tg], dtype=torch.float64, device=dev)
         dist.all_reduce(tg, op=dist.ReduceOp.MAX)
         gather = {"collective": "one padded gather to rank 0 (RCCL over xGMI, backend nccl) + a size all_reduce",
+                  "backend": dist.get_backend(),
                   "gather_s": round(float(tg[0]), 5), "gather_bytes": int(nbytes), "ranks_seen": int(ranks_seen.item()),
                   "GBs_into_rank0": round(nbytes * (world - 1) / world / float(tg[0]) / 1e9, 1),
-                  "rank0_result_intact": None if got is None else bool(torch.equal(got["rank0.w"][0], q))}
+                  "rank0_result_intact": None if got is None else bool(torch.equal(got["rank0.w"][0].to(q.device), q))}
 
     # ---- verify rank 0's last outputs against the reference digests (asymmetric / symmetric KAT2)
     verified = None
@@ -540,6 +547,8 @@ def main() -> None:
         "gather": gather,
         "gptq": gptq,
     }
+    if os.environ.get("OQ_BENCH_REHEARSAL", "0") == "1":
+        result["rehearsal"] = "ranks share one GPU, collectives on gloo: the multi-rank code path executed, NOT a scaling measurement"
     if world == 1 and not args.no_cpu_baseline:
         base, (cq, cs, cz) = cpu_baseline(w_host)
         base["digest_ok"] = bool(sha16(cq) == digests["config2_asym"]["q_sha"] and sha16(cs) == digests["config2_asym"]["s_sha"])

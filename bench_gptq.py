@@ -261,9 +261,14 @@ def run(args, dev, rank: int, world: int):
         rq, rs, rz = ops.rtn_quantize(w, "int4", "group", 128)
         same_q = bool(torch.equal(packed, ops.pack_nibbles(rq)))
         same_z = bool(torch.equal(results[i][2].reshape(-1), rz.reshape(-1)))
-        rel = float(((results[i][1].reshape(-1) - rs.reshape(-1)).abs() / rs.reshape(-1)).max())
+        # gptq.py:219-231 re-derives the parameters from the DEQUANTIZED integers: a group whose integers do not reach both
+        # ends of the grid (x / s landing exactly on a tie can leave level 15 unused: a handful of the 352 256 groups of a
+        # matrix) gets scale * span / 15.  That, not RTN's scale itself, is what the emitted scale is held to.
+        span = (rq.reshape(k // 128, 128, n).amax(dim=1).to(torch.float32) - rq.reshape(k // 128, 128, n).amin(dim=1).to(torch.float32))
+        expect = rs.reshape(-1) * (span.t().reshape(-1) / 15.0)
+        rel = float(((results[i][1].reshape(-1) - expect).abs() / expect).max())
         verify["shapes"].append({"k": k, "n": n, "layer": specs[i].name, "integers_equal_rtn": same_q, "zero_points_equal_rtn": same_z,
-                                 "scale_max_rel_diff_vs_rtn": rel})
+                                 "scale_max_rel_diff_vs_rtn": rel, "groups_not_spanning_the_grid": int((span < 15).sum())})
         if args.mode == "parity":
             ok = ok and same_q and rel <= 1e-5
     if rank == 0 and args.mode == "parity" and args.hidden == 4096:
@@ -281,6 +286,9 @@ def run(args, dev, rank: int, world: int):
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        by_rank = [None] * world
+        dist.all_gather_object(by_rank, {"rank": rank, "ok": bool(ok), "shapes": verify["shapes"]})
+        verify["by_rank"] = by_rank                                  # every rank checks the first layer of each shape it owns
     verify["verified"] = bool(int(flag.item())) if args.mode == "parity" else None
 
     # the Hessian kernel that just ran against float64 (a 256-column strip of one input)

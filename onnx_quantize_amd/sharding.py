@@ -174,6 +174,10 @@ def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], min
     recv = [torch.empty(max(cap, 1), dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
     metas = [None] * world
     dist.all_gather_object(metas, meta, group=group)
+    if dist.get_backend(group) != "nccl" and send.is_cuda:
+        # gloo has no gather for device tensors (tests and the one-GPU rehearsal of bench.py): stage through the host
+        send = send.cpu()
+        recv = [torch.empty(max(cap, 1), dtype=torch.uint8) for _ in range(world)] if rank == 0 else None
     dist.gather(send, recv, dst=0, group=group)
     total = int(sizes.sum().item())
     if rank != 0:

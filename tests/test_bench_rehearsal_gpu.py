@@ -1,0 +1,31 @@
+"""The multi-rank flow of bench.py executed for real on ONE GPU (`OQ_BENCH_REHEARSAL=1`: ranks share cuda:0, collectives on
+gloo with host staging): LPT plans, the sharded GPTQ run with batched factors, the end-of-run gather, max-over-ranks timing,
+every rank verifying its own first layers.  Not a scaling measurement -- the scaling bench is the driver's, on 8 GPUs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_runs_the_multi_rank_path_on_one_gpu(ranks):
+    env = dict(os.environ, OQ_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29650 + ranks))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
+                        "--gptq-layers", "3"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == ranks and "rehearsal" in line
+    assert line["verified_vs_reference_digest"] is True
+    g = line["gather"]
+    assert g["ranks_seen"] == ranks and g["rank0_result_intact"] is True and g["gather_bytes"] > 0
+    q = line["gptq"]
+    assert q["n_gpus"] == ranks and q["ranks_seen"] == ranks
+    assert q["verified"] is True, q["verification"]
+    assert sorted(b["rank"] for b in q["verification"]["by_rank"]) == list(range(ranks))
+    assert all(b["ok"] for b in q["verification"]["by_rank"])
+    assert q["gather_bytes"] > 0 and q["cpu_baseline" if "cpu_baseline" in q else "value"] is not None
