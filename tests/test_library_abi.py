@@ -81,6 +81,20 @@ def test_host_only_entry_points(lib_path):
     st = lib.oq_rtn_quantize_f32(None, 4, 4, 4, 0, 0, -1, 0, 0, 1.0, 0, None, None, None, 0, None, 0, None)
     assert st == -1 and b"null pointer" in lib.oq_last_error()
     assert lib.oq_rtn_workspace_bytes(4096, 11008, _lib.OQ_GROUP, 128, 0) > 0
+    # the batched factor: workspace grows linearly with the batch, bad batches are refused before any launch
+    one, four = lib.oq_gptq_factor_workspace_bytes(4096), lib.oq_gptq_factor_batched_workspace_bytes(4096, 4)
+    assert lib.oq_gptq_factor_batched_workspace_bytes(4096, 1) == one and four - 256 == 4 * (one - 256)
+    assert lib.oq_gptq_factor_batched_workspace_bytes(4096, 0) == 0
+    import ctypes as C
+    dummy = (C.c_float * 4)()
+    info = (C.c_int32 * 4)()
+    for count, stride, needle in ((0, 16, b"bad argument"), (70000, 16, b"bad argument"), (2, 8, b"overlap")):
+        st = lib.oq_gptq_factor_batched_f32(dummy, 4, stride, count, 0.01, 0, dummy, stride, info, dummy, 16, None)
+        assert st == -1 and needle in lib.oq_last_error(), (count, stride, lib.oq_last_error())
+    st = lib.oq_gptq_factor_batched_f32(dummy, 4, 16, 2, 0.01, 0, dummy, 16, info, dummy, 16, None)
+    assert st == -3 and b"workspace" in lib.oq_last_error()
+    assert lib.oq_hessian_set_method(5) == -1 and lib.oq_hessian_set_method(4) == 0 and lib.oq_hessian_method() == 4
+    assert lib.oq_hessian_set_method(0) == 0
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):
