@@ -335,7 +335,8 @@ def run(args, dev, rank: int, world: int):
             fp32_equiv = 2.0 * t_rows * (tiles * (tiles + 1) // 2) * edge * edge          # upper tiles, as executed
             terms = {"bf16x9": 9, "bf16x6": 6}.get(method, 3)           # "auto" is the fp16-piece kernel for K >= 1024
             roof = {"bound": "mfma", "method": method,
-                    "kernel": "oq::syrk_pieces_kernel<%d> (+ split / reduce)" % terms if split else "oq::gemm_tn_kernel",
+                    "kernel": (("oq::syrk_f16_m16_kernel" if terms == 3 and os.environ.get("OQ_SYRK_F16_M16", "1") != "0"
+                                else "oq::syrk_pieces_kernel<%d>" % terms) + " (+ split / reduce)") if split else "oq::gemm_tn_kernel",
                     "achieved": round(fp32_equiv * (terms if split else 1) / ms / 1e9, 1), "peak": 2500.0 if split else 157.3,
                     "unit": "TFLOP/s",
                     "dtype": ("%s pieces of fp32 operands, fp32 accumulate" % ("fp16" if terms == 3 else "bf16")) if split else "f32",

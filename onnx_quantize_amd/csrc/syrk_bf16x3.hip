@@ -38,6 +38,9 @@
 #define OQ_SYRK_F16_STRIDE 3   /* measured on K = 11008: stride 5 21.7, 4 21.4, 3 21.1, 2 21.1, 1 21.3 ms per 65 536 rows */
 #endif
 #define OQ_SYRK_F16_STRIDE_EXPR (F16 ? OQ_SYRK_F16_STRIDE : 4)
+#ifndef OQ_SYRK_M16_STRIDE
+#define OQ_SYRK_M16_STRIDE 4   /* K = 11008, ms per 65 536 rows: stride 2 19.0-19.2, 4 18.83, 6 18.9, 8 18.9-19.0, 10 19.2-19.3 */
+#endif
 #ifndef OQ_SYRK_F16_DEEP
 #define OQ_SYRK_F16_DEEP 1
 #endif
@@ -392,6 +395,151 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
         }
 }
 
+// ---- 2b. The fp16-piece GEMM on v_mfma_f32_16x16x32_f16 (experiment: OQ_SYRK_F16_M16=1).  Same block tile, stage geometry
+// (32 rows = four 8-row chunks = ONE k-step of this instruction), ring of two and LDS-DMA staging as syrk_pieces_kernel<3>;
+// a wave's 64 x 128 tile is 4 x 8 tiles of 16 x 16.  Lane l supplies rows / columns i = l & 15 and the eight k-values of
+// chunk l >> 4 -- the same 16-byte vector P holds.  C/D map: col = l & 15, row = 4 (l >> 4) + e, e = 0..3.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
+                                                                 const float alpha_in, const float beta, float* __restrict__ C,
+                                                                 float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
+                                                                 const float* __restrict__ post_scale) {
+    using G = StageGeom<3>;
+    static_assert(G::CH == 4 && G::RING == 2, "one 32-deep k-step per stage");
+    constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
+    constexpr int kPlaneBytes = G::PLANE, kOperandBytes = G::OPERAND, kStageBytes = G::STAGE;
+    const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int tile_m, tile_n;
+    upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles, tile_m, tile_n);
+    const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
+    const int64_t s_begin = static_cast<int64_t>(blockIdx.y) * stages_per_slice;
+    const int64_t s_end = s_begin + stages_per_slice < nstages_all ? s_begin + stages_per_slice : nstages_all;
+    const int64_t nstages = s_end - s_begin;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = lane >> 4, cl = lane & 15;
+
+    const char* gsrc[8];
+    uint32_t ldst[8];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int q = wave * NDMA + i;
+        const int quarter = q & 3, cc = (q >> 2) % CH, pc = (q / (4 * CH)) % PIECES, op = q / (4 * CH * PIECES);
+        ldst[i] = static_cast<uint32_t>(q) * 1024u;
+        const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
+        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * CH + cc) * PIECES + pc) * Kp + colq);
+    }
+    const int64_t stage_bytes = static_cast<int64_t>(CH) * PIECES * Kp * 16;
+    auto stage_dma = [&](int64_t s_rel, int slot, int i) {
+        __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes,
+                                         (__attribute__((address_space(3))) void*)(lds + slot * kStageBytes + ldst[i]), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) stage_dma(0, 0, i);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_barrier();
+
+    f32x4v acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const uint32_t rd_a = static_cast<uint32_t>((kc * kST + wm * 64 + cl) * 16);
+    const uint32_t rd_b = static_cast<uint32_t>(kOperandBytes + (kc * kST + wn * 128 + cl) * 16);
+    f16x8 a[4][2], b[2][2];
+    auto read_a = [&](int slot, int i) {
+#pragma unroll
+        for (int p = PIECES - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_a + p * kPlaneBytes + i * 16 * 16);
+    };
+    auto read_b = [&](int slot, int j, int which) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p) b[which][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_b + p * kPlaneBytes + j * 16 * 16);
+    };
+    auto stage_body = [&](auto phase_tag, int64_t s, int cur, int wr) {
+        constexpr int STRIDE = OQ_SYRK_M16_STRIDE;                       // in 16-cycle MFMA slots
+        constexpr int DMA0 = decltype(phase_tag)::value ? 4 : 0;
+        const int64_t s_dma = s + 1 < nstages ? s + 1 : nstages - 1;
+        int slot = 0;
+        auto mm = [&](const f16x8& x, const f16x8& y, f32x4v& c) {
+            __builtin_amdgcn_sched_barrier(0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (slot >= DMA0 && slot < DMA0 + NDMA * STRIDE && (slot - DMA0) % STRIDE == 0) stage_dma(s_dma, wr, (slot - DMA0) / STRIDE);
+            ++slot;
+        };
+        read_a(cur, 1); read_a(cur, 2); read_a(cur, 3);      // a[0], b[0] were fetched right behind the barrier
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cb = j & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4v c = acc[i][j];
+                if (i == 1 && j < 7) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_b(cur, j + 1, cb ^ 1);
+                }
+                mm(a[i][1], b[cb][0], c);     // lo . hi
+                mm(a[i][0], b[cb][1], c);     // hi . lo
+                mm(a[i][0], b[cb][0], c);     // hi . hi
+                acc[i][j] = c;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    read_b(0, 0, 0);
+    read_a(0, 0);
+    int cur = 0, wr = 1;
+    const int phase = __builtin_amdgcn_readfirstlane((wave >> 2) ^ (wave & 1));
+    if (phase) {
+        for (int64_t s = 0; s < nstages; ++s) {
+            stage_body(std::true_type{}, s, cur, wr);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_barrier();
+            const int t = cur; cur = wr; wr = t;
+            read_b(cur, 0, 0);
+            read_a(cur, 0);
+        }
+    } else {
+        for (int64_t s = 0; s < nstages; ++s) {
+            stage_body(std::false_type{}, s, cur, wr);
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_barrier();
+            const int t = cur; cur = wr; wr = t;
+            read_b(cur, 0, 0);
+            read_a(cur, 0);
+        }
+    }
+
+    float* out = slab ? slab + static_cast<int64_t>(blockIdx.y) * K * K : C;
+    const bool direct = slab == nullptr;
+    const bool diag = tile_m == tile_n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t colj = n0 + wn * 128 + j * 16 + cl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = m0 + wm * 64 + i * 16 + 4 * kc + e;
+                if (row < K && colj < K) {
+                    float val = acc[i][j][e];
+                    if (direct) {
+                        if (diag && colj < row) continue;
+                        val = alpha * val;
+                        if (beta != 0.0f) val = beta * out[row * K + colj] + val;
+                        if (colj != row) out[colj * K + row] = val;
+                    }
+                    out[row * K + colj] = val;
+                }
+            }
+        }
+}
+
 constexpr int kAbsmaxBlocks = 2048;
 constexpr size_t kScaleHeaderBytes = 16384;   // fp16 pieces: [scale, 1 / scale^2, -, -] + the absmax partials, in front of P
 static int64_t padded_k(int64_t K) { return ceil_div(K, kST) * kST; }
@@ -421,7 +569,9 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     float* slab = reinterpret_cast<float*>(base + pieces);
     const size_t slab_bytes = workspace_bytes - pieces - 256;
     // per launch, not once: the attribute belongs to the current device's copy of the kernel
-    const void* kfn = terms == 9 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<9>)
+    static const bool f16_m16_env = [] { const char* v = getenv("OQ_SYRK_F16_M16"); return !v || atoi(v) != 0; }();   // default on; 0: the 32x32x16 form
+    const bool f16_m16 = f16 && f16_m16_env;
+    const void* kfn = f16_m16 ? reinterpret_cast<const void*>(&syrk_f16_m16_kernel) : terms == 9 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<9>)
                                  : (terms == 6 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<6>) : reinterpret_cast<const void*>(&syrk_pieces_kernel<3>));
     const int lds_bytes = f16 ? StageGeom<3>::LDS : StageGeom<6>::LDS;
     const int stage_rows = f16 ? StageGeom<3>::ROWS : StageGeom<6>::ROWS, stage_chunks = stage_rows / 8;
@@ -470,6 +620,9 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
         hipLaunchKernelGGL(syrk_pieces_kernel<9>, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn, no_scale);
     else if (terms == 6)
         hipLaunchKernelGGL(syrk_pieces_kernel<6>, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn, no_scale);
+    else if (f16_m16)
+        hipLaunchKernelGGL(syrk_f16_m16_kernel, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn,
+                           static_cast<const float*>(scale));
     else
         hipLaunchKernelGGL(syrk_pieces_kernel<3>, grid, dim3(kSThreads), lds_bytes, s, P, K, Kp, nstages, alpha, beta, C, slab_f, per, tn,
                            static_cast<const float*>(scale));
