@@ -217,7 +217,7 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *                          [2^14, 2^15)): x = hi + lo to 22 bits (fewer below 2^-17 max |x|, where fp16 runs out of
  *                          exponent; a sample whose fp32 square is still positive never vanishes entirely, so a channel
  *                          is dead here exactly when it is dead for gptq.py:284), products hi.hi + hi.lo + lo.hi on
- *                          v_mfma_f32_32x32x16_f16, 2 / (n s^2) applied to the sum: half the matrix-core work of
+ *                          v_mfma_f32_16x16x32_f16, 2 / (n s^2) applied to the sum: half the matrix-core work of
  *                          BF16X6, measured error against float64 not larger (8e-7 vs 2e-6 of max |H|, K = 11008);
  *       OQ_HESSIAN_AUTO    F16X3 for K >= 1024 (its block tile is 256 x 256; K < 2048 also needs T >= 2048) when the
  *                          workspace holds the pieces,

@@ -23,7 +23,8 @@
 //     exactly the order P holds them, so staging is 48 global_load_lds_dwordx4 (1 KB each, 6 per wave): no staging
 //     registers, no ds_write, no VALU.  LDS is a ring of three stages (144 KB, one block per CU).
 //
-// Round 2, `terms` = 3 ("f16x3"): the same machinery on v_mfma_f32_32x32x16_f16 with TWO fp16 pieces per element,
+// Round 2, `terms` = 3 ("f16x3"): the same machinery on the fp16 matrix instructions (syrk_f16_m16_kernel, 16x16x32, by
+// default; syrk_pieces_kernel<3>, 32x32x16, with OQ_SYRK_F16_M16=0) with TWO fp16 pieces per element,
 // hi = f16(x s), lo = f16(x s - hi): 11 + 11 significand bits, i.e. operands rounded to 22 bits (relative 2^-23), and the
 // three products hi.hi, hi.lo, lo.hi (what is dropped -- lo.lo and the operand roundings -- is <= 3 * 2^-23 |x y|, the
 // size of the product roundings of an fp32 fma chain and of either sign).  HALF the matrix-core work of terms = 6.
