@@ -242,20 +242,25 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
         q, s, z = _rtn_quantize(w, a.dtype, a.strategy, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse, a.scale_dtype, a.zp_dtype)
         last = _prepare_for_matmul_nbits(q, s, z, qc)
     t_plugin = time.perf_counter() - t0
-    # device-resident seam, uploads on demand
-    mats = fresh()
-    t0 = time.perf_counter()
-    for i, w in enumerate(mats):
-        last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
-    t_demand = time.perf_counter() - t0
-    # ... and with the model's weights prefetched from the worker thread while the previous one is quantized
-    mats = fresh()
+    # device-resident seam, uploads on demand; then with the model's weights prefetched from the worker thread while the
+    # previous one is quantized.  Host-side effects (page faults and page-locking of fresh arrays, the worker thread's
+    # scheduling) make single passes scatter by a factor of two between boxes: three passes each, the median is reported
+    # and all three are listed.
     hits0 = st.stats["hits"]
-    t0 = time.perf_counter()
-    st.prefetch([(f"w{i}", w) for i, w in enumerate(mats)])
-    for i, w in enumerate(mats):
-        last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
-    t_after = time.perf_counter() - t0
+    demand_trials, after_trials = [], []
+    for _ in range(3):
+        mats = fresh()
+        t0 = time.perf_counter()
+        for i, w in enumerate(mats):
+            last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
+        demand_trials.append(time.perf_counter() - t0)
+        mats = fresh()
+        t0 = time.perf_counter()
+        st.prefetch([(f"w{i}", w) for i, w in enumerate(mats)])
+        for i, w in enumerate(mats):
+            last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
+        after_trials.append(time.perf_counter() - t0)
+    t_demand, t_after = sorted(demand_trials)[1], sorted(after_trials)[1]
     ok_after = check(*last)
     rate = lambda t: round(params / t / 1e6, 1)  # noqa: E731
     return {"what": "host->host through quantize_weights' arrays (qrules/_common.py:133-137), uint4 g128 4096x11008, "
@@ -266,9 +271,11 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
             "plugin_functions": {"route": "_rtn_quantize + _prepare_for_matmul_nbits of this round (NumPy in / NumPy out, two round trips)",
                                  "value": rate(t_plugin), "ms_per_weight": round(t_plugin * 1e3 / count, 2)},
             "after_on_demand": {"route": "seam.weight_arrays, upload per call", "value": rate(t_demand),
-                                "ms_per_weight": round(t_demand * 1e3 / count, 2)},
+                                "ms_per_weight": round(t_demand * 1e3 / count, 2),
+                                "ms_per_weight_trials": [round(t * 1e3 / count, 2) for t in demand_trials]},
             "after": {"route": "seam.weight_arrays + WeightStager.prefetch (worker thread, side stream)", "value": rate(t_after),
-                      "ms_per_weight": round(t_after * 1e3 / count, 2), "digest_ok": ok_after,
+                      "ms_per_weight": round(t_after * 1e3 / count, 2),
+                      "ms_per_weight_trials": [round(t * 1e3 / count, 2) for t in after_trials], "digest_ok": ok_after,
                       "prefetch_hits": st.stats["hits"] - hits0},
             "speedup": round(t_before / t_after, 2),
             "note": "every route is timed on fresh host arrays (memory the GPU has not mapped yet), as a model's weights are"}
