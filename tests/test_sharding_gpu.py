@@ -1,0 +1,79 @@
+"""SURVEY.md 8e (2) with the product's own kernels (sharding.HipKernels) and more than one rank: the ranks share cuda:0 and
+talk over gloo (a one-GPU box; the gather is staged through the host there), the results are compared on rank 0 with the
+UNSHARDED GPU path -- integers and parameters bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from onnx_quantize_amd import sharding as S
+    from onnx_quantize_amd.hip import ops
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, n = 1024, 352                                                  # 11 strips of 32 columns: uneven over 2 / 3 ranks
+    rng = np.random.default_rng(23)
+    w_np = rng.standard_normal((k, n)).astype(np.float32)
+    w_np[:, 330:] *= 7                                                # the global range lives on the last rank only
+    x_np = (rng.standard_normal((6, 96, k)) * rng.uniform(0.3, 3, size=k)).astype(np.float32)
+    w = torch.from_numpy(w_np).cuda()
+    ranges = S.column_ranges(n, world, 32)
+    a, b = ranges[rank]
+    w_cols = w[:, a:b].contiguous()
+    ok = []
+    for qtype, strategy, g, sym in (("uint4", "group", 128, False), ("int8", "channel", -1, True), ("uint8", "tensor", -1, False),
+                                    ("int8", "tensor", -1, True)):
+        local = S.rtn_quantize_column_shard(w_cols, qtype, strategy, g, sym, False, 0.9)
+        whole = S.gather_column_shards(local, ranges, strategy)
+        if rank == 0:
+            eq, es, ez = ops.rtn_quantize(w, qtype, strategy, g, sym, False, 0.9)
+            ok.append(torch.equal(whole[0].cuda(), eq) and torch.equal(whole[1].cuda().reshape(es.shape), es)
+                      and torch.equal(whole[2].cuda().reshape(ez.shape), ez))
+    mine = [torch.from_numpy(x_np[i:i + 1]).cuda() for i in range(rank, 6, world)]      # samples dealt round robin
+    local = S.gptq_quantize_column_shard(w_cols, mine, "int4", "group", 128)
+    whole = S.gather_column_shards(local, ranges, "group")
+    if rank == 0:
+        h = torch.zeros((k, k), device="cuda")
+        ops.hessian_accumulate(torch.from_numpy(x_np).cuda(), h, 0)
+        eq, es, ez, _ = ops.gptq_quantize(w, h, "int4", "group", 128)
+        ok.append(torch.equal(whole[0].cuda(), eq) and torch.equal(whole[2].cuda().reshape(ez.shape), ez))
+        ok.append(bool(torch.allclose(whole[1].cuda().reshape(es.shape), es, rtol=1e-6, atol=0)))
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_matrix_sharded_by_columns_on_the_gpu(world):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    res = q.get(timeout=5)
+    assert res == [True] * len(res) and len(res) == 6, res
