@@ -31,3 +31,21 @@ def test_headline_kernels_keep_their_occupancy(tmp_path):
     assert fused[0] <= 128 and fused[1] >= 4 and fused[2] == 0, fused
     for name, (vgprs, occ, spill) in report.items():
         assert spill == 0, (name, vgprs, occ, spill)                                   # no kernel of the file may spill
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_hessian_gemm_kernels_fit_two_waves_per_simd_without_spilling(tmp_path):
+    """The split-operand SYRK kernels run one 8-wave block per CU (two waves per SIMD: <= 256 registers) with all 128
+    accumulator registers live across the stage loop: a spill there would sit inside the MFMA stream."""
+    from onnx_quantize_amd import _build
+    src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "syrk_bf16x3.hip")
+    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+                        str(tmp_path / "syrk.s"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = 0
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, re.S):
+        name, vgprs, scratch, occ = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
+        if "syrk_pieces_kernel" in name or "syrk_f16_m16_kernel" in name:
+            seen += 1
+            assert vgprs <= 256 and scratch == 0 and occ >= 2, (name, vgprs, scratch, occ)
+    assert seen == 4          # three instantiations of the 32x32 form + the 16x16x32 fp16 kernel
