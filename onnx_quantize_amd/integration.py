@@ -179,8 +179,10 @@ def quantize_with_reference_pipeline(model, qconfig):
         return ref.quantize(model, ref_qconfig)
     finally:
         try:
+            from . import seam
             from .staging import default_stager
 
             default_stager().cancel()
+            seam.clear_shared_inputs()
         except Exception:  # noqa: BLE001
             pass

@@ -18,10 +18,11 @@ names); an algorithm plugin this package does not know keeps the reference's Num
 from __future__ import annotations
 
 import logging
+from collections import OrderedDict  # noqa: F401  (annotation of _SHARED_INPUTS)
 
 import numpy as np
 
-__all__ = ["quantize_weights", "weight_arrays", "prefetch_model_weights"]
+__all__ = ["quantize_weights", "weight_arrays", "prefetch_model_weights", "clear_shared_inputs", "shared_input_stats"]
 
 logger = logging.getLogger(__name__)
 
@@ -29,6 +30,61 @@ _GPTQ_FALLBACK_WARNING = (
     "Failed to invert hessian due to numerical instability. Consider increasing percdamp, increasing the "
     "number of calibration samples, or shuffling the calibration dataset. Falling back to round-to-nearest "
     "for this module.")
+
+
+# Nodes that read the same value (q / k / v, gate / up) carry the SAME calibration array in `node.meta["input"]`
+# (calibrate.py:301-307 concatenates once per value name and hands that object to every consumer).  Everything `_gptq`
+# derives from the input alone -- the upload of X, the Hessian, dead channels, permutation, inverse factor (gptq.py:118-150,
+# :246-260) -- is computed once per such object and kept for the next nodes; consumers of one value are neighbours in graph
+# order, so two entries are enough.  The entry holds the array itself: its id cannot be reused while it is cached.
+_SHARED_INPUTS: "OrderedDict[tuple, tuple]" = None
+_SHARED_KEEP = 2
+shared_input_stats = {"hits": 0, "misses": 0}
+
+
+def clear_shared_inputs() -> None:
+    """Drop the cached Hessians / factors (end of a `quantize()` run)."""
+    if _SHARED_INPUTS is not None:
+        _SHARED_INPUTS.clear()
+
+
+def _hessian_and_factor(x, k, device, percdamp, actorder):
+    """(H [K, K], shared factor dictionary) of calibration input ``x`` on ``device``."""
+    global _SHARED_INPUTS
+    from collections import OrderedDict
+
+    import torch
+
+    from .hip import ops
+
+    if _SHARED_INPUTS is None:
+        _SHARED_INPUTS = OrderedDict()
+    cacheable = isinstance(x, (np.ndarray, torch.Tensor))
+    key = (id(x), int(k), str(device), float(percdamp), bool(actorder), ops.hessian_method())
+    mark = None
+    if isinstance(x, np.ndarray):
+        from .staging import _identity
+
+        mark = _identity(x)                 # shape, dtype and a strided sample: an array rewritten in place is not a hit
+    if cacheable:
+        hit = _SHARED_INPUTS.get(key)
+        if hit is not None and hit[0] is x and hit[3] == mark:
+            _SHARED_INPUTS.move_to_end(key)
+            shared_input_stats["hits"] += 1
+            return hit[1], hit[2]
+    shared_input_stats["misses"] += 1
+    h = torch.zeros((k, k), dtype=torch.float32, device=device)
+    n = 0
+    batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
+    for b in batches:
+        xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
+        n = ops.hessian_accumulate(xb.to(device, torch.float32), h, n)
+    shared = ops.gptq_shared_factor(h, percdamp, actorder)
+    if cacheable:
+        _SHARED_INPUTS[key] = (x, h, shared, mark)
+        while len(_SHARED_INPUTS) > _SHARED_KEEP:
+            _SHARED_INPUTS.popitem(last=False)
+    return h, shared
 
 
 def _key(qtype) -> str:
@@ -84,16 +140,10 @@ def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool):
         assert out is not None, "Output value is required for GPTQ quantization."      # gptq.py:54
         node = out.producer()
         assert "input" in node.meta, "GPTQ requires calibration data in node meta."    # gptq.py:56
-        x = node.meta["input"]
-        h = torch.zeros((k, k), dtype=torch.float32, device=w_dev.device)
-        n = 0
-        batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
-        for b in batches:
-            xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
-            n = ops.hessian_accumulate(xb.to(w_dev.device, torch.float32), h, n)
+        h, shared = _hessian_and_factor(node.meta["input"], k, w_dev.device, float(algo.percdamp), bool(algo.actorder))
         q, s, z, info = ops.gptq_quantize(w_dev, h, qt, st, a.group_size, bool(a.symmetric), bool(a.reduce_range),
                                           float(a.clip_ratio), int(algo.block_size), float(algo.percdamp), bool(algo.actorder),
-                                          bool(a.mse), mode=getattr(algo, "mode", "parity"))
+                                          bool(a.mse), mode=getattr(algo, "mode", "parity"), shared=shared)
         if int(info.item()) != 0:                                                     # gptq.py:143-150
             logger.warning(_GPTQ_FALLBACK_WARNING)
         return q, s, z, False

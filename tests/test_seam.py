@@ -121,6 +121,49 @@ def test_seam_emits_the_reference_initializers(onnx_ir_tensor):
 
 
 @pytest.mark.gpu
+def test_seam_computes_the_hessian_and_factor_once_per_shared_input(onnx_ir_tensor):
+    """calibrate.py:301-307 hands ONE array to every node that reads a value (q / k / v, gate / up): the seam uploads it,
+    accumulates H and factors it once, the following consumers reuse that -- with the results of the per-node computation,
+    bit for bit -- and an array rewritten in place is not mistaken for the one that was cached."""
+    from onnx_quantize_amd import GPTQConfig, QConfig, QuantType, QWeightArgs, seam
+
+    G = load_npz("seam_qw.npz")
+    case = next(c for c in CASES if c["algorithm"] == "gptq")
+    key = case["key"]
+    kw = {**case["weights"], "dtype": QuantType.from_string(case["weights"]["dtype"]), "algorithm": GPTQConfig(**case["config"])}
+    qc = QConfig(weights=QWeightArgs(**kw))
+    qc.weights.group_size = case["resolved_group_size"]
+    x = G[key + "_x"].copy()
+    w1 = G[key + "_w"]
+    w2 = (w1 * 0.5 + 0.01).astype(np.float32)
+
+    def run(w, xin):
+        node = types.SimpleNamespace(meta={"input": xin})
+        out = types.SimpleNamespace(producer=lambda node=node: node)
+        return seam.weight_arrays(_Value("fc.weight", _Tensor(w)), qc, out, case["flagged"])
+
+    seam.clear_shared_inputs()
+    before = dict(seam.shared_input_stats)
+    a1 = run(w1, x)
+    a2 = run(w2, x)                                   # same input object: one Hessian, one factor
+    assert seam.shared_input_stats["misses"] == before["misses"] + 1 and seam.shared_input_stats["hits"] == before["hits"] + 1
+    b2 = run(w2, x.copy())                            # a different object with the same content: computed afresh, same result
+    assert seam.shared_input_stats["misses"] == before["misses"] + 2
+    for u, v in zip(a2, b2):
+        assert np.asarray(u).tobytes() == np.asarray(v).tobytes()
+    for j, u in enumerate(a1):                        # and the first node still matches the reference's recording
+        exp = G[f"{key}_i{j}"]
+        assert (np.asarray(u, np.float32).tobytes() == exp.tobytes()) if exp.dtype.kind == "f" else np.array_equal(np.asarray(u).astype(np.int32), exp)
+    x *= 3.0                                          # rewritten in place: id unchanged, content changed
+    c2 = run(w2, x)
+    assert seam.shared_input_stats["misses"] == before["misses"] + 3
+    fresh = run(w2, x.copy())
+    for u, v in zip(c2, fresh):
+        assert np.asarray(u).tobytes() == np.asarray(v).tobytes()
+    seam.clear_shared_inputs()
+
+
+@pytest.mark.gpu
 def test_seam_fused_blob_at_full_size_matches_the_reference_digest(onnx_ir_tensor):
     """BASELINE config 2 through the seam: the fused kernel's blob, unpacked, has the reference's KAT2 digest; scales and
     (unpacked) zero points too; a prefetched upload gives the same bytes as an on-demand one."""
