@@ -649,7 +649,7 @@ def gptq_quantize(w: torch.Tensor, h: torch.Tensor, qtype: str, strategy: str, g
         u, info = gptq_factor(h1, percdamp)                                      # :134-150
     else:   # H-only work done once for all layers with this input
         u, info, perm = shared["u"], shared["info"], shared["perm"]
-        w1[shared["dead"], :] = 0                                                # :121
+        w1.masked_fill_(shared["dead"].unsqueeze(1), 0.0)                        # :121 (no host round trip, unlike w1[mask] = 0)
         if perm is not None:
             w1 = w1.index_select(0, perm.to(torch.int64)).contiguous()          # :126
     loop_g = group_size if (group_size and group_size != -1) else 0
