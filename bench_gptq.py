@@ -206,7 +206,8 @@ def run(args, dev, rank: int, world: int):
         # waves of `factor_wave` layers: the Hessians of a wave accumulate into one stack per input width, and each stack
         # is factored in lock-step (oq_gptq_factor_batched_f32: the latency of ONE chain of diagonal blocks for the whole
         # stack) while the Hessian stream is already on the next wave
-        per_wave = max(1, args.factor_wave * max(1, len(groups) // max(1, args.layers)))
+        inputs_per_layer = max(1, len({sp.hessian_key for sp in specs}) // max(1, args.layers))     # of the MODEL, not of this rank's share
+        per_wave = max(1, args.factor_wave * inputs_per_layer)
         for w0 in range(0, len(groups), per_wave):
             wave = groups[w0:w0 + per_wave]
             s_q = q_streams[(w0 // per_wave) % len(q_streams)]
