@@ -603,7 +603,37 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
         auto low_bytes = [](uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {   // [b0.0, b1.0, b2.0, b3.0]
             return __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
         };
-        if (a.grid.bits == 4) {
+        if (a.grid.bits == 4 && LPR == 8 && !(a.nt & 64)) {
+            // 16-byte stores: the lane sets 2m and 2m + 1 of a 16-lane DPP row hold neighbouring 8-byte pieces of every
+            // column slot.  The even set takes its partner's pieces of slots 0 and 1, the odd set its partner's pieces of
+            // slots 2 and 3 (one row_ror:8 per dword), and every lane issues TWO 16-byte stores instead of four 8-byte ones.
+            const uint32_t flip = bias ? 0x88888888u : 0u;
+            uint32_t wq[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int wd = 0; wd < 2; ++wd) {
+                    uint32_t pr[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)   // byte 0 = odd row << 4 | even row (levels < 16, M's low byte is 0)
+                        pr[j] = (__float_as_uint(v[wd * 8 + 2 * j + 1][i]) << 4) | __float_as_uint(v[wd * 8 + 2 * j][i]);
+                    wq[i][wd] = low_bytes(pr[0], pr[1], pr[2], pr[3]) ^ flip;
+                }
+            const bool odd = (h & 1) != 0;
+            auto swap8 = [](uint32_t x) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false)); };
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                // this lane stores slot t (even set) or slot 2 + t (odd set); it sends the pieces of the slot its partner stores
+                const uint32_t s0 = odd ? wq[t][0] : wq[2 + t][0], s1 = odd ? wq[t][1] : wq[2 + t][1];
+                const uint32_t r0 = swap8(s0), r1 = swap8(s1);
+                const uint32_t m0 = odd ? wq[2 + t][0] : wq[t][0], m1 = odd ? wq[2 + t][1] : wq[t][1];
+                const u32x4 val = odd ? u32x4{r0, r1, m0, m1} : u32x4{m0, m1, r0, r1};
+                const idx_t col = c0 + (odd ? 2 + t : t);
+                u32x4* o = reinterpret_cast<u32x4*>(a.q + ((col * kgroups_i + kg_i) * (G / 2) + (h & ~1) * 8));
+                if (a.nt & 2) __builtin_nontemporal_store(val, o);
+                else *o = val;
+            }
+        } else if (a.grid.bits == 4) {
             const uint32_t flip = bias ? 0x88888888u : 0u;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
