@@ -1,0 +1,9 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_rtn_gpu.py tests/test_api_gpu.py tests/test_gptq_gpu.py -m gpu -x -q > gpurun_out/kn16.log 2>&1 || { tail -20 gpurun_out/kn16.log; exit 1; }
+tail -2 gpurun_out/kn16.log
+run() { r=$(env "$@" python bench.py --no-cpu-baseline --no-extras --layout kn --steps 600 --warmup 60 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['roofline']['launch_us'], d['verified_vs_reference_digest'])"); echo "$* -> launch_us,verified = $r"; }
+for rep in 1 2 3; do
+run OQ_RTN_NT=1
+run OQ_RTN_NT=65
+done
