@@ -26,7 +26,7 @@ Prints ONE JSON line (contract in the task description) with these extra objects
   cpu_baseline  the NumPy oracle (oracle/oq_oracle.py) timed on the host, rank 0 at N=1 only
   seam          host -> host throughput through the plugin seam (qrules/_common.py:126-142) on the same configuration:
                 round-1 route ([K,N] kernel, 45 MB download, second round trip for the packer) vs the device-resident
-                seam with pinned, prefetched uploads (seam.py, staging.py), digest-checked
+                seam (seam.py: one upload, fused blob kernel, one download), digest-checked
   gptq          BASELINE configs 4 / 5 from the same run: GPTQ QInt4 g128 of all Llama-2-7B MatMul weights
                 (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`
   gather        N > 1: seconds, bytes and ranks of the end-of-run RCCL gather
@@ -189,7 +189,6 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
 
     from onnx_quantize_amd import QConfig, QuantType, QWeightArgs, seam
     from onnx_quantize_amd.algorithms.rtn import _rtn_quantize
-    from onnx_quantize_amd.staging import default_stager
     from onnx_quantize_amd.wire_format import _prepare_for_matmul_nbits
 
     qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=GROUP))
@@ -219,14 +218,11 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
 
     from onnx_quantize_amd.hip import ops
 
-    st = default_stager()
     # one untimed call per route: first launches of a kernel / first use of a stream carry 0.1 s of one-time set-up
     warm = w_host.copy()
     round1_route(warm)
     _prepare_for_matmul_nbits(*_rtn_quantize(warm, a.dtype, a.strategy, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse,
                                              a.scale_dtype, a.zp_dtype), qc)
-    seam.weight_arrays(_Value("warm", warm), qc, None, True)
-    st.prefetch([("warm", warm)])
     seam.weight_arrays(_Value("warm", warm), qc, None, True)
     mats = fresh()
     torch.cuda.synchronize()
@@ -242,25 +238,16 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
         q, s, z = _rtn_quantize(w, a.dtype, a.strategy, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse, a.scale_dtype, a.zp_dtype)
         last = _prepare_for_matmul_nbits(q, s, z, qc)
     t_plugin = time.perf_counter() - t0
-    # device-resident seam, uploads on demand; then with the model's weights prefetched from the worker thread while the
-    # previous one is quantized.  Host-side effects (page faults and page-locking of fresh arrays, the worker thread's
-    # scheduling) make single passes scatter by a factor of two between boxes: three passes each, the median is reported
-    # and all three are listed.
-    hits0 = st.stats["hits"]
-    demand_trials, after_trials = [], []
+    # device-resident seam (upload per call).  Host-side effects (page faults of fresh arrays) make single passes scatter by
+    # a factor of two between boxes: three passes, the median is reported and all three are listed.
+    trials = []
     for _ in range(3):
         mats = fresh()
         t0 = time.perf_counter()
         for i, w in enumerate(mats):
             last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
-        demand_trials.append(time.perf_counter() - t0)
-        mats = fresh()
-        t0 = time.perf_counter()
-        st.prefetch([(f"w{i}", w) for i, w in enumerate(mats)])
-        for i, w in enumerate(mats):
-            last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
-        after_trials.append(time.perf_counter() - t0)
-    t_demand, t_after = sorted(demand_trials)[1], sorted(after_trials)[1]
+        trials.append(time.perf_counter() - t0)
+    t_after = sorted(trials)[1]
     ok_after = check(*last)
     rate = lambda t: round(params / t / 1e6, 1)  # noqa: E731
     return {"what": "host->host through quantize_weights' arrays (qrules/_common.py:133-137), uint4 g128 4096x11008, "
@@ -268,15 +255,12 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
             "unit": "M-param/s",
             "before": {"route": "round 1: pageable upload, [K,N] kernel, 45 MB pageable download, packer as a second round trip",
                        "value": rate(t_before), "ms_per_weight": round(t_before * 1e3 / count, 2), "digest_ok": ok_before},
-            "plugin_functions": {"route": "_rtn_quantize + _prepare_for_matmul_nbits of this round (NumPy in / NumPy out, two round trips)",
+            "plugin_functions": {"route": "_rtn_quantize + _prepare_for_matmul_nbits (NumPy in / NumPy out, two round trips)",
                                  "value": rate(t_plugin), "ms_per_weight": round(t_plugin * 1e3 / count, 2)},
-            "after_on_demand": {"route": "seam.weight_arrays, upload per call", "value": rate(t_demand),
-                                "ms_per_weight": round(t_demand * 1e3 / count, 2),
-                                "ms_per_weight_trials": [round(t * 1e3 / count, 2) for t in demand_trials]},
-            "after": {"route": "seam.weight_arrays + WeightStager.prefetch (worker thread, side stream)", "value": rate(t_after),
-                      "ms_per_weight": round(t_after * 1e3 / count, 2),
-                      "ms_per_weight_trials": [round(t * 1e3 / count, 2) for t in after_trials], "digest_ok": ok_after,
-                      "prefetch_hits": st.stats["hits"] - hits0},
+            "after": {"route": "seam.weight_arrays: one blocking upload, fused blob kernel, one download (the only route since round 3: "
+                               "the worker-thread prefetcher of round 2 was slower in the driver record and was removed)",
+                      "value": rate(t_after), "ms_per_weight": round(t_after * 1e3 / count, 2),
+                      "ms_per_weight_trials": [round(t * 1e3 / count, 2) for t in trials], "digest_ok": ok_after},
             "speedup": round(t_before / t_after, 2),
             "note": "every route is timed on fresh host arrays (memory the GPU has not mapped yet), as a model's weights are"}
 

@@ -46,12 +46,12 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src: str, force: bool) -> str:
+def _compile(src: str, force: bool, extra: tuple = ()) -> str:
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     newest = max(os.path.getmtime(src), _deps_mtime())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj
-    cmd = [hipcc(), *CXXFLAGS, "-c", src, "-o", obj]
+    cmd = [hipcc(), *CXXFLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -60,12 +60,15 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, extra_flags: tuple = ()) -> str:
+    """``extra_flags`` is for lab builds only (``--attribution`` below adds -DOQ_RTN_ATTRIBUTION, the store-dropping
+    variants of the RTN kernel that scripts/sweep_rtn*.sh time on a GPU box's scratch copy); `__graft_entry__.build()`
+    and the tests never pass any."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     srcs = sources()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, tuple(extra_flags)), srcs))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -79,4 +82,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--attribution" in sys.argv:          # never the shipped library: forces a full rebuild with the lab switches compiled in
+        build(force=True, extra_flags=("-DOQ_RTN_ATTRIBUTION",))
+    else:
+        build(force="--force" in sys.argv)

@@ -2,6 +2,7 @@
 // building blocks the reference calls by name (utils.py:72-137, :242-299; rtn.py:112-138;
 // qrules/_common.py:96-121; _pack.py:8-22); the bulk RTN path fuses them in rtn.hip instead.
 #include "oq_common.hpp"
+#include "row_params.hpp"
 
 namespace oq {
 
@@ -36,13 +37,6 @@ __global__ void qparams_kernel_f64(const double* rmin, const double* rmax, int64
         zp[i] = static_cast<int32_t>(rint(z));
     }
 }
-
-struct ParamIndex {
-    int64_t row_div, row_stride, col_stride;
-    __device__ __forceinline__ int64_t operator()(int64_t r, int64_t c) const {
-        return (r / row_div) * row_stride + c * col_stride;
-    }
-};
 
 template <typename OutT>
 __global__ __launch_bounds__(256) void quantize_kernel(const float* x, int64_t R, int64_t C, int64_t ldx,
@@ -87,18 +81,6 @@ __global__ __launch_bounds__(256) void dequantize_kernel(const InT* q, int64_t R
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kTileRows = 32;
 
-struct RowParams {   // where the parameters of row r live; next() steps to r + 1 without dividing
-    int64_t base, left, row_stride, row_div;
-    __device__ __forceinline__ RowParams(int64_t r, const ParamIndex& pi)
-        : base((r / pi.row_div) * pi.row_stride), left(pi.row_div - r % pi.row_div), row_stride(pi.row_stride), row_div(pi.row_div) {}
-    __device__ __forceinline__ bool next() {   // true when the parameter row changed
-        if (--left > 0) return false;
-        left = row_div;
-        base += row_stride;
-        return row_stride != 0;
-    }
-};
-
 template <bool QUANT>
 __global__ __launch_bounds__(256) void tile_kernel(const float* __restrict__ xin, const uint8_t* __restrict__ qin, int64_t R, int64_t C, int64_t ldx,
                                                    const float* __restrict__ scale, const int32_t* __restrict__ zp, ParamIndex pi,
@@ -108,18 +90,18 @@ __global__ __launch_bounds__(256) void tile_kernel(const float* __restrict__ xin
     if (c >= C) return;                                         // C % 4 == 0: a thread's four columns are all inside or all outside
     const int64_t r0 = static_cast<int64_t>(blockIdx.y) * kTileRows;
     const int64_t r1 = r0 + kTileRows < R ? r0 + kTileRows : R;
-    RowParams rp(r0, pi);
     float s[4];
     int32_t z[4];
-    auto load_params = [&]() {
+    auto load_params = [&](int64_t base) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t p = rp.base + (c + u) * pi.col_stride;
+            const int64_t p = base + (c + u) * pi.col_stride;
             s[u] = scale[p];
             z[u] = zp[p];
         }
     };
-    load_params();
+    TileParamCursor<decltype(load_params)> params(r0, r1, pi, load_params);   // row_params.hpp: never loads behind the tile's last row
+    params.start();
     for (int64_t r = r0; r < r1; r += 8) {
         f32x4 v[8];
         uint32_t b[8];
@@ -148,9 +130,7 @@ __global__ __launch_bounds__(256) void tile_kernel(const float* __restrict__ xin
                     }
                     *reinterpret_cast<f32x4*>(xout + (r + u) * ldx + c) = o;
                 }
-                // uniform over the block; not after the tile's last row: the next parameter row may not exist (one entry
-                // past the end of scale / zp for the matrix' last rows: a page fault when the array ends its mapping)
-                if (rp.next() && r + u + 1 < r1) load_params();
+                params.row_done(r + u);   // uniform over the block
             }
         }
     }

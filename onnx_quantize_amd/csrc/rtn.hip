@@ -10,6 +10,19 @@
 
 namespace oq {
 
+// Attribution switches (bits 3-6 of OQ_RTN_NT: drop the parameter stores, drop the blob stores, write a wave-contiguous
+// -- WRONG -- layout, 8-byte instead of 16-byte blob stores) exist only in builds made with -DOQ_RTN_ATTRIBUTION
+// (scripts/sweep_rtn*.sh).  The shipped library compiles them out and masks the environment value to the two
+// layout-neutral bits (0: non-temporal W loads / [K,N] stores, 1: non-temporal blob stores), so no environment variable
+// can make liboq_hip.so return anything but the reference's bytes (tests/test_library_abi.py).
+#ifdef OQ_RTN_ATTRIBUTION
+#define OQ_ATTR(nt, bit) (((nt) & (bit)) != 0)
+constexpr int kNtMask = 127;
+#else
+#define OQ_ATTR(nt, bit) false
+constexpr int kNtMask = 3;
+#endif
+
 // Division of a block id by a launch constant without the ~30-instruction integer-divide expansion: the quotient
 // estimate float(n) * fl(1/d) is within 1 of n / d for n < 2^22 and is corrected with the exact remainder.
 struct FastDiv {
@@ -503,9 +516,9 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
         const ColQ c = make_colq(qparam_from_minmax(mnj, mxj, a.grid), mnj, mxj, bias);
         own_scale = c.scale;
         if (h < 4) s_scale[wave][j * LPR + cl] = c.scale;      // for the fallback: slot i of strip column cl at [i * LPR + cl]
-        if (h < 4 && col_ok && !(a.nt & 8)) {   // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j  [nt bit 3: attribution runs only]
+        if (h < 4 && col_ok && !OQ_ATTR(a.nt, 8)) {   // rtn.py:98-109 result layout (entry n * K/g + kg); lane set j stores column slot j
             idx_t o = (c0 + j) * kgroups_i + kg_i;
-            if (a.nt & 32) o = static_cast<idx_t>((kg * (a.N / (4 * LPR)) + strip0 / (4 * LPR)) * (4 * LPR) + lane);   // attribution runs only: wave-contiguous (wrong) layout
+            if (OQ_ATTR(a.nt, 32)) o = static_cast<idx_t>((kg * (a.N / (4 * LPR)) + strip0 / (4 * LPR)) * (4 * LPR) + lane);   // attribution builds only
             a.scale[o] = c.scale;
             a.zp[o] = static_cast<uint8_t>(static_cast<int32_t>(c.zpb) - bias);
         }
@@ -597,13 +610,13 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[r][i] = f[i];
         }
-        if (!col_ok || (a.nt & 16)) return;   // nt bit 4: attribution runs only
+        if (!col_ok || OQ_ATTR(a.nt, 16)) return;
         // qrules/_common.py:72-87: out-channel n, k-group kg -> G * bits / 8 bytes, k ascending, even k in the low nibble.
         // v[r][i] holds M + level: the level is byte 0 of its bits (the other three bytes are those of M).
         auto low_bytes = [](uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {   // [b0.0, b1.0, b2.0, b3.0]
             return __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u) | __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);
         };
-        if (a.grid.bits == 4 && LPR == 8 && !(a.nt & 64)) {
+        if (a.grid.bits == 4 && LPR == 8 && !OQ_ATTR(a.nt, 64)) {
             // 16-byte stores: the lane sets 2m and 2m + 1 of a 16-lane DPP row hold neighbouring 8-byte pieces of every
             // column slot.  The even set takes its partner's pieces of slots 0 and 1, the odd set its partner's pieces of
             // slots 2 and 3 (one row_ror:8 per dword), and every lane issues TWO 16-byte stores instead of four 8-byte ones.
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
                     words[wd] = low_bytes(pr[0], pr[1], pr[2], pr[3]) ^ flip;
                 }
                 u32x2* o = reinterpret_cast<u32x2*>(a.q + (((c0 + i) * kgroups_i + kg_i) * (G / 2) + h * 8));
-                if (a.nt & 32)   // attribution runs only: every store instruction writes 512 contiguous bytes (wrong layout)
+                if (OQ_ATTR(a.nt, 32))   // attribution builds only: every store instruction writes 512 contiguous bytes
                     o = reinterpret_cast<u32x2*>(a.q + ((kg * (a.N / (4 * LPR)) + strip0 / (4 * LPR)) * (2 * G * LPR) + i * 512 + lane * 8));
                 const u32x2 t = {words[0], words[1]};
                 if (a.nt & 2) __builtin_nontemporal_store(t, o);
@@ -1058,7 +1071,7 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
     }
 }
 
-// Experiment knobs (never needed for correctness): -1 = use the tuned default.
+// Experiment knobs: speed only, every setting produces the same bytes (-1 = the tuned default).
 struct Tuning {
     int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1, wps = -1;
     static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
@@ -1066,7 +1079,7 @@ struct Tuning {
         Tuning t;
         t.order = env_int("OQ_RTN_ORDER");      // 0 K-fastest + XCD strips, 1 column tiles fastest, 2 L2-merging blocks
         t.gk = env_int("OQ_RTN_GK");            // row tiles per id block of order 2
-        t.nt = env_int("OQ_RTN_NT");            // bit 0 non-temporal W loads and [K,N] stores, bit 1 non-temporal blob stores
+        t.nt = env_int("OQ_RTN_NT");            // bit 0 non-temporal W loads and [K,N] stores, bit 1 non-temporal blob stores (masked with kNtMask)
         t.stage = env_int("OQ_RTN_STAGE");      // stage (scale, zp) as [K/g, N] + transpose launch
         t.stage_q = env_int("OQ_RTN_STAGE_Q");  // assemble blob chunks in LDS
         t.wavek = env_int("OQ_RTN_WAVEK");      // blob layout: wave-owns-group kernel (1) or the block kernel (0)
@@ -1264,7 +1277,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.nrow_tiles = static_cast<uint32_t>(ceil_div(kgroups, gpb));
             a.order = tw.order >= 0 ? tw.order : 2;
             a.gk = tw.gk > 0 ? tw.gk : 4;
-            a.nt = tw.nt >= 0 ? tw.nt : 1;
+            a.nt = (tw.nt >= 0 ? tw.nt : 1) & kNtMask;
             set_block_order(a);
             const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(wpb * kWave));
             // the 5-waves-per-SIMD build addresses its outputs with 32-bit offsets and needs blocks of <= 4 waves
@@ -1314,7 +1327,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         const bool blob = layout == OQ_LAYOUT_NBITS;
         a.order = tune.order >= 0 ? tune.order : (blob ? 2 : 1);
         a.gk = tune.gk > 0 ? tune.gk : 8;
-        a.nt = tune.nt >= 0 ? tune.nt : 1;
+        a.nt = (tune.nt >= 0 ? tune.nt : 1) & kNtMask;
         a.stage_q = ((tune.stage_q != 0) && blob && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves && kgroups % a.gpb == 0) ? 1 : 0;
         a.spb_log2 = 0;
         set_block_order(a);

@@ -103,7 +103,7 @@ def install_into_reference() -> dict:
         ref_calibrate = None
     _extend_providers(ref_base, ref_calibrate)
     rebound = {"algorithms": ["_rtn_quantize", "_gptq_quantize", "_hqq_quantize"], "calibrator": "minmax",
-               "quantize_weights": _rebind_seam(), "awq": False, "prefetch": False}
+               "quantize_weights": _rebind_seam(), "awq": False, "cleanup": False}
     # the AWQ pass binds the two helpers by name at import time (pre_passes/awq.py:10-11): rebind them in its namespace
     try:
         import onnx_quantize.pre_passes.awq as ref_awq
@@ -113,27 +113,24 @@ def install_into_reference() -> dict:
         rebound["awq"] = True
     except ImportError:
         pass
-    # between the pre-passes and the rewrite every weight is final: start uploading all of them (quantize.py:58-65)
+    # the rewrite is over when quantize.py:68 asks for the emitted functions (`get_qfunctions`, resolved by name in that
+    # module at call time, so this also covers callers that bound `quantize` before the install): drop the cached
+    # Hessians / factors of the GPTQ nodes there, on the drop-in path too
     try:
-        import onnx_quantize.quantize as ref_quantize
+        ref_quantize = importlib.import_module("onnx_quantize.quantize")   # the module (the package attribute is the function)
 
-        if not getattr(ref_quantize.apply_pre_passes, "_oq_prefetching", False):
-            original = ref_quantize.apply_pre_passes
+        if not getattr(ref_quantize.get_qfunctions, "_oq_cleanup", False):
+            original = ref_quantize.get_qfunctions
 
-            def apply_pre_passes(model, qconfig):
-                from .seam import prefetch_model_weights
+            def get_qfunctions(*args, **kwargs):
+                from .seam import clear_shared_inputs
 
-                model = original(model, qconfig)
-                try:
-                    n = prefetch_model_weights(model, tuple(qconfig.target_op_types))
-                    logger.debug("prefetching %d weights into HBM", n)
-                except Exception as e:  # noqa: BLE001 -- prefetching is an optimisation: the seam uploads on demand without it
-                    logger.warning("weight prefetch disabled: %s", e)
-                return model
+                clear_shared_inputs()
+                return original(*args, **kwargs)
 
-            apply_pre_passes._oq_prefetching = True
-            ref_quantize.apply_pre_passes = apply_pre_passes
-        rebound["prefetch"] = True
+            get_qfunctions._oq_cleanup = True
+            ref_quantize.get_qfunctions = get_qfunctions
+        rebound["cleanup"] = True
     except ImportError:
         pass
     _installed.update(rebound)
@@ -178,11 +175,6 @@ def quantize_with_reference_pipeline(model, qconfig):
     try:
         return ref.quantize(model, ref_qconfig)
     finally:
-        try:
-            from . import seam
-            from .staging import default_stager
+        from . import seam
 
-            default_stager().cancel()
-            seam.clear_shared_inputs()
-        except Exception:  # noqa: BLE001
-            pass
+        seam.clear_shared_inputs()

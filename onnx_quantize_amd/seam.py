@@ -5,7 +5,7 @@
 plugin NumPy -> NumPy and then, for MatMulNBits, repacks the result in NumPy (`_prepare_for_matmul_nbits`, :65-123).
 Behind the same signature this module keeps the weight in HBM from upload to the final wire format:
 
-    upload once (on demand or prefetched from a worker thread, staging.py)
+    upload once (one blocking copy, staging.py)
       -> RTN | GPTQ | HQQ kernels on the device
       -> MatMulNBits blob written by the kernel epilogue (RTN, HQQ) or by oq_pack_matmul_nbits (GPTQ, RTN + mse)
       -> zero points nibble-packed by oq_pack_zero_points_u4
@@ -22,7 +22,7 @@ from collections import OrderedDict  # noqa: F401  (annotation of _SHARED_INPUTS
 
 import numpy as np
 
-__all__ = ["quantize_weights", "weight_arrays", "prefetch_model_weights", "clear_shared_inputs", "shared_input_stats"]
+__all__ = ["quantize_weights", "weight_arrays", "clear_shared_inputs", "shared_input_stats"]
 
 logger = logging.getLogger(__name__)
 
@@ -63,9 +63,9 @@ def _hessian_and_factor(x, k, device, percdamp, actorder):
     key = (id(x), int(k), str(device), float(percdamp), bool(actorder), ops.hessian_method())
     mark = None
     if isinstance(x, np.ndarray):
-        from .staging import _identity
+        from .staging import content_mark
 
-        mark = _identity(x)                 # shape, dtype and a strided sample: an array rewritten in place is not a hit
+        mark = content_mark(x)              # shape, dtype and a content SAMPLE (see staging.content_mark for its limits)
     if cacheable:
         hit = _SHARED_INPUTS.get(key)
         if hit is not None and hit[0] is x and hit[3] == mark:
@@ -97,9 +97,9 @@ def _strategy(s) -> str:
 
 
 def _upload(name, array):
-    from .staging import default_stager
+    from .staging import upload
 
-    return default_stager().take(name, array)
+    return upload(array)
 
 
 def _host(t, dtype=None):
@@ -203,26 +203,3 @@ def quantize_weights(op, w, qconfig, out=None, is_matmul_nbits_compatible: bool 
     w_scale = op.initializer(ir.tensor(w_scale), name=f"{w.name}/scale")
     w_zero_point = op.initializer(ir.tensor(w_zero_point), name=f"{w.name}/zero_point")
     return w_q, w_scale, w_zero_point
-
-
-def prefetch_model_weights(model, op_types=("MatMul", "Gemm")) -> int:
-    """Start uploading every constant weight the rewrite rules are going to quantize (nodes stamped with a `qconfig` by the
-    pre-passes, pre_passes/__init__.py:17-26; weight = input 1 with a constant 2-D fp32 value) in graph order.  Returns the
-    number of weights queued.  Called between the pre-passes and the rewrite (integration.py)."""
-    from .staging import default_stager
-
-    items, seen = [], set()
-    for node in model.graph:
-        if node.op_type not in op_types or node.meta.get("qconfig") is None or len(node.inputs) < 2:
-            continue
-        v = node.inputs[1]
-        c = getattr(v, "const_value", None)
-        if c is None or v.name in seen:
-            continue
-        a = c.numpy()
-        if a.ndim == 2 and a.dtype == np.float32:
-            seen.add(v.name)
-            items.append((v.name, a))
-    if items:
-        default_stager().prefetch(items)
-    return len(items)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the attribution build: python -m onnx_quantize_amd._build --attribution (scripts/README.md)
 cd $GRAFT_REPO_ROOT
 timeout -k 10 600 python -m pytest tests/test_rtn_gpu.py tests/test_api_gpu.py tests/test_gptq_gpu.py -m gpu -x -q > gpurun_out/kn16.log 2>&1 || { tail -20 gpurun_out/kn16.log; exit 1; }
 tail -2 gpurun_out/kn16.log

@@ -192,7 +192,10 @@ def test_streamed_hessian_and_gptq_equal_the_concatenated_flow():
         eq, es, ez = O.gptq_quantize(w.cpu().numpy(), whole[value], "int4", "group", 32)
         assert q.shape == eq.shape and s.shape == es.shape
         np.testing.assert_allclose(s.cpu().numpy(), es, rtol=1e-5)
-        assert (q.cpu().numpy() != eq).mean() <= 1e-3 and (z.cpu().numpy() != ez).mean() <= 1e-3
+        # parity mode: the integers depend on H only through diag(H) == 0 (SURVEY.md finding 1), so a streamed Hessian
+        # that differs from the concatenated one in the last bits gives the SAME integers and zero points
+        np.testing.assert_array_equal(q.cpu().numpy(), eq)
+        np.testing.assert_array_equal(z.cpu().numpy(), ez)
     # inputs of one width are factored as one batch: same results as one factor chain per input
     hs = dict(stream.hessians)
     hs["a1_again"] = stream.hessians["a1"]                                 # a second input of fc2's width

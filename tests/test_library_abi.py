@@ -161,3 +161,50 @@ def test_c_program_quantizes_on_the_gpu(tmp_path):
     assert int(kn["zp"], 16) == _fnv1a(np.ascontiguousarray(z, np.uint8).tobytes())
     assert int(out[1].split("=")[1], 16) == _fnv1a(blob.tobytes())
     assert out[2].startswith("error status=-2") and "NBITS layout needs the group strategy" in out[2]
+
+
+def test_shipped_library_has_no_attribution_switches():
+    """The store-dropping / wrong-layout variants of the RTN kernel (OQ_RTN_NT bits 3-6) exist only behind
+    -DOQ_RTN_ATTRIBUTION; the build used by `__graft_entry__.build()` and the tests never defines it."""
+    from onnx_quantize_amd import _build
+    assert not any("OQ_RTN_ATTRIBUTION" in f for f in _build.CXXFLAGS)
+    src = open(os.path.join(_build.SRC, "rtn.hip")).read()
+    assert "#ifdef OQ_RTN_ATTRIBUTION" in src and "constexpr int kNtMask = 3;" in src
+    # every use of the upper bits goes through the macro that the shipped build defines as `false`
+    import re
+    assert not re.search(r"a\.nt\s*&\s*(8|16|32|64)\b", src)
+
+
+@pytest.mark.gpu
+def test_environment_knobs_cannot_change_the_bytes():
+    """one stray environment variable (OQ_RTN_NT=56 dropped the parameter and blob stores in round 2) must not
+    make liboq_hip.so return anything but the reference's bytes.  A fresh process (the knobs are read once) quantizes the
+    KAT2 matrix with every output-relevant knob set to a hostile value and must still produce the reference's digests."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, json, numpy as np, torch
+from onnx_quantize_amd.hip import ops
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+w = torch.from_numpy(np.random.default_rng(0).standard_normal((4096, 11008), dtype=np.float32)).cuda()
+out = {}
+blob, s, z = ops.rtn_quantize(w, "uint4", "group", 128, layout="nbits")
+b = blob.cpu().numpy()
+full = np.empty((11008, 32, 128), np.uint8); full[..., 0::2] = b & 0x0F; full[..., 1::2] = b >> 4
+out["nbits"] = [sha(full.reshape(11008, 4096).T), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
+q, s, z = ops.rtn_quantize(w, "uint4", "group", 128, layout="kn")
+out["kn"] = [sha(q.cpu().numpy()), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
+print(json.dumps(out))
+'''
+    with open(os.path.join(root, "tests", "golden", "digests.json")) as f:
+        d = json.load(f)["config2_asym"]
+    expect = [d["q_sha"], d["s_sha"], d["z_sha"]]
+    for nt in ("56", "127", "120"):
+        env = dict(os.environ, OQ_RTN_NT=nt, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = json.loads(r.stdout.strip().splitlines()[-1])
+        assert got["nbits"] == expect and got["kn"] == expect, (nt, got)
