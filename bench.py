@@ -27,8 +27,12 @@ Prints ONE JSON line (contract in the task description) with these extra objects
   seam          host -> host throughput through the plugin seam (qrules/_common.py:126-142) on the same configuration:
                 round-1 route ([K,N] kernel, 45 MB download, second round trip for the packer) vs the device-resident
                 seam (seam.py: one upload, fused blob kernel, one download), digest-checked
+  calibration   BASELINE config 3 stand-in from the same run (bench_calib.run): 51 batches x 72 activation tensors through
+                MinMaxCalibrator.collect_many, `roofline` of oq::minmax_partial, a CPU baseline, `verified`
   gptq          BASELINE configs 4 / 5 from the same run: GPTQ QInt4 g128 of all Llama-2-7B MatMul weights
-                (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`
+                (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`;
+                `corrected` = the same model with the error-correcting loop, `wall_by_hessian_method` = the whole-model
+                wall with the Hessian on the fp32 MFMA kernel next to the default split-operand one
   gather        N > 1: seconds, bytes and ranks of the end-of-run RCCL gather
 """
 from __future__ import annotations
@@ -282,6 +286,9 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="time only the headline configuration (used under rocprofv3)")
     ap.add_argument("--no-gptq", action="store_true", help="skip the `gptq` object (configs 4 / 5)")
     ap.add_argument("--no-seam", action="store_true", help="skip the `seam` object")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the `calibration` object (config 3 stand-in)")
+    ap.add_argument("--gptq-extra-passes", default="corrected,f32",
+                    help="further whole-model GPTQ passes of the `gptq` object (bench_gptq.py --extra-passes)")
     ap.add_argument("--gptq-layers", type=int, default=32)
     ap.add_argument("--gptq-tokens", type=int, default=128 * 2048)
     ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
@@ -481,15 +488,23 @@ def main() -> None:
     if world == 1 and not args.no_seam and not args.no_extras and not args.symmetric:
         seam = seam_bench(w_host, digests["config2_asym"])
 
-    # ---- configs 4 / 5: GPTQ of a Llama-2-7B-shaped model from the same run (all ranks take part)
     del ws, outs, calls, w_src
     torch.cuda.empty_cache()
+    # ---- config 3 stand-in: min-max calibration of a gemma-3-270m-shaped activation population (rank 0 at N = 1)
+    calibration = None
+    if world == 1 and not args.no_calibration and not args.no_extras:
+        import bench_calib
+
+        calibration = bench_calib.run(dev, cpu=not args.no_cpu_baseline)
+        torch.cuda.empty_cache()
+    # ---- configs 4 / 5: GPTQ of a Llama-2-7B-shaped model from the same run (all ranks take part)
     gptq = None
     if not args.no_gptq and not args.no_extras:
         import bench_gptq
 
         gargs = bench_gptq.build_parser().parse_args(["--gpus", str(world), "--layers", str(args.gptq_layers),
-                                                      "--tokens", str(args.gptq_tokens)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
+                                                      "--tokens", str(args.gptq_tokens), "--extra-passes", args.gptq_extra_passes] +
+                                                     (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         gptq = bench_gptq.run(gargs, dev, rank, world)
 
     if rank != 0:
@@ -536,6 +551,7 @@ def main() -> None:
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
         "seam": seam,
         "gather": gather,
+        "calibration": calibration,
         "gptq": gptq,
     }
     if os.environ.get("OQ_BENCH_REHEARSAL", "0") == "1":

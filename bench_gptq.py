@@ -61,6 +61,10 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--factor-wave", type=int, default=8,
                     help="layers per wave whose Hessians of one width are factored as ONE batch (0: a factor chain per input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extra-passes", default="corrected,f32",
+                    help="further whole-model passes reported next to the headline one: `corrected` (mode=corrected: the error-"
+                         "correcting loop north_star names), `f32` (parity with the Hessian on the fp32 MFMA kernel, the reference's "
+                         "arithmetic class); empty to skip")
     ap.add_argument("--hessian-methods", default="auto,bf16x6,f32",
                     help="comma list of X^T X kernels to time alone for the roofline objects (auto = the fp16-piece split-operand kernel for K >= 1024)")
     return ap
@@ -158,70 +162,36 @@ def run(args, dev, rank: int, world: int):
             groups.append((key, []))
         groups[seen[key]][1].append(i)
 
-    s_h = torch.cuda.Stream(device=dev)
-    # batched factors (factor_wave > 0) run on the Hessian's stream unless --overlap: side by side the two kinds of
-    # matrix-core kernels only slow each other down (measured: 4.88 s in sequence, 5.2-5.6 s on 1 + 2..4 streams)
-    one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
-    q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
-    results, timings, samples = {}, [], {}
-    fence()
-    t0 = time.perf_counter()
-    def quantize_members(members, h, shared):
-        for j, i in enumerate(members):
-            sp = specs[i]
-            w = wpool[(sp.k, sp.n)][(i + j) % 3]
-            e4, e5 = ev(), ev()
-            e4.record()
-            q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128, mode=args.mode, shared=shared)
-            results[i] = (ops.pack_nibbles(q), s, z)               # 0.5 B / param on the wire
-            e5.record()
-            timings.append(("l", e4, e5))
-            if (sp.k, sp.n) not in samples:                         # first layer of every shape: verified after the clock stops
-                samples[(sp.k, sp.n)] = (i, w)
+    def model_pass(mode: str) -> dict:
+        """One timed pass over this rank's share of the model: Hessians, factors, loop, packing, the gather to rank 0."""
+        s_h = torch.cuda.Stream(device=dev)
+        # batched factors (factor_wave > 0) run on the Hessian's stream unless --overlap: side by side the two kinds of
+        # matrix-core kernels only slow each other down (measured: 4.88 s in sequence, 5.2-5.6 s on 1 + 2..4 streams)
+        one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
+        q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
+        results, timings, samples = {}, [], {}
+        fence()
+        t0 = time.perf_counter()
+        def quantize_members(members, h, shared):
+            for j, i in enumerate(members):
+                sp = specs[i]
+                w = wpool[(sp.k, sp.n)][(i + j) % 3]
+                e4, e5 = ev(), ev()
+                e4.record()
+                q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128, mode=mode, shared=shared)
+                results[i] = (ops.pack_nibbles(q), s, z)               # 0.5 B / param on the wire
+                if (sp.k, sp.n) not in samples:                         # first layer of every shape: verified after the clock stops
+                    samples[(sp.k, sp.n)] = (i, w, q if mode == "corrected" else None)
+                e5.record()
+                timings.append(("l", e4, e5))
 
-    if args.factor_wave <= 0:
-        # one factor chain per input, as soon as its Hessian is complete
-        for gi, (key, members) in enumerate(groups):
-            s_q = q_streams[gi % len(q_streams)]
-            k = specs[members[0]].k
-            with torch.cuda.stream(s_h):
-                h = torch.zeros((k, k), device=dev)
-                e0, e1 = ev(), ev()
-                e0.record()
-                n = 0
-                for x in acts[k]:
-                    n = ops.hessian_accumulate(x, h, n)
-                e1.record()
-                timings.append(("h", e0, e1))
-            with torch.cuda.stream(s_q):
-                s_q.wait_event(e1)
-                h.record_stream(s_q)
-                e2, e3 = ev(), ev()
-                e2.record()
-                shared = ops.gptq_shared_factor(h, 0.01, False)
-                e3.record()
-                timings.append(("f", e2, e3))
-                quantize_members(members, h, shared)
-    else:
-        # waves of `factor_wave` layers: the Hessians of a wave accumulate into one stack per input width, and each stack
-        # is factored in lock-step (oq_gptq_factor_batched_f32: the latency of ONE chain of diagonal blocks for the whole
-        # stack) while the Hessian stream is already on the next wave
-        inputs_per_layer = max(1, len({sp.hessian_key for sp in specs}) // max(1, args.layers))     # of the MODEL, not of this rank's share
-        per_wave = max(1, args.factor_wave * inputs_per_layer)
-        for w0 in range(0, len(groups), per_wave):
-            wave = groups[w0:w0 + per_wave]
-            s_q = q_streams[(w0 // per_wave) % len(q_streams)]
-            slots, last = {}, {}
-            for gi, (key, members) in enumerate(wave):
+        if args.factor_wave <= 0:
+            # one factor chain per input, as soon as its Hessian is complete
+            for gi, (key, members) in enumerate(groups):
+                s_q = q_streams[gi % len(q_streams)]
                 k = specs[members[0]].k
-                slots.setdefault(k, []).append(gi)
-                last[k] = gi
-            with torch.cuda.stream(s_h):
-                stacks = {k: torch.zeros((len(g), k, k), device=dev) for k, g in slots.items()}
-                done = {}
-                for gi, (key, members) in enumerate(wave):
-                    k = specs[members[0]].k
-                    h = stacks[k][slots[k].index(gi)]
+                with torch.cuda.stream(s_h):
+                    h = torch.zeros((k, k), device=dev)
                     e0, e1 = ev(), ev()
                     e0.record()
                     n = 0
@@ -229,35 +199,79 @@ def run(args, dev, rank: int, world: int):
                         n = ops.hessian_accumulate(x, h, n)
                     e1.record()
                     timings.append(("h", e0, e1))
-                    if last[k] == gi:
-                        done[k] = e1
-            with torch.cuda.stream(s_q):
-                for k in sorted(slots, key=lambda kk: last[kk]):           # widths in the order their stacks complete
-                    s_q.wait_event(done[k])
-                    stacks[k].record_stream(s_q)
+                with torch.cuda.stream(s_q):
+                    s_q.wait_event(e1)
+                    h.record_stream(s_q)
                     e2, e3 = ev(), ev()
                     e2.record()
-                    shared_list = ops.gptq_shared_factors(stacks[k], 0.01)
+                    shared = ops.gptq_shared_factor(h, 0.01, False)
                     e3.record()
                     timings.append(("f", e2, e3))
-                    for j, gi in enumerate(slots[k]):
-                        quantize_members(wave[gi][1], stacks[k][j], shared_list[j])
-    torch.cuda.synchronize()
-    t_quant = time.perf_counter() - t0
-    fence()
-    t1 = time.perf_counter()
-    gathered, nbytes = gather_device_results(specs, plan, results)
-    fence()
-    t_gather = time.perf_counter() - t1
-    wall = t_quant + t_gather
-    t_h = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "h")
-    t_f = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "f")
-    t_l = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "l")
+                    quantize_members(members, h, shared)
+        else:
+            # waves of `factor_wave` layers: the Hessians of a wave accumulate into one stack per input width, and each stack
+            # is factored in lock-step (oq_gptq_factor_batched_f32: the latency of ONE chain of diagonal blocks for the whole
+            # stack) while the Hessian stream is already on the next wave
+            inputs_per_layer = max(1, len({sp.hessian_key for sp in specs}) // max(1, args.layers))     # of the MODEL, not of this rank's share
+            per_wave = max(1, args.factor_wave * inputs_per_layer)
+            for w0 in range(0, len(groups), per_wave):
+                wave = groups[w0:w0 + per_wave]
+                s_q = q_streams[(w0 // per_wave) % len(q_streams)]
+                slots, last = {}, {}
+                for gi, (key, members) in enumerate(wave):
+                    k = specs[members[0]].k
+                    slots.setdefault(k, []).append(gi)
+                    last[k] = gi
+                with torch.cuda.stream(s_h):
+                    stacks = {k: torch.zeros((len(g), k, k), device=dev) for k, g in slots.items()}
+                    done = {}
+                    for gi, (key, members) in enumerate(wave):
+                        k = specs[members[0]].k
+                        h = stacks[k][slots[k].index(gi)]
+                        e0, e1 = ev(), ev()
+                        e0.record()
+                        n = 0
+                        for x in acts[k]:
+                            n = ops.hessian_accumulate(x, h, n)
+                        e1.record()
+                        timings.append(("h", e0, e1))
+                        if last[k] == gi:
+                            done[k] = e1
+                with torch.cuda.stream(s_q):
+                    for k in sorted(slots, key=lambda kk: last[kk]):           # widths in the order their stacks complete
+                        s_q.wait_event(done[k])
+                        stacks[k].record_stream(s_q)
+                        e2, e3 = ev(), ev()
+                        e2.record()
+                        shared_list = ops.gptq_shared_factors(stacks[k], 0.01)
+                        e3.record()
+                        timings.append(("f", e2, e3))
+                        for j, gi in enumerate(slots[k]):
+                            quantize_members(wave[gi][1], stacks[k][j], shared_list[j])
+        torch.cuda.synchronize()
+        t_quant = time.perf_counter() - t0
+        fence()
+        t1 = time.perf_counter()
+        gathered, nbytes = gather_device_results(specs, plan, results)
+        fence()
+        t_gather = time.perf_counter() - t1
+        wall = t_quant + t_gather
+        t_h = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "h")
+        t_f = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "f")
+        t_l = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "l")
+
+        return {"wall": wall, "t_quant": t_quant, "t_gather": t_gather, "t_h": t_h, "t_f": t_f, "t_l": t_l, "results": results,
+                "samples": samples, "gathered": gathered, "nbytes": nbytes, "one_stream": one_stream, "n_streams": len(q_streams)}
+
+    first = model_pass(args.mode)
+    n_gathered = len(first["gathered"]) if first["gathered"] is not None else -1
+    wall, t_quant, t_gather, t_h, t_f, t_l = (first[k] for k in ("wall", "t_quant", "t_gather", "t_h", "t_f", "t_l"))
+    results, samples, gathered, nbytes, one_stream = (first[k] for k in ("results", "samples", "gathered", "nbytes", "one_stream"))
 
     # ---- outside the timed region: what was emitted against the fused RTN kernel and the reference's digest
     verify = {"mode": args.mode, "shapes": [], "kat_4096_digest_ok": None}
     ok = True
-    for (k, n), (i, w) in sorted(samples.items()):
+    for (k, n), (i, w, _) in sorted(samples.items()):
         packed = results[i][0]
         rq, rs, rz = ops.rtn_quantize(w, "int4", "group", 128)
         same_q = bool(torch.equal(packed, ops.pack_nibbles(rq)))
@@ -348,6 +362,67 @@ def run(args, dev, rank: int, world: int):
         ops.hessian_set_method(saved)
         del hw
 
+    # ---- further whole-model passes on the same data (every rank takes part: the passes end in the same gather)
+    n_params = sum(sp.k * sp.n for sp in specs)
+    extras = [e for e in args.extra_passes.split(",") if e]
+    headline_method = ops.hessian_method()
+    del gathered
+    results = first["results"] = first["gathered"] = None
+    corrected, by_method = None, None
+
+    def reduce_max(vals):
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    if "corrected" in extras and args.mode == "parity":
+        torch.cuda.empty_cache()
+        cp = model_pass("corrected")
+        cw, ch, cf, cl = reduce_max([cp["wall"], cp["t_h"], cp["t_f"], cp["t_l"]])
+        # gptq.py:186-208 as intended: the layer OUTPUT error ||X W - X W^||_F of the first layer of every shape must be
+        # below RTN's on the same weight (what tests/test_gptq_gpu.py::test_gptq_corrected_mode_vs_oracle asserts on a
+        # small layer); X = 4096 calibration rows of the layer's own input, float64 products (checker, outside the clock)
+        shapes_c, ok_c = [], True
+        for (k, n), (i, w, q) in sorted(cp["samples"].items()):
+            x = acts[k][0].reshape(-1, k)[:4096].double()
+            _, sc, zc = cp["results"][i]
+            dq = ops.dequantize(q, sc.reshape(-1), zc.reshape(-1), "int4", mode="group", group=128)
+            rq, rs, rz = ops.rtn_quantize(w, "int4", "group", 128)
+            dr = ops.dequantize(rq, rs.reshape(-1), rz.reshape(-1), "int4", mode="group", group=128)
+            ref = x @ w.double()
+            e_g = float(torch.linalg.norm(x @ dq.double() - ref))
+            e_r = float(torch.linalg.norm(x @ dr.double() - ref))
+            changed = float((q != rq).float().mean())
+            shapes_c.append({"k": k, "n": n, "layer": specs[i].name, "output_err_gptq": e_g, "output_err_rtn": e_r,
+                             "ratio": round(e_g / e_r, 4), "integers_changed_vs_rtn": round(changed, 4)})
+            ok_c = ok_c and e_g < e_r and changed > 0.0
+            del x, dq, dr, ref
+        flag_c = torch.tensor([1 if ok_c else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag_c, op=dist.ReduceOp.MIN)
+        corrected = {"mode": "corrected", "what": "same model, GPTQConfig(mode='corrected'): the error-correcting block / row loop "
+                     "(gptq.py:153-208 with the upper factor's rows, the update GPTQ intends) + lazy batch updates on the fp32 MFMA GEMM",
+                     "value": round(n_params / cw / 1e6, 2), "unit": "M-param/s",
+                     "seconds": {"wall": round(cw, 3), "hessian_ms_max_rank": round(ch, 1), "factor_ms_max_rank": round(cf, 1),
+                                 "loop_ms_max_rank": round(cl, 1)},
+                     "verified": bool(int(flag_c.item())), "verification": shapes_c}
+        del cp
+    if "f32" in extras and headline_method != "f32":
+        torch.cuda.empty_cache()
+        ops.hessian_set_method("f32")
+        fp = model_pass("parity")
+        ops.hessian_set_method(headline_method)
+        fw, fh, ff, fl = reduce_max([fp["wall"], fp["t_h"], fp["t_f"], fp["t_l"]])
+        del fp
+        by_method = {headline_method: {"wall_s": round(float(wall), 3), "hessian_ms": round(float(t_h), 1),
+                                       "hessian_dtype": "fp16x2 pieces of fp32 operands (22 significand bits, lo*lo dropped), fp32 accumulate"
+                                       if headline_method in ("auto", "f16x3") else headline_method},
+                     "f32": {"wall_s": round(fw, 3), "hessian_ms": round(fh, 1), "factor_ms": round(ff, 1), "loop_ms": round(fl, 1),
+                             "value": round(n_params / fw / 1e6, 2), "unit": "M-param/s",
+                             "hessian_dtype": "f32 operands on v_mfma_f32_32x32x2_f32: the arithmetic class of the reference's sgemm"}}
+    torch.cuda.empty_cache()
+
     stats = torch.tensor([wall, t_quant, t_gather, t_h, t_f, t_l], dtype=torch.float64, device=dev)
     ranks_seen = torch.ones(1, dtype=torch.int32, device=dev)
     if world > 1:
@@ -356,16 +431,20 @@ def run(args, dev, rank: int, world: int):
     if rank != 0:
         return None
     params = sum(s.k * s.n for s in specs)
-    assert gathered is not None and len(gathered) == len(specs)
+    assert n_gathered == len(specs)
     wall = float(stats[0])
     flops_exec = float(sum(args.tokens * specs[i].k ** 2 for i in {specs[j].hessian_key: j for j in range(len(specs))}.values()))
     out = {
         "metric": "M-params quantized/sec, GPTQ QInt4 group-128, Llama-2-7B MatMul weights",
         "value": round(params / wall / 1e6, 2), "unit": "M-param/s", "n_gpus": world, "ranks_seen": int(ranks_seen.item()),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        # what the dominant kernel (the Hessian, 87 % of the wall) computes in; the factor and the loop are fp32
+        "dtype": {"auto": "fp16x2 pieces of fp32 operands, fp32 accumulate (Hessian); f32 elsewhere", "f16x3": "fp16x2 pieces of fp32 operands, fp32 accumulate (Hessian); f32 elsewhere",
+                  "bf16x6": "bf16x3 pieces of fp32 operands, fp32 accumulate (Hessian); f32 elsewhere", "bf16x9": "bf16x3 pieces of fp32 operands, fp32 accumulate (Hessian); f32 elsewhere"}.get(ops.hessian_method(), "f32"),
+        "data": "synthetic",
         "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
                    "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
-                   "streams": 1 if one_stream else 1 + len(q_streams), "factor_wave_layers": args.factor_wave,
+                   "streams": 1 if one_stream else 1 + first["n_streams"], "factor_wave_layers": args.factor_wave,
                    "hessian_method": ops.hessian_method()},
         "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
                     "gather": round(float(stats[2]), 4),
@@ -378,6 +457,8 @@ def run(args, dev, rank: int, world: int):
         "verified": verify["verified"], "verification": verify,
         "roofline": roofs[0] if roofs else None,
         "roofline_by_method": roofs,
+        "corrected": corrected,
+        "wall_by_hessian_method": by_method,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -265,7 +265,11 @@ int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, 
  *     group_size: the reference's loop value; > 0 re-derives per-column (scale, zp) from rows
  *                 [r, r+group_size) of W whenever r % group_size == 0 (gptq.py:168-184); <= 0: never.
  *     init_scale/init_zp: the parameters computed before the loop (gptq.py:104-116), init_count = 1 (tensor) or N.
- *     block_size: gptq.py:153; blocks taller than 128 rows are processed as 128-row blocks.
+ *     block_size: gptq.py:153, any value > 0.  A launch walks <= 128 rows; a taller block is a chain of such launches on a
+ *                 working copy of its rows (the reference's W1) that alone receives the in-block updates, while group
+ *                 parameters are read from W as it stood when the block began -- the reference's semantics.  OQ_GPTQ_CORRECTED
+ *                 with block_size <= 128 additionally defers the update of everything behind a SUPER-block of up to 512 rows
+ *                 (a multiple of block_size and group_size) to one product with Kd = 512: the same sums, grouped differently.
  *     Outputs: q_int_out [K, N] one value per byte; q_deq_out [K, N] fp32 (the dequantized rows the final qparams
  *     are re-derived from, gptq.py:219-231); used_scale/used_zp [ceil(K/group_size), N] = the parameters actually
  *     applied per (k-group, column) (NULL to skip; only written when group_size > 0).

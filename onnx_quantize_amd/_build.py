@@ -84,5 +84,7 @@ def build(force: bool = False, verbose: bool = True, extra_flags: tuple = ()) ->
 if __name__ == "__main__":
     if "--attribution" in sys.argv:          # never the shipped library: forces a full rebuild with the lab switches compiled in
         build(force=True, extra_flags=("-DOQ_RTN_ATTRIBUTION",))
+    elif "--define" in sys.argv:             # lab builds on a GPU box's scratch copy: --define NAME [--define NAME ...]
+        build(force=True, extra_flags=tuple("-D" + sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--define"))
     else:
         build(force="--force" in sys.argv)
