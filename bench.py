@@ -24,6 +24,8 @@ reported as the `gather` object.
 Prints ONE JSON line (contract in the task description) with these extra objects:
   roofline      algorithmic bytes per launch / measured launch duration vs the 8 TB/s HBM peak
   cpu_baseline  the NumPy oracle (oracle/oq_oracle.py) timed on the host, rank 0 at N=1 only
+  model_rtn     a whole model's weights in one call: Llama-2-7B's 224 MatMul weights resident in HBM through
+                oq_rtn_quantize_ptrs_f32 (one launch per distinct shape), HIP events, fraction of the HBM peak
   seam          host -> host throughput through the plugin seam (qrules/_common.py:126-142) on the same configuration:
                 round-1 route ([K,N] kernel, 45 MB download, second round trip for the packer) vs the device-resident
                 seam (seam.py: one upload, fused blob kernel, one download), digest-checked
@@ -269,6 +271,97 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
             "note": "every route is timed on fresh host arrays (memory the GPU has not mapped yet), as a model's weights are"}
 
 
+# ------------------------------------------------------------------------------------------------ a model's weights in one call
+def model_rtn_bench(dev, layout: str, headline_out, w_headline, layers: int = 32) -> dict:
+    """RTN uint4 g128 of every MatMul weight of a Llama-2-7B-shaped model (q/k/v/o 4096x4096, gate/up 4096x11008, down
+    11008x4096, x 32 layers = 224 matrices, 6.48 B parameters) resident in HBM, through `ops.rtn_quantize_many`
+    (oq_rtn_quantize_ptrs_f32): what replaces the reference's per-node loop (qrules/_common.py:126-142) for a device-resident
+    model.  Timed with HIP events on the launch stream around the second call (the first warms the allocator); the per-matrix
+    loop over `ops.rtn_quantize` on the same weights is timed next to it; outputs of one matrix per shape are compared bit for
+    bit with the single-matrix entry point, and the 4096 x 11008 KAT2 matrix is one of the weights (checked against the
+    headline run's output)."""
+    import torch
+
+    from onnx_quantize_amd.hip import ops
+
+    gen = torch.Generator(device=dev).manual_seed(5)
+    shapes = [(4096, 4096)] * 4 + [(4096, 11008)] * 2 + [(11008, 4096)]
+    base = {sh: torch.randn(sh, generator=gen, device=dev) * 0.02 for sh in set(shapes)}
+    ws = []
+    for layer in range(layers):
+        for j, sh in enumerate(shapes):
+            if layer == 0 and j == 4:
+                ws.append(w_headline)                                # the KAT2 matrix rides along
+            else:
+                ws.append(base[sh].clone())                          # distinct buffers: 25.9 GB, nothing is served from a cache
+    params = sum(w.numel() for w in ws)
+    n_ws = len(ws)
+    groups = params // GROUP
+    alg = params * 4 + params // 2 + groups * 5
+    ops.rtn_quantize_many(ws, "uint4", GROUP, layout=layout)         # warm-up (allocator, table upload path)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    res = ops.rtn_quantize_many(ws, "uint4", GROUP, layout=layout)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    ok = True
+    for i in (0, 4, 6):                                              # one matrix per shape against the single-matrix entry point
+        q, s, z = ops.rtn_quantize(ws[i], "uint4", "group", GROUP, layout=layout)
+        ok = ok and bool(torch.equal(q.reshape(-1), res[i][0].reshape(-1)) and torch.equal(s.reshape(-1), res[i][1].reshape(-1)) and
+                         torch.equal(z.reshape(-1), res[i][2].reshape(-1)))
+    ok = ok and bool(torch.equal(res[4][0].reshape(-1), headline_out[0].reshape(-1)))
+    del res
+    torch.cuda.synchronize()
+    l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    l0.record()
+    keep = [ops.rtn_quantize(w, "uint4", "group", GROUP, layout=layout) for w in ws]   # outputs kept: every matrix writes its own 24 MB
+    l1.record()
+    torch.cuda.synchronize()
+    loop_ms = l0.elapsed_time(l1)
+    del keep
+    gbs = alg / (dev_ms * 1e-3) / 1e9
+    del ws, base
+    torch.cuda.empty_cache()
+    # the small-matrix regime: gemma-3-270m's 126 MatMul weights (18 layers x {q 640x1024, k / v 640x256, o 1024x640, gate / up
+    # 640x2048, down 2048x640}; 100 M parameters), int8 g128 (the examples' RTN configuration): one launch per shape
+    gshapes = [(640, 1024), (640, 256), (640, 256), (1024, 640), (640, 2048), (640, 2048), (2048, 640)]
+    gws = [torch.randn(sh, generator=gen, device=dev) * 0.05 for _ in range(18) for sh in gshapes]
+    gparams = sum(w.numel() for w in gws)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        r = fn()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1), r
+    g_many_ms, g_many = timed(lambda: ops.rtn_quantize_many(gws, "int8", GROUP, layout="kn"))
+    g_loop_ms, g_loop = timed(lambda: [ops.rtn_quantize(w, "int8", "group", GROUP, layout="kn") for w in gws])
+    g_ok = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) for a, b in zip(g_many, g_loop))
+    small = {"what": "gemma-3-270m's 126 MatMul weights (100 M parameters), int8 g128, [K,N] layout: ops.rtn_quantize_many (one launch "
+                     "per distinct shape: 5) against the per-matrix loop",
+             "matrices": len(gws), "params": gparams, "one_call_device_ms": round(g_many_ms, 3), "per_matrix_loop_device_ms": round(g_loop_ms, 3),
+             "speedup": round(g_loop_ms / g_many_ms, 2), "equals_per_matrix_outputs": bool(g_ok)}
+    del gws, g_many, g_loop
+    return {"small_matrices": small,
+            "what": "Llama-2-7B's 224 MatMul weights (6.48 B parameters, 25.9 GB fp32) resident in HBM, uint4 g128, ONE call: "
+                    "ops.rtn_quantize_many -> oq_rtn_quantize_ptrs_f32 (a device table of pointers, ~1.6e8 parameters per launch; the call's own "
+                    "allocations and table upload are inside the timed region); at this footprint every matrix' 24 MB of output is really "
+                    "written to HBM, while the single headline matrix' output stays in the 256 MiB Infinity Cache",
+            "out_layout": layout, "matrices": n_ws, "params": params,
+            "device_ms": round(dev_ms, 3), "host_wall_ms": round(wall * 1e3, 3),
+            "value": round(params / (dev_ms * 1e-3) / 1e6, 1), "unit": "M-param/s",
+            "algorithmic_bytes": alg, "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "per_matrix_loop_device_ms": round(loop_ms, 3), "per_matrix_loop_frac": round(alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "equals_single_matrix_outputs": ok}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -286,6 +379,7 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="time only the headline configuration (used under rocprofv3)")
     ap.add_argument("--no-gptq", action="store_true", help="skip the `gptq` object (configs 4 / 5)")
     ap.add_argument("--no-seam", action="store_true", help="skip the `seam` object")
+    ap.add_argument("--no-model-rtn", action="store_true", help="skip the `model_rtn` object (224 Llama-2-7B weights in one call)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the `calibration` object (config 3 stand-in)")
     ap.add_argument("--gptq-extra-passes", default="corrected,f32",
                     help="further whole-model GPTQ passes of the `gptq` object (bench_gptq.py --extra-passes)")
@@ -433,6 +527,12 @@ def main() -> None:
                    "equals_single_launch_output": same}
         del wb, qb, sb, zb, bws
 
+    # a whole model's weights in one call: Llama-2-7B's 224 MatMul weights resident in HBM (25.9 GB fp32), uint4 g128, through
+    # oq_rtn_quantize_ptrs_f32 -- one launch per distinct shape (3), a device table of pointers instead of a per-node loop
+    model_rtn = None
+    if world == 1 and not args.qparams_only and not args.no_extras and not args.no_model_rtn and not args.symmetric:
+        model_rtn = model_rtn_bench(dev, args.layout, outs[0], w_src)
+
     t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
     ranks_seen = torch.ones(1, dtype=torch.int32, device=dev)
     if world > 1:
@@ -541,6 +641,7 @@ def main() -> None:
                    "out_layout": args.layout, "rotating_buffers": max(1, args.rotate), "matrices_per_step_per_gpu": 1},
         "verified_vs_reference_digest": verified,
         "batched_launch": batched,
+        "model_rtn": model_rtn,
         "other_layout": None if other_us is None else {
             "out_layout": other, "launch_us": round(other_us, 2),
             "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -99,6 +99,26 @@ int32_t oq_rtn_quantize_batched_f32(const float* W, int64_t batch, int64_t w_str
                                     void* zp_out, int32_t layout, void* workspace, size_t workspace_bytes,
                                     void* stream);
 
+/* A1 over a LIST of equally shaped matrices that live anywhere in device memory (the MatMul weights of a model: the
+ *     reference walks them node by node, qrules/_common.py:126-142): entry i of the table holds the four device pointers
+ *     of matrix i -- W [K, N] fp32 with leading dimension ldw, q_out (K*N bytes resp. the blob), scale_out / zp_out
+ *     (N*K/g entries).  About 1.6e8 parameters share a launch (blockIdx.y = entry; 9 matrices of 4096 x 4096, 3 of
+ *     4096 x 11008, hundreds of gemma-sized ones): rounds of waves merge across matrices and small matrices are not
+ *     launch-bound (measured per shape in rtn.hip).  Per matrix the result is bit-identical to oq_rtn_quantize_f32.
+ *     `table_host` and `table_device` are the same `count` entries in host and device memory (the host copy is what the
+ *     alignment checks read; the kernels read the device copy, which may be NULL when count == 1).  Group strategy, K % group_size == 0, group_size <= 256;
+ *     every W and q_out 16-byte aligned.  Workspace: oq_rtn_batched_workspace_bytes(count, K, N, group_size). */
+typedef struct {
+    const float* W;
+    void* q_out;
+    float* scale_out;
+    void* zp_out;
+} oq_rtn_ptrs;
+int32_t oq_rtn_quantize_ptrs_f32(const oq_rtn_ptrs* table_host, const oq_rtn_ptrs* table_device, int64_t count, int64_t K,
+                                 int64_t N, int64_t ldw, int32_t qtype, int64_t group_size, int32_t symmetric,
+                                 int32_t reduce_range, float clip_ratio, int32_t layout, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+
 /* Q2  core/_algorithms/utils.py:302-348  _compute_qparams_from_array on [K, N] weights (no integer
  *     output): same arguments and outputs as above minus q_out. */
 int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,

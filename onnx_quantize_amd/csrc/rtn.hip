@@ -39,6 +39,13 @@ __device__ __forceinline__ uint32_t fast_divmod(uint32_t n, const FastDiv& f, ui
     return q;
 }
 
+struct RtnPtrs {   // mirrors oq_rtn_ptrs (include/oq_hip.h): the four device pointers of one matrix of a list
+    const float* W;
+    uint8_t* q;
+    float* scale;
+    uint8_t* zp;
+};
+
 struct RtnArgs {
     const float* W;
     int64_t K, N, ldw;
@@ -63,6 +70,7 @@ struct RtnArgs {
     uint32_t pair_owner;  // fused kernel, direct parameter stores: wave (inside its group) that stores pair p, 3 bits each
     // strided batch (oq_rtn_quantize_batched_f32): matrix b lives at base + b * stride (elements / bytes as noted)
     int64_t w_stride, q_stride, p_stride;  // fp32 elements of W; bytes of q; entries of scale / zp (also of the staging)
+    const RtnPtrs* table;  // list of matrices (oq_rtn_quantize_ptrs_f32): matrix b = table[b] instead of base + b * stride
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -150,10 +158,15 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     const uint32_t mat = blockIdx.y;   // strided batch: x runs fastest, so the tail of one matrix overlaps the head of the next
     const uint32_t bid = blockIdx.x;
     RtnArgs a = a_in;
-    a.W += static_cast<int64_t>(mat) * a.w_stride;
-    if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
-    a.scale += static_cast<int64_t>(mat) * a.p_stride;
-    a.zp += static_cast<int64_t>(mat) * a.p_stride;
+    if (a.table != nullptr) {   // wave-uniform: four scalar loads
+        const RtnPtrs p = a.table[mat];
+        a.W = p.W; a.q = p.q; a.scale = p.scale; a.zp = p.zp;
+    } else {
+        a.W += static_cast<int64_t>(mat) * a.w_stride;
+        if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
+        a.scale += static_cast<int64_t>(mat) * a.p_stride;
+        a.zp += static_cast<int64_t>(mat) * a.p_stride;
+    }
     if (a.scale_t) { a.scale_t += static_cast<int64_t>(mat) * a.p_stride; a.zp_t += static_cast<int64_t>(mat) * a.p_stride; }
     uint32_t col_tile, row_tile;
     tile_of_block(a, bid, nblk, row_tile, col_tile);
@@ -439,10 +452,15 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
     const uint32_t mat = blockIdx.y;   // strided batch: x runs fastest, so the tail of one matrix overlaps the head of the next
     const uint32_t bid = blockIdx.x;
     RtnArgs a = a_in;
-    a.W += static_cast<int64_t>(mat) * a.w_stride;
-    if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
-    a.scale += static_cast<int64_t>(mat) * a.p_stride;
-    a.zp += static_cast<int64_t>(mat) * a.p_stride;
+    if (a.table != nullptr) {   // wave-uniform: four scalar loads
+        const RtnPtrs p = a.table[mat];
+        a.W = p.W; a.q = p.q; a.scale = p.scale; a.zp = p.zp;
+    } else {
+        a.W += static_cast<int64_t>(mat) * a.w_stride;
+        if (a.q) a.q += static_cast<int64_t>(mat) * a.q_stride;
+        a.scale += static_cast<int64_t>(mat) * a.p_stride;
+        a.zp += static_cast<int64_t>(mat) * a.p_stride;
+    }
     uint32_t col_tile, row_tile;
     tile_of_block(a, bid, nblk, row_tile, col_tile);
 
@@ -1195,9 +1213,23 @@ int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, in
     return check_launch("quantize_kn");
 }
 
+// oq_rtn_quantize_ptrs_f32: matrices of one shape per launch.  Measured with a model's worth of weights and DISTINCT outputs
+// in HBM (scripts/quick_many3.py; uint4 g128 blob, fraction of the 8 TB/s peak at 1 / best / all matrices per launch):
+//   2048 x 2048   0.18 / 0.73 (16) / 0.70      4096 x 4096    0.54 / 0.72 (8-16) / 0.69      8192 x 8192  0.56 / 0.59 / 0.59
+//   4096 x 11008  0.62 / 0.63 (2-4) / 0.58     11008 x 4096   0.64 / 0.67 (4-8) / 0.63
+// A lone small matrix cannot fill the chip (4096 waves on 5120 slots all start and end together); very long merged launches
+// of large matrices lose a little again (dirty output lines evicted between another matrix' reads instead of written back
+// in a burst at a kernel's end).  ~1.6e8 parameters per launch sits at or next to the best point of every row.
+static int64_t matrices_per_launch(int64_t K, int64_t N, int64_t count) {
+    int64_t m = 160000000 / (K * N);
+    if (m > 65535) m = 65535;   // blockIdx.y
+    if (m < 1) m = 1;
+    return m < count ? m : count;
+}
+
 // Strided batch of equally shaped matrices for the fused group kernel (set by oq_rtn_quantize_batched_f32 around
 // its call of rtn_impl; 1 matrix otherwise).
-struct BatchCtx { int64_t count = 1, w_stride = 0, q_stride = 0; };
+struct BatchCtx { int64_t count = 1, w_stride = 0, q_stride = 0; const RtnPtrs* table = nullptr; };
 static thread_local BatchCtx g_batch;
 
 int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
@@ -1261,7 +1293,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
             a.scale_t = nullptr; a.zp_t = nullptr; a.wpg = 1; a.stage_q = 0; a.pair_owner = 0;
             const int64_t batch = g_batch.count;
-            a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups;
+            a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups; a.table = g_batch.table;
             const int lpr = static_cast<int>(1024 / g);
             int wpb = tw.wpb > 0 ? tw.wpb : 4;
             if (wpb > kMaxWaves) wpb = kMaxWaves;
@@ -1303,7 +1335,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
         a.scale_t = nullptr; a.zp_t = nullptr;
         const int64_t batch = g_batch.count;
-        a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups;
+        a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups; a.table = g_batch.table;
         static const Tuning tune_s = Tuning::from_env();
         const bool want_stage = tune_s.stage >= 0 ? tune_s.stage != 0 : layout != OQ_LAYOUT_NBITS;
         const bool staged = want_stage && vec4 && kgroups > 1 && workspace != nullptr &&
@@ -1439,6 +1471,39 @@ int32_t oq_rtn_quantize_batched_f32(const float* W, int64_t batch, int64_t w_str
                       workspace, workspace_bytes, stream, true);
     oq::g_batch = oq::BatchCtx();
     return st;
+}
+
+int32_t oq_rtn_quantize_ptrs_f32(const oq_rtn_ptrs* table_host, const oq_rtn_ptrs* table_device, int64_t count, int64_t K, int64_t N,
+                                 int64_t ldw, int32_t qtype, int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio,
+                                 int32_t layout, void* workspace, size_t workspace_bytes, void* stream) {
+    static_assert(sizeof(oq::RtnPtrs) == sizeof(oq_rtn_ptrs), "device view of oq_rtn_ptrs");
+    const int64_t per_launch = oq::matrices_per_launch(K, N, count);
+    OQ_REQUIRE(table_host && (table_device || per_launch == 1) && count >= 1, OQ_ERR_INVALID_ARGUMENT,
+               "oq_rtn_quantize_ptrs_f32: bad table / count %lld", (long long)count);
+    int64_t g;
+    int32_t st = oq::resolve_group(OQ_GROUP, K, group_size, &g);
+    if (st != OQ_OK) return st;
+    OQ_REQUIRE(K % g == 0, OQ_ERR_UNSUPPORTED, "oq_rtn_quantize_ptrs_f32 needs K %% group_size == 0");
+    int rpw = 0, wpg = 0;
+    OQ_REQUIRE(oq::fused_shape(g, &rpw, &wpg), OQ_ERR_UNSUPPORTED, "oq_rtn_quantize_ptrs_f32 needs a group the fused kernel holds (<= 256 rows)");
+    // the kernel variant is chosen from the alignment of ONE matrix: every entry has to meet what the first one promises
+    for (int64_t i = 0; i < count; ++i) {
+        const oq_rtn_ptrs& p = table_host[i];
+        OQ_REQUIRE(p.W && p.q_out && p.scale_out && p.zp_out, OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_ptrs_f32: null pointer in entry %lld", (long long)i);
+        OQ_REQUIRE(oq::aligned16(p.W) && oq::aligned16(p.q_out) && (reinterpret_cast<uintptr_t>(p.scale_out) & 3u) == 0, OQ_ERR_UNSUPPORTED,
+                   "oq_rtn_quantize_ptrs_f32: entry %lld is not 16-byte aligned", (long long)i);
+    }
+    // How many matrices share a launch (blockIdx.y = entry): oq::matrices_per_launch.
+    for (int64_t i = 0; i < count; i += per_launch) {
+        const int64_t m = count - i < per_launch ? count - i : per_launch;
+        oq::g_batch.count = m;
+        oq::g_batch.table = m > 1 ? reinterpret_cast<const oq::RtnPtrs*>(table_device) + i : nullptr;
+        st = oq::rtn_impl(table_host[i].W, K, N, ldw, qtype, OQ_GROUP, group_size, symmetric, reduce_range, clip_ratio, 0, table_host[i].q_out,
+                          table_host[i].scale_out, table_host[i].zp_out, layout, workspace, workspace_bytes, stream, true);
+        oq::g_batch = oq::BatchCtx();
+        if (st != OQ_OK) return st;
+    }
+    return OQ_OK;
 }
 
 }  // extern "C"

@@ -583,3 +583,33 @@ def test_random_configurations_against_the_oracle():
             assert torch.equal(s2.reshape(-1), s.reshape(-1)) and torch.equal(z2.reshape(-1), z.reshape(-1))
 
     run()
+
+
+@pytest.mark.parametrize("qtype,g,layout", [("uint4", 128, "nbits"), ("uint4", 64, "nbits"), ("int4", 128, "kn"), ("int8", 32, "kn"),
+                                            ("uint8", 128, "nbits"), ("uint4", 256, "kn")])
+def test_list_of_weights_in_one_call_equals_the_per_matrix_calls(qtype, g, layout):
+    """oq_rtn_quantize_ptrs_f32: a mixed-shape list -- repeated shapes, gemma-3-270m and Llama slices,
+    a strided view -- through `ops.rtn_quantize_many` gives, per matrix, the bits of `ops.rtn_quantize`."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    shapes = [(512, 384), (640, 2048), (512, 384), (2048, 640), (640, 1024), (512, 384), (1024, 4096), (640, 2048), (256, 132)]
+    ws = [torch.randn(sh, generator=gen, device="cuda") * (0.01 + 0.1 * i) for i, sh in enumerate(shapes)]
+    big = torch.randn((512, 1024), generator=gen, device="cuda")
+    ws.append(big[:, :384])                                              # row-major view with ldw = 1024: its own shape group
+    ws = [w for w in ws if w.shape[0] % g == 0]
+    many = ops.rtn_quantize_many(ws, qtype, g, layout=layout)
+    assert len(many) == len(ws)
+    for w, (q, s, z) in zip(ws, many):
+        q1, s1, z1 = ops.rtn_quantize(w, qtype, "group", g, layout=layout)
+        assert q.shape == q1.shape and q.dtype == q1.dtype and torch.equal(q, q1)
+        assert s.shape == s1.shape and torch.equal(s, s1)
+        assert z.shape == z1.shape and z.dtype == z1.dtype and torch.equal(z, z1)
+    sym = ops.rtn_quantize_many(ws[:3], qtype, g, symmetric=True, reduce_range=True, clip_ratio=0.9, layout=layout)
+    for w, (q, s, z) in zip(ws[:3], sym):
+        q1, s1, z1 = ops.rtn_quantize(w, qtype, "group", g, True, True, 0.9, layout=layout)
+        assert torch.equal(q, q1) and torch.equal(s, s1) and torch.equal(z, z1)
+    assert ops.rtn_quantize_many([], qtype, g) == []
+    with pytest.raises(ValueError):
+        ops.rtn_quantize_many([torch.zeros((g + g // 2, 8), device="cuda")], qtype, g)     # K % g != 0
