@@ -86,4 +86,16 @@ size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K);
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C,
                            void* workspace, size_t workspace_bytes, int terms, hipStream_t s);
 
+// Two-operand GEMM on fp16 pieces (syrk_bf16x3.hip, section 3): C = beta C + alpha A^T B for k-major A [Kd, M], B [Kd, N].
+//   make_f16x2_pieces      absmax -> power-of-two scale -> two fp16 pieces of every element, zero-padded to 32 contraction rows
+//                          and 256 columns; `pieces` (256-byte aligned, gemm_f16x3_pieces_bytes(Kd, cols)) holds the scale
+//                          header and the pieces.  contraction_is_fast_axis: the source is [cols, Kd] row-major (A = X^T).
+//   launch_gemm_f16x3      exactly one of C (store: alpha / beta like launch_gemm_tn) and loss_partial (one float per block
+//                          = gemm_f16x3_tiles(M, N): the sum of squares of that block's part of A^T B, nothing else written).
+size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols);
+int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s);
+int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
+                          int64_t ldc, float* loss_partial, hipStream_t s);
+int64_t gemm_f16x3_tiles(int64_t M, int64_t N);
+
 }  // namespace oq

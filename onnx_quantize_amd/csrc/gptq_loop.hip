@@ -718,6 +718,12 @@ static size_t coef_image_bytes(int64_t K, int64_t block_size) {
     return static_cast<size_t>(ceil_div(K, block_size) * launches_per_block(block_size)) * kCoefFloats * sizeof(float);
 }
 
+// operand pieces of the lazy batch update behind a super-block on the fp16-piece GEMM (gemm_tn.hpp): U rows x all columns, Err
+static size_t piece_gemm_bytes(int64_t K, int64_t N, int64_t block_size) {
+    const int64_t s = super_rows_bound(K, block_size);
+    return gemm_f16x3_pieces_bytes(s, K) + gemm_f16x3_pieces_bytes(s, N) + 1024;
+}
+
 size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size) {
     if (K <= 0 || N <= 0 || block_size <= 0) return 0;
     // Err [super-block rows, N] + carried (scale, zp) [N] + (mse) per-group parameters of one launch [128, N] x (4 + 1) B
@@ -725,7 +731,7 @@ size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size) {
     // + the coefficient images of all launches (rows-over-lanes kernel)
     const size_t tall = block_size > kLoopMaxRows ? static_cast<size_t>(block_size < K ? block_size : K) * N * 4 : 0;
     return static_cast<size_t>(super_rows_bound(K, block_size)) * N * 4 + static_cast<size_t>(N) * 8 + static_cast<size_t>(kLoopMaxRows) * N * 5 + tall +
-           coef_image_bytes(K, block_size) + oq_rtn_workspace_bytes(K, N, OQ_CHANNEL, -1, 1) + 4096;
+           coef_image_bytes(K, block_size) + piece_gemm_bytes(K, N, block_size) + oq_rtn_workspace_bytes(K, N, OQ_CHANNEL, -1, 1) + 4096;
 }
 
 int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size, int32_t symmetric,
@@ -768,6 +774,11 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
     wsp += (256 - reinterpret_cast<uintptr_t>(wsp) % 256) % 256;
     float* image = reinterpret_cast<float*>(wsp);                       // coefficient images of all launches
     wsp += coef_image_bytes(K, block_size);
+    wsp += (256 - reinterpret_cast<uintptr_t>(wsp) % 256) % 256;
+    char* pieces_a = wsp;                                               // fp16 pieces of U[s0:s_end, s_end:] ...
+    wsp += (gemm_f16x3_pieces_bytes(err_rows, K) + 255) / 256 * 256;
+    char* pieces_b = wsp;                                               // ... and of the super-block's Err
+    wsp += (gemm_f16x3_pieces_bytes(err_rows, N) + 255) / 256 * 256;
     char* mse_ws = wsp + (256 - reinterpret_cast<uintptr_t>(wsp) % 256) % 256;
     const size_t mse_ws_bytes = static_cast<size_t>(static_cast<char*>(workspace) + workspace_bytes - mse_ws);
     a.pre_scale = nullptr; a.pre_zp = nullptr; a.pre_first_group = 0;
@@ -879,7 +890,16 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
             g.B = a.err; g.ldb = N; g.N = N;
             g.C = W + s_end * N; g.ldc = N;
             g.Kd = s_end - s0; g.alpha = -1.0f; g.beta = 1.0f; g.sa = 1.0f; g.sb = 1.0f; g.upper_only = 0; g.mirror = 0;
-            st = launch_gemm_tn(g, s);
+            // Large products run on the fp16-piece GEMM (22-bit operands, fp32 accumulate: the Hessian's arithmetic, 3-5 x
+            // the fp32 MFMA rate); with OQ_HESSIAN_F32 selected -- the reference's arithmetic class throughout -- and for
+            // small problems the fp32 MFMA kernel.
+            if (oq_hessian_method() != OQ_HESSIAN_F32 && g.Kd >= 64 && g.M * g.N >= (int64_t{1} << 20)) {
+                st = make_f16x2_pieces(g.At, g.Kd, g.M, g.lda, false, pieces_a, s);
+                if (st == OQ_OK) st = make_f16x2_pieces(g.B, g.Kd, g.N, g.ldb, false, pieces_b, s);
+                if (st == OQ_OK) st = launch_gemm_f16x3(pieces_a, pieces_b, g.M, g.N, g.Kd, g.alpha, g.beta, g.C, g.ldc, nullptr, s);
+            } else {
+                st = launch_gemm_tn(g, s);
+            }
             if (st != OQ_OK) return st;
         }
     }

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __rest
     if (threadIdx.x == 0) partial[blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
 }
 
-// partial maxima -> scale[0] = s = 2^(15 - exponent of max) (1 for an all-zero or non-finite batch), scale[1] = 1 / s^2
+// partial maxima -> scale[0] = s = 2^(15 - exponent of max) (1 for an all-zero or non-finite batch), scale[1] = 1 / s^2, scale[2] = 1 / s
 __global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
     float m = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) m = nmax(m, partial[i]);
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restri
         }
         scale[0] = s;
         scale[1] = inv2;
+        scale[2] = 1.0f / s;   // exact: a power of two
     }
 }
 
@@ -401,40 +402,26 @@ __global__ __launch_bounds__(kSThreads) void syrk_pieces_kernel(const u32x4* __r
 // a wave's 64 x 128 tile is 4 x 8 tiles of 16 x 16.  Lane l supplies rows / columns i = l & 15 and the eight k-values of
 // chunk l >> 4 -- the same 16-byte vector P holds.  C/D map: col = l & 15, row = 4 (l >> 4) + e, e = 0..3.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
-                                                                 const float alpha_in, const float beta, float* __restrict__ C,
-                                                                 float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
-                                                                 const float* __restrict__ post_scale) {
+
+// The stage loop of the 16x16x32 kernels, shared by the SYRK (A = B = one piece array) and the two-operand GEMM
+// (gemm_f16x3_kernel).  gsrc[i]: where this wave's i-th 1 KB piece of stage 0 comes from; a stage further is
+// gsrc[i] + stage_bytes[i >= split ? 1 : 0] (the two operands may have different padded widths).  acc: the wave's 64 x 128
+// tile as 4 x 8 tiles of 16 x 16, zeroed here.
+template <int NDMA>
+__device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], const int64_t (&stage_bytes)[8], const int64_t nstages,
+                                                 unsigned char* lds, f32x4v (&acc)[4][8]) {
     using G = StageGeom<3>;
     static_assert(G::CH == 4 && G::RING == 2, "one 32-deep k-step per stage");
-    constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
+    constexpr int PIECES = 2;
     constexpr int kPlaneBytes = G::PLANE, kOperandBytes = G::OPERAND, kStageBytes = G::STAGE;
-    const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    int tile_m, tile_n;
-    upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles, tile_m, tile_n);
-    const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
-    const int64_t s_begin = static_cast<int64_t>(blockIdx.y) * stages_per_slice;
-    const int64_t s_end = s_begin + stages_per_slice < nstages_all ? s_begin + stages_per_slice : nstages_all;
-    const int64_t nstages = s_end - s_begin;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int kc = lane >> 4, cl = lane & 15;
-
-    const char* gsrc[8];
     uint32_t ldst[8];
 #pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-        const int q = wave * NDMA + i;
-        const int quarter = q & 3, cc = (q >> 2) % CH, pc = (q / (4 * CH)) % PIECES, op = q / (4 * CH * PIECES);
-        ldst[i] = static_cast<uint32_t>(q) * 1024u;
-        const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
-        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * CH + cc) * PIECES + pc) * Kp + colq);
-    }
-    const int64_t stage_bytes = static_cast<int64_t>(CH) * PIECES * Kp * 16;
+    for (int i = 0; i < NDMA; ++i) ldst[i] = static_cast<uint32_t>(wave * NDMA + i) * 1024u;
     auto stage_dma = [&](int64_t s_rel, int slot, int i) {
-        __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes,
+        __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes[i],
                                          (__attribute__((address_space(3))) void*)(lds + slot * kStageBytes + ldst[i]), 16, 0, 0);
     };
 #pragma unroll
@@ -442,7 +429,6 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_s_barrier();
 
-    f32x4v acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -515,6 +501,39 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __
             read_a(cur, 0);
         }
     }
+}
+
+__global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
+                                                                 const float alpha_in, const float beta, float* __restrict__ C,
+                                                                 float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
+                                                                 const float* __restrict__ post_scale) {
+    using G = StageGeom<3>;
+    constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
+    const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    int tile_m, tile_n;
+    upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles, tile_m, tile_n);
+    const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
+    const int64_t s_begin = static_cast<int64_t>(blockIdx.y) * stages_per_slice;
+    const int64_t s_end = s_begin + stages_per_slice < nstages_all ? s_begin + stages_per_slice : nstages_all;
+    const int64_t nstages = s_end - s_begin;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = lane >> 4, cl = lane & 15;
+
+    const char* gsrc[8];
+    int64_t stage_bytes[8];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int q = wave * NDMA + i;
+        const int quarter = q & 3, cc = (q >> 2) % CH, pc = (q / (4 * CH)) % PIECES, op = q / (4 * CH * PIECES);
+        const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
+        gsrc[i] = reinterpret_cast<const char*>(P + ((s_begin * CH + cc) * PIECES + pc) * Kp + colq);
+        stage_bytes[i] = static_cast<int64_t>(CH) * PIECES * Kp * 16;
+    }
+    f32x4v acc[4][8];
+    f16_m16_mainloop<NDMA>(gsrc, stage_bytes, nstages, lds, acc);
 
     float* out = slab ? slab + static_cast<int64_t>(blockIdx.y) * K * K : C;
     const bool direct = slab == nullptr;
@@ -539,6 +558,120 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __
                 }
             }
         }
+}
+
+// ---- 3. Two-operand GEMM on fp16 pieces: C = beta C + alpha A^T B, A [Kd, M] and B [Kd, N] both k-major (gemm_tn.hpp's
+// convention), each split into two fp16 pieces of its own power-of-two scaled elements (same pieces, same three products and
+// the same stage loop as the SYRK above: 22-bit operands, fp32 accumulate).  Users: the lazy batch updates of the corrected
+// GPTQ loop (gptq.py:208: W[i2:] -= U[i1:i2, i2:]^T Err, Kd = 512) and the AWQ / clip searches' X (W - W^) products
+// (pre_passes/awq.py:177, :247), whose squared-error loss is reduced in the epilogue without ever writing the [T, N] product.
+struct PieceGemm {
+    const u32x4* PA;        // pieces of A: [stage chunks][2][Mp] x 16 B   (Mp, Np: M, N padded to 256)
+    const u32x4* PB;
+    int64_t M, N, Mp, Np, nstages;
+    const float* scale_a;   // device: [s, 1 / s^2, 1 / s] of A (absmax_scale_kernel)
+    const float* scale_b;
+    float alpha, beta;
+    float* C;               // EPI 0: [M, N], leading dimension ldc
+    int64_t ldc;
+    float* partial;         // EPI 1: per-block sum of squares of the block's part of A^T B
+};
+
+template <int EPI>
+__global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g) {
+    using G = StageGeom<3>;
+    constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tiles_n = static_cast<int>(g.Np / kST);
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = lane >> 4, cl = lane & 15;
+    const char* gsrc[8];
+    int64_t stage_bytes[8];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int q = wave * NDMA + i;
+        const int quarter = q & 3, cc = (q >> 2) % CH, pc = (q / (4 * CH)) % PIECES, op = q / (4 * CH * PIECES);
+        const int64_t width = op ? g.Np : g.Mp;
+        const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
+        gsrc[i] = reinterpret_cast<const char*>((op ? g.PB : g.PA) + (static_cast<int64_t>(cc) * PIECES + pc) * width + colq);
+        stage_bytes[i] = static_cast<int64_t>(CH) * PIECES * width * 16;
+    }
+    f32x4v acc[4][8];
+    f16_m16_mainloop<NDMA>(gsrc, stage_bytes, g.nstages, lds, acc);
+    const float unscale = g.scale_a[2] * g.scale_b[2];   // 1 / (s_a s_b): exact, powers of two
+    if constexpr (EPI == 0) {
+        const float alpha = g.alpha * unscale;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t col = n0 + wn * 128 + j * 16 + cl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t row = m0 + wm * 64 + i * 16 + 4 * kc + e;
+                    if (row < g.M && col < g.N) {
+                        float v = alpha * acc[i][j][e];
+                        if (g.beta != 0.0f) v = g.beta * g.C[row * g.ldc + col] + v;
+                        g.C[row * g.ldc + col] = v;
+                    }
+                }
+            }
+    } else {
+        // rows / columns past M / N are zero pieces: their products are exact zeros, no masks
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[i][j][e] * unscale;
+                    sum += v * v;
+                }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        float* red = reinterpret_cast<float*>(lds);   // the ring is free behind the stage loop's last barrier
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < kSThreads / 64; ++w) t += red[w];   // fixed order: deterministic
+            g.partial[blockIdx.x] = t;
+        }
+    }
+}
+
+// Source with the contraction index as its FAST axis (X [T, K] row-major used as A = X^T: contraction over k, columns t):
+// pieces P[k / 8][piece][t padded to 256].  A thread takes one row t and 8 consecutive k (32 contiguous bytes).
+__global__ __launch_bounds__(256) void split_f16x2_fast_axis_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                                    const int64_t Tp, const int64_t nchunks, const float* __restrict__ scale,
+                                                                    u32x4* __restrict__ P) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const bool ok = t < T;
+    const float* src = X + (ok ? t : T - 1) * ldx;
+    const float sc = scale[0];
+    for (int64_t c = static_cast<int64_t>(blockIdx.y) * 4; c < nchunks && c < static_cast<int64_t>(blockIdx.y) * 4 + 4; ++c) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t k = c * 8 + r;
+            const float x = src[k < K ? k : K - 1];
+            v[r] = (k < K && ok) ? x * sc : 0.f;
+        }
+        u32x4 hi, lo;
+#pragma unroll
+        for (int rp = 0; rp < 4; ++rp) {
+            const f16x2 h2 = {static_cast<_Float16>(v[2 * rp]), static_cast<_Float16>(v[2 * rp + 1])};
+            hi[rp] = __builtin_bit_cast(uint32_t, h2);
+            lo[rp] = pk_f16(v[2 * rp] - static_cast<float>(h2[0]), v[2 * rp + 1] - static_cast<float>(h2[1]));
+        }
+        u32x4* o = P + (c * 2) * Tp + t;
+        o[0] = hi;
+        o[Tp] = lo;
+    }
 }
 
 constexpr int kAbsmaxBlocks = 2048;
@@ -631,5 +764,59 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     if (st != OQ_OK || splits == 1) return st;
     return launch_syrk_reduce(slab_f, splits, K, alpha, beta, C, kST, s, f16 ? scale : nullptr);
 }
+
+
+// ---- host side of the two-operand GEMM (gemm_tn.hpp)
+size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols) {
+    if (Kd <= 0 || cols <= 0) return 0;
+    return static_cast<size_t>(stages_of(Kd, StageGeom<3>::ROWS)) * StageGeom<3>::CH * 2 * padded_k(cols) * 16 + kScaleHeaderBytes;
+}
+
+int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s) {
+    OQ_REQUIRE(X && pieces && Kd > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT, "make_f16x2_pieces: bad argument");
+    float* scale = static_cast<float*>(pieces);
+    u32x4* P = reinterpret_cast<u32x4*>(static_cast<unsigned char*>(pieces) + kScaleHeaderBytes);
+    const int64_t Cp = padded_k(cols), nstages = stages_of(Kd, StageGeom<3>::ROWS), nchunks = nstages * StageGeom<3>::CH;
+    OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "make_f16x2_pieces: contraction too long (%lld)", (long long)Kd);
+    // absmax over the whole operand: rows x row length as stored
+    const int64_t rows = contraction_is_fast_axis ? cols : Kd, rowlen = contraction_is_fast_axis ? Kd : cols;
+    const int nb = static_cast<int>(rows < kAbsmaxBlocks ? rows : kAbsmaxBlocks);
+    hipLaunchKernelGGL(absmax_partial_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, X, rows, rowlen, ldx, scale + 4);
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
+    const dim3 grid(static_cast<uint32_t>(Cp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4)));
+    if (contraction_is_fast_axis)
+        hipLaunchKernelGGL(split_f16x2_fast_axis_kernel, grid, dim3(256), 0, s, X, cols, Kd, ldx, Cp, nchunks, scale, P);
+    else   // alpha = 0: no dead-channel guard (only the Hessian needs a vanishing sample to stay visible)
+        hipLaunchKernelGGL(split_f16x2_kernel, grid, dim3(256), 0, s, X, Kd, cols, ldx, Cp, nchunks, scale, 0.0f, P);
+    return check_launch("split_f16x2 (gemm pieces)");
+}
+
+int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
+                          int64_t ldc, float* loss_partial, hipStream_t s) {
+    OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && (C != nullptr) != (loss_partial != nullptr), OQ_ERR_INVALID_ARGUMENT,
+               "gemm_f16x3: bad argument");
+    PieceGemm g;
+    g.scale_a = static_cast<const float*>(pieces_a);
+    g.scale_b = static_cast<const float*>(pieces_b);
+    g.PA = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(pieces_a) + kScaleHeaderBytes);
+    g.PB = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(pieces_b) + kScaleHeaderBytes);
+    g.M = M; g.N = N; g.Mp = padded_k(M); g.Np = padded_k(N); g.nstages = stages_of(Kd, StageGeom<3>::ROWS);
+    g.alpha = alpha; g.beta = beta; g.C = C; g.ldc = ldc; g.partial = loss_partial;
+    const int64_t tiles = (g.Mp / kST) * (g.Np / kST);
+    OQ_REQUIRE(tiles < (1 << 30), OQ_ERR_UNSUPPORTED, "gemm_f16x3: too many tiles");
+    const int lds_bytes = StageGeom<3>::LDS;
+    if (loss_partial) {
+        OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
+                   OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
+        hipLaunchKernelGGL(gemm_f16x3_kernel<1>, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
+    } else {
+        OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
+                   OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
+        hipLaunchKernelGGL(gemm_f16x3_kernel<0>, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
+    }
+    return check_launch("gemm_f16x3_kernel");
+}
+
+int64_t gemm_f16x3_tiles(int64_t M, int64_t N) { return (padded_k(M) / kST) * (padded_k(N) / kST); }
 
 }  // namespace oq
