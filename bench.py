@@ -31,6 +31,7 @@ Prints ONE JSON line (contract in the task description) with these extra objects
                 seam (seam.py: one upload, fused blob kernel, one download), digest-checked
   calibration   BASELINE config 3 stand-in from the same run (bench_calib.run): 51 batches x 72 activation tensors through
                 MinMaxCalibrator.collect_many, `roofline` of oq::minmax_partial, a CPU baseline, `verified`
+  awq           the AWQ scale / clip searches of one 4096 x 4096 layer on own kernels (next row N2), verified in float64
   gptq          BASELINE configs 4 / 5 from the same run: GPTQ QInt4 g128 of all Llama-2-7B MatMul weights
                 (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`;
                 `corrected` = the same model with the error-correcting loop, `wall_by_hessian_method` = the whole-model
@@ -362,6 +363,51 @@ def model_rtn_bench(dev, layout: str, headline_out, w_headline, layers: int = 32
             "equals_single_matrix_outputs": ok}
 
 
+# ------------------------------------------------------------------------------------------------ AWQ searches
+def awq_bench(dev, k: int = 4096, n: int = 4096, t: int = 4096) -> dict:
+    """pre_passes/awq.py:114-184 / :207-259 on one Llama-2-7B-sized layer (q_proj: K = N = 4096, 4096 calibration rows), uint4
+    g128, device resident (oq_awq_scale_search_f32 / oq_awq_clip_search_f32: own kernels, the 20 / 10 products on the fp16-piece
+    GEMM with the loss reduced in its epilogue).  Verified: the winning candidate's loss recomputed in float64 from this
+    package's own RTN / dequantize kernels agrees within 2e-3."""
+    import torch
+
+    from onnx_quantize_amd.hip import ops
+
+    gen = torch.Generator(device=dev).manual_seed(9)
+    x = torch.randn((t, k), generator=gen, device=dev) * (0.1 + 3.9 * torch.rand(k, generator=gen, device=dev))
+    w = torch.randn((k, n), generator=gen, device=dev) * 0.02
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(reps):
+            r = fn()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / reps, r
+    ms_scale, (best_scale, losses) = timed(lambda: ops.awq_scale_search(x, w, "uint4", "group", GROUP))
+    ms_clip, (best_ratio, closses) = timed(lambda: ops.awq_clip_search(x, w, "uint4", "group", GROUP))
+    col = best_scale.reshape(-1, 1)
+    q, sc, zp = ops.rtn_quantize(w * col, "uint4", "group", GROUP)
+    w_hat = ops.dequantize(q, sc, zp, "uint4", mode="group", group=GROUP) / col
+    x64 = x[:1024].double()
+    ref = float(((x64 @ (w.double() - w_hat.double())) ** 2).mean())
+    sub = ops.awq_scale_search(x[:1024], w, "uint4", "group", GROUP)     # the same rows through the kernels
+    i = int(losses.argmin())
+    # the 1024-row search has its own statistics, so compare like with like: its loss at ITS winning scale
+    q2, s2, z2 = ops.rtn_quantize(w * sub[0].reshape(-1, 1), "uint4", "group", GROUP)
+    wh2 = ops.dequantize(q2, s2, z2, "uint4", mode="group", group=GROUP) / sub[0].reshape(-1, 1)
+    ref2 = float(((x64 @ (w.double() - wh2.double())) ** 2).mean())
+    ok = abs(float(sub[1].min()) - ref2) <= 2e-3 * ref2
+    return {"what": "AWQ scale search (20 candidates) and clip search (10 ratios) of one 4096 x 4096 layer with 4096 calibration rows, uint4 g128, "
+                    "device resident; round 2 (torch elementwise + rocBLAS): 23.4 / 11.2 ms",
+            "scale_search_ms": round(ms_scale, 3), "clip_search_ms": round(ms_clip, 3), "best_grid_point": i, "best_clip_ratio": best_ratio,
+            "loss_at_best": float(losses[i]), "loss_float64_check_rows": 1024, "loss_float64": ref2, "loss_kernel": float(sub[1].min()),
+            "verified": bool(ok), "unused_full_rows_reference": ref}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -380,6 +426,7 @@ def main() -> None:
     ap.add_argument("--no-gptq", action="store_true", help="skip the `gptq` object (configs 4 / 5)")
     ap.add_argument("--no-seam", action="store_true", help="skip the `seam` object")
     ap.add_argument("--no-model-rtn", action="store_true", help="skip the `model_rtn` object (224 Llama-2-7B weights in one call)")
+    ap.add_argument("--no-awq", action="store_true", help="skip the `awq` object (AWQ scale / clip searches of one layer)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the `calibration` object (config 3 stand-in)")
     ap.add_argument("--gptq-extra-passes", default="corrected,f32",
                     help="further whole-model GPTQ passes of the `gptq` object (bench_gptq.py --extra-passes)")
@@ -597,6 +644,10 @@ def main() -> None:
 
         calibration = bench_calib.run(dev, cpu=not args.no_cpu_baseline)
         torch.cuda.empty_cache()
+    awq = None
+    if world == 1 and not args.no_awq and not args.no_extras:
+        awq = awq_bench(dev)
+        torch.cuda.empty_cache()
     # ---- configs 4 / 5: GPTQ of a Llama-2-7B-shaped model from the same run (all ranks take part)
     gptq = None
     if not args.no_gptq and not args.no_extras:
@@ -653,6 +704,7 @@ def main() -> None:
         "seam": seam,
         "gather": gather,
         "calibration": calibration,
+        "awq": awq,
         "gptq": gptq,
     }
     if os.environ.get("OQ_BENCH_REHEARSAL", "0") == "1":

@@ -319,6 +319,32 @@ int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
                             void* q_out, int32_t layout, float* zero_point_out, int32_t* rounds_out,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* N2  pre_passes/awq.py:47-72, 114-184: AWQ's scale search for one layer, device resident.  X [T, K] calibration rows
+ *     (leading dimension ldx), W [K, N].  For the n_grid candidates i: s_i = clip(mean|x|^r / weight_scale^(1-r), 1e-4),
+ *     r = i / n_grid, normalised by sqrt(max * min); loss_i = mean((X W - X W^_i)^2) with W^_i = dequant(RTN(W * s_i)) / s_i
+ *     (rtn.py:54-109 with the given type / strategy / group size).  The loss is evaluated as || X (W - W^_i) ||^2 / (T N) by
+ *     ONE product per candidate on the matrix cores (fp16 pieces of fp32 operands, fp32 accumulate) whose epilogue squares
+ *     and sums: no [T, N] product is written.  Outputs (device): scales_out [n_grid, K], losses_out [n_grid], best_out =
+ *     the first minimum (awq.py:178).  4- / 8-bit types; group strategy needs group_size >= 16 dividing K.
+ *     Workspace (256-byte aligned): oq_awq_workspace_bytes(T, K, N). */
+size_t oq_awq_workspace_bytes(int64_t T, int64_t K, int64_t N);
+int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw,
+                                int32_t qtype, int32_t strategy, int64_t group_size, int32_t symmetric,
+                                int32_t reduce_range, int32_t n_grid, float* scales_out, float* losses_out,
+                                int32_t* best_out, void* workspace, size_t workspace_bytes, void* stream);
+/* N2  pre_passes/awq.py:207-259: the clip search: losses_out[i] (i = 0..9) = mean((X W - X dequant(RTN(W, clip_ratio =
+ *     1 - i / 100)))^2), best_out = the first minimum.  Same machinery and workspace as the scale search. */
+int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw,
+                               int32_t qtype, int32_t strategy, int64_t group_size, int32_t symmetric,
+                               int32_t reduce_range, float* losses_out, int32_t* best_out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+/* N2  pre_passes/smooth_quant.py:62-74, 104-113: scale_out[k] = max(max_t |x[t,k]|, 1e-5)^alpha /
+ *     (max_n |w[k,n]| + 1e-9)^(1 - alpha). */
+size_t oq_smooth_quant_workspace_bytes(int64_t K);
+int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N,
+                                  int64_t ldw, float alpha, float* scale_out, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* N3  qrules/_common.py:65-123: MatMulNBits zero-point packing [N, ceil(K/g / 2)] (pad nibble 0x8)
  *     from the per-group zero points [N*K/g] (1 byte each).  4-bit only. */
 int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out, void* stream);

@@ -1,0 +1,419 @@
+// N2: the numeric cores of the AWQ and SmoothQuant pre-passes for gfx950, device resident from the activations to the
+// winning grid point (reference: pre_passes/awq.py:47-72, 114-184, 207-259; pre_passes/smooth_quant.py:62-74, 104-113).
+//
+// The reference evaluates, for each of 20 scale candidates (10 clip ratios), loss = mean((X W - X W^)^2) with two NumPy
+// matmuls.  Here the loss is || X (W - W^) ||_F^2 / (T N): ONE product per candidate, on the matrix cores with fp16 pieces
+// (gemm_f16x3_kernel, 22-bit operands, fp32 accumulate), whose epilogue squares and sums the accumulators -- the [T, N]
+// product is never written.  The pieces of X are made once per layer; per candidate the passes over [K, N] memory are
+//   scale rows -> oq RTN kernels (rtn.hip) -> awq_diff_kernel (D = W - dequant / s, absmax partials) -> split -> GEMM.
+// Round 2 ran the same composition through torch elementwise kernels and rocBLAS (23.4 ms per 4096^3 layer, bound by 20
+// fp32 GEMMs of 137 GFLOP).
+#include "gemm_tn.hpp"
+#include "row_params.hpp"
+
+namespace oq {
+
+int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy, int64_t group_size, int32_t symmetric,
+                 int32_t reduce_range, float clip_ratio, int32_t mse, void* q_out, float* scale_out, void* zp_out, int32_t layout, void* workspace,
+                 size_t workspace_bytes, void* stream, bool emit_q);
+
+constexpr int kAwqMaxGrid = 64;
+constexpr int kColChunks = 64;   // row chunks of the column reductions
+
+// ---- column sums of |x| (awq.py:47-50) / column max of |x| (smooth_quant.py:62-69): partial[chunk][k]
+template <bool MAX>
+__global__ __launch_bounds__(256) void col_abs_partial_kernel(const float* __restrict__ X, int64_t T, int64_t K, int64_t ldx, float* __restrict__ partial) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int64_t per = (T + static_cast<int64_t>(gridDim.y) - 1) / static_cast<int64_t>(gridDim.y);
+    const int64_t t0 = static_cast<int64_t>(blockIdx.y) * per, t1 = t0 + per < T ? t0 + per : T;
+    float acc = 0.f;
+    int64_t t = t0;
+    for (; t + 3 < t1; t += 4) {   // four loads in flight per lane
+        const float a = fabsf(X[t * ldx + k]), b = fabsf(X[(t + 1) * ldx + k]), c = fabsf(X[(t + 2) * ldx + k]), d = fabsf(X[(t + 3) * ldx + k]);
+        if constexpr (MAX) acc = nmax(nmax(acc, a), nmax(b, nmax(c, d)));
+        else acc += (a + b) + (c + d);
+    }
+    for (; t < t1; ++t) {
+        const float a = fabsf(X[t * ldx + k]);
+        if constexpr (MAX) acc = nmax(acc, a); else acc += a;
+    }
+    partial[static_cast<int64_t>(blockIdx.y) * K + k] = acc;
+}
+
+template <bool MAX>
+__global__ __launch_bounds__(256) void col_abs_finish_kernel(const float* __restrict__ partial, int chunks, int64_t K, float inv_count, float* __restrict__ out) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        const float v = partial[static_cast<int64_t>(c) * K + k];
+        if constexpr (MAX) acc = nmax(acc, v); else acc += v;
+    }
+    out[k] = MAX ? acc : acc * inv_count;
+}
+
+// ---- awq.py:52-72: |w| / absmax of its quantization group, mean over the output channels -> ws[k].
+// gmax[kg][n] = absmax over rows [kg g, kg g + g) of column n (g = K: one row of maxima per column).
+__global__ __launch_bounds__(256) void group_absmax_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, int64_t g, float* __restrict__ gmax) {
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int64_t kg = blockIdx.y;
+    const int64_t r0 = kg * g, r1 = r0 + g < K ? r0 + g : K;
+    float m = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4)
+        m = nmax(nmax(m, fabsf(W[r * ldw + n])), nmax(fabsf(W[(r + 1) * ldw + n]), nmax(fabsf(W[(r + 2) * ldw + n]), fabsf(W[(r + 3) * ldw + n]))));
+    for (; r < r1; ++r) m = nmax(m, fabsf(W[r * ldw + n]));
+    gmax[kg * N + n] = m;
+}
+
+// tensor strategy: one maximum for all of W (folds the per-column maxima in place into gmax[0..N) = the same value)
+__global__ __launch_bounds__(1024) void fold_to_scalar_kernel(float* v, int64_t count) {
+    __shared__ float sm[16];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) m = nmax(m, v[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = threadIdx.x < (blockDim.x >> 6) ? sm[threadIdx.x] : 0.f;
+        t = wave_max(t);
+        if (threadIdx.x == 0) sm[0] = t;
+    }
+    __syncthreads();
+    m = sm[0];
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) v[i] = m;
+}
+
+__global__ __launch_bounds__(256) void weight_scale_rows_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, int64_t g,
+                                                                const float* __restrict__ gmax, float* __restrict__ ws) {
+    __shared__ float sm[4];
+    const int64_t k = blockIdx.x;
+    const float* row = W + k * ldw;
+    const float* mx = gmax + (k / g) * N;
+    float acc = 0.f;
+    for (int64_t n = threadIdx.x; n < N; n += 256) acc += fabsf(row[n]) / mx[n];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[k] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) / static_cast<float>(N);
+}
+
+// ---- awq.py:143-150: the n_grid candidate scales, one block per candidate:
+//   s = clip(act^r / ws^(1 - r), 1e-4), r = i / n_grid;  s /= sqrt(max(s) * min(s))
+__global__ __launch_bounds__(1024) void grid_scales_kernel(const float* __restrict__ act, const float* __restrict__ ws, int64_t K, int n_grid,
+                                                           float* __restrict__ scales /* [n_grid][K] */) {
+    __shared__ float s_mx[16], s_mn[16];
+    const int i = blockIdx.x;
+    const float ratio = static_cast<float>(static_cast<double>(i) / static_cast<double>(n_grid));   // Python float -> fp32 operand of np.power
+    const float one_minus = static_cast<float>(1.0 - static_cast<double>(i) / static_cast<double>(n_grid));
+    float* out = scales + static_cast<int64_t>(i) * K;
+    float mx = 0.f, mn = INFINITY;
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = powf(act[k], ratio) / powf(ws[k], one_minus);
+        s = nmax(s, 1e-4f);
+        out[k] = s;
+        mx = nmax(mx, s);
+        mn = nmin(mn, s);
+    }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_mn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < static_cast<int>(blockDim.x >> 6); ++w) { mx = nmax(mx, s_mx[w]); mn = nmin(mn, s_mn[w]); }
+        s_mx[0] = sqrtf(mx * mn);
+    }
+    __syncthreads();
+    const float norm = s_mx[0];
+    for (int64_t k = threadIdx.x; k < K; k += blockDim.x) out[k] = out[k] / norm;
+}
+
+// ---- W * s[:, None] (awq.py:156) -> Ws, four columns per thread
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, const float* __restrict__ s,
+                                                         float* __restrict__ out) {
+    const int64_t n4 = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+    const int64_t k = blockIdx.y;
+    if (n4 >= N) return;
+    const float sk = s[k];
+    if (n4 + 3 < N && (ldw & 3) == 0 && (N & 3) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(W + k * ldw + n4);
+        *reinterpret_cast<float4*>(out + k * N + n4) = make_float4(v.x * sk, v.y * sk, v.z * sk, v.w * sk);
+    } else {
+        for (int64_t n = n4; n < N && n < n4 + 4; ++n) out[k * N + n] = W[k * ldw + n] * sk;
+    }
+}
+
+// ---- D = W - dequant(q) / s[:, None]  (awq.py:166-175; s == null: the clip search's D = W - dequant(q), awq.py:236-245),
+// with the block's max |D| for the fp16 pieces' power-of-two scale.  One thread = one column x 8 rows.
+__global__ __launch_bounds__(256) void awq_diff_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, const uint8_t* __restrict__ q,
+                                                       const float* __restrict__ qscale, const uint8_t* __restrict__ qzp, ParamIndex pi, int32_t is_signed,
+                                                       const float* __restrict__ s, float* __restrict__ D, float* __restrict__ absmax_partial) {
+    __shared__ float sm[4];
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 8;
+    float m = 0.f;
+    if (n < N) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = r0 + u;
+            if (r >= K) break;
+            const int64_t p = pi(r, n);
+            const uint32_t byte = q[r * N + n];
+            const int32_t qi = is_signed ? static_cast<int32_t>(static_cast<int8_t>(byte)) : static_cast<int32_t>(byte);
+            const int32_t zp = is_signed ? static_cast<int32_t>(static_cast<int8_t>(qzp[p])) : static_cast<int32_t>(qzp[p]);
+            float w_hat = dequantize_one(qi, qscale[p], zp);          // utils.py:130-132
+            if (s != nullptr) w_hat = w_hat / s[r];                    // awq.py:175
+            const float d = W[r * ldw + n] - w_hat;
+            D[r * N + n] = d;
+            m = nmax(m, fabsf(d));
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) absmax_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+}
+
+// ---- losses[i] = sum of the GEMM's per-block sums / (T N), in block order
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int64_t nblocks, double inv_count, float* __restrict__ loss) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += 256) acc += static_cast<double>(partial[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss = static_cast<float>(((sm[0] + sm[1]) + (sm[2] + sm[3])) * inv_count);
+}
+
+// ---- first minimum (`loss < best_error`, awq.py:178 / :250)
+__global__ void argmin_first_kernel(const float* __restrict__ losses, int n, int32_t* __restrict__ best) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int b = 0;
+    float v = INFINITY;
+    for (int i = 0; i < n; ++i)
+        if (losses[i] < v) { v = losses[i]; b = i; }
+    *best = b;
+}
+
+// smooth_quant.py:111-113: act^alpha / (w + 1e-9)^(1 - alpha), act clamped to >= 1e-5 (:66-67)
+__global__ __launch_bounds__(256) void smooth_scale_kernel(const float* __restrict__ act, const float* __restrict__ wmax, int64_t K, float alpha, float one_minus,
+                                                           float* __restrict__ out) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= K) return;
+    out[k] = powf(nmax(act[k], 1e-5f), alpha) / powf(wmax[k] + 1e-9f, one_minus);
+}
+
+__global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, float* __restrict__ out) {
+    __shared__ float sm[4];
+    const int64_t k = blockIdx.x;
+    float m = 0.f;
+    for (int64_t n = threadIdx.x; n < N; n += 256) m = nmax(m, fabsf(W[k * ldw + n]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[k] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+}
+
+struct AwqWs {   // carving of the caller's workspace
+    char* pieces_x;     // fp16 pieces of X^T (made once)
+    char* pieces_d;     // fp16 pieces of D (per candidate)
+    float* Ws;          // [K, N] scaled weights
+    float* D;           // [K, N]
+    uint8_t* q;         // [K, N]
+    float* qscale;      // [N * K/g] (>= N, >= 1)
+    uint8_t* qzp;
+    float* act;         // [K]
+    float* wsc;         // [K]
+    float* gmax;        // [K/g, N]
+    float* colpart;     // [kColChunks, K]
+    float* gemm_part;   // [tiles]
+    float* diff_part;   // absmax partials of awq_diff_kernel
+    char* rtn_ws;
+    size_t rtn_ws_bytes;
+};
+
+static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+static int64_t diff_blocks(int64_t K, int64_t N) { return ceil_div(N, 256) * ceil_div(K, 8); }
+
+static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* base) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
+    char* px = take(gemm_f16x3_pieces_bytes(K, T));
+    char* pd = take(gemm_f16x3_pieces_bytes(K, N));
+    char* Ws = take(static_cast<size_t>(K) * N * 4);
+    char* D = take(static_cast<size_t>(K) * N * 4);
+    char* q = take(static_cast<size_t>(K) * N);
+    char* qs = take(static_cast<size_t>(K) * N / 1 * 0 + static_cast<size_t>(K) * N * 4 / 16 + static_cast<size_t>(N) * 4 + 1024);   // groups of >= 16 rows
+    char* qz = take(static_cast<size_t>(K) * N / 16 + static_cast<size_t>(N) + 1024);
+    char* act = take(static_cast<size_t>(K) * 4);
+    char* wsc = take(static_cast<size_t>(K) * 4);
+    char* gmax = take(static_cast<size_t>(K) * N * 4 / 16 + static_cast<size_t>(N) * 4 + 1024);
+    char* colpart = take(static_cast<size_t>(kColChunks) * K * 4);
+    char* gpart = take(static_cast<size_t>(gemm_f16x3_tiles(T, N)) * 4 + 1024);
+    char* dpart = take(static_cast<size_t>(diff_blocks(K, N)) * 4 + 1024);
+    const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) + oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
+    char* rtn = take(rtn_bytes);
+    if (w) {
+        w->pieces_x = px; w->pieces_d = pd; w->Ws = reinterpret_cast<float*>(Ws); w->D = reinterpret_cast<float*>(D);
+        w->q = reinterpret_cast<uint8_t*>(q); w->qscale = reinterpret_cast<float*>(qs); w->qzp = reinterpret_cast<uint8_t*>(qz);
+        w->act = reinterpret_cast<float*>(act); w->wsc = reinterpret_cast<float*>(wsc); w->gmax = reinterpret_cast<float*>(gmax);
+        w->colpart = reinterpret_cast<float*>(colpart); w->gemm_part = reinterpret_cast<float*>(gpart); w->diff_part = reinterpret_cast<float*>(dpart);
+        w->rtn_ws = rtn; w->rtn_ws_bytes = rtn_bytes;
+    }
+    return off + 256;
+}
+
+static int32_t param_index(int32_t strategy, int64_t K, int64_t g, ParamIndex* pi) {
+    if (strategy == OQ_TENSOR) *pi = ParamIndex{1, 0, 0};
+    else if (strategy == OQ_CHANNEL) *pi = ParamIndex{1, 0, 1};
+    else *pi = ParamIndex{g, 1, K / g};   // rtn.py:98-109: entry n * (K / g) + kg
+    return OQ_OK;
+}
+
+// one candidate: quantize `Wq` (the weights as the candidate sees them), D = W - dequant (/ s), loss -> loss_out
+static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const float* Wq, int64_t ldq, const float* row_scale, int64_t T, int64_t K,
+                              int64_t N, int32_t qtype, int32_t strategy, int64_t group_size, int64_t g, int32_t symmetric, int32_t reduce_range,
+                              float clip_ratio, float* loss_out, hipStream_t s) {
+    int32_t st = rtn_impl(Wq, K, N, ldq, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, 0, w.q, w.qscale, w.qzp, OQ_LAYOUT_KN,
+                          w.rtn_ws, w.rtn_ws_bytes, s, true);
+    if (st != OQ_OK) return st;
+    ParamIndex pi;
+    param_index(strategy, K, g, &pi);
+    const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K, 8)));
+    hipLaunchKernelGGL(awq_diff_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0,
+                       row_scale, w.D, w.diff_part);
+    st = check_launch("awq_diff_kernel");
+    if (st != OQ_OK) return st;
+    // the pieces of D with the scale from awq_diff_kernel's partial maxima (instead of a second pass over D)
+    st = make_f16x2_pieces_from_partials(w.D, K, N, N, w.diff_part, static_cast<int>(diff_blocks(K, N)), w.pieces_d, s);
+    if (st != OQ_OK) return st;
+    st = launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, w.gemm_part, s);
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, w.gemm_part, gemm_f16x3_tiles(T, N), 1.0 / (static_cast<double>(T) * static_cast<double>(N)),
+                       loss_out);
+    return check_launch("loss_finish_kernel");
+}
+
+static int32_t check_common(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                            int64_t group_size, int64_t* g) {
+    OQ_REQUIRE(X && W && T > 0 && K > 0 && N > 0 && ldx >= K && ldw >= N, OQ_ERR_INVALID_ARGUMENT, "awq: bad argument");
+    OQ_REQUIRE(qtype == OQ_INT4 || qtype == OQ_UINT4 || qtype == OQ_INT8 || qtype == OQ_UINT8, OQ_ERR_UNSUPPORTED, "awq: 4- and 8-bit types only");
+    OQ_REQUIRE(strategy == OQ_TENSOR || strategy == OQ_CHANNEL || strategy == OQ_GROUP, OQ_ERR_INVALID_ARGUMENT, "awq: unknown strategy %d", strategy);
+    *g = K;
+    if (strategy == OQ_GROUP) {
+        int64_t gs = group_size > K ? K : group_size;
+        if (gs == -1) gs = K;
+        OQ_REQUIRE(gs >= 16 && K % gs == 0, OQ_ERR_UNSUPPORTED, "awq: group_size must divide K and be >= 16 (got %lld for K = %lld)", (long long)group_size,
+                   (long long)K);
+        *g = gs;
+    }
+    OQ_REQUIRE(ceil_div(K, 8) <= 65535 && K <= 65535 && ceil_div(K, *g) <= 65535, OQ_ERR_UNSUPPORTED, "awq: K too large");
+    return OQ_OK;
+}
+
+}  // namespace oq
+
+extern "C" {
+
+using namespace oq;
+
+size_t oq_awq_workspace_bytes(int64_t T, int64_t K, int64_t N) {
+    if (T <= 0 || K <= 0 || N <= 0) return 0;
+    return awq_workspace(T, K, N, nullptr, nullptr);
+}
+
+int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, int32_t qtype,
+                                int32_t strategy, int64_t group_size, int32_t symmetric, int32_t reduce_range, int32_t n_grid, float* scales_out,
+                                float* losses_out, int32_t* best_out, void* workspace, size_t workspace_bytes, void* stream) {
+    int64_t g;
+    int32_t st = check_common(X, T, K, ldx, W, N, ldw, qtype, strategy, group_size, &g);
+    if (st != OQ_OK) return st;
+    OQ_REQUIRE(scales_out && losses_out && best_out && n_grid >= 1 && n_grid <= kAwqMaxGrid, OQ_ERR_INVALID_ARGUMENT, "oq_awq_scale_search_f32: bad argument");
+    const size_t need = oq_awq_workspace_bytes(T, K, N);
+    OQ_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, OQ_ERR_WORKSPACE,
+               "oq_awq_scale_search_f32: 256-byte aligned workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    AwqWs w;
+    awq_workspace(T, K, N, &w, static_cast<char*>(workspace));
+    // awq.py:47-50: mean |x| per input channel
+    const dim3 cgrid(static_cast<uint32_t>(ceil_div(K, 256)), static_cast<uint32_t>(T < kColChunks ? T : kColChunks));
+    hipLaunchKernelGGL(col_abs_partial_kernel<false>, cgrid, dim3(256), 0, s, X, T, K, ldx, w.colpart);
+    hipLaunchKernelGGL(col_abs_finish_kernel<false>, dim3(cgrid.x), dim3(256), 0, s, w.colpart, static_cast<int>(cgrid.y), K, 1.0f / static_cast<float>(T), w.act);
+    // awq.py:52-72: weight scale
+    const int64_t kgroups = K / g;
+    hipLaunchKernelGGL(group_absmax_kernel, dim3(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups)), dim3(256), 0, s, W, K, N, ldw, g, w.gmax);
+    if (strategy == OQ_TENSOR) hipLaunchKernelGGL(fold_to_scalar_kernel, dim3(1), dim3(1024), 0, s, w.gmax, N);
+    hipLaunchKernelGGL(weight_scale_rows_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, g, w.gmax, w.wsc);
+    hipLaunchKernelGGL(grid_scales_kernel, dim3(static_cast<uint32_t>(n_grid)), dim3(1024), 0, s, w.act, w.wsc, K, n_grid, scales_out);
+    st = check_launch("awq statistics");
+    if (st != OQ_OK) return st;
+    // X^T as the GEMM's first operand: pieces over the contraction index k, once
+    st = make_f16x2_pieces(X, K, T, ldx, true, w.pieces_x, s);
+    if (st != OQ_OK) return st;
+    for (int i = 0; i < n_grid; ++i) {
+        const float* si = scales_out + static_cast<int64_t>(i) * K;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(static_cast<uint32_t>(ceil_div(ceil_div(N, 4), 256)), static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw,
+                           si, w.Ws);
+        st = candidate_loss(w, W, ldw, w.Ws, N, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, losses_out + i, s);
+        if (st != OQ_OK) return st;
+    }
+    hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, n_grid, best_out);
+    return check_launch("argmin_first_kernel");
+}
+
+int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, int32_t qtype,
+                               int32_t strategy, int64_t group_size, int32_t symmetric, int32_t reduce_range, float* losses_out, int32_t* best_out,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    int64_t g;
+    int32_t st = check_common(X, T, K, ldx, W, N, ldw, qtype, strategy, group_size, &g);
+    if (st != OQ_OK) return st;
+    OQ_REQUIRE(losses_out && best_out, OQ_ERR_INVALID_ARGUMENT, "oq_awq_clip_search_f32: bad argument");
+    const size_t need = oq_awq_workspace_bytes(T, K, N);
+    OQ_REQUIRE(workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, OQ_ERR_WORKSPACE,
+               "oq_awq_clip_search_f32: 256-byte aligned workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    AwqWs w;
+    awq_workspace(T, K, N, &w, static_cast<char*>(workspace));
+    st = make_f16x2_pieces(X, K, T, ldx, true, w.pieces_x, s);
+    if (st != OQ_OK) return st;
+    for (int i = 0; i < 10; ++i) {
+        const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227
+        st = candidate_loss(w, W, ldw, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, losses_out + i, s);
+        if (st != OQ_OK) return st;
+    }
+    hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, 10, best_out);
+    return check_launch("argmin_first_kernel");
+}
+
+int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, float alpha, float* scale_out,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(X && W && scale_out && T > 0 && K > 0 && N > 0 && ldx >= K && ldw >= N && K <= (int64_t{1} << 31), OQ_ERR_INVALID_ARGUMENT,
+               "oq_smooth_quant_scale_f32: bad argument");
+    const size_t need = align256(static_cast<size_t>(kColChunks) * K * 4) + 2 * align256(static_cast<size_t>(K) * 4) + 256;
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_smooth_quant_scale_f32: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    char* base = static_cast<char*>(workspace);
+    base += (256 - reinterpret_cast<uintptr_t>(base) % 256) % 256;
+    float* colpart = reinterpret_cast<float*>(base);
+    float* act = reinterpret_cast<float*>(base + align256(static_cast<size_t>(kColChunks) * K * 4));
+    float* wmax = act + align256(static_cast<size_t>(K) * 4) / 4;
+    const dim3 cgrid(static_cast<uint32_t>(ceil_div(K, 256)), static_cast<uint32_t>(T < kColChunks ? T : kColChunks));
+    hipLaunchKernelGGL(col_abs_partial_kernel<true>, cgrid, dim3(256), 0, s, X, T, K, ldx, colpart);                 // smooth_quant.py:62-69
+    hipLaunchKernelGGL(col_abs_finish_kernel<true>, dim3(cgrid.x), dim3(256), 0, s, colpart, static_cast<int>(cgrid.y), K, 1.0f, act);
+    hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, wmax);      // :71-74
+    hipLaunchKernelGGL(smooth_scale_kernel, dim3(static_cast<uint32_t>(ceil_div(K, 256))), dim3(256), 0, s, act, wmax, K, alpha,
+                       static_cast<float>(1.0 - static_cast<double>(alpha)), scale_out);
+    return check_launch("smooth_scale_kernel");
+}
+
+size_t oq_smooth_quant_workspace_bytes(int64_t K) {
+    if (K <= 0) return 0;
+    return oq::align256(static_cast<size_t>(oq::kColChunks) * K * 4) + 2 * oq::align256(static_cast<size_t>(K) * 4) + 512;
+}
+
+}  // extern "C"

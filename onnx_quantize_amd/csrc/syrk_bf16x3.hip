@@ -791,6 +791,22 @@ int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx,
     return check_launch("split_f16x2 (gemm pieces)");
 }
 
+// The same for a row-major [Kd, cols] source whose maximum |x| the caller already has as `npart` partial maxima on the
+// device (a producer kernel that folded them while writing X): no second pass over X for the scale.
+int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols, int64_t ldx, const float* absmax_partials, int npart, void* pieces,
+                                        hipStream_t s) {
+    OQ_REQUIRE(X && pieces && absmax_partials && npart > 0 && Kd > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT,
+               "make_f16x2_pieces_from_partials: bad argument");
+    float* scale = static_cast<float*>(pieces);
+    u32x4* P = reinterpret_cast<u32x4*>(static_cast<unsigned char*>(pieces) + kScaleHeaderBytes);
+    const int64_t Cp = padded_k(cols), nstages = stages_of(Kd, StageGeom<3>::ROWS), nchunks = nstages * StageGeom<3>::CH;
+    OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "make_f16x2_pieces_from_partials: contraction too long (%lld)", (long long)Kd);
+    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, absmax_partials, npart, scale);
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3(static_cast<uint32_t>(Cp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s, X, Kd, cols, ldx,
+                       Cp, nchunks, scale, 0.0f, P);
+    return check_launch("split_f16x2 (gemm pieces, given maxima)");
+}
+
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
                           int64_t ldc, float* loss_partial, hipStream_t s) {
     OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && (C != nullptr) != (loss_partial != nullptr), OQ_ERR_INVALID_ARGUMENT,

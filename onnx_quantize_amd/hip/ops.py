@@ -454,76 +454,71 @@ def _flat_inputs(x: torch.Tensor) -> torch.Tensor:
     return x.reshape(-1, x.shape[-1])
 
 
-def _strategy_mode(strategy: str, k: int, group_size):
-    if strategy == "group":
-        return "group", resolve_group("group", k, group_size)
-    return ("col" if strategy == "channel" else "tensor"), 1      # oq_dequantize_f32 addressing: per column / one entry
-
-
-def awq_weight_scale(w: torch.Tensor, strategy: str, group_size) -> torch.Tensor:
-    """pre_passes/awq.py:52-72 on W [K, N] in HBM: |w| / absmax of its quantization group, mean over the
-    output channels -> [K]."""
-    k, n = w.shape
-    a = w.abs()
-    if strategy == "tensor":
-        return (a / a.max()).mean(dim=1)
-    if strategy == "group":
-        g = int(group_size)
-        amax = a.t().reshape(n, k // g, g).amax(dim=2, keepdim=True)                 # [N, K/g, 1]
-        return (a.t().reshape(n, k // g, g) / amax).reshape(n, k).mean(dim=0)
-    return (a / a.amax(dim=0, keepdim=True)).mean(dim=1)                            # channel: per output column
+def _search_args(x, w, qtype, strategy, group_size):
+    x2, ldx = _row_major(_flat_inputs(x))
+    _require_device(w, "w", torch.float32)
+    if w.dim() != 2 or w.shape[0] != x2.shape[1]:
+        raise ValueError(f"weights must be [K, N] with K = {x2.shape[1]}, got {tuple(w.shape)}")
+    w2, ldw = _row_major(w)
+    if BITS[qtype] > 8:
+        raise NotImplementedError("the AWQ searches take 4- and 8-bit types")
+    gs = -1 if group_size is None else int(group_size)
+    return x2, ldx, w2, ldw, gs
 
 
 def awq_scale_search(x: torch.Tensor, w: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
                      reduce_range=False, n_grid: int = 20):
-    """pre_passes/awq.py:114-184, device resident: 20 x {scale -> RTN (oq_rtn_quantize_f32) -> dequantize ->
-    X @ W^ (rocBLAS through torch) -> MSE}; nothing leaves the GPU until the 20 losses are read.
+    """pre_passes/awq.py:114-184 on the device, one C call (oq_awq_scale_search_f32): activation / weight statistics, the
+    n_grid candidate scales, and per candidate RTN -> dequantize -> X (W - W^) on the matrix cores with the squared error
+    reduced in the GEMM's epilogue.  Nothing leaves the GPU until the losses and the winning scale are read.
     Returns (best_scale [K] on device, losses float64[n_grid] on host)."""
-    x2 = _flat_inputs(x)
-    _require_device(w, "w", torch.float32)
-    k, n = w.shape
-    mode, g = _strategy_mode(strategy, k, group_size)
-    act = x2.abs().mean(dim=0)
-    ws = awq_weight_scale(w, strategy, group_size)
-    ref_out = x2 @ w
-    losses, scales = [], []
-    for i in range(n_grid):
-        ratio = i * 1 / n_grid
-        scale = torch.clamp(torch.pow(act, ratio) / torch.pow(ws, 1 - ratio), min=1e-4)
-        scale = scale / torch.sqrt(scale.max() * scale.min())
-        col = scale.reshape(-1, 1)
-        q, s, z = rtn_quantize(w * col, qtype, strategy, group_size, symmetric, reduce_range)
-        w_hat = dequantize(q, s, z, qtype, mode=mode, group=g) / col
-        d = (ref_out - x2 @ w_hat).reshape(-1)
-        losses.append(torch.dot(d, d) / d.numel())
-        scales.append(scale)
-    lv = torch.stack(losses).double().cpu().numpy()
-    best = int(lv.argmin())                      # first minimum, like `loss < best_error` in awq.py:178
-    return scales[best], lv
+    x2, ldx, w2, ldw, gs = _search_args(x, w, qtype, strategy, group_size)
+    t, k = x2.shape
+    n = w2.shape[1]
+    lib = L.load()
+    dev = w2.device
+    scales = torch.empty((n_grid, k), dtype=torch.float32, device=dev)
+    losses = torch.empty(n_grid, dtype=torch.float32, device=dev)
+    best = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.oq_awq_workspace_bytes(t, k, n) + 256, dev)
+    off = (-ws.data_ptr()) % 256
+    L.check(lib.oq_awq_scale_search_f32(_ptr(x2), t, k, ldx, _ptr(w2), n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
+                                        int(symmetric), int(reduce_range), int(n_grid), _ptr(scales), _ptr(losses), _ptr(best),
+                                        C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()))
+    lv = losses.double().cpu().numpy()
+    return scales[int(best.item())], lv
 
 
 def awq_clip_search(x: torch.Tensor, w: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
                     reduce_range=False):
-    """pre_passes/awq.py:207-259: (best clip_ratio, losses[10])."""
-    x2 = _flat_inputs(x)
-    _require_device(w, "w", torch.float32)
-    mode, g = _strategy_mode(strategy, w.shape[0], group_size)
-    ref_out = x2 @ w
-    losses = []
-    for i in range(10):
-        ratio = 1 - i / 100
-        q, s, z = rtn_quantize(w, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio=ratio)
-        d = (ref_out - x2 @ dequantize(q, s, z, qtype, mode=mode, group=g)).reshape(-1)
-        losses.append(torch.dot(d, d) / d.numel())
-    lv = torch.stack(losses).double().cpu().numpy()
-    return 1 - int(lv.argmin()) / 100, lv
+    """pre_passes/awq.py:207-259 (oq_awq_clip_search_f32): (best clip_ratio, losses[10])."""
+    x2, ldx, w2, ldw, gs = _search_args(x, w, qtype, strategy, group_size)
+    t, k = x2.shape
+    n = w2.shape[1]
+    lib = L.load()
+    dev = w2.device
+    losses = torch.empty(10, dtype=torch.float32, device=dev)
+    best = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.oq_awq_workspace_bytes(t, k, n) + 256, dev)
+    off = (-ws.data_ptr()) % 256
+    L.check(lib.oq_awq_clip_search_f32(_ptr(x2), t, k, ldx, _ptr(w2), n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
+                                       int(symmetric), int(reduce_range), _ptr(losses), _ptr(best), C.c_void_p(ws.data_ptr() + off),
+                                       ws.numel() - off, _stream()))
+    return 1 - int(best.item()) / 100, losses.double().cpu().numpy()
 
 
 def smooth_quant_scale(x: torch.Tensor, w: torch.Tensor, alpha: float) -> torch.Tensor:
-    """pre_passes/smooth_quant.py:62-74, :111-113 with the column / row absmax kernels (oq_absmax_f32)."""
-    act = torch.clamp(absmax(_flat_inputs(x)), min=1e-5)
-    wsc = absmax(w, per_row=True)
-    return torch.pow(act, alpha) / torch.pow(wsc + 1e-9, 1 - alpha)
+    """pre_passes/smooth_quant.py:62-74, :111-113 (oq_smooth_quant_scale_f32): the smoothing scale [K] on the device."""
+    x2, ldx = _row_major(_flat_inputs(x))
+    _require_device(w, "w", torch.float32)
+    w2, ldw = _row_major(w)
+    t, k = x2.shape
+    lib = L.load()
+    out = torch.empty(k, dtype=torch.float32, device=w2.device)
+    ws = _workspace(lib.oq_smooth_quant_workspace_bytes(k), w2.device)
+    L.check(lib.oq_smooth_quant_scale_f32(_ptr(x2), t, k, ldx, _ptr(w2), w2.shape[1], ldw, float(alpha), _ptr(out), _ptr(ws), ws.numel(),
+                                          _stream()))
+    return out
 
 
 # ----------------------------------------------------------------------------- N3
