@@ -389,14 +389,11 @@ def awq_bench(dev, k: int = 4096, n: int = 4096, t: int = 4096) -> dict:
         return a0.elapsed_time(a1) / reps, r
     ms_scale, (best_scale, losses) = timed(lambda: ops.awq_scale_search(x, w, "uint4", "group", GROUP))
     ms_clip, (best_ratio, closses) = timed(lambda: ops.awq_clip_search(x, w, "uint4", "group", GROUP))
-    col = best_scale.reshape(-1, 1)
-    q, sc, zp = ops.rtn_quantize(w * col, "uint4", "group", GROUP)
-    w_hat = ops.dequantize(q, sc, zp, "uint4", mode="group", group=GROUP) / col
-    x64 = x[:1024].double()
-    ref = float(((x64 @ (w.double() - w_hat.double())) ** 2).mean())
-    sub = ops.awq_scale_search(x[:1024], w, "uint4", "group", GROUP)     # the same rows through the kernels
     i = int(losses.argmin())
-    # the 1024-row search has its own statistics, so compare like with like: its loss at ITS winning scale
+    # float64 check on 1024 rows (a float64 product of all 4096 would dominate the bench): the search on those rows, then
+    # the loss of ITS winning scale recomputed from this package's RTN / dequantize kernels and a float64 product
+    x64 = x[:1024].double()
+    sub = ops.awq_scale_search(x[:1024], w, "uint4", "group", GROUP)
     q2, s2, z2 = ops.rtn_quantize(w * sub[0].reshape(-1, 1), "uint4", "group", GROUP)
     wh2 = ops.dequantize(q2, s2, z2, "uint4", mode="group", group=GROUP) / sub[0].reshape(-1, 1)
     ref2 = float(((x64 @ (w.double() - wh2.double())) ** 2).mean())
@@ -405,7 +402,7 @@ def awq_bench(dev, k: int = 4096, n: int = 4096, t: int = 4096) -> dict:
                     "device resident; round 2 (torch elementwise + rocBLAS): 23.4 / 11.2 ms",
             "scale_search_ms": round(ms_scale, 3), "clip_search_ms": round(ms_clip, 3), "best_grid_point": i, "best_clip_ratio": best_ratio,
             "loss_at_best": float(losses[i]), "loss_float64_check_rows": 1024, "loss_float64": ref2, "loss_kernel": float(sub[1].min()),
-            "verified": bool(ok), "unused_full_rows_reference": ref}
+            "verified": bool(ok)}
 
 
 # ------------------------------------------------------------------------------------------------ main
