@@ -61,6 +61,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--factor-wave", type=int, default=8,
                     help="layers per wave whose Hessians of one width are factored as ONE batch (0: a factor chain per input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hessian-pipeline", action="store_true",
+                    help="one stream for the Hessian: preparation (absmax / split) and product of every batch in sequence")
     ap.add_argument("--extra-passes", default="corrected,f32",
                     help="further whole-model passes reported next to the headline one: `corrected` (mode=corrected: the error-"
                          "correcting loop north_star names), `f32` (parity with the Hessian on the fp32 MFMA kernel, the reference's "
@@ -170,6 +172,9 @@ def run(args, dev, rank: int, world: int):
         one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
         q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
         results, timings, samples = {}, [], {}
+        # two-stream Hessian (ops.HessianPipeline): only the fp16-piece method has a separable preparation
+        pipe = ops.HessianPipeline(dev) if (not args.no_hessian_pipeline and ops.hessian_method() in ("auto", "f16x3") and
+                                            min(sp.k for sp in specs) >= 2048) else None
         fence()
         t0 = time.perf_counter()
         def quantize_members(members, h, shared):
@@ -225,18 +230,33 @@ def run(args, dev, rank: int, world: int):
                 with torch.cuda.stream(s_h):
                     stacks = {k: torch.zeros((len(g), k, k), device=dev) for k, g in slots.items()}
                     done = {}
-                    for gi, (key, members) in enumerate(wave):
-                        k = specs[members[0]].k
+                    # every (input, batch) of the wave in order, so that the pipeline can prepare the next batch -- of this
+                    # input or of the next one -- on its side stream while the product of the current one runs
+                    seq = [(gi, bi) for gi, (key, members) in enumerate(wave) for bi in range(len(acts[specs[members[0]].k]))]
+                    n = 0
+                    for si, (gi, bi) in enumerate(seq):
+                        k = specs[wave[gi][1][0]].k
                         h = stacks[k][slots[k].index(gi)]
-                        e0, e1 = ev(), ev()
-                        e0.record()
-                        n = 0
-                        for x in acts[k]:
+                        x = acts[k][bi]
+                        if bi == 0:
+                            n = 0
+                            e0 = ev()
+                            e0.record()
+                        if pipe is not None:
+                            nxt, nxt_total = None, None
+                            if si + 1 < len(seq):
+                                g2, b2 = seq[si + 1]
+                                nxt = acts[specs[wave[g2][1][0]].k][b2]
+                                nxt_total = (n + x.shape[0] if b2 != 0 else 0) + nxt.shape[0]
+                            n = pipe.accumulate(x, h, n, nxt, nxt_total)
+                        else:
                             n = ops.hessian_accumulate(x, h, n)
-                        e1.record()
-                        timings.append(("h", e0, e1))
-                        if last[k] == gi:
-                            done[k] = e1
+                        if bi == len(acts[k]) - 1:
+                            e1 = ev()
+                            e1.record()
+                            timings.append(("h", e0, e1))
+                            if last[k] == gi:
+                                done[k] = e1
                 with torch.cuda.stream(s_q):
                     for k in sorted(slots, key=lambda kk: last[kk]):           # widths in the order their stacks complete
                         s_q.wait_event(done[k])
@@ -261,7 +281,8 @@ def run(args, dev, rank: int, world: int):
         t_l = sum(a.elapsed_time(b) for tag, a, b in timings if tag == "l")
 
         return {"wall": wall, "t_quant": t_quant, "t_gather": t_gather, "t_h": t_h, "t_f": t_f, "t_l": t_l, "results": results,
-                "samples": samples, "gathered": gathered, "nbytes": nbytes, "one_stream": one_stream, "n_streams": len(q_streams)}
+                "samples": samples, "gathered": gathered, "nbytes": nbytes, "one_stream": one_stream, "n_streams": len(q_streams),
+                "pipelined": pipe is not None}
 
     first = model_pass(args.mode)
     n_gathered = len(first["gathered"]) if first["gathered"] is not None else -1
@@ -445,7 +466,7 @@ def run(args, dev, rank: int, world: int):
         "config": {"workload": f"gptq_qint4_g128_llama2_7b_{args.layers}layers", "params": params,
                    "tokens_per_input": args.tokens, "mode": args.mode, "block_size": 128, "percdamp": 0.01,
                    "streams": 1 if one_stream else 1 + first["n_streams"], "factor_wave_layers": args.factor_wave,
-                   "hessian_method": ops.hessian_method()},
+                   "hessian_method": ops.hessian_method(), "hessian_pipeline": first["pipelined"]},
         "seconds": {"wall": round(wall, 3), "quantize_max_rank": round(float(stats[1]), 3),
                     "gather": round(float(stats[2]), 4),
                     # per-phase device time (with several streams the phases overlap: their sum exceeds the wall time)

@@ -252,6 +252,22 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
                                   int64_t n_add, float* H, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* G1 in two halves, for callers that own more than one stream.  With the fp16-piece method a batch costs one HBM-bound
+ *     preparation (max |x|, the power-of-two scale, the two fp16 pieces: X read twice, 4 B / element written) and one
+ *     matrix-core bound product; issued on two streams, the preparation of batch i + 1 runs beside the product of batch i.
+ *       oq_hessian_prepare_f32               X -> `pieces` (256-byte aligned, oq_hessian_pieces_bytes(T, K)); n_total = the
+ *                                            sample count AFTER this batch (n_seen + n_add: gptq.py:284's dead-channel test
+ *                                            sees the same 2 / n as the fp32 path)
+ *       oq_hessian_accumulate_prepared_f32   `pieces` -> H, exactly what oq_hessian_accumulate_f32 with OQ_HESSIAN_F16X3 does
+ *                                            behind its own preparation: the two calls in sequence give the same bits.
+ *     `slabs` (oq_hessian_slab_bytes(K), may be NULL): partial sums of the T-slices. */
+size_t oq_hessian_pieces_bytes(int64_t T, int64_t K);
+size_t oq_hessian_slab_bytes(int64_t K);
+int32_t oq_hessian_prepare_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_total, void* pieces,
+                               size_t pieces_bytes, void* stream);
+int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_t K, int64_t n_seen, int64_t n_add,
+                                           float* H, void* slabs, size_t slab_bytes, void* stream);
+
 /* G3 prologue  gptq.py:118-127: dead = diag(H) == 0 -> H[d,d] = 1, W[d,:] = 0 (both in place);
  *     when actorder: perm_out = argsort(diag(H)) reversed (ties: larger index first) and W, H are
  *     permuted in place (Wtmp/Htmp-free: uses the workspace).  perm_out may be NULL otherwise. */

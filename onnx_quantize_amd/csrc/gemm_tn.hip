@@ -421,4 +421,34 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
     return launch_syrk_tn(X, T, K, ldx, sx, 1.0f, beta, H, workspace, workspace_bytes, as_stream(stream));
 }
 
+// G1 in two halves (fp16-piece method): the HBM-bound preparation of a batch and its matrix-core bound product, so that a
+// caller can run the preparation of batch i + 1 on a side stream while the product of batch i occupies the matrix cores.
+size_t oq_hessian_pieces_bytes(int64_t T, int64_t K) { return (T <= 0 || K <= 0) ? 0 : syrk_bf16x3_pieces_bytes(T, K) + 256; }
+size_t oq_hessian_slab_bytes(int64_t K) { return hessian_slab_budget(K) + 256; }
+
+int32_t oq_hessian_prepare_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_total, void* pieces, size_t pieces_bytes, void* stream) {
+    OQ_REQUIRE(X && pieces && T > 0 && K > 0 && ldx >= K && n_total > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_prepare_f32: bad argument");
+    OQ_REQUIRE((reinterpret_cast<uintptr_t>(pieces) & 255u) == 0 && pieces_bytes >= syrk_bf16x3_pieces_bytes(T, K), OQ_ERR_WORKSPACE,
+               "oq_hessian_prepare_f32: 256-byte aligned buffer of %zu bytes needed, %zu given", syrk_bf16x3_pieces_bytes(T, K), pieces_bytes);
+    const float alpha = static_cast<float>(2.0 / static_cast<double>(n_total));
+    return syrk_pieces_phases(X, T, K, ldx, alpha, 0.0f, nullptr, static_cast<unsigned char*>(pieces), nullptr, 0, 3, 1, as_stream(stream));
+}
+
+int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_t K, int64_t n_seen, int64_t n_add, float* H, void* slabs,
+                                           size_t slab_bytes, void* stream) {
+    OQ_REQUIRE(pieces && H && T > 0 && K > 0 && n_seen >= 0 && n_add > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_hessian_accumulate_prepared_f32: bad argument");
+    const int64_t n_total = n_seen + n_add;
+    const float beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));   // gptq.py:254
+    const float alpha = static_cast<float>(2.0 / static_cast<double>(n_total));
+    unsigned char* sl = static_cast<unsigned char*>(slabs);
+    if (sl != nullptr) {
+        const size_t pad = (256 - (reinterpret_cast<uintptr_t>(sl) & 255u)) & 255u;
+        sl = slab_bytes > pad ? sl + pad : nullptr;
+        slab_bytes = sl ? slab_bytes - pad : 0;
+    }
+    return syrk_pieces_phases(nullptr, T, K, K, alpha, beta, H, const_cast<unsigned char*>(static_cast<const unsigned char*>(pieces)),
+                              reinterpret_cast<float*>(sl), slab_bytes, 3, 2, as_stream(stream));
+}
+
 }  // extern "C"

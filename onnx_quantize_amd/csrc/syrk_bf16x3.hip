@@ -687,21 +687,32 @@ size_t syrk_bf16x3_pieces_bytes(int64_t T, int64_t K) {
     return (b16 > f16 ? b16 : f16) * padded_k(K) * 16 + kScaleHeaderBytes;
 }
 
+// phases: 1 = X -> pieces (absmax / scale / split), 2 = pieces -> C (GEMM + slab reduce), 3 = both.  `base`: the 256-byte
+// aligned pieces region (syrk_bf16x3_pieces_bytes); `slab`: room for the T-slice partial sums (may be null).  The two phases
+// of one batch may run on different streams (oq_hessian_prepare_f32 / oq_hessian_accumulate_prepared_f32): phase 1 is
+// HBM-bound, phase 2 matrix-core bound, so the preparation of the next batch hides behind the product of this one.
+int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, unsigned char* base, float* slab,
+                           size_t slab_bytes, int terms, int phases, hipStream_t s);
+
 int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, void* workspace,
                            size_t workspace_bytes, int terms, hipStream_t s) {
     OQ_REQUIRE(X != nullptr && C != nullptr && T > 0 && K >= 1 && ldx >= K, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: bad argument");
     OQ_REQUIRE(terms == 3 || terms == 6 || terms == 9, OQ_ERR_INVALID_ARGUMENT, "syrk_bf16x3: terms must be 3 (fp16 pieces), 6 or 9");
-    const bool f16 = terms == 3;
     const size_t pieces = syrk_bf16x3_pieces_bytes(T, K);
     OQ_REQUIRE(workspace != nullptr && workspace_bytes >= pieces + 256, OQ_ERR_WORKSPACE,
                "syrk_bf16x3: workspace of %zu bytes needed for the operand pieces, %zu given", pieces + 256, workspace_bytes);
     unsigned char* base = static_cast<unsigned char*>(workspace);
     base += (256 - (reinterpret_cast<uintptr_t>(base) & 255u)) & 255u;
+    return syrk_pieces_phases(X, T, K, ldx, alpha, beta, C, base, reinterpret_cast<float*>(base + pieces), workspace_bytes - pieces - 256, terms, 3, s);
+}
+
+int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, unsigned char* base, float* slab,
+                           size_t slab_bytes, int terms, int phases, hipStream_t s) {
+    const bool f16 = terms == 3;
     // fp16 pieces take 2/3 of the bf16 pieces' room: the scale header lives in the spare third
     float* scale = f16 ? reinterpret_cast<float*>(base) : nullptr;
     u32x4* P = reinterpret_cast<u32x4*>(base + (f16 ? kScaleHeaderBytes : 0));
-    float* slab = reinterpret_cast<float*>(base + pieces);
-    const size_t slab_bytes = workspace_bytes - pieces - 256;
+    if (slab == nullptr) slab_bytes = 0;
     // per launch, not once: the attribute belongs to the current device's copy of the kernel
     static const bool f16_m16_env = [] { const char* v = getenv("OQ_SYRK_F16_M16"); return !v || atoi(v) != 0; }();   // default on; 0: the 32x32x16 form
     const bool f16_m16 = f16 && f16_m16_env;
@@ -713,8 +724,10 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "syrk_bf16x3: cannot reserve %d bytes of LDS", lds_bytes);
     const int64_t Kp = padded_k(K), nstages = stages_of(T, stage_rows), nchunks = nstages * stage_chunks;
     OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "syrk_bf16x3: at most 2 097 120 rows per call, %lld given", (long long)T);
-    int32_t st;
-    if (f16) {
+    int32_t st = OQ_OK;
+    if (!(phases & 1)) {
+        // pieces prepared by an earlier call
+    } else if (f16) {
         const int nb = static_cast<int>(T < kAbsmaxBlocks ? T : kAbsmaxBlocks);
         hipLaunchKernelGGL(absmax_partial_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, X, T, K, ldx, scale + 4);
         hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
@@ -726,7 +739,7 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
                            X, T, K, ldx, Kp, nchunks, P);
         st = check_launch("split_bf16x3_kernel");
     }
-    if (st != OQ_OK) return st;
+    if (st != OQ_OK || !(phases & 2)) return st;
 
     const int tn = static_cast<int>(Kp / kST);
     const int64_t tiles = static_cast<int64_t>(tn) * (tn + 1) / 2;

@@ -570,6 +570,85 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
     return int(n_seen) + n_add
 
 
+class HessianPipeline:
+    """gptq.py:246-260 for a SEQUENCE of batches, possibly of many inputs, with the two halves of every batch on two
+    streams: the HBM-bound preparation (max |x|, scale, fp16 pieces: oq_hessian_prepare_f32) of batch i + 1 runs on a side
+    stream while the matrix-core bound product of batch i (oq_hessian_accumulate_prepared_f32) runs on the caller's
+    stream.  Two piece buffers, one slab buffer.  `accumulate(x, h, n_seen, next_x)` returns the new sample count like
+    `hessian_accumulate`; `next_x` (the batch that will be accumulated next, for any H, or None) is prepared ahead.
+    The results are bit-identical to `hessian_accumulate` with the fp16-piece method."""
+
+    def __init__(self, device):
+        self.device = device
+        self.side = torch.cuda.Stream(device=device)
+        self.bufs = [None, None]        # piece buffers
+        self.ready = [None, None]       # event: pieces of the buffer are complete
+        self.free = [None, None]        # event: the product that read the buffer is done
+        self.tag = [None, None]         # (data_ptr, shape, n_total) the buffer was prepared for
+        self.slab = None
+        self.slot = 0
+
+    @staticmethod
+    def _flat(x):
+        _require_device(x, "x", torch.float32)
+        x2 = x.reshape(-1, x.shape[-1])
+        return _row_major(x2)
+
+    def _prepare(self, i, x, n_total):
+        lib = L.load()
+        x2, ldx = self._flat(x)
+        t, k = x2.shape
+        need = lib.oq_hessian_pieces_bytes(t, k)
+        if self.bufs[i] is None or self.bufs[i].numel() < need:
+            self.bufs[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        buf = self.bufs[i]
+        off = (-buf.data_ptr()) % 256
+        cur = torch.cuda.current_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(cur)                                  # X is ready on the caller's stream at this point
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            if self.free[i] is not None:
+                self.side.wait_event(self.free[i])      # the product that read this buffer last
+            L.check(lib.oq_hessian_prepare_f32(_ptr(x2), t, k, ldx, int(n_total), C.c_void_p(buf.data_ptr() + off), buf.numel() - off,
+                                               C.c_void_p(self.side.cuda_stream)))
+            done = torch.cuda.Event()
+            done.record(self.side)
+        x2.record_stream(self.side)
+        self.ready[i] = done
+        self.tag[i] = (x2.data_ptr(), tuple(x2.shape), int(n_total))
+
+    def accumulate(self, x, h, n_seen: int, next_x=None, next_n_total: int | None = None) -> int:
+        lib = L.load()
+        _require_device(h, "H", torch.float32)
+        n_add = int(x.shape[0])
+        x2, ldx = self._flat(x)
+        t, k = x2.shape
+        if h.shape != (k, k) or not h.is_contiguous():
+            raise ValueError(f"H must be a contiguous [{k}, {k}] tensor")
+        n_total = int(n_seen) + n_add
+        i = self.slot
+        if self.tag[i] != (x2.data_ptr(), tuple(x2.shape), n_total):
+            self._prepare(i, x, n_total)                # nothing was prepared ahead for this batch
+        if next_x is not None:
+            self._prepare(1 - i, next_x, next_n_total if next_n_total is not None else int(next_x.shape[0]))
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(self.ready[i])
+        need = lib.oq_hessian_slab_bytes(k)
+        if self.slab is None or self.slab.numel() < need:
+            self.slab = torch.empty(need, dtype=torch.uint8, device=self.device)
+        buf = self.bufs[i]
+        off = (-buf.data_ptr()) % 256
+        L.check(lib.oq_hessian_accumulate_prepared_f32(C.c_void_p(buf.data_ptr() + off), t, k, int(n_seen), n_add, _ptr(h), _ptr(self.slab),
+                                                       self.slab.numel(), C.c_void_p(cur.cuda_stream)))
+        fr = torch.cuda.Event()
+        fr.record(cur)
+        self.free[i] = fr
+        self.tag[i] = None
+        self.slot = 1 - i
+        return n_total
+
+
 HESSIAN_METHODS = {"auto": 0, "f32": 1, "bf16x6": 2, "bf16x9": 3, "f16x3": 4}
 
 

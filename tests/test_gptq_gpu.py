@@ -822,3 +822,50 @@ def test_corrected_mode_at_llama_size_follows_the_oracle_on_a_column_strip(ops):
         return float(torch.linalg.norm(x64 @ (dq - w).double()))
     e_gptq, e_rtn = out_err(q, s, z), out_err(rq, rs, rz)
     assert e_gptq < 0.8 * e_rtn, (e_gptq, e_rtn)
+
+
+def test_two_stream_hessian_pipeline_gives_the_one_call_bits(ops):
+    """oq_hessian_prepare_f32 + oq_hessian_accumulate_prepared_f32 through `ops.HessianPipeline` (preparation of the next
+    batch on a side stream beside the product of this one) against `hessian_accumulate` with the fp16-piece method, over
+    two inputs of different widths and batch counts: bit-identical Hessians, same sample counts."""
+    import torch
+    before = ops.hessian_method()
+    ops.hessian_set_method("f16x3")
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(41)
+        inputs = {1024: [torch.randn((3, 700, 1024), generator=gen, device="cuda") * 3 for _ in range(3)],
+                  2304: [torch.randn((2, 1000, 2304), generator=gen, device="cuda") for _ in range(2)] + [torch.randn((1, 1000, 2304), generator=gen, device="cuda")]}
+        ref = {}
+        for k, batches in inputs.items():
+            h = torch.zeros((k, k), device="cuda")
+            n = 0
+            for x in batches:
+                n = ops.hessian_accumulate(x, h, n)
+            ref[k] = (h, n)
+        pipe = ops.HessianPipeline(torch.device("cuda", torch.cuda.current_device()))
+        seq = [(k, i) for k in inputs for i in range(len(inputs[k]))]
+        got = {k: torch.zeros((k, k), device="cuda") for k in inputs}
+        n = 0
+        for si, (k, i) in enumerate(seq):
+            if i == 0:
+                n = 0
+            x = inputs[k][i]
+            nxt, nxt_total = None, None
+            if si + 1 < len(seq):
+                k2, i2 = seq[si + 1]
+                nxt = inputs[k2][i2]
+                nxt_total = (n + x.shape[0] if i2 != 0 else 0) + nxt.shape[0]
+            n = pipe.accumulate(x, got[k], n, nxt, nxt_total)
+            if i == len(inputs[k]) - 1:
+                assert n == ref[k][1]
+        torch.cuda.synchronize()
+        for k in inputs:
+            assert torch.equal(got[k], ref[k][0]), k
+        # without look-ahead (next_x = None) the pipeline prepares on demand: same bits
+        h2 = torch.zeros((1024, 1024), device="cuda")
+        n = 0
+        for x in inputs[1024]:
+            n = pipe.accumulate(x, h2, n)
+        assert torch.equal(h2, ref[1024][0])
+    finally:
+        ops.hessian_set_method(before)
