@@ -12,7 +12,9 @@ distinct input width generated BEFORE the timed region and reused for every laye
 calibration forward pass, which is not part of the path), streamed batch by batch into the MFMA Hessian kernel
 (never concatenated).  Weight matrices are sharded over the ranks by `onnx_quantize_amd.sharding.plan_lpt`
 (layers sharing an input stay together: one Hessian and one inverse factor serve q/k/v resp. gate/up); no
-collective while quantizing; one RCCL gather of (packed int4, scales, zero points) to rank 0 at the end.
+collective while quantizing; the (packed int4, scales, zero points) of every wave of layers travel to rank 0 by point-to-point
+sends over RCCL / xGMI while the next wave computes (sharding.StreamedGather); `gather` in the result = what was still in flight
+behind the last kernel.
 Strong scaling: the model is fixed.
 
 HIP streams per rank: one for the Hessians (chip-filling MFMA GEMMs) and `--factor-streams` (4) that take the inverse
@@ -122,7 +124,7 @@ def run(args, dev, rank: int, world: int):
     import torch.distributed as dist
 
     from onnx_quantize_amd.hip import ops
-    from onnx_quantize_amd.sharding import gather_device_results, llama2_7b_specs, plan_lpt
+    from onnx_quantize_amd.sharding import StreamedGather, gather_device_results, llama2_7b_specs, plan_lpt, wave_bundles
 
     specs = llama2_7b_specs(tokens=args.tokens, layers=args.layers, hidden=args.hidden, ffn=args.ffn)
     plan = plan_lpt(specs, world)
@@ -172,6 +174,7 @@ def run(args, dev, rank: int, world: int):
         one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
         q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
         results, timings, samples = {}, [], {}
+        streamer = None
         # two-stream Hessian (ops.HessianPipeline): only the fp16-piece method has a separable preparation
         pipe = ops.HessianPipeline(dev) if (not args.no_hessian_pipeline and ops.hessian_method() in ("auto", "f16x3") and
                                             min(sp.k for sp in specs) >= 2048) else None
@@ -219,6 +222,12 @@ def run(args, dev, rank: int, world: int):
             # stack) while the Hessian stream is already on the next wave
             inputs_per_layer = max(1, len({sp.hessian_key for sp in specs}) // max(1, args.layers))     # of the MODEL, not of this rank's share
             per_wave = max(1, args.factor_wave * inputs_per_layer)
+            # results travel to rank 0 wave by wave while the next wave computes (sharding.StreamedGather): rank 0 posts its
+            # receives now, a rank sends a wave's (packed int4, scales, zero points) as soon as they exist
+            bundles = wave_bundles(specs, plan, per_wave)
+            g128 = lambda sp: sp.n * sp.k // 128  # noqa: E731
+            streamer = StreamedGather(specs, bundles, lambda sp: [(torch.uint8, (sp.k * sp.n // 2,)), (torch.float32, (g128(sp), 1)),
+                                                                   (torch.int8, (g128(sp), 1))], device=dev)
             for w0 in range(0, len(groups), per_wave):
                 wave = groups[w0:w0 + per_wave]
                 s_q = q_streams[(w0 // per_wave) % len(q_streams)]
@@ -268,11 +277,19 @@ def run(args, dev, rank: int, world: int):
                         timings.append(("f", e2, e3))
                         for j, gi in enumerate(slots[k]):
                             quantize_members(wave[gi][1], stacks[k][j], shared_list[j])
+                    if world > 1:
+                        # the wave's kernels must have produced the bytes before the communicator's stream reads them
+                        torch.cuda.current_stream().synchronize()
+                    b = w0 // per_wave
+                    streamer.push(b, {i: results[i] for i in bundles[rank][b]})
         torch.cuda.synchronize()
         t_quant = time.perf_counter() - t0
         fence()
         t1 = time.perf_counter()
-        gathered, nbytes = gather_device_results(specs, plan, results)
+        if streamer is not None:
+            gathered, nbytes = streamer.finish()           # only what is still in flight behind the last wave
+        else:
+            gathered, nbytes = gather_device_results(specs, plan, results)
         fence()
         t_gather = time.perf_counter() - t1
         wall = t_quant + t_gather
@@ -319,6 +336,16 @@ def run(args, dev, rank: int, world: int):
         verify["kat_4096_zero_point_digest_ok"] = bool(_sha16(zk.cpu().numpy()) == d["z_sha"])
         ok = ok and verify["kat_4096_digest_ok"]
         del wk, hk, xk
+    if world > 1:
+        # what arrived on rank 0 against what the senders hold: digests of the first and last layer of every rank's list
+        probe = sorted({my[0], my[-1]}) if my else []
+        mine_d = {i: [_sha16(t.cpu().numpy()) for t in results[i]] for i in probe}
+        all_d = [None] * world
+        dist.all_gather_object(all_d, mine_d)
+        if rank == 0:
+            intact = all([_sha16(t.cpu().numpy()) for t in gathered[specs[i].name]] == d for dd in all_d for i, d in dd.items())
+            verify["gathered_equals_senders"] = bool(intact)
+            ok = ok and intact
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
     if world > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -473,6 +500,8 @@ def run(args, dev, rank: int, world: int):
                     "hessian_ms_max_rank": round(float(stats[3]), 1),
                     "factor_ms_max_rank": round(float(stats[4]), 1), "loop_ms_max_rank": round(float(stats[5]), 1)},
         "gather_bytes": nbytes,
+        "gather_how": "sharding.StreamedGather: isend per wave of layers to rank 0 while the next wave computes; seconds.gather = the tail "
+                      "behind the last kernel" if args.factor_wave > 0 else "sharding.gather_device_results: one padded gather at the end",
         "hessian_flops_executed": flops_exec,
         "hessian_check_vs_float64": hcheck,
         "verified": verify["verified"], "verification": verify,

@@ -194,6 +194,130 @@ def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], min
     return {s.name: out[s.name] for s in specs}, total
 
 
+class StreamedGather:
+    """Results to rank 0 WHILE the ranks still compute, instead of one padded gather behind all of it.
+
+    Every rank's layers are cut into bundles (`bundles[r][b]` = the layer indices rank r finishes b-th; all ranks pass the
+    same structure, e.g. `wave_bundles`), and the byte layout of a layer's result is a function of its spec
+    (`layout_fn(spec) -> [(dtype, shape)] * 3` for q, scale, zp), so nobody exchanges sizes or metadata:
+      * rank 0 posts one `irecv` per (rank, bundle) up front, into buffers of exactly the bundle's size (its own results stay
+        where they are);
+      * rank r calls `push(b, results)` when its bundle b is done: the tensors are packed into ONE flat byte tensor (one copy)
+        and `isend`-ed (NCCL over xGMI with backend nccl: asynchronous on the communicator's stream, so the next bundle's
+        kernels run beside the transfer; gloo: staged through the host, for the CPU tests and the one-GPU rehearsal);
+      * `finish()` waits for what is still in flight and returns ({name: (q, scale, zp)} on rank 0 | None, bytes received).
+    Round 2's `gather_device_results` made three full copies of a rank's results (cat, padded send, world x cap receive
+    buffers) and started after the last kernel."""
+
+    def __init__(self, specs: Sequence[LayerSpec], bundles: list[list[list[int]]], layout_fn, *, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.specs, self.bundles, self.layout_fn, self.group = specs, bundles, layout_fn, group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.rank = dist.get_rank(group) if self.distributed else 0
+        self.nccl = self.distributed and dist.get_backend(group) == "nccl"
+        self.device = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if self.nccl else torch.device("cpu"))
+        self.own: dict = {}
+        self.sent: list = []          # (flat tensor, work) kept alive until finish()
+        self.recv: list = []          # rank 0: (rank, bundle, buffer, work)
+        self.nbytes = 0
+        if len(bundles) != self.world:
+            raise ValueError(f"bundles for {len(bundles)} ranks, world size {self.world}")
+        if self.world > 1 and self.rank == 0:
+            rounds = max(len(b) for b in bundles)
+            for b in range(rounds):                      # bundle-major: the order in which the ranks will send
+                for r in range(1, self.world):
+                    if b < len(bundles[r]) and bundles[r][b]:
+                        n = self._bundle_bytes(bundles[r][b])
+                        buf = torch.empty(n, dtype=torch.uint8, device=self.device if self.nccl else torch.device("cpu"))
+                        self.recv.append((r, b, buf, dist.irecv(buf, src=r, group=group)))
+                        self.nbytes += n
+
+    @staticmethod
+    def _pad16(n: int) -> int:
+        return (n + 15) // 16 * 16
+
+    def _layer_layout(self, i: int):
+        import torch
+
+        out = []
+        for dtype, shape in self.layout_fn(self.specs[i]):
+            n = int(np.prod(shape)) if len(shape) else 1
+            out.append((dtype, tuple(shape), n * torch.empty(0, dtype=dtype).element_size()))
+        return out
+
+    def _bundle_bytes(self, idx) -> int:
+        return sum(self._pad16(nb) for i in idx for (_, _, nb) in self._layer_layout(i))
+
+    def push(self, b: int, results: dict) -> None:
+        """This rank's bundle `b` is complete: `results[i] = (q, scale, zp)` for i in bundles[rank][b]."""
+        import torch
+        import torch.distributed as dist
+
+        idx = self.bundles[self.rank][b]
+        if self.rank == 0 or self.world == 1:
+            for i in idx:
+                self.own[i] = results[i]
+            return
+        if not idx:
+            return
+        parts = []
+        for i in idx:
+            for t, (dtype, shape, nb) in zip(results[i], self._layer_layout(i)):
+                if t.dtype != dtype or tuple(t.shape) != shape:
+                    raise ValueError(f"{self.specs[i].name}: result {t.dtype} {tuple(t.shape)} does not match the layout {dtype} {shape}")
+                flat = t.contiguous().view(-1).view(torch.uint8)
+                parts.append(flat)
+                if self._pad16(nb) != nb:
+                    parts.append(torch.zeros(self._pad16(nb) - nb, dtype=torch.uint8, device=flat.device))
+        flat = torch.cat(parts)                           # the one copy on the sending side
+        if not self.nccl and flat.is_cuda:
+            flat = flat.cpu()
+        self.sent.append((flat, dist.isend(flat, dst=0, group=self.group)))
+
+    def finish(self):
+        """Wait for the transfers still in flight.  Returns ({name: (q, scale, zp)} on rank 0 | None, bytes received)."""
+        import torch
+
+        for _, w in self.sent:
+            w.wait()
+        self.sent.clear()
+        if self.rank != 0:
+            return None, self.nbytes
+        out = {i: v for i, v in self.own.items()}
+        for r, b, buf, w in self.recv:
+            w.wait()
+            o = 0
+            for i in self.bundles[r][b]:
+                got = []
+                for dtype, shape, nb in self._layer_layout(i):
+                    got.append(buf[o:o + nb].view(dtype).reshape(shape))
+                    o += self._pad16(nb)
+                out[i] = tuple(got)
+        if self.nccl:
+            torch.cuda.current_stream().synchronize()
+        return {s.name: out[i] for i, s in enumerate(self.specs) if i in out}, self.nbytes
+
+
+def wave_bundles(specs: Sequence[LayerSpec], plan: list[list[int]], groups_per_wave: int) -> list[list[list[int]]]:
+    """The bundles `StreamedGather` works with, for the wave structure of bench_gptq.py: a rank's layers are grouped by the
+    input they share (plan order), `groups_per_wave` such groups form a wave, and a wave is one bundle."""
+    out = []
+    for mine in plan:
+        groups, seen = [], {}
+        for i in mine:
+            key = specs[i].hessian_key
+            if key not in seen:
+                seen[key] = len(groups)
+                groups.append([])
+            groups[seen[key]].append(i)
+        per = max(1, groups_per_wave)
+        out.append([[i for g in groups[w0:w0 + per] for i in g] for w0 in range(0, len(groups), per)])
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ inside one matrix
 # SURVEY.md 8e (2): groups run along K for a fixed output channel, so a matrix also shards by COLUMNS: group / channel RTN
 # and the GPTQ loop need no exchange at all (every output channel is independent given the inverse factor); per-tensor RTN

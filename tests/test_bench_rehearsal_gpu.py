@@ -1,5 +1,5 @@
 """The multi-rank flow of bench.py executed for real on ONE GPU (`OQ_BENCH_REHEARSAL=1`: ranks share cuda:0, collectives on
-gloo with host staging): LPT plans, the sharded GPTQ run with batched factors, the end-of-run gather, max-over-ranks timing,
+gloo with host staging): LPT plans, the sharded GPTQ run with batched factors, the wave-by-wave streamed gather, max-over-ranks timing,
 every rank verifying its own first layers.  Not a scaling measurement -- the scaling bench is the driver's, on 8 GPUs."""
 import json
 import os
@@ -28,4 +28,5 @@ def test_bench_runs_the_multi_rank_path_on_one_gpu(ranks):
     assert q["verified"] is True, q["verification"]
     assert sorted(b["rank"] for b in q["verification"]["by_rank"]) == list(range(ranks))
     assert all(b["ok"] for b in q["verification"]["by_rank"])
+    assert q["verification"]["gathered_equals_senders"] is True          # the streamed gather delivered the senders' bytes
     assert q["gather_bytes"] > 0 and q["cpu_baseline" if "cpu_baseline" in q else "value"] is not None

@@ -264,3 +264,77 @@ def test_one_matrix_sharded_by_columns_gloo(world):
         p.join(150)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_streamed_gather(rank, world, port, q):
+    """StreamedGather over gloo: bundles pushed as they finish, odd byte counts, a rank without work, an empty bundle; what
+    rank 0 assembles equals what every rank produced (and what the end-of-run gather_device_results returns)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from onnx_quantize_amd.sharding import LayerSpec, StreamedGather, gather_device_results, wave_bundles
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [LayerSpec(f"m{i}", 8 + i, 5 + 2 * i, hessian_key=f"h{i // 2}") for i in range(9)]
+    plan = [[0, 1, 4, 5, 8], [2, 3, 6, 7]] if world == 2 else [[0, 1, 6, 7], [2, 3, 4, 5, 8], []]
+    bundles = wave_bundles(specs, plan, groups_per_wave=1)
+    assert [len(b) for b in bundles] == ([3, 2] if world == 2 else [2, 3, 0])
+
+    def layout(sp):
+        return [(torch.uint8, ((sp.k * sp.n + 1) // 2,)), (torch.float32, (sp.n * 3, 1)), (torch.int8, (sp.n * 3, 1))]
+
+    def result(i):
+        g = torch.Generator().manual_seed(100 + i)
+        k, n = specs[i].k, specs[i].n
+        return (torch.randint(0, 255, ((k * n + 1) // 2,), generator=g, dtype=torch.uint8),
+                torch.rand((n * 3, 1), generator=g), torch.randint(-8, 7, (n * 3, 1), generator=g, dtype=torch.int8))
+    sg = StreamedGather(specs, bundles, layout)
+    mine = {}
+    for b, idx in enumerate(bundles[rank]):
+        res = {i: result(i) for i in idx}
+        mine.update(res)
+        sg.push(b, res)
+    out, nbytes = sg.finish()
+    ref, _ = gather_device_results(specs, plan, mine)
+    if rank == 0:
+        ok = list(out) == [s.name for s in specs] and nbytes > 0
+        for i, s in enumerate(specs):
+            e = result(i)
+            ok = ok and all(torch.equal(a, b) and a.dtype == b.dtype and a.shape == b.shape for a, b in zip(out[s.name], e))
+            ok = ok and all(torch.equal(a, b) for a, b in zip(out[s.name], ref[s.name]))
+        q.put(bool(ok))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("world", [2, 3])
+def test_streamed_gather_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_streamed_gather, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(100)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_streamed_gather_single_rank_and_layout_check():
+    import torch
+    from onnx_quantize_amd.sharding import StreamedGather, wave_bundles
+    specs = [LayerSpec("a", 8, 4), LayerSpec("b", 8, 6)]
+    layout = lambda sp: [(torch.uint8, (sp.k * sp.n,)), (torch.float32, (sp.n,)), (torch.int8, (sp.n,))]  # noqa: E731
+    bundles = wave_bundles(specs, [[0, 1]], 1)
+    sg = StreamedGather(specs, bundles, layout)
+    res = {i: (torch.zeros(sp.k * sp.n, dtype=torch.uint8), torch.ones(sp.n), torch.zeros(sp.n, dtype=torch.int8)) for i, sp in enumerate(specs)}
+    for b, idx in enumerate(bundles[0]):
+        sg.push(b, {i: res[i] for i in idx})
+    out, nbytes = sg.finish()
+    assert list(out) == ["a", "b"] and nbytes == 0 and out["b"][1].shape == (6,)
