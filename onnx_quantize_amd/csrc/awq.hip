@@ -177,6 +177,58 @@ __global__ __launch_bounds__(256) void awq_diff_kernel(const float* __restrict__
     if (threadIdx.x == 0) absmax_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
 }
 
+// The same for vector-aligned operands: four neighbouring columns per thread (16-byte loads of W, 4-byte loads of q, 16-byte
+// stores of D), parameters fetched once for the thread's 8 rows (8 divides every group size this path accepts).
+__global__ __launch_bounds__(256) void awq_diff4_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, const uint8_t* __restrict__ q,
+                                                        const float* __restrict__ qscale, const uint8_t* __restrict__ qzp, ParamIndex pi, int32_t is_signed,
+                                                        const float* __restrict__ s, float* __restrict__ D, float* __restrict__ absmax_partial) {
+    __shared__ float sm[4];
+    const int64_t n = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 8;
+    float m = 0.f;
+    if (n < N) {
+        float sc[4];
+        int32_t zp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t p = pi(r0, n + e);
+            sc[e] = qscale[p];
+            zp[e] = is_signed ? static_cast<int32_t>(static_cast<int8_t>(qzp[p])) : static_cast<int32_t>(qzp[p]);
+        }
+        float4 w[8];
+        uint32_t qb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = r0 + u < K ? r0 + u : K - 1;   // clamped, never predicated
+            w[u] = *reinterpret_cast<const float4*>(W + r * ldw + n);
+            qb[u] = *reinterpret_cast<const uint32_t*>(q + r * N + n);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t r = r0 + u;
+            if (r < K) {
+                const float inv = s != nullptr ? s[r] : 1.0f;
+                const float wv[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t byte = (qb[u] >> (8 * e)) & 0xffu;
+                    const int32_t qi = is_signed ? static_cast<int32_t>(static_cast<int8_t>(byte)) : static_cast<int32_t>(byte);
+                    float w_hat = dequantize_one(qi, sc[e], zp[e]);
+                    if (s != nullptr) w_hat = w_hat / inv;
+                    d[e] = wv[e] - w_hat;
+                    m = nmax(m, fabsf(d[e]));
+                }
+                *reinterpret_cast<float4*>(D + r * N + n) = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) absmax_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+}
+
 // ---- losses[i] = sum of the GEMM's per-block sums / (T N), in block order
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int64_t nblocks, double inv_count, float* __restrict__ loss) {
     __shared__ double sm[4];
@@ -284,13 +336,22 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
     if (st != OQ_OK) return st;
     ParamIndex pi;
     param_index(strategy, K, g, &pi);
-    const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K, 8)));
-    hipLaunchKernelGGL(awq_diff_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0,
-                       row_scale, w.D, w.diff_part);
+    const int32_t is_signed = (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0;
+    const bool vec = N % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 && (strategy != OQ_GROUP || g % 8 == 0);
+    int nparts;
+    if (vec) {
+        const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 1024)), static_cast<uint32_t>(ceil_div(K, 8)));
+        hipLaunchKernelGGL(awq_diff4_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, is_signed, row_scale, w.D, w.diff_part);
+        nparts = static_cast<int>(dgrid.x * dgrid.y);
+    } else {
+        const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K, 8)));
+        hipLaunchKernelGGL(awq_diff_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, is_signed, row_scale, w.D, w.diff_part);
+        nparts = static_cast<int>(dgrid.x * dgrid.y);
+    }
     st = check_launch("awq_diff_kernel");
     if (st != OQ_OK) return st;
     // the pieces of D with the scale from awq_diff_kernel's partial maxima (instead of a second pass over D)
-    st = make_f16x2_pieces_from_partials(w.D, K, N, N, w.diff_part, static_cast<int>(diff_blocks(K, N)), w.pieces_d, s);
+    st = make_f16x2_pieces_from_partials(w.D, K, N, N, w.diff_part, nparts, w.pieces_d, s);
     if (st != OQ_OK) return st;
     st = launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, w.gemm_part, s);
     if (st != OQ_OK) return st;
