@@ -588,6 +588,17 @@ class HessianPipeline:
         self.slab = None
         self.slot = 0
 
+    def reserve(self, rows: int, k: int) -> None:
+        """Allocate the two piece buffers and the slab buffer for batches of up to `rows` x `k` now (otherwise on first use)."""
+        lib = L.load()
+        need = lib.oq_hessian_pieces_bytes(int(rows), int(k))
+        for i in (0, 1):
+            if self.bufs[i] is None or self.bufs[i].numel() < need:
+                self.bufs[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        sl = lib.oq_hessian_slab_bytes(int(k))
+        if self.slab is None or self.slab.numel() < sl:
+            self.slab = torch.empty(sl, dtype=torch.uint8, device=self.device)
+
     @staticmethod
     def _flat(x):
         _require_device(x, "x", torch.float32)
