@@ -228,12 +228,20 @@ class StreamedGather:
         if self.world > 1 and self.rank == 0:
             rounds = max(len(b) for b in bundles)
             for b in range(rounds):                      # bundle-major: the order in which the ranks will send
+                ops, bufs = [], []
                 for r in range(1, self.world):
                     if b < len(bundles[r]) and bundles[r][b]:
                         n = self._bundle_bytes(bundles[r][b])
                         buf = torch.empty(n, dtype=torch.uint8, device=self.device if self.nccl else torch.device("cpu"))
-                        self.recv.append((r, b, buf, dist.irecv(buf, src=r, group=group)))
+                        ops.append(dist.P2POp(dist.irecv, buf, r, group))
+                        bufs.append((r, b, buf))
                         self.nbytes += n
+                if ops:
+                    # one grouped launch per round on the communicator that already exists (a bare irecv would create a
+                    # two-rank communicator per peer on first use and block this host thread until that peer's first send)
+                    works = dist.batch_isend_irecv(ops)
+                    for j, (r, bb, buf) in enumerate(bufs):
+                        self.recv.append((r, bb, buf, works[j] if j < len(works) else works[-1]))
 
     @staticmethod
     def _pad16(n: int) -> int:
@@ -275,7 +283,8 @@ class StreamedGather:
         flat = torch.cat(parts)                           # the one copy on the sending side
         if not self.nccl and flat.is_cuda:
             flat = flat.cpu()
-        self.sent.append((flat, dist.isend(flat, dst=0, group=self.group)))
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, 0, self.group)])
+        self.sent.append((flat, works[-1]))
 
     def finish(self):
         """Wait for the transfers still in flight.  Returns ({name: (q, scale, zp)} on rank 0 | None, bytes received)."""
@@ -283,6 +292,8 @@ class StreamedGather:
 
         for _, w in self.sent:
             w.wait()
+        if self.nccl and self.sent:
+            torch.cuda.current_stream().synchronize()   # NCCL's wait() orders streams; the flat buffers are freed below
         self.sent.clear()
         if self.rank != 0:
             return None, self.nbytes
