@@ -45,7 +45,28 @@ def test_hessian_gemm_kernels_fit_two_waves_per_simd_without_spilling(tmp_path):
     seen = 0
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, re.S):
         name, vgprs, scratch, occ = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4))
-        if "syrk_pieces_kernel" in name or "syrk_f16_m16_kernel" in name:
+        if "syrk_pieces_kernel" in name or "syrk_f16_m16_kernel" in name or "gemm_f16x3_kernel" in name:
             seen += 1
             assert vgprs <= 256 and scratch == 0 and occ >= 2, (name, vgprs, scratch, occ)
-    assert seen == 4          # three instantiations of the 32x32 form + the 16x16x32 fp16 kernel
+    assert seen == 6          # three instantiations of the 32x32 form + the 16x16x32 fp16 kernel + the two-operand GEMM's two epilogues
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_gptq_loop_kernels_do_not_spill(tmp_path):
+    """`gptq_rows16_kernel` is launched with up to 1024 threads (<= 128 registers) and is a chain of dependent instructions:
+    twice during its writing the optimiser produced 140 spilled registers (updates of later slabs sunk to the end of the
+    slab; all 16 steps' LDS reads hoisted) without any functional test noticing.  `panel_update_kernel` needs two blocks per
+    CU (64 KB of LDS each)."""
+    from onnx_quantize_amd import _build
+    src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "gptq_loop.hip")
+    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+                        str(tmp_path / "loop.s"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = {}
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)",
+                         r.stderr, re.S):
+        seen[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4, 5))
+    rows16 = next(v for k, v in seen.items() if "gptq_rows16_kernel" in k)
+    panel = next(v for k, v in seen.items() if "panel_update_kernel" in k)
+    assert rows16[0] <= 128 and rows16[1] == 0 and rows16[3] <= 65536, rows16
+    assert panel[1] == 0 and panel[2] >= 2 and panel[3] <= 65536, panel
