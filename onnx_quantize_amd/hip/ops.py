@@ -40,8 +40,37 @@ def _require_device(t: torch.Tensor, name: str, dtype=None) -> None:
         raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
 
 
+_ARENA_MIN_BYTES = 32 << 20
+_ARENA: dict = {}     # (device index, stream handle) -> scratch tensor, grow-only
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor | None:
-    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+    """Scratch memory for ONE library call on the current stream.  Nothing a call returns lives in it.
+
+    Small requests come from torch's allocator.  Requests of 32 MiB and more (the factor chain of a stack of eight
+    11008 x 11008 Hessians asks for 15.5 GB) are served from one grow-only buffer per (device, stream): calls on a stream run
+    in order, so the next call may overwrite what the previous one left.  Why not `torch.empty` every time: when the
+    caching allocator has split its one block of that size for a smaller request in between, the next call maps a new one,
+    and `hipMalloc` of 15.5 GB takes 0.36 s on the MI355X host (measured, scripts/lab_alloc_trace.py) -- with the kernels of
+    the call waiting behind it.  `release_workspaces()` hands the buffers back."""
+    nbytes = max(int(nbytes), 256)
+    if nbytes < _ARENA_MIN_BYTES:
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream)
+    buf = _ARENA.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _ARENA.pop(key, None)
+        del buf
+        buf = _ARENA[key] = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
+    return buf[:nbytes]       # exactly what was asked for: some calls size their split-K slabs by the room they are given
+
+
+def release_workspaces() -> None:
+    """Drop the per-stream scratch buffers `_workspace` keeps (they return to torch's caching allocator)."""
+    _ARENA.clear()
+    _MINMAX_WS.clear()
 
 
 def _row_major(t: torch.Tensor) -> tuple[torch.Tensor, int]:
