@@ -252,6 +252,28 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
                                   int64_t n_add, float* H, void* workspace, size_t workspace_bytes,
                                   void* stream);
 
+/* G1 for a LIST of inputs in one launch chain (core/_calibration/calibrate.py:292-305 walks the GPTQ nodes and hands
+ *     `_accumulate_hessian`, gptq.py:246-260, one input each; a calibration batch of gemma-3-270m taps 72 of them, 5120 rows
+ *     by 640 / 1024 / 2048 columns: 6 to 36 tiles of the 256 x 256 product kernel each, five launches per tensor).  Every
+ *     item is one oq_hessian_accumulate_f32 call: H <- H n_seen / (n_seen + n_add) + 2 / (n_seen + n_add) X^T X.  All items
+ *     run the fp16-piece method (OQ_HESSIAN_F16X3 above) whatever their size, each with a scale of its own, the product
+ *     writing H directly: the same <= 1e-5 max |H| bound; NOT bit-identical to the per-tensor call, which may slice T or
+ *     pick the fp32 kernel for small K.  OQ_ERR_UNSUPPORTED when oq_hessian_set_method selected another method.
+ *     `items_host` / `items_device`: the same `count` items in host and in device memory (the host copy sizes the
+ *     launches, the kernels read the device copy).  Workspace: oq_hessian_many_workspace_bytes(items_host, count) =
+ *     the fp16 pieces of all items (4 B per element of the zero-padded inputs) + a table. */
+typedef struct {
+    const float* X;   /* [T, K] fp32 rows, leading dimension ldx */
+    float* H;         /* [K, K] fp32, contiguous; read only when n_seen > 0 */
+    int64_t T, K, ldx;
+    int64_t n_seen;   /* samples (leading-dimension entries, gptq.py:247) already in H */
+    int64_t n_add;    /* samples this X adds */
+    int64_t reserved; /* 0 */
+} oq_hessian_item;
+size_t oq_hessian_many_workspace_bytes(const oq_hessian_item* items_host, int64_t count);
+int32_t oq_hessian_accumulate_many_f32(const oq_hessian_item* items_host, const oq_hessian_item* items_device,
+                                       int64_t count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* G1 in two halves, for callers that own more than one stream.  With the fp16-piece method a batch costs one HBM-bound
  *     preparation (max |x|, the power-of-two scale, the two fp16 pieces: X read twice, 4 B / element written) and one
  *     matrix-core bound product; issued on two streams, the preparation of batch i + 1 runs beside the product of batch i.

@@ -91,13 +91,14 @@ class ActivationStream:
 
     def __init__(self, *, calibrator=None, input_names: Iterable[str] = (), output_names: Iterable[str] = (),
                  hessian_names: Iterable[str] = (), absmax_names: Iterable[str] = (), keep_names: Iterable[str] = (),
-                 hessian_streams: int = 4):
+                 hessian_streams: int = 0):
         self.calibrator = calibrator if calibrator is not None else MinMaxCalibrator()
         self.input_names, self.output_names = list(dict.fromkeys(input_names)), list(dict.fromkeys(output_names))
         self.hessian_names, self.absmax_names = set(hessian_names), set(absmax_names)
         self.keep_names = set(keep_names)
         self.hessians: dict[str, HessianAccumulator] = {}
-        self.hessian_streams = max(0, int(hessian_streams))      # side streams for the Hessian updates of one batch (0: none)
+        # 0 (default): the Hessian updates of a batch in one grouped launch chain; n > 0: per-tensor calls on n side streams
+        self.hessian_streams = max(0, int(hessian_streams))
         self._side = None
         self.absmax: dict = {}
         self._kept: dict[str, list] = {}
@@ -128,9 +129,22 @@ class ActivationStream:
             else:
                 self.calibrator.collect_many(activations)
         wanted = sorted(self.hessian_names & activations.keys())
-        if wanted:
-            # The updates of different names are independent and, for small models, launch-bound (a few tens of
-            # microseconds of GEMM each): spread them over a few side streams so that they overlap, fork / join by events.
+        if wanted and self.hessian_streams == 0:
+            # one launch chain for all tapped inputs of the batch (ops.hessian_accumulate_many): a batch of a small model is
+            # 72 tensors of 6 to 36 product tiles each, launch-bound and never filling the chip one at a time
+            xs = []
+            for name in wanted:
+                x = activations[name]
+                x32 = x if x.dtype == torch.float32 else x.to(torch.float32)
+                if name not in self.hessians:
+                    self.hessians[name] = HessianAccumulator(x32.shape[-1], x32.device)
+                xs.append(x32)
+            accs = [self.hessians[name] for name in wanted]
+            for acc, n in zip(accs, ops.hessian_accumulate_many(xs, [a.h for a in accs], [a.n for a in accs])):
+                acc.n = n
+        elif wanted:
+            # per-tensor calls spread over a few side streams (fork / join by events): the route for the Hessian methods
+            # the grouped call does not run (hessian_streams > 0 selects it)
             cur = torch.cuda.current_stream()
             if self._side is None:
                 self._side = [torch.cuda.Stream(device=activations[wanted[0]].device) for _ in range(self.hessian_streams)]

@@ -421,6 +421,22 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
     return launch_syrk_tn(X, T, K, ldx, sx, 1.0f, beta, H, workspace, workspace_bytes, as_stream(stream));
 }
 
+// G1 for the tensors of one calibration batch (calibrate.py:292-305 hands `_accumulate_hessian` one input per node): one
+// launch chain for all of them, fp16-piece method.
+size_t oq_hessian_many_workspace_bytes(const oq_hessian_item* items_host, int64_t count) {
+    return syrk_f16x3_many_workspace_bytes(reinterpret_cast<const int64_t*>(items_host), count);
+}
+
+int32_t oq_hessian_accumulate_many_f32(const oq_hessian_item* items_host, const oq_hessian_item* items_device, int64_t count, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    static_assert(sizeof(oq_hessian_item) == 64, "eight 8-byte fields");
+    const int32_t method = oq_hessian_method();
+    OQ_REQUIRE(method == OQ_HESSIAN_AUTO || method == OQ_HESSIAN_F16X3, OQ_ERR_UNSUPPORTED,
+               "oq_hessian_accumulate_many_f32 runs the fp16-piece method only (method %d is set: use oq_hessian_accumulate_f32 per tensor)", method);
+    return launch_syrk_f16x3_many(reinterpret_cast<const int64_t*>(items_host), reinterpret_cast<const int64_t*>(items_device), count, workspace,
+                                  workspace_bytes, as_stream(stream));
+}
+
 // G1 in two halves (fp16-piece method): the HBM-bound preparation of a batch and its matrix-core bound product, so that a
 // caller can run the preparation of batch i + 1 on a side stream while the product of batch i occupies the matrix cores.
 size_t oq_hessian_pieces_bytes(int64_t T, int64_t K) { return (T <= 0 || K <= 0) ? 0 : syrk_bf16x3_pieces_bytes(T, K) + 256; }

@@ -89,6 +89,11 @@ int32_t launch_syrk_bf16x3(const float* X, int64_t T, int64_t K, int64_t ldx, fl
 int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, float alpha, float beta, float* C, unsigned char* base, float* slab,
                            size_t slab_bytes, int terms, int phases, hipStream_t s);   // phases: 1 = X -> pieces, 2 = pieces -> C, 3 = both
 
+// Many Hessian updates in one launch chain (syrk_bf16x3.hip, section 2c).  items: int64 {X, H, T, K, ldx, n_seen, n_add, 0} each.
+size_t syrk_f16x3_many_workspace_bytes(const int64_t* items_host, int64_t count);
+int32_t launch_syrk_f16x3_many(const int64_t* items_host, const int64_t* items_device, int64_t count, void* workspace, size_t workspace_bytes,
+                               hipStream_t s);
+
 // Two-operand GEMM on fp16 pieces (syrk_bf16x3.hip, section 3): C = beta C + alpha A^T B for k-major A [Kd, M], B [Kd, N].
 //   make_f16x2_pieces      absmax -> power-of-two scale -> two fp16 pieces of every element, zero-padded to 32 contraction rows
 //                          and 256 columns; `pieces` (256-byte aligned, gemm_f16x3_pieces_bytes(Kd, cols)) holds the scale

@@ -117,22 +117,27 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 // ---- 1b. fp16 pieces: scale, then hi = f16(x s), lo = f16(x s - hi)
-__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
-                                                             float* __restrict__ partial) {
+__device__ __forceinline__ void absmax_partial_body(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                    float* __restrict__ partial, const int64_t nblocks, const int64_t block) {
     float m = 0.f;
-    const int64_t rows_per = (T + static_cast<int64_t>(gridDim.x) - 1) / static_cast<int64_t>(gridDim.x);
-    const int64_t t0 = static_cast<int64_t>(blockIdx.x) * rows_per, t1 = t0 + rows_per < T ? t0 + rows_per : T;
+    const int64_t rows_per = (T + nblocks - 1) / nblocks;
+    const int64_t t0 = block * rows_per, t1 = t0 + rows_per < T ? t0 + rows_per : T;
     for (int64_t t = t0; t < t1; ++t)
         for (int64_t k = threadIdx.x; k < K; k += 256) m = nmax(m, fabsf(X[t * ldx + k]));
     m = wave_max(m);
     __shared__ float sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+    if (threadIdx.x == 0) partial[block] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+}
+
+__global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                             float* __restrict__ partial) {
+    absmax_partial_body(X, T, K, ldx, partial, static_cast<int64_t>(gridDim.x), static_cast<int64_t>(blockIdx.x));
 }
 
 // partial maxima -> scale[0] = s = 2^(15 - exponent of max) (1 for an all-zero or non-finite batch), scale[1] = 1 / s^2, scale[2] = 1 / s
-__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
+__device__ __forceinline__ void absmax_scale_body(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
     float m = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) m = nmax(m, partial[i]);
     m = wave_max(m);
@@ -156,20 +161,24 @@ __global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
+    absmax_scale_body(partial, n, scale);
+}
+
 __device__ __forceinline__ uint32_t pk_f16(float a, float b) {
     const f16x2 v = {static_cast<_Float16>(a), static_cast<_Float16>(b)};   // v_cvt_f16_f32: round to nearest even
     return __builtin_bit_cast(uint32_t, v);
 }
 
-__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
-                                                          const int64_t Kp, const int64_t nchunks, const float* __restrict__ scale,
-                                                          const float alpha, u32x4* __restrict__ P) {
-    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+__device__ __forceinline__ void split_f16x2_body(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                 const int64_t Kp, const int64_t nchunks, const float* __restrict__ scale,
+                                                 const float alpha, u32x4* __restrict__ P, const int64_t bx, const int64_t by) {
+    const int64_t k = bx * 256 + threadIdx.x;
     const bool col_ok = k < K;
     const float* src = X + (col_ok ? k : K - 1);
     const float sc = scale[0];
 #pragma unroll 1
-    for (int64_t c = static_cast<int64_t>(blockIdx.y) * 4; c < nchunks && c < static_cast<int64_t>(blockIdx.y) * 4 + 4; ++c) {
+    for (int64_t c = by * 4; c < nchunks && c < by * 4 + 4; ++c) {
         float v[8];
         uint32_t alive = 0;
 #pragma unroll
@@ -195,6 +204,12 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
         __builtin_nontemporal_store(hi, o);
         __builtin_nontemporal_store(lo, o + Kp);
     }
+}
+
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                          const int64_t Kp, const int64_t nchunks, const float* __restrict__ scale,
+                                                          const float alpha, u32x4* __restrict__ P) {
+    split_f16x2_body(X, T, K, ldx, Kp, nchunks, scale, alpha, P, static_cast<int64_t>(blockIdx.x), static_cast<int64_t>(blockIdx.y));
 }
 
 // one matrix-core instruction on a piece pair, chosen by the piece type
@@ -503,18 +518,18 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     }
 }
 
-__global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
-                                                                 const float alpha_in, const float beta, float* __restrict__ C,
-                                                                 float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
-                                                                 const float* __restrict__ post_scale) {
+// `tile`: the block's (XCD-remapped) index among the upper-triangle tiles of this matrix; `slice`: its T-slice
+__device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
+                                                  const float alpha_in, const float beta, float* __restrict__ C,
+                                                  float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
+                                                  const float* __restrict__ post_scale, const int tile, const int64_t slice, unsigned char* lds) {
     using G = StageGeom<3>;
     constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
     const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     int tile_m, tile_n;
-    upper_tile_of(static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), ntiles, tile_m, tile_n);
+    upper_tile_of(tile, ntiles, tile_m, tile_n);
     const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
-    const int64_t s_begin = static_cast<int64_t>(blockIdx.y) * stages_per_slice;
+    const int64_t s_begin = slice * stages_per_slice;
     const int64_t s_end = s_begin + stages_per_slice < nstages_all ? s_begin + stages_per_slice : nstages_all;
     const int64_t nstages = s_end - s_begin;
 
@@ -535,7 +550,7 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __
     f32x4v acc[4][8];
     f16_m16_mainloop<NDMA>(gsrc, stage_bytes, nstages, lds, acc);
 
-    float* out = slab ? slab + static_cast<int64_t>(blockIdx.y) * K * K : C;
+    float* out = slab ? slab + slice * K * K : C;
     const bool direct = slab == nullptr;
     const bool diag = tile_m == tile_n;
 #pragma unroll
@@ -558,6 +573,103 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __
                 }
             }
         }
+}
+
+__global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
+                                                                 const float alpha_in, const float beta, float* __restrict__ C,
+                                                                 float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
+                                                                 const float* __restrict__ post_scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    syrk_f16_m16_body(P, K, Kp, nstages_all, alpha_in, beta, C, slab, stages_per_slice, ntiles, post_scale,
+                      static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), static_cast<int64_t>(blockIdx.y), lds);
+}
+
+// ---- 2c. Many Hessian updates in one launch chain (oq_hessian_accumulate_many_f32): the activations a calibration batch
+// taps (72 tensors of 5120 rows on gemma-3-270m shapes) are each far too small to fill 256 CUs -- 6 to 36 tiles -- and five
+// launches per tensor made the per-tensor route launch-bound.  One table of items, one launch per step: blockIdx -> (item,
+// block of that item) by a binary search over the items' first block ids (uniform: scalar loads).  Every item takes the
+// fp16-piece route with ONE T-slice, so the product writes H directly (alpha / beta in the epilogue, no slabs).
+struct SyrkItem {
+    const float* X;
+    float* C;
+    u32x4* P;
+    float* scale;            // the item's header in front of P: [s, 1 / s^2, 1 / s, -, absmax partials ...]
+    int64_t T, K, ldx, Kp, nchunks, nstages;
+    int64_t split0;          // first block of this item in the split launch; its split grid is (Kp / 256) x ceil(nchunks / 4)
+    int64_t tile0;           // first block of this item in the product launch
+    float alpha, beta;
+    int32_t tn, absmax_blocks;
+};
+
+constexpr int kManyAbsmaxBlocks = 64;
+
+// public items (oq_hip.h: int64 {X, H, T, K, ldx, n_seen, n_add, 0}) -> SyrkItem table; one thread, count is small
+__global__ void syrk_many_plan_kernel(const int64_t* __restrict__ pub, const int count, unsigned char* __restrict__ pieces_base, SyrkItem* __restrict__ items) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t split0 = 0, tile0 = 0;
+    size_t off = 0;
+    for (int m = 0; m < count; ++m) {
+        const int64_t* it = pub + static_cast<int64_t>(m) * 8;
+        SyrkItem o;
+        o.X = reinterpret_cast<const float*>(it[0]);
+        o.C = reinterpret_cast<float*>(it[1]);
+        o.T = it[2]; o.K = it[3]; o.ldx = it[4];
+        const int64_t n_seen = it[5], n_total = it[5] + it[6];
+        o.Kp = (o.K + kST - 1) / kST * kST;
+        o.nstages = (o.T + StageGeom<3>::ROWS - 1) / StageGeom<3>::ROWS;
+        o.nchunks = o.nstages * StageGeom<3>::CH;
+        o.scale = reinterpret_cast<float*>(pieces_base + off);
+        o.P = reinterpret_cast<u32x4*>(pieces_base + off + 16384);
+        off += 16384 + static_cast<size_t>(o.nchunks) * 2 * static_cast<size_t>(o.Kp) * 16;
+        o.split0 = split0;
+        split0 += (o.Kp / 256) * ((o.nchunks + 3) / 4);
+        o.tn = static_cast<int32_t>(o.Kp / kST);
+        o.tile0 = tile0;
+        tile0 += static_cast<int64_t>(o.tn) * (o.tn + 1) / 2;
+        o.alpha = static_cast<float>(2.0 / static_cast<double>(n_total));                                               // as oq_hessian_accumulate_f32
+        o.beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));   // gptq.py:254
+        o.absmax_blocks = static_cast<int32_t>(o.T < kManyAbsmaxBlocks ? o.T : kManyAbsmaxBlocks);
+        items[m] = o;
+    }
+}
+
+// the item whose block range holds `id`: FIRST(items[m]) <= id < FIRST(items[m + 1])
+template <typename First>
+__device__ __forceinline__ int item_of_block(const SyrkItem* __restrict__ items, const int count, const int64_t id, First first) {
+    int lo = 0, hi = count - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first(items[mid]) <= id) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void absmax_partial_many_kernel(const SyrkItem* __restrict__ items) {
+    const SyrkItem& it = items[blockIdx.y];
+    if (static_cast<int>(blockIdx.x) >= it.absmax_blocks) return;
+    absmax_partial_body(it.X, it.T, it.K, it.ldx, it.scale + 4, it.absmax_blocks, static_cast<int64_t>(blockIdx.x));
+}
+
+__global__ __launch_bounds__(256) void absmax_scale_many_kernel(const SyrkItem* __restrict__ items) {
+    const SyrkItem& it = items[blockIdx.x];
+    absmax_scale_body(it.scale + 4, it.absmax_blocks, it.scale);
+}
+
+__global__ __launch_bounds__(256) void split_f16x2_many_kernel(const SyrkItem* __restrict__ items, const int count) {
+    const int64_t id = blockIdx.x;
+    const int m = item_of_block(items, count, id, [](const SyrkItem& i) { return i.split0; });
+    const SyrkItem& it = items[m];
+    const int64_t local = id - it.split0, nbx = it.Kp / 256;
+    split_f16x2_body(it.X, it.T, it.K, it.ldx, it.Kp, it.nchunks, it.scale, it.alpha, it.P, local % nbx, local / nbx);
+}
+
+__global__ __launch_bounds__(kSThreads) void syrk_f16_m16_many_kernel(const SyrkItem* __restrict__ items, const int count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int64_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const int m = item_of_block(items, count, id, [](const SyrkItem& i) { return i.tile0; });
+    const SyrkItem& it = items[m];
+    syrk_f16_m16_body(it.P, it.K, it.Kp, it.nstages, it.alpha, it.beta, it.C, nullptr, it.nstages, it.tn, it.scale,
+                      static_cast<int>(id - it.tile0), 0, lds);
 }
 
 // ---- 3. Two-operand GEMM on fp16 pieces: C = beta C + alpha A^T B, A [Kd, M] and B [Kd, N] both k-major (gemm_tn.hpp's
@@ -758,6 +870,12 @@ int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, fl
             if (fill > best + 0.02) { best = fill; splits = c; }      // more slices only for a real gain (each costs a K x K pass)
         }
     }
+#ifdef OQ_SYRK_LAB
+    if (const char* v = getenv("OQ_SYRK_SPLITS")) {      // lab builds only (scripts/lab_syrk_splits.sh): force the slice count
+        const int c = atoi(v);
+        if (c >= 1 && (c == 1 || static_cast<size_t>(c) * K * K * sizeof(float) <= slab_bytes)) splits = c;
+    }
+#endif
     int64_t per = ceil_div(nstages, splits);
     splits = static_cast<int>(ceil_div(nstages, per));
     float* slab_f = splits > 1 ? slab : nullptr;
@@ -778,6 +896,51 @@ int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     return launch_syrk_reduce(slab_f, splits, K, alpha, beta, C, kST, s, f16 ? scale : nullptr);
 }
 
+
+// ---- many Hessian updates, one launch chain (section 2c)
+static size_t syrk_many_item_bytes(int64_t T, int64_t K) {
+    return kScaleHeaderBytes + static_cast<size_t>(stages_of(T, StageGeom<3>::ROWS)) * StageGeom<3>::CH * 2 * static_cast<size_t>(padded_k(K)) * 16;
+}
+static size_t syrk_many_table_bytes(int64_t count) { return (static_cast<size_t>(count) * sizeof(SyrkItem) + 255) / 256 * 256; }
+
+size_t syrk_f16x3_many_workspace_bytes(const int64_t* items_host, int64_t count) {
+    if (items_host == nullptr || count <= 0) return 256;
+    size_t total = syrk_many_table_bytes(count) + 512;
+    for (int64_t m = 0; m < count; ++m) total += syrk_many_item_bytes(items_host[m * 8 + 2], items_host[m * 8 + 3]);
+    return total;
+}
+
+int32_t launch_syrk_f16x3_many(const int64_t* items_host, const int64_t* items_device, int64_t count, void* workspace, size_t workspace_bytes,
+                               hipStream_t s) {
+    OQ_REQUIRE(items_host && items_device && count > 0 && count <= 65535, OQ_ERR_INVALID_ARGUMENT, "hessian_many: 1 to 65535 items, in host and device memory");
+    int64_t split_blocks = 0, tiles = 0;
+    for (int64_t m = 0; m < count; ++m) {
+        const int64_t* it = items_host + m * 8;
+        OQ_REQUIRE(it[0] != 0 && it[1] != 0 && it[2] > 0 && it[3] > 0 && it[4] >= it[3] && it[5] >= 0 && it[6] > 0, OQ_ERR_INVALID_ARGUMENT,
+                   "hessian_many: item %lld: X, H, T > 0, K > 0, ldx >= K, n_seen >= 0, n_add > 0 expected", (long long)m);
+        const int64_t Kp = padded_k(it[3]), nchunks = stages_of(it[2], StageGeom<3>::ROWS) * StageGeom<3>::CH, tn = Kp / kST;
+        split_blocks += (Kp / 256) * ceil_div(nchunks, 4);
+        tiles += tn * (tn + 1) / 2;
+    }
+    OQ_REQUIRE(split_blocks < (1ll << 31) && tiles < (1ll << 31), OQ_ERR_UNSUPPORTED, "hessian_many: too many blocks for one launch");
+    const size_t need = syrk_f16x3_many_workspace_bytes(items_host, count);
+    OQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, OQ_ERR_WORKSPACE, "hessian_many: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    base += (256 - (reinterpret_cast<uintptr_t>(base) & 255u)) & 255u;
+    SyrkItem* table = reinterpret_cast<SyrkItem*>(base);
+    unsigned char* pieces = base + syrk_many_table_bytes(count);
+    const int n = static_cast<int>(count);
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_f16_m16_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, StageGeom<3>::LDS);
+    OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "hessian_many: cannot reserve %d bytes of LDS", StageGeom<3>::LDS);
+    hipLaunchKernelGGL(syrk_many_plan_kernel, dim3(1), dim3(64), 0, s, items_device, n, pieces, table);
+    hipLaunchKernelGGL(absmax_partial_many_kernel, dim3(kManyAbsmaxBlocks, static_cast<uint32_t>(n)), dim3(256), 0, s, table);
+    hipLaunchKernelGGL(absmax_scale_many_kernel, dim3(static_cast<uint32_t>(n)), dim3(256), 0, s, table);
+    hipLaunchKernelGGL(split_f16x2_many_kernel, dim3(static_cast<uint32_t>(split_blocks)), dim3(256), 0, s, table, n);
+    int32_t st = check_launch("split_f16x2_many_kernel");
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(syrk_f16_m16_many_kernel, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), StageGeom<3>::LDS, s, table, n);
+    return check_launch("syrk_f16_m16_many_kernel");
+}
 
 // ---- host side of the two-operand GEMM (gemm_tn.hpp)
 size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols) {

@@ -56,6 +56,8 @@ PROTOTYPES = {
     "oq_rtn_batched_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "oq_rtn_quantize_batched_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _p, _p, _p,
                                            _i32, _p, _sz, _p]),
+    "oq_hessian_many_workspace_bytes": (_sz, [_p, _i64]),
+    "oq_hessian_accumulate_many_f32": (_i32, [_p, _p, _i64, _p, _sz, _p]),
     "oq_hessian_pieces_bytes": (_sz, [_i64, _i64]),
     "oq_hessian_slab_bytes": (_sz, [_i64]),
     "oq_hessian_prepare_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _p, _sz, _p]),

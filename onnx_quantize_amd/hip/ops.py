@@ -599,6 +599,46 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
     return int(n_seen) + n_add
 
 
+_MANY_MIN_K, _MANY_MIN_ROWS = 512, 512
+
+
+def hessian_accumulate_many(xs, hs, n_seen) -> list[int]:
+    """gptq.py:246-260 for a list of (input, Hessian) pairs -- the tensors one calibration batch taps -- in ONE launch chain
+    (`oq_hessian_accumulate_many_f32`).  ``xs[i]`` [n_add, ..., K_i] fp32, ``hs[i]`` [K_i, K_i] updated in place, ``n_seen[i]``
+    the samples already in it; returns the new sample counts.  Items narrower than 512 columns or shorter than 512 rows, and
+    every item when another Hessian method than the fp16 pieces is selected, go through `hessian_accumulate` one by one
+    (their padding to 256-wide tiles would cost more than the launches save)."""
+    xs, hs, n_seen = list(xs), list(hs), [int(n) for n in n_seen]
+    if not (len(xs) == len(hs) == len(n_seen)):
+        raise ValueError("hessian_accumulate_many: xs, hs and n_seen must have one entry per item")
+    out = [0] * len(xs)
+    rows, keep = [], []
+    grouped = hessian_method() in ("auto", "f16x3")
+    for i, (x, h) in enumerate(zip(xs, hs)):
+        _require_device(x, "x", torch.float32)
+        _require_device(h, "H", torch.float32)
+        x2, ldx = _row_major(x.reshape(-1, x.shape[-1]))
+        t, k = x2.shape
+        if h.shape != (k, k) or not h.is_contiguous():
+            raise ValueError(f"H[{i}] must be a contiguous [{k}, {k}] tensor")
+        if not grouped or k < _MANY_MIN_K or t < _MANY_MIN_ROWS:
+            out[i] = hessian_accumulate(x, h, n_seen[i])
+            continue
+        rows.append((x2.data_ptr(), h.data_ptr(), t, k, ldx, n_seen[i], int(x.shape[0]), 0))
+        keep.append(x2)
+        out[i] = n_seen[i] + int(x.shape[0])
+    if rows:
+        import numpy as np
+
+        lib = L.load()
+        host = np.asarray(rows, dtype=np.int64)
+        dev = torch.from_numpy(host).to(keep[0].device)                   # 64 bytes per item, one blocking copy
+        hp = C.c_void_p(host.ctypes.data)
+        ws = _workspace(lib.oq_hessian_many_workspace_bytes(hp, len(rows)), keep[0].device)
+        L.check(lib.oq_hessian_accumulate_many_f32(hp, _ptr(dev), len(rows), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
 class HessianPipeline:
     """gptq.py:246-260 for a SEQUENCE of batches, possibly of many inputs, with the two halves of every batch on two
     streams: the HBM-bound preparation (max |x|, scale, fp16 pieces: oq_hessian_prepare_f32) of batch i + 1 runs on a side

@@ -39,9 +39,9 @@ batches = [torch.randn((10, 512, 640), device=dev) for _ in range(4)]       # re
 args = QActivationArgs(dtype=QuantType.QUInt8, is_static=True)
 
 
-def run(hessians: bool):
+def run(hessians: bool, hessian_streams: int = 0):
     stream = ActivationStream(calibrator=MinMaxCalibrator(), input_names=in_names, output_names=out_names,
-                              hessian_names=in_names if hessians else ())
+                              hessian_names=in_names if hessians else (), hessian_streams=hessian_streams)
     torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
     t_model = t_feed = 0.0
     t0 = time.perf_counter()
@@ -60,9 +60,9 @@ def run(hessians: bool):
 
 
 run(False)
-for hess in (False, True):
-    stream, total, t_model, t_feed, nbytes, peak, nq = run(hess)
-    print(f"hessians={hess}: 51 batches x {len(taps)} tapped tensors ({nbytes / 1e9:.2f} GB per batch, {51 * nbytes / 1e9:.0f} GB in all): "
+for hess, hs in ((False, 0), (True, 4), (True, 0)):
+    stream, total, t_model, t_feed, nbytes, peak, nq = run(hess, hs)
+    print(f"hessians={hess} ({'one grouped call per batch' if hs == 0 else f'per-tensor calls on {hs} side streams'}): 51 batches x {len(taps)} tapped tensors ({nbytes / 1e9:.2f} GB per batch, {51 * nbytes / 1e9:.0f} GB in all): "
           f"{total * 1e3:.1f} ms (model forward {t_model * 1e3:.1f}, stream.feed {t_feed * 1e3:.1f} = {51 * nbytes / t_feed / 1e12:.2f} TB/s of activations), "
           f"{nq} (scale, zp) pairs, peak device memory {peak:.2f} GiB", flush=True)
 layers = {f"{i}.{n}": (getattr(model[i], n).weight.detach().t().contiguous(), f"{i}.{n}/in") for i in range(18) for n in ("qkv", "o", "up", "down")}

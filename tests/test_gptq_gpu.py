@@ -869,3 +869,106 @@ def test_two_stream_hessian_pipeline_gives_the_one_call_bits(ops):
         assert torch.equal(h2, ref[1024][0])
     finally:
         ops.hessian_set_method(before)
+
+
+# ----------------------------------------------------------------------------- a calibration batch's Hessians in one call
+def _f64_update(h0, n_seen, x):
+    """gptq.py:246-260 in float64 on the flattened input (n = leading-dimension entries, :247)."""
+    n_add = x.shape[0]
+    x2 = x.reshape(-1, x.shape[-1]).astype(np.float64)
+    n = n_seen + n_add
+    return h0.astype(np.float64) * (n_seen / n) + (2.0 / n) * (x2.T @ x2), n
+
+
+def test_hessians_of_a_batch_in_one_call_follow_float64_and_the_per_tensor_route(ops):
+    """`ops.hessian_accumulate_many` (oq_hessian_accumulate_many_f32): mixed widths and lengths -- gemma-3-270m's 640 / 1024 /
+    2048 columns by 5120 rows, ragged ones, one below the grouped route's limits --, some Hessians already holding samples.
+    Every result within 1e-5 max|H| of float64 (the north-star tolerance) and of the per-tensor call, exactly symmetric, dead
+    channels exact zeros."""
+    import torch
+    rng = np.random.default_rng(11)
+    shapes = [((10, 512, 640), 0), ((10, 512, 1024), 30), ((10, 512, 2048), 0), ((3, 333, 700), 7), ((1, 512, 513), 0),
+              ((4, 200, 640), 12), ((2, 64, 96), 5), ((10, 512, 640), 10)]
+    xs, hs, seen, refs, singles = [], [], [], [], []
+    for shape, n_seen in shapes:
+        k = shape[-1]
+        x = rng.standard_normal(shape, dtype=np.float32) * rng.uniform(0.05, 4.0, size=k).astype(np.float32)
+        x[..., 3] = 0.0                                               # a dead channel
+        x[..., 5] *= 60.0                                             # an outlier channel
+        a = rng.standard_normal((k + 8, k)).astype(np.float32)
+        h0 = ((a.T @ a) / (k + 8)).astype(np.float32) if n_seen else np.zeros((k, k), np.float32)
+        h0[3, :] = 0.0
+        h0[:, 3] = 0.0
+        ref, _ = _f64_update(h0, n_seen, x)
+        h_single = dev(h0)
+        ops.hessian_accumulate(dev(x), h_single, n_seen)
+        xs.append(dev(x)); hs.append(dev(h0)); seen.append(n_seen); refs.append(ref); singles.append(h_single)
+    out = ops.hessian_accumulate_many(xs, hs, seen)
+    assert out == [s + sh[0][0] for s, sh in zip(seen, shapes)]
+    for h, ref, single, (shape, _) in zip(hs, refs, singles, shapes):
+        got = h.cpu().numpy()
+        tol = 1e-5 * float(np.abs(ref).max())
+        np.testing.assert_allclose(got, ref, rtol=0, atol=tol, err_msg=str(shape))
+        np.testing.assert_allclose(got, single.cpu().numpy(), rtol=0, atol=tol, err_msg=str(shape))
+        np.testing.assert_array_equal(got, got.T)
+        assert got[3, 3] == 0.0 and not got[3].any() and not got[:, 3].any()
+    # the item below the limits took the per-tensor route: the same bits
+    assert torch.equal(hs[6], singles[6])
+
+
+def test_hessians_of_a_batch_stream_like_the_per_tensor_accumulators(ops):
+    """Three batches through the grouped call == the running update of gptq.py:254-258 in float64, and a repeated run gives
+    the same bits (one fixed summation order per item)."""
+    import torch
+    rng = np.random.default_rng(12)
+    widths = [640, 1024, 2048, 640]
+    batches = [[rng.standard_normal((5, 256, k), dtype=np.float32) * 1.5 for k in widths] for _ in range(3)]
+
+    def run():
+        hs = [torch.zeros((k, k), device="cuda") for k in widths]
+        n = [0] * len(widths)
+        for b in batches:
+            n = ops.hessian_accumulate_many([dev(x) for x in b], hs, n)
+        return hs, n
+
+    hs, n = run()
+    hs2, _ = run()
+    assert n == [15] * len(widths)
+    for i, k in enumerate(widths):
+        ref, seen = np.zeros((k, k)), 0
+        for b in batches:
+            ref, seen = _f64_update(ref, seen, b[i])
+        np.testing.assert_allclose(hs[i].cpu().numpy(), ref, rtol=0, atol=1e-5 * float(np.abs(ref).max()))
+        assert torch.equal(hs[i], hs2[i])
+
+
+def test_hessians_of_a_batch_honour_the_method_knob_and_reject_bad_items(ops):
+    import torch
+    from onnx_quantize_amd.hip import _lib as L
+    rng = np.random.default_rng(13)
+    x = dev(rng.standard_normal((4, 256, 640), dtype=np.float32))
+    before = ops.hessian_method()
+    ops.hessian_set_method("f32")
+    try:
+        a, b = torch.zeros((640, 640), device="cuda"), torch.zeros((640, 640), device="cuda")
+        ops.hessian_accumulate_many([x], [a], [0])                     # per-tensor route on the fp32 kernel
+        ops.hessian_accumulate(x, b, 0)
+        assert torch.equal(a, b)
+        import ctypes as C
+        lib = L.load()
+        host = np.asarray([[x.data_ptr(), a.data_ptr(), 1024, 640, 640, 0, 4, 0]], dtype=np.int64)
+        d = torch.from_numpy(host).cuda()
+        ws = torch.empty(lib.oq_hessian_many_workspace_bytes(C.c_void_p(host.ctypes.data), 1), dtype=torch.uint8, device="cuda")
+        st = lib.oq_hessian_accumulate_many_f32(C.c_void_p(host.ctypes.data), C.c_void_p(d.data_ptr()), 1, C.c_void_p(ws.data_ptr()), ws.numel(), None)
+        assert st == L.OQ_ERR_UNSUPPORTED
+    finally:
+        ops.hessian_set_method(before)
+    with pytest.raises(ValueError):
+        ops.hessian_accumulate_many([x], [torch.zeros((512, 512), device="cuda")], [0])
+    host = np.asarray([[x.data_ptr(), a.data_ptr(), 1024, 640, 600, 0, 4, 0]], dtype=np.int64)      # ldx < K
+    import ctypes as C
+    lib = L.load()
+    d = torch.from_numpy(host).cuda()
+    ws = torch.empty(1 << 24, dtype=torch.uint8, device="cuda")
+    assert lib.oq_hessian_accumulate_many_f32(C.c_void_p(host.ctypes.data), C.c_void_p(d.data_ptr()), 1, C.c_void_p(ws.data_ptr()), ws.numel(), None) == L.OQ_ERR_INVALID_ARGUMENT
+    assert lib.oq_hessian_accumulate_many_f32(C.c_void_p(host.ctypes.data), C.c_void_p(d.data_ptr()), 1, C.c_void_p(ws.data_ptr()), 1024, None) != 0
