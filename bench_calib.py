@@ -14,8 +14,9 @@ calibrate.py:264-266 is timed next to it), then compute_range + _compute_qparams
                 HIP events over 20 launches, against the 8 TB/s HBM peak
   cpu_baseline  the oracle's MinMaxOracle.collect (minmax.py:40-64 restated: np.min + np.max per tensor) over ONE batch of
                 the same 72 tensors on the host (kind "port", one core: NumPy reductions are single-threaded)
+  hessians      the GPTQ side of a batch: the 72 Hessian updates in one grouped call against one call per tensor
   verified      every (min, max) of the timed run equals torch's own reduction of the same tensors and the oracle's on the
-                sampled batch, bit for bit
+                sampled batch, bit for bit; the two Hessian routes agree to 2e-5 of max |H|
 """
 import json
 import os
@@ -109,6 +110,30 @@ def run(dev, cpu: bool = True, layers: int = 18, batches: int = 51) -> dict:
     ok = ok and all(torch.equal(a[0], b[0]) and float(a[1]) == float(b[1]) for a, b in zip(wq[:5], wq_many[:5]))
     wparams = sum(w.numel() for w in weights)
 
+    # the GPTQ side of a calibration batch (calibrate.py:292-305 -> gptq.py:246-260): the Hessian updates of the 72 tapped
+    # inputs, one grouped launch chain per batch (oq_hessian_accumulate_many_f32) against one call per tensor
+    names = list(acts)
+    xs = [acts[n] for n in names]
+    def hessian_batches(many: bool, reps: int):
+        hs = [torch.zeros((x.shape[-1], x.shape[-1]), device=dev) for x in xs]
+        n = [0] * len(xs)
+        def one():
+            nonlocal n
+            n = ops.hessian_accumulate_many(xs, hs, n) if many else [ops.hessian_accumulate(x, h, k) for x, h, k in zip(xs, hs, n)]
+        one()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            one()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps, hs
+    t_h_many, hs_many = hessian_batches(True, 10)
+    t_h_each, hs_each = hessian_batches(False, 10)
+    h_dev = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(hs_many, hs_each))
+    h_flop = sum(2.0 * x.shape[0] * x.shape[1] * x.shape[2] ** 2 for x in xs)
+    ok = ok and h_dev <= 2e-5 and all(bool(torch.equal(h, h.T)) for h in hs_many[:4])
+    del hs_many, hs_each
+
     # the reduction kernel alone: one 1.3 GB tensor, HIP events over 20 launches on the launch stream
     big = torch.randn((64, 2048, 2560), generator=gen, device=dev)
     st = ops.minmax_state(dev)
@@ -140,6 +165,11 @@ def run(dev, cpu: bool = True, layers: int = 18, batches: int = 51) -> dict:
                     "weights_rtn_int8_per_tensor": round(t_weights, 4), "weights_rtn_int8_per_tensor_one_call": round(t_weights_many, 5)},
         "weights": {"matrices": len(weights), "params": wparams, "M_params_per_s": round(wparams / t_weights / 1e6, 1),
                     "M_params_per_s_one_call": round(wparams / t_weights_many / 1e6, 1)},
+        "hessians": {"what": "gptq.py:246-260 for the 72 tapped inputs of one batch: ops.hessian_accumulate_many (one launch chain, fp16-piece "
+                             "products) against ops.hessian_accumulate per tensor, wall clock over 10 batches",
+                     "ms_per_batch_one_call": round(t_h_many * 1e3, 3), "ms_per_batch_per_tensor_calls": round(t_h_each * 1e3, 3),
+                     "fp32_equivalent_TFLOPs_one_call": round(h_flop / t_h_many / 1e12, 1),
+                     "max_abs_diff_between_routes_over_max_abs_h": h_dev},
         "tensors_per_s": round(len(acts) * batches / t_collect, 1),
         "frac_of_hbm_peak_end_to_end": round(nbytes * batches / dev_collect / 1e9 / HBM_PEAK_GBS, 4),
         "per_tensor_calls": {"GBs": round(nbytes * batches / t_per_tensor / 1e9, 1),

@@ -166,18 +166,28 @@ def run(args, dev, rank: int, world: int):
             groups.append((key, []))
         groups[seen[key]][1].append(i)
 
-    def model_pass(mode: str) -> dict:
-        """One timed pass over this rank's share of the model: Hessians, factors, loop, packing, the gather to rank 0."""
-        s_h = torch.cuda.Stream(device=dev)
-        # batched factors (factor_wave > 0) run on the Hessian's stream unless --overlap: side by side the two kinds of
-        # matrix-core kernels only slow each other down (measured: 4.88 s in sequence, 5.2-5.6 s on 1 + 2..4 streams)
-        one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
-        q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
+    # the streams of every pass: torch's caching allocator keeps freed blocks per stream, so passes on the same streams reuse
+    # what the first one mapped
+    s_h = torch.cuda.Stream(device=dev)
+    # batched factors (factor_wave > 0) run on the Hessian's stream unless --overlap: side by side the two kinds of
+    # matrix-core kernels only slow each other down (measured: 4.88 s in sequence, 5.2-5.6 s on 1 + 2..4 streams)
+    one_stream = args.no_overlap or (args.factor_wave > 0 and not args.overlap)
+    q_streams = [s_h] if one_stream else [torch.cuda.Stream(device=dev) for _ in range(max(1, args.factor_streams))]
+
+    shared_pipe = {}
+
+    def model_pass(mode: str, warm: bool = False) -> dict:
+        """One timed pass over this rank's share of the model: Hessians, factors, loop, packing, the gather to rank 0.
+        ``warm``: the first wave (or input) only, nothing gathered -- run once, untimed, before a timed pass so that every
+        buffer size of a wave has been mapped: the first `hipMalloc` of the 15.5 GB factor workspace took anything from 5 ms to
+        2.4 s on the MI355X host (scripts/lab_alloc_trace.py, two of six processes), inside the factor phase."""
         results, timings, samples = {}, [], {}
         streamer = None
         # two-stream Hessian (ops.HessianPipeline): only the fp16-piece method has a separable preparation
-        pipe = ops.HessianPipeline(dev) if (not args.no_hessian_pipeline and ops.hessian_method() in ("auto", "f16x3") and
-                                            min(sp.k for sp in specs) >= 2048) else None
+        use_pipe = not args.no_hessian_pipeline and ops.hessian_method() in ("auto", "f16x3") and min(sp.k for sp in specs) >= 2048
+        if use_pipe and "pipe" not in shared_pipe:
+            shared_pipe["pipe"] = ops.HessianPipeline(dev)                                          # its buffers serve every pass
+        pipe = shared_pipe["pipe"] if use_pipe else None
         if pipe is not None and acts:
             kmax = max(acts)
             pipe.reserve(max(x.shape[0] * x.shape[1] for x in acts[kmax]), kmax)      # workspaces exist before the clock starts
@@ -198,7 +208,7 @@ def run(args, dev, rank: int, world: int):
 
         if args.factor_wave <= 0:
             # one factor chain per input, as soon as its Hessian is complete
-            for gi, (key, members) in enumerate(groups):
+            for gi, (key, members) in enumerate(groups[:1] if warm else groups):
                 s_q = q_streams[gi % len(q_streams)]
                 k = specs[members[0]].k
                 with torch.cuda.stream(s_h):
@@ -229,9 +239,10 @@ def run(args, dev, rank: int, world: int):
             # receives now, a rank sends a wave's (packed int4, scales, zero points) as soon as they exist
             bundles = wave_bundles(specs, plan, per_wave)
             g128 = lambda sp: sp.n * sp.k // 128  # noqa: E731
-            streamer = StreamedGather(specs, bundles, lambda sp: [(torch.uint8, (sp.k * sp.n // 2,)), (torch.float32, (g128(sp), 1)),
-                                                                   (torch.int8, (g128(sp), 1))], device=dev)
-            for w0 in range(0, len(groups), per_wave):
+            if not warm:
+                streamer = StreamedGather(specs, bundles, lambda sp: [(torch.uint8, (sp.k * sp.n // 2,)), (torch.float32, (g128(sp), 1)),
+                                                                       (torch.int8, (g128(sp), 1))], device=dev)
+            for w0 in range(0, per_wave if warm else len(groups), per_wave):
                 wave = groups[w0:w0 + per_wave]
                 s_q = q_streams[(w0 // per_wave) % len(q_streams)]
                 slots, last = {}, {}
@@ -280,6 +291,8 @@ def run(args, dev, rank: int, world: int):
                         timings.append(("f", e2, e3))
                         for j, gi in enumerate(slots[k]):
                             quantize_members(wave[gi][1], stacks[k][j], shared_list[j])
+                    if warm:
+                        continue
                     if world > 1:
                         # the wave's kernels must have produced the bytes before the communicator's stream reads them
                         torch.cuda.current_stream().synchronize()
@@ -287,6 +300,8 @@ def run(args, dev, rank: int, world: int):
                     streamer.push(b, {i: results[i] for i in bundles[rank][b]})
         torch.cuda.synchronize()
         t_quant = time.perf_counter() - t0
+        if warm:
+            return {}
         fence()
         t1 = time.perf_counter()
         if streamer is not None:
@@ -304,6 +319,7 @@ def run(args, dev, rank: int, world: int):
                 "samples": samples, "gathered": gathered, "nbytes": nbytes, "one_stream": one_stream, "n_streams": len(q_streams),
                 "pipelined": pipe is not None}
 
+    model_pass(args.mode, warm=True)
     first = model_pass(args.mode)
     n_gathered = len(first["gathered"]) if first["gathered"] is not None else -1
     wall, t_quant, t_gather, t_h, t_f, t_l = (first[k] for k in ("wall", "t_quant", "t_gather", "t_h", "t_f", "t_l"))
@@ -430,6 +446,7 @@ def run(args, dev, rank: int, world: int):
     if "corrected" in extras and args.mode == "parity":
         # no torch.cuda.empty_cache() between the passes: handing tens of GB back to the driver and mapping them again costs
         # seconds that land inside the next pass's timed region (measured: +1.9 s)
+        model_pass("corrected", warm=True)
         cp = model_pass("corrected")
         cw, ch, cf, cl = reduce_max([cp["wall"], cp["t_h"], cp["t_f"], cp["t_l"]])
         # gptq.py:186-208 as intended: the layer OUTPUT error ||X W - X W^||_F of the first layer of every shape must be
@@ -462,6 +479,7 @@ def run(args, dev, rank: int, world: int):
         del cp
     if "f32" in extras and headline_method != "f32":
         ops.hessian_set_method("f32")
+        model_pass("parity", warm=True)
         fp = model_pass("parity")
         ops.hessian_set_method(headline_method)
         fw, fh, ff, fl = reduce_max([fp["wall"], fp["t_h"], fp["t_f"], fp["t_l"]])

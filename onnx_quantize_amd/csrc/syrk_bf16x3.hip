@@ -117,13 +117,18 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restri
 }
 
 // ---- 1b. fp16 pieces: scale, then hi = f16(x s), lo = f16(x s - hi)
+#ifdef OQ_PREP_NT
+#define OQ_PREP_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define OQ_PREP_LOAD(p) (*(p))
+#endif
 __device__ __forceinline__ void absmax_partial_body(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
                                                     float* __restrict__ partial, const int64_t nblocks, const int64_t block) {
     float m = 0.f;
     const int64_t rows_per = (T + nblocks - 1) / nblocks;
     const int64_t t0 = block * rows_per, t1 = t0 + rows_per < T ? t0 + rows_per : T;
     for (int64_t t = t0; t < t1; ++t)
-        for (int64_t k = threadIdx.x; k < K; k += 256) m = nmax(m, fabsf(X[t * ldx + k]));
+        for (int64_t k = threadIdx.x; k < K; k += 256) m = nmax(m, fabsf(OQ_PREP_LOAD(X + t * ldx + k)));
     m = wave_max(m);
     __shared__ float sm[4];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
@@ -184,7 +189,7 @@ __device__ __forceinline__ void split_f16x2_body(const float* __restrict__ X, co
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int64_t t = c * 8 + r;
-            const float x = src[(t < T ? t : T - 1) * ldx];
+            const float x = OQ_PREP_LOAD(src + (t < T ? t : T - 1) * ldx);
             v[r] = (t < T && col_ok) ? x * sc : 0.f;                       // a power of two: exact
             // a sample whose square the fp32 path still sees (H[k][k] > 0: the channel is NOT dead, gptq.py:284-286) must not
             // vanish below fp16's last subnormal (|x| < 2^-40 max|x|): it keeps one unit there
