@@ -860,19 +860,26 @@ int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, fl
 
     const int tn = static_cast<int>(Kp / kST);
     const int64_t tiles = static_cast<int64_t>(tn) * (tn + 1) / 2;
-    // T-slices: one block per CU (144 KB of LDS), 256 CUs.  Choose the slice count (<= 16, slices of >= 32 stages, slab
-    // permitting) whose block count fills whole rounds of 256 best; ties go to fewer slices.
+    // T-slices: one block per CU (128-144 KB of LDS), 256 CUs.  Choose the slice count (<= 16, slices of >= 512 rows, slab
+    // permitting) by a cost in stage times: rounds of 256 blocks x (stages of a slice + ~20 stages of prologue and 256 KB
+    // epilogue per block) + one K x K pass per slice for the reduction (64 MB at ~5 TB/s = 13 us = 16 stages of 0.8 us at
+    // K = 4096).  Measured on K = 4096, 65 536 rows (scripts/lab_syrk_splits.py, ms per product): 1 slice 3.26, 3: 2.72,
+    // 5: 2.57, 7: 2.54, 9: 2.53, 15: 2.61 -- the best fill (15: 2040 blocks = 7.97 rounds) is not the fastest; at 262 144
+    // rows 15 is (9.74 against 9.95 for 7), and K = 11008 is flat (1 slice 17.04, 4: 17.02).  Ties go to fewer slices.
     int splits = 1;
     {
         const int64_t min_stages = 512 / stage_rows;                 // slices of >= 512 rows
         const int64_t by_rows = nstages / min_stages > 0 ? nstages / min_stages : 1;
         int64_t cap = by_rows < 16 ? by_rows : 16;
         while (cap > 1 && static_cast<size_t>(cap) * K * K * sizeof(float) > slab_bytes) --cap;
-        double best = -1.0;
+        const double stage_us = 0.8 * (stage_rows / 32.0), block_overhead = 20.0 * (32.0 / stage_rows);
+        const double slab_pass = static_cast<double>(K) * static_cast<double>(K) * 4.0 / 5.0e6 / stage_us;     // stages per K x K pass
+        double best = 0.0;
         for (int c = 1; c <= cap; ++c) {
             const int64_t blocks = tiles * c;
-            const double fill = static_cast<double>(blocks) / static_cast<double>(ceil_div(blocks, 256) * 256);
-            if (fill > best + 0.02) { best = fill; splits = c; }      // more slices only for a real gain (each costs a K x K pass)
+            const double cost = static_cast<double>(ceil_div(blocks, 256)) * (static_cast<double>(ceil_div(nstages, c)) + block_overhead) +
+                                (c > 1 ? c * slab_pass : 0.0);
+            if (c == 1 || cost < best * 0.995) { best = cost; splits = c; }
         }
     }
 #ifdef OQ_SYRK_LAB
