@@ -140,13 +140,18 @@ def run(dev, cpu: bool = True, layers: int = 18, batches: int = 51) -> dict:
     for _ in range(3):
         ops.minmax_collect(big, st)
     torch.cuda.synchronize()
-    e0, e1 = ev(), ev()
-    e0.record()
-    for _ in range(20):
-        ops.minmax_collect(big, st)
-    e1.record()
-    torch.cuda.synchronize()
-    big_us = e0.elapsed_time(e1) * 1e3 / 20
+    # three trials of 20 launches, the fastest counts: the events bracket the GPU timeline, so one host hiccup between two
+    # launches (64 ms once, in a driver-style run of bench.py) would otherwise be booked as kernel time; all trials are reported
+    big_trials = []
+    for _ in range(3):
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(20):
+            ops.minmax_collect(big, st)
+        e1.record()
+        torch.cuda.synchronize()
+        big_trials.append(e0.elapsed_time(e1) * 1e3 / 20)
+    big_us = min(big_trials)
     big_bytes = big.numel() * 4
     big_gbs = big_bytes / (big_us * 1e-6) / 1e9
     ok = ok and float(st[0]) == big.min().item() and float(st[1]) == big.max().item()
@@ -176,7 +181,7 @@ def run(dev, cpu: bool = True, layers: int = 18, batches: int = 51) -> dict:
                              "tensors_per_s": round(len(acts) * batches / t_per_tensor, 1)},
         "roofline": {"bound": "hbm", "achieved": round(big_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(big_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "oq::minmax_partial<float> (+ oq::minmax_update, one block)", "launch_us": round(big_us, 2),
+                     "kernel": "oq::minmax_partial<float> (+ oq::minmax_update, one block)", "launch_us": round(big_us, 2), "launch_us_trials": [round(t, 2) for t in big_trials],
                      "algorithmic_bytes_per_launch": big_bytes, "bytes_per_element": 4},
         "verified": bool(ok),
     }
