@@ -41,7 +41,8 @@ def _require_device(t: torch.Tensor, name: str, dtype=None) -> None:
 
 
 _ARENA_MIN_BYTES = 32 << 20
-_ARENA: dict = {}     # (device index, stream handle) -> scratch tensor, grow-only
+_ARENA_MAX_STREAMS = 4
+_ARENA: dict = {}     # (device index, stream handle) -> scratch tensor, grow-only; most recently used last
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor | None:
@@ -49,7 +50,8 @@ def _workspace(nbytes: int, device) -> torch.Tensor | None:
 
     Small requests come from torch's allocator.  Requests of 32 MiB and more (the factor chain of a stack of eight
     11008 x 11008 Hessians asks for 15.5 GB) are served from one grow-only buffer per (device, stream): calls on a stream run
-    in order, so the next call may overwrite what the previous one left.  Why not `torch.empty` every time: when the
+    in order, so the next call may overwrite what the previous one left; at most four streams keep one (least recently used
+    out).  Why not `torch.empty` every time: when the
     caching allocator has split its one block of that size for a smaller request in between, the next call maps a new one,
     and `hipMalloc` of 15.5 GB takes 0.36 s on the MI355X host (measured, scripts/lab_alloc_trace.py) -- with the kernels of
     the call waiting behind it.  `release_workspaces()` hands the buffers back."""
@@ -59,11 +61,13 @@ def _workspace(nbytes: int, device) -> torch.Tensor | None:
     dev = torch.device(device)
     index = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (index, torch.cuda.current_stream(index).cuda_stream)
-    buf = _ARENA.get(key)
+    buf = _ARENA.pop(key, None)
     if buf is None or buf.numel() < nbytes:
-        _ARENA.pop(key, None)
         del buf
-        buf = _ARENA[key] = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", index))
+    _ARENA[key] = buf                                   # (re-)inserted last: dicts keep insertion order
+    while len(_ARENA) > _ARENA_MAX_STREAMS:             # a caller cycling through many streams must not pin one buffer per stream:
+        _ARENA.pop(next(iter(_ARENA)))                  # the least recently used one goes back to torch's allocator (stream-ordered)
     return buf[:nbytes]       # exactly what was asked for: some calls size their split-K slabs by the room they are given
 
 

@@ -32,3 +32,11 @@ def test_large_workspaces_are_reused_per_stream_and_results_do_not_depend_on_the
     assert torch.equal(h1, h2)
     ops.release_workspaces()
     assert not ops._ARENA
+    # a caller cycling through many streams does not pin one buffer per stream
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ops._ARENA_MAX_STREAMS + 3)]
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            ops._workspace(40 << 20, dev)
+    assert len(ops._ARENA) == ops._ARENA_MAX_STREAMS
+    assert (0, streams[-1].cuda_stream) in ops._ARENA and (0, streams[0].cuda_stream) not in ops._ARENA
+    ops.release_workspaces()
