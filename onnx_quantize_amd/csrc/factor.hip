@@ -362,8 +362,7 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
     float* Dinv = reinterpret_cast<float*>(base + 4 * count * kk);
     float* S = P;   // P is dead once the Cholesky loop has finished
 
-    if (hipMemsetAsync(info, 0, sizeof(int32_t) * count, s) != hipSuccess || hipMemsetAsync(X, 0, 2 * count * kk, s) != hipSuccess)
-        return fail(OQ_ERR_LAUNCH, "%s: memset failed", who);
+    if (hipMemsetAsync(info, 0, sizeof(int32_t) * count, s) != hipSuccess) return fail(OQ_ERR_LAUNCH, "%s: memset failed", who);
     hipLaunchKernelGGL(reverse_copy_kernel, dim3(static_cast<uint32_t>(K), cnt), dim3(256), 0, s, H, K, P, h_stride, ms, fix_dead);
     hipLaunchKernelGGL(damp_kernel, dim3(cnt), dim3(1024), 0, s, P, K, percdamp, ms);
     int32_t st = check_launch("reverse/damp");
@@ -383,6 +382,10 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
     // ONE update per outer panel with Kd = kOuter instead of four with Kd = 128 (each a read-modify-write of the whole
     // trailing matrix through 4 stages of MFMA work per tile: 27 TFLOP/s on K = 11008).
     constexpr int64_t kOuter = 4 * kNB;
+    constexpr int64_t kPieceUpdateMin = 1024;      // trailing squares narrower than this stay on the fp32 kernel
+    // OQ_HESSIAN_F32 keeps the whole GPTQ path on fp32 operands (the reference's arithmetic class); the X region must hold the pieces
+    const bool pieces_ok = oq_hessian_method() != OQ_HESSIAN_F32 &&
+                           syrk_f16x3_factor_update_bytes(K, kOuter, count) <= static_cast<size_t>(count) * kk;
     for (int64_t O = 0; O < K; O += kOuter) {
         const int64_t pend = O + kOuter < K ? O + kOuter : K;
         for (int64_t o = O; o < pend; o += kNB) {
@@ -416,7 +419,15 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
             }
         }
         const int64_t rest2 = K - pend;
-        if (rest2 > 0) {
+        if (rest2 >= kPieceUpdateMin && pieces_ok) {
+            // the same update on the fp16 matrix cores (two fp16 pieces per operand element, three products: 22-bit operands,
+            // fp32 accumulate -- scripts/lab_factor_precision.py: the factor's error against float64 does not move, 5.8e-8 vs
+            // 6.0e-8 at K = 11008): the panel Lt[O:pend, pend:] is a 512-row "batch of activations", the update a Hessian
+            // accumulation with alpha = -1, beta = 1 into a block of P.  The X region (not needed before the inverse) holds
+            // the pieces.  fp32 kernel: 83 TFLOP/s on the first update of K = 11008 (a read-modify-write of 3.5 GB).
+            st = launch_syrk_f16x3_factor_update(Lt, P, ms, count, K, O, pend, X, static_cast<size_t>(count) * kk, s);
+            if (st != OQ_OK) return st;
+        } else if (rest2 > 0) {
             // deferred update of the square behind the outer panel (both triangles stay current):
             // P[i][j] -= sum_{c in panel} Lt[c][i] * Lt[c][j]
             GemmTN tg;
@@ -435,6 +446,7 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
     // 2b * (K + 1)), so a level is two launches with K / 2b * (b / 128)^2 tiles each instead of one 128-row block
     // row (a single tile row) at a time.  Both X and Y = X^T are kept: the TN GEMM wants its left operand k-major,
     // i.e. X22 transposed; the second GEMM writes its result to both.
+    if (hipMemsetAsync(X, 0, 2 * count * kk, s) != hipSuccess) return fail(OQ_ERR_LAUNCH, "%s: memset failed", who);   // X and Y start from zero
     hipLaunchKernelGGL(place_diag_inverse_kernel, dim3(static_cast<uint32_t>(nb), cnt), dim3(256), 0, s, Dinv, K, X, Y, ms, ds);
     st = check_launch("place_diag_inverse_kernel");
     if (st != OQ_OK) return st;

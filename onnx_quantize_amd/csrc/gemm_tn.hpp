@@ -94,6 +94,13 @@ size_t syrk_f16x3_many_workspace_bytes(const int64_t* items_host, int64_t count)
 int32_t launch_syrk_f16x3_many(const int64_t* items_host, const int64_t* items_device, int64_t count, void* workspace, size_t workspace_bytes,
                                hipStream_t s);
 
+// The blocked Cholesky's deferred trailing update on the same grouped kernels: for m < count,
+//   P_m[pend:, pend:] -= Lt_m[O:pend, pend:K]^T Lt_m[O:pend, pend:K]   (both triangles), matrices `ms` floats apart.
+// workspace: syrk_f16x3_factor_update_bytes(columns = K - pend, rows = pend - O, count).
+size_t syrk_f16x3_factor_update_bytes(int64_t K, int64_t kd_max, int64_t count);
+int32_t launch_syrk_f16x3_factor_update(const float* Lt, float* P, int64_t ms, int64_t count, int64_t K, int64_t O, int64_t pend, void* workspace,
+                                        size_t workspace_bytes, hipStream_t s);
+
 // Two-operand GEMM on fp16 pieces (syrk_bf16x3.hip, section 3): C = beta C + alpha A^T B for k-major A [Kd, M], B [Kd, N].
 //   make_f16x2_pieces      absmax -> power-of-two scale -> two fp16 pieces of every element, zero-padded to 32 contraction rows
 //                          and 256 columns; `pieces` (256-byte aligned, gemm_f16x3_pieces_bytes(Kd, cols)) holds the scale

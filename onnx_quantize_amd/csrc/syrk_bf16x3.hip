@@ -527,7 +527,9 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
 __device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
                                                   const float alpha_in, const float beta, float* __restrict__ C,
                                                   float* __restrict__ slab, const int64_t stages_per_slice, const int ntiles,
-                                                  const float* __restrict__ post_scale, const int tile, const int64_t slice, unsigned char* lds) {
+                                                  const float* __restrict__ post_scale, const int tile, const int64_t slice, unsigned char* lds,
+                                                  const int64_t ldc,    // leading dimension of C (slabs are always K x K)
+                                                  const bool mirror_all = true) {   // false: only diagonal tiles write their lower half
     using G = StageGeom<3>;
     constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
     const float alpha = post_scale ? alpha_in * post_scale[1] : alpha_in;
@@ -557,6 +559,7 @@ __device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, c
 
     float* out = slab ? slab + slice * K * K : C;
     const bool direct = slab == nullptr;
+    const int64_t ld = direct ? ldc : K;
     const bool diag = tile_m == tile_n;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -571,10 +574,10 @@ __device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, c
                     if (direct) {
                         if (diag && colj < row) continue;
                         val = alpha * val;
-                        if (beta != 0.0f) val = beta * out[row * K + colj] + val;
-                        if (colj != row) out[colj * K + row] = val;
+                        if (beta != 0.0f) val = beta * out[row * ld + colj] + val;
+                        if (colj != row && (mirror_all || diag)) out[colj * ld + row] = val;
                     }
-                    out[row * K + colj] = val;
+                    out[row * ld + colj] = val;
                 }
             }
         }
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __
                                                                  const float* __restrict__ post_scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     syrk_f16_m16_body(P, K, Kp, nstages_all, alpha_in, beta, C, slab, stages_per_slice, ntiles, post_scale,
-                      static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), static_cast<int64_t>(blockIdx.y), lds);
+                      static_cast<int>(xcd_remap(blockIdx.x, gridDim.x)), static_cast<int64_t>(blockIdx.y), lds, K);
 }
 
 // ---- 2c. Many Hessian updates in one launch chain (oq_hessian_accumulate_many_f32): the activations a calibration batch
@@ -600,10 +603,13 @@ struct SyrkItem {
     u32x4* P;
     float* scale;            // the item's header in front of P: [s, 1 / s^2, 1 / s, -, absmax partials ...]
     int64_t T, K, ldx, Kp, nchunks, nstages;
+    int64_t ldc;             // leading dimension of C (K for a Hessian; the factor's trailing blocks live inside a larger matrix)
     int64_t split0;          // first block of this item in the split launch; its split grid is (Kp / 256) x ceil(nchunks / 4)
     int64_t tile0;           // first block of this item in the product launch
     float alpha, beta;
     int32_t tn, absmax_blocks;
+    int32_t mirror_all;      // 1: H comes out exactly symmetric, both triangles written; 0: lower halves only inside diagonal tiles
+    int32_t pad_;
 };
 
 constexpr int kManyAbsmaxBlocks = 64;
@@ -618,7 +624,7 @@ __global__ void syrk_many_plan_kernel(const int64_t* __restrict__ pub, const int
         SyrkItem o;
         o.X = reinterpret_cast<const float*>(it[0]);
         o.C = reinterpret_cast<float*>(it[1]);
-        o.T = it[2]; o.K = it[3]; o.ldx = it[4];
+        o.T = it[2]; o.K = it[3]; o.ldx = it[4]; o.ldc = it[3];
         const int64_t n_seen = it[5], n_total = it[5] + it[6];
         o.Kp = (o.K + kST - 1) / kST * kST;
         o.nstages = (o.T + StageGeom<3>::ROWS - 1) / StageGeom<3>::ROWS;
@@ -634,8 +640,38 @@ __global__ void syrk_many_plan_kernel(const int64_t* __restrict__ pub, const int
         o.alpha = static_cast<float>(2.0 / static_cast<double>(n_total));                                               // as oq_hessian_accumulate_f32
         o.beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));   // gptq.py:254
         o.absmax_blocks = static_cast<int32_t>(o.T < kManyAbsmaxBlocks ? o.T : kManyAbsmaxBlocks);
+        o.mirror_all = 1; o.pad_ = 0;
         items[m] = o;
     }
+}
+
+// The deferred trailing update of the blocked Cholesky (factor.hip) as `count` items of the same shape:
+// C_m[pend:, pend:] -= A_m^T A_m with A_m = Lt_m[O:pend, pend:K] (Kd = pend - O rows, k-major like a batch of activations),
+// both inside K x K matrices `ms` floats apart.  alpha = -1, beta = 1, both triangles written (the factor keeps them current).
+__global__ void syrk_factor_plan_kernel(const float* __restrict__ Lt, float* __restrict__ P, const int64_t ms, const int count, const int64_t K,
+                                        const int64_t O, const int64_t pend, unsigned char* __restrict__ pieces_base, SyrkItem* __restrict__ items) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= count) return;
+    SyrkItem o;
+    o.X = Lt + m * ms + O * K + pend;
+    o.C = P + m * ms + pend * K + pend;
+    o.T = pend - O; o.K = K - pend; o.ldx = K; o.ldc = K;
+    o.Kp = (o.K + kST - 1) / kST * kST;
+    o.nstages = (o.T + StageGeom<3>::ROWS - 1) / StageGeom<3>::ROWS;
+    o.nchunks = o.nstages * StageGeom<3>::CH;
+    const size_t item_bytes = 16384 + static_cast<size_t>(o.nchunks) * 2 * static_cast<size_t>(o.Kp) * 16;
+    o.scale = reinterpret_cast<float*>(pieces_base + m * item_bytes);
+    o.P = reinterpret_cast<u32x4*>(pieces_base + m * item_bytes + 16384);
+    o.split0 = m * ((o.Kp / 256) * ((o.nchunks + 3) / 4));
+    o.tn = static_cast<int32_t>(o.Kp / kST);
+    o.tile0 = m * (static_cast<int64_t>(o.tn) * (o.tn + 1) / 2);
+    o.alpha = -1.0f;
+    o.beta = 1.0f;
+    o.absmax_blocks = static_cast<int32_t>(o.T < kManyAbsmaxBlocks ? o.T : kManyAbsmaxBlocks);
+    // what reads the trailing square later: rows of the upper triangle (panel GEMM) and whole 128 x 128 diagonal blocks
+    // (chol_diag_kernel) -- the lower halves of off-diagonal tiles (a 4-byte scatter down columns) are never read
+    o.mirror_all = 0; o.pad_ = 0;
+    items[m] = o;
 }
 
 // the item whose block range holds `id`: FIRST(items[m]) <= id < FIRST(items[m + 1])
@@ -674,7 +710,7 @@ __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_many_kernel(const Syrk
     const int m = item_of_block(items, count, id, [](const SyrkItem& i) { return i.tile0; });
     const SyrkItem& it = items[m];
     syrk_f16_m16_body(it.P, it.K, it.Kp, it.nstages, it.alpha, it.beta, it.C, nullptr, it.nstages, it.tn, it.scale,
-                      static_cast<int>(id - it.tile0), 0, lds);
+                      static_cast<int>(id - it.tile0), 0, lds, it.ldc, it.mirror_all != 0);
 }
 
 // ---- 3. Two-operand GEMM on fp16 pieces: C = beta C + alpha A^T B, A [Kd, M] and B [Kd, N] both k-major (gemm_tn.hpp's
@@ -952,6 +988,35 @@ int32_t launch_syrk_f16x3_many(const int64_t* items_host, const int64_t* items_d
     if (st != OQ_OK) return st;
     hipLaunchKernelGGL(syrk_f16_m16_many_kernel, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), StageGeom<3>::LDS, s, table, n);
     return check_launch("syrk_f16_m16_many_kernel");
+}
+
+size_t syrk_f16x3_factor_update_bytes(int64_t K, int64_t kd_max, int64_t count) {
+    if (K <= 0 || kd_max <= 0 || count <= 0) return 0;
+    return syrk_many_table_bytes(count) + static_cast<size_t>(count) * syrk_many_item_bytes(kd_max, K) + 512;
+}
+
+int32_t launch_syrk_f16x3_factor_update(const float* Lt, float* P, int64_t ms, int64_t count, int64_t K, int64_t O, int64_t pend, void* workspace,
+                                        size_t workspace_bytes, hipStream_t s) {
+    const int64_t rest = K - pend, kd = pend - O;
+    OQ_REQUIRE(Lt && P && count > 0 && count <= 65535 && rest > 0 && kd > 0, OQ_ERR_INVALID_ARGUMENT, "factor update: bad argument");
+    const size_t need = syrk_f16x3_factor_update_bytes(rest, kd, count);
+    OQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, OQ_ERR_WORKSPACE, "factor update: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    base += (256 - (reinterpret_cast<uintptr_t>(base) & 255u)) & 255u;
+    SyrkItem* table = reinterpret_cast<SyrkItem*>(base);
+    unsigned char* pieces = base + syrk_many_table_bytes(count);
+    const int n = static_cast<int>(count);
+    const int64_t Kp = padded_k(rest), nchunks = stages_of(kd, StageGeom<3>::ROWS) * StageGeom<3>::CH, tn = Kp / kST;
+    const int64_t split_blocks = count * (Kp / 256) * ceil_div(nchunks, 4), tiles = count * (tn * (tn + 1) / 2);
+    OQ_REQUIRE(split_blocks < (1ll << 31) && tiles < (1ll << 31), OQ_ERR_UNSUPPORTED, "factor update: too many blocks for one launch");
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk_f16_m16_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, StageGeom<3>::LDS);
+    OQ_REQUIRE(e1 == hipSuccess, OQ_ERR_LAUNCH, "factor update: cannot reserve %d bytes of LDS", StageGeom<3>::LDS);
+    hipLaunchKernelGGL(syrk_factor_plan_kernel, dim3(static_cast<uint32_t>(ceil_div(count, 64))), dim3(64), 0, s, Lt, P, ms, n, K, O, pend, pieces, table);
+    hipLaunchKernelGGL(absmax_partial_many_kernel, dim3(kManyAbsmaxBlocks, static_cast<uint32_t>(n)), dim3(256), 0, s, table);
+    hipLaunchKernelGGL(absmax_scale_many_kernel, dim3(static_cast<uint32_t>(n)), dim3(256), 0, s, table);
+    hipLaunchKernelGGL(split_f16x2_many_kernel, dim3(static_cast<uint32_t>(split_blocks)), dim3(256), 0, s, table, n);
+    hipLaunchKernelGGL(syrk_f16_m16_many_kernel, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), StageGeom<3>::LDS, s, table, n);
+    return check_launch("syrk_f16_m16_many_kernel (factor update)");
 }
 
 // ---- host side of the two-operand GEMM (gemm_tn.hpp)
