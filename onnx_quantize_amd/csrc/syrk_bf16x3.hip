@@ -523,6 +523,52 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     }
 }
 
+// The block's 256 x 256 accumulator tile -> memory through LDS, in four passes of 64 rows (the rows of the waves wm == pass).
+// In the MFMA's C/D layout a store instruction covers 4 rows x 64 bytes and a read-modify-write of C costs 128 loads + 128
+// stores of 4 bytes per lane; short products (the factor's and the GPTQ loop's 512-deep updates: 16 stages, 13 us of matrix
+// work per tile) spent most of their time there.  Staged, every wave handles whole rows: one ds_read_b128 and one 16-byte
+// global access per lane and row (1 KB per wave-instruction).  `rows(r, c4, v)`: row r of the tile (0..255), the lane's four
+// columns c4..c4+3 with their values; returns what `cols` should see for them (written back to LDS).  `cols(c, r, x)`, only
+// when TRANSPOSED: column c of the tile, the lane's row r, for the mirrored half of a symmetric result -- 64 consecutive
+// rows per wave-instruction.  The ring buffers of the stage loop are dead when this runs (its last barrier has passed).
+constexpr int kEpiLd = 260;   // floats per staged row: 4 kc * 260 = 16 kc (mod 64 banks), the 16 cl lanes consecutive: no conflicts
+template <bool TRANSPOSED, typename Rows, typename Cols>
+__device__ __forceinline__ void staged_tile_epilogue(const f32x4v (&acc)[4][8], unsigned char* lds, Rows&& rows, Cols&& cols) {
+    static_assert(64 * kEpiLd * 4 <= StageGeom<3>::LDS, "a 64-row pass fits the stage ring");
+    float* t = reinterpret_cast<float*>(lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = lane >> 4, cl = lane & 15;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        __syncthreads();
+        if (wm == p) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[(i * 16 + 4 * kc + e) * kEpiLd + wn * 128 + j * 16 + cl] = acc[i][j][e];
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = wave * 8 + rr;
+            f32x4v* cell = reinterpret_cast<f32x4v*>(t + r * kEpiLd + lane * 4);
+            const f32x4v v = rows(p * 64 + r, lane * 4, *cell);
+            if constexpr (TRANSPOSED) *cell = v;
+        }
+        if constexpr (TRANSPOSED) {
+            __syncthreads();
+#pragma unroll 4
+            for (int cc = 0; cc < 32; ++cc) {
+                const int c = wave * 32 + cc;
+                cols(c, p * 64 + lane, t[lane * kEpiLd + c]);
+            }
+        }
+    }
+}
+
 // `tile`: the block's (XCD-remapped) index among the upper-triangle tiles of this matrix; `slice`: its T-slice
 __device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
                                                   const float alpha_in, const float beta, float* __restrict__ C,
@@ -541,8 +587,6 @@ __device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, c
     const int64_t nstages = s_end - s_begin;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kc = lane >> 4, cl = lane & 15;
 
     const char* gsrc[8];
     int64_t stage_bytes[8];
@@ -561,26 +605,46 @@ __device__ __forceinline__ void syrk_f16_m16_body(const u32x4* __restrict__ P, c
     const bool direct = slab == nullptr;
     const int64_t ld = direct ? ldc : K;
     const bool diag = tile_m == tile_n;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t colj = n0 + wn * 128 + j * 16 + cl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t row = m0 + wm * 64 + i * 16 + 4 * kc + e;
-                if (row < K && colj < K) {
-                    float val = acc[i][j][e];
-                    if (direct) {
-                        if (diag && colj < row) continue;
-                        val = alpha * val;
-                        if (beta != 0.0f) val = beta * out[row * ld + colj] + val;
-                        if (colj != row && (mirror_all || diag)) out[colj * ld + row] = val;
-                    }
-                    out[row * ld + colj] = val;
-                }
-            }
+    const bool vec_ok = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    // rows: slab mode stores the tile as it is (the reduction applies alpha / beta and the symmetry); direct mode applies alpha
+    // and beta, writes the upper part (diagonal tiles: from the diagonal on) and hands the final values to the mirror pass
+    auto rows = [&](int r, int c4, f32x4v v) -> f32x4v {
+        const int64_t row = m0 + r, col = n0 + c4;
+        if (row >= K || col >= K) return v;
+        float* o = out + row * ld + col;
+        const bool full = col + 3 < K;
+        if (!direct) {
+            if (full && vec_ok) *reinterpret_cast<f32x4v*>(o) = v;
+            else for (int q = 0; q < 4 && col + q < K; ++q) o[q] = v[q];
+            return v;
         }
+        f32x4v old = {0.f, 0.f, 0.f, 0.f};
+        if (beta != 0.0f) {
+            if (full && vec_ok) old = *reinterpret_cast<const f32x4v*>(o);
+            else for (int q = 0; q < 4 && col + q < K; ++q) old[q] = o[q];
+        }
+        f32x4v val;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = alpha * v[q];
+            if (beta != 0.0f) x = beta * old[q] + x;
+            val[q] = x;
+        }
+        if (full && vec_ok && !(diag && col < row)) {
+            *reinterpret_cast<f32x4v*>(o) = val;
+        } else {
+            for (int q = 0; q < 4 && col + q < K; ++q)
+                if (!(diag && col + q < row)) o[q] = val[q];
+        }
+        return val;
+    };
+    // the mirrored half: element (r, c) of the tile goes to C[n0 + c][m0 + r]; diagonal tiles mirror their strictly upper part
+    auto cols = [&](int c, int r, float x) {
+        const int64_t row = m0 + r, col = n0 + c;
+        if (row < K && col < K && (diag ? col > row : true)) out[col * ld + row] = x;
+    };
+    if (direct && (diag || mirror_all)) staged_tile_epilogue<true>(acc, lds, rows, cols);
+    else staged_tile_epilogue<false>(acc, lds, rows, cols);
 }
 
 __global__ __launch_bounds__(kSThreads) void syrk_f16_m16_kernel(const u32x4* __restrict__ P, const int64_t K, const int64_t Kp, const int64_t nstages_all,
@@ -739,8 +803,6 @@ __global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g
     const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
     const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int kc = lane >> 4, cl = lane & 15;
     const char* gsrc[8];
     int64_t stage_bytes[8];
 #pragma unroll
@@ -757,21 +819,29 @@ __global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g
     const float unscale = g.scale_a[2] * g.scale_b[2];   // 1 / (s_a s_b): exact, powers of two
     if constexpr (EPI == 0) {
         const float alpha = g.alpha * unscale;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t col = n0 + wn * 128 + j * 16 + cl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int64_t row = m0 + wm * 64 + i * 16 + 4 * kc + e;
-                    if (row < g.M && col < g.N) {
-                        float v = alpha * acc[i][j][e];
-                        if (g.beta != 0.0f) v = g.beta * g.C[row * g.ldc + col] + v;
-                        g.C[row * g.ldc + col] = v;
-                    }
-                }
+        const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0;
+        auto rows = [&](int r, int c4, f32x4v v) -> f32x4v {
+            const int64_t row = m0 + r, col = n0 + c4;
+            if (row >= g.M || col >= g.N) return v;
+            float* o = g.C + row * g.ldc + col;
+            const bool vec = vec_ok && col + 3 < g.N;
+            f32x4v old = {0.f, 0.f, 0.f, 0.f};
+            if (g.beta != 0.0f) {
+                if (vec) old = *reinterpret_cast<const f32x4v*>(o);
+                else for (int q = 0; q < 4 && col + q < g.N; ++q) old[q] = o[q];
             }
+            f32x4v val;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x = alpha * v[q];
+                if (g.beta != 0.0f) x = g.beta * old[q] + x;
+                val[q] = x;
+            }
+            if (vec) *reinterpret_cast<f32x4v*>(o) = val;
+            else for (int q = 0; q < 4 && col + q < g.N; ++q) o[q] = val[q];
+            return val;
+        };
+        staged_tile_epilogue<false>(acc, lds, rows, [](int, int, float) {});
     } else {
         // rows / columns past M / N are zero pieces: their products are exact zeros, no masks
         float sum = 0.f;
@@ -897,25 +967,22 @@ int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     const int tn = static_cast<int>(Kp / kST);
     const int64_t tiles = static_cast<int64_t>(tn) * (tn + 1) / 2;
     // T-slices: one block per CU (128-144 KB of LDS), 256 CUs.  Choose the slice count (<= 16, slices of >= 512 rows, slab
-    // permitting) by a cost in stage times: rounds of 256 blocks x (stages of a slice + ~20 stages of prologue and 256 KB
-    // epilogue per block) + one K x K pass per slice for the reduction (64 MB at ~5 TB/s = 13 us = 16 stages of 0.8 us at
-    // K = 4096).  Measured on K = 4096, 65 536 rows (scripts/lab_syrk_splits.py, ms per product): 1 slice 3.26, 3: 2.72,
-    // 5: 2.57, 7: 2.54, 9: 2.53, 15: 2.61 -- the best fill (15: 2040 blocks = 7.97 rounds) is not the fastest; at 262 144
-    // rows 15 is (9.74 against 9.95 for 7), and K = 11008 is flat (1 slice 17.04, 4: 17.02).  Ties go to fewer slices.
+    // permitting) whose block count fills whole rounds of 256 best; ties go to fewer slices.  Measured on K = 4096, 65 536
+    // rows (scripts/lab_syrk_splits.py, ms per product): 1 slice 3.26, 3: 2.72, 5: 2.57, 7: 2.54, 9: 2.53, 15: 2.61; K = 11008
+    // is flat (1 slice 17.04, 4: 17.02).  A cost model that prefers fewer slices (5 and 1 for these shapes) was tried and
+    // measured equal in time, but every slice is also a shorter fp32 accumulation chain: with one slice instead of four the
+    // error against float64 of an 8192-row K = 11008 call rose from 8e-7 to 4e-6 of max |H| (bound: 1e-5).  More slices stay.
     int splits = 1;
     {
         const int64_t min_stages = 512 / stage_rows;                 // slices of >= 512 rows
         const int64_t by_rows = nstages / min_stages > 0 ? nstages / min_stages : 1;
         int64_t cap = by_rows < 16 ? by_rows : 16;
         while (cap > 1 && static_cast<size_t>(cap) * K * K * sizeof(float) > slab_bytes) --cap;
-        const double stage_us = 0.8 * (stage_rows / 32.0), block_overhead = 20.0 * (32.0 / stage_rows);
-        const double slab_pass = static_cast<double>(K) * static_cast<double>(K) * 4.0 / 5.0e6 / stage_us;     // stages per K x K pass
-        double best = 0.0;
+        double best = -1.0;
         for (int c = 1; c <= cap; ++c) {
             const int64_t blocks = tiles * c;
-            const double cost = static_cast<double>(ceil_div(blocks, 256)) * (static_cast<double>(ceil_div(nstages, c)) + block_overhead) +
-                                (c > 1 ? c * slab_pass : 0.0);
-            if (c == 1 || cost < best * 0.995) { best = cost; splits = c; }
+            const double fill = static_cast<double>(blocks) / static_cast<double>(ceil_div(blocks, 256) * 256);
+            if (fill > best + 0.02) { best = fill; splits = c; }      // more slices only for a real gain (each costs a K x K pass)
         }
     }
 #ifdef OQ_SYRK_LAB

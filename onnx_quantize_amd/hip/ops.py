@@ -603,15 +603,17 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
     return int(n_seen) + n_add
 
 
-_MANY_MIN_K, _MANY_MIN_ROWS = 512, 512
+_MANY_MIN_K, _MANY_MIN_ROWS, _MANY_MAX_ROWS = 512, 512, 32768
 
 
 def hessian_accumulate_many(xs, hs, n_seen) -> list[int]:
     """gptq.py:246-260 for a list of (input, Hessian) pairs -- the tensors one calibration batch taps -- in ONE launch chain
     (`oq_hessian_accumulate_many_f32`).  ``xs[i]`` [n_add, ..., K_i] fp32, ``hs[i]`` [K_i, K_i] updated in place, ``n_seen[i]``
-    the samples already in it; returns the new sample counts.  Items narrower than 512 columns or shorter than 512 rows, and
-    every item when another Hessian method than the fp16 pieces is selected, go through `hessian_accumulate` one by one
-    (their padding to 256-wide tiles would cost more than the launches save)."""
+    the samples already in it; returns the new sample counts.  Items narrower than 512 columns or shorter than 512 rows
+    (their padding to 256-wide tiles would cost more than the launches save), items longer than 32 768 rows (the grouped
+    product sums an item's rows in ONE fp32 chain; the per-tensor call slices long inputs, which also keeps the rounding error
+    at 1e-6 of max |H|), and every item when another Hessian method than the fp16 pieces is selected, go through
+    `hessian_accumulate` one by one."""
     xs, hs, n_seen = list(xs), list(hs), [int(n) for n in n_seen]
     if not (len(xs) == len(hs) == len(n_seen)):
         raise ValueError("hessian_accumulate_many: xs, hs and n_seen must have one entry per item")
@@ -625,7 +627,7 @@ def hessian_accumulate_many(xs, hs, n_seen) -> list[int]:
         t, k = x2.shape
         if h.shape != (k, k) or not h.is_contiguous():
             raise ValueError(f"H[{i}] must be a contiguous [{k}, {k}] tensor")
-        if not grouped or k < _MANY_MIN_K or t < _MANY_MIN_ROWS:
+        if not grouped or k < _MANY_MIN_K or t < _MANY_MIN_ROWS or t > _MANY_MAX_ROWS:
             out[i] = hessian_accumulate(x, h, n_seen[i])
             continue
         rows.append((x2.data_ptr(), h.data_ptr(), t, k, ldx, n_seen[i], int(x.shape[0]), 0))
