@@ -333,9 +333,24 @@ int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t ac
 static size_t factor_matrix_bytes(int64_t K) { return align256(static_cast<size_t>(K) * K * 4); }
 static size_t factor_dinv_bytes(int64_t K) { return align256(static_cast<size_t>(ceil_div(K, kNB)) * kNB * kNB * 4); }
 
+// levels of the recursive-doubling inverse from this block size on run on the fp16-piece kernels (section 3b of syrk_bf16x3.hip)
+constexpr int64_t kPieceInverseMin = 2048;
+
+// room for the operand pieces of the largest such level (0 when no level qualifies)
+static size_t inverse_pieces_bytes(int64_t K, int64_t count) {
+    size_t most = 0;
+    for (int64_t b = kNB; b < K; b *= 2) {
+        if (b < kPieceInverseMin) continue;
+        const int64_t npairs = (K - b + 2 * b - 1) / (2 * b), full = K / (2 * b);
+        if (full > 0) most = std::max(most, inverse_level_f16x3_bytes(b, b, full * count));
+        if (npairs > full) most = std::max(most, inverse_level_f16x3_bytes(b, K - (full * 2 * b + b), (npairs - full) * count));
+    }
+    return most ? most + 256 : 0;
+}
+
 size_t oq_gptq_factor_batched_workspace_bytes(int64_t K, int64_t count) {
     if (K <= 0 || count <= 0) return 0;
-    return static_cast<size_t>(count) * (4 * factor_matrix_bytes(K) + factor_dinv_bytes(K)) + 256;
+    return static_cast<size_t>(count) * (4 * factor_matrix_bytes(K) + factor_dinv_bytes(K)) + inverse_pieces_bytes(K, count) + 256;
 }
 
 size_t oq_gptq_factor_workspace_bytes(int64_t K) { return oq_gptq_factor_batched_workspace_bytes(K, 1); }
@@ -360,6 +375,8 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
     float* X = reinterpret_cast<float*>(base + 2 * count * kk);
     float* Y = reinterpret_cast<float*>(base + 3 * count * kk);
     float* Dinv = reinterpret_cast<float*>(base + 4 * count * kk);
+    unsigned char* inv_pieces = reinterpret_cast<unsigned char*>(base + 4 * count * kk + static_cast<size_t>(count) * factor_dinv_bytes(K));
+    const size_t inv_pieces_bytes = inverse_pieces_bytes(K, count);
     float* S = P;   // P is dead once the Cholesky loop has finished
 
     if (hipMemsetAsync(info, 0, sizeof(int32_t) * count, s) != hipSuccess) return fail(OQ_ERR_LAUNCH, "%s: memset failed", who);
@@ -459,6 +476,13 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
             if (pairs <= 0) continue;
             const int64_t o1 = first * 2 * b, o2 = o1 + b;
             const int64_t b2 = part == 0 ? b : K - o2;               // rows of the second block
+            if (b >= kPieceInverseMin && pieces_ok && inv_pieces_bytes > 0) {
+                // the two products of a level with 22-bit operands on the fp16 matrix cores; the fp32 kernel runs the top
+                // level of K = 11008 at 138 TFLOP/s (88 % of its peak) -- only another instruction makes it faster
+                st = launch_inverse_level_f16x3(Lt, X, Y, S, ms, count, K, b, first, pairs, b2, inv_pieces, inv_pieces_bytes, s);
+                if (st != OQ_OK) return st;
+                continue;
+            }
             GemmTN sg;  // S[r][j] = sum_k L21[r][k] * X11[k][j] = sum_k Lt[o1+k][o2+r] * X[o1+k][o1+j]
             sg.At = Lt + o1 * K + o2; sg.lda = K; sg.M = b2;
             sg.B = X + o1 * K + o1; sg.ldb = K; sg.N = b;

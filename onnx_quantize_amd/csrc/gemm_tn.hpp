@@ -101,6 +101,13 @@ size_t syrk_f16x3_factor_update_bytes(int64_t K, int64_t kd_max, int64_t count);
 int32_t launch_syrk_f16x3_factor_update(const float* Lt, float* P, int64_t ms, int64_t count, int64_t K, int64_t O, int64_t pend, void* workspace,
                                         size_t workspace_bytes, hipStream_t s);
 
+// One level of the factor's recursive-doubling inverse on the fp16-piece kernels (syrk_bf16x3.hip, section 3b): for every pair
+// p < pairs (first block at (first + p) * 2b, b rows; second b2 <= b rows) of every matrix m < count:  X21 = -X22 (L21 X11),
+// Y12 = X21^T.  S: scratch of (first + pairs) * b * b floats per matrix.  workspace: inverse_level_f16x3_bytes(b, b2, pairs * count).
+size_t inverse_level_f16x3_bytes(int64_t b, int64_t b2, int64_t problems);
+int32_t launch_inverse_level_f16x3(const float* Lt, float* X, float* Y, float* S, int64_t ms, int64_t count, int64_t K, int64_t b, int64_t first,
+                                   int64_t pairs, int64_t b2, void* workspace, size_t workspace_bytes, hipStream_t s);
+
 // Two-operand GEMM on fp16 pieces (syrk_bf16x3.hip, section 3): C = beta C + alpha A^T B for k-major A [Kd, M], B [Kd, N].
 //   make_f16x2_pieces      absmax -> power-of-two scale -> two fp16 pieces of every element, zero-padded to 32 contraction rows
 //                          and 256 columns; `pieces` (256-byte aligned, gemm_f16x3_pieces_bytes(Kd, cols)) holds the scale

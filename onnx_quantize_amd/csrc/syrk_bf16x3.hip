@@ -792,17 +792,25 @@ struct PieceGemm {
     float* C;               // EPI 0: [M, N], leading dimension ldc
     int64_t ldc;
     float* partial;         // EPI 1: per-block sum of squares of the block's part of A^T B
+    float* Ct = nullptr;    // EPI 0, optional: the same values transposed, Ct[n][m], leading dimension ldct
+    int64_t ldct = 0;
+    int32_t k_from_n = 0;   // B[k][n] = 0 for k < n (lower triangular B): a column tile starts its contraction at its first column
+    int32_t k_to_m = 0;     // A[k][m] = 0 for k > m (upper triangular A^T): a row tile ends its contraction behind its last row
 };
 
 template <int EPI>
-__global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g) {
+__device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int tile, unsigned char* lds) {
     using G = StageGeom<3>;
     constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tiles_n = static_cast<int>(g.Np / kST);
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
     const int64_t m0 = static_cast<int64_t>(tile_m) * kST, n0 = static_cast<int64_t>(tile_n) * kST;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // triangular operands (the recursive-doubling inverse of factor.hip): stages that only meet structural zeros are skipped
+    int64_t s_begin = 0, s_end = g.nstages;
+    if (g.k_from_n) s_begin = n0 / G::ROWS;
+    if (g.k_to_m) { const int64_t e = (m0 + kST + G::ROWS - 1) / G::ROWS; s_end = e < s_end ? e : s_end; }
+    if (s_begin > s_end) s_begin = s_end;
     const char* gsrc[8];
     int64_t stage_bytes[8];
 #pragma unroll
@@ -811,11 +819,18 @@ __global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g
         const int quarter = q & 3, cc = (q >> 2) % CH, pc = (q / (4 * CH)) % PIECES, op = q / (4 * CH * PIECES);
         const int64_t width = op ? g.Np : g.Mp;
         const int64_t colq = (op ? n0 : m0) + quarter * 64 + lane;
-        gsrc[i] = reinterpret_cast<const char*>((op ? g.PB : g.PA) + (static_cast<int64_t>(cc) * PIECES + pc) * width + colq);
         stage_bytes[i] = static_cast<int64_t>(CH) * PIECES * width * 16;
+        gsrc[i] = reinterpret_cast<const char*>((op ? g.PB : g.PA) + (static_cast<int64_t>(cc) * PIECES + pc) * width + colq) + s_begin * stage_bytes[i];
     }
     f32x4v acc[4][8];
-    f16_m16_mainloop<NDMA>(gsrc, stage_bytes, g.nstages, lds, acc);
+    if (s_end > s_begin) {
+        f16_m16_mainloop<NDMA>(gsrc, stage_bytes, s_end - s_begin, lds, acc);
+    } else {   // block-uniform: nothing to contract
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
     const float unscale = g.scale_a[2] * g.scale_b[2];   // 1 / (s_a s_b): exact, powers of two
     if constexpr (EPI == 0) {
         const float alpha = g.alpha * unscale;
@@ -841,7 +856,11 @@ __global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g
             else for (int q = 0; q < 4 && col + q < g.N; ++q) o[q] = val[q];
             return val;
         };
-        staged_tile_epilogue<false>(acc, lds, rows, [](int, int, float) {});
+        auto cols = [&](int c, int r, float x) {
+            if (m0 + r < g.M && n0 + c < g.N) g.Ct[(n0 + c) * g.ldct + m0 + r] = x;
+        };
+        if (g.Ct != nullptr) staged_tile_epilogue<true>(acc, lds, rows, cols);
+        else staged_tile_epilogue<false>(acc, lds, rows, cols);
     } else {
         // rows / columns past M / N are zero pieces: their products are exact zeros, no masks
         float sum = 0.f;
@@ -862,9 +881,97 @@ __global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g
         if (tid == 0) {
             float t = 0.f;
             for (int w = 0; w < kSThreads / 64; ++w) t += red[w];   // fixed order: deterministic
-            g.partial[blockIdx.x] = t;
+            g.partial[tile] = t;
         }
     }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    gemm_f16x3_body<EPI>(g, static_cast<int>(blockIdx.x), lds);
+}
+
+// many products of one shape in one launch: blockIdx.y = problem (its PieceGemm in device memory: uniform scalar loads)
+__global__ __launch_bounds__(kSThreads) void gemm_f16x3_many_kernel(const PieceGemm* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const PieceGemm g = items[blockIdx.y];
+    gemm_f16x3_body<0>(g, static_cast<int>(blockIdx.x), lds);
+}
+
+// ---- 3b. One level of the recursive-doubling inverse of factor.hip on the fp16-piece kernels.  With L = [[L11, 0], [L21, L22]]
+// and X = inv(L):  X21 = -X22 (L21 X11).  Per problem q (pair p of the level, matrix m of the batch), b = size of the first
+// block, b2 = rows of the second:
+//   S   [b2, b]  = sum_k Lt[o1 + k][o2 + r] X[o1 + k][o1 + j]      (X11 lower triangular: k >= j)
+//   X21 [b2, b]  = -sum_c Y[o2 + c][o2 + r] S[c][j]                 (Y22 = X22^T upper triangular: c <= r),  Y12 = X21^T
+// Operand pieces come from the grouped preparation kernels of section 2c (SyrkItem tables: only X, T, K, ldx, P, scale, split0
+// and absmax_blocks are read by them); this kernel lays out the tables.  One thread per problem.
+struct InverseLevel {
+    const float* Lt; float* X; float* Y; float* S;
+    int64_t ms, K, b, b2, first, pairs;
+    int32_t count;
+};
+
+__device__ __forceinline__ size_t piece_bytes_dev(int64_t T, int64_t cols) {
+    const int64_t st = (T + StageGeom<3>::ROWS - 1) / StageGeom<3>::ROWS, cp = (cols + kST - 1) / kST * kST;
+    return 16384 + static_cast<size_t>(st) * StageGeom<3>::CH * 2 * static_cast<size_t>(cp) * 16;
+}
+
+__device__ __forceinline__ SyrkItem prep_item(const float* X, int64_t T, int64_t cols, int64_t ldx, unsigned char* where, int64_t split0) {
+    SyrkItem o;
+    o.X = X; o.C = nullptr; o.T = T; o.K = cols; o.ldx = ldx; o.ldc = 0;
+    o.Kp = (cols + kST - 1) / kST * kST;
+    o.nstages = (T + StageGeom<3>::ROWS - 1) / StageGeom<3>::ROWS;
+    o.nchunks = o.nstages * StageGeom<3>::CH;
+    o.scale = reinterpret_cast<float*>(where);
+    o.P = reinterpret_cast<u32x4*>(where + 16384);
+    o.split0 = split0; o.tile0 = 0; o.tn = 0;
+    o.alpha = -1.0f; o.beta = 0.0f;          // alpha <= 0: no dead-channel bookkeeping in the split (a Hessian matter)
+    o.absmax_blocks = static_cast<int32_t>(T < kManyAbsmaxBlocks ? T : kManyAbsmaxBlocks);
+    o.mirror_all = 0; o.pad_ = 0;
+    return o;
+}
+
+__device__ __forceinline__ int64_t split_blocks_of(int64_t T, int64_t cols) {
+    const int64_t st = (T + StageGeom<3>::ROWS - 1) / StageGeom<3>::ROWS, cp = (cols + kST - 1) / kST * kST;
+    return (cp / 256) * ((st * StageGeom<3>::CH + 3) / 4);
+}
+
+__global__ void inverse_level_plan_kernel(const InverseLevel lv, unsigned char* __restrict__ pieces_base, SyrkItem* __restrict__ prep,
+                                          PieceGemm* __restrict__ gemms) {
+    const int64_t n = lv.pairs * lv.count;
+    const int64_t q = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int64_t m = q / lv.pairs, p = q - m * lv.pairs;
+    const int64_t b = lv.b, b2 = lv.b2, K = lv.K;
+    const int64_t o1 = (lv.first + p) * 2 * b, o2 = o1 + b;
+    const float* Lt = lv.Lt + m * lv.ms;
+    float* X = lv.X + m * lv.ms;
+    float* Y = lv.Y + m * lv.ms;
+    float* S = lv.S + m * lv.ms + (lv.first + p) * b * b;
+    const size_t bA1 = piece_bytes_dev(b, b2), bB1 = piece_bytes_dev(b, b), bA2 = piece_bytes_dev(b2, b2), bS = piece_bytes_dev(b2, b);
+    unsigned char* w = pieces_base + static_cast<size_t>(q) * (bA1 + bB1 + bA2 + bS);
+    const int64_t sA1 = split_blocks_of(b, b2), sB1 = split_blocks_of(b, b), sA2 = split_blocks_of(b2, b2), sS = split_blocks_of(b2, b);
+    // first preparation launch: A1 | B1 | A2 (3 n items), second: S (n items, block ids from 0 again)
+    prep[q] = prep_item(Lt + o1 * K + o2, b, b2, K, w, q * sA1);
+    prep[n + q] = prep_item(X + o1 * K + o1, b, b, K, w + bA1, n * sA1 + q * sB1);
+    prep[2 * n + q] = prep_item(Y + o2 * K + o2, b2, b2, K, w + bA1 + bB1, n * (sA1 + sB1) + q * sA2);
+    prep[3 * n + q] = prep_item(S, b2, b, b, w + bA1 + bB1 + bA2, q * sS);
+    PieceGemm g1;
+    g1.PA = prep[q].P; g1.scale_a = prep[q].scale;
+    g1.PB = prep[n + q].P; g1.scale_b = prep[n + q].scale;
+    g1.M = b2; g1.N = b; g1.Mp = prep[q].Kp; g1.Np = prep[n + q].Kp; g1.nstages = prep[q].nstages;
+    g1.alpha = 1.0f; g1.beta = 0.0f; g1.C = S; g1.ldc = b; g1.partial = nullptr; g1.Ct = nullptr; g1.ldct = 0;
+    g1.k_from_n = 1; g1.k_to_m = 0;
+    gemms[q] = g1;
+    PieceGemm g2;
+    g2.PA = prep[2 * n + q].P; g2.scale_a = prep[2 * n + q].scale;
+    g2.PB = prep[3 * n + q].P; g2.scale_b = prep[3 * n + q].scale;
+    g2.M = b2; g2.N = b; g2.Mp = prep[2 * n + q].Kp; g2.Np = prep[3 * n + q].Kp; g2.nstages = prep[2 * n + q].nstages;
+    g2.alpha = -1.0f; g2.beta = 0.0f; g2.C = X + o2 * K + o1; g2.ldc = K; g2.partial = nullptr;
+    g2.Ct = Y + o1 * K + o2; g2.ldct = K;
+    g2.k_from_n = 0; g2.k_to_m = 1;
+    gemms[n + q] = g2;
 }
 
 // Source with the contraction index as its FAST axis (X [T, K] row-major used as A = X^T: contraction over k, columns t):
@@ -1084,6 +1191,49 @@ int32_t launch_syrk_f16x3_factor_update(const float* Lt, float* P, int64_t ms, i
     hipLaunchKernelGGL(split_f16x2_many_kernel, dim3(static_cast<uint32_t>(split_blocks)), dim3(256), 0, s, table, n);
     hipLaunchKernelGGL(syrk_f16_m16_many_kernel, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), StageGeom<3>::LDS, s, table, n);
     return check_launch("syrk_f16_m16_many_kernel (factor update)");
+}
+
+static size_t piece_bytes_host(int64_t T, int64_t cols) {
+    return kScaleHeaderBytes + static_cast<size_t>(stages_of(T, StageGeom<3>::ROWS)) * StageGeom<3>::CH * 2 * static_cast<size_t>(padded_k(cols)) * 16;
+}
+static int64_t split_blocks_host(int64_t T, int64_t cols) { return (padded_k(cols) / 256) * ceil_div(stages_of(T, StageGeom<3>::ROWS) * StageGeom<3>::CH, 4); }
+
+size_t inverse_level_f16x3_bytes(int64_t b, int64_t b2, int64_t problems) {
+    if (b <= 0 || b2 <= 0 || problems <= 0) return 0;
+    const size_t tables = (static_cast<size_t>(problems) * (4 * sizeof(SyrkItem) + 2 * sizeof(PieceGemm)) + 255) / 256 * 256;
+    return tables + static_cast<size_t>(problems) * (piece_bytes_host(b, b2) + piece_bytes_host(b, b) + piece_bytes_host(b2, b2) + piece_bytes_host(b2, b)) + 512;
+}
+
+int32_t launch_inverse_level_f16x3(const float* Lt, float* X, float* Y, float* S, int64_t ms, int64_t count, int64_t K, int64_t b, int64_t first,
+                                   int64_t pairs, int64_t b2, void* workspace, size_t workspace_bytes, hipStream_t s) {
+    const int64_t n = pairs * count;
+    OQ_REQUIRE(Lt && X && Y && S && n > 0 && n <= 65535 && b > 0 && b2 > 0 && b2 <= b, OQ_ERR_INVALID_ARGUMENT, "inverse level: bad argument");
+    const size_t need = inverse_level_f16x3_bytes(b, b2, n);
+    OQ_REQUIRE(workspace != nullptr && workspace_bytes >= need, OQ_ERR_WORKSPACE, "inverse level: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    base += (256 - (reinterpret_cast<uintptr_t>(base) & 255u)) & 255u;
+    SyrkItem* prep = reinterpret_cast<SyrkItem*>(base);
+    PieceGemm* gemms = reinterpret_cast<PieceGemm*>(base + static_cast<size_t>(n) * 4 * sizeof(SyrkItem));
+    unsigned char* pieces = base + (static_cast<size_t>(n) * (4 * sizeof(SyrkItem) + 2 * sizeof(PieceGemm)) + 255) / 256 * 256;
+    const int64_t split1 = n * (split_blocks_host(b, b2) + split_blocks_host(b, b) + split_blocks_host(b2, b2)), split2 = n * split_blocks_host(b2, b);
+    const int64_t tiles = (padded_k(b2) / kST) * (padded_k(b) / kST);
+    OQ_REQUIRE(split1 < (1ll << 31) && split2 < (1ll << 31) && tiles < (1ll << 31), OQ_ERR_UNSUPPORTED, "inverse level: too many blocks for one launch");
+    OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_many_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, StageGeom<3>::LDS) == hipSuccess,
+               OQ_ERR_LAUNCH, "inverse level: cannot reserve %d bytes of LDS", StageGeom<3>::LDS);
+    InverseLevel lv;
+    lv.Lt = Lt; lv.X = X; lv.Y = Y; lv.S = S; lv.ms = ms; lv.K = K; lv.b = b; lv.b2 = b2; lv.first = first; lv.pairs = pairs;
+    lv.count = static_cast<int32_t>(count);
+    const uint32_t n3 = static_cast<uint32_t>(3 * n), n1 = static_cast<uint32_t>(n);
+    hipLaunchKernelGGL(inverse_level_plan_kernel, dim3(static_cast<uint32_t>(ceil_div(n, 64))), dim3(64), 0, s, lv, pieces, prep, gemms);
+    hipLaunchKernelGGL(absmax_partial_many_kernel, dim3(kManyAbsmaxBlocks, n3), dim3(256), 0, s, prep);
+    hipLaunchKernelGGL(absmax_scale_many_kernel, dim3(n3), dim3(256), 0, s, prep);
+    hipLaunchKernelGGL(split_f16x2_many_kernel, dim3(static_cast<uint32_t>(split1)), dim3(256), 0, s, prep, static_cast<int>(n3));
+    hipLaunchKernelGGL(gemm_f16x3_many_kernel, dim3(static_cast<uint32_t>(tiles), n1), dim3(kSThreads), StageGeom<3>::LDS, s, gemms);
+    hipLaunchKernelGGL(absmax_partial_many_kernel, dim3(kManyAbsmaxBlocks, n1), dim3(256), 0, s, prep + 3 * n);
+    hipLaunchKernelGGL(absmax_scale_many_kernel, dim3(n1), dim3(256), 0, s, prep + 3 * n);
+    hipLaunchKernelGGL(split_f16x2_many_kernel, dim3(static_cast<uint32_t>(split2)), dim3(256), 0, s, prep + 3 * n, static_cast<int>(n1));
+    hipLaunchKernelGGL(gemm_f16x3_many_kernel, dim3(static_cast<uint32_t>(tiles), n1), dim3(kSThreads), StageGeom<3>::LDS, s, gemms + n);
+    return check_launch("inverse level (fp16 pieces)");
 }
 
 // ---- host side of the two-operand GEMM (gemm_tn.hpp)
