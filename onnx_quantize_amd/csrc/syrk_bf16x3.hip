@@ -676,7 +676,7 @@ struct SyrkItem {
     int32_t pad_;
 };
 
-constexpr int kManyAbsmaxBlocks = 64;
+constexpr int kManyAbsmaxBlocks = 256;   // row slices per item in the grouped absmax (64 left an 8192 x 8192 operand of the factor to 64 blocks: 0.5 ms)
 
 // public items (oq_hip.h: int64 {X, H, T, K, ldx, n_seen, n_add, 0}) -> SyrkItem table; one thread, count is small
 __global__ void syrk_many_plan_kernel(const int64_t* __restrict__ pub, const int count, unsigned char* __restrict__ pieces_base, SyrkItem* __restrict__ items) {

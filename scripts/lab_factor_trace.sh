@@ -13,7 +13,7 @@ for k in ("k11008", "k4096"):
     f = glob.glob(f"{root}/{k}/**/*kernel_trace.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     # the last chain = second half of the factor kernels
-    fac = [r for r in rows if any(t in r["Kernel_Name"] for t in ("gemm_tn_kernel", "chol_diag", "place_diag", "finish_factor", "reverse_copy", "damp", "_many_kernel", "factor_plan"))]
+    fac = [r for r in rows if any(t in r["Kernel_Name"] for t in ("gemm_tn_kernel", "chol_diag", "place_diag", "finish_factor", "reverse_copy", "damp", "_many_kernel", "factor_plan", "inverse_level_plan"))]
     fac = fac[len(fac) // 2:]
     agg = collections.OrderedDict()
     for r in fac:
