@@ -258,7 +258,8 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
  *     item is one oq_hessian_accumulate_f32 call: H <- H n_seen / (n_seen + n_add) + 2 / (n_seen + n_add) X^T X.  All items
  *     run the fp16-piece method (OQ_HESSIAN_F16X3 above) whatever their size, each with a scale of its own, the product
  *     writing H directly: the same <= 1e-5 max |H| bound; NOT bit-identical to the per-tensor call, which may slice T or
- *     pick the fp32 kernel for small K.  OQ_ERR_UNSUPPORTED when oq_hessian_set_method selected another method.
+ *     pick the fp32 kernel for small K; an item's rows are summed in ONE fp32 chain, so very long items (beyond ~32 768 rows)
+ *     are better served by the per-tensor call.  OQ_ERR_UNSUPPORTED when oq_hessian_set_method selected another method.
  *     `items_host` / `items_device`: the same `count` items in host and in device memory (the host copy sizes the
  *     launches, the kernels read the device copy).  Workspace: oq_hessian_many_workspace_bytes(items_host, count) =
  *     the fp16 pieces of all items (4 B per element of the zero-padded inputs) + a table. */
@@ -300,7 +301,11 @@ int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t ac
 /* G2  gptq.py:134-150: H += percdamp*mean(diag H) on the diagonal, then the UPPER factor U with
  *     inv(H) = U^T U, written to U_out [K, K] (strictly-lower part zeroed).  H is read only.
  *     info (DEVICE int32): 0 = ok; > 0 = first non-positive pivot (1-based), in which case U_out = I
- *     (the reference's LinAlgError fallback, gptq.py:143-150).  The call itself still returns OQ_OK. */
+ *     (the reference's LinAlgError fallback, gptq.py:143-150).  The call itself still returns OQ_OK.
+ *     Arithmetic: fp32 throughout, except that the large products (trailing updates of 512-row panels on squares of
+ *     >= 1024 columns, inverse levels of >= 2048-row blocks) take their operands as two fp16 pieces (22 bits, fp32
+ *     accumulate) like the Hessian's OQ_HESSIAN_F16X3 -- measured no less accurate against float64 than fp32 products
+ *      --; oq_hessian_set_method(OQ_HESSIAN_F32) keeps them on the fp32 kernel as well. */
 size_t oq_gptq_factor_workspace_bytes(int64_t K);
 int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info,
                            void* workspace, size_t workspace_bytes, void* stream);
