@@ -24,7 +24,9 @@ rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $OUT/loop/pmc_mfma -- python3 $R/scripts/quick_loop.py > $OUT/loop.mfma.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hess/trace -- python3 $R/scripts/quick_hessian.py f16x3 11008 > $OUT/hess.trace.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d $OUT/hess/pmc_mfma -- python3 $R/scripts/quick_hessian.py f16x3 11008 > $OUT/hess.mfma.log 2>&1
-echo "loop / hessian done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/factor/trace -- python3 $R/scripts/lab_factor_trace.py 11008 8 > $OUT/factor.trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/hess_many/trace -- python3 $R/scripts/quick_hessian_many.py > $OUT/hess_many.trace.log 2>&1
+echo "loop / hessian / factor done"
 # 4. calibration (config 3 stand-in) and the AWQ searches: kernel traces
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/calib/trace -- python3 $R/bench_calib.py --no-cpu-baseline > $OUT/calib.trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/awq/trace -- python3 $R/scripts/quick_awq.py > $OUT/awq.trace.log 2>&1

@@ -113,6 +113,16 @@ if k and "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
     h["derived"] = {"clock_GHz": round(cyc / (k["avg_us"] * 1e3), 3), "mfma_pipe_busy_frac": round(c["SQ_VALU_MFMA_BUSY_CYCLES"]["avg_per_launch"] / 1024 / cyc, 4)}
 json.dump(h, open(os.path.join(out, "r03_hessian_f16x3_kernels.json"), "w"), indent=1)
 
+f = kernel_table("factor/trace", top=16, only=["chol_diag", "gemm_tn", "gemm_f16x3", "syrk_f16_m16_many", "split_f16x2_many", "absmax", "reverse_copy",
+                                                "finish_factor", "place_diag", "plan"])
+f["command"] = ("rocprofv3 --kernel-trace --stats -- python3 scripts/lab_factor_trace.py 11008 8   (two batched factor chains of 8 Hessians of 11008: "
+                "halve the totals for one chain)")
+json.dump(f, open(os.path.join(out, "r03_factor_kernels.json"), "w"), indent=1)
+hm = kernel_table("hess_many/trace", top=10, only=["_many_kernel", "syrk", "split", "absmax", "gemm_tn", "plan"])
+hm["command"] = ("rocprofv3 --kernel-trace --stats -- python3 scripts/quick_hessian_many.py   (72 gemma-3-270m-shaped inputs per batch: 12 batches per route, "
+                 "per-tensor calls on one and on four streams, then the grouped call)")
+json.dump(hm, open(os.path.join(out, "r03_hessian_many_kernels.json"), "w"), indent=1)
+
 # ---- 4. calibration / AWQ
 cal = kernel_table("calib/trace", top=8, only=["minmax", "rtn_many", "qparams"])
 cal["command"] = "rocprofv3 --kernel-trace --stats -- python3 bench_calib.py --no-cpu-baseline"
