@@ -972,3 +972,38 @@ def test_hessians_of_a_batch_honour_the_method_knob_and_reject_bad_items(ops):
     ws = torch.empty(1 << 24, dtype=torch.uint8, device="cuda")
     assert lib.oq_hessian_accumulate_many_f32(C.c_void_p(host.ctypes.data), C.c_void_p(d.data_ptr()), 1, C.c_void_p(ws.data_ptr()), ws.numel(), None) == L.OQ_ERR_INVALID_ARGUMENT
     assert lib.oq_hessian_accumulate_many_f32(C.c_void_p(host.ctypes.data), C.c_void_p(d.data_ptr()), 1, C.c_void_p(ws.data_ptr()), 1024, None) != 0
+
+
+# ----------------------------------------------------------------------------- the factor's large products on fp16 pieces
+@pytest.mark.parametrize("k", [2601, 4224])
+def test_factor_with_piece_products_follows_float64_and_the_fp32_kernel(ops, k):
+    """From 1024-column trailing squares / 2048-row inverse blocks on, the factor's products take 22-bit operands on the fp16
+    matrix cores (factor.hip).  Widths that exercise those branches with ragged edges (2601: not a multiple of 4, scalar
+    epilogue; 4224 = 2 x 2048 + 128: a full pair and a ragged pair on the top level): U against a float64 factorisation
+    (on the device, checker only), against the same call with fp32 products, and batched == single, bit for bit."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(k)
+    x = torch.randn((3 * k, k), generator=g, device="cuda") * (0.2 + 1.8 * torch.rand(k, generator=g, device="cuda"))
+    h = torch.zeros((k, k), device="cuda")
+    ops.hessian_accumulate(x.reshape(3, k, k), h, 0)
+    hd = h.double()
+    hd = hd + 0.01 * hd.diagonal().mean() * torch.eye(k, device="cuda", dtype=torch.float64)
+    ref = torch.linalg.cholesky(torch.linalg.inv(hd)).T
+    before = ops.hessian_method()
+    try:
+        got = {}
+        for method in ("auto", "f32"):
+            ops.hessian_set_method(method)
+            u, info = ops.gptq_factor(h, 0.01)
+            assert int(info.item()) == 0
+            assert float(torch.tril(u, -1).abs().max()) == 0.0 and bool((u.diagonal() > 0).all())
+            got[method] = u
+            err = float((u.double() - ref).abs().max() / ref.abs().max())
+            assert err < 2e-5, (method, err)
+        assert float((got["auto"] - got["f32"]).abs().max() / ref.abs().max()) < 2e-5
+        assert not torch.equal(got["auto"], got["f32"])             # the piece kernels really ran
+        ops.hessian_set_method("auto")
+        ub, ib = ops.gptq_factor_batched(torch.stack([h, 2.0 * h, h]), 0.01)
+        assert torch.equal(ub[0], got["auto"]) and torch.equal(ub[2], got["auto"]) and ib.tolist() == [0, 0, 0]
+    finally:
+        ops.hessian_set_method(before)
