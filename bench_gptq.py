@@ -376,21 +376,23 @@ def run(args, dev, rank: int, world: int):
     # the Hessian kernel that just ran against float64 (a 256-column strip of one input)
     hcheck = None
     if rank == 0:
-        kc = min(acts)
-        hc = torch.zeros((kc, kc), device=dev)
-        ref = torch.zeros((256, kc), dtype=torch.float64, device=dev)
-        nc = 0
-        for x in acts[kc]:
-            nc = ops.hessian_accumulate(x, hc, nc)
-            x2 = x.reshape(-1, kc)
-            for i in range(0, x2.shape[0], 16384):
-                blk = x2[i:i + 16384].double()
-                ref += blk[:, :256].t() @ blk
-        ref *= 2.0 / nc
-        hcheck = {"k": kc, "rows": int(sum(x.shape[0] * x.shape[1] for x in acts[kc])),
-                  "max_abs_err_over_max_abs_h": float((hc[:256].double() - ref).abs().max() / ref.abs().max()),
-                  "exactly_symmetric": bool(torch.equal(hc, hc.T))}
-        del hc, ref
+        def check_width(kc):
+            hc = torch.zeros((kc, kc), device=dev)
+            ref = torch.zeros((256, kc), dtype=torch.float64, device=dev)
+            nc = 0
+            for x in acts[kc]:
+                nc = ops.hessian_accumulate(x, hc, nc)
+                x2 = x.reshape(-1, kc)
+                for i in range(0, x2.shape[0], 16384):
+                    blk = x2[i:i + 16384].double()
+                    ref += blk[:, :256].t() @ blk
+            ref *= 2.0 / nc
+            return {"k": kc, "rows": int(sum(x.shape[0] * x.shape[1] for x in acts[kc])),
+                    "max_abs_err_over_max_abs_h": float((hc[:256].double() - ref).abs().max() / ref.abs().max()),
+                    "exactly_symmetric": bool(torch.equal(hc, hc.T))}
+        hcheck = check_width(min(acts))
+        if max(acts) != min(acts):
+            hcheck["widest_input"] = check_width(max(acts))     # the same check on the widest input (K = 11008)
     # and its rate alone (no other stream active): one batch of the widest input, per requested kernel
     roofs = []
     if rank == 0:

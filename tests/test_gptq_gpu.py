@@ -1007,3 +1007,38 @@ def test_factor_with_piece_products_follows_float64_and_the_fp32_kernel(ops, k):
         assert torch.equal(ub[0], got["auto"]) and torch.equal(ub[2], got["auto"]) and ib.tolist() == [0, 0, 0]
     finally:
         ops.hessian_set_method(before)
+
+
+def test_hessians_of_a_batch_property(ops):
+    """Property test (hypothesis, fixed seed) of the grouped call: 1-5 items per call with widths that are multiples of
+    nothing, lengths from 512 to 3000 rows, padded leading dimensions, Hessians that already hold samples -- every result
+    within 1e-5 max|H| of float64 and exactly symmetric (checker on the device in float64)."""
+    import torch
+    from hypothesis import HealthCheck, given, seed, settings, strategies as st
+
+    item = st.tuples(st.integers(512, 1500), st.integers(512, 3000), st.integers(0, 7), st.integers(0, 40), st.integers(1, 4))
+
+    @seed(20261004)
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.lists(item, min_size=1, max_size=5), st.integers(0, 2**31 - 1))
+    def run(items, sd):
+        g = torch.Generator(device="cuda").manual_seed(sd)
+        xs, hs, seen, refs = [], [], [], []
+        for k, t, pad, n_seen, lead in items:
+            t = t // lead * lead
+            full = torch.randn((t, k + pad), generator=g, device="cuda") * (0.05 + 3.0 * torch.rand(k + pad, generator=g, device="cuda"))
+            x = full[:, :k].reshape(lead, t // lead, k) if pad == 0 else full[:, :k].unflatten(0, (lead, t // lead))
+            a = torch.randn((k, k), generator=g, device="cuda")
+            h0 = (a @ a.T / k) if n_seen else torch.zeros((k, k), device="cuda")
+            h0 = torch.triu(h0) + torch.triu(h0, 1).T           # exactly symmetric, as every H the path produces is
+            n = n_seen + lead
+            x2 = full[:, :k].double()
+            refs.append(h0.double() * (n_seen / n) + (2.0 / n) * (x2.T @ x2))
+            xs.append(x); hs.append(h0.clone()); seen.append(n_seen)
+        out = ops.hessian_accumulate_many(xs, hs, seen)
+        assert out == [s + it[4] for s, it in zip(seen, items)]
+        for h, ref in zip(hs, refs):
+            assert float((h.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+            assert torch.equal(h, h.T)
+
+    run()
