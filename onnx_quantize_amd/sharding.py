@@ -194,6 +194,26 @@ def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], min
     return {s.name: out[s.name] for s in specs}, total
 
 
+def rtn_quantize_model_sharded(specs: Sequence[LayerSpec], weights: dict, qtype: str, group_size: int, symmetric: bool = False,
+                               reduce_range: bool = False, clip_ratio: float = 1.0, layout: str = "kn", *, group=None):
+    """SURVEY.md 8e (1) for an RTN-configured model whose weights already live in HBM: the node-by-node walk of
+    `qrules/_common.py:126-142` becomes, per rank, ONE `ops.rtn_quantize_many` call over this rank's share of the LPT plan (a
+    table of pointers per shape, a few launches for the whole share) and one gather of (q, scale, zp) to rank 0.
+    ``weights[i]``: the [K, N] fp32 device tensor of ``specs[i]`` (only this rank's indices are read).  Per matrix the bits are
+    those of `ops.rtn_quantize`.  Returns ``({name: (q, scale, zp)} on rank 0 | None, bytes gathered)``."""
+    import torch.distributed as dist
+
+    from .hip import ops
+
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if distributed else 1
+    rank = dist.get_rank(group) if distributed else 0
+    plan = plan_lpt(specs, world)
+    order = plan[rank]
+    results = ops.rtn_quantize_many([weights[i] for i in order], qtype, group_size, symmetric, reduce_range, clip_ratio, layout) if order else []
+    return gather_device_results(specs, plan, dict(zip(order, results)), group=group)
+
+
 class StreamedGather:
     """Results to rank 0 WHILE the ranks still compute, instead of one padded gather behind all of it.
 

@@ -77,3 +77,52 @@ def test_one_matrix_sharded_by_columns_on_the_gpu(world):
         assert p.exitcode == 0
     res = q.get(timeout=5)
     assert res == [True] * len(res) and len(res) == 6, res
+
+
+def _model_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from onnx_quantize_amd import sharding as S
+    from onnx_quantize_amd.hip import ops
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shapes = [(512, 768), (512, 768), (768, 512), (256, 1024), (512, 768), (768, 512), (256, 1024)]
+    specs = [S.LayerSpec(name=f"l{i}", k=k, n=n, tokens=0, hessian_key=f"l{i}") for i, (k, n) in enumerate(shapes)]
+    g = torch.Generator(device="cuda").manual_seed(31)
+    weights = {i: torch.randn(kn, generator=g, device="cuda") * (0.5 + i) for i, kn in enumerate(shapes)}   # every rank: the same model
+    out, nbytes = S.rtn_quantize_model_sharded(specs, weights, "uint4", 128, layout="nbits")
+    if rank == 0:
+        ok = []
+        for i, sp in enumerate(specs):
+            eq, es, ez = ops.rtn_quantize(weights[i], "uint4", "group", 128, layout="nbits")
+            gq, gs, gz = out[sp.name]
+            ok.append(bool(torch.equal(gq.cuda().reshape(eq.shape), eq) and torch.equal(gs.cuda().reshape(es.shape), es)
+                           and torch.equal(gz.cuda().reshape(ez.shape), ez)))
+        q.put((ok, nbytes > 0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_rtn_model_sharded_by_layers_uses_one_list_call_per_rank(world):
+    """sharding.rtn_quantize_model_sharded: every rank quantizes its LPT share with one ops.rtn_quantize_many call, rank 0
+    receives all layers -- bit-equal to the per-matrix kernel."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    ok, moved = q.get(timeout=5)
+    assert ok == [True] * 7 and moved
