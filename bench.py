@@ -32,6 +32,8 @@ Prints ONE JSON line (contract in the task description) with these extra objects
   calibration   BASELINE config 3 stand-in from the same run (bench_calib.run): 51 batches x 72 activation tensors through
                 MinMaxCalibrator.collect_many, `roofline` of oq::minmax_partial, a CPU baseline, `verified`
   awq           the AWQ scale / clip searches of one 4096 x 4096 layer on own kernels (next row N2), verified in float64
+  searches      the MSE range search (row M1) and HQQ's zero-point optimisation (next row N2) on the headline matrix, each
+                verified through the error it is meant to lower
   gptq          BASELINE configs 4 / 5 from the same run: GPTQ QInt4 g128 of all Llama-2-7B MatMul weights
                 (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`;
                 `corrected` = the same model with the error-correcting loop, `wall_by_hessian_method` = the whole-model
@@ -405,6 +407,52 @@ def awq_bench(dev, k: int = 4096, n: int = 4096, t: int = 4096) -> dict:
             "verified": bool(ok)}
 
 
+def search_bench(dev, w) -> dict:
+    """The two iterative weight-only searches on the headline matrix (4096 x 11008, uint4 g128, device resident), from the same
+    run: the MSE range search of utils.py:140-239 (`mse=True`: 20 shrink candidates per group, fake-quantize, |.|^2.4 error) and
+    HQQ's zero-point optimisation (hqq.py:106-144: up to 20 rounds of quantize / shrink / row mean with ONE global early-stop
+    decision per round, taken on the device).  Verified through what each search is for: the MSE parameters do not raise any
+    group's |.|^2.4 error above plain RTN's, HQQ does not raise the mean |w - w_r| of its starting point."""
+    import torch
+
+    from onnx_quantize_amd.hip import ops
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(reps):
+            r = fn()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / reps, r
+    k, n = w.shape
+    ms_plain, (q0, s0, z0) = timed(lambda: ops.rtn_quantize(w, "uint4", "group", GROUP))
+    ms_mse, (q1, s1, z1) = timed(lambda: ops.rtn_quantize(w, "uint4", "group", GROUP, mse=True))
+    ms_hqq, (q2, s2, z2, rounds) = timed(lambda: ops.hqq_quantize(w, GROUP))
+
+    def group_err(q, s, z, p):      # per (column, k-group) sum |w - dequant|^p over a 512-column strip (checker, float64)
+        c = 512
+        d = ops.dequantize(q, s.reshape(-1), z.reshape(-1), "uint4", mode="group", group=GROUP)[:, :c].double() - w[:, :c].double()
+        return d.abs().pow(p).reshape(k // GROUP, GROUP, c).sum(dim=1)
+    e_rtn, e_mse = group_err(q0, s0, z0, 2.4), group_err(q1, s1, z1, 2.4)
+    mse_ok = bool((e_mse <= e_rtn * (1 + 1e-6)).all()) and bool((e_mse < e_rtn).any())
+    # HQQ keeps float zero points: w_r = (q - z) * s with them
+    c = 512
+    zf = z2.reshape(n, k // GROUP)[:c].t().repeat_interleave(GROUP, dim=0)
+    sf = s2.reshape(n, k // GROUP)[:c].t().repeat_interleave(GROUP, dim=0)
+    l1_hqq = float(((q2[:, :c].double() - zf.double()) * sf.double() - w[:, :c].double()).abs().mean())
+    l1_rtn = float(group_err(q0, s0, z0, 1.0).sum() / (k * c))
+    hqq_ok = l1_hqq <= l1_rtn * (1 + 1e-6) and int(rounds.item()) >= 1
+    params = k * n
+    return {"what": "MSE range search (QWeightArgs(mse=True)) and HQQ zero-point optimisation of the headline matrix, uint4 g128, device resident",
+            "rtn_ms": round(ms_plain, 4), "mse_ms": round(ms_mse, 3), "mse_M_params_per_s": round(params / ms_mse / 1e3, 1),
+            "hqq_ms": round(ms_hqq, 3), "hqq_rounds": int(rounds.item()), "hqq_M_params_per_s": round(params / ms_hqq / 1e3, 1),
+            "mse_groups_improved_frac": round(float((e_mse < e_rtn).double().mean()), 4),
+            "mean_abs_error_rtn": l1_rtn, "mean_abs_error_hqq": l1_hqq, "verified": bool(mse_ok and hqq_ok)}
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -632,6 +680,9 @@ def main() -> None:
     if world == 1 and not args.no_seam and not args.no_extras and not args.symmetric:
         seam = seam_bench(w_host, digests["config2_asym"])
 
+    searches = None
+    if world == 1 and not args.no_awq and not args.no_extras and not args.symmetric:
+        searches = search_bench(dev, w_src)
     del ws, outs, calls, w_src
     torch.cuda.empty_cache()
     # ---- config 3 stand-in: min-max calibration of a gemma-3-270m-shaped activation population (rank 0 at N = 1)
@@ -702,6 +753,7 @@ def main() -> None:
         "gather": gather,
         "calibration": calibration,
         "awq": awq,
+        "searches": searches,
         "gptq": gptq,
     }
     if os.environ.get("OQ_BENCH_REHEARSAL", "0") == "1":
