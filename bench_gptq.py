@@ -124,7 +124,7 @@ def run(args, dev, rank: int, world: int):
     import torch.distributed as dist
 
     from onnx_quantize_amd.hip import ops
-    from onnx_quantize_amd.sharding import StreamedGather, gather_device_results, llama2_7b_specs, plan_lpt, wave_bundles
+    from onnx_quantize_amd.sharding import StreamedGather, connect_to_rank0, gather_device_results, llama2_7b_specs, plan_lpt, wave_bundles
 
     specs = llama2_7b_specs(tokens=args.tokens, layers=args.layers, hidden=args.hidden, ffn=args.ffn)
     plan = plan_lpt(specs, world)
@@ -319,6 +319,7 @@ def run(args, dev, rank: int, world: int):
                 "samples": samples, "gathered": gathered, "nbytes": nbytes, "one_stream": one_stream, "n_streams": len(q_streams),
                 "pipelined": pipe is not None}
 
+    connect_to_rank0(dev)            # N > 1: the point-to-point connections of the streamed gather exist before the clock starts
     model_pass(args.mode, warm=True)
     first = model_pass(args.mode)
     n_gathered = len(first["gathered"]) if first["gathered"] is not None else -1

@@ -332,6 +332,39 @@ class StreamedGather:
         return {s.name: out[i] for i, s in enumerate(self.specs) if i in out}, self.nbytes
 
 
+def connect_to_rank0(device=None, *, group=None) -> None:
+    """One tiny grouped send / receive between rank 0 and every other rank, waited for: with NCCL the first point-to-point
+    operation between two ranks sets up their connection, and the host thread that issues it blocks until the peer issues its
+    side.  `StreamedGather` posts rank 0's receives before rank 0 computes anything while a peer sends only when its first
+    bundle is done -- without this call rank 0 would sit in that handshake for as long as the slowest peer's first bundle
+    takes.  Call it once per process group, outside any timed region (every rank must call it)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return
+    nccl = dist.get_backend(group) == "nccl"
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu"))
+    if not nccl:
+        dev = torch.device("cpu")
+    if rank == 0:
+        bufs = [torch.zeros(16, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
+        works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, r, group) for r, b in zip(range(1, world), bufs)])
+        for w in works:
+            w.wait()
+        if any(int(b[0]) != r for r, b in zip(range(1, world), bufs)):
+            raise RuntimeError("connect_to_rank0: a peer's greeting did not arrive intact")
+    else:
+        hello = torch.full((16,), rank % 256, dtype=torch.uint8, device=dev)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, hello, 0, group)]):
+            w.wait()
+    if nccl:
+        torch.cuda.current_stream().synchronize()
+
+
 def wave_bundles(specs: Sequence[LayerSpec], plan: list[list[int]], groups_per_wave: int) -> list[list[list[int]]]:
     """The bundles `StreamedGather` works with, for the wave structure of bench_gptq.py: a rank's layers are grouped by the
     input they share (plan order), `groups_per_wave` such groups form a wave, and a wave is one bundle."""

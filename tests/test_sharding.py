@@ -273,10 +273,11 @@ def _worker_streamed_gather(rank, world, port, q):
     import torch
     import torch.distributed as dist
 
-    from onnx_quantize_amd.sharding import LayerSpec, StreamedGather, gather_device_results, wave_bundles
+    from onnx_quantize_amd.sharding import LayerSpec, StreamedGather, connect_to_rank0, gather_device_results, wave_bundles
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    connect_to_rank0()                      # the handshake bench_gptq does before its clock starts; every rank takes part
     specs = [LayerSpec(f"m{i}", 8 + i, 5 + 2 * i, hessian_key=f"h{i // 2}") for i in range(9)]
     plan = [[0, 1, 4, 5, 8], [2, 3, 6, 7]] if world == 2 else [[0, 1, 6, 7], [2, 3, 4, 5, 8], []]
     bundles = wave_bundles(specs, plan, groups_per_wave=1)
