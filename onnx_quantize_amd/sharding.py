@@ -220,8 +220,9 @@ class StreamedGather:
     Every rank's layers are cut into bundles (`bundles[r][b]` = the layer indices rank r finishes b-th; all ranks pass the
     same structure, e.g. `wave_bundles`), and the byte layout of a layer's result is a function of its spec
     (`layout_fn(spec) -> [(dtype, shape)] * 3` for q, scale, zp), so nobody exchanges sizes or metadata:
-      * rank 0 posts one `irecv` per (rank, bundle) up front, into buffers of exactly the bundle's size (its own results stay
-        where they are);
+      * rank 0 posts the `irecv`s of round b (bundle b of every other rank, buffers of exactly the bundles' sizes) when its OWN
+        bundle b is done -- the peers' bundle b is due about then -- and whatever is left in `finish()`; its own results stay
+        where they are;
       * rank r calls `push(b, results)` when its bundle b is done: the tensors are packed into ONE flat byte tensor (one copy)
         and `isend`-ed (NCCL over xGMI with backend nccl: asynchronous on the communicator's stream, so the next bundle's
         kernels run beside the transfer; gloo: staged through the host, for the CPU tests and the one-GPU rehearsal);
@@ -245,23 +246,34 @@ class StreamedGather:
         self.nbytes = 0
         if len(bundles) != self.world:
             raise ValueError(f"bundles for {len(bundles)} ranks, world size {self.world}")
-        if self.world > 1 and self.rank == 0:
-            rounds = max(len(b) for b in bundles)
-            for b in range(rounds):                      # bundle-major: the order in which the ranks will send
-                ops, bufs = [], []
-                for r in range(1, self.world):
-                    if b < len(bundles[r]) and bundles[r][b]:
-                        n = self._bundle_bytes(bundles[r][b])
-                        buf = torch.empty(n, dtype=torch.uint8, device=self.device if self.nccl else torch.device("cpu"))
-                        ops.append(dist.P2POp(dist.irecv, buf, r, group))
-                        bufs.append((r, b, buf))
-                        self.nbytes += n
-                if ops:
-                    # one grouped launch per round on the communicator that already exists (a bare irecv would create a
-                    # two-rank communicator per peer on first use and block this host thread until that peer's first send)
-                    works = dist.batch_isend_irecv(ops)
-                    for j, (r, bb, buf) in enumerate(bufs):
-                        self.recv.append((r, bb, buf, works[j] if j < len(works) else works[-1]))
+        self.rounds = max(len(b) for b in bundles) if bundles else 0
+        self.posted = 0               # rank 0: rounds whose receives have been posted
+
+    def _post_round(self, b: int) -> None:
+        """Rank 0: the receives of round `b` (bundle b of every other rank), as one grouped launch on the communicator that
+        already exists (a bare irecv would create a two-rank communicator per peer on first use).  Posted when rank 0 has
+        finished its OWN bundle b, not at construction: a receive kernel that spins on the GPU for a whole wave can hold the
+        hardware queue a compute stream shares, and the peers' bundle b is due about now anyway."""
+        import torch
+        import torch.distributed as dist
+
+        ops, bufs = [], []
+        for r in range(1, self.world):
+            if b < len(self.bundles[r]) and self.bundles[r][b]:
+                n = self._bundle_bytes(self.bundles[r][b])
+                buf = torch.empty(n, dtype=torch.uint8, device=self.device if self.nccl else torch.device("cpu"))
+                ops.append(dist.P2POp(dist.irecv, buf, r, self.group))
+                bufs.append((r, b, buf))
+                self.nbytes += n
+        if ops:
+            works = dist.batch_isend_irecv(ops)
+            for j, (r, bb, buf) in enumerate(bufs):
+                self.recv.append((r, bb, buf, works[j] if j < len(works) else works[-1]))
+
+    def _post_through(self, b: int) -> None:
+        while self.posted <= b and self.posted < self.rounds:
+            self._post_round(self.posted)
+            self.posted += 1
 
     @staticmethod
     def _pad16(n: int) -> int:
@@ -288,6 +300,8 @@ class StreamedGather:
         if self.rank == 0 or self.world == 1:
             for i in idx:
                 self.own[i] = results[i]
+            if self.world > 1:
+                self._post_through(b)
             return
         if not idx:
             return
@@ -317,6 +331,8 @@ class StreamedGather:
         self.sent.clear()
         if self.rank != 0:
             return None, self.nbytes
+        if self.world > 1:
+            self._post_through(self.rounds - 1)         # rounds rank 0 has no bundle of its own for
         out = {i: v for i, v in self.own.items()}
         for r, b, buf, w in self.recv:
             w.wait()
