@@ -274,16 +274,21 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
     dev = mats[0].device
     out = [None] * len(ws)
     table = np.empty((len(ws), 4), dtype=np.int64)
-    plan, row = [], 0
+    plan, row, made = [], 0, []
     for (k, n, ldw, g), idx in groups.items():
         cnt = len(idx)
         q = (torch.empty((cnt, k, n), dtype=cdt, device=dev) if layout == "kn"
              else torch.empty((cnt, n, k // g, g * bits // 8), dtype=torch.uint8, device=dev))
         sc = torch.empty((cnt, n * k // g, 1), dtype=torch.float32, device=dev)
         zp = torch.empty((cnt, n * k // g, 1), dtype=cdt, device=dev)
-        for j, i in enumerate(idx):
-            table[row + j] = (mats[i].data_ptr(), q[j].data_ptr(), sc[j].data_ptr(), zp[j].data_ptr())
-            out[i] = (q[j], sc[j], zp[j])
+        # output pointers by arithmetic (the per-matrix views the caller gets back are made AFTER the launches below: with
+        # hundreds of weights their construction was a millisecond of idle GPU in front of the first kernel)
+        steps = np.arange(cnt, dtype=np.int64)
+        table[row:row + cnt, 0] = [mats[i].data_ptr() for i in idx]
+        table[row:row + cnt, 1] = q.data_ptr() + steps * (q[0].numel() * q.element_size())
+        table[row:row + cnt, 2] = sc.data_ptr() + steps * (sc[0].numel() * 4)
+        table[row:row + cnt, 3] = zp.data_ptr() + steps * (zp[0].numel() * zp.element_size())
+        made.append((idx, q, sc, zp))
         plan.append((k, n, ldw, g, row, cnt))
         row += cnt
     table_dev = torch.from_numpy(table).to(dev) if len(ws) > 1 else None   # one small upload for the whole list
@@ -295,6 +300,9 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
         L.check(lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(table[r0:].ctypes.data), dev_rows, cnt, k, n, ldw, L.QTYPE_CODE[qtype],
                                              int(group_size), int(symmetric), int(reduce_range), float(clip_ratio), lay, _ptr(wsb),
                                              wsb.numel(), _stream()))
+    for idx, q, sc, zp in made:
+        for j, i in enumerate(idx):
+            out[i] = (q[j], sc[j], zp[j])
     return out
 
 
