@@ -81,13 +81,20 @@ def _gptq_quantize(weights, inputs, quant_type=QuantType.QInt8, strategy=Quantiz
 
     from ..staging import upload
 
+    from ..reference_passes import StreamedGptqInput
+
     w = upload(np.asarray(weights))
     k = w.shape[0]
-    h = torch.zeros((k, k), dtype=torch.float32, device=w.device)          # gptq.py:304
-    n = 0
-    batches = inputs if isinstance(inputs, (list, tuple)) or hasattr(inputs, "__next__") else [inputs]
-    for x in batches:
-        h, n = _accumulate_hessian(x, h, n)                                # :305
+    if isinstance(inputs, StreamedGptqInput):                              # H accumulated by the calibration walk (calibrate.py:288-307 rebound)
+        if tuple(inputs.h.shape) != (k, k):
+            raise ValueError(f"streamed Hessian of '{inputs.name}' is {tuple(inputs.h.shape)}, the weight has {k} input channels")
+        h = inputs.h
+    else:
+        h = torch.zeros((k, k), dtype=torch.float32, device=w.device)      # gptq.py:304
+        n = 0
+        batches = inputs if isinstance(inputs, (list, tuple)) or hasattr(inputs, "__next__") else [inputs]
+        for x in batches:
+            h, n = _accumulate_hessian(x, h, n)                            # :305
     q, s, z, info = ops.gptq_quantize(w, h, quant_type.key, strategy.value, group_size, bool(is_symmetric),
                                       bool(reduce_range), float(clip_ratio), int(block_size), float(percdamp),
                                       bool(actorder), bool(mse), mode=mode)

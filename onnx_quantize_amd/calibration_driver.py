@@ -97,7 +97,8 @@ class ActivationStream:
         self.hessian_names, self.absmax_names = set(hessian_names), set(absmax_names)
         self.keep_names = set(keep_names)
         self.hessians: dict[str, HessianAccumulator] = {}
-        # 0 (default): the Hessian updates of a batch in one grouped launch chain; n > 0: per-tensor calls on n side streams
+        # 0 (default): the Hessian updates of a batch in one grouped launch chain (per-tensor calls on 4 side streams when a
+        # Hessian method the grouped chain does not run is selected); n > 0: per-tensor calls on n side streams
         self.hessian_streams = max(0, int(hessian_streams))
         self._side = None
         self.absmax: dict = {}
@@ -129,7 +130,11 @@ class ActivationStream:
             else:
                 self.calibrator.collect_many(activations)
         wanted = sorted(self.hessian_names & activations.keys())
-        if wanted and self.hessian_streams == 0:
+        streams = self.hessian_streams
+        if wanted and streams == 0 and ops.hessian_method() not in ("auto", "f16x3"):
+            streams = 4      # the grouped chain runs the fp16-piece kernels only: other methods would become serial per-tensor
+                             # calls on one stream, so they take the side-stream route below
+        if wanted and streams == 0:
             # one launch chain for all tapped inputs of the batch (ops.hessian_accumulate_many): a batch of a small model is
             # 72 tensors of 6 to 36 product tiles each, launch-bound and never filling the chip one at a time
             xs = []
@@ -147,7 +152,7 @@ class ActivationStream:
             # the grouped call does not run (hessian_streams > 0 selects it)
             cur = torch.cuda.current_stream()
             if self._side is None:
-                self._side = [torch.cuda.Stream(device=activations[wanted[0]].device) for _ in range(self.hessian_streams)]
+                self._side = [torch.cuda.Stream(device=activations[wanted[0]].device) for _ in range(streams)]
             fork = cur.record_event()
             for i, name in enumerate(wanted):
                 x = activations[name]

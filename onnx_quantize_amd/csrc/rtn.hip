@@ -1061,12 +1061,15 @@ __global__ __launch_bounds__(256) void rtn_flat_groups(const float* W, int64_t K
 
 // [kgroups, N] staging -> the reference's n-major [N*K/g] arrays (entry n*kgroups + kg), 32x32 tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, const uint8_t* zp_t, int64_t kgroups, int64_t N,
-                                                         float* scale, uint8_t* zp) {
+                                                         float* scale, uint8_t* zp, const RtnPtrs* table) {
     __shared__ float ts[32][33];
     __shared__ uint8_t tz[32][36];
-    {   // blockIdx.z = matrix of a strided batch: every array advances by kgroups * N entries
+    {   // blockIdx.z = matrix of the launch: the staging advances by kgroups * N entries; the outputs do so too for a
+        // strided batch and come from the entry's own pointers for a list of matrices (oq_rtn_quantize_ptrs_f32)
         const int64_t off = static_cast<int64_t>(blockIdx.z) * kgroups * N;
-        scale_t += off; zp_t += off; scale += off; zp += off;
+        scale_t += off; zp_t += off;
+        if (table != nullptr) { scale = table[blockIdx.z].scale; zp = table[blockIdx.z].zp; }
+        else { scale += off; zp += off; }
     }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const int64_t n0 = static_cast<int64_t>(blockIdx.x) * 32, k0 = static_cast<int64_t>(blockIdx.y) * 32;
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
 
 // Experiment knobs: speed only, every setting produces the same bytes (-1 = the tuned default).
 struct Tuning {
-    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1, wps = -1;
+    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1, wps = -1, resident = -1;
     static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
     static Tuning from_env() {
         Tuning t;
@@ -1104,6 +1107,7 @@ struct Tuning {
         t.gpb = env_int("OQ_RTN_GPB");          // wave kernel: k-groups per block
         t.wpb = env_int("OQ_RTN_WPB");          // wave kernel: waves per block
         t.wps = env_int("OQ_RTN_WPS");          // wave kernel: 0 = the 4-waves-per-SIMD build, 5 = the 92-register build (5 per SIMD)
+        t.resident = env_int("OQ_RTN_RESIDENT"); // channel / tensor / tall groups: 0 = the three-launch path that reads W twice
         return t;
     }
 };
@@ -1185,8 +1189,13 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
 
 }  // namespace oq
 
-// MSE search lives in rtn_mse.hip
+// MSE search lives in rtn_mse.hip, the one-read channel / tensor kernels in rtn_resident.hip
 namespace oq {
+bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, const void* q, int32_t strategy, int64_t g, int32_t layout,
+                           bool emit_q, size_t workspace_bytes);
+int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
+                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s);
+size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
 int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy,
                      int64_t g, void* q_out, float* scale_out, void* zp_out, int32_t zp_signed, void* workspace,
                      size_t workspace_bytes, hipStream_t s, bool emit_q);
@@ -1375,10 +1384,19 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         if (st != OQ_OK || !staged) return st;
         hipLaunchKernelGGL(transpose_qparams,
                            dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32)), static_cast<uint32_t>(batch)),
-                           dim3(256), 0, s, a.scale_t, a.zp_t, kgroups, N, scale_out, zp8);
+                           dim3(256), 0, s, a.scale_t, a.zp_t, kgroups, N, scale_out, zp8, a.table);
         return check_launch("transpose_qparams");
     }
     OQ_REQUIRE(g_batch.count == 1, OQ_ERR_UNSUPPORTED, "batched call needs the fused group path");
+
+    // channel, tensor, groups taller than the fused kernel holds: W read once, ranges completed across workgroups
+    // (rtn_resident.hip); what it does not take (scalar-aligned operands, the blob layout, ranges without integers,
+    // columns taller than 16384 rows) runs on the three launches below
+    {
+        static const Tuning tr = Tuning::from_env();
+        if (tr.resident != 0 && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, workspace ? workspace_bytes : 0))
+            return rtn_resident_impl(W, K, N, ldw, grid, strategy, g, q8, scale_out, zp8, layout, workspace, workspace_bytes, s);
+    }
 
     // two-pass
     const size_t need = twopass_ws(K, N, g);
@@ -1424,6 +1442,8 @@ size_t oq_rtn_workspace_bytes(int64_t K, int64_t N, int32_t strategy, int64_t gr
     size_t need = oq::twopass_ws(K, N, g);
     const size_t st = oq::stage_ws(K, N, g);
     if (st > need) need = st;
+    const size_t rs = oq::rtn_resident_workspace(K, N, strategy, g);
+    if (rs > need) need = rs;
     if (mse) need += oq::rtn_mse_workspace(K, N, strategy, g);
     return need + 256;
 }
@@ -1477,6 +1497,8 @@ int32_t oq_rtn_quantize_ptrs_f32(const oq_rtn_ptrs* table_host, const oq_rtn_ptr
                                  int64_t ldw, int32_t qtype, int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio,
                                  int32_t layout, void* workspace, size_t workspace_bytes, void* stream) {
     static_assert(sizeof(oq::RtnPtrs) == sizeof(oq_rtn_ptrs), "device view of oq_rtn_ptrs");
+    OQ_REQUIRE(K > 0 && N > 0 && count >= 1, OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_ptrs_f32: bad shape K=%lld N=%lld / count %lld",
+               (long long)K, (long long)N, (long long)count);
     const int64_t per_launch = oq::matrices_per_launch(K, N, count);
     OQ_REQUIRE(table_host && (table_device || per_launch == 1) && count >= 1, OQ_ERR_INVALID_ARGUMENT,
                "oq_rtn_quantize_ptrs_f32: bad table / count %lld", (long long)count);

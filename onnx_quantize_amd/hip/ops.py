@@ -266,6 +266,8 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
             raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
         w2, ldw = _row_major(w)
         k, n = w2.shape
+        if k == 0 or n == 0:
+            raise ValueError(f"rtn_quantize_many: weight {i} is empty ({k} x {n})")
         g = resolve_group("group", k, group_size)
         if g <= 0 or k % g:
             raise ValueError("rtn_quantize_many needs K % group_size == 0 for every weight")
@@ -552,8 +554,12 @@ def smooth_quant_scale(x: torch.Tensor, w: torch.Tensor, alpha: float) -> torch.
     """pre_passes/smooth_quant.py:62-74, :111-113 (oq_smooth_quant_scale_f32): the smoothing scale [K] on the device."""
     x2, ldx = _row_major(_flat_inputs(x))
     _require_device(w, "w", torch.float32)
-    w2, ldw = _row_major(w)
     t, k = x2.shape
+    if w.dim() != 2 or w.shape[0] != k:           # the kernel reads K rows of W: a shorter W would be read out of bounds
+        raise ValueError(f"weights must be [K, N] with K = {k}, got {tuple(w.shape)}")
+    if w.device != x2.device:
+        raise RuntimeError(f"inputs live on {x2.device} and weights on {w.device}")
+    w2, ldw = _row_major(w)
     lib = L.load()
     out = torch.empty(k, dtype=torch.float32, device=w2.device)
     ws = _workspace(lib.oq_smooth_quant_workspace_bytes(k), w2.device)
@@ -667,7 +673,7 @@ class HessianPipeline:
         self.bufs = [None, None]        # piece buffers
         self.ready = [None, None]       # event: pieces of the buffer are complete
         self.free = [None, None]        # event: the product that read the buffer is done
-        self.tag = [None, None]         # (data_ptr, shape, n_total) the buffer was prepared for
+        self.tag = [None, None]         # (the prepared tensor itself, its ._version, shape, n_total): identity, not address
         self.slab = None
         self.slot = 0
 
@@ -693,11 +699,20 @@ class HessianPipeline:
         x2, ldx = self._flat(x)
         t, k = x2.shape
         need = lib.oq_hessian_pieces_bytes(t, k)
+        cur = torch.cuda.current_stream(self.device)
         if self.bufs[i] is None or self.bufs[i].numel() < need:
+            old = self.bufs[i]
+            if old is not None:
+                # a prepare-ahead that was never consumed may still be writing the old buffer on the side stream, and a
+                # product may still be reading it on the caller's: the block must not go back to the allocator (which
+                # hands it out in the CALLER's stream order) before both are done
+                old.record_stream(self.side)
+                if self.ready[i] is not None:
+                    cur.wait_event(self.ready[i])
             self.bufs[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.ready[i] = self.free[i] = self.tag[i] = None
         buf = self.bufs[i]
         off = (-buf.data_ptr()) % 256
-        cur = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
         ev.record(cur)                                  # X is ready on the caller's stream at this point
         with torch.cuda.stream(self.side):
@@ -710,7 +725,9 @@ class HessianPipeline:
             done.record(self.side)
         x2.record_stream(self.side)
         self.ready[i] = done
-        self.tag[i] = (x2.data_ptr(), tuple(x2.shape), int(n_total))
+        # the tag holds the tensor: while it is held its address cannot be handed to another batch by the allocator, and
+        # `_version` catches an in-place edit between the preparation and the product
+        self.tag[i] = (x2, x2._version, tuple(x2.shape), int(n_total))
 
     def accumulate(self, x, h, n_seen: int, next_x=None, next_n_total: int | None = None) -> int:
         lib = L.load()
@@ -722,8 +739,13 @@ class HessianPipeline:
             raise ValueError(f"H must be a contiguous [{k}, {k}] tensor")
         n_total = int(n_seen) + n_add
         i = self.slot
-        if self.tag[i] != (x2.data_ptr(), tuple(x2.shape), n_total):
-            self._prepare(i, x, n_total)                # nothing was prepared ahead for this batch
+        tag = self.tag[i]
+        # same storage (held by the tag, so its address cannot have been handed to another batch), same view, unedited
+        prepared = (tag is not None and tag[0].untyped_storage().data_ptr() == x2.untyped_storage().data_ptr() and
+                    tag[0].data_ptr() == x2.data_ptr() and tag[0].stride() == x2.stride() and tag[1] == x2._version and
+                    tag[2] == tuple(x2.shape) and tag[3] == n_total)
+        if not prepared:
+            self._prepare(i, x, n_total)                # nothing (valid) was prepared ahead for this batch
         if next_x is not None:
             self._prepare(1 - i, next_x, next_n_total if next_n_total is not None else int(next_x.shape[0]))
         cur = torch.cuda.current_stream(self.device)

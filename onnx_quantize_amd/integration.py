@@ -103,16 +103,36 @@ def install_into_reference() -> dict:
         ref_calibrate = None
     _extend_providers(ref_base, ref_calibrate)
     rebound = {"algorithms": ["_rtn_quantize", "_gptq_quantize", "_hqq_quantize"], "calibrator": "minmax",
-               "quantize_weights": _rebind_seam(), "awq": False, "cleanup": False}
-    # the AWQ pass binds the two helpers by name at import time (pre_passes/awq.py:10-11): rebind them in its namespace
+               "quantize_weights": _rebind_seam(), "awq": False, "awq_pass": [], "smooth_quant_pass": [], "calibrate": [],
+               "cleanup": False}
+    # the AWQ pass binds the two helpers by name at import time (pre_passes/awq.py:10-11): rebind them in its namespace --
+    # and, since round 4, its two search methods themselves (one device call each instead of a 20- / 10-iteration host loop
+    # with a PCIe round trip per candidate), SmoothQuant's node method and the calibration walks (reference_passes.py)
+    from . import reference_passes
+
     try:
         import onnx_quantize.pre_passes.awq as ref_awq
 
         ref_awq._rtn_quantize = _rtn_quantize
         ref_awq._dequantize_array = _dequantize_array
+        reference_passes.install_awq(ref_awq)
         rebound["awq"] = True
+        rebound["awq_pass"] = ["AwqPass._apply_awq", "AwqPass._apply_awq_clip"]
     except ImportError:
         pass
+    try:
+        import onnx_quantize.pre_passes.smooth_quant as ref_sq
+
+        reference_passes.install_smooth_quant(ref_sq)
+        rebound["smooth_quant_pass"] = ["SmoothQuantPass._smooth_quant_node"]
+    except ImportError:
+        pass
+    if ref_calibrate is not None:
+        import sys
+
+        # pre_passes/__init__.py:8 imported `calibrate_model` by name (that package needs onnxscript: only if it is loaded)
+        reference_passes.install_calibrate(ref_calibrate, also=[m for m in (sys.modules.get("onnx_quantize.pre_passes"),) if m is not None])
+        rebound["calibrate"] = ["_set_qparams", "_set_qparams_gptq", "calibrate_model"]
     # the rewrite is over when quantize.py:68 asks for the emitted functions (`get_qfunctions`, resolved by name in that
     # module at call time, so this also covers callers that bound `quantize` before the install): drop the cached
     # Hessians / factors of the GPTQ nodes there, on the drop-in path too

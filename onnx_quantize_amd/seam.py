@@ -57,9 +57,12 @@ def _hessian_and_factor(x, k, device, percdamp, actorder):
 
     from .hip import ops
 
+    from .reference_passes import StreamedGptqInput
+
     if _SHARED_INPUTS is None:
         _SHARED_INPUTS = OrderedDict()
-    cacheable = isinstance(x, (np.ndarray, torch.Tensor))
+    streamed = isinstance(x, StreamedGptqInput)       # the calibration walk already accumulated H on the device
+    cacheable = streamed or isinstance(x, (np.ndarray, torch.Tensor))
     key = (id(x), int(k), str(device), float(percdamp), bool(actorder), ops.hessian_method())
     mark = None
     if isinstance(x, np.ndarray):
@@ -73,12 +76,17 @@ def _hessian_and_factor(x, k, device, percdamp, actorder):
             shared_input_stats["hits"] += 1
             return hit[1], hit[2]
     shared_input_stats["misses"] += 1
-    h = torch.zeros((k, k), dtype=torch.float32, device=device)
-    n = 0
-    batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
-    for b in batches:
-        xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
-        n = ops.hessian_accumulate(xb.to(device, torch.float32), h, n)
+    if streamed:
+        if tuple(x.h.shape) != (k, k):
+            raise ValueError(f"streamed Hessian of '{x.name}' is {tuple(x.h.shape)}, the weight has {k} input channels")
+        h = x.h if x.h.device == torch.device(device) else x.h.to(device)
+    else:
+        h = torch.zeros((k, k), dtype=torch.float32, device=device)
+        n = 0
+        batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
+        for b in batches:
+            xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
+            n = ops.hessian_accumulate(xb.to(device, torch.float32), h, n)
     shared = ops.gptq_shared_factor(h, percdamp, actorder)
     if cacheable:
         _SHARED_INPUTS[key] = (x, h, shared, mark)

@@ -871,6 +871,42 @@ def test_two_stream_hessian_pipeline_gives_the_one_call_bits(ops):
         ops.hessian_set_method(before)
 
 
+def test_hessian_pipeline_never_reuses_stale_pieces(ops):
+    """the pipeline recognised "prepared ahead" by (data_ptr, shape, n_total).  A batch edited in place after
+    the look-ahead, or a NEW batch the allocator put at the address of a dropped one, matched that tag and the product ran
+    on the stale fp16 pieces.  The tag now holds the tensor (its address cannot be recycled while held) and its version."""
+    import torch
+    before = ops.hessian_method()
+    ops.hessian_set_method("f16x3")
+    try:
+        gen = torch.Generator(device="cuda").manual_seed(43)
+        k = 1024
+        a = torch.randn((2, 600, k), generator=gen, device="cuda")
+        b = torch.randn((2, 600, k), generator=gen, device="cuda")
+        pipe = ops.HessianPipeline(torch.device("cuda", torch.cuda.current_device()))
+        h = torch.zeros((k, k), device="cuda")
+        n = pipe.accumulate(a, h, 0, b, 4)           # b's pieces are prepared ahead ...
+        b.mul_(3.0)                                  # ... and then b is edited in place
+        n = pipe.accumulate(b, h, n)
+        ref = torch.zeros((k, k), device="cuda")
+        m = ops.hessian_accumulate(a, ref, 0)
+        m = ops.hessian_accumulate(b, ref, m)
+        assert n == m == 4 and torch.equal(h, ref)
+        # a dropped look-ahead batch whose memory the allocator hands to the next one
+        h2 = torch.zeros((k, k), device="cuda")
+        c = torch.randn((2, 600, k), generator=gen, device="cuda")
+        n = pipe.accumulate(a, h2, 0, c, 4)
+        del c
+        d = torch.randn((2, 600, k), generator=gen, device="cuda") * 0.5     # typically lands at c's address
+        n = pipe.accumulate(d, h2, n)
+        ref2 = torch.zeros((k, k), device="cuda")
+        m = ops.hessian_accumulate(a, ref2, 0)
+        m = ops.hessian_accumulate(d, ref2, m)
+        assert torch.equal(h2, ref2)
+    finally:
+        ops.hessian_set_method(before)
+
+
 # ----------------------------------------------------------------------------- a calibration batch's Hessians in one call
 def _f64_update(h0, n_seen, x):
     """gptq.py:246-260 in float64 on the flattened input (n = leading-dimension entries, :247)."""

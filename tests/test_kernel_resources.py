@@ -72,3 +72,23 @@ def test_gptq_loop_kernels_do_not_spill(tmp_path):
     panel = next(v for k, v in seen.items() if "panel_update_kernel" in k)
     assert rows16[0] <= 128 and rows16[1] == 0 and rows16[3] <= 65536, rows16
     assert panel[1] == 0 and panel[2] >= 2 and panel[3] <= 65536, panel
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_resident_rtn_kernels_keep_two_workgroups_per_cu(tmp_path):
+    """`rtn_resident_groups` / `rtn_tensor_onepass` (channel, tensor, tall groups: W read once) hold a 128 x 256 tile in 64
+    registers per lane while the range completes elsewhere; two 8-wave workgroups per CU (<= 128 registers, no scratch) are
+    what keeps loads in flight while one of them waits."""
+    from onnx_quantize_amd import _build
+    src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "rtn_resident.hip")
+    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+                        str(tmp_path / "res.s"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = {}
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, re.S):
+        seen[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
+    for key in ("rtn_resident_groups", "rtn_tensor_onepass"):
+        hits = [v for k, v in seen.items() if key in k]
+        assert hits, (key, list(seen))
+        for vgprs, scratch, occ in hits:
+            assert vgprs <= 128 and scratch == 0 and occ >= 4, (key, vgprs, scratch, occ)

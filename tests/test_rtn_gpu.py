@@ -613,3 +613,57 @@ def test_list_of_weights_in_one_call_equals_the_per_matrix_calls(qtype, g, layou
     assert ops.rtn_quantize_many([], qtype, g) == []
     with pytest.raises(ValueError):
         ops.rtn_quantize_many([torch.zeros((g + g // 2, 8), device="cuda")], qtype, g)     # K % g != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["kn", "nbits"])
+def test_ptrs_entry_point_with_outputs_anywhere_in_memory(layout):
+    """oq_hip.h promises a list of matrices AND outputs 'anywhere in device memory'.  ADVICE r03: with the staged [K,N]
+    parameter path the transpose launch wrote entry z of a launch to scale_out(first entry) + z * stride, which is only
+    right for the stacked buffers `ops.rtn_quantize_many` happens to build.  Here the C entry point is called directly
+    with separately allocated outputs in scrambled order (and guard bytes around every parameter array)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    from onnx_quantize_amd.hip import _lib as L, ops
+
+    lib = L.load()
+    k, n, g, count = 512, 384, 64, 5
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    ws = [torch.randn((k, n), generator=gen, device="cuda") * (0.05 + 0.2 * i) for i in range(count)]
+    per = n * k // g
+    qshape = (k, n) if layout == "kn" else (n, k // g, g // 2)
+    # outputs allocated one by one, in an order unrelated to the table's, with a guard row in front of and behind the payload
+    order = [3, 0, 4, 2, 1]
+    bufs = {}
+    for i in order:
+        bufs[i] = (torch.zeros(qshape, dtype=torch.uint8, device="cuda"),
+                   torch.full((per + 64,), -7.0, dtype=torch.float32, device="cuda"),
+                   torch.full((per + 64,), 0xAB, dtype=torch.uint8, device="cuda"))
+        torch.empty((1000 + 37 * i,), device="cuda")            # shift the next allocation
+    table = np.empty((count, 4), dtype=np.int64)
+    for i in range(count):
+        q, sc, zp = bufs[i]
+        table[i] = (ws[i].data_ptr(), q.data_ptr(), sc.data_ptr() + 32 * 4, zp.data_ptr() + 32)
+    table_dev = torch.from_numpy(table).cuda()
+    nbytes = lib.oq_rtn_batched_workspace_bytes(count, k, n, g)
+    wsb = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    lay = L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS
+    L.check(lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(table.ctypes.data), C.c_void_p(table_dev.data_ptr()), count, k, n, n,
+                                         L.QTYPE_CODE["uint4"], g, 0, 0, 1.0, lay, C.c_void_p(wsb.data_ptr()), wsb.numel(),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    for i in range(count):
+        q1, s1, z1 = ops.rtn_quantize(ws[i], "uint4", "group", g, layout=layout)
+        q, sc, zp = bufs[i]
+        assert torch.equal(q.reshape(-1), q1.reshape(-1).view(torch.uint8)), f"entry {i}: integers"
+        assert torch.equal(sc[32:32 + per], s1.reshape(-1)) and torch.equal(zp[32:32 + per], z1.reshape(-1)), f"entry {i}: parameters"
+        assert bool((sc[:32] == -7.0).all()) and bool((sc[32 + per:] == -7.0).all()), f"entry {i}: scale guard overwritten"
+        assert bool((zp[:32] == 0xAB).all()) and bool((zp[32 + per:] == 0xAB).all()), f"entry {i}: zero-point guard overwritten"
+    # an empty shape is an argument error, not a division by zero (ADVICE r03)
+    st = lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(table.ctypes.data), C.c_void_p(table_dev.data_ptr()), count, k, 0, 0,
+                                      L.QTYPE_CODE["uint4"], g, 0, 0, 1.0, lay, C.c_void_p(wsb.data_ptr()), wsb.numel(), C.c_void_p(0))
+    assert st == L.OQ_ERR_INVALID_ARGUMENT
+    with pytest.raises(ValueError):
+        ops.rtn_quantize_many([torch.zeros((g, 0), device="cuda")], "uint4", g)
