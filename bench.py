@@ -453,6 +453,45 @@ def search_bench(dev, w) -> dict:
             "mean_abs_error_rtn": l1_rtn, "mean_abs_error_hqq": l1_hqq, "verified": bool(mse_ok and hqq_ok)}
 
 
+def strategies_bench(dev, ws, rank: int) -> dict:
+    """Per-channel and per-tensor int8 RTN of the headline matrix (rtn.py:54-109 with the reference's default QWeightArgs():
+    core/_qconfig.py:232-268) -- `rtn_resident_groups` / `rtn_tensor_onepass` of rtn_resident.hip, W read once.  HIP events on
+    the launch stream over rotating inputs; algorithmic bytes = W once + one byte per value + the parameters; outputs
+    checked against the digests of what the reference itself returned (tests/golden/digests.json, rank 0's matrix)."""
+    import torch
+
+    from onnx_quantize_amd.hip import ops
+
+    with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+        digests = json.load(f)
+    out = {"what": "int8 RTN of the 4096x11008 matrix with one range per column / per tensor; W read once (rtn_resident.hip); "
+                   "rounds 1-3 read it twice in three launches (89 / 94 us)"}
+    for strategy, kernel in (("channel", "oq::rtn_resident_groups"), ("tensor", "oq::rtn_tensor_onepass")):
+        outs = ops.rtn_quantize(ws[0], "int8", strategy, -1)
+        for i in range(10):
+            ops.rtn_quantize(ws[i % len(ws)], "int8", strategy, -1, out=outs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 100
+        e0.record()
+        for i in range(reps):
+            ops.rtn_quantize(ws[i % len(ws)], "int8", strategy, -1, out=outs)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        nparam = N_DIM if strategy == "channel" else 1
+        alg = K_DIM * N_DIM * 4 + K_DIM * N_DIM + nparam * 5
+        rec = {"kernel": kernel, "launch_us": round(us, 2), "algorithmic_bytes": alg, "achieved_GBs": round(alg / us / 1e3, 1),
+               "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
+        d = digests.get(f"headline_int8_{strategy}")
+        if rank == 0 and d is not None:
+            q, sc, z = outs
+            rec["verified_vs_reference_digest"] = bool(sha16(q.cpu().numpy()) == d["q_sha"] and sha16(sc.cpu().numpy()) == d["s_sha"] and
+                                                       sha16(z.cpu().numpy()) == d["z_sha"])
+        out[strategy] = rec
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main() -> None:
     ap = argparse.ArgumentParser()
@@ -460,6 +499,9 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rotate", type=int, default=4, help="distinct input/output buffer sets cycled through")
+    ap.add_argument("--rotate-out", type=int, default=12,
+                    help="output sets of the SECOND timed run (`roofline.frac_outputs_streamed`): 12 x 24.3 MB = 291 MB, more than "
+                         "the 256 MiB Infinity Cache, so every output byte is written to HBM between the reads (0: skip)")
     ap.add_argument("--layout", choices=["kn", "nbits"], default="nbits",
                     help="kn: [K,N] one value per byte (what _rtn_quantize returns); "
                          "nbits: MatMulNBits blob [N,K/g,g/2] (what the emitted graph holds for this config)")
@@ -475,6 +517,7 @@ def main() -> None:
     ap.add_argument("--no-calibration", action="store_true", help="skip the `calibration` object (config 3 stand-in)")
     ap.add_argument("--gptq-extra-passes", default="corrected,f32",
                     help="further whole-model GPTQ passes of the `gptq` object (bench_gptq.py --extra-passes)")
+    ap.add_argument("--gptq-gather", choices=["streamed", "padded"], default="streamed", help="bench_gptq.py --gather (N > 1)")
     ap.add_argument("--gptq-layers", type=int, default=32)
     ap.add_argument("--gptq-tokens", type=int, default=128 * 2048)
     ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
@@ -490,6 +533,14 @@ def main() -> None:
     import torch.distributed as dist
 
     dev, rank, world = init_ranks(args.gpus)
+    if world > 1:          # before any clock: a bounded wait that names missing ranks, then the count the driver asked for
+        from onnx_quantize_amd.sharding import await_all_ranks
+
+        await_all_ranks("oq/bench", timeout_s=120.0)
+        early = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(early)
+        if int(early.item()) != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but {int(early.item())} ranks joined")
 
     from onnx_quantize_amd.hip import _lib as L
     lib = L.load()
@@ -545,6 +596,33 @@ def main() -> None:
     fence()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)            # HIP events on the launch stream: device time of the K launches
+
+    # the same launches with outputs that do not fit the Infinity Cache: `--rotate` output sets are 96 MB and
+    # stay on chip from one step to the next, as the output of ONE quantized matrix does in real use; with `--rotate-out`
+    # sets every output byte of a step is really written to HBM before its buffer comes round again
+    streamed_us = None
+    if world == 1 and not args.no_extras and not args.qparams_only and args.rotate_out > len(outs):
+        more = [(torch.empty(q_elems, dtype=torch.uint8, device=dev), torch.empty(groups, dtype=torch.float32, device=dev),
+                 torch.empty(groups, dtype=torch.uint8, device=dev)) for _ in range(args.rotate_out - len(outs))]
+        sets = [(C.c_void_p(q.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(z.data_ptr())) for (q, sc, z) in list(outs) + more]
+
+        def sstep(i: int) -> None:
+            qp, sp, zp = sets[i % len(sets)]
+            st = fn(calls[i % len(calls)][0], K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, qp, sp, zp, layout, wsp, wsn, stream)
+            if st != 0:
+                L.check(st)
+        for i in range(max(args.warmup, len(sets))):
+            sstep(i)
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for i in range(max(args.steps, 2 * len(sets))):
+            sstep(i)
+        s1.record()
+        torch.cuda.synchronize()
+        streamed_us = s0.elapsed_time(s1) * 1e3 / max(args.steps, 2 * len(sets))
+        streamed_same = bool(torch.equal(more[-1][0], outs[0][0]) and torch.equal(more[-1][1], outs[0][1]))   # same matrix, other buffers
+        del more, sets
 
     # per-launch distribution (median, p10 / p90): 100 more launches, one event pair each
     pct = None
@@ -625,6 +703,11 @@ def main() -> None:
     if world == 1 and not args.qparams_only and not args.no_extras and not args.no_model_rtn and not args.symmetric:
         model_rtn = model_rtn_bench(dev, args.layout, outs[0], w_src)
 
+    # the reference's DEFAULT strategies (QWeightArgs(): int8, group_size=None -> per tensor; and per channel) on the same matrix
+    strategies = None
+    if world == 1 and not args.qparams_only and not args.no_extras and not args.symmetric:
+        strategies = strategies_bench(dev, ws, rank)
+
     t = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
     ranks_seen = torch.ones(1, dtype=torch.int32, device=dev)
     if world > 1:
@@ -702,7 +785,8 @@ def main() -> None:
         import bench_gptq
 
         gargs = bench_gptq.build_parser().parse_args(["--gpus", str(world), "--layers", str(args.gptq_layers),
-                                                      "--tokens", str(args.gptq_tokens), "--extra-passes", args.gptq_extra_passes] +
+                                                      "--tokens", str(args.gptq_tokens), "--extra-passes", args.gptq_extra_passes,
+                                                      "--gather", args.gptq_gather] +
                                                      (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
         gptq = bench_gptq.run(gargs, dev, rank, world)
 
@@ -748,7 +832,15 @@ def main() -> None:
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "oq::rtn_group_wave<8,true,5>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
                      "launch_us": round(launch_us, 2), "launch_us_p10_p50_p90": pct,
+                     "frac_outputs_streamed": None if streamed_us is None else round(alg / (streamed_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "launch_us_outputs_streamed": None if streamed_us is None else round(streamed_us, 2),
+                     "outputs_streamed": None if streamed_us is None else {
+                         "output_sets": args.rotate_out, "output_bytes_in_rotation": args.rotate_out * (moved_bytes(args.layout) - K_DIM * N_DIM * 4),
+                         "same_bytes_as_headline": streamed_same,
+                         "what": "`frac` is BASELINE's single-matrix regime: 4 rotating output sets (96 MB) stay in the 256 MiB Infinity "
+                                 "Cache between steps; here 12 sets (291 MB) force every output byte to HBM, as inside a model-sized call"},
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
+        "strategies": strategies,
         "seam": seam,
         "gather": gather,
         "calibration": calibration,

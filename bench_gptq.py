@@ -63,6 +63,12 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--factor-wave", type=int, default=8,
                     help="layers per wave whose Hessians of one width are factored as ONE batch (0: a factor chain per input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", choices=["streamed", "padded"], default="streamed",
+                    help="N > 1: how results reach rank 0 -- streamed: sharding.StreamedGather (grouped point-to-point per wave of layers, "
+                         "beside the next wave's kernels); padded: sharding.gather_device_results (ONE padded collective gather after the "
+                         "last kernel: the simpler path, for a first run on a new node or when the streamed one misbehaves)")
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0,
+                    help="N > 1: seconds to wait for all ranks (key-value store) and for the point-to-point handshake before exiting non-zero")
     ap.add_argument("--no-hessian-pipeline", action="store_true",
                     help="one stream for the Hessian: preparation (absmax / split) and product of every batch in sequence")
     ap.add_argument("--extra-passes", default="corrected,f32",
@@ -111,6 +117,49 @@ def cpu_baseline(k: int = 2048, n: int = 2048, tokens: int = 8192) -> dict:
             "seconds": round(dt, 3), "integers_equal_rtn": bool(np.array_equal(q, rq)), **cpu_info()}
 
 
+CORRECTED_RATIO_BAR = 0.9
+
+
+def _unpack_int4(packed, k: int, n: int):
+    """[K, N/2] nibble pairs (core/_pack.py:8-22 order, two's complement) -> [K, N] int8.  Checker code (torch), outside the clock."""
+    import torch
+
+    p = packed.reshape(k, n // 2)
+    q = torch.stack([p & 0xF, p >> 4], dim=-1).reshape(k, n).to(torch.int16)
+    return ((q ^ 8) - 8).to(torch.int8)
+
+
+def corrected_strip_check(ops, w, q, scale, batches, k: int, n: int, strip: int = 512) -> dict:
+    """Output columns are independent given H: the oracle's corrected mode (checker: oracle/oq_oracle.py::gptq, NumPy on the
+    host) on columns [0, strip) with the GPU's own Hessian is the reference for that strip of the GPU result.  The bar is
+    the one of tests/test_gptq_gpu.py::test_corrected_mode_at_llama_size_follows_the_oracle_on_a_column_strip: <= 2 % of the
+    integers differ, and in every column the FIRST difference is a single level (a flipped rounding; larger ones only below
+    it, where the flip was fed back)."""
+    import numpy as np
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oq_oracle as O          # checker only, outside every timed region
+
+    h = torch.zeros((k, k), device=w.device)
+    nn = 0
+    for x in batches:
+        nn = ops.hessian_accumulate(x, h, nn)
+    t0 = time.perf_counter()
+    qo, so, _ = O.gptq(w[:, :strip].cpu().numpy(), h.cpu().numpy(), "int4", "group", 128, False, False, 1.0, 128, 0.01, False, False,
+                       mode="corrected")
+    dt = time.perf_counter() - t0
+    diff = np.abs(q[:, :strip].cpu().numpy().astype(np.int32) - qo.astype(np.int32))
+    first = np.where(diff.any(axis=0), diff[np.argmax(diff != 0, axis=0), np.arange(strip)], 0)     # the first difference of each column
+    rel = np.abs(scale.reshape(n, k // 128)[:strip].cpu().numpy() - so.reshape(strip, k // 128)) / so.reshape(strip, k // 128)
+    rec = {"columns": strip, "oracle_seconds": round(dt, 2), "integers_differ": round(float(np.mean(diff != 0)), 5),
+           "differ_by_more_than_one": round(float(np.mean(diff > 1)), 6), "max_level_diff": int(diff.max()),
+           "first_difference_of_a_column_max": int(first.max()), "scales_off_by_more_than_5e-3": round(float(np.mean(rel > 5e-3)), 5)}
+    rec["ok"] = bool(rec["integers_differ"] < 0.02 and rec["first_difference_of_a_column_max"] <= 1)
+    del h
+    return rec
+
+
 def _sha16(a) -> str:
     import numpy as np
 
@@ -138,12 +187,21 @@ def run(args, dev, rank: int, world: int):
         torch.cuda.synchronize()
 
     # ---- synthetic calibration activations, one set per input width (outside the timed region)
+    # CORRELATED rows: a rank-64 mix on top of per-channel noise (the recipe of tests/test_gptq_gpu.py::_corr_inputs).  Rounds 1-3
+    # used independent channels (randn x per-channel scale): H was almost diagonal, the error feedback of the corrected loop had
+    # nothing to do and its bench verification (error below RTN's) passed at a ratio of 0.99 -- a nearly-no-op loop would have
+    # passed too.  The Hessian / factor / loop kernels do the same work on either input.
     acts = {}
     for k in sorted({specs[i].k for i in my}):
         gen = torch.Generator(device=dev).manual_seed(1234 + k)
-        chan = 0.1 + 3.9 * torch.rand(k, generator=gen, device=dev)
-        acts[k] = [torch.randn((min(args.batch_seqs, n_seqs - b), args.seq, k), generator=gen, device=dev) * chan
-                   for b in range(0, n_seqs, args.batch_seqs)]
+        mix = torch.randn((64, k), generator=gen, device=dev)
+        acts[k] = []
+        for b in range(0, n_seqs, args.batch_seqs):
+            rows = min(args.batch_seqs, n_seqs - b) * args.seq
+            xb = torch.randn((rows, 64), generator=gen, device=dev) @ mix        # data synthesis, outside every timed region
+            xb.add_(torch.randn((rows, k), generator=gen, device=dev), alpha=0.5)
+            acts[k].append(xb.reshape(-1, args.seq, k))
+        del mix
     # weights: a few distinct random matrices per shape, reused round robin (generation is not part of the path either)
     wpool = {}
     for i in my:
@@ -199,8 +257,10 @@ def run(args, dev, rank: int, world: int):
                 w = wpool[(sp.k, sp.n)][(i + j) % 3]
                 e4, e5 = ev(), ev()
                 e4.record()
-                q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128, mode=mode, shared=shared)
-                results[i] = (ops.pack_nibbles(q), s, z)               # 0.5 B / param on the wire
+                # the loop kernels write core/_pack.py:8-22's [K, N/2] serialisation themselves (OQ_LAYOUT_KN_PACKED4): 0.5 B / param
+                # on the wire without the separate packing launch of rounds 1-3
+                q, s, z, info = ops.gptq_quantize(w, h, "int4", "group", 128, mode=mode, shared=shared, layout="kn_packed4")
+                results[i] = (q.reshape(-1), s, z)
                 if (sp.k, sp.n) not in samples:                         # first layer of every shape: verified after the clock stops
                     samples[(sp.k, sp.n)] = (i, w, q if mode == "corrected" else None)
                 e5.record()
@@ -239,7 +299,7 @@ def run(args, dev, rank: int, world: int):
             # receives now, a rank sends a wave's (packed int4, scales, zero points) as soon as they exist
             bundles = wave_bundles(specs, plan, per_wave)
             g128 = lambda sp: sp.n * sp.k // 128  # noqa: E731
-            if not warm:
+            if not warm and args.gather == "streamed":
                 streamer = StreamedGather(specs, bundles, lambda sp: [(torch.uint8, (sp.k * sp.n // 2,)), (torch.float32, (g128(sp), 1)),
                                                                        (torch.int8, (g128(sp), 1))], device=dev)
             for w0 in range(0, per_wave if warm else len(groups), per_wave):
@@ -297,7 +357,8 @@ def run(args, dev, rank: int, world: int):
                         # the wave's kernels must have produced the bytes before the communicator's stream reads them
                         torch.cuda.current_stream().synchronize()
                     b = w0 // per_wave
-                    streamer.push(b, {i: results[i] for i in bundles[rank][b]})
+                    if streamer is not None:
+                        streamer.push(b, {i: results[i] for i in bundles[rank][b]})
         torch.cuda.synchronize()
         t_quant = time.perf_counter() - t0
         if warm:
@@ -319,7 +380,19 @@ def run(args, dev, rank: int, world: int):
                 "samples": samples, "gathered": gathered, "nbytes": nbytes, "one_stream": one_stream, "n_streams": len(q_streams),
                 "pipelined": pipe is not None}
 
-    connect_to_rank0(dev)            # N > 1: the point-to-point connections of the streamed gather exist before the clock starts
+    # ---- N > 1, BEFORE the clock: everybody is here (bounded wait in the key-value store, the error names the missing ranks), the
+    # ranks agree on --gpus, and -- for the streamed gather -- the point-to-point connections exist.  A first run on a real
+    # multi-GPU node must end in an N-rank line or a readable failure, never in a silent wait for the communicator's watchdog.
+    if world > 1:
+        from onnx_quantize_amd.sharding import await_all_ranks
+
+        await_all_ranks("oq/bench_gptq", timeout_s=args.rendezvous_timeout)
+        seen = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(seen)
+        if int(seen.item()) != args.gpus or world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but {int(seen.item())} ranks joined (world size {world})")
+        if args.gather == "streamed":
+            connect_to_rank0(dev, timeout_s=args.rendezvous_timeout)
     model_pass(args.mode, warm=True)
     first = model_pass(args.mode)
     n_gathered = len(first["gathered"]) if first["gathered"] is not None else -1
@@ -420,8 +493,8 @@ def run(args, dev, rank: int, world: int):
             fp32_equiv = 2.0 * t_rows * (tiles * (tiles + 1) // 2) * edge * edge          # upper tiles, as executed
             terms = {"bf16x9": 9, "bf16x6": 6}.get(method, 3)           # "auto" is the fp16-piece kernel for K >= 1024
             roof = {"bound": "mfma", "method": method,
-                    "kernel": (("oq::syrk_f16_m16_kernel" if terms == 3 and os.environ.get("OQ_SYRK_F16_M16", "1") != "0"
-                                else "oq::syrk_pieces_kernel<%d>" % terms) + " (+ split / reduce)") if split else "oq::gemm_tn_kernel",
+                    "kernel": (("oq::syrk_f16_m16_kernel" if terms == 3 else "oq::syrk_pieces_kernel<%d>" % terms) + " (+ split / reduce)")
+                              if split else "oq::gemm_tn_kernel",
                     "achieved": round(fp32_equiv * (terms if split else 1) / ms / 1e9, 1), "peak": 2500.0 if split else 157.3,
                     "unit": "TFLOP/s",
                     "dtype": ("%s pieces of fp32 operands, fp32 accumulate" % ("fp16" if terms == 3 else "bf16")) if split else "f32",
@@ -456,9 +529,10 @@ def run(args, dev, rank: int, world: int):
         # below RTN's on the same weight (what tests/test_gptq_gpu.py::test_gptq_corrected_mode_vs_oracle asserts on a
         # small layer); X = 4096 calibration rows of the layer's own input, float64 products (checker, outside the clock)
         shapes_c, ok_c = [], True
-        for (k, n), (i, w, q) in sorted(cp["samples"].items()):
+        for (k, n), (i, w, qpk) in sorted(cp["samples"].items()):
             x = acts[k][0].reshape(-1, k)[:4096].double()
             _, sc, zc = cp["results"][i]
+            q = _unpack_int4(qpk, k, n)                                      # the loop kernels wrote [K, N/2] nibble pairs
             dq = ops.dequantize(q, sc.reshape(-1), zc.reshape(-1), "int4", mode="group", group=128)
             rq, rs, rz = ops.rtn_quantize(w, "int4", "group", 128)
             dr = ops.dequantize(rq, rs.reshape(-1), rz.reshape(-1), "int4", mode="group", group=128)
@@ -468,13 +542,21 @@ def run(args, dev, rank: int, world: int):
             changed = float((q != rq).float().mean())
             shapes_c.append({"k": k, "n": n, "layer": specs[i].name, "output_err_gptq": e_g, "output_err_rtn": e_r,
                              "ratio": round(e_g / e_r, 4), "integers_changed_vs_rtn": round(changed, 4)})
-            ok_c = ok_c and e_g < e_r and changed > 0.0
+            # on correlated rows the corrected loop takes 20-40 % off RTN's output error (the GPU test asserts < 0.8 at this
+            # size); 0.9 leaves room for the widest input and still fails a loop that merely rounds
+            ok_c = ok_c and e_g <= CORRECTED_RATIO_BAR * e_r and changed > 0.0
+            if rank == 0 and (k, n) == (args.hidden, args.hidden) and not args.no_cpu_baseline:
+                shapes_c[-1]["oracle_strip"] = corrected_strip_check(ops, w, q, sc, acts[k], k, n)
+                ok_c = ok_c and shapes_c[-1]["oracle_strip"]["ok"]
             del x, dq, dr, ref
         flag_c = torch.tensor([1 if ok_c else 0], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(flag_c, op=dist.ReduceOp.MIN)
         corrected = {"mode": "corrected", "what": "same model, GPTQConfig(mode='corrected'): the error-correcting block / row loop "
-                     "(gptq.py:153-208 with the upper factor's rows, the update GPTQ intends) + lazy batch updates on the fp32 MFMA GEMM",
+                     "(gptq.py:153-208 with the upper factor's rows, the update GPTQ intends) + lazy batch updates of 512-row super-blocks on "
+                     "the fp16-piece GEMM (22-bit operands, fp32 accumulate; fp32 MFMA kernel when the f32 method is selected); verified by "
+                     f"layer-output error <= {CORRECTED_RATIO_BAR} x RTN's on correlated calibration rows and by the oracle's corrected mode on a "
+                     "512-column strip",
                      "value": round(n_params / cw / 1e6, 2), "unit": "M-param/s",
                      "seconds": {"wall": round(cw, 3), "hessian_ms_max_rank": round(ch, 1), "factor_ms_max_rank": round(cf, 1),
                                  "loop_ms_max_rank": round(cl, 1)},
@@ -525,7 +607,8 @@ def run(args, dev, rank: int, world: int):
                     "factor_ms_max_rank": round(float(stats[4]), 1), "loop_ms_max_rank": round(float(stats[5]), 1)},
         "gather_bytes": nbytes,
         "gather_how": "sharding.StreamedGather: isend per wave of layers to rank 0 while the next wave computes; seconds.gather = the tail "
-                      "behind the last kernel" if args.factor_wave > 0 else "sharding.gather_device_results: one padded gather at the end",
+                      "behind the last kernel" if (args.factor_wave > 0 and args.gather == "streamed")
+                      else "sharding.gather_device_results: one padded gather at the end (--gather padded)",
         "hessian_flops_executed": flops_exec,
         "hessian_check_vs_float64": hcheck,
         "verified": verify["verified"], "verification": verify,

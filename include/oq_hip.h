@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OQ_ABI_VERSION 1
+#define OQ_ABI_VERSION 2   /* 2: the Hessian method is an argument of every call that uses it (no process-wide setter); q_layout in oq_gptq_loop_f32 */
 
 typedef enum {
     OQ_OK = 0,
@@ -47,13 +47,21 @@ typedef enum { OQ_INT4 = 0, OQ_UINT4 = 1, OQ_INT8 = 2, OQ_UINT8 = 3, OQ_INT32 = 
 typedef enum { OQ_TENSOR = 0, OQ_CHANNEL = 1, OQ_GROUP = 2 } oq_strategy;
 /* layout of the integer output of oq_rtn_quantize_f32 */
 typedef enum {
-    OQ_LAYOUT_KN = 0,    /* [K, N], one value per byte: what _rtn_quantize returns (rtn.py:106-109)     */
-    OQ_LAYOUT_NBITS = 1  /* MatMulNBits blob [N, K/g, g*bits/8] (qrules/_common.py:65-87), 4/8-bit group */
+    OQ_LAYOUT_KN = 0,         /* [K, N], one value per byte: what _rtn_quantize returns (rtn.py:106-109)     */
+    OQ_LAYOUT_NBITS = 1,      /* MatMulNBits blob [N, K/g, g*bits/8] (qrules/_common.py:65-87), 4/8-bit group */
+    OQ_LAYOUT_KN_PACKED4 = 2  /* [K, N/2] bytes: core/_pack.py:8-22 applied to the [K, N] result of a 4-bit type (flat
+                                 order, even index in the low nibble, signed values as two's-complement nibbles) -- what
+                                 the reference serialises for int4 / uint4 initializers; written by the kernel epilogue.
+                                 4-bit types, group strategy with K % g == 0 and g <= 256, N % 4 == 0 (else
+                                 OQ_ERR_UNSUPPORTED) */
 } oq_layout;
 /* error-feedback indexing of the GPTQ loop */
 typedef enum {
-    OQ_GPTQ_PARITY = 0,   /* gptq.py:199,:208 as written: column of the UPPER factor below the diagonal (zeros) */
-    OQ_GPTQ_CORRECTED = 1 /* row of the upper factor right of the diagonal (what GPTQ intends); opt-in          */
+    OQ_GPTQ_PARITY = 0,            /* gptq.py:199,:208 as written: column of the UPPER factor below the diagonal (zeros) */
+    OQ_GPTQ_CORRECTED = 1,         /* row of the upper factor right of the diagonal (what GPTQ intends); opt-in          */
+    OQ_GPTQ_CORRECTED_COLUMNS = 2  /* the same bytes as 1 from the one-column-per-lane kernel (the fallback of 1 for group
+                                      sizes that are not a multiple of 16); selectable so that the two kernels can be held
+                                      against each other without an environment switch                                  */
 } oq_gptq_mode;
 
 int32_t oq_abi_version(void);
@@ -73,7 +81,7 @@ int32_t oq_qrange(int32_t qtype, int32_t symmetric, int32_t reduce_range, int64_
  *   group_size GROUP only: > 0 (clamped to K), or -1 (= K).  K % group_size must be 0 (the reference's
  *              product path guarantees it, qrules/_common.py:13-29) or N*K % group_size == 0 (groups
  *              then straddle columns exactly like W.T.reshape(-1, g)).
- *   q_out      OQ_LAYOUT_KN: K*N bytes.  OQ_LAYOUT_NBITS: N*(K/g)*(g*bits/8) bytes (group strategy, 4/8-bit types,
+ *   q_out      OQ_LAYOUT_KN: K*N bytes.  OQ_LAYOUT_KN_PACKED4: K*N/2 bytes (4-byte aligned).  OQ_LAYOUT_NBITS: N*(K/g)*(g*bits/8) bytes (group strategy, 4/8-bit types,
  *              K % g == 0, g % 16 == 0, 16-byte aligned; g <= 256 in the fused kernels, larger g -- group_size -1
  *              = the whole column is MatMulNBits-eligible, qrules/_common.py:32-62 -- needs g % 128 == 0 and
  *              N % 4 == 0; anything else is OQ_ERR_UNSUPPORTED, never a silent fallback).  Signed types are
@@ -227,7 +235,8 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *     number of samples, not T.  workspace (oq_hessian_workspace_bytes; optional for OQ_HESSIAN_F32, where
  *     it may be NULL): the bf16 operand pieces of the split methods (6 B per element of X) and partial-sum
  *     slabs that let the T dimension be split over more workgroups (deterministic two-stage sum).
- *     Method (process-wide, oq_hessian_set_method; environment OQ_HESSIAN_METHOD = 0..4 sets the initial value):
+ *     `method` (an argument of every entry point that multiplies on the matrix cores -- there is no process-wide setting and
+ *     the library reads no environment variable for it, so two threads may use different methods):
  *       OQ_HESSIAN_F32     v_mfma_f32_32x32x2_f32 on the operands scaled by sqrt(2/n) as gptq.py:257 does;
  *       OQ_HESSIAN_BF16X6  every fp32 element split EXACTLY into three bf16 pieces (x = hi + mid + lo), the six piece
  *                          products down to 2^-16 |x y| on v_mfma_f32_32x32x16_bf16, fp32 accumulation; what is left
@@ -245,12 +254,10 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
  *     The reference's own H goes through sgemm in BLAS order: parity is to a tolerance for every method.
  * ------------------------------------------------------------------------------------------- */
 enum { OQ_HESSIAN_AUTO = 0, OQ_HESSIAN_F32 = 1, OQ_HESSIAN_BF16X6 = 2, OQ_HESSIAN_BF16X9 = 3, OQ_HESSIAN_F16X3 = 4 };
-int32_t oq_hessian_set_method(int32_t method);
-int32_t oq_hessian_method(void);
 size_t oq_hessian_workspace_bytes(int64_t T, int64_t K);
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen,
-                                  int64_t n_add, float* H, void* workspace, size_t workspace_bytes,
-                                  void* stream);
+                                  int64_t n_add, float* H, int32_t method, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* G1 for a LIST of inputs in one launch chain (core/_calibration/calibrate.py:292-305 walks the GPTQ nodes and hands
  *     `_accumulate_hessian`, gptq.py:246-260, one input each; a calibration batch of gemma-3-270m taps 72 of them, 5120 rows
@@ -259,7 +266,7 @@ int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t 
  *     run the fp16-piece method (OQ_HESSIAN_F16X3 above) whatever their size, each with a scale of its own, the product
  *     writing H directly: the same <= 1e-5 max |H| bound; NOT bit-identical to the per-tensor call, which may slice T or
  *     pick the fp32 kernel for small K; an item's rows are summed in ONE fp32 chain, so very long items (beyond ~32 768 rows)
- *     are better served by the per-tensor call.  OQ_ERR_UNSUPPORTED when oq_hessian_set_method selected another method.
+ *     are better served by the per-tensor call.  A caller that wants another method calls oq_hessian_accumulate_f32 per item.
  *     `items_host` / `items_device`: the same `count` items in host and in device memory (the host copy sizes the
  *     launches, the kernels read the device copy).  Workspace: oq_hessian_many_workspace_bytes(items_host, count) =
  *     the fp16 pieces of all items (4 B per element of the zero-padded inputs) + a table. */
@@ -305,10 +312,10 @@ int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t ac
  *     Arithmetic: fp32 throughout, except that the large products (trailing updates of 512-row panels on squares of
  *     >= 1024 columns, inverse levels of >= 2048-row blocks) take their operands as two fp16 pieces (22 bits, fp32
  *     accumulate) like the Hessian's OQ_HESSIAN_F16X3 -- measured no less accurate against float64 than fp32 products
- *      --; oq_hessian_set_method(OQ_HESSIAN_F32) keeps them on the fp32 kernel as well. */
+ *      --; method = OQ_HESSIAN_F32 keeps them on the fp32 kernel as well (any other value: fp16 pieces). */
 size_t oq_gptq_factor_workspace_bytes(int64_t K);
 int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           int32_t method, void* workspace, size_t workspace_bytes, void* stream);
 /*     The same for `count` matrices of one width in lock-step (the inputs of a model that share K: the reference
  *     factors each node's H by itself, gptq.py:134-150 once per `_gptq` call).  Matrix i is H + i * h_stride, its
  *     factor U_out + i * u_stride (strides in floats, >= K * K), its status info[i].  The chain of a factorisation is
@@ -320,7 +327,7 @@ int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_o
 size_t oq_gptq_factor_batched_workspace_bytes(int64_t K, int64_t count);
 int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, int64_t count, float percdamp,
                                    int32_t fix_dead, float* U_out, int64_t u_stride, int32_t* info,
-                                   void* workspace, size_t workspace_bytes, void* stream);
+                                   int32_t method, void* workspace, size_t workspace_bytes, void* stream);
 
 /* G3  gptq.py:153-216: the block / row loop.  W [K, N] is the working copy (after oq_gptq_prepare_f32); it
  *     receives the lazy batch updates of gptq.py:208 (OQ_GPTQ_CORRECTED only: in OQ_GPTQ_PARITY the update term
@@ -333,7 +340,10 @@ int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, 
  *                 parameters are read from W as it stood when the block began -- the reference's semantics.  OQ_GPTQ_CORRECTED
  *                 with block_size <= 128 additionally defers the update of everything behind a SUPER-block of up to 512 rows
  *                 (a multiple of block_size and group_size) to one product with Kd = 512: the same sums, grouped differently.
- *     Outputs: q_int_out [K, N] one value per byte; q_deq_out [K, N] fp32 (the dequantized rows the final qparams
+ *     method: OQ_HESSIAN_F32 keeps the deferred updates on the fp32 MFMA kernel, any other value runs the large ones on
+ *                 the fp16-piece GEMM (22-bit operands, fp32 accumulate).
+ *     Outputs: q_int_out [K, N] one value per byte (q_layout = OQ_LAYOUT_KN) or [K, N/2] nibble pairs in core/_pack.py:8-22
+ *     order (OQ_LAYOUT_KN_PACKED4: 4-bit types, N even; written by the loop kernels themselves); q_deq_out [K, N] fp32 (the dequantized rows the final qparams
  *     are re-derived from, gptq.py:219-231); used_scale/used_zp [ceil(K/group_size), N] = the parameters actually
  *     applied per (k-group, column) (NULL to skip; only written when group_size > 0).
  *     mse != 0 with group_size > 0: the per-group parameters come from the MSE search (utils.py:140-239, channel strategy
@@ -342,9 +352,10 @@ int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, 
 size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size);
 int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size,
                          int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
-                         int64_t block_size, int32_t mode, const float* init_scale, const int32_t* init_zp,
-                         int64_t init_count, void* q_int_out, float* q_deq_out, float* used_scale,
-                         int32_t* used_zp, void* workspace, size_t workspace_bytes, void* stream);
+                         int64_t block_size, int32_t mode, int32_t method, const float* init_scale,
+                         const int32_t* init_zp, int64_t init_count, void* q_int_out, int32_t q_layout,
+                         float* q_deq_out, float* used_scale, int32_t* used_zp, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* N2  core/_algorithms/hqq.py:106-213 (`_optimize_zero_point` + the final quantize of `_hqq_quantize`): uint4,
  *     asymmetric, group strategy, float zero points.  W [K, N] fp32; scale / zero_point_in / zero_point_out
@@ -354,12 +365,17 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
  *     OQ_LAYOUT_NBITS the MatMulNBits blob [N, K/g, g/2] HQQ is meant for (qrules/_common.py:65-87; float zero
  *     points stay unpacked [N, K/g], :96-99); NULL: zero points only.  rounds_out (device int32, may be NULL) receives the number of rounds evaluated before the
  *     early stop.  Every round, the mean-error reduction and the best / early-stop decision run on the
- *     device; nothing synchronises with the host.  K % group_size != 0 is OQ_ERR_UNSUPPORTED. */
+ *     device; nothing synchronises with the host.  K % group_size != 0 is OQ_ERR_UNSUPPORTED.
+ *     Route: group sizes 16 / 32 / 64 / 128 with 1 .. 32 rounds walk ALL rounds of a row out of registers in one pass over
+ *     W (a row's zero-point trajectory depends on the global error only through WHICH round is kept, hqq.py:131-140) and
+ *     replay the decisions afterwards: 3 launches; anything else, or per_round_launches != 0, runs one launch pair per round
+ *     (W re-read every round).  The two routes give the same bits. */
 size_t oq_hqq_workspace_bytes(int64_t K, int64_t N, int64_t group_size);
 int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int64_t group_size,
                             int32_t reduce_range, const float* scale, const float* zero_point_in,
                             double lp_norm, double beta, double kappa, int32_t iters, int32_t early_stop,
-                            void* q_out, int32_t layout, float* zero_point_out, int32_t* rounds_out,
+                            int32_t per_round_launches, void* q_out, int32_t layout, float* zero_point_out,
+                            int32_t* rounds_out,
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* N2  pre_passes/awq.py:47-72, 114-184: AWQ's scale search for one layer, device resident.  X [T, K] calibration rows

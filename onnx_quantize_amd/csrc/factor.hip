@@ -359,7 +359,9 @@ size_t oq_gptq_factor_workspace_bytes(int64_t K) { return oq_gptq_factor_batched
 // square, the levels of the inverse) carries all of them -- blockIdx of the small kernels, the outer batch of the TN
 // GEMM -- so a batch costs the LATENCY of one chain (nb sequential diagonal blocks) and the GEMM work of `count`.
 static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64_t count, float percdamp, float* U_out, int64_t u_stride,
-                              int32_t* info, int32_t fix_dead, void* workspace, size_t workspace_bytes, hipStream_t s, const char* who) {
+                              int32_t* info, int32_t fix_dead, int32_t method, void* workspace, size_t workspace_bytes, hipStream_t s,
+                              const char* who) {
+    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "%s: unknown method %d", who, method);
     OQ_REQUIRE(H && U_out && info && K > 0 && count > 0 && count <= 65535, OQ_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
     OQ_REQUIRE(count == 1 || (h_stride >= K * K && u_stride >= K * K), OQ_ERR_INVALID_ARGUMENT, "%s: matrices of the batch overlap", who);
     const size_t need = oq_gptq_factor_batched_workspace_bytes(K, count);
@@ -401,7 +403,7 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
     constexpr int64_t kOuter = 4 * kNB;
     constexpr int64_t kPieceUpdateMin = 1024;      // trailing squares narrower than this stay on the fp32 kernel
     // OQ_HESSIAN_F32 keeps the whole GPTQ path on fp32 operands (the reference's arithmetic class); the X region must hold the pieces
-    const bool pieces_ok = oq_hessian_method() != OQ_HESSIAN_F32 &&
+    const bool pieces_ok = method != OQ_HESSIAN_F32 &&
                            syrk_f16x3_factor_update_bytes(K, kOuter, count) <= static_cast<size_t>(count) * kk;
     for (int64_t O = 0; O < K; O += kOuter) {
         const int64_t pend = O + kOuter < K ? O + kOuter : K;
@@ -511,14 +513,15 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
     return check_launch("finish_factor_kernel");
 }
 
-int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info, void* workspace,
+int32_t oq_gptq_factor_f32(const float* H, int64_t K, float percdamp, float* U_out, int32_t* info, int32_t method, void* workspace,
                            size_t workspace_bytes, void* stream) {
-    return factor_batched(H, K, 0, 1, percdamp, U_out, 0, info, 0, workspace, workspace_bytes, as_stream(stream), "oq_gptq_factor_f32");
+    return factor_batched(H, K, 0, 1, percdamp, U_out, 0, info, 0, method, workspace, workspace_bytes, as_stream(stream), "oq_gptq_factor_f32");
 }
 
 int32_t oq_gptq_factor_batched_f32(const float* H, int64_t K, int64_t h_stride, int64_t count, float percdamp, int32_t fix_dead,
-                                   float* U_out, int64_t u_stride, int32_t* info, void* workspace, size_t workspace_bytes, void* stream) {
-    return factor_batched(H, K, h_stride, count, percdamp, U_out, u_stride, info, fix_dead, workspace, workspace_bytes, as_stream(stream),
+                                   float* U_out, int64_t u_stride, int32_t* info, int32_t method, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    return factor_batched(H, K, h_stride, count, percdamp, U_out, u_stride, info, fix_dead, method, workspace, workspace_bytes, as_stream(stream),
                           "oq_gptq_factor_batched_f32");
 }
 

@@ -377,33 +377,16 @@ size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) {
     return (f32 > split ? f32 : split) + 512;
 }
 
-static int32_t g_hessian_method = -1;   // -1: not set yet (environment OQ_HESSIAN_METHOD, else OQ_HESSIAN_AUTO)
-
-int32_t oq_hessian_set_method(int32_t method) {
-    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_set_method: unknown method %d", method);
-    g_hessian_method = method;
-    return OQ_OK;
-}
-
-int32_t oq_hessian_method(void) {
-    if (g_hessian_method < 0) {
-        const char* e = std::getenv("OQ_HESSIAN_METHOD");
-        const int v = e ? std::atoi(e) : OQ_HESSIAN_AUTO;
-        g_hessian_method = (v >= OQ_HESSIAN_AUTO && v <= OQ_HESSIAN_F16X3) ? v : OQ_HESSIAN_AUTO;
-    }
-    return g_hessian_method;
-}
-
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen, int64_t n_add, float* H,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  int32_t method, void* workspace, size_t workspace_bytes, void* stream) {
     OQ_REQUIRE(X && H && T > 0 && K > 0 && ldx >= K, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: bad argument");
+    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: unknown method %d", method);
     OQ_REQUIRE(n_seen >= 0 && n_add > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: bad sample counts %lld + %lld",
                (long long)n_seen, (long long)n_add);
     const int64_t n_total = n_seen + n_add;
     // gptq.py:254  H *= num_samples / (num_samples + num_added): a Python float applied to an fp32 array.
     // The first call of the reference starts from zeros (gptq.py:304): beta = 0, nothing is read.
     const float beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));
-    int32_t method = oq_hessian_method();
     // auto: the split-operand kernels where their 256-wide tiles are worth it and the caller's workspace holds the
     // pieces; small problems stay on the fp32 MFMA
     if (method == OQ_HESSIAN_AUTO)
@@ -430,9 +413,6 @@ size_t oq_hessian_many_workspace_bytes(const oq_hessian_item* items_host, int64_
 int32_t oq_hessian_accumulate_many_f32(const oq_hessian_item* items_host, const oq_hessian_item* items_device, int64_t count, void* workspace,
                                        size_t workspace_bytes, void* stream) {
     static_assert(sizeof(oq_hessian_item) == 64, "eight 8-byte fields");
-    const int32_t method = oq_hessian_method();
-    OQ_REQUIRE(method == OQ_HESSIAN_AUTO || method == OQ_HESSIAN_F16X3, OQ_ERR_UNSUPPORTED,
-               "oq_hessian_accumulate_many_f32 runs the fp16-piece method only (method %d is set: use oq_hessian_accumulate_f32 per tensor)", method);
     return launch_syrk_f16x3_many(reinterpret_cast<const int64_t*>(items_host), reinterpret_cast<const int64_t*>(items_device), count, workspace,
                                   workspace_bytes, as_stream(stream));
 }

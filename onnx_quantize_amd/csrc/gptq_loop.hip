@@ -46,8 +46,23 @@ struct LoopArgs {
     const float* pre_scale;   // mse: [groups starting in this block][N] parameters found by the MSE search, else null
     const uint8_t* pre_zp;
     int32_t zp_signed;
+    int32_t packed4;          // OQ_LAYOUT_KN_PACKED4: q_int is [K, N/2], two columns per byte (core/_pack.py:8-22 order)
     int64_t pre_first_group;  // index (row / g) of the first group that starts in this block
 };
+
+// The integer of (row, column c): one byte of [K, N], or its nibble of byte (row * N + c) / 2 -- the even column's lane takes its
+// right-hand neighbour's level (XOR = lane distance between neighbouring columns: 1, or 16 where a column is a DPP row) and
+// stores both.  N is even (checked by the host), so a pair is in or out together; the low nibble of the two's-complement byte IS
+// the two's-complement nibble.  Every lane of the pair must reach this call.
+template <int XOR>
+__device__ __forceinline__ void store_level(const LoopArgs& a, int64_t row, int64_t c, bool live, uint32_t level) {
+    if (!a.packed4) {
+        if (live) a.q_int[row * a.N + c] = static_cast<uint8_t>(level);
+        return;
+    }
+    const uint32_t partner = static_cast<uint32_t>(__shfl_xor(static_cast<int>(level), XOR, 64));
+    if (live && (c & 1) == 0) a.q_int[(row * a.N + c) >> 1] = static_cast<uint8_t>((level & 0xfu) | ((partner & 0xfu) << 4));
+}
 
 // One workgroup = 64 columns x one block of <= 128 rows, 4 waves.  The block is walked in sub-blocks of 32 rows:
 //   * wave 0 holds the sub-block's rows of its 64 columns in REGISTERS (one column per lane) and runs the 32
@@ -192,8 +207,8 @@ __global__ __launch_bounds__(256) void gptq_block_kernel(const LoopArgs a) {
                     const int32_t qi = quantize_one(w[i], scale, zp, qmin, qmax);   // gptq.py:186-188
                     const float q = dequantize_one(qi, scale, zp);                    // :189
                     const float e = (w[i] - q) / coef[i][s0 + i];                     // :164, :197
+                    store_level<1>(a, row, c, live, static_cast<uint32_t>(qi));
                     if (live) {
-                        a.q_int[row * a.N + c] = static_cast<uint8_t>(qi);
                         a.q_deq[row * a.N + c] = q;
                         a.err[(a.err_row0 + s0 + i) * a.N + c] = e;
                     }
@@ -543,10 +558,10 @@ __global__ __launch_bounds__(1024) void gptq_rows16_kernel(const LoopArgs a) {
                 default: slab16<7, false>(w2, in, save_e, save_cl); break;
             }
         }
+        store_level<16>(a, row0 + r16, c, live && r16 < in.rows, __float_as_uint(save_cl) & 0xffu);   // lanes 16 apart: columns c, c + 1, same row
         if (live && r16 < in.rows) {
             const int64_t row = row0 + r16;
             a.err[(a.err_row0 + 16 * k0 + r16) * a.N + c] = save_e;
-            a.q_int[row * a.N + c] = static_cast<uint8_t>(__float_as_uint(save_cl) & 0xffu);
             a.q_deq[row * a.N + c] = (save_cl - in.cs.zm) * in.cs.scale;
         }
         OQ_STAMP(4 + k0);
@@ -685,12 +700,11 @@ __global__ __launch_bounds__(256) void gptq_parity_kernel(const LoopArgs a, int6
         scale = a.init_scale[pi];
         zp = a.init_zp[pi];
     }
-    if (!live) return;
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
-    for (int64_t r = r0; r < r1; ++r) {
-        const int32_t qi = quantize_one(a.W[r * a.N + c], scale, zp, qmin, qmax);   // gptq.py:186-188
-        a.q_int[r * a.N + c] = static_cast<uint8_t>(qi);
-        a.q_deq[r * a.N + c] = dequantize_one(qi, scale, zp);                       // :189
+    for (int64_t r = r0; r < r1; ++r) {   // lanes past N walk along on a clamped column (the packed layout pairs neighbouring lanes)
+        const int32_t qi = quantize_one(a.W[r * a.N + cc], scale, zp, qmin, qmax);  // gptq.py:186-188
+        store_level<1>(a, r, c, live, static_cast<uint32_t>(qi));
+        if (live) a.q_deq[r * a.N + c] = dequantize_one(qi, scale, zp);             // :189
     }
 }
 
@@ -735,15 +749,22 @@ size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size) {
 }
 
 int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t qtype, int64_t group_size, int32_t symmetric,
-                         int32_t reduce_range, float clip_ratio, int32_t mse, int64_t block_size, int32_t mode,
-                         const float* init_scale, const int32_t* init_zp, int64_t init_count, void* q_int_out,
+                         int32_t reduce_range, float clip_ratio, int32_t mse, int64_t block_size, int32_t mode, int32_t method,
+                         const float* init_scale, const int32_t* init_zp, int64_t init_count, void* q_int_out, int32_t q_layout,
                          float* q_deq_out, float* used_scale, int32_t* used_zp, void* workspace, size_t workspace_bytes,
                          void* stream) {
     OQ_REQUIRE(W && U && init_scale && init_zp && q_int_out && q_deq_out && K > 0 && N > 0, OQ_ERR_INVALID_ARGUMENT,
                "oq_gptq_loop_f32: bad argument");
     OQ_REQUIRE(init_count == 1 || init_count == N, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: init_count must be 1 or N");
     OQ_REQUIRE(block_size > 0, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: block_size must be positive");
-    OQ_REQUIRE(mode == OQ_GPTQ_PARITY || mode == OQ_GPTQ_CORRECTED, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: bad mode %d", mode);
+    OQ_REQUIRE(mode == OQ_GPTQ_PARITY || mode == OQ_GPTQ_CORRECTED || mode == OQ_GPTQ_CORRECTED_COLUMNS, OQ_ERR_INVALID_ARGUMENT,
+               "oq_gptq_loop_f32: bad mode %d", mode);
+    OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: unknown method %d", method);
+    OQ_REQUIRE(q_layout == OQ_LAYOUT_KN || q_layout == OQ_LAYOUT_KN_PACKED4, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: bad q_layout %d", q_layout);
+    OQ_REQUIRE(q_layout == OQ_LAYOUT_KN || ((qtype == OQ_INT4 || qtype == OQ_UINT4) && N % 2 == 0), OQ_ERR_UNSUPPORTED,
+               "oq_gptq_loop_f32: the packed layout takes a 4-bit type and an even N");
+    const bool columns_kernel = mode == OQ_GPTQ_CORRECTED_COLUMNS;      // same bytes as OQ_GPTQ_CORRECTED, the one-column-per-lane kernel
+    if (columns_kernel) mode = OQ_GPTQ_CORRECTED;
     OQ_REQUIRE(clip_ratio > 0.0f && clip_ratio <= 1.0f, OQ_ERR_INVALID_ARGUMENT, "clip_ratio must be in (0.0, 1.0], got %g", clip_ratio);
     QGrid grid;
     int32_t st = make_grid(qtype, symmetric, reduce_range, clip_ratio, &grid);
@@ -756,7 +777,7 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
     LoopArgs a;
     a.W = W; a.U = U; a.K = K; a.N = N; a.g = group_size > 0 ? group_size : 0; a.grid = grid; a.mode = mode;
     a.init_scale = init_scale; a.init_zp = init_zp; a.init_count = init_count;
-    a.q_int = static_cast<uint8_t*>(q_int_out); a.q_deq = q_deq_out;
+    a.q_int = static_cast<uint8_t*>(q_int_out); a.q_deq = q_deq_out; a.packed4 = q_layout == OQ_LAYOUT_KN_PACKED4 ? 1 : 0;
     a.used_scale = (group_size > 0) ? used_scale : nullptr;
     a.used_zp = used_zp;
     if (a.used_scale != nullptr && used_zp == nullptr) return fail(OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: used_zp missing");
@@ -816,8 +837,7 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
         }
         if (unit <= kSuperRows) S = kSuperRows / unit * unit;
     }
-    static const bool rows16_on = [] { const char* v = getenv("OQ_GPTQ_ROWS16"); return !(v && v[0] == '0'); }();   // 0: the one-column-per-lane kernel (same bytes)
-    const bool rows16 = rows16_on && mode == OQ_GPTQ_CORRECTED && (a.g <= 0 || a.g % 16 == 0) && sub % 16 == 0;
+    const bool rows16 = !columns_kernel && mode == OQ_GPTQ_CORRECTED && (a.g <= 0 || a.g % 16 == 0) && sub % 16 == 0;
     const uint32_t nblk = static_cast<uint32_t>(ceil_div(N, kLoopColsV2));
     // rows-over-lanes kernel: 4 columns per wave; as many waves per block as keep the grid within one block per CU
     int wpb16 = 4 * static_cast<int>(ceil_div(ceil_div(N, 16), 256));
@@ -893,7 +913,7 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
             // Large products run on the fp16-piece GEMM (22-bit operands, fp32 accumulate: the Hessian's arithmetic, 3-5 x
             // the fp32 MFMA rate); with OQ_HESSIAN_F32 selected -- the reference's arithmetic class throughout -- and for
             // small problems the fp32 MFMA kernel.
-            if (oq_hessian_method() != OQ_HESSIAN_F32 && g.Kd >= 64 && g.M * g.N >= (int64_t{1} << 20)) {
+            if (method != OQ_HESSIAN_F32 && g.Kd >= 64 && g.M * g.N >= (int64_t{1} << 20)) {
                 st = make_f16x2_pieces(g.At, g.Kd, g.M, g.lda, false, pieces_a, s);
                 if (st == OQ_OK) st = make_f16x2_pieces(g.B, g.Kd, g.N, g.ldb, false, pieces_b, s);
                 if (st == OQ_OK) st = launch_gemm_f16x3(pieces_a, pieces_b, g.M, g.N, g.Kd, g.alpha, g.beta, g.C, g.ldc, nullptr, s);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     // Q1 in registers (every wave of the group derives the same parameters).
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
     // bias: signed levels are produced as 0..255 (0..15 for packed nibbles) and flipped back with one XOR per word
-    const int32_t bias = qmin < 0 ? ((a.layout == OQ_LAYOUT_NBITS && a.grid.bits == 4) ? 8 : 128) : 0;
+    const int32_t bias = qmin < 0 ? (((a.layout == OQ_LAYOUT_NBITS || a.layout == OQ_LAYOUT_KN_PACKED4) && a.grid.bits == 4) ? 8 : 128) : 0;
     ColQ cq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -320,6 +320,45 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                     if (col_ok[i])
                         a.q[(row0 + r) * a.N + slot_col<false>(tile_col0, lane, i)] =
                             static_cast<uint8_t>((__builtin_amdgcn_cvt_pk_u8_f32(v[r][i], 0, 0) ^ flip) & 0xffu);
+        }
+    } else if (a.layout == OQ_LAYOUT_KN_PACKED4) {
+        // core/_pack.py:8-22 on the [K, N] result: flat order, even index in the low nibble -- with N even, byte j of row k
+        // holds columns 2j (low) and 2j + 1 (high); signed levels as two's-complement nibbles.  A lane's four columns of a
+        // row are two bytes.  VEC4 only (checked by the host).
+        const uint32_t flip = bias ? 0x88888888u : 0u;
+        uint32_t t[RPW];    // byte 0 = columns 0 | 1 << 4, byte 2 = columns 2 | 3 << 4 of row r
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][0], 0, 0);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][1], 1, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][2], 2, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][3], 3, w);
+            t[r] = (w | (w >> 4)) ^ flip;           // levels < 16: the high nibble of every byte of w is zero
+        }
+        uint8_t* o = a.q + (row0 * a.N + tile_col0 + lane * 4) / 2;
+        const int64_t row_bytes = a.N / 2;
+        if constexpr (RPW == 16) {
+            if ((a.N & 7) == 0) {
+                // Dword stores: lanes 2m and 2m + 1 hold neighbouring byte pairs of every row.  Row j and row j + 8 travel in one
+                // dword; after one quad-perm exchange the even lane stores rows 0-7 (its own pair below its partner's), the
+                // odd lane rows 8-15: eight 4-byte stores per lane, every instruction two rows x 128 contiguous bytes.
+                const bool odd = (lane & 1) != 0;
+                const bool pair_ok = tile_col0 + (lane & ~1) * 4 < a.N;     // N % 8 == 0: a lane pair is in or out together
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t mine = __builtin_amdgcn_perm(t[j + 8], t[j], 0x06040200u);   // [row j pair, row j + 8 pair]
+                    const uint32_t theirs = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine), 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
+                    const uint32_t out = odd ? ((theirs >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (theirs << 16));
+                    uint8_t* dst = a.q + ((row0 + j + (odd ? 8 : 0)) * a.N + tile_col0 + (lane & ~1) * 4) / 2;
+                    if (pair_ok) *reinterpret_cast<uint32_t*>(dst) = out;
+                }
+                return;
+            }
+        }
+        if (col_ok[0]) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+                *reinterpret_cast<uint16_t*>(o + r * row_bytes) = static_cast<uint16_t>(__builtin_amdgcn_perm(0u, t[r], 0x0c0c0200u));
         }
     } else {
         // MatMulNBits blob (qrules/_common.py:72-87): for out-channel n, k-group kg: g*bits/8 bytes,
@@ -1251,7 +1290,8 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     OQ_REQUIRE(K * N < (1LL << 40), OQ_ERR_UNSUPPORTED, "rtn: matrix too large");
     OQ_REQUIRE(clip_ratio > 0.0f && clip_ratio <= 1.0f, OQ_ERR_INVALID_ARGUMENT,
                "clip_ratio must be in (0.0, 1.0], got %g", clip_ratio);
-    OQ_REQUIRE(layout == OQ_LAYOUT_KN || layout == OQ_LAYOUT_NBITS, OQ_ERR_INVALID_ARGUMENT, "rtn: bad layout %d", layout);
+    OQ_REQUIRE(layout == OQ_LAYOUT_KN || layout == OQ_LAYOUT_NBITS || layout == OQ_LAYOUT_KN_PACKED4, OQ_ERR_INVALID_ARGUMENT,
+               "rtn: bad layout %d", layout);
     QGrid grid;
     int32_t st = make_grid(qtype, symmetric, reduce_range, clip_ratio, &grid);
     if (st != OQ_OK) return st;
@@ -1263,6 +1303,15 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     uint8_t* q8 = static_cast<uint8_t*>(q_out);
     uint8_t* zp8 = static_cast<uint8_t*>(zp_out);
 
+    if (layout == OQ_LAYOUT_KN_PACKED4) {
+        // two columns per byte, written by the fused group kernel's epilogue; everything else is refused loudly, never routed
+        // through an unpacked result + a second launch
+        int rpw_p = 0, wpg_p = 0;
+        OQ_REQUIRE(emit_q && grid.bits == 4 && strategy == OQ_GROUP && K % g == 0 && fused_shape(g, &rpw_p, &wpg_p) && !mse, OQ_ERR_UNSUPPORTED,
+                   "KN_PACKED4 layout needs a 4-bit type, the group strategy with K %% group_size == 0 and group_size <= 256, no mse");
+        OQ_REQUIRE(N % 4 == 0 && ldw % 4 == 0 && aligned16(W) && (reinterpret_cast<uintptr_t>(q_out) & 3u) == 0, OQ_ERR_UNSUPPORTED,
+                   "KN_PACKED4 layout needs N %% 4 == 0, ldw %% 4 == 0, a 16-byte aligned W and a 4-byte aligned output");
+    }
     if (strategy == OQ_GROUP && K % g != 0) {
         OQ_REQUIRE((K * N) % g == 0, OQ_ERR_INVALID_ARGUMENT,
                    "cannot reshape array of size %lld into rows of %lld", (long long)(K * N), (long long)g);
@@ -1366,7 +1415,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         // environment variables override these choices for experiments only.
         static const Tuning tune = Tuning::from_env();
         const bool blob = layout == OQ_LAYOUT_NBITS;
-        a.order = tune.order >= 0 ? tune.order : (blob ? 2 : 1);
+        a.order = tune.order >= 0 ? tune.order : (blob ? 2 : 1);      // KN and KN_PACKED4 alike: plain column-fastest ids
         a.gk = tune.gk > 0 ? tune.gk : 8;
         a.nt = (tune.nt >= 0 ? tune.nt : 1) & kNtMask;
         a.stage_q = ((tune.stage_q != 0) && blob && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves && kgroups % a.gpb == 0) ? 1 : 0;
@@ -1486,7 +1535,7 @@ int32_t oq_rtn_quantize_batched_f32(const float* W, int64_t batch, int64_t w_str
     const int64_t bits = (qtype == OQ_INT4 || qtype == OQ_UINT4) ? 4 : 8;
     oq::g_batch.count = batch;
     oq::g_batch.w_stride = w_stride;
-    oq::g_batch.q_stride = layout == OQ_LAYOUT_KN ? K * N : K * N * bits / 8;
+    oq::g_batch.q_stride = layout == OQ_LAYOUT_KN ? K * N : K * N * bits / 8;      // blob and KN_PACKED4 (4-bit only) alike
     st = oq::rtn_impl(W, K, N, ldw, qtype, OQ_GROUP, group_size, symmetric, reduce_range, clip_ratio, 0, q_out, scale_out, zp_out, layout,
                       workspace, workspace_bytes, stream, true);
     oq::g_batch = oq::BatchCtx();

@@ -79,6 +79,57 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(const float* W, int64_t K
     if ((threadIdx.x & 63) == 0 && m) atomicOr(any_mask, m);
 }
 
+// The same search with the group's G values held in REGISTERS across the 20 candidates: W is read once
+// (G strided 4-byte loads per thread, coalesced across the lanes of a row) instead of 21 times from L2 / Infinity Cache,
+// and the candidate loop is pure ALU.  Same per-element arithmetic and the same summation order (r = 0 .. G-1 into one fp32
+// accumulator) as mse_rows_kernel: bit-identical masks.  G <= 128 keeps the tile within 256 VGPRs (two waves per SIMD: an
+// ALU-bound loop with G independent chains per candidate needs no more).
+template <int G>
+__global__ __launch_bounds__(256, 2) void mse_rows_reg_kernel(const float* W, int64_t N, int64_t ldw, int64_t kgroups, QGrid grid,
+                                                             MseRow* rows, uint32_t* any_mask) {
+    const int64_t n = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t kg = blockIdx.y;
+    const bool live = n < N;
+    const int64_t nc = live ? n : N - 1;
+    // wave-uniform row base + one 32-bit lane offset for all G loads (no 64-bit per-lane address per row)
+    const char* base = reinterpret_cast<const char*>(W + kg * G * ldw);
+    const uint32_t lane_off = static_cast<uint32_t>(nc) * 4u;
+    const int64_t row_bytes = ldw * 4;
+    float x[G];
+#pragma unroll
+    for (int r = 0; r < G; ++r) x[r] = *reinterpret_cast<const float*>(base + r * row_bytes + lane_off);
+    float mn = x[0], mx = x[0];
+#pragma unroll
+    for (int r = 1; r < G; ++r) {
+        mn = nmin(mn, x[r]);
+        mx = nmax(mx, x[r]);
+    }
+    const float lo0 = nmin(mn, 0.0f), hi0 = nmax(mx, 0.0f);
+    float best = FLT_MAX;   // np.finfo(float32).max, utils.py:190
+    uint32_t mask = 0;
+#pragma unroll 1
+    for (int i = 0; i < kMseSteps; ++i) {
+        const float p = shrink_factor(i);
+        const QParam qp = qparam_from_range(p * lo0, p * hi0, grid);
+        float err = 0.f;
+#pragma unroll
+        for (int r = 0; r < G; ++r) err += fake_quant_error(x[r], qp, grid);
+        if (err < best) {  // utils.py:225
+            best = err;
+            mask |= 1u << i;
+        }
+    }
+    if (live) {
+        MseRow o;
+        o.lo0 = lo0; o.hi0 = hi0; o.mask = mask;
+        rows[n * kgroups + kg] = o;
+    }
+    uint32_t m = live ? mask : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m |= __shfl_xor(m, off, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicOr(any_mask, m);
+}
+
 // tensor: per-block partial sums of all 20 candidate errors
 __global__ __launch_bounds__(256) void mse_tensor_partial(const float* W, int64_t K, int64_t N, int64_t ldw, const float* range,
                                                           QGrid grid, float* partial /* [blocks][20] */) {
@@ -207,8 +258,11 @@ int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QG
         hipLaunchKernelGGL(mse_tensor_mask, dim3(1), dim3(64), 0, s, partial, nblocks, range, rowbuf, any_mask);
         st = check_launch("mse_tensor");
     } else {
-        hipLaunchKernelGGL(mse_rows_kernel, dim3(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups)), dim3(256), 0, s,
-                           W, K, N, ldw, g, kgroups, grid, rowbuf, any_mask);
+        const dim3 gd(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups));
+        if (g == 128) hipLaunchKernelGGL((mse_rows_reg_kernel<128>), gd, dim3(256), 0, s, W, N, ldw, kgroups, grid, rowbuf, any_mask);
+        else if (g == 64) hipLaunchKernelGGL((mse_rows_reg_kernel<64>), gd, dim3(256), 0, s, W, N, ldw, kgroups, grid, rowbuf, any_mask);
+        else if (g == 32) hipLaunchKernelGGL((mse_rows_reg_kernel<32>), gd, dim3(256), 0, s, W, N, ldw, kgroups, grid, rowbuf, any_mask);
+        else hipLaunchKernelGGL(mse_rows_kernel, gd, dim3(256), 0, s, W, K, N, ldw, g, kgroups, grid, rowbuf, any_mask);
         st = check_launch("mse_rows_kernel");
     }
     if (st != OQ_OK) return st;

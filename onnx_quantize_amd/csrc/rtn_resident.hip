@@ -39,6 +39,7 @@ constexpr int kResRows = 16;                      // rows per wave
 constexpr int kResTileRows = kResWaves * kResRows;  // 128, the chunk height of the two-pass path (rtn.hip kChunkRows)
 constexpr int kResCols = 256;                     // 64 lanes x 4 columns
 constexpr int kResHeader = 160;
+constexpr int kResMaxTensorTiles = 65536;         // bitmap of kept tiles in LDS (8 KB): 2 G parameters; larger tensors take the three-launch path
 constexpr int kResTensorHeader = 128 + 64 * 32 + 64 * 32;   // tickets / counter, 64 key shards, 64 result replicas (a 128-byte line each)
 constexpr int kResGroupTileRows = 128;            // default tile height of rtn_resident_groups (see groups_tile_rows)
 constexpr int kResCtrPad = 32;                   // uint32 words per range counter: a 128-byte line each (hundreds of workgroups poll them)
@@ -60,7 +61,7 @@ struct ResidentArgs {
     uint32_t* key_nmin;   // [slots] complement of the ordered key of the running minimum (kept as a maximum)
     uint32_t* counters;   // groups: one per (column tile, k-group); tensor: [0] = tiles counted
     uint32_t* tickets;    // [0] phase A, [32] phase B
-    uint32_t* held;       // tensor: [ntiles] 1 = quantized from its owner's registers
+    uint32_t* held;       // tensor: bitmap over tiles, 1 = quantized from its owner's registers
 };
 
 __device__ __forceinline__ uint32_t okey_plain(float x) {   // monotone float -> uint32 for everything but NaN
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const ResidentArgs a) {
     __shared__ float s_mn[kResWaves], s_mx[kResWaves];
-    __shared__ uint32_t s_ticket, s_keys[2];
+    __shared__ uint32_t s_ticket, s_keys[2], s_first_b;
+    __shared__ uint32_t s_held[kResMaxTensorTiles / 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ntiles = a.ntiles, ncol = a.ncol_tiles;
 
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
     uint32_t* shard = a.key_max + (blockIdx.x & 63u) * 32u;          // {max key, complemented min key} of this shard
     uint32_t* replica = a.key_nmin + (blockIdx.x & 63u) * 32u;      // {go, final max key, final complemented min key}
     if (processed) {
-        if (threadIdx.x == 0) __hip_atomic_store(a.held + mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.held + (mine >> 5), 1u << (mine & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rmn = wave_min(rmn);
         rmx = wave_max(rmx);
         if (lane == 0) { s_mn[wave] = rmn; s_mx[wave] = rmx; }
@@ -336,6 +338,7 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
     // One 16-byte agent-scope load per poll returns {go, max key, min key} together (the keys were performed before `go`
     // was stored, and a 16-byte piece of a line is read in one request), so no second round trip for the keys.
     if (threadIdx.x == 0) {
+        const uint32_t first_b = agent_add(a.tickets + 32, 1u);   // returns while this thread polls
         u32x4r line;
         do {
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(line) : "v"(replica) : "memory");
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         } while (line[0] == 0u);
         s_keys[0] = line[1];
         s_keys[1] = line[2];
+        s_first_b = first_b;
     }
     __syncthreads();
     const float gmx = max_of_key(s_keys[0]), gmn = min_of_key(s_keys[1]);
@@ -359,15 +363,17 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         quantize_store_tile(a, cq, v, static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows, a.K,
                             static_cast<int64_t>(col_tile) * kResCols, lane);
     }
-    // Phase B: what nobody kept, most recently read first
-    if (threadIdx.x == 0) s_ticket = agent_add(a.tickets + 32, 1u);
+    // Phase B: what nobody kept, most recently read first.  The bitmap of kept tiles is complete (every owner set its bit
+    // before it counted its tiles) and is read once into LDS: a flag load per tile would put a memory round trip in front
+    // of every tile's loads.
+    for (uint32_t i = threadIdx.x; i < (ntiles + 31u) / 32u; i += kResWaves * kWave) s_held[i] = agent_load(a.held + i);
     __syncthreads();
-    uint32_t tb = s_ticket;
+    uint32_t tb = s_first_b;      // taken before the wait (below the publish): phase B's order does not matter, its latency does
     __syncthreads();
     while (tb < ntiles) {
         if (threadIdx.x == 0) s_ticket = agent_add(a.tickets + 32, 1u);
         const uint32_t tile = ntiles - 1u - tb;
-        if (__builtin_amdgcn_readfirstlane(agent_load(a.held + tile)) == 0u) {   // wave-uniform by construction
+        if (((s_held[tile >> 5] >> (tile & 31u)) & 1u) == 0u) {   // block-uniform
             const uint32_t row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
             const int64_t row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows;
             load_tile(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
@@ -395,13 +401,14 @@ static int resident_blocks(const void* kernel) {
     return cus * per_cu;
 }
 
-// Tile of the channel / tall-group kernel: rows per workgroup.  Speed only (OQ_RTN_RES_TILE = 128 | 64 | 32 for experiments):
-// smaller tiles put more independent workgroups on a CU, so that some of them load while others wait for their range.
+// Tile of the channel / tall-group kernel: rows per workgroup.  Speed only (OQ_RTN_RES_TILE = 256 | 128 for experiments).
+// 64- and 32-row tiles (4 / 7 workgroups per CU) were built and measured SLOWER (92 / 154 us against 70 on 4096 x 11008): more
+// siblings per range mean more key atomics and a longer wait for the last of them.
 static int groups_tile_rows(int64_t g) {
     static const int forced = [] {
         const char* v = getenv("OQ_RTN_RES_TILE");
         const int r = v ? atoi(v) : 0;
-        return (r == 256 || r == 128 || r == 64 || r == 32) ? r : 0;
+        return (r == 256 || r == 128) ? r : 0;
     }();
     if (forced) return forced;
     // measured on 4096 x 11008 / 4096 x 4096 / 11008 x 4096 (int8 channel): 256-row tiles 65 / 29 / 95 us, 128-row tiles
@@ -426,7 +433,7 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
     if (K % g) return false;
     const int64_t chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g));
     const int64_t ntiles = ceil_div(N, kResCols) * (K / g) * chunks;
-    if (ntiles >= (1LL << 31)) return false;
+    if (ntiles >= (1LL << 31) || (strategy == OQ_TENSOR && ntiles > kResMaxTensorTiles)) return false;
     if (strategy != OQ_TENSOR && chunks > 192) return false;   // forward progress needs `chunks` running workgroups (256 CUs)
     return workspace_bytes >= rtn_resident_workspace(K, N, strategy, g);
 }
@@ -465,9 +472,7 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
     a.key_max = a.counters + ranges * kResCtrPad;
     a.key_nmin = a.key_max + a.kgroups * static_cast<int64_t>(a.ncol_tiles) * kResCols;
     if (tile_rows == 256) hipLaunchKernelGGL((rtn_resident_groups<16, 16, 4>), dim3(a.ntiles), dim3(16 * kWave), 0, s, a);
-    else if (tile_rows == 128) hipLaunchKernelGGL((rtn_resident_groups<8, 16, 4>), dim3(a.ntiles), dim3(8 * kWave), 0, s, a);
-    else if (tile_rows == 64) hipLaunchKernelGGL((rtn_resident_groups<4, 16, 4>), dim3(a.ntiles), dim3(4 * kWave), 0, s, a);
-    else hipLaunchKernelGGL((rtn_resident_groups<4, 8, 7>), dim3(a.ntiles), dim3(4 * kWave), 0, s, a);
+    else hipLaunchKernelGGL((rtn_resident_groups<8, 16, 4>), dim3(a.ntiles), dim3(8 * kWave), 0, s, a);
     return check_launch("rtn_resident_groups");
 }
 

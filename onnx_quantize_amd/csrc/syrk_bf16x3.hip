@@ -1044,8 +1044,12 @@ int32_t syrk_pieces_phases(const float* X, int64_t T, int64_t K, int64_t ldx, fl
     u32x4* P = reinterpret_cast<u32x4*>(base + (f16 ? kScaleHeaderBytes : 0));
     if (slab == nullptr) slab_bytes = 0;
     // per launch, not once: the attribute belongs to the current device's copy of the kernel
-    static const bool f16_m16_env = [] { const char* v = getenv("OQ_SYRK_F16_M16"); return !v || atoi(v) != 0; }();   // default on; 0: the 32x32x16 form
+#ifdef OQ_SYRK_LAB
+    static const bool f16_m16_env = [] { const char* v = getenv("OQ_SYRK_F16_M16"); return !v || atoi(v) != 0; }();   // lab builds only; 0: the 32x32x16 form
     const bool f16_m16 = f16 && f16_m16_env;
+#else
+    const bool f16_m16 = f16;      // the shipped library reads no environment here
+#endif
     const void* kfn = f16_m16 ? reinterpret_cast<const void*>(&syrk_f16_m16_kernel) : terms == 9 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<9>)
                                  : (terms == 6 ? reinterpret_cast<const void*>(&syrk_pieces_kernel<6>) : reinterpret_cast<const void*>(&syrk_pieces_kernel<3>));
     const int lds_bytes = f16 ? StageGeom<3>::LDS : StageGeom<6>::LDS;

@@ -17,9 +17,9 @@ LIB_PATH = os.path.join(_PKG, "lib", "liboq_hip.so")
 # enums of include/oq_hip.h
 OQ_INT4, OQ_UINT4, OQ_INT8, OQ_UINT8, OQ_INT32, OQ_UINT32 = range(6)
 OQ_TENSOR, OQ_CHANNEL, OQ_GROUP = range(3)
-OQ_LAYOUT_KN, OQ_LAYOUT_NBITS = range(2)
-OQ_GPTQ_PARITY, OQ_GPTQ_CORRECTED = range(2)
-OQ_ABI_VERSION = 1
+OQ_LAYOUT_KN, OQ_LAYOUT_NBITS, OQ_LAYOUT_KN_PACKED4 = range(3)
+OQ_GPTQ_PARITY, OQ_GPTQ_CORRECTED, OQ_GPTQ_CORRECTED_COLUMNS = range(3)
+OQ_ABI_VERSION = 2
 OQ_ERR_INVALID_ARGUMENT, OQ_ERR_UNSUPPORTED, OQ_ERR_WORKSPACE, OQ_ERR_LAUNCH, OQ_ERR_NOT_SPD = -1, -2, -3, -4, -5
 
 QTYPE_CODE = {"int4": OQ_INT4, "uint4": OQ_UINT4, "int8": OQ_INT8, "uint8": OQ_UINT8,
@@ -87,21 +87,19 @@ PROTOTYPES = {
     "oq_rtn_tensor_many_workspace_bytes": (_sz, [_i64]),
     "oq_rtn_tensor_many_f32": (_i32, [_p, _i64, _i32, _i32, _i32, _f32, _p, _sz, _p]),
     "oq_pack_matmul_nbits": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _p]),
-    "oq_hessian_set_method": (_i32, [_i32]),
-    "oq_hessian_method": (_i32, []),
     "oq_hessian_workspace_bytes": (_sz, [_i64, _i64]),
-    "oq_hessian_accumulate_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _sz, _p]),
+    "oq_hessian_accumulate_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i64, _p, _i32, _p, _sz, _p]),
     "oq_gptq_prepare_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "oq_gptq_prepare_f32": (_i32, [_p, _i64, _i64, _p, _i32, _p, _p, _sz, _p]),
     "oq_gptq_factor_workspace_bytes": (_sz, [_i64]),
-    "oq_gptq_factor_f32": (_i32, [_p, _i64, _f32, _p, _p, _p, _sz, _p]),
+    "oq_gptq_factor_f32": (_i32, [_p, _i64, _f32, _p, _p, _i32, _p, _sz, _p]),
     "oq_gptq_factor_batched_workspace_bytes": (_sz, [_i64, _i64]),
-    "oq_gptq_factor_batched_f32": (_i32, [_p, _i64, _i64, _i64, _f32, _i32, _p, _i64, _p, _p, _sz, _p]),
+    "oq_gptq_factor_batched_f32": (_i32, [_p, _i64, _i64, _i64, _f32, _i32, _p, _i64, _p, _i32, _p, _sz, _p]),
     "oq_gptq_loop_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "oq_gptq_loop_f32": (_i32, [_p, _i64, _i64, _p, _i32, _i64, _i32, _i32, _f32, _i32, _i64, _i32,
-                                _p, _p, _i64, _p, _p, _p, _p, _p, _sz, _p]),
+    "oq_gptq_loop_f32": (_i32, [_p, _i64, _i64, _p, _i32, _i64, _i32, _i32, _f32, _i32, _i64, _i32, _i32,
+                                _p, _p, _i64, _p, _i32, _p, _p, _p, _p, _sz, _p]),
     "oq_hqq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
-    "oq_hqq_optimize_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _f64, _f64, _f64, _i32, _i32, _p, _i32, _p, _p,
+    "oq_hqq_optimize_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _f64, _f64, _f64, _i32, _i32, _i32, _p, _i32, _p, _p,
                                    _p, _sz, _p]),
     "oq_pack_zero_points_u4": (_i32, [_p, _i64, _i64, _p, _p]),
     "oq_pack_nibbles": (_i32, [_p, _i64, _p, _p]),

@@ -7,6 +7,7 @@ implementation: a missing library or a non-CUDA tensor is an error.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -19,6 +20,28 @@ BITS = {"int4": 4, "uint4": 4, "int8": 8, "uint8": 8, "int32": 32, "uint32": 32}
 
 def container_dtype(qtype: str) -> torch.dtype:
     return _CONTAINER[qtype]
+
+
+_LAYOUTS = {"kn": L.OQ_LAYOUT_KN, "nbits": L.OQ_LAYOUT_NBITS, "kn_packed4": L.OQ_LAYOUT_KN_PACKED4}
+
+
+def _layout_code(layout: str) -> int:
+    if layout not in _LAYOUTS:
+        raise ValueError(f"layout must be one of {sorted(_LAYOUTS)}, got {layout!r}")
+    return _LAYOUTS[layout]
+
+
+def _q_buffer(layout: str, lead: tuple, k: int, n: int, g: int, qtype: str, device):
+    """The integer output of one matrix (or a stack: ``lead``) in the requested layout: [K, N] one value per byte, the
+    MatMulNBits blob [N, K/g, g*bits/8], or [K, N/2] packed nibbles (core/_pack.py:8-22 order)."""
+    _layout_code(layout)
+    if layout == "kn":
+        return torch.empty((*lead, k, n), dtype=container_dtype(qtype), device=device)
+    if layout == "kn_packed4":
+        if BITS[qtype] != 4 or n % 2:
+            raise ValueError("layout 'kn_packed4' takes a 4-bit type and an even number of columns")
+        return torch.empty((*lead, k, n // 2), dtype=torch.uint8, device=device)
+    return torch.empty((*lead, n, k // g, g * BITS[qtype] // 8), dtype=torch.uint8, device=device)
 
 
 def _ptr(t: torch.Tensor | None) -> C.c_void_p:
@@ -99,8 +122,9 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
                  out=None):
     """rtn.py:54-109 on the GPU.  ``w`` [K, N] fp32 in HBM.
 
-    Returns (q, scale, zp) -- q [K, N] (layout "kn") or the MatMulNBits blob [N, K/g, g*bits/8]
-    (layout "nbits"); scale/zp 0-d | [N] | [N*K/g, 1].  With ``emit_q=False`` q is None
+    Returns (q, scale, zp) -- q [K, N] (layout "kn"), the MatMulNBits blob [N, K/g, g*bits/8] (layout "nbits") or
+    [K, N/2] nibble pairs in core/_pack.py:8-22 order (layout "kn_packed4": 4-bit types, group strategy);
+    scale/zp 0-d | [N] | [N*K/g, 1].  With ``emit_q=False`` q is None
     (utils.py:302-348 only).
     """
     _require_device(w, "w", torch.float32)
@@ -125,10 +149,8 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
     else:
         if not emit_q:
             q = None
-        elif layout == "kn":
-            q = torch.empty((k, n), dtype=cdt, device=dev)
         else:
-            q = torch.empty((n, k // g, g * BITS[qtype] // 8), dtype=torch.uint8, device=dev)
+            q = _q_buffer(layout, (), k, n, g, qtype, dev)
         scale = torch.empty(count, dtype=torch.float32, device=dev)
         zp = torch.empty(count, dtype=cdt, device=dev)
     gs = -1 if group_size is None else int(group_size)
@@ -137,7 +159,7 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
     if emit_q:
         st = lib.oq_rtn_quantize_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
                                      int(symmetric), int(reduce_range), float(clip_ratio), int(mse), _ptr(q),
-                                     _ptr(scale), _ptr(zp), L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS,
+                                     _ptr(scale), _ptr(zp), _layout_code(layout),
                                      _ptr(ws), ws.numel(), _stream())
     else:
         st = lib.oq_rtn_qparams_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
@@ -148,7 +170,7 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
 
 
 def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_ratio=1.0, mse=False, lp_norm=0.7, beta=1e1,
-                 kappa=1.01, iters=20, early_stop=True, emit_q: bool = True, layout: str = "kn"):
+                 kappa=1.01, iters=20, early_stop=True, emit_q: bool = True, layout: str = "kn", per_round_launches: bool = False):
     """hqq.py:147-213 on the GPU: uint4 / asymmetric / group with float zero points.  ``w`` [K, N] fp32 in HBM.
     Returns (q [K, N] uint8 | MatMulNBits blob [N, K/g, g/2] for layout="nbits" | None, scale [N*K/g, 1] fp32,
     zero_point [N*K/g, 1] fp32, rounds int32[1] on device)."""
@@ -177,7 +199,7 @@ def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_rati
     gs = -1 if group_size is None else int(group_size)
     ws = _workspace(lib.oq_hqq_workspace_bytes(k, n, gs), dev)
     L.check(lib.oq_hqq_optimize_f32(_ptr(w), k, n, ldw, gs, int(reduce_range), _ptr(scale), _ptr(zp_in), float(lp_norm),
-                                    float(beta), float(kappa), int(iters), int(early_stop), _ptr(q),
+                                    float(beta), float(kappa), int(iters), int(early_stop), int(bool(per_round_launches)), _ptr(q),
                                     L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS, _ptr(zp), _ptr(rounds),
                                     _ptr(ws), ws.numel(), _stream()))
     return q, scale.reshape(rows, 1), zp.reshape(rows, 1), rounds
@@ -232,16 +254,29 @@ def rtn_quantize_batched(w: torch.Tensor, qtype: str, group_size: int, symmetric
     if out is not None:
         q, scale, zp = out
     else:
-        q = (torch.empty((b, k, n), dtype=cdt, device=w.device) if layout == "kn"
-             else torch.empty((b, n, k // g, g * BITS[qtype] // 8), dtype=torch.uint8, device=w.device))
+        q = _q_buffer(layout, (b,), k, n, g, qtype, w.device)
         scale = torch.empty((b, n * k // g, 1), dtype=torch.float32, device=w.device)
         zp = torch.empty((b, n * k // g, 1), dtype=cdt, device=w.device)
     ws = _workspace(lib.oq_rtn_batched_workspace_bytes(b, k, n, int(group_size)), w.device)
     L.check(lib.oq_rtn_quantize_batched_f32(_ptr(w), b, k * n, k, n, n, L.QTYPE_CODE[qtype], int(group_size), int(symmetric),
                                             int(reduce_range), float(clip_ratio), _ptr(q), _ptr(scale), _ptr(zp),
-                                            L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS, _ptr(ws), ws.numel(),
-                                            _stream()))
+                                            _layout_code(layout), _ptr(ws), ws.numel(), _stream()))
     return q, scale, zp
+
+
+_TABLE_STAGE: dict = {}     # device index -> (pinned int64 [cap, 4], side stream): the pointer tables of rtn_quantize_many
+
+
+def _table_stage(dev, rows: int):
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    pin, side = _TABLE_STAGE.get(index, (None, None))
+    if side is None:
+        side = torch.cuda.Stream(device=dev)
+    if pin is None or pin.shape[0] < rows:
+        pin = torch.empty((max(rows, 256), 4), dtype=torch.int64).pin_memory()
+    _TABLE_STAGE[index] = (pin, side)
+    side.synchronize()          # an earlier call's copies have left the pinned rows (they ran long ago: this returns at once)
+    return pin, side
 
 
 def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_range=False, clip_ratio=1.0, layout: str = "kn"):
@@ -250,59 +285,106 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
     through ONE C call (oq_rtn_quantize_ptrs_f32), which puts about 1.6e8 parameters into a launch (a device table of
     pointers, blockIdx.y = entry): rounds of waves merge across matrices and small matrices are no longer launch-bound
     (gemma-3-270m's 126 weights: 1.0 ms instead of 2.6 ms in a per-matrix loop; 4096 x 4096 at a model's footprint: 0.72 of
-    the HBM peak instead of 0.54).  Per matrix the bits are those of `rtn_quantize`.  Returns [(q, scale, zp)] in input order; q [K, N] or the
-    MatMulNBits blob [N, K/g, g*bits/8], scale / zp [N*K/g, 1]; the outputs of one shape are views of three shared buffers."""
-    import numpy as np
+    the HBM peak instead of 0.54).  Per matrix the bits are those of `rtn_quantize`.  Returns [(q, scale, zp)] in input order; q [K, N], the
+    MatMulNBits blob [N, K/g, g*bits/8] or [K, N/2] nibble pairs (layout "kn_packed4"), scale / zp [N*K/g, 1]; the outputs of
+    one C call (a shape, or a piece of the first shapes) are views of three shared buffers.
 
+    Host work runs beside the kernels (see the comments in the body): the pointer tables go through a page-locked staging
+    buffer and a side stream, and the calls are ordered and cut so that only ~50 us of head have the GPU waiting (with all
+    tables built and uploaded before the first launch a 224-matrix model had 0.4 ms of idle GPU in front of 5.7 ms of
+    kernels; a blocking upload per shape on the launch stream was worse: it queues behind the previous shape's kernels)."""
     if not ws:
         return []
     lib = L.load()
     cdt = container_dtype(qtype)
-    bits = BITS[qtype]
-    mats, groups = [], {}
-    for i, w in enumerate(ws):
-        _require_device(w, "w", torch.float32)
-        if w.dim() != 2:
-            raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
-        w2, ldw = _row_major(w)
-        k, n = w2.shape
+    lay = _layout_code(layout)
+
+    def key_of(w):
+        return (w.shape, w.stride())           # two attribute reads per weight: the scan of 224 weights is 0.1 ms of head otherwise
+
+    dev = ws[0].device
+    out = [None] * len(ws)
+    pin, side = _table_stage(dev, len(ws))
+    table_dev = torch.empty((len(ws), 4), dtype=torch.int64, device=dev)
+    table_dev.record_stream(side)
+    cur = torch.cuda.current_stream()
+    state = {"wsb": None, "row": 0}
+    made = []
+
+    def run(key, idx):
+        """One C call: check the members, allocate their outputs, write and copy their table rows, launch."""
+        (k, n), _strides = key
         if k == 0 or n == 0:
-            raise ValueError(f"rtn_quantize_many: weight {i} is empty ({k} x {n})")
+            raise ValueError(f"rtn_quantize_many: weight {idx[0]} is empty ({k} x {n})")
         g = resolve_group("group", k, group_size)
         if g <= 0 or k % g:
             raise ValueError("rtn_quantize_many needs K % group_size == 0 for every weight")
-        mats.append(w2)
-        groups.setdefault((k, n, ldw, g), []).append(i)
-    dev = mats[0].device
-    out = [None] * len(ws)
-    table = np.empty((len(ws), 4), dtype=np.int64)
-    plan, row, made = [], 0, []
-    for (k, n, ldw, g), idx in groups.items():
-        cnt = len(idx)
-        q = (torch.empty((cnt, k, n), dtype=cdt, device=dev) if layout == "kn"
-             else torch.empty((cnt, n, k // g, g * bits // 8), dtype=torch.uint8, device=dev))
+        mats, ldw = [], None
+        for i in idx:
+            _require_device(ws[i], "w", torch.float32)
+            w2, ldw = _row_major(ws[i])
+            mats.append(w2)
+        cnt, row = len(idx), state["row"]
+        q = _q_buffer(layout, (cnt,), k, n, g, qtype, dev)
         sc = torch.empty((cnt, n * k // g, 1), dtype=torch.float32, device=dev)
         zp = torch.empty((cnt, n * k // g, 1), dtype=cdt, device=dev)
-        # output pointers by arithmetic (the per-matrix views the caller gets back are made AFTER the launches below: with
-        # hundreds of weights their construction was a millisecond of idle GPU in front of the first kernel)
-        steps = np.arange(cnt, dtype=np.int64)
-        table[row:row + cnt, 0] = [mats[i].data_ptr() for i in idx]
-        table[row:row + cnt, 1] = q.data_ptr() + steps * (q[0].numel() * q.element_size())
-        table[row:row + cnt, 2] = sc.data_ptr() + steps * (sc[0].numel() * 4)
-        table[row:row + cnt, 3] = zp.data_ptr() + steps * (zp[0].numel() * zp.element_size())
-        made.append((idx, q, sc, zp))
-        plan.append((k, n, ldw, g, row, cnt))
-        row += cnt
-    table_dev = torch.from_numpy(table).to(dev) if len(ws) > 1 else None   # one small upload for the whole list
-    ws_bytes = max(lib.oq_rtn_batched_workspace_bytes(cnt, k, n, int(group_size)) for (k, n, ldw, g, r0, cnt) in plan)
-    wsb = _workspace(ws_bytes, dev)
-    lay = L.OQ_LAYOUT_KN if layout == "kn" else L.OQ_LAYOUT_NBITS
-    for (k, n, ldw, g, r0, cnt) in plan:
-        dev_rows = C.c_void_p(0 if table_dev is None else table_dev.data_ptr() + 32 * r0)
-        L.check(lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(table[r0:].ctypes.data), dev_rows, cnt, k, n, ldw, L.QTYPE_CODE[qtype],
-                                             int(group_size), int(symmetric), int(reduce_range), float(clip_ratio), lay, _ptr(wsb),
-                                             wsb.numel(), _stream()))
-    for idx, q, sc, zp in made:
+        need = lib.oq_rtn_batched_workspace_bytes(cnt, k, n, int(group_size))
+        if state["wsb"] is None or state["wsb"].numel() < need:
+            state["wsb"] = _workspace(need, dev)     # calls on one stream run in order: a later, larger shape may take a new buffer
+        wsb = state["wsb"]
+        # output pointers by arithmetic (the per-matrix views the caller gets back are made AFTER the launches)
+        rows = pin[row:row + cnt]
+        rows[:, 0] = torch.tensor([m.data_ptr() for m in mats], dtype=torch.int64)
+        steps = torch.arange(cnt, dtype=torch.int64)
+        rows[:, 1] = q.data_ptr() + steps * (q[0].numel() * q.element_size())
+        rows[:, 2] = sc.data_ptr() + steps * (sc[0].numel() * 4)
+        rows[:, 3] = zp.data_ptr() + steps * (zp[0].numel() * zp.element_size())
+        dev_rows = table_dev[row:row + cnt]
+        if cnt > 1:
+            with torch.cuda.stream(side):
+                dev_rows.copy_(rows, non_blocking=True)
+                ready = side.record_event()
+            cur.wait_event(ready)
+        L.check(lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(rows.data_ptr()), C.c_void_p(dev_rows.data_ptr() if cnt > 1 else 0), cnt, k, n, ldw,
+                                             L.QTYPE_CODE[qtype], int(group_size), int(symmetric), int(reduce_range), float(clip_ratio), lay,
+                                             _ptr(wsb), wsb.numel(), _stream()))
+        made.append((idx, q, sc, zp, mats))      # operands stay referenced until the views are made
+        state["row"] = row + cnt
+
+    for w in ws[:1]:
+        if not isinstance(w, torch.Tensor) or w.dim() != 2:
+            _require_device(w, "w", torch.float32)
+            raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
+    # Host work beside the kernels.  (1) Look at the first 24 weights only and launch up to 8 of the shape that carries the
+    # most parameters among them: the GPU starts after ~50 us of head.  (2) Group everything else by shape while those
+    # kernels run.  (3) Shape by shape, fewest matrices first; the first shape in pieces (4, 8, rest) so that every call is
+    # prepared in less time than the kernels in front of it take.
+    early: dict = {}
+    for i, w in enumerate(ws[:24]):
+        if not isinstance(w, torch.Tensor) or w.dim() != 2:
+            _require_device(w, "w", torch.float32)
+            raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
+        early.setdefault(key_of(w), []).append(i)
+    taken = set()
+    if len(ws) > 24:
+        key0, idx0 = max(early.items(), key=lambda kv: len(kv[1]) * kv[0][0][0] * kv[0][0][1])
+        run(key0, idx0[:8])
+        taken = set(idx0[:8])
+    groups: dict = {}
+    for i, w in enumerate(ws):
+        if i in taken:
+            continue
+        if not isinstance(w, torch.Tensor) or w.dim() != 2:
+            _require_device(w, "w", torch.float32)
+            raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
+        groups.setdefault(key_of(w), []).append(i)
+    order = sorted(groups.items(), key=lambda kv: len(kv[1]))
+    if order and len(order[0][1]) > 12:
+        key1, idx1 = order[0]
+        order = [(key1, idx1[:4]), (key1, idx1[4:12]), (key1, idx1[12:])] + order[1:]
+    for key, idx in order:
+        run(key, idx)
+    for idx, q, sc, zp, _mats in made:
         for j, i in enumerate(idx):
             out[i] = (q[j], sc[j], zp[j])
     return out
@@ -600,9 +682,10 @@ def pack_nibbles(values: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- G1 - G4
-def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
+def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int, method: str | None = None) -> int:
     """gptq.py:246-260, in place on ``h`` [K, K]; ``x`` [n_add, ..., K] fp32.  Returns the new sample
-    count.  The activations are streamed through the MFMA TN GEMM; nothing is concatenated."""
+    count.  The activations are streamed through the MFMA TN GEMM; nothing is concatenated.  ``method``: the X^T X kernel
+    of this call (None: the calling thread's default, `hessian_set_method`)."""
     _require_device(x, "x", torch.float32)
     _require_device(h, "H", torch.float32)
     n_add = int(x.shape[0])
@@ -613,7 +696,8 @@ def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int) -> int:
         raise ValueError(f"H must be a contiguous [{k}, {k}] tensor")
     lib = L.load()
     ws = _workspace(lib.oq_hessian_workspace_bytes(t, k), x.device)
-    L.check(lib.oq_hessian_accumulate_f32(_ptr(x2), t, k, ldx, int(n_seen), n_add, _ptr(h), _ptr(ws), ws.numel(), _stream()))
+    L.check(lib.oq_hessian_accumulate_f32(_ptr(x2), t, k, ldx, int(n_seen), n_add, _ptr(h), _method_code(method), _ptr(ws), ws.numel(),
+                                          _stream()))
     return int(n_seen) + n_add
 
 
@@ -766,16 +850,27 @@ class HessianPipeline:
 
 
 HESSIAN_METHODS = {"auto": 0, "f32": 1, "bf16x6": 2, "bf16x9": 3, "f16x3": 4}
+_METHOD_DEFAULT = threading.local()
 
 
 def hessian_set_method(method: str) -> None:
-    """Process-wide choice of the X^T X kernel (include/oq_hip.h, G1): "auto" | "f32" | "bf16x6" | "bf16x9" | "f16x3"."""
-    L.check(L.load().oq_hessian_set_method(HESSIAN_METHODS[method]))
+    """The calling THREAD's default for the matrix-core products of the GPTQ path (include/oq_hip.h, G1): "auto" | "f32" |
+    "bf16x6" | "bf16x9" | "f16x3".  A default provider only: the C library has no such state (ABI 2: the method is an
+    argument of every entry point that uses it), and every function below also takes ``method=`` per call."""
+    if method not in HESSIAN_METHODS:
+        raise ValueError(f"unknown Hessian method {method!r}: one of {sorted(HESSIAN_METHODS)}")
+    _METHOD_DEFAULT.value = method
 
 
 def hessian_method() -> str:
-    code = L.load().oq_hessian_method()
-    return next(k for k, v in HESSIAN_METHODS.items() if v == code)
+    return getattr(_METHOD_DEFAULT, "value", "auto")
+
+
+def _method_code(method: str | None) -> int:
+    m = hessian_method() if method is None else method
+    if m not in HESSIAN_METHODS:
+        raise ValueError(f"unknown Hessian method {m!r}: one of {sorted(HESSIAN_METHODS)}")
+    return HESSIAN_METHODS[m]
 
 
 def gptq_prepare(w: torch.Tensor, h: torch.Tensor, actorder: bool):
@@ -791,7 +886,7 @@ def gptq_prepare(w: torch.Tensor, h: torch.Tensor, actorder: bool):
     return perm
 
 
-def gptq_factor(h: torch.Tensor, percdamp: float):
+def gptq_factor(h: torch.Tensor, percdamp: float, method: str | None = None):
     """gptq.py:134-150: returns (U [K, K] upper with inv(H + damp I) = U^T U, info int32[1] on device)."""
     _require_device(h, "H", torch.float32)
     assert h.is_contiguous() and h.dim() == 2 and h.shape[0] == h.shape[1]
@@ -800,11 +895,11 @@ def gptq_factor(h: torch.Tensor, percdamp: float):
     u = torch.empty((k, k), dtype=torch.float32, device=h.device)
     info = torch.zeros(1, dtype=torch.int32, device=h.device)
     ws = _workspace(lib.oq_gptq_factor_workspace_bytes(k), h.device)
-    L.check(lib.oq_gptq_factor_f32(_ptr(h), k, float(percdamp), _ptr(u), _ptr(info), _ptr(ws), ws.numel(), _stream()))
+    L.check(lib.oq_gptq_factor_f32(_ptr(h), k, float(percdamp), _ptr(u), _ptr(info), _method_code(method), _ptr(ws), ws.numel(), _stream()))
     return u, info
 
 
-def gptq_factor_batched(h: torch.Tensor, percdamp: float, fix_dead: bool = False):
+def gptq_factor_batched(h: torch.Tensor, percdamp: float, fix_dead: bool = False, method: str | None = None):
     """gptq.py:134-150 for a stack ``h`` [B, K, K] of Hessians of one width, factored in lock-step (one chain of
     launches for all of them).  Returns (U [B, K, K], info int32[B] on the device); matrix by matrix bit-identical to
     `gptq_factor`.  ``fix_dead``: zero diagonal entries count as 1 (gptq.py:119-120)."""
@@ -817,30 +912,36 @@ def gptq_factor_batched(h: torch.Tensor, percdamp: float, fix_dead: bool = False
     info = torch.zeros(b, dtype=torch.int32, device=h.device)
     ws = _workspace(lib.oq_gptq_factor_batched_workspace_bytes(k, b), h.device)
     L.check(lib.oq_gptq_factor_batched_f32(_ptr(h), k, k * k, b, float(percdamp), int(bool(fix_dead)), _ptr(u), k * k, _ptr(info),
-                                           _ptr(ws), ws.numel(), _stream()))
+                                           _method_code(method), _ptr(ws), ws.numel(), _stream()))
     return u, info
 
 
-def gptq_shared_factors(h: torch.Tensor, percdamp: float):
+def gptq_shared_factors(h: torch.Tensor, percdamp: float, method: str | None = None):
     """`gptq_shared_factor` (no actorder) for a stack of Hessians [B, K, K]: one batched factor chain; returns the list
     of per-input dictionaries ``gptq_quantize(..., shared=...)`` takes (views into the batched results)."""
-    u, info = gptq_factor_batched(h, percdamp, fix_dead=True)
+    u, info = gptq_factor_batched(h, percdamp, fix_dead=True, method=method)
     dead = torch.diagonal(h, dim1=1, dim2=2) == 0
     return [{"u": u[i], "info": info[i:i + 1], "perm": None, "dead": dead[i]} for i in range(h.shape[0])]
 
 
+_LOOP_MODES = {"parity": L.OQ_GPTQ_PARITY, "corrected": L.OQ_GPTQ_CORRECTED, "corrected_columns": L.OQ_GPTQ_CORRECTED_COLUMNS}
+
+
 def gptq_loop(w: torch.Tensor, u: torch.Tensor, qtype: str, group_size, symmetric: bool, reduce_range: bool,
               clip_ratio: float, mse: bool, block_size: int, mode: str, init_scale: torch.Tensor,
-              init_zp: torch.Tensor, want_used: bool = False):
+              init_zp: torch.Tensor, want_used: bool = False, layout: str = "kn", method: str | None = None):
     """gptq.py:153-216 on the working copy ``w`` (modified in place in corrected mode).
-    Returns (q_int [K, N], q_deq [K, N], used_scale | None, used_zp | None)."""
+    Returns (q_int [K, N] or, with layout "kn_packed4", [K, N/2] nibble pairs; q_deq [K, N]; used_scale | None; used_zp | None).
+    ``mode`` "corrected_columns" = "corrected" on the one-column-per-lane kernel (same bytes)."""
     _require_device(w, "W", torch.float32)
     _require_device(u, "U", torch.float32)
     assert w.is_contiguous() and u.is_contiguous()
     k, n = w.shape
     lib = L.load()
     g = int(group_size) if group_size else 0
-    q_int = torch.empty((k, n), dtype=container_dtype(qtype), device=w.device)
+    if layout not in ("kn", "kn_packed4"):
+        raise ValueError("the GPTQ loop writes layout 'kn' or 'kn_packed4'")
+    q_int = _q_buffer(layout, (), k, n, 0, qtype, w.device)
     q_deq = torch.empty((k, n), dtype=torch.float32, device=w.device)
     used_s = used_z = None
     if want_used and g > 0:
@@ -851,14 +952,13 @@ def gptq_loop(w: torch.Tensor, u: torch.Tensor, qtype: str, group_size, symmetri
     z0 = init_zp.to(torch.int32).contiguous().reshape(-1)
     ws = _workspace(lib.oq_gptq_loop_workspace_bytes(k, n, int(block_size)), w.device)
     L.check(lib.oq_gptq_loop_f32(_ptr(w), k, n, _ptr(u), L.QTYPE_CODE[qtype], g, int(symmetric), int(reduce_range),
-                                 float(clip_ratio), int(mse), int(block_size),
-                                 L.OQ_GPTQ_PARITY if mode == "parity" else L.OQ_GPTQ_CORRECTED, _ptr(s0), _ptr(z0),
-                                 s0.numel(), _ptr(q_int), _ptr(q_deq), _ptr(used_s), _ptr(used_z), _ptr(ws),
+                                 float(clip_ratio), int(mse), int(block_size), _LOOP_MODES[mode], _method_code(method), _ptr(s0), _ptr(z0),
+                                 s0.numel(), _ptr(q_int), _layout_code(layout), _ptr(q_deq), _ptr(used_s), _ptr(used_z), _ptr(ws),
                                  ws.numel(), _stream()))
     return q_int, q_deq, used_s, used_z
 
 
-def gptq_shared_factor(h: torch.Tensor, percdamp: float, actorder: bool):
+def gptq_shared_factor(h: torch.Tensor, percdamp: float, actorder: bool, method: str | None = None):
     """Everything of `_gptq` that depends on H only (gptq.py:118-150): the dead-channel mask, the optional
     actorder permutation and the inverse factor.  The reference recomputes this for every node; nodes that
     share an input (q/k/v, gate/up) share H, so one factor serves them all -- pass the result to
@@ -868,17 +968,18 @@ def gptq_shared_factor(h: torch.Tensor, percdamp: float, actorder: bool):
     h1 = h.contiguous().clone()
     dummy = torch.zeros((k, 4), dtype=torch.float32, device=h.device)
     perm = gptq_prepare(dummy, h1, actorder)
-    u, info = gptq_factor(h1, percdamp)
+    u, info = gptq_factor(h1, percdamp, method)
     dead = torch.diagonal(h) == 0
     return {"u": u, "info": info, "perm": perm, "dead": dead}
 
 
 def gptq_quantize(w: torch.Tensor, h: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
                   reduce_range=False, clip_ratio=1.0, block_size=128, percdamp=0.01, actorder=False, mse=False,
-                  mode: str = "parity", shared=None):
+                  mode: str = "parity", shared=None, layout: str = "kn", method: str | None = None):
     """gptq.py:76-243 (`_gptq`) on device tensors: ``w`` [K, N] weights, ``h`` [K, K] accumulated Hessian.
-    Neither input is modified.  Returns (q_int, scale, zp, info) with the reference's output shapes."""
-    if mode not in ("parity", "corrected"):
+    Neither input is modified.  Returns (q_int, scale, zp, info) with the reference's output shapes; ``layout``
+    "kn_packed4": q_int [K, N/2] as core/_pack.py:8-22 serialises the 4-bit result, written by the loop kernels."""
+    if mode not in _LOOP_MODES:
         raise ValueError("mode must be 'parity' or 'corrected'")
     _require_device(w, "W", torch.float32)
     _require_device(h, "H", torch.float32)
@@ -890,16 +991,16 @@ def gptq_quantize(w: torch.Tensor, h: torch.Tensor, qtype: str, strategy: str, g
     _, s0, z0 = rtn_quantize(w1, qtype, used, -1, symmetric, reduce_range, clip_ratio, mse, emit_q=False)
     if shared is None:
         perm = gptq_prepare(w1, h1, actorder)                                    # :118-127
-        u, info = gptq_factor(h1, percdamp)                                      # :134-150
+        u, info = gptq_factor(h1, percdamp, method)                              # :134-150
     else:   # H-only work done once for all layers with this input
         u, info, perm = shared["u"], shared["info"], shared["perm"]
         w1.masked_fill_(shared["dead"].unsqueeze(1), 0.0)                        # :121 (no host round trip, unlike w1[mask] = 0)
         if perm is not None:
             w1 = w1.index_select(0, perm.to(torch.int64)).contiguous()          # :126
     loop_g = group_size if (group_size and group_size != -1) else 0
-    corrected_own = mode == "corrected" and not actorder
+    corrected_own = mode != "parity" and not actorder
     q_int, q_deq, us, uz = gptq_loop(w1, u, qtype, loop_g, symmetric, reduce_range, clip_ratio, mse, block_size,
-                                     mode, s0, z0, want_used=corrected_own and strategy == "group")
+                                     mode, s0, z0, want_used=corrected_own and strategy == "group", layout=layout, method=method)
     if actorder:                                                                 # :210-213
         inv = torch.argsort(perm.to(torch.int64))
         q_int = q_int.index_select(0, inv)

@@ -348,12 +348,60 @@ class StreamedGather:
         return {s.name: out[i] for i, s in enumerate(self.specs) if i in out}, self.nbytes
 
 
-def connect_to_rank0(device=None, *, group=None) -> None:
+class PeersMissing(RuntimeError):
+    """A rank did not reach the rendezvous in time; `.missing` lists the ranks that were not seen."""
+
+    def __init__(self, msg: str, missing):
+        super().__init__(msg)
+        self.missing = list(missing)
+
+
+def await_all_ranks(tag: str = "oq", *, timeout_s: float = 120.0, group=None) -> int:
+    """Bounded "is everybody here?" that does not touch the data-path communicator: every rank writes one key into the
+    process group's key-value store and waits -- at most ``timeout_s`` -- for the keys of all ranks.  Returns the number of
+    ranks seen (= world size) or raises `PeersMissing` naming the absent ranks.  First contact with a real multi-GPU node
+    must end in a line of output or a readable error, never in a silent hang until the driver's limit:
+    an RCCL collective with a missing peer blocks for as long as the watchdog allows."""
+    import datetime
+
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return 1
+    from torch.distributed import distributed_c10d as c10d
+
+    store = c10d._get_default_store()
+    store.set(f"{tag}/here/{rank}", b"1")
+    keys = [f"{tag}/here/{r}" for r in range(world)]
+    try:
+        store.wait(keys, datetime.timedelta(seconds=float(timeout_s)))
+    except Exception as e:      # the store's timeout error type differs between back ends
+        missing = []
+        for r, k in enumerate(keys):
+            try:
+                store.wait([k], datetime.timedelta(milliseconds=50))
+            except Exception:
+                missing.append(r)
+        raise PeersMissing(f"rank {rank}: {len(missing)} of {world} ranks did not arrive within {timeout_s:.0f} s: missing {missing}", missing) from e
+    return world
+
+
+def connect_to_rank0(device=None, *, group=None, timeout_s: float = 120.0) -> None:
     """One tiny grouped send / receive between rank 0 and every other rank, waited for: with NCCL the first point-to-point
     operation between two ranks sets up their connection, and the host thread that issues it blocks until the peer issues its
     side.  `StreamedGather` posts rank 0's receives before rank 0 computes anything while a peer sends only when its first
     bundle is done -- without this call rank 0 would sit in that handshake for as long as the slowest peer's first bundle
-    takes.  Call it once per process group, outside any timed region (every rank must call it)."""
+    takes.  Call it once per process group, outside any timed region (every rank must call it).
+
+    Bounded: the ranks first meet in the key-value store (`await_all_ranks`, which names missing peers), then the
+    point-to-point handshake runs on a helper thread that the caller joins for at most ``timeout_s``; if the transport
+    itself does not come up the call raises (the helper thread is a daemon: the process can exit non-zero) instead of
+    blocking for the communicator's own watchdog time.  Nothing is retried and nothing is re-executed."""
+    import threading
+
     import torch
     import torch.distributed as dist
 
@@ -362,23 +410,45 @@ def connect_to_rank0(device=None, *, group=None) -> None:
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world == 1:
         return
+    await_all_ranks("oq/connect", timeout_s=timeout_s, group=group)
     nccl = dist.get_backend(group) == "nccl"
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu"))
     if not nccl:
         dev = torch.device("cpu")
-    if rank == 0:
-        bufs = [torch.zeros(16, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
-        works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, r, group) for r, b in zip(range(1, world), bufs)])
-        for w in works:
-            w.wait()
-        if any(int(b[0]) != r for r, b in zip(range(1, world), bufs)):
-            raise RuntimeError("connect_to_rank0: a peer's greeting did not arrive intact")
-    else:
-        hello = torch.full((16,), rank % 256, dtype=torch.uint8, device=dev)
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, hello, 0, group)]):
-            w.wait()
-    if nccl:
-        torch.cuda.current_stream().synchronize()
+    failure: list = []
+
+    def handshake():
+        try:
+            if nccl:
+                torch.cuda.set_device(dev)
+            if rank == 0:
+                bufs = [torch.zeros(16, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
+                works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, r, group) for r, b in zip(range(1, world), bufs)])
+                for w in works:
+                    w.wait()
+                if nccl:
+                    torch.cuda.current_stream().synchronize()
+                bad = [r for r, b in zip(range(1, world), bufs) if int(b[0]) != r % 256]
+                if bad:
+                    failure.append(RuntimeError(f"connect_to_rank0: the greetings of ranks {bad} did not arrive intact"))
+            else:
+                hello = torch.full((16,), rank % 256, dtype=torch.uint8, device=dev)
+                for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, hello, 0, group)]):
+                    w.wait()
+                if nccl:
+                    torch.cuda.current_stream().synchronize()
+        except Exception as e:      # surfaced on the calling thread below
+            failure.append(e)
+
+    t = threading.Thread(target=handshake, name="oq-connect", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        peers = list(range(1, world)) if rank == 0 else [0]
+        raise PeersMissing(f"rank {rank}: the point-to-point handshake with ranks {peers} over {dist.get_backend(group)} did not complete "
+                           f"within {timeout_s:.0f} s (all ranks had reached the rendezvous): the transport did not come up", peers)
+    if failure:
+        raise failure[0]
 
 
 def wave_bundles(specs: Sequence[LayerSpec], plan: list[list[int]], groups_per_wave: int) -> list[list[list[int]]]:

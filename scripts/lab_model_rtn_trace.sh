@@ -1,26 +1,30 @@
 #!/bin/bash
-# kernel trace of the model-scale RTN call (bench.py model_rtn): launch durations by grid, against the bytes each moves
+# kernel trace of the model-scale RTN call: where the time between the first and the last kernel of a call goes
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/model_rtn_trace; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-gptq --no-seam --no-awq --no-calibration > $OUT/log.txt 2>&1
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/model_rtn_trace; rm -rf $OUT; mkdir -p $OUT
+python3 $R/scripts/lab_model_rtn.py > $OUT/plain.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $R/scripts/lab_model_rtn.py > $OUT/log.txt 2>&1
 python3 - <<'PY'
-import csv, glob, os, collections
+import csv, glob, os
 root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/model_rtn_trace"
+print(open(root + "/plain.txt").read())
 f = glob.glob(f"{root}/t/**/*kernel_trace.csv", recursive=True)[0]
-rows = [r for r in csv.DictReader(open(f)) if "rtn_group_wave" in r["Kernel_Name"]]
-agg = collections.OrderedDict()
-for r in rows:
-    key = (r["Grid_Size_X"], r["Grid_Size_Y"])
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    a = agg.setdefault(key, []); a.append((int(r["Start_Timestamp"]), d))
-for key, v in agg.items():
-    ds = sorted(d for _, d in v)
-    print(key, "launches", len(v), "median_us", round(ds[len(ds) // 2], 1), "min", round(ds[0], 1), "max", round(ds[-1], 1))
-# gaps inside the last burst of Y > 1 launches (the one-call model pass)
-multi = sorted((s, d) for k, v in agg.items() if int(k[1]) > 1 for s, d in v)
-if multi:
-    last = multi[-48:]
-    span = (last[-1][0] + last[-1][1] * 1e3 - last[0][0]) / 1e3
-    busy = sum(d for _, d in last)
-    print("last", len(last), "multi-matrix launches: span_us", round(span), "kernel_sum_us", round(busy), "gaps_us", round(span - busy))
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][-40:], r["Grid_Size_X"], r["Grid_Size_Y"]) for r in csv.DictReader(open(f))))
+rtn = [r for r in rows if "rtn_group_wave" in r[2]]
+# split into calls: a gap of more than 2 ms between rtn kernels starts a new call
+calls, cur = [], [rtn[0]]
+for a, b in zip(rtn, rtn[1:]):
+    if b[0] - a[1] > 2_000_000: calls.append(cur); cur = []
+    cur.append(b)
+calls.append(cur)
+for c in calls[-2:]:
+    span = (c[-1][1] - c[0][0]) / 1e3
+    busy = sum(e - s for s, e, *_ in c) / 1e3
+    gaps = [((b[0] - a[1]) / 1e3, i) for i, (a, b) in enumerate(zip(c, c[1:]))]
+    big = [(round(g, 1), i, c[i][3], c[i][4], c[i + 1][3], c[i + 1][4]) for g, i in gaps if g > 3.0]
+    print("launches", len(c), "span_us", round(span), "kernel_sum_us", round(busy), "gaps_us", round(span - busy), "gaps > 3 us:", big)
+    byshape = {}
+    for s, e, nme, gx, gy in c:
+        byshape.setdefault((gx, gy), []).append((e - s) / 1e3)
+    print({k: (len(v), round(sum(v) / len(v), 1)) for k, v in byshape.items()})
 PY

@@ -21,7 +21,6 @@ int main(void) {
     TAKE(oq_minmax_workspace_bytes); TAKE(oq_minmax_collect_f32); TAKE(oq_minmax_collect_f64);
     TAKE(oq_minmax_many_workspace_bytes); TAKE(oq_minmax_collect_many_f32);
     TAKE(oq_absmax_workspace_bytes); TAKE(oq_absmax_f32); TAKE(oq_hessian_workspace_bytes); TAKE(oq_hessian_accumulate_f32);
-    TAKE(oq_hessian_set_method); TAKE(oq_hessian_method);
     TAKE(oq_rtn_tensor_many_workspace_bytes); TAKE(oq_rtn_tensor_many_f32); TAKE(oq_pack_matmul_nbits);
     TAKE(oq_gptq_prepare_workspace_bytes); TAKE(oq_gptq_prepare_f32); TAKE(oq_gptq_factor_workspace_bytes);
     TAKE(oq_gptq_factor_f32); TAKE(oq_gptq_factor_batched_workspace_bytes); TAKE(oq_gptq_factor_batched_f32); TAKE(oq_gptq_loop_workspace_bytes); TAKE(oq_gptq_loop_f32);
@@ -30,7 +29,7 @@ int main(void) {
     int64_t lo = 0, hi = 0;
     if (oq_qrange(OQ_INT4, 1, 0, &lo, &hi) != OQ_OK || lo != -7 || hi != 7) return 3;              /* _dtypes.py:17-21 */
     if (oq_qrange(OQ_UINT8, 0, 1, &lo, &hi) != OQ_OK || lo != 0 || hi != 127) return 4;            /* _dtypes.py:23-30 */
-    if (strcmp(oq_target_arch(), "gfx950") != 0 || oq_abi_version() != 1) return 5;
+    if (strcmp(oq_target_arch(), "gfx950") != 0 || oq_abi_version() != 2) return 5;
     if (oq_rtn_quantize_f32(NULL, 4, 4, 4, OQ_INT8, OQ_TENSOR, -1, 0, 0, 1.0f, 0, NULL, NULL, NULL, OQ_LAYOUT_KN, NULL, 0, NULL)
         != OQ_ERR_INVALID_ARGUMENT) return 6;
     if (strstr(oq_last_error(), "null pointer") == NULL) return 7;

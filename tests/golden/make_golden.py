@@ -1065,6 +1065,20 @@ def gen_digests(out):
     d["int4_g128_4096"] = dict(k=4096, n=4096, seed=5, kind="normal", qtype="int4",
                                strategy="group", group_size=128, symmetric=False,
                                w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(s), z_sha=sha16(z))
+    # round 4: the reference's DEFAULT strategies on the headline matrix (bench.py `strategies`), and the packed int4 [K, N]
+    # serialisation (core/_pack.py:8-22 on what _rtn_quantize returns) of the int4 g128 configurations (configs 4 / 5)
+    w = weight("normal", 0, 4096, 11008)
+    for strategy in ("channel", "tensor"):
+        q, s, z = rtn_call(w, "int8", strategy, -1, False, False, 1.0, False)
+        d[f"headline_int8_{strategy}"] = dict(k=4096, n=11008, seed=0, kind="normal", qtype="int8", strategy=strategy, group_size=-1,
+                                              symmetric=False, w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(np.asarray(s)),
+                                              z_sha=sha16(np.asarray(z)))
+    for qtype in ("int4", "uint4"):
+        q, s, z = rtn_call(w, qtype, "group", 128, False, False, 1.0, False)
+        packed = R.pack.pack(q, QT[qtype])
+        d[f"headline_{qtype}_g128_packed"] = dict(k=4096, n=11008, seed=0, kind="normal", qtype=qtype, strategy="group", group_size=128,
+                                                  symmetric=False, w_sha=sha16(w), q_sha=sha16(q), packed_sha=sha16(packed),
+                                                  packed_bytes=int(packed.size), s_sha=sha16(s), z_sha=sha16(z))
     with open(os.path.join(out, "digests.json"), "w") as f:
         json.dump(d, f, indent=1)
     print("digests: ok")

@@ -30,3 +30,17 @@ def test_bench_runs_the_multi_rank_path_on_one_gpu(ranks):
     assert all(b["ok"] for b in q["verification"]["by_rank"])
     assert q["verification"]["gathered_equals_senders"] is True          # the streamed gather delivered the senders' bytes
     assert q["gather_bytes"] > 0 and q["cpu_baseline" if "cpu_baseline" in q else "value"] is not None
+
+
+@pytest.mark.gpu
+def test_bench_gptq_padded_gather_switch_on_one_gpu():
+    """`--gather padded`: the fallback of the streamed point-to-point gather -- one padded collective gather
+    after the last kernel -- through the same two-rank run; what arrives on rank 0 equals what the senders hold."""
+    env = dict(os.environ, OQ_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29661")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gptq-layers", "2",
+                        "--gptq-gather", "padded", "--gptq-extra-passes", "", "--no-model-rtn", "--no-awq", "--no-calibration", "--no-seam"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    q = json.loads(r.stdout.strip().splitlines()[-1])["gptq"]
+    assert q["n_gpus"] == 2 and q["ranks_seen"] == 2 and q["verified"] is True
+    assert "padded" in q["gather_how"] and q["verification"]["gathered_equals_senders"] is True and q["gather_bytes"] > 0

@@ -165,3 +165,29 @@ def test_gpu_errors_are_loud():
         ops.hqq_quantize(torch.zeros((64, 64)), 32)
     with pytest.raises(ValueError, match="cannot reshape"):
         ops.hqq_quantize(torch.zeros((10, 3), device="cuda"), 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("g", [16, 32, 64, 128])
+def test_gpu_one_pass_route_gives_the_per_round_route_s_bits(g):
+    """all rounds of a row out of registers in one pass over W (hqq_rounds_reg_kernel + the replayed
+    decisions) against one launch pair per round (W re-read every round): the same zero points, integers and round counts,
+    bit for bit -- with and without early stop, with an early stop that really triggers (a huge kappa makes the error rise
+    after a few rounds), ragged columns, a leading dimension, and the blob layout."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    gen = torch.Generator(device="cuda").manual_seed(40 + g)
+    big = torch.randn((512, 600), generator=gen, device="cuda") * (0.5 + torch.rand(600, generator=gen, device="cuda"))
+    for w in (big[:, :520], big[:256, 8:8 + 132]):            # ldw = 600; N % 256 != 0, N % 4 == 0 / != 0 mixes
+        for kwargs in (dict(), dict(early_stop=False, iters=9), dict(kappa=3.0, iters=12), dict(iters=1), dict(reduce_range=True)):
+            a = ops.hqq_quantize(w, g, **kwargs)
+            b = ops.hqq_quantize(w, g, per_round_launches=True, **kwargs)
+            assert int(a[3]) == int(b[3]) >= 1, (g, kwargs, int(a[3]), int(b[3]))
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]), (g, kwargs)
+        ab = ops.hqq_quantize(w, g, layout="nbits")
+        bb = ops.hqq_quantize(w, g, layout="nbits", per_round_launches=True)
+        assert torch.equal(ab[0], bb[0]) and torch.equal(ab[2], bb[2])
+    # more rounds than the one-pass kernel holds: the per-round route takes over, silently and with the same contract
+    c = ops.hqq_quantize(big[:, :520], g, iters=40, early_stop=False)
+    d = ops.hqq_quantize(big[:, :520], g, iters=40, early_stop=False, per_round_launches=True)
+    assert int(c[3]) == 40 and torch.equal(c[2], d[2]) and torch.equal(c[0], d[0])

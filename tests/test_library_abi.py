@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(lib_path):
         assert hasattr(lib, name), f"{name} is declared in include/oq_hip.h but not exported"
     lib.oq_target_arch.restype = ctypes.c_char_p
     assert lib.oq_target_arch() == b"gfx950"
-    assert lib.oq_abi_version() == 1
+    assert lib.oq_abi_version() == 2
 
 
 def test_code_object_is_gfx950(lib_path, tmp_path):
@@ -90,12 +90,16 @@ def test_host_only_entry_points(lib_path):
     dummy = (C.c_float * 4)()
     info = (C.c_int32 * 4)()
     for count, stride, needle in ((0, 16, b"bad argument"), (70000, 16, b"bad argument"), (2, 8, b"overlap")):
-        st = lib.oq_gptq_factor_batched_f32(dummy, 4, stride, count, 0.01, 0, dummy, stride, info, dummy, 16, None)
+        st = lib.oq_gptq_factor_batched_f32(dummy, 4, stride, count, 0.01, 0, dummy, stride, info, 0, dummy, 16, None)
         assert st == -1 and needle in lib.oq_last_error(), (count, stride, lib.oq_last_error())
-    st = lib.oq_gptq_factor_batched_f32(dummy, 4, 16, 2, 0.01, 0, dummy, 16, info, dummy, 16, None)
+    st = lib.oq_gptq_factor_batched_f32(dummy, 4, 16, 2, 0.01, 0, dummy, 16, info, 0, dummy, 16, None)
     assert st == -3 and b"workspace" in lib.oq_last_error()
-    assert lib.oq_hessian_set_method(5) == -1 and lib.oq_hessian_set_method(4) == 0 and lib.oq_hessian_method() == 4
-    assert lib.oq_hessian_set_method(0) == 0
+    # ABI 2: the method is an argument (no process-wide setter is exported any more); unknown values are refused per call
+    assert not hasattr(lib, "oq_hessian_set_method") and not hasattr(lib, "oq_hessian_method")
+    st = lib.oq_gptq_factor_batched_f32(dummy, 4, 16, 2, 0.01, 0, dummy, 16, info, 7, dummy, 16, None)
+    assert st == -1 and b"unknown method" in lib.oq_last_error()
+    st = lib.oq_hessian_accumulate_f32(dummy, 4, 4, 4, 0, 1, dummy, 9, None, 0, None)
+    assert st == -1 and b"unknown method" in lib.oq_last_error()
 
 
 def test_missing_library_is_loud(monkeypatch, tmp_path):
@@ -198,14 +202,29 @@ full = np.empty((11008, 32, 128), np.uint8); full[..., 0::2] = b & 0x0F; full[..
 out["nbits"] = [sha(full.reshape(11008, 4096).T), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
 q, s, z = ops.rtn_quantize(w, "uint4", "group", 128, layout="kn")
 out["kn"] = [sha(q.cpu().numpy()), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
+# the GPTQ path: Hessian, factor, corrected loop (VERDICT r03 item 7: OQ_HESSIAN_METHOD / OQ_GPTQ_ROWS16 / OQ_SYRK_F16_M16 used to
+# be read by the shipped library; they must now change nothing)
+g = torch.Generator(device="cuda").manual_seed(3)
+x = torch.randn((4, 512, 1024), generator=g, device="cuda") * (1 + torch.arange(1024, device="cuda") % 7)
+wg = torch.randn((1024, 256), generator=g, device="cuda") * 0.05
+h = torch.zeros((1024, 1024), device="cuda")
+ops.hessian_accumulate(x, h, 0)
+q, s, z, _ = ops.gptq_quantize(wg, h, "int4", "group", 128, mode="corrected")
+out["gptq"] = [sha(h.cpu().numpy()), sha(q.cpu().numpy()), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
 print(json.dumps(out))
 '''
     with open(os.path.join(root, "tests", "golden", "digests.json")) as f:
         d = json.load(f)["config2_asym"]
     expect = [d["q_sha"], d["s_sha"], d["z_sha"]]
-    for nt in ("56", "127", "120"):
-        env = dict(os.environ, OQ_RTN_NT=nt, PYTHONPATH=root)
+    gptq_bytes = None
+    hostile = [dict(OQ_RTN_NT="56"), dict(OQ_RTN_NT="127"), dict(OQ_RTN_NT="120", OQ_RTN_RESIDENT="0", OQ_RTN_RES_TILE="32"),
+               dict(OQ_HESSIAN_METHOD="1", OQ_GPTQ_ROWS16="0", OQ_SYRK_F16_M16="0", OQ_SYRK_SPLITS="1"), dict()]
+    for knobs in hostile:
+        clean = {k: v for k, v in os.environ.items() if not k.startswith("OQ_")}
+        env = dict(clean, PYTHONPATH=root, **knobs)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         got = json.loads(r.stdout.strip().splitlines()[-1])
-        assert got["nbits"] == expect and got["kn"] == expect, (nt, got)
+        assert got["nbits"] == expect and got["kn"] == expect, (knobs, got)
+        gptq_bytes = gptq_bytes or got["gptq"]
+        assert got["gptq"] == gptq_bytes, (knobs, got["gptq"], gptq_bytes)     # Hessian, integers, scales, zero points: the same bits

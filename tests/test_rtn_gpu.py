@@ -119,7 +119,7 @@ def test_config1_plumbing(ops):
 
 
 @pytest.mark.parametrize("key", ["config2_asym", "config2_sym", "config2_heavy", "config2_zero_groups",
-                                 "channel_4096", "int4_g128_4096"])
+                                 "channel_4096", "int4_g128_4096", "headline_int8_channel", "headline_int8_tensor"])
 def test_full_size_digests(ops, key):
     """BASELINE.json configs[1] (4096x11008 uint4 g128) and friends at full size, against digests
     of what the reference itself produced (tests/golden/make_golden.py::gen_digests)."""
@@ -667,3 +667,50 @@ def test_ptrs_entry_point_with_outputs_anywhere_in_memory(layout):
     assert st == L.OQ_ERR_INVALID_ARGUMENT
     with pytest.raises(ValueError):
         ops.rtn_quantize_many([torch.zeros((g, 0), device="cuda")], "uint4", g)
+
+
+@pytest.mark.parametrize("qtype", ["int4", "uint4"])
+@pytest.mark.parametrize("shape,g", [((256, 1024), 128), ((128, 264), 16), ((512, 132), 64), ((96, 520), 32), ((512, 2056), 256),
+                                     ((384, 256), 128), ((64, 8), 2)])
+def test_packed_int4_kn_layout_is_the_reference_pack_of_the_kn_result(ops, qtype, shape, g):
+    """OQ_LAYOUT_KN_PACKED4: the fused group kernel's epilogue writes core/_pack.py:8-22's serialisation of
+    the [K, N] result directly -- N % 8 == 0 takes the dword stores (lane pairs exchange their byte pairs), N % 8 == 4 the
+    two-byte ones, RPW != 16 (g = 2, 32 with 4 waves, 256) the generic form.  Checked against the oracle's `pack_nibbles` of
+    the oracle's integers (pinned by the reference's own packing KATs) and against the unpacked GPU result."""
+    k, n = shape
+    rng = np.random.default_rng(k * 7 + n + g)
+    w = rng.standard_t(3, size=(k, n)).astype(np.float32)
+    for sym, red in ((False, False), (True, False), (False, True)):
+        qp, s, z = ops.rtn_quantize(dev(w), qtype, "group", g, sym, red, 1.0, layout="kn_packed4")
+        eq, es, ez = O.rtn_quantize(w, qtype, "group", g, sym, red)
+        assert qp.shape == (k, n // 2) and qp.dtype.is_floating_point is False
+        np.testing.assert_array_equal(qp.cpu().numpy().reshape(-1), O.pack_nibbles(eq))
+        assert s.cpu().numpy().tobytes() == es.tobytes()
+        np.testing.assert_array_equal(z.cpu().numpy(), ez)
+        q1, _, _ = ops.rtn_quantize(dev(w), qtype, "group", g, sym, red, 1.0)
+        assert ops.pack_nibbles(q1).cpu().numpy().tobytes() == qp.cpu().numpy().tobytes()
+
+
+def test_packed_int4_kn_layout_refuses_what_it_cannot_write(ops):
+    import torch
+    w = torch.randn((256, 128), device="cuda")
+    with pytest.raises(Exception, match="KN_PACKED4|4-bit"):
+        ops.rtn_quantize(w, "int8", "group", 128, layout="kn_packed4")
+    with pytest.raises(Exception, match="KN_PACKED4"):
+        ops.rtn_quantize(w, "uint4", "channel", -1, layout="kn_packed4")
+    with pytest.raises(ValueError):
+        ops.rtn_quantize(w, "uint4", "group", 128, layout="nope")
+
+
+@pytest.mark.parametrize("key", ["headline_int4_g128_packed", "headline_uint4_g128_packed"])
+def test_packed_int4_full_size_digest(ops, key):
+    """The 4096 x 11008 matrix, int4 / uint4 g128: the kernel's packed [K, N/2] bytes against the digest of
+    `core/_pack.py::pack(_rtn_quantize(...))` run by the reference itself (make_golden.py::gen_digests)."""
+    d = DIGESTS[key]
+    w = synth_weight(d["kind"], d["seed"], d["k"], d["n"])
+    q, s, z = ops.rtn_quantize(dev(w), d["qtype"], "group", d["group_size"], layout="kn_packed4")
+    assert q.numel() == d["packed_bytes"]
+    assert sha16(q.cpu().numpy()) == d["packed_sha"]
+    assert sha16(s.cpu().numpy()) == d["s_sha"] and sha16(z.cpu().numpy()) == d["z_sha"]
+    many = ops.rtn_quantize_many([dev(w), dev(w)], d["qtype"], d["group_size"], layout="kn_packed4")
+    assert all(sha16(m[0].cpu().numpy()) == d["packed_sha"] for m in many)

@@ -339,3 +339,54 @@ def test_streamed_gather_single_rank_and_layout_check():
         sg.push(b, {i: res[i] for i in idx})
     out, nbytes = sg.finish()
     assert list(out) == ["a", "b"] and nbytes == 0 and out["b"][1].shape == (6,)
+
+
+def _worker_missing_peer(rank, world, port, q):
+    """Rank 1 never reaches the rendezvous: rank 0's bounded wait names it instead of hanging."""
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch.distributed as dist
+
+    from onnx_quantize_amd.sharding import PeersMissing, await_all_ranks, connect_to_rank0
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 0:
+        t0 = time.time()
+        try:
+            await_all_ranks("t/missing", timeout_s=2.0)
+            q.put(("no error", None, 0.0))
+        except PeersMissing as e:
+            q.put(("missing", e.missing, time.time() - t0))
+        try:
+            connect_to_rank0(timeout_s=2.0)          # the same bounded wait in front of the point-to-point handshake
+            q.put(("no error", None, 0.0))
+        except PeersMissing as e:
+            q.put(("missing", e.missing, 0.0))
+        await_all_ranks("t/late", timeout_s=60.0)    # everybody arrives eventually: returns the world size
+        q.put(("seen", await_all_ranks("t/again", timeout_s=60.0), 0.0))
+    else:
+        time.sleep(8.0)
+        await_all_ranks("t/late", timeout_s=60.0)
+        await_all_ranks("t/again", timeout_s=60.0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bounded_rendezvous_names_the_missing_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_missing_peer, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    first = q.get(timeout=60)
+    assert first[0] == "missing" and first[1] == [1] and first[2] < 6.0, first
+    second = q.get(timeout=60)
+    assert second[0] == "missing" and second[1] == [1], second
+    assert q.get(timeout=90) == ("seen", 2, 0.0)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
