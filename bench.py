@@ -664,6 +664,45 @@ def main() -> None:
         torch.cuda.synchronize()
         del oq
 
+    # the packed [K, N/2] layout of the int4 configurations (configs 4 / 5 are QInt4: not MatMulNBits-eligible, the reference
+    # serialises their [K, N] integers two per byte, core/_pack.py:8-22): written by the fused kernel's epilogue
+    packed_kn = None
+    if world == 1 and not args.qparams_only and not args.no_extras and not args.symmetric:
+        pq = torch.empty(K_DIM * N_DIM // 2, dtype=torch.uint8, device=dev)
+        pz = torch.empty(groups, dtype=torch.int8, device=dev)
+        pqp, pzp = C.c_void_p(pq.data_ptr()), C.c_void_p(pz.data_ptr())
+
+        def pstep(i: int) -> None:
+            wp, _, sp, _ = calls[i % len(calls)]
+            st = fn(wp, K_DIM, N_DIM, N_DIM, L.OQ_INT4, L.OQ_GROUP, GROUP, 0, 0, 1.0, 0, pqp, sp, pzp, L.OQ_LAYOUT_KN_PACKED4, wsp, wsn, stream)
+            if st != 0:
+                L.check(st)
+        for i in range(10):
+            pstep(i)
+        torch.cuda.synchronize()
+        p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p0.record()
+        for i in range(100):
+            pstep(i)
+        p1.record()
+        torch.cuda.synchronize()
+        p_us = p0.elapsed_time(p1) * 10.0
+        palg = algorithmic_bytes("nbits")            # W once + half a byte per value + (scale, zero point) per group: the same count
+        packed_kn = {"what": "int4 g128 RTN of the same matrix in OQ_LAYOUT_KN_PACKED4 ([K, N/2] nibble pairs, core/_pack.py order), "
+                             "rtn_group_fused<16> + transpose_qparams; 22.5 MB of integers written instead of 45",
+                     "qtype": "int4", "launch_us": round(p_us, 2), "achieved_GBs": round(palg / (p_us * 1e-6) / 1e9, 1),
+                     "frac": round(palg / (p_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        if rank == 0:
+            with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+                dpk = json.load(f).get("headline_int4_g128_packed")
+            if dpk is not None:
+                packed_kn["verified_vs_reference_digest"] = bool(sha16(pq.cpu().numpy()) == dpk["packed_sha"] and
+                                                                  sha16(pz.cpu().numpy()) == dpk["z_sha"])
+        for i in range(len(calls)):          # the scales of the headline outputs were overwritten (shared buffers): restore
+            step(i)
+        torch.cuda.synchronize()
+        del pq, pz
+
     # batched entry point: `--batch-extra` matrices per launch (stacked weights); reported separately
     batched = None
     if world == 1 and not args.qparams_only and not args.no_extras and args.batch_extra > 1:
@@ -840,6 +879,7 @@ def main() -> None:
                          "what": "`frac` is BASELINE's single-matrix regime: 4 rotating output sets (96 MB) stay in the 256 MiB Infinity "
                                  "Cache between steps; here 12 sets (291 MB) force every output byte to HBM, as inside a model-sized call"},
                      "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved_bytes(args.layout)},
+        "packed_kn_layout": packed_kn,
         "strategies": strategies,
         "seam": seam,
         "gather": gather,
