@@ -22,9 +22,11 @@
 // consecutive tickets, are loaded at about the same time by different workgroups, and every one of them waits for its
 // siblings' partial ranges before it quantizes: one read of W, no second pass.
 // `rtn_tensor_onepass`: per-tensor.  Phase A streams all tiles once (running min / max in registers, no barrier per tile);
-// every workgroup KEEPS the last tile it loaded; when all tiles are counted the kept tiles are quantized from registers
-// and the others are re-read in reverse order (most recently read first: the Infinity Cache still holds them).  A matrix
-// of up to (resident workgroups) tiles -- 64 MB on this chip -- is read exactly once.
+// every workgroup KEEPS the last tile it loaded in registers and the first half of the one before in LDS (96 MB of the
+// matrix stay on the chip); one returning add per workgroup counts the tiles and hands out an arrival slot for its partial
+// range and the ids of the tiles it keeps; the workgroup that completes the count folds the slots and broadcasts {go, keys};
+// kept tiles are quantized from registers / LDS, the other half tiles are dealt out statically (no tickets, no barriers)
+// and re-read most-recent-first: the Infinity Cache still holds them.  A matrix of up to 768 tiles is read exactly once.
 #include "oq_common.hpp"
 
 #include <cstdlib>
@@ -39,10 +41,13 @@ constexpr int kResRows = 16;                      // rows per wave
 constexpr int kResTileRows = kResWaves * kResRows;  // 128, the chunk height of the two-pass path (rtn.hip kChunkRows)
 constexpr int kResCols = 256;                     // 64 lanes x 4 columns
 constexpr int kResHeader = 160;
-constexpr int kResMaxTensorTiles = 65536;         // bitmap of kept tiles in LDS (8 KB): 2 G parameters; larger tensors take the three-launch path
+constexpr int kResMaxTensorTiles = 32768;         // bitmap of kept half tiles in LDS (8 KB): 1 G parameters; larger tensors take the three-launch path
 constexpr int kResTensorHeader = 128 + 64 * 32 + 64 * 32;   // tickets / counter, 64 key shards, 64 result replicas (a 128-byte line each)
 constexpr int kResGroupTileRows = 128;            // default tile height of rtn_resident_groups (see groups_tile_rows)
 constexpr int kResCtrPad = 32;                   // uint32 words per range counter: a 128-byte line each (hundreds of workgroups poll them)
+#ifndef OQ_RES_A_NT
+#define OQ_RES_A_NT false   /* default-policy loads in phase A keep the lines in the Infinity Cache for phase B: 75 us against 78 with nt */
+#endif
 #ifndef OQ_RES_SLEEP
 #define OQ_RES_SLEEP 8
 #endif                   // uint32 words in front of the arrays: tickets, keys, counter on 128-byte lines of their own
@@ -61,7 +66,7 @@ struct ResidentArgs {
     uint32_t* key_nmin;   // [slots] complement of the ordered key of the running minimum (kept as a maximum)
     uint32_t* counters;   // groups: one per (column tile, k-group); tensor: [0] = tiles counted
     uint32_t* tickets;    // [0] phase A, [32] phase B
-    uint32_t* held;       // tensor: bitmap over tiles, 1 = quantized from its owner's registers
+    uint32_t* held;       // tensor: bitmap over HALF tiles (bit 2 t + h), 1 = quantized from its owner's registers / LDS
 };
 
 __device__ __forceinline__ uint32_t okey_plain(float x) {   // monotone float -> uint32 for everything but NaN
@@ -263,16 +268,23 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
 // resident workgroups is; a workgroup that starts late finds no ticket, adds nothing and waits like the others.  Phase B
 // never waits either.
 // ---------------------------------------------------------------------------------------------
+constexpr int kParkWaves = kResWaves / 2;                        // the waves whose rows (the first half of a tile) are parked in LDS
+constexpr int kParkBytes = kParkWaves * kResRows * kWave * 16;   // 64 KB
+constexpr int kHalfRows = kResTileRows / 2;                      // phase-B unit: half a tile, 8 rows per wave
+
 __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const ResidentArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char park_lds[];   // kParkBytes: [wave < 4][row 16][lane 64] x 16 B
     __shared__ float s_mn[kResWaves], s_mx[kResWaves];
-    __shared__ uint32_t s_ticket, s_keys[2], s_first_b;
-    __shared__ uint32_t s_held[kResMaxTensorTiles / 32];
+    __shared__ uint32_t s_ticket, s_keys[3];
+    __shared__ uint32_t s_held[kResMaxTensorTiles / 16];          // two bits per tile: its halves
+    __shared__ uint32_t s_pref[kResMaxTensorTiles / 16], s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t ntiles = a.ntiles, ncol = a.ncol_tiles;
+    const uint32_t ntiles = a.ntiles, ncol = a.ncol_tiles, nunits = 2u * ntiles;
+    float4* park = reinterpret_cast<float4*>(park_lds) + (wave * kResRows) * kWave + lane;   // this lane's slot of row 0 (waves < 4 only)
 
     float v[kResRows][4];
     float rmn = INFINITY, rmx = -INFINITY;
-    uint32_t processed = 0, mine = 0xFFFFFFFFu;
+    uint32_t processed = 0, mine = 0xFFFFFFFFu, parked = 0xFFFFFFFFu;
     bool first = false;
     if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
     __syncthreads();
@@ -281,9 +293,18 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
     first = t == 0;
     while (t < ntiles) {
         if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // the next ticket travels while this tile loads
+        if (processed > 0 && wave < kParkWaves) {
+            // The tile in `v` is about to be overwritten: its first half (the rows of waves 0-3) is parked in LDS.  If the
+            // tile that is loaded now turns out to be this workgroup's last one, the parked half needs no second read either:
+            // 64 KB of registers + 64 KB of LDS per workgroup = 96 MB of the matrix stay on the chip across the hand-off.
+#pragma unroll
+            for (int r = 0; r < kResRows; ++r) park[r * kWave] = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        }
+        if (processed > 0) parked = mine;
+        mine = t;
         const uint32_t row_tile = t / ncol, col_tile = t - row_tile * ncol;
         const int64_t row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows;
-        load_tile<false>(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
+        load_tile<OQ_RES_A_NT>(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
 #pragma unroll
         for (int r = 0; r < kResRows; ++r)
 #pragma unroll
@@ -295,18 +316,18 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         __syncthreads();
         const uint32_t nxt = s_ticket;
         __syncthreads();
-        if (nxt >= ntiles) { mine = t; break; }   // uniform: the tile in `v` is this workgroup's last one and stays
+        if (nxt >= ntiles) break;   // uniform: the tile in `v` (`mine`) is this workgroup's last one and stays
         t = nxt;
     }
-    // Publish: 512 workgroups adding to ONE key pair and polling ONE counter serialise at the memory side (an atomic on a
-    // contended line takes 11-13 ns: MI355X_MICROARCH.md "fanin"; the first build of this kernel spent 40 us here).  So the
-    // partial ranges go to 64 shards, the tiles are counted on one word by ONE returning add per workgroup, and the
-    // workgroup whose add completes the count folds the shards and broadcasts the result with a "go" word to 64 replica
-    // lines; everybody polls its own replica (8 pollers per line).
-    uint32_t* shard = a.key_max + (blockIdx.x & 63u) * 32u;          // {max key, complemented min key} of this shard
+    // Publish.  512 workgroups adding to ONE key pair and polling ONE counter serialise at the memory side (an atomic on a
+    // contended line takes 11-13 ns: MI355X_MICROARCH.md "fanin"; the first build of this kernel spent 40 us here).  So: ONE
+    // returning add per workgroup counts its tiles (low 16 bits) and hands out an arrival number (high bits); the partial
+    // range goes, as one 16-byte store {1, max key, min key}, into the slot of that number -- no atomics on shared keys, no
+    // drain in front of the add; the workgroup whose add completes the count reads the slots of all arrivals (re-reading the
+    // rare one whose store is still in flight), folds them and broadcasts {go, keys} to 64 replica lines; everybody polls
+    // its own replica (8 pollers per line).
     uint32_t* replica = a.key_nmin + (blockIdx.x & 63u) * 32u;      // {go, final max key, final complemented min key}
     if (processed) {
-        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.held + (mine >> 5), 1u << (mine & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         rmn = wave_min(rmn);
         rmx = wave_max(rmx);
         if (lane == 0) { s_mn[wave] = rmn; s_mx[wave] = rmx; }
@@ -314,31 +335,47 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int w = 1; w < kResWaves; ++w) { rmn = nmin(rmn, s_mn[w]); rmx = nmax(rmx, s_mx[w]); }
-            agent_max(shard, key_of_max(rmx));
-            agent_max(shard + 1, key_of_min(rmn));
-            drain_vmem();                          // range and `held` flag are performed before the tiles are counted
-            const uint32_t before = agent_add(a.counters, processed);
-            s_ticket = (before + processed == ntiles) ? 1u : 0u;
+            const uint32_t before = agent_add(a.counters, (1u << 16) | processed);
+            const uint32_t arrival = before >> 16;
+            // the slot also says which tiles this workgroup keeps (registers: `mine`, both halves; LDS: the first half of
+            // `parked`): everybody builds the bitmap of kept halves from the slots, no shared bitmap, no atomics, no drain
+            const u32x4r slot = {key_of_max(rmx), key_of_min(rmn), mine + 1u, parked + 1u /* 0: none */};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(a.key_max + arrival * 4u), "v"(slot) : "memory");
+            s_ticket = ((before & 0xffffu) + processed == ntiles) ? arrival + 1u : 0u;   // the last finisher learns how many arrived
         }
         __syncthreads();
-        if (s_ticket != 0u && wave == 0) {         // the last finisher: every other workgroup's shard update precedes its add
-            uint32_t kmx = agent_load(a.key_max + lane * 32), kmn = agent_load(a.key_max + lane * 32 + 1);
+        const uint32_t arrivals = s_ticket;
+        if (arrivals != 0u) {                      // the last finisher (uniform over the workgroup): one slot per thread
+            uint32_t kmx = 0u, kmn = 0u;
+            if (threadIdx.x < arrivals) {
+                u32x4r line;
+                do {
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(line) : "v"(a.key_max + threadIdx.x * 4u) : "memory");
+                } while (line[2] == 0u);
+                kmx = line[0];
+                kmn = line[1];
+            }
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 kmx = max(kmx, static_cast<uint32_t>(__shfl_xor(static_cast<int>(kmx), off, 64)));
                 kmn = max(kmn, static_cast<uint32_t>(__shfl_xor(static_cast<int>(kmn), off, 64)));
             }
-            uint32_t* rep = a.key_nmin + lane * 32;
-            __hip_atomic_store(rep + 1, kmx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(rep + 2, kmn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            drain_vmem();
-            __hip_atomic_store(rep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) { s_mn[wave] = __uint_as_float(kmx); s_mx[wave] = __uint_as_float(kmn); }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int w = 0; w < kResWaves; ++w) { kmx = max(kmx, __float_as_uint(s_mn[w])); kmn = max(kmn, __float_as_uint(s_mx[w])); }
+                // {go, max key, min key} as ONE 16-byte agent-scope store per replica: a 16-byte piece of a line is written by
+                // one request (MI355X_MICROARCH.md: 16-byte sc1 granules are observed untorn), so no drain between keys and `go`
+                uint32_t* rep = a.key_nmin + lane * 32;
+                const u32x4r line = {1u, kmx, kmn, arrivals};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(rep), "v"(line) : "memory");
+            }
         }
     }
     // One 16-byte agent-scope load per poll returns {go, max key, min key} together (the keys were performed before `go`
     // was stored, and a 16-byte piece of a line is read in one request), so no second round trip for the keys.
     if (threadIdx.x == 0) {
-        const uint32_t first_b = agent_add(a.tickets + 32, 1u);   // returns while this thread polls
         u32x4r line;
         do {
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(line) : "v"(replica) : "memory");
@@ -346,9 +383,15 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         } while (line[0] == 0u);
         s_keys[0] = line[1];
         s_keys[1] = line[2];
-        s_first_b = first_b;
+        s_keys[2] = line[3];      // how many workgroups arrived = how many slots describe kept tiles
     }
+    // Every slot is complete once `go` is up (the last finisher read them all).  One slot per thread: its load is issued here
+    // and lands while the kept tiles are quantized below; the bitmap of kept halves is then built in LDS from the slots.
     __syncthreads();
+    u32x4r my_slot = {0u, 0u, 0u, 0u};
+    if (threadIdx.x < s_keys[2])
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(my_slot) : "v"(a.key_max + threadIdx.x * 4u) : "memory");
+    for (uint32_t i = threadIdx.x; i < (nunits + 31u) / 32u; i += kResWaves * kWave) s_held[i] = 0u;
     const float gmx = max_of_key(s_keys[0]), gmn = min_of_key(s_keys[1]);
     const int32_t bias = a.grid.qmin < 0 ? 128 : 0;
     ColQ cq[4];
@@ -362,26 +405,76 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         const uint32_t row_tile = mine / ncol, col_tile = mine - row_tile * ncol;
         quantize_store_tile(a, cq, v, static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows, a.K,
                             static_cast<int64_t>(col_tile) * kResCols, lane);
-    }
-    // Phase B: what nobody kept, most recently read first.  The bitmap of kept tiles is complete (every owner set its bit
-    // before it counted its tiles) and is read once into LDS: a flag load per tile would put a memory round trip in front
-    // of every tile's loads.
-    for (uint32_t i = threadIdx.x; i < (ntiles + 31u) / 32u; i += kResWaves * kWave) s_held[i] = agent_load(a.held + i);
-    __syncthreads();
-    uint32_t tb = s_first_b;      // taken before the wait (below the publish): phase B's order does not matter, its latency does
-    __syncthreads();
-    while (tb < ntiles) {
-        if (threadIdx.x == 0) s_ticket = agent_add(a.tickets + 32, 1u);
-        const uint32_t tile = ntiles - 1u - tb;
-        if (((s_held[tile >> 5] >> (tile & 31u)) & 1u) == 0u) {   // block-uniform
-            const uint32_t row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
-            const int64_t row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows;
-            load_tile(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
-            quantize_store_tile(a, cq, v, row0, a.K, static_cast<int64_t>(col_tile) * kResCols, lane);
+        if (parked != 0xFFFFFFFFu && wave < kParkWaves) {   // the parked half: back from LDS into the same lanes' registers
+#pragma unroll
+            for (int r = 0; r < kResRows; ++r) {
+                const float4 x = park[r * kWave];
+                v[r][0] = x.x; v[r][1] = x.y; v[r][2] = x.z; v[r][3] = x.w;
+            }
+            const uint32_t prow = parked / ncol, pcol = parked - prow * ncol;
+            quantize_store_tile(a, cq, v, static_cast<int64_t>(prow) * kResTileRows + wave * kResRows, a.K,
+                                static_cast<int64_t>(pcol) * kResCols, lane);
         }
-        __syncthreads();
-        tb = s_ticket;
-        __syncthreads();
+    }
+    // Phase B: the half tiles nobody kept.  No tickets and no barriers any more: the bitmap is the same for everybody, so
+    // the unheld halves are dealt out statically -- the j-th unheld half (counted from the END: most recently read first, the
+    // Infinity Cache still holds them) goes to team j mod (2 x workgroups), a team = four waves = 64 rows x 256 columns with
+    // 16 loads per lane in flight.  (With whole tiles per ticket and a barrier per tile this phase took two rounds of 12 us
+    // for 1.7 tiles per workgroup; half tiles of 8 rows per wave were slower still: half the loads in flight.)
+    // Safe without residency assumptions: nobody waits in this phase; a workgroup that starts late does its share late.
+    const uint32_t nwords = (nunits + 31u) / 32u;
+    __syncthreads();                                   // s_held zeroed
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_slot) : : "memory");
+    if (my_slot[2] != 0u) {
+        const uint32_t u = 2u * (my_slot[2] - 1u);
+        atomicOr(&s_held[u >> 5], 3u << (u & 31u));
+        if (my_slot[3] != 0u) {
+            const uint32_t up = 2u * (my_slot[3] - 1u);
+            atomicOr(&s_held[up >> 5], 1u << (up & 31u));
+        }
+    }
+    __syncthreads();                                   // s_held complete
+    if (wave == 0) {                                   // s_pref[w] = unheld halves in words [0, w); 32 words per lane
+        uint32_t cnt = 0;
+        const uint32_t w0 = lane * (kResMaxTensorTiles / 16 / kWave), w1 = w0 + kResMaxTensorTiles / 16 / kWave;
+        for (uint32_t w = w0; w < w1 && w < nwords; ++w) {
+            uint32_t bits = ~s_held[w];
+            if (w == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
+            cnt += __popc(bits);
+        }
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), off, 64));
+            if (lane >= off) incl += up;
+        }
+        uint32_t run = incl - cnt;
+        for (uint32_t w = w0; w < w1 && w < nwords; ++w) {
+            s_pref[w] = run;
+            uint32_t bits = ~s_held[w];
+            if (w == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
+            run += __popc(bits);
+        }
+        if (lane == 63) s_total = incl;
+    }
+    __syncthreads();
+    const uint32_t total = s_total;
+    const uint32_t team = blockIdx.x * 2u + (wave >> 2), nteams = gridDim.x * 2u;
+    for (uint32_t j = team; j < total; j += nteams) {
+        const uint32_t want = total - 1u - j;          // rank of the unit among the unheld ones, ascending
+        uint32_t lo = 0, hi = nwords - 1u;             // last word whose prefix is <= want
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1u) >> 1;
+            if (s_pref[mid] <= want) lo = mid; else hi = mid - 1u;
+        }
+        uint32_t bits = ~s_held[lo];
+        if (lo == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
+        for (uint32_t skip = want - s_pref[lo]; skip > 0; --skip) bits &= bits - 1u;   // drop the lowest set bits
+        const uint32_t unit = lo * 32u + static_cast<uint32_t>(__builtin_ctz(bits));
+        const uint32_t tile = unit >> 1, row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
+        const int64_t row0 = static_cast<int64_t>(row_tile) * kResTileRows + (unit & 1u) * kHalfRows + (wave & 3) * kResRows;
+        load_tile(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
+        quantize_store_tile(a, cq, v, row0, a.K, static_cast<int64_t>(col_tile) * kResCols, lane);
     }
 }
 
@@ -393,11 +486,11 @@ __global__ __launch_bounds__(256) void clear_words_kernel(uint4* p, uint32_t n16
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int resident_blocks(const void* kernel) {
+static int resident_blocks(const void* kernel, size_t dynamic_lds) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kResWaves * kWave, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kResWaves * kWave, dynamic_lds) != hipSuccess) return 0;
     return cus * per_cu;
 }
 
@@ -420,7 +513,7 @@ static int groups_tile_rows(int64_t g) {
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g) {
     const int64_t kgroups = K / g, chunks = ceil_div(g, groups_tile_rows(g));
     const int64_t ncol_tiles = ceil_div(N, kResCols);
-    if (strategy == OQ_TENSOR) return static_cast<size_t>(kResTensorHeader + ncol_tiles * ceil_div(K, kResTileRows)) * 4 + 256;
+    if (strategy == OQ_TENSOR) return static_cast<size_t>(kResTensorHeader + (2 * ncol_tiles * ceil_div(K, kResTileRows) + 31) / 32 + 1) * 4 + 256;
     (void)chunks;
     return static_cast<size_t>(2 * kgroups * ncol_tiles * kResCols + ncol_tiles * kgroups * kResCtrPad + kResHeader) * 4 + 256;
 }
@@ -457,13 +550,17 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
     if (strategy == OQ_TENSOR) {
         a.ntiles = a.ncol_tiles * static_cast<uint32_t>(ceil_div(K, kResTileRows));
         a.counters = base + 64;                  // tiles counted
-        a.key_max = base + 128;                  // 64 shards x 32 words: {max key, complemented min key}
+        a.key_max = base + 128;                  // one 16-byte slot {1, max key, complemented min key} per arrival (<= 512 workgroups)
         a.key_nmin = base + 128 + 64 * 32;       // 64 replicas x 32 words: {go, final max key, final complemented min key}
         a.held = base + kResTensorHeader;
-        static const int resident = resident_blocks(reinterpret_cast<const void*>(rtn_tensor_onepass));
+        // per launch, not once: the attribute belongs to the current device's copy of the kernel
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rtn_tensor_onepass), hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes) != hipSuccess)
+            return fail(OQ_ERR_LAUNCH, "rtn: %d bytes of LDS refused", kParkBytes);
+        const int resident = resident_blocks(reinterpret_cast<const void*>(rtn_tensor_onepass), kParkBytes);
         OQ_REQUIRE(resident > 0, OQ_ERR_LAUNCH, "rtn: occupancy query failed");
-        const uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
-        hipLaunchKernelGGL(rtn_tensor_onepass, dim3(blocks), dim3(kResWaves * kWave), 0, s, a);
+        uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
+        if (blocks > 512u) blocks = 512u;        // the arrival slots (and one slot per thread of the last finisher)
+        hipLaunchKernelGGL(rtn_tensor_onepass, dim3(blocks), dim3(kResWaves * kWave), kParkBytes, s, a);
         return check_launch("rtn_tensor_onepass");
     }
     const int64_t ranges = static_cast<int64_t>(a.ncol_tiles) * a.kgroups;
