@@ -96,6 +96,21 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
                             float* scale_out, void* zp_out, int32_t layout, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* A1 with caller-kept STATE for the strategies whose range spans several workgroups (per channel, per tensor, groups taller than
+ *     256 rows: rtn_resident.hip).  Those kernels hand work out by tickets and complete ranges through counters and keys in
+ *     device memory that must start from zero; oq_rtn_quantize_f32 clears them in its workspace with a launch of its own (a
+ *     tenth of the call on a 4096 x 11008 matrix).  Here the caller provides `state` (oq_rtn_state_bytes, 16-byte aligned):
+ *     ZERO before the first call that uses it, and left zero by every call (the last workgroup to leave cleans up), so no clear
+ *     launch runs.  One state buffer serves any sequence of calls of any shapes (each call needs its own size) on ONE stream; two
+ *     calls that may run concurrently need two buffers.  state == NULL or too small: exactly oq_rtn_quantize_f32.  A call
+ *     that fails on the device leaves the state undefined. */
+size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size);
+int32_t oq_rtn_quantize_stateful_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,
+                                     int32_t strategy, int64_t group_size, int32_t symmetric,
+                                     int32_t reduce_range, float clip_ratio, int32_t mse, void* q_out,
+                                     float* scale_out, void* zp_out, int32_t layout, void* workspace,
+                                     size_t workspace_bytes, void* state, size_t state_bytes, void* stream);
+
 /* A1 over a strided batch of equally shaped matrices (stacked projection weights, experts, ...): matrix b is
  *     W + b * w_stride (fp32 elements); outputs are packed back to back (q: K*N bytes resp. the blob size per
  *     matrix; scale / zp: N*K/g entries per matrix).  Group strategy, K % group_size == 0, group_size <= 256.

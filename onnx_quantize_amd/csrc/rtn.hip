@@ -1233,7 +1233,7 @@ namespace oq {
 bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, const void* q, int32_t strategy, int64_t g, int32_t layout,
                            bool emit_q, size_t workspace_bytes);
 int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
-                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s);
+                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state);
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
 int32_t rtn_mse_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy,
                      int64_t g, void* q_out, float* scale_out, void* zp_out, int32_t zp_signed, void* workspace,
@@ -1279,6 +1279,9 @@ static int64_t matrices_per_launch(int64_t K, int64_t N, int64_t count) {
 // its call of rtn_impl; 1 matrix otherwise).
 struct BatchCtx { int64_t count = 1, w_stride = 0, q_stride = 0; const RtnPtrs* table = nullptr; };
 static thread_local BatchCtx g_batch;
+// oq_rtn_quantize_stateful_f32: the caller's zeroed, self-cleaning state for the one-read channel / tensor kernels
+struct StateCtx { void* state = nullptr; size_t bytes = 0; };
+static thread_local StateCtx g_state;
 
 int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
                  int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, int32_t mse,
@@ -1443,8 +1446,10 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     // columns taller than 16384 rows) runs on the three launches below
     {
         static const Tuning tr = Tuning::from_env();
+        if (tr.resident != 0 && g_state.state != nullptr && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, g_state.bytes))
+            return rtn_resident_impl(W, K, N, ldw, grid, strategy, g, q8, scale_out, zp8, layout, g_state.state, g_state.bytes, s, true);
         if (tr.resident != 0 && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, workspace ? workspace_bytes : 0))
-            return rtn_resident_impl(W, K, N, ldw, grid, strategy, g, q8, scale_out, zp8, layout, workspace, workspace_bytes, s);
+            return rtn_resident_impl(W, K, N, ldw, grid, strategy, g, q8, scale_out, zp8, layout, workspace, workspace_bytes, s, false);
     }
 
     // two-pass
@@ -1503,6 +1508,29 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
                             void* workspace, size_t workspace_bytes, void* stream) {
     return oq::rtn_impl(W, K, N, ldw, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, mse, q_out,
                         scale_out, zp_out, layout, workspace, workspace_bytes, stream, true);
+}
+
+size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size) {
+    if (K <= 0 || N <= 0) return 0;
+    int64_t g;
+    if (oq::resolve_group(strategy, K, group_size, &g) != OQ_OK || K % g != 0) return 0;
+    int rpw = 0, wpg = 0;
+    if (strategy == OQ_GROUP && oq::fused_shape(g, &rpw, &wpg)) return 0;     // the fused group kernels keep no state
+    return oq::rtn_resident_workspace(K, N, strategy, g);
+}
+
+int32_t oq_rtn_quantize_stateful_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                                     int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio,
+                                     int32_t mse, void* q_out, float* scale_out, void* zp_out, int32_t layout,
+                                     void* workspace, size_t workspace_bytes, void* state, size_t state_bytes, void* stream) {
+    OQ_REQUIRE(state == nullptr || (reinterpret_cast<uintptr_t>(state) & 15u) == 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_rtn_quantize_stateful_f32: state must be 16-byte aligned");
+    oq::g_state.state = state;
+    oq::g_state.bytes = state ? state_bytes : 0;
+    const int32_t st = oq::rtn_impl(W, K, N, ldw, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, mse, q_out, scale_out, zp_out,
+                                    layout, workspace, workspace_bytes, stream, true);
+    oq::g_state = oq::StateCtx();
+    return st;
 }
 
 int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,

@@ -66,7 +66,13 @@ struct ResidentArgs {
     uint32_t* key_nmin;   // [slots] complement of the ordered key of the running minimum (kept as a maximum)
     uint32_t* counters;   // groups: one per (column tile, k-group); tensor: [0] = tiles counted
     uint32_t* tickets;    // [0] phase A, [32] phase B
-    uint32_t* held;       // tensor: bitmap over HALF tiles (bit 2 t + h), 1 = quantized from its owner's registers / LDS
+    uint32_t* held;       // unused since the kept tiles travel in the arrival slots (kept for the layout of the workspace)
+    // Self-cleaning (oq_rtn_quantize_stateful_f32: the caller's `state` is zero when the call starts and zero again when it
+    // ends, so no clear launch runs in front of the kernel): every workgroup counts itself out at `done`; the cleaner --
+    // the one that holds the last ticket / ticket 0 -- waits for all the others and zeroes [clean_base, +clean_words).
+    uint32_t* done;         // nullptr: the state is a plain workspace that the host cleared
+    uint32_t* clean_base;
+    uint32_t clean_words;
 };
 
 __device__ __forceinline__ uint32_t okey_plain(float x) {   // monotone float -> uint32 for everything but NaN
@@ -100,6 +106,15 @@ __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)"
 __device__ __forceinline__ void spin_until(const uint32_t* p, uint32_t target) {
     while (agent_load(p) < target) __builtin_amdgcn_s_sleep(OQ_RES_SLEEP);
 }
+
+// the cleaner's last act: every other workgroup of the grid has left (`expected` of them), nobody reads the state any more
+__device__ __forceinline__ void clean_state(const ResidentArgs& a, uint32_t expected, int nthreads) {
+    if (threadIdx.x == 0) spin_until(a.done, expected);
+    __syncthreads();
+    uint4* p = reinterpret_cast<uint4*>(a.clean_base);
+    for (uint32_t i = threadIdx.x; i < (a.clean_words + 3u) / 4u; i += nthreads) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 
 // 16 rows x 4 columns of a lane, clamped addresses (never a predicated load: rtn.hip).  Rows past `row_end` repeat the
 // last row of the range and columns past N repeat the last four: duplicates of valid elements of the SAME range, so they
@@ -255,6 +270,11 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
         }
     }
     quantize_store_tile<ROWS>(a, cq, v, row0, row_end, tile_col0, lane);
+    if (a.done != nullptr) {   // uniform
+        // every state access of this workgroup is complete (its key loads returned, its counter add was seen by its own poll)
+        if (t + 1u == a.ntiles) clean_state(a, a.ntiles - 1u, WAVES * kWave);
+        else if (threadIdx.x == 0) agent_add(a.done, 1u);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,6 +496,10 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         load_tile(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
         quantize_store_tile(a, cq, v, row0, a.K, static_cast<int64_t>(col_tile) * kResCols, lane);
     }
+    if (a.done != nullptr) {   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
+        if (first) clean_state(a, gridDim.x - 1u, kResWaves * kWave);
+        else if (threadIdx.x == 0) agent_add(a.done, 1u);
+    }
 }
 
 // Tickets, counters and keys start from zero.  hipMemsetAsync's fill kernel took 4.6 us for these ~100 KB (rocprofv3,
@@ -532,7 +556,7 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
 }
 
 int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
-                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
     ResidentArgs a;
     const int tile_rows = groups_tile_rows(g);
     a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = K / g; a.chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : tile_rows);
@@ -541,7 +565,10 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
     const size_t need = rtn_resident_workspace(K, N, strategy, g);
     OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "rtn: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
     uint32_t* base = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~static_cast<uintptr_t>(255));
-    {
+    a.done = nullptr; a.clean_base = base; a.clean_words = static_cast<uint32_t>((need - 256) / 4);
+    if (zeroed_state) {
+        a.done = base + 40;           // a line of its own between the tickets and the counters
+    } else {
         const uint32_t n16 = static_cast<uint32_t>((need - 256 + 15) / 16);   // `need` counts whole words past the aligned base; the +256 slack covers the round-up
         hipLaunchKernelGGL(clear_words_kernel, dim3((n16 + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint4*>(base), n16);
     }

@@ -67,6 +67,8 @@ PROTOTYPES = {
     "oq_awq_clip_search_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
     "oq_smooth_quant_workspace_bytes": (_sz, [_i64]),
     "oq_smooth_quant_scale_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _f32, _p, _p, _sz, _p]),
+    "oq_rtn_state_bytes": (_sz, [_i64, _i64, _i32, _i64]),
+    "oq_rtn_quantize_stateful_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _f32, _i32, _p, _p, _p, _i32, _p, _sz, _p, _sz, _p]),
     "oq_rtn_quantize_ptrs_f32": (_i32, [_p, _p, _i64, _i64, _i64, _i64, _i32, _i64, _i32, _i32, _f32, _i32, _p, _sz, _p]),
     "oq_rtn_qparams_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _f32, _i32,
                                   _p, _p, _p, _sz, _p]),

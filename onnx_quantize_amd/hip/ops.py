@@ -98,6 +98,28 @@ def release_workspaces() -> None:
     """Drop the per-stream scratch buffers `_workspace` keeps (they return to torch's caching allocator)."""
     _ARENA.clear()
     _MINMAX_WS.clear()
+    _RTN_STATE.clear()
+
+
+_RTN_STATE: dict = {}     # (device index, stream handle) -> zero-filled state of the one-read channel / tensor RTN kernels
+
+
+def _rtn_state(nbytes: int, device) -> torch.Tensor | None:
+    """The caller-kept state of `oq_rtn_quantize_stateful_f32`: zero before its first use and left zero by every call (the
+    kernels clean up after themselves), so per-channel / per-tensor RTN needs no clear launch.  One buffer per (device,
+    stream): calls on a stream run in order; at most four streams keep one.  A larger request takes a NEW zero-filled buffer."""
+    if nbytes <= 0:
+        return None
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream)
+    buf = _RTN_STATE.pop(key, None)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=torch.device("cuda", index))
+    _RTN_STATE[key] = buf
+    while len(_RTN_STATE) > _ARENA_MAX_STREAMS:
+        _RTN_STATE.pop(next(iter(_RTN_STATE)))
+    return buf
 
 
 def _row_major(t: torch.Tensor) -> tuple[torch.Tensor, int]:
@@ -157,10 +179,11 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
     ws_bytes = lib.oq_rtn_workspace_bytes(k, n, L.STRATEGY_CODE[strategy], gs, int(mse))
     ws = _workspace(ws_bytes, dev)
     if emit_q:
-        st = lib.oq_rtn_quantize_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
-                                     int(symmetric), int(reduce_range), float(clip_ratio), int(mse), _ptr(q),
-                                     _ptr(scale), _ptr(zp), _layout_code(layout),
-                                     _ptr(ws), ws.numel(), _stream())
+        state = None if mse else _rtn_state(lib.oq_rtn_state_bytes(k, n, L.STRATEGY_CODE[strategy], gs), dev)
+        st = lib.oq_rtn_quantize_stateful_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
+                                              int(symmetric), int(reduce_range), float(clip_ratio), int(mse), _ptr(q),
+                                              _ptr(scale), _ptr(zp), _layout_code(layout),
+                                              _ptr(ws), ws.numel(), _ptr(state), 0 if state is None else state.numel(), _stream())
     else:
         st = lib.oq_rtn_qparams_f32(_ptr(w), k, n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy], gs,
                                     int(symmetric), int(reduce_range), float(clip_ratio), int(mse), _ptr(scale),

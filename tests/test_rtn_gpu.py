@@ -714,3 +714,43 @@ def test_packed_int4_full_size_digest(ops, key):
     assert sha16(s.cpu().numpy()) == d["s_sha"] and sha16(z.cpu().numpy()) == d["z_sha"]
     many = ops.rtn_quantize_many([dev(w), dev(w)], d["qtype"], d["group_size"], layout="kn_packed4")
     assert all(sha16(m[0].cpu().numpy()) == d["packed_sha"] for m in many)
+
+
+def test_stateful_entry_point_leaves_its_state_zero_and_equals_the_plain_call(ops):
+    """oq_rtn_quantize_stateful_f32: the caller's zeroed state replaces the clear launch of the one-read channel / tensor kernels;
+    every call must leave it all-zero again (the last workgroup cleans up), whatever the shape, and give the bytes of
+    oq_rtn_quantize_f32 (which clears a workspace region itself).  Interleaved shapes and strategies on one state buffer."""
+    import ctypes as C
+
+    import torch
+    from onnx_quantize_amd.hip import _lib as L
+
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    state = torch.zeros(4 << 20, dtype=torch.uint8, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for (k, n), strategy, g in (((512, 1028), "channel", -1), ((384, 260), "tensor", -1), ((4096, 2048), "tensor", -1), ((1024, 516), "group", 512),
+                                ((2048, 4096), "channel", -1), ((130, 2052), "tensor", -1), ((4096, 4096), "channel", -1)):
+        w = torch.randn((k, n), generator=gen, device="cuda") * 0.3
+        scode = L.STRATEGY_CODE[strategy]
+        need = lib.oq_rtn_state_bytes(k, n, scode, g)
+        assert 0 < need <= state.numel()
+        count = {"tensor": 1, "channel": n}.get(strategy, n * k // max(g, 1))
+        outs = []
+        for use_state in (True, False):
+            q = torch.empty((k, n), dtype=torch.int8, device="cuda")
+            sc = torch.empty(count, dtype=torch.float32, device="cuda")
+            zp = torch.empty(count, dtype=torch.int8, device="cuda")
+            ws = torch.empty(lib.oq_rtn_workspace_bytes(k, n, scode, g, 0), dtype=torch.uint8, device="cuda")
+            st = lib.oq_rtn_quantize_stateful_f32(C.c_void_p(w.data_ptr()), k, n, n, L.QTYPE_CODE["int8"], scode, g, 0, 0, 1.0, 0,
+                                                  C.c_void_p(q.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(zp.data_ptr()), L.OQ_LAYOUT_KN,
+                                                  C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(state.data_ptr() if use_state else 0),
+                                                  state.numel() if use_state else 0, stream)
+            assert st == 0, lib.oq_last_error()
+            outs.append((q, sc, zp))
+        torch.cuda.synchronize()
+        assert int(state.count_nonzero()) == 0, (k, n, strategy)          # cleaned up: ready for the next call
+        assert all(torch.equal(a, b) for a, b in zip(*outs)), (k, n, strategy)
+        eq, es, ez = O.rtn_quantize(w.cpu().numpy(), "int8", strategy, g)
+        np.testing.assert_array_equal(outs[0][0].cpu().numpy(), eq)
+    assert lib.oq_rtn_state_bytes(4096, 4096, L.STRATEGY_CODE["group"], 128) == 0       # the fused group kernels keep no state
