@@ -103,7 +103,11 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
  *     ZERO before the first call that uses it, and left zero by every call (the last workgroup to leave cleans up), so no clear
  *     launch runs.  One state buffer serves any sequence of calls of any shapes (each call needs its own size) on ONE stream; two
  *     calls that may run concurrently need two buffers.  state == NULL or too small: exactly oq_rtn_quantize_f32.  A call
- *     that fails on the device leaves the state undefined. */
+ *     that fails on the device leaves the state undefined.
+ *     Concurrency of the ticketed kernels (both entry points): inside a call a workgroup may wait for other workgroups of the
+ *     SAME launch, which is safe on its own (see rtn_resident.hip); two such launches running at the same time on one device
+ *     (two streams) compete for the CUs their waiting workgroups hold, so issue per-channel / per-tensor / tall-group calls of
+ *     one device on one stream.  The fused group kernels (group_size <= 256) never wait and have no such restriction. */
 size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size);
 int32_t oq_rtn_quantize_stateful_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,
                                      int32_t strategy, int64_t group_size, int32_t symmetric,
