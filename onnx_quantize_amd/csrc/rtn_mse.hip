@@ -10,7 +10,8 @@
 // until the stop), the masks are OR-ed into one device word, and a resolve kernel derives the stop
 // iteration from that word and picks, per row, the last improving iteration not after it.  The search is
 // ALU-bound (an IEEE divide and |d|^2.4 per element and candidate, 20 candidates); W is re-read from
-// L2 / Infinity Cache per candidate instead of being tiled.  The power runs on the hardware log / exp units (the library
+// L2 / Infinity Cache per candidate instead of being tiled (g > 128), or held in registers (g <= 128, mse_rows_reg_kernel: the division
+// there is the proven-equal reciprocal product of the RTN kernels with an exact redo inside the tie band).  The power runs on the hardware log / exp units (the library
 // powf was 3/4 of the kernel: 4.6 -> 1.2 ms on the 4096 x 11008 matrix).
 //
 // Numerics: per-element arithmetic follows the reference (divide, rint, clamp, (q - zp) * s, subtract, abs,
@@ -23,6 +24,7 @@ namespace oq {
 constexpr int kMseSteps = 20;      // int(maxshrink * grid) = int(0.20 * 100.0), utils.py:197
 constexpr int kMsePatience = 5;    // utils.py:150
 constexpr float kMseNorm = 2.4f;   // utils.py:152
+constexpr int kMseChunk = 16;      // elements per tie-band check of the register kernel
 
 // candidate i: p = 1 - i / 100.0 (Python float), applied to fp32 ranges as a weak scalar -> fp32 product
 __device__ __forceinline__ float shrink_factor(int i) { return static_cast<float>(1.0 - static_cast<double>(i) / 100.0); }
@@ -111,9 +113,36 @@ __global__ __launch_bounds__(256, 2) void mse_rows_reg_kernel(const float* W, in
     for (int i = 0; i < kMseSteps; ++i) {
         const float p = shrink_factor(i);
         const QParam qp = qparam_from_range(p * lo0, p * hi0, grid);
+        // the division-free level of oq_common.hpp (proved equal to the reference's integer away from rounding ties), in
+        // chunks of 16 elements: a chunk in which any lane of the wave sits inside the tie band (~1 % of the chunks) is
+        // redone with the true division by the whole wave.  Same values, same summation order as the plain loop.
+        const ColQ c = make_colq(qp, mn, mx, 0);
+        const float lo_f = static_cast<float>(grid.qmin), hi_f = static_cast<float>(grid.qmax);
         float err = 0.f;
 #pragma unroll
-        for (int r = 0; r < G; ++r) err += fake_quant_error(x[r], qp, grid);
+        for (int r0 = 0; r0 < G; r0 += kMseChunk) {
+            float e[kMseChunk];
+            float off = 0.f;   // max |t - rint(t)| of the chunk (t is finite whenever c.thr > 0, make_colq)
+            // one chunk at a time: its reciprocal is opaque until the previous chunk's sum exists (left alone, the compiler
+            // runs several chunks' temporaries at once and spills the tile at G = 128)
+            float rinv = c.rinv;
+            asm volatile("" : "+v"(rinv), "+v"(err));
+#pragma unroll
+            for (int r = 0; r < kMseChunk; ++r) {
+                const float t = x[r0 + r] * rinv;
+                const float k = rintf(t);
+                off = fmaxf(off, fabsf(t - k));
+                const float lvl = __builtin_amdgcn_fmed3f(k + c.zpb, lo_f, hi_f);
+                const float d = (lvl - c.zpb) * c.scale - x[r0 + r];
+                e[r] = __builtin_amdgcn_exp2f(kMseNorm * __builtin_amdgcn_logf(fabsf(d)));
+            }
+            if (__builtin_amdgcn_ballot_w64(!(off < c.thr)) != 0) {
+#pragma unroll
+                for (int r = 0; r < kMseChunk; ++r) e[r] = fake_quant_error(x[r0 + r], qp, grid);
+            }
+#pragma unroll
+            for (int r = 0; r < kMseChunk; ++r) err += e[r];
+        }
         if (err < best) {  // utils.py:225
             best = err;
             mask |= 1u << i;

@@ -92,3 +92,24 @@ def test_resident_rtn_kernels_keep_two_workgroups_per_cu(tmp_path):
         assert hits, (key, list(seen))
         for vgprs, scratch, occ in hits:
             assert vgprs <= 128 and scratch == 0 and occ >= 4, (key, vgprs, scratch, occ)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("source,kernels", [("rtn_mse.hip", ("mse_rows_reg_kernel",)), ("hqq.hip", ("hqq_rounds_reg_kernel",))])
+def test_register_tile_search_kernels_do_not_spill(tmp_path, source, kernels):
+    """The MSE and HQQ searches hold a group's G values in registers across all candidates / rounds.  Left to itself the
+    optimiser interleaves independent chunks until the G = 128 tile spills (1.1 KB of scratch per lane and 3x the time, with
+    every parity test still green): the chunks are chained through opaque copies and this test watches the result."""
+    from onnx_quantize_amd import _build
+    src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", source)
+    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+                        str(tmp_path / "k.s"), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = {}
+    for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, re.S):
+        seen[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
+    for key in kernels:
+        hits = {k: v for k, v in seen.items() if key in k}
+        assert hits, (key, list(seen))
+        for name, (vgprs, scratch, occ) in hits.items():
+            assert scratch == 0 and occ >= 2, (name, vgprs, scratch, occ)
