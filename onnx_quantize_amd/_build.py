@@ -29,6 +29,16 @@ CXXFLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contra
             "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+# Per-file additions.  hqq.hip: the SLP vectoriser pairs the register tile's values for v_pk_mul / v_pk_add; the aligned
+# register pairs fragment the allocation until the G = 128 tile of hqq_rounds_reg_kernel spills (256 registers + scratch against
+# 165 registers without pairing; tests/test_kernel_resources.py watches it).
+PER_FILE_FLAGS = {"hqq.hip": ("-fno-slp-vectorize",)}
+
+
+def flags_for(src: str) -> list[str]:
+    return [*CXXFLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), ())]
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(exe):
@@ -51,7 +61,7 @@ def _compile(src: str, force: bool, extra: tuple = ()) -> str:
     newest = max(os.path.getmtime(src), _deps_mtime())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj
-    cmd = [hipcc(), *CXXFLAGS, *extra, "-c", src, "-o", obj]
+    cmd = [hipcc(), *flags_for(src), *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -283,7 +283,6 @@ struct ColState {
     float scale, neg_scale, rinv, zm;   // rinv = refined reciprocal of scale (div_refined), zm = float(zp) + 1.5 * 2^23
     int32_t zp;
 };
-__device__ __forceinline__ float refined_rcp(float s);
 __device__ __forceinline__ ColState make_colstate(float scale, int32_t zp) {
     ColState c;
     c.scale = scale;
@@ -322,20 +321,6 @@ __device__ __forceinline__ void load_coef(StepCoef& c, const SlabIn& in) {
     c.ca = *reinterpret_cast<const f32x4*>(in.crow + R * 64);
     if constexpr (LIVE >= 4) c.cb = *reinterpret_cast<const f32x4*>(in.crow + kCoefB + R * 64);
     c.dd = *reinterpret_cast<const f32x2*>(in.drow + R * 32);
-}
-
-// fl(x / s) from the refined reciprocal r1 of s and -s: the last five instructions of the compiler's own division
-// sequence (see the header of this section); no v_div_scale / v_div_fixup, no branch.
-__device__ __forceinline__ float div_refined(float x, float neg_s, float r1) {
-    const float q0 = x * r1;
-    const float e1 = __builtin_fmaf(neg_s, q0, x);
-    const float q1 = __builtin_fmaf(e1, r1, q0);
-    const float e2 = __builtin_fmaf(neg_s, q1, x);
-    return __builtin_fmaf(e2, r1, q1);
-}
-__device__ __forceinline__ float refined_rcp(float s) {
-    const float r0 = __builtin_amdgcn_rcpf(s);
-    return __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
 }
 
 // w2[p] = block rows of slots (2p, 2p + 1) relative to the current slab: packed mul / add, two rows per instruction.

@@ -101,8 +101,8 @@ __device__ __forceinline__ float hqq_shrink(float d, float inv_beta, float expo)
     // reproduced bit for bit either way, see the header)
     const float t = a - inv_beta * __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf(a + 1e-8f));
     const float m = nmax(0.0f, t);
-    const float sg = d > 0.f ? 1.0f : (d < 0.f ? -1.0f : d);   // np.sign keeps +-0 and NaN
-    return sg * m;
+    // np.sign(d) * m with m >= 0 (or NaN): m under d's sign bit -- the same bits, +-0 and NaN included (d = +-0 gives m = 0)
+    return __builtin_copysignf(m, d);
 }
 
 __global__ __launch_bounds__(256) void hqq_round_kernel(const HqqArgs a) {
@@ -122,11 +122,12 @@ __global__ __launch_bounds__(256) void hqq_round_kernel(const HqqArgs a) {
     if (active) {
         const float z = a.zp_cur[r];
         const float inv = 1.0f / a.scale[r];                               // hqq.py:120
+        const float ninv = -inv, rr = refined_rcp(inv);                    // the row's divisor of :125, see div_refined
         const float* w = a.W + kg * a.g * a.ldw + col;
         const float zmean = pairwise_row(a.g, [&](int64_t t) {
             const float x = w[t * a.ldw];
             const float wq = nmin(nmax(rintf(x * inv + z), a.qmin), a.qmax);   // :124
-            const float wr = (wq - z) / inv;                                   // :125
+            const float wr = div_refined(wq - z, ninv, rr);                    // :125 (wq - z) / inv
             const float d = x - wr;
             abs_sum += static_cast<double>(fabsf(d));                          // :131
             const float we = hqq_shrink(d, a.inv_beta, a.expo);                // :126
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void hqq_rounds_reg_kernel(const HqqArgs a,
     for (int t = 0; t < G; ++t) x[t] = *reinterpret_cast<const float*>(base + t * row_bytes + lane_off);
     float z = zero_point_in[r];
     const float inv = 1.0f / a.scale[r];                                       // hqq.py:120
+    const float ninv = -inv, rr = refined_rcp(inv);                            // the row's divisor of :125, see div_refined
     if (live) traj[r] = z;
 #pragma unroll 1
     for (int32_t it = 0; it < iters; ++it) {
@@ -196,14 +198,14 @@ __global__ __launch_bounds__(256, 2) void hqq_rounds_reg_kernel(const HqqArgs a,
         float acc[8];
 #pragma unroll
         for (int t0 = 0; t0 < G; t0 += 8) {
-            float zg = z, ig = inv_r;
-            if (t0 == 0) asm volatile("" : "+v"(zg), "+v"(ig));
-            else asm volatile("" : "+v"(zg), "+v"(ig) : "v"(acc[0]), "v"(acc[3]), "v"(acc[7]));   // ... and AFTER the previous group is folded
+            float zg = z, ig = inv_r, ng = ninv, rg = rr;
+            if (t0 == 0) asm volatile("" : "+v"(zg), "+v"(ig), "+v"(ng), "+v"(rg));
+            else asm volatile("" : "+v"(zg), "+v"(ig), "+v"(ng), "+v"(rg) : "v"(acc[0]), "v"(acc[3]), "v"(acc[7]));   // ... and AFTER the previous group is folded
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xv = x[t0 + j];
                 const float wq = nmin(nmax(rintf(xv * ig + zg), a.qmin), a.qmax);   // :124
-                const float wr = (wq - zg) / ig;                                      // :125
+                const float wr = div_refined(wq - zg, ng, rg);                        // :125 (wq - zg) / inv
                 const float d = xv - wr;
                 abs_sum += static_cast<double>(fabsf(d));                             // :131
                 const float we = hqq_shrink(d, inv_beta, a.expo);                     // :126

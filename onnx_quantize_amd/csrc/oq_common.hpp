@@ -156,6 +156,23 @@ __device__ __forceinline__ float quantize_exact_biased(float x, const ColQ& c, i
     return static_cast<float>(quantize_one(x, c.scale, c.zp, qmin, qmax) + bias);
 }
 
+// Division by a divisor known ahead of the numerators (a row's scale, a pivot): r1 = refined_rcp(s) is the first four
+// instructions of the compiler's own fp32 division sequence (rcp, fma(-s, r0, 1), fma(., r0, r0)), div_refined runs its
+// remaining five on the numerator (mul, fma x 4) -- no v_div_scale / v_div_fmas / v_div_fixup, no branch.  That IS the
+// correctly rounded quotient whenever v_div_scale would not rescale (numerator and quotient in [2^-100, 2^100], or a zero
+// numerator); outside (degenerate data) the result may differ from IEEE in the last bit.
+__device__ __forceinline__ float div_refined(float x, float neg_s, float r1) {
+    const float q0 = x * r1;
+    const float e1 = __builtin_fmaf(neg_s, q0, x);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(neg_s, q1, x);
+    return __builtin_fmaf(e2, r1, q1);
+}
+__device__ __forceinline__ float refined_rcp(float s) {
+    const float r0 = __builtin_amdgcn_rcpf(s);
+    return __builtin_fmaf(__builtin_fmaf(-s, r0, 1.0f), r0, r0);
+}
+
 // K2 utils.py:130-132: (f32(q) - f32(zp)) * scale, two roundings.
 __device__ __forceinline__ float dequantize_one(int32_t q, float scale, int32_t zp) {
     return (static_cast<float>(q) - static_cast<float>(zp)) * scale;

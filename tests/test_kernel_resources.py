@@ -19,7 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 def test_headline_kernels_keep_their_occupancy(tmp_path):
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "rtn.hip")
-    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+    r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
                         str(tmp_path / "rtn.s"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     report = {}
@@ -39,7 +39,7 @@ def test_hessian_gemm_kernels_fit_two_waves_per_simd_without_spilling(tmp_path):
     accumulator registers live across the stage loop: a spill there would sit inside the MFMA stream."""
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "syrk_bf16x3.hip")
-    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+    r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
                         str(tmp_path / "syrk.s"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     seen = 0
@@ -61,7 +61,7 @@ def test_gptq_loop_kernels_do_not_spill(tmp_path):
     CU (64 KB of LDS each)."""
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "gptq_loop.hip")
-    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+    r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
                         str(tmp_path / "loop.s"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     seen = {}
@@ -81,7 +81,7 @@ def test_resident_rtn_kernels_keep_two_workgroups_per_cu(tmp_path):
     what keeps loads in flight while one of them waits."""
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "rtn_resident.hip")
-    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+    r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
                         str(tmp_path / "res.s"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     seen = {}
@@ -102,7 +102,7 @@ def test_register_tile_search_kernels_do_not_spill(tmp_path, source, kernels):
     every parity test still green): the chunks are chained through opaque copies and this test watches the result."""
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", source)
-    r = subprocess.run([HIPCC, *_build.CXXFLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
+    r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
                         str(tmp_path / "k.s"), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     seen = {}
