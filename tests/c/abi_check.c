@@ -12,7 +12,7 @@ int main(void) {
     TAKE(oq_abi_version); TAKE(oq_last_error); TAKE(oq_status_string); TAKE(oq_target_arch); TAKE(oq_qrange);
     TAKE(oq_rtn_workspace_bytes); TAKE(oq_rtn_quantize_f32); TAKE(oq_rtn_batched_workspace_bytes);
     TAKE(oq_rtn_quantize_batched_f32);
-    TAKE(oq_rtn_quantize_ptrs_f32);
+    TAKE(oq_rtn_quantize_ptrs_f32); TAKE(oq_rtn_state_bytes); TAKE(oq_rtn_quantize_stateful_f32);
     TAKE(oq_hessian_many_workspace_bytes); TAKE(oq_hessian_accumulate_many_f32);
     TAKE(oq_hessian_pieces_bytes); TAKE(oq_hessian_slab_bytes); TAKE(oq_hessian_prepare_f32); TAKE(oq_hessian_accumulate_prepared_f32);
     TAKE(oq_awq_workspace_bytes); TAKE(oq_awq_scale_search_f32); TAKE(oq_awq_clip_search_f32);
@@ -34,6 +34,7 @@ int main(void) {
         != OQ_ERR_INVALID_ARGUMENT) return 6;
     if (strstr(oq_last_error(), "null pointer") == NULL) return 7;
     if (oq_rtn_workspace_bytes(4096, 11008, OQ_GROUP, 128, 0) == 0 || oq_hqq_workspace_bytes(4096, 11008, 128) == 0) return 8;
+    if (oq_rtn_state_bytes(4096, 11008, OQ_CHANNEL, -1) == 0) return 13;
     if (sizeof(oq_minmax_desc) != 24) return 9;
     if (sizeof(oq_rtn_tensor_desc) != 40) return 10;
     printf("ok %d entry points\n", count);
