@@ -21,12 +21,14 @@
 // `rtn_resident_groups`: channel and tall groups.  The tiles of one range (one column tile x one k-group) have
 // consecutive tickets, are loaded at about the same time by different workgroups, and every one of them waits for its
 // siblings' partial ranges before it quantizes: one read of W, no second pass.
-// `rtn_tensor_onepass`: per-tensor.  Phase A streams all tiles once (running min / max in registers, no barrier per tile);
-// every workgroup KEEPS the last tile it loaded in registers and the first half of the one before in LDS (96 MB of the
-// matrix stay on the chip); one returning add per workgroup counts the tiles and hands out an arrival slot for its partial
+// `rtn_tensor_onepass`: per-tensor.  ONE 8-wave workgroup per CU.  Phase A streams all tiles once (running min / max in
+// registers, no barrier per tile beyond the ticket exchange); a workgroup KEEPS the last two tiles it loaded in registers
+// (two slots written alternately, 128 of its <= 256 registers per lane) and the one before in 128 KB of LDS: 96 MB of the
+// matrix stay on the chip.  One returning add per workgroup counts the tiles and hands out an arrival slot for its partial
 // range and the ids of the tiles it keeps; the workgroup that completes the count folds the slots and broadcasts {go, keys};
-// kept tiles are quantized from registers / LDS, the other half tiles are dealt out statically (no tickets, no barriers)
-// and re-read most-recent-first: the Infinity Cache still holds them.  A matrix of up to 768 tiles is read exactly once.
+// kept tiles are quantized from registers / LDS; the rows of the other half tiles are dealt out statically and evenly over
+// all waves (no tickets, no barriers), re-read most-recent-first (the Infinity Cache still holds them) and software-pipelined
+// over the two register slots.  A matrix of up to 768 tiles is read exactly once and skips that phase altogether.
 #include "oq_common.hpp"
 
 #include <cstdlib>
@@ -41,7 +43,7 @@ constexpr int kResRows = 16;                      // rows per wave
 constexpr int kResTileRows = kResWaves * kResRows;  // 128, the chunk height of the two-pass path (rtn.hip kChunkRows)
 constexpr int kResCols = 256;                     // 64 lanes x 4 columns
 constexpr int kResHeader = 160;
-constexpr int kResMaxTensorTiles = 32768;         // bitmap of kept half tiles in LDS (8 KB): 1 G parameters; larger tensors take the three-launch path
+constexpr int kResMaxTensorTiles = 32768;         // bitmap of kept half tiles + its prefix sums in LDS (8 KB each): 1 G parameters; larger tensors take the three-launch path
 constexpr int kResTensorHeader = 128 + 64 * 32 + 64 * 32;   // tickets / counter, 64 key shards, 64 result replicas (a 128-byte line each)
 constexpr int kResGroupTileRows = 128;            // default tile height of rtn_resident_groups (see groups_tile_rows)
 constexpr int kResCtrPad = 32;                   // uint32 words per range counter: a 128-byte line each (hundreds of workgroups poll them)
@@ -288,65 +290,106 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
 // resident workgroups is; a workgroup that starts late finds no ticket, adds nothing and waits like the others.  Phase B
 // never waits either.
 // ---------------------------------------------------------------------------------------------
-constexpr int kParkWaves = kResWaves / 2;                        // the waves whose rows (the first half of a tile) are parked in LDS
-constexpr int kParkBytes = kParkWaves * kResRows * kWave * 16;   // 64 KB
-constexpr int kHalfRows = kResTileRows / 2;                      // phase-B unit: half a tile, 8 rows per wave
+constexpr int kHalfRows = kResTileRows / 2;                      // phase-B unit: half a tile, 64 rows x 256 columns (a team of four waves)
+constexpr int kParkBytes = kResWaves * kResRows * kWave * 16;    // one tile: 128 KB
 
-__global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const ResidentArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char park_lds[];   // kParkBytes: [wave < 4][row 16][lane 64] x 16 B
+#ifdef OQ_TENSOR_STAMPS   // lab build only (scripts/lab_tensor_stamps.py): 100 MHz wall-clock stamps of every workgroup's phases
+__device__ uint64_t g_tensor_stamps[512 * 8];
+#define OQ_STAMP(i) do { if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define OQ_STAMP(i) do { } while (0)
+#endif
+
+constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+
+// tile -> first row of this wave's 16 rows, first column
+__device__ __forceinline__ void tile_origin(uint32_t tile, uint32_t ncol, int wave, int64_t& row0, int64_t& col0) {
+    const uint32_t row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
+    row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows;
+    col0 = static_cast<int64_t>(col_tile) * kResCols;
+}
+
+// One phase-A step into a register slot: the tile the slot held goes to the LDS park buffer (overwriting the tile parked
+// before, which will be read a second time in phase B), the new tile is loaded and folded.
+__device__ __forceinline__ void tensor_step(const ResidentArgs& a, uint32_t tile, uint32_t ncol, int lane, int wave, float4* park,
+                                            float (&v)[kResRows][4], uint32_t& held, uint32_t& parked, float& rmn, float& rmx) {
+    if (held != kNoTile) {   // uniform
+#pragma unroll
+        for (int r = 0; r < kResRows; ++r) park[r * kWave] = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        parked = held;
+    }
+    held = tile;
+    int64_t row0, col0;
+    tile_origin(tile, ncol, wave, row0, col0);
+    load_tile<OQ_RES_A_NT>(a, row0 < a.K ? row0 : a.K - 1, a.K, col0, lane, v);
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rmn = nmin(rmn, v[r][i]);
+            rmx = nmax(rmx, v[r][i]);
+        }
+}
+
+// One workgroup per CU (8 waves, up to 256 registers per lane): TWO tiles in registers + ONE in 128 KB of LDS.
+__global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const ResidentArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char park_lds[];   // kParkBytes: [wave 8][row 16][lane 64] x 16 B
     __shared__ float s_mn[kResWaves], s_mx[kResWaves];
     __shared__ uint32_t s_ticket, s_keys[3];
     __shared__ uint32_t s_held[kResMaxTensorTiles / 16];          // two bits per tile: its halves
     __shared__ uint32_t s_pref[kResMaxTensorTiles / 16], s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t ntiles = a.ntiles, ncol = a.ncol_tiles, nunits = 2u * ntiles;
-    float4* park = reinterpret_cast<float4*>(park_lds) + (wave * kResRows) * kWave + lane;   // this lane's slot of row 0 (waves < 4 only)
+    float4* park = reinterpret_cast<float4*>(park_lds) + (wave * kResRows) * kWave + lane;   // this lane's slot of row 0
 
-    float v[kResRows][4];
+    float v0[kResRows][4], v1[kResRows][4];          // the two register slots
     float rmn = INFINITY, rmx = -INFINITY;
-    uint32_t processed = 0, mine = 0xFFFFFFFFu, parked = 0xFFFFFFFFu;
+    uint32_t processed = 0, parked = kNoTile, held0 = kNoTile, held1 = kNoTile;
     bool first = false;
+    OQ_STAMP(0);
     if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
     __syncthreads();
     uint32_t t = s_ticket;
     __syncthreads();
     first = t == 0;
+    // Tile index = ticket (column tiles fastest: co-resident workgroups stream whole rows).  The slots are written
+    // alternately, so the registers hold the last TWO tiles a workgroup loaded and the LDS park buffer the one before:
+    // 3 tiles = 384 KB per CU, 96 MB of the matrix stay on the chip across the hand-off.  (Two 8-wave workgroups per CU
+    // with 1.5 tiles each hold the same, but streamed slower: phase A ended at 39 us instead of 32 on 4096 x 11008, with
+    // half-tile tickets at 46.)
     while (t < ntiles) {
-        if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // the next ticket travels while this tile loads
-        if (processed > 0 && wave < kParkWaves) {
-            // The tile in `v` is about to be overwritten: its first half (the rows of waves 0-3) is parked in LDS.  If the
-            // tile that is loaded now turns out to be this workgroup's last one, the parked half needs no second read either:
-            // 64 KB of registers + 64 KB of LDS per workgroup = 96 MB of the matrix stay on the chip across the hand-off.
-#pragma unroll
-            for (int r = 0; r < kResRows; ++r) park[r * kWave] = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+        {
+            if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // the next ticket travels while this tile loads
+            tensor_step(a, t, ncol, lane, wave, park, v0, held0, parked, rmn, rmx);
+            ++processed;
+            __syncthreads();
+            const uint32_t nxt = s_ticket;
+            __syncthreads();
+            t = nxt;
+            if (t >= ntiles) break;   // uniform
         }
-        if (processed > 0) parked = mine;
-        mine = t;
-        const uint32_t row_tile = t / ncol, col_tile = t - row_tile * ncol;
-        const int64_t row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows;
-        load_tile<OQ_RES_A_NT>(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
-#pragma unroll
-        for (int r = 0; r < kResRows; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                rmn = nmin(rmn, v[r][i]);
-                rmx = nmax(rmx, v[r][i]);
-            }
-        ++processed;
-        __syncthreads();
-        const uint32_t nxt = s_ticket;
-        __syncthreads();
-        if (nxt >= ntiles) break;   // uniform: the tile in `v` (`mine`) is this workgroup's last one and stays
-        t = nxt;
+        {
+            if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
+            tensor_step(a, t, ncol, lane, wave, park, v1, held1, parked, rmn, rmx);
+            ++processed;
+            __syncthreads();
+            const uint32_t nxt = s_ticket;
+            __syncthreads();
+            t = nxt;
+        }
     }
     // Publish.  512 workgroups adding to ONE key pair and polling ONE counter serialise at the memory side (an atomic on a
     // contended line takes 11-13 ns: MI355X_MICROARCH.md "fanin"; the first build of this kernel spent 40 us here).  So: ONE
     // returning add per workgroup counts its tiles (low 16 bits) and hands out an arrival number (high bits); the partial
-    // range goes, as one 16-byte store {1, max key, min key}, into the slot of that number -- no atomics on shared keys, no
+    // range goes, as one 16-byte store {max key, min key, kept tiles}, into the slot of that number -- no atomics on shared keys, no
     // drain in front of the add; the workgroup whose add completes the count reads the slots of all arrivals (re-reading the
     // rare one whose store is still in flight), folds them and broadcasts {go, keys} to 64 replica lines; everybody polls
     // its own replica (8 pollers per line).
     uint32_t* replica = a.key_nmin + (blockIdx.x & 63u) * 32u;      // {go, final max key, final complemented min key}
+    OQ_STAMP(1);
+#ifdef OQ_TENSOR_STAMPS
+    if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + 6] = processed;
+#endif
     if (processed) {
         rmn = wave_min(rmn);
         rmx = wave_max(rmx);
@@ -357,16 +400,18 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
             for (int w = 1; w < kResWaves; ++w) { rmn = nmin(rmn, s_mn[w]); rmx = nmax(rmx, s_mx[w]); }
             const uint32_t before = agent_add(a.counters, (1u << 16) | processed);
             const uint32_t arrival = before >> 16;
-            // the slot also says which tiles this workgroup keeps (registers: `mine`, both halves; LDS: the first half of
-            // `parked`): everybody builds the bitmap of kept halves from the slots, no shared bitmap, no atomics, no drain
-            const u32x4r slot = {key_of_max(rmx), key_of_min(rmn), mine + 1u, parked + 1u /* 0: none */};
+            // the slot also says which tiles this workgroup keeps (registers: held0, held1; LDS: `parked`), as tile + 1 in
+            // 16 bits each (0: none; slot 0 always holds one): everybody builds the bitmap of kept tiles from the slots, no
+            // shared bitmap, no atomics, no drain
+            // bit 31 of the last word: this workgroup dropped a tile (it loaded more than the three it keeps)
+            const u32x4r slot = {key_of_max(rmx), key_of_min(rmn), (held0 + 1u) | ((held1 + 1u) << 16), (parked + 1u) | (processed > 3u ? 0x80000000u : 0u)};
             asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(a.key_max + arrival * 4u), "v"(slot) : "memory");
             s_ticket = ((before & 0xffffu) + processed == ntiles) ? arrival + 1u : 0u;   // the last finisher learns how many arrived
         }
         __syncthreads();
         const uint32_t arrivals = s_ticket;
         if (arrivals != 0u) {                      // the last finisher (uniform over the workgroup): one slot per thread
-            uint32_t kmx = 0u, kmn = 0u;
+            uint32_t kmx = 0u, kmn = 0u, dropped = 0u;
             if (threadIdx.x < arrivals) {
                 u32x4r line;
                 do {
@@ -374,7 +419,9 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
                 } while (line[2] == 0u);
                 kmx = line[0];
                 kmn = line[1];
+                dropped = line[3] & 0x80000000u;
             }
+            dropped = __syncthreads_or(static_cast<int>(dropped != 0u)) ? 0x80000000u : 0u;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 kmx = max(kmx, static_cast<uint32_t>(__shfl_xor(static_cast<int>(kmx), off, 64)));
@@ -388,7 +435,7 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
                 // {go, max key, min key} as ONE 16-byte agent-scope store per replica: a 16-byte piece of a line is written by
                 // one request (MI355X_MICROARCH.md: 16-byte sc1 granules are observed untorn), so no drain between keys and `go`
                 uint32_t* rep = a.key_nmin + lane * 32;
-                const u32x4r line = {1u, kmx, kmn, arrivals};
+                const u32x4r line = {1u, kmx, kmn, arrivals | dropped};   // bit 31: somebody dropped a tile, i.e. phase B has work
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(rep), "v"(line) : "memory");
             }
         }
@@ -403,15 +450,19 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         } while (line[0] == 0u);
         s_keys[0] = line[1];
         s_keys[1] = line[2];
-        s_keys[2] = line[3];      // how many workgroups arrived = how many slots describe kept tiles
+        s_keys[2] = line[3];      // how many workgroups arrived = how many slots describe kept tiles; bit 31: phase B has work
     }
     // Every slot is complete once `go` is up (the last finisher read them all).  One slot per thread: its load is issued here
     // and lands while the kept tiles are quantized below; the bitmap of kept halves is then built in LDS from the slots.
     __syncthreads();
+    OQ_STAMP(2);
+    const bool any_dropped = (s_keys[2] & 0x80000000u) != 0u;      // uniform over the grid
     u32x4r my_slot = {0u, 0u, 0u, 0u};
-    if (threadIdx.x < s_keys[2])
+    if (any_dropped && threadIdx.x < (s_keys[2] & 0x7fffffffu))
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(my_slot) : "v"(a.key_max + threadIdx.x * 4u) : "memory");
-    for (uint32_t i = threadIdx.x; i < (nunits + 31u) / 32u; i += kResWaves * kWave) s_held[i] = 0u;
+    const uint32_t nwords = (nunits + 31u) / 32u;
+    if (any_dropped)
+        for (uint32_t i = threadIdx.x; i < nwords; i += kResWaves * kWave) s_held[i] = 0u;
     const float gmx = max_of_key(s_keys[0]), gmn = min_of_key(s_keys[1]);
     const int32_t bias = a.grid.qmin < 0 ? 128 : 0;
     ColQ cq[4];
@@ -421,81 +472,131 @@ __global__ __launch_bounds__(kResWaves* kWave, 4) void rtn_tensor_onepass(const 
         a.scale[0] = cq[0].scale;
         a.zp[0] = static_cast<uint8_t>(cq[0].zp);
     }
-    if (processed) {
-        const uint32_t row_tile = mine / ncol, col_tile = mine - row_tile * ncol;
-        quantize_store_tile(a, cq, v, static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows, a.K,
-                            static_cast<int64_t>(col_tile) * kResCols, lane);
-        if (parked != 0xFFFFFFFFu && wave < kParkWaves) {   // the parked half: back from LDS into the same lanes' registers
+    if (held0 != kNoTile) {   // uniform
+        int64_t row0, col0;
+        tile_origin(held0, ncol, wave, row0, col0);
+        quantize_store_tile(a, cq, v0, row0, a.K, col0, lane);
+    }
+    OQ_STAMP(3);
+    // Phase B: the half tiles nobody kept (skipped when nobody dropped a tile: up to 768 tiles, 96 MB, are read exactly
+    // once).  No tickets and no barriers: the bitmap is the same for everybody, so the ROWS of the unheld halves -- flattened,
+    // most recently read half first (the Infinity Cache still holds them) -- are dealt out statically and evenly over all
+    // waves of the grid; a wave walks its share in steps of up to 16 rows inside one half.  (Whole halves per team of four
+    // waves left 2.4 units per team on 4096 x 11008: three rounds for some, two for the others, 9 us between the first and
+    // the last workgroup to finish.)  The steps are software-pipelined over the two register slots, and the first step's
+    // loads are issued BEFORE the second kept tile and the parked tile are stored: a stretch of stores alone ran at
+    // 2 TB/s (24 MB in 11.5 us), reads beside them are almost free.  Safe without residency assumptions: nobody waits in
+    // this phase; a workgroup that starts late does its share late.
+    uint32_t total = 0, pos = 0, stop = 0;
+    if (any_dropped) {
+        __syncthreads();                                   // s_held zeroed
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_slot) : : "memory");
+        {
+            const uint32_t ids[3] = {my_slot[2] & 0xffffu, my_slot[2] >> 16, my_slot[3] & 0xffffu};
 #pragma unroll
-            for (int r = 0; r < kResRows; ++r) {
-                const float4 x = park[r * kWave];
-                v[r][0] = x.x; v[r][1] = x.y; v[r][2] = x.z; v[r][3] = x.w;
+            for (int i = 0; i < 3; ++i)
+                if (ids[i] != 0u) atomicOr(&s_held[(ids[i] - 1u) >> 4], 3u << ((2u * (ids[i] - 1u)) & 31u));   // both halves of the tile
+        }
+        __syncthreads();                                   // s_held complete
+        // s_pref[w] = unheld halves in words [0, w): four words per thread, a wave scan, the waves' sums through LDS
+        {
+            uint32_t c[4], cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w = threadIdx.x * 4u + i;
+                uint32_t bits = w < nwords ? ~s_held[w] : 0u;
+                if (w == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
+                c[i] = __popc(bits);
+                cnt += c[i];
             }
-            const uint32_t prow = parked / ncol, pcol = parked - prow * ncol;
-            quantize_store_tile(a, cq, v, static_cast<int64_t>(prow) * kResTileRows + wave * kResRows, a.K,
-                                static_cast<int64_t>(pcol) * kResCols, lane);
-        }
-    }
-    // Phase B: the half tiles nobody kept.  No tickets and no barriers any more: the bitmap is the same for everybody, so
-    // the unheld halves are dealt out statically -- the j-th unheld half (counted from the END: most recently read first, the
-    // Infinity Cache still holds them) goes to team j mod (2 x workgroups), a team = four waves = 64 rows x 256 columns with
-    // 16 loads per lane in flight.  (With whole tiles per ticket and a barrier per tile this phase took two rounds of 12 us
-    // for 1.7 tiles per workgroup; half tiles of 8 rows per wave were slower still: half the loads in flight.)
-    // Safe without residency assumptions: nobody waits in this phase; a workgroup that starts late does its share late.
-    const uint32_t nwords = (nunits + 31u) / 32u;
-    __syncthreads();                                   // s_held zeroed
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_slot) : : "memory");
-    if (my_slot[2] != 0u) {
-        const uint32_t u = 2u * (my_slot[2] - 1u);
-        atomicOr(&s_held[u >> 5], 3u << (u & 31u));
-        if (my_slot[3] != 0u) {
-            const uint32_t up = 2u * (my_slot[3] - 1u);
-            atomicOr(&s_held[up >> 5], 1u << (up & 31u));
-        }
-    }
-    __syncthreads();                                   // s_held complete
-    if (wave == 0) {                                   // s_pref[w] = unheld halves in words [0, w); 32 words per lane
-        uint32_t cnt = 0;
-        const uint32_t w0 = lane * (kResMaxTensorTiles / 16 / kWave), w1 = w0 + kResMaxTensorTiles / 16 / kWave;
-        for (uint32_t w = w0; w < w1 && w < nwords; ++w) {
-            uint32_t bits = ~s_held[w];
-            if (w == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
-            cnt += __popc(bits);
-        }
-        uint32_t incl = cnt;
+            uint32_t incl = cnt;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), off, 64));
-            if (lane >= off) incl += up;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), off, 64));
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_mn[wave] = __uint_as_float(incl);
+            __syncthreads();
+            uint32_t run = incl - cnt;
+#pragma unroll
+            for (int w = 0; w < kResWaves; ++w)
+                if (w < wave) run += __float_as_uint(s_mn[w]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t w = threadIdx.x * 4u + i;
+                if (w < nwords) s_pref[w] = run;
+                run += c[i];
+            }
+            if (threadIdx.x == kResWaves * kWave - 1) s_total = run;
         }
-        uint32_t run = incl - cnt;
-        for (uint32_t w = w0; w < w1 && w < nwords; ++w) {
-            s_pref[w] = run;
-            uint32_t bits = ~s_held[w];
-            if (w == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
-            run += __popc(bits);
-        }
-        if (lane == 63) s_total = incl;
+        __syncthreads();
+        total = s_total;
+        const uint32_t total_rows = total * kHalfRows;
+        const uint32_t nwv = gridDim.x * kResWaves, per = (total_rows + nwv - 1u) / nwv;
+        pos = (blockIdx.x * kResWaves + wave) * per;
+        stop = pos + per < total_rows ? pos + per : total_rows;
     }
-    __syncthreads();
-    const uint32_t total = s_total;
-    const uint32_t team = blockIdx.x * 2u + (wave >> 2), nteams = gridDim.x * 2u;
-    for (uint32_t j = team; j < total; j += nteams) {
-        const uint32_t want = total - 1u - j;          // rank of the unit among the unheld ones, ascending
-        uint32_t lo = 0, hi = nwords - 1u;             // last word whose prefix is <= want
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi + 1u) >> 1;
-            if (s_pref[mid] <= want) lo = mid; else hi = mid - 1u;
+    OQ_STAMP(4);
+    // the next step of this wave's share: rows [row0, row_end) x columns [col0, col0 + 256) of one unheld half; false at the end
+    int64_t a_row0 = 0, a_end = 0, a_col0 = 0, b_row0 = 0, b_end = 0, b_col0 = 0;
+    auto next_step = [&](int64_t& row0, int64_t& row_end, int64_t& col0) -> bool {
+        while (pos < stop) {
+            const uint32_t j = pos / kHalfRows, r_in = pos - j * kHalfRows;
+            uint32_t n = kHalfRows - r_in;
+            n = n < static_cast<uint32_t>(kResRows) ? n : static_cast<uint32_t>(kResRows);
+            n = n < stop - pos ? n : stop - pos;
+            pos += n;
+            const uint32_t want = total - 1u - j;          // rank of the half among the unheld ones, ascending
+            uint32_t lo = 0, hi = nwords - 1u;             // last word whose prefix is <= want
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1u) >> 1;
+                if (s_pref[mid] <= want) lo = mid; else hi = mid - 1u;
+            }
+            uint32_t bits = ~s_held[lo];
+            if (lo == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
+            for (uint32_t skip = want - s_pref[lo]; skip > 0; --skip) bits &= bits - 1u;   // drop the lowest set bits
+            const uint32_t unit = lo * 32u + static_cast<uint32_t>(__builtin_ctz(bits));
+            const uint32_t tile = unit >> 1, row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
+            row0 = static_cast<int64_t>(row_tile) * kResTileRows + (unit & 1u) * kHalfRows + r_in;
+            if (row0 >= a.K) continue;                     // uniform over the wave: rows past the matrix
+            row_end = row0 + n < a.K ? row0 + n : a.K;
+            col0 = static_cast<int64_t>(col_tile) * kResCols;
+            return true;
         }
-        uint32_t bits = ~s_held[lo];
-        if (lo == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
-        for (uint32_t skip = want - s_pref[lo]; skip > 0; --skip) bits &= bits - 1u;   // drop the lowest set bits
-        const uint32_t unit = lo * 32u + static_cast<uint32_t>(__builtin_ctz(bits));
-        const uint32_t tile = unit >> 1, row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
-        const int64_t row0 = static_cast<int64_t>(row_tile) * kResTileRows + (unit & 1u) * kHalfRows + (wave & 3) * kResRows;
-        load_tile(a, row0 < a.K ? row0 : a.K - 1, a.K, static_cast<int64_t>(col_tile) * kResCols, lane, v);
-        quantize_store_tile(a, cq, v, row0, a.K, static_cast<int64_t>(col_tile) * kResCols, lane);
+        return false;
+    };
+    bool a_live = next_step(a_row0, a_end, a_col0);
+    if (a_live) load_tile(a, a_row0, a_end, a_col0, lane, v0);         // in flight while the other kept tiles are stored
+    if (held1 != kNoTile) {   // uniform
+        int64_t row0, col0;
+        tile_origin(held1, ncol, wave, row0, col0);
+        quantize_store_tile(a, cq, v1, row0, a.K, col0, lane);
     }
+    if (parked != kNoTile) {   // uniform: back from LDS into the same lanes' registers
+#pragma unroll
+        for (int r = 0; r < kResRows; ++r) {
+            const float4 x = park[r * kWave];
+            v1[r][0] = x.x; v1[r][1] = x.y; v1[r][2] = x.z; v1[r][3] = x.w;
+        }
+        int64_t prow0, pcol0;
+        tile_origin(parked, ncol, wave, prow0, pcol0);
+        quantize_store_tile(a, cq, v1, prow0, a.K, pcol0, lane);
+    }
+    bool b_live = next_step(b_row0, b_end, b_col0);
+    if (b_live) load_tile(a, b_row0, b_end, b_col0, lane, v1);
+    while (a_live || b_live) {
+        if (a_live) {
+            quantize_store_tile(a, cq, v0, a_row0, a_end, a_col0, lane);
+            a_live = next_step(a_row0, a_end, a_col0);
+            if (a_live) load_tile(a, a_row0, a_end, a_col0, lane, v0);
+        }
+        if (b_live) {
+            quantize_store_tile(a, cq, v1, b_row0, b_end, b_col0, lane);
+            b_live = next_step(b_row0, b_end, b_col0);
+            if (b_live) load_tile(a, b_row0, b_end, b_col0, lane, v1);
+        }
+    }
+    OQ_STAMP(5);
     if (a.done != nullptr) {   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
         if (first) clean_state(a, gridDim.x - 1u, kResWaves * kWave);
         else if (threadIdx.x == 0) agent_add(a.done, 1u);
@@ -601,3 +702,9 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
 }
 
 }  // namespace oq
+
+#ifdef OQ_TENSOR_STAMPS
+extern "C" int32_t oq_lab_tensor_stamps(uint64_t* host_out /* [512 * 8] */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(oq::g_tensor_stamps), sizeof(uint64_t) * 512 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

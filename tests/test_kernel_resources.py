@@ -75,10 +75,11 @@ def test_gptq_loop_kernels_do_not_spill(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_resident_rtn_kernels_keep_two_workgroups_per_cu(tmp_path):
-    """`rtn_resident_groups` / `rtn_tensor_onepass` (channel, tensor, tall groups: W read once) hold a 128 x 256 tile in 64
-    registers per lane while the range completes elsewhere; two 8-wave workgroups per CU (<= 128 registers, no scratch) are
-    what keeps loads in flight while one of them waits."""
+def test_resident_rtn_kernels_keep_their_tiles_in_registers(tmp_path):
+    """`rtn_resident_groups` (channel, tall groups: W read once) holds a 128 x 256 tile in 64 registers per lane while the range
+    completes elsewhere; two 8-wave workgroups per CU (<= 128 registers, no scratch) are what keeps loads in flight while one of
+    them waits.  `rtn_tensor_onepass` runs ONE 8-wave workgroup per CU that keeps two tiles in registers (128 of <= 256) and
+    one in LDS; a spill would turn its kept tiles into scratch traffic."""
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "rtn_resident.hip")
     r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
@@ -87,11 +88,11 @@ def test_resident_rtn_kernels_keep_two_workgroups_per_cu(tmp_path):
     seen = {}
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?Occupancy \[waves/SIMD\]: (\d+)", r.stderr, re.S):
         seen[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
-    for key in ("rtn_resident_groups", "rtn_tensor_onepass"):
+    for key, max_vgprs, min_occ in (("rtn_resident_groups", 128, 4), ("rtn_tensor_onepass", 256, 2)):
         hits = [v for k, v in seen.items() if key in k]
         assert hits, (key, list(seen))
         for vgprs, scratch, occ in hits:
-            assert vgprs <= 128 and scratch == 0 and occ >= 4, (key, vgprs, scratch, occ)
+            assert vgprs <= max_vgprs and scratch == 0 and occ >= min_occ, (key, vgprs, scratch, occ)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
