@@ -280,6 +280,250 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
 }
 
 // ---------------------------------------------------------------------------------------------
+// Channel / tall groups, streamed: ONE persistent 8-wave workgroup per CU with TWO tile slots in registers (the per-tensor
+// kernel's shape).  A workgroup loads, folds and PUBLISHES a tile into one slot and only then waits for the range of the
+// tile in the other slot -- which was published a whole tile-load earlier and is normally complete -- quantizes and stores
+// it, takes the next ticket and refills that slot.  The memory-side round trips of the hand-off no longer stand between a
+// tile's load and its store with nothing else in flight on the CU (rtn_resident_groups: 65 us on 4096 x 11008 int8).
+//
+// Forward progress.  A ticket is taken only right in front of its load and is published before the workgroup waits for
+// anything (between take and publish lie the stores of the other slot's tile, a load and a fold: no wait).  Let R be the
+// oldest incomplete range.  If one of R's tickets has not been taken, no later ticket has been taken either, so nobody holds
+// a tile of a younger range and every waiting workgroup waits for R while holding a published tile of R: at most
+// chunks - 1 of them.  Any other running workgroup is loading / storing, or waits for an older, i.e. complete range: it goes
+// on and takes the next ticket, which is R's.  With at least `chunks` workgroups running (the host enforces chunks <= 192
+// against 256 CUs) R completes.  Workgroups that are not resident yet hold no ticket and nobody waits for them.
+// ---------------------------------------------------------------------------------------------
+#ifdef OQ_TENSOR_STAMPS   // lab build only (scripts/lab_tensor_stamps.py): 100 MHz wall-clock stamps of every workgroup's phases
+__device__ uint64_t g_tensor_stamps[512 * 8];
+#define OQ_STAMP(i) do { if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// accumulate the time since *T0 into counter i and restart the clock (stream kernel: per-phase sums over a workgroup's tiles)
+#define OQ_LAP(i, T0) do { if (threadIdx.x == 0) { const uint64_t now_ = wall_clock64(); g_tensor_stamps[blockIdx.x * 8 + (i)] += now_ - (T0); (T0) = now_; } } while (0)
+#else
+#define OQ_STAMP(i) do { } while (0)
+#define OQ_LAP(i, T0) do { } while (0)
+#endif
+
+struct StreamTile {          // everything uniform over the workgroup except slot0 / col_ok
+    uint32_t range, c, kg;
+    int64_t row0, row_end, tile_col0, slot0;
+    bool col_ok;
+};
+
+__device__ __forceinline__ StreamTile stream_tile(const ResidentArgs& a, uint32_t t, int lane, int wave) {
+    StreamTile s;
+    const uint32_t chunks = static_cast<uint32_t>(a.chunks), kgroups = static_cast<uint32_t>(a.kgroups);
+    s.range = t / chunks;
+    s.c = t - s.range * chunks;
+    const uint32_t col_tile = s.range / kgroups;
+    s.kg = s.range - col_tile * kgroups;
+    s.row_end = min(static_cast<int64_t>(s.kg) * a.g + a.g, a.K);
+    s.row0 = static_cast<int64_t>(s.kg) * a.g + static_cast<int64_t>(s.c) * kResTileRows + wave * kResRows;
+    s.tile_col0 = static_cast<int64_t>(col_tile) * kResCols;
+    // slot of column (tile_col0 + lane * 4 + i) of k-group kg: [kg][column tile][i][lane] -- a wave-instruction of key
+    // atomics (fixed i) then covers 256 contiguous bytes = four 64-byte requests at the memory side instead of sixteen
+    s.slot0 = (static_cast<int64_t>(s.kg) * a.ncol_tiles + col_tile) * kResCols + lane;
+    s.col_ok = s.tile_col0 + lane * 4 < a.N;
+    return s;
+}
+
+// lane-local column ranges of a freshly loaded tile -> this wave's row of the LDS exchange
+__device__ __forceinline__ void stream_fold_local(int lane, int wave, const float (&v)[kResRows][4], float4 (&s_mn)[kResWaves][kWave],
+                                                  float4 (&s_mx)[kResWaves][kWave]) {
+    float mn[4], mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mn[i] = mx[i] = v[0][i];
+#pragma unroll
+    for (int r = 1; r < kResRows; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mn[i] = nmin(mn[i], v[r][i]);
+            mx[i] = nmax(mx[i], v[r][i]);
+        }
+    s_mn[wave][lane] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+    s_mx[wave][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+}
+
+// one wave folds the workgroup's partials of a tile and publishes them: key atomics, drain, counter add.  Never waits for
+// another workgroup.
+__device__ __forceinline__ void stream_publish_wave(const ResidentArgs& a, const StreamTile& s, int lane, float4 (&s_mn)[kResWaves][kWave],
+                                                    float4 (&s_mx)[kResWaves][kWave]) {
+    float4 tn = s_mn[0][lane], tx = s_mx[0][lane];
+    float mn[4] = {tn.x, tn.y, tn.z, tn.w}, mx[4] = {tx.x, tx.y, tx.z, tx.w};
+#pragma unroll
+    for (int w = 1; w < kResWaves; ++w) {
+        tn = s_mn[w][lane]; tx = s_mx[w][lane];
+        mn[0] = nmin(mn[0], tn.x); mn[1] = nmin(mn[1], tn.y); mn[2] = nmin(mn[2], tn.z); mn[3] = nmin(mn[3], tn.w);
+        mx[0] = nmax(mx[0], tx.x); mx[1] = nmax(mx[1], tx.y); mx[2] = nmax(mx[2], tx.z); mx[3] = nmax(mx[3], tx.w);
+    }
+    if (s.col_ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            agent_max(a.key_max + s.slot0 + i * kWave, key_of_max(mx[i]));
+            agent_max(a.key_nmin + s.slot0 + i * kWave, key_of_min(mn[i]));
+        }
+    }
+    drain_vmem();                                        // this wave's key atomics are performed ...
+    if (lane == 0) agent_add(a.counters + s.range * kResCtrPad, 1u);    // ... before the range counts this tile
+}
+
+// final keys of a complete range -> this lane's four parameter sets; chunk 0 writes them out (rtn.py:98-109 layout: entry n * kgroups + kg)
+__device__ __forceinline__ void stream_params(const ResidentArgs& a, const StreamTile& s, int lane, int wave, ColQ (&cq)[4]) {
+    float mn[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (s.col_ok) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mx[i] = max_of_key(agent_load(a.key_max + s.slot0 + i * kWave));
+            mn[i] = min_of_key(agent_load(a.key_nmin + s.slot0 + i * kWave));
+        }
+    }
+    const int32_t bias = a.grid.qmin < 0 ? 128 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cq[i] = make_colq(qparam_from_minmax(mn[i], mx[i], a.grid), mn[i], mx[i], bias);
+    if (s.c == 0 && wave == 0 && s.col_ok) {
+        if (a.kgroups == 1) {
+            *reinterpret_cast<float4*>(a.scale + s.tile_col0 + lane * 4) = make_float4(cq[0].scale, cq[1].scale, cq[2].scale, cq[3].scale);
+            *reinterpret_cast<uint32_t*>(a.zp + s.tile_col0 + lane * 4) =
+                (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 8) |
+                ((static_cast<uint32_t>(cq[2].zp) & 0xffu) << 16) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 24);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t o = (s.tile_col0 + lane * 4 + i) * a.kgroups + s.kg;
+                a.scale[o] = cq[i].scale;
+                a.zp[o] = static_cast<uint8_t>(cq[i].zp);
+            }
+        }
+    }
+}
+
+// Quantize and store the tile in `v` ROW BY ROW, each row's registers refilled at once with the same row of tile `n` (when
+// `refill`): the CU's loads run beside its stores instead of after them.
+__device__ __forceinline__ void stream_rows(const ResidentArgs& a, const StreamTile& s, const ColQ (&cq)[4], bool refill, const StreamTile& n,
+                                            int lane, float (&v)[kResRows][4]) {
+    const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
+    const int32_t bias = qmin < 0 ? 128 : 0;
+    int64_t lcol = n.tile_col0 + lane * 4;
+    lcol = lcol < a.N ? lcol : a.N - 4;
+    const float* src = a.W + lcol;
+    const int64_t nrow0 = n.row0 < n.row_end ? n.row0 : n.row_end - 1;   // a wave past the range's end repeats its last row
+    const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+    const uint32_t flip = bias ? 0x80808080u : 0u;
+    uint8_t* o = a.q + s.row0 * a.N + s.tile_col0 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < kResRows; ++r) {
+        float f[4];
+        bool unsafe = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(v[r][i], cq[i], lo_b, hi_b, unsafe);
+        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {   // wave-uniform, rare: redo this row with the IEEE divide
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(v[r][i], cq[i], qmin, qmax, bias);
+        }
+        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
+        w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
+        if (s.col_ok && s.row0 + r < s.row_end) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
+        if (refill) {
+            const int64_t row = nrow0 + r < n.row_end ? nrow0 + r : n.row_end - 1;
+            const f32x4r u = __builtin_nontemporal_load(reinterpret_cast<const f32x4r*>(src + row * a.ldw));
+            v[r][0] = u[0]; v[r][1] = u[1]; v[r][2] = u[2]; v[r][3] = u[3];
+        }
+    }
+}
+
+// Wait for the range of the tile in `v`, then quantize and store it while its registers are refilled with the next tile
+// (ticket taken after the wait, so that it is never held across one); the new tile is folded and published before this
+// returns.  Returns the new ticket (>= ntiles: the slot is empty).
+__device__ __forceinline__ uint32_t stream_finish_refill(const ResidentArgs& a, uint32_t t, int lane, int wave, float (&v)[kResRows][4],
+                                                         float4 (&s_mn)[kResWaves][kWave], float4 (&s_mx)[kResWaves][kWave],
+                                                         uint32_t& s_ticket, uint64_t& lap0) {
+    const StreamTile s = stream_tile(a, t, lane, wave);
+    // the poller sits in wave 1: wave 0 may still be draining the key atomics of the tile it has just published
+    if (threadIdx.x == kWave) spin_until(a.counters + s.range * kResCtrPad, static_cast<uint32_t>(a.chunks));
+    __syncthreads();
+    OQ_LAP(1, lap0);
+    uint32_t pending = 0;
+    if (threadIdx.x == 0) pending = agent_add(a.tickets, 1u);     // travels beside the key loads; published before any wait
+    ColQ cq[4];
+    stream_params(a, s, lane, wave, cq);
+    if (threadIdx.x == 0) s_ticket = pending;
+    __syncthreads();
+    const uint32_t tn = s_ticket;     // the next write of s_ticket lies behind the barrier of the fold below or of the next call
+    OQ_LAP(2, lap0);
+    const bool refill = tn < a.ntiles;                         // uniform
+    const StreamTile n = stream_tile(a, refill ? tn : t, lane, wave);
+    stream_rows(a, s, cq, refill, n, lane, v);
+    OQ_LAP(3, lap0);
+    if (refill) {
+        stream_fold_local(lane, wave, v, s_mn, s_mx);
+        __syncthreads();
+        if (wave == 0) stream_publish_wave(a, n, lane, s_mn, s_mx);
+    }
+    OQ_LAP(4, lap0);
+#ifdef OQ_TENSOR_STAMPS
+    if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + 6] += 1;
+#endif
+    return tn;
+}
+
+__global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_resident_stream(const ResidentArgs a) {
+    __shared__ float4 s_mn[kResWaves][kWave];
+    __shared__ float4 s_mx[kResWaves][kWave];
+    __shared__ uint32_t s_ticket;
+    // the wave index as a scalar: row numbers and row pointers of the tile descriptors stay out of the vector registers
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const uint32_t ntiles = a.ntiles;
+    float v0[kResRows][4], v1[kResRows][4];
+    uint64_t lap0 = 0;
+#ifdef OQ_TENSOR_STAMPS
+    if (threadIdx.x < 8) g_tensor_stamps[blockIdx.x * 8 + threadIdx.x] = 0;
+    __syncthreads();
+    lap0 = wall_clock64();
+    const uint64_t kernel_t0 = lap0;
+#endif
+    if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
+    __syncthreads();
+    uint32_t ta = s_ticket, tb = ntiles;
+    __syncthreads();
+    const bool first = ta == 0;
+    if (ta < ntiles) {   // uniform
+        {
+            const StreamTile s = stream_tile(a, ta, lane, wave);
+            // a wave whose rows all lie past the range's end (last chunk of a ragged range) repeats the range's last row
+            load_tile<true>(a, s.row0 < s.row_end ? s.row0 : s.row_end - 1, s.row_end, s.tile_col0, lane, v0);
+            stream_fold_local(lane, wave, v0, s_mn, s_mx);
+            __syncthreads();
+            if (wave == 0) stream_publish_wave(a, s, lane, s_mn, s_mx);
+        }
+        if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // after the publish: no ticket is held unpublished across a barrier that a wait could sit behind
+        __syncthreads();
+        tb = s_ticket;
+        __syncthreads();
+        if (tb < ntiles) {
+            const StreamTile s = stream_tile(a, tb, lane, wave);
+            load_tile<true>(a, s.row0 < s.row_end ? s.row0 : s.row_end - 1, s.row_end, s.tile_col0, lane, v1);
+            stream_fold_local(lane, wave, v1, s_mn, s_mx);
+            __syncthreads();
+            if (wave == 0) stream_publish_wave(a, s, lane, s_mn, s_mx);
+        }
+        OQ_LAP(0, lap0);      // prologue: two tiles loaded and published
+        while (ta < ntiles || tb < ntiles) {
+            if (ta < ntiles) ta = stream_finish_refill(a, ta, lane, wave, v0, s_mn, s_mx, s_ticket, lap0);
+            if (tb < ntiles) tb = stream_finish_refill(a, tb, lane, wave, v1, s_mn, s_mx, s_ticket, lap0);
+        }
+    }
+#ifdef OQ_TENSOR_STAMPS
+    if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + 5] = wall_clock64() - kernel_t0;
+#endif
+    if (a.done != nullptr) {   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
+        if (first) clean_state(a, gridDim.x - 1u, kResWaves * kWave);
+        else if (threadIdx.x == 0) agent_add(a.done, 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Per-tensor.  Persistent workgroups; tile index = ticket (column tiles fastest: co-resident workgroups stream whole rows).
 //
 // Forward progress.  Phase A never waits: a workgroup takes tickets, loads, folds the tile into a running min / max
@@ -293,12 +537,6 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
 constexpr int kHalfRows = kResTileRows / 2;                      // phase-B unit: half a tile, 64 rows x 256 columns (a team of four waves)
 constexpr int kParkBytes = kResWaves * kResRows * kWave * 16;    // one tile: 128 KB
 
-#ifdef OQ_TENSOR_STAMPS   // lab build only (scripts/lab_tensor_stamps.py): 100 MHz wall-clock stamps of every workgroup's phases
-__device__ uint64_t g_tensor_stamps[512 * 8];
-#define OQ_STAMP(i) do { if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define OQ_STAMP(i) do { } while (0)
-#endif
 
 constexpr uint32_t kNoTile = 0xFFFFFFFFu;
 
@@ -619,20 +857,29 @@ static int resident_blocks(const void* kernel, size_t dynamic_lds) {
     return cus * per_cu;
 }
 
-// Tile of the channel / tall-group kernel: rows per workgroup.  Speed only (OQ_RTN_RES_TILE = 256 | 128 for experiments).
-// 64- and 32-row tiles (4 / 7 workgroups per CU) were built and measured SLOWER (92 / 154 us against 70 on 4096 x 11008): more
-// siblings per range mean more key atomics and a longer wait for the last of them.
-static int groups_tile_rows(int64_t g) {
+// Which kernel takes a channel / tall-group call (speed only, same bytes).  Measured, int8 per channel, same box
+// (scripts/quick_strategies.py --lib, round 4):
+//                                   4096x11008  4096x4096  8192x8192  11008x4096
+//   rtn_resident_groups, 256 rows      65.3        27.3      103.3       84.4 us
+//   rtn_resident_groups, 128 rows      70          30          -         84
+//   rtn_resident_stream (128 rows)     65.8        33.5       89.0       64.3
+// so columns of up to 4096 rows keep the one-tile-per-workgroup kernel (a range has <= 16 tiles: the streamed kernel's two
+// tiles per workgroup are all it ever loads, and they are loaded one after the other), taller ones are streamed.
+// 64- and 32-row tiles (4 / 7 workgroups per CU) took 92 / 154 us on the first.  OQ_RTN_RES_TILE = 256 | 128 forces
+// rtn_resident_groups with that tile height, OQ_RTN_RES_TILE = 1 the streamed kernel (lab switch).
+constexpr int64_t kResStreamAbove = 4096;
+static int forced_tile_rows() {
     static const int forced = [] {
         const char* v = getenv("OQ_RTN_RES_TILE");
         const int r = v ? atoi(v) : 0;
-        return (r == 256 || r == 128) ? r : 0;
+        return (r == 256 || r == 128 || r == 1) ? r : 0;
     }();
-    if (forced) return forced;
-    // measured on 4096 x 11008 / 4096 x 4096 / 11008 x 4096 (int8 channel): 256-row tiles 65 / 29 / 95 us, 128-row tiles
-    // 70 / 30 / 84 us: fewer, larger tiles win while a range has few of them (less skew, fewer atomics), smaller ones when
-    // a column is tall (one 16-wave workgroup per CU waits too long for 42 siblings)
-    return g <= 8192 ? 256 : kResGroupTileRows;
+    return forced;
+}
+static bool groups_streamed(int64_t g) { return forced_tile_rows() ? forced_tile_rows() == 1 : g > kResStreamAbove; }
+static int groups_tile_rows(int64_t g) {
+    if (forced_tile_rows() > 1) return forced_tile_rows();
+    return groups_streamed(g) ? kResGroupTileRows : 256;
 }
 
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g) {
@@ -696,8 +943,19 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
     a.held = nullptr;
     a.key_max = a.counters + ranges * kResCtrPad;
     a.key_nmin = a.key_max + a.kgroups * static_cast<int64_t>(a.ncol_tiles) * kResCols;
-    if (tile_rows == 256) hipLaunchKernelGGL((rtn_resident_groups<16, 16, 4>), dim3(a.ntiles), dim3(16 * kWave), 0, s, a);
-    else hipLaunchKernelGGL((rtn_resident_groups<8, 16, 4>), dim3(a.ntiles), dim3(8 * kWave), 0, s, a);
+    if (!groups_streamed(g)) {
+        if (tile_rows == 256) hipLaunchKernelGGL((rtn_resident_groups<16, 16, 4>), dim3(a.ntiles), dim3(16 * kWave), 0, s, a);
+        else hipLaunchKernelGGL((rtn_resident_groups<8, 16, 4>), dim3(a.ntiles), dim3(8 * kWave), 0, s, a);
+    } else {
+        const int resident = resident_blocks(reinterpret_cast<const void*>(rtn_resident_stream), 0);
+        OQ_REQUIRE(resident > 0, OQ_ERR_LAUNCH, "rtn: occupancy query failed");
+        // forward progress needs at least `chunks` running workgroups (see the kernel): the chunk limit of
+        // rtn_resident_eligible (192) against one workgroup on each of 256 CUs
+        OQ_REQUIRE(a.chunks <= resident || a.ntiles <= static_cast<uint32_t>(resident), OQ_ERR_UNSUPPORTED,
+                   "rtn: %lld chunks per range need as many resident workgroups, the device holds %d", (long long)a.chunks, resident);
+        const uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
+        hipLaunchKernelGGL(rtn_resident_stream, dim3(blocks), dim3(kResWaves * kWave), 0, s, a);
+    }
     return check_launch("rtn_resident_groups");
 }
 

@@ -14,6 +14,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:      # lab: another build of the library (same ABI), e.g. the previous commit's, for a same-box comparison
+    from onnx_quantize_amd.hip import _lib  # noqa: E402
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from onnx_quantize_amd.hip import ops  # noqa: E402
 
 
@@ -24,6 +27,7 @@ def sha(t):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--lib", default=None, help="lab: path of another build of liboq_hip.so")
     ap.add_argument("--json", default=None)
     ap.add_argument("--shapes", default="4096x11008,4096x4096,11008x4096,256x512,640x2048")
     args = ap.parse_args()

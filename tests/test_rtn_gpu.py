@@ -106,6 +106,28 @@ def test_rtn_two_pass_vs_oracle(ops, strategy, g):
         assert s.shape == es.shape and z.shape == ez.shape
 
 
+@pytest.mark.parametrize("k,n,strategy,g", [(4100, 260, "channel", -1), (8192, 516, "channel", -1), (12288, 300, "channel", -1),
+                                            (16384, 264, "group", 8192), (24576, 68, "channel", -1), (9000, 1028, "group", 4500)])
+def test_streamed_kernel_for_tall_ranges_vs_oracle(ops, k, n, strategy, g):
+    """Ranges taller than 4096 rows run on `rtn_resident_stream` (persistent workgroups, two tile slots, the next tile loaded
+    while the previous one is stored): ragged last chunks, partial column tiles, two k-groups, up to the 192-chunk limit; the
+    state must come back zero (ops.rtn_quantize reuses one state buffer per stream without clearing it)."""
+    import torch
+    rng = np.random.default_rng(k + n)
+    w = (rng.standard_t(4, size=(k, n)) * 0.05).astype(np.float32)
+    wd = dev(w)
+    for qtype, sym in (("int8", False), ("uint8", True), ("uint4", False)):
+        for _ in range(2):                                    # the second call meets the state the first one left
+            q, s, z = ops.rtn_quantize(wd, qtype, strategy, g, sym)
+        eq, es, ez = O.rtn_quantize(w, qtype, strategy, g, sym)
+        np.testing.assert_array_equal(q.cpu().numpy(), eq)
+        np.testing.assert_array_equal(z.cpu().numpy(), ez)
+        assert s.cpu().numpy().tobytes() == np.asarray(es).tobytes()
+    state = ops._rtn_state(1, wd.device)                    # the buffer the calls above used (same device, same stream)
+    torch.cuda.synchronize()
+    assert int(state.count_nonzero()) == 0
+
+
 DIGESTS = load_json("digests.json")
 
 
