@@ -882,6 +882,26 @@ static int groups_tile_rows(int64_t g) {
     return groups_streamed(g) ? kResGroupTileRows : 256;
 }
 
+// workgroups of the channel / tall-group kernel chosen for `g` that the current device runs at once (cached per device)
+static int groups_resident(int64_t g) {
+    static int cache[3][64];
+    static bool filled[3][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    const int which = groups_streamed(g) ? 0 : (groups_tile_rows(g) == 256 ? 1 : 2);
+    if (!filled[which][dev]) {   // benign race: every thread computes the same value
+        int cus = 0, per_cu = 0;
+        const void* k = which == 0 ? reinterpret_cast<const void*>(rtn_resident_stream)
+                      : which == 1 ? reinterpret_cast<const void*>(rtn_resident_groups<16, 16, 4>) : reinterpret_cast<const void*>(rtn_resident_groups<8, 16, 4>);
+        const int threads = which == 1 ? 16 * kWave : kResWaves * kWave;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, threads, 0) != hipSuccess) return 0;
+        cache[which][dev] = cus * per_cu;
+        filled[which][dev] = true;
+    }
+    return cache[which][dev];
+}
+
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g) {
     const int64_t kgroups = K / g, chunks = ceil_div(g, groups_tile_rows(g));
     const int64_t ncol_tiles = ceil_div(N, kResCols);
@@ -899,7 +919,9 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
     const int64_t chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g));
     const int64_t ntiles = ceil_div(N, kResCols) * (K / g) * chunks;
     if (ntiles >= (1LL << 31) || (strategy == OQ_TENSOR && ntiles > kResMaxTensorTiles)) return false;
-    if (strategy != OQ_TENSOR && chunks > 192) return false;   // forward progress needs `chunks` running workgroups (256 CUs)
+    // forward progress needs `chunks` running workgroups (see the kernels): at most 3/4 of what THIS device holds of the kernel
+    // that would run (192 of one workgroup on each of 256 CUs; a 32-CU partition takes ranges of up to 24 chunks)
+    if (strategy != OQ_TENSOR && chunks > 1 && chunks * 4 > static_cast<int64_t>(groups_resident(g)) * 3) return false;
     return workspace_bytes >= rtn_resident_workspace(K, N, strategy, g);
 }
 
@@ -947,11 +969,9 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
         if (tile_rows == 256) hipLaunchKernelGGL((rtn_resident_groups<16, 16, 4>), dim3(a.ntiles), dim3(16 * kWave), 0, s, a);
         else hipLaunchKernelGGL((rtn_resident_groups<8, 16, 4>), dim3(a.ntiles), dim3(8 * kWave), 0, s, a);
     } else {
-        const int resident = resident_blocks(reinterpret_cast<const void*>(rtn_resident_stream), 0);
-        OQ_REQUIRE(resident > 0, OQ_ERR_LAUNCH, "rtn: occupancy query failed");
-        // forward progress needs at least `chunks` running workgroups (see the kernel): the chunk limit of
-        // rtn_resident_eligible (192) against one workgroup on each of 256 CUs
-        OQ_REQUIRE(a.chunks <= resident || a.ntiles <= static_cast<uint32_t>(resident), OQ_ERR_UNSUPPORTED,
+        const int resident = groups_resident(g);
+        // forward progress needs at least `chunks` running workgroups (see the kernel): rtn_resident_eligible has checked it
+        OQ_REQUIRE(resident > 0 && (a.chunks <= resident || a.ntiles <= static_cast<uint32_t>(resident)), OQ_ERR_UNSUPPORTED,
                    "rtn: %lld chunks per range need as many resident workgroups, the device holds %d", (long long)a.chunks, resident);
         const uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
         hipLaunchKernelGGL(rtn_resident_stream, dim3(blocks), dim3(kResWaves * kWave), 0, s, a);

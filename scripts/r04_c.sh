@@ -7,7 +7,8 @@ python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r04_c/bench.json').read().strip().splitlines()[-1])
 r=d['roofline']; print('headline', d['value'], r['frac'], r['launch_us'], 'streamed', r.get('frac_outputs_streamed'), r.get('launch_us_outputs_streamed'))
-print('strategies', json.dumps(d.get('strategies'))[:600])
+print('strategies', json.dumps(d.get('strategies'))[-700:])
+print('searches', json.dumps(d.get('searches'))[:400])
 print('model_rtn', d['model_rtn']['frac'], d['model_rtn']['device_ms'], d['model_rtn']['equals_single_matrix_outputs'])
 print('other_layout', d['other_layout'])
 g=d['gptq']; print('gptq', g['value'], g['seconds'] if 'seconds' in g else '', g.get('verification', {}).get('verified'))
