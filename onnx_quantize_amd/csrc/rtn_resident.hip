@@ -18,9 +18,12 @@
 //   * the integers come out of the same registers with the exact-reciprocal fast path of the group kernels
 //     (oq_common.hpp), so they are the reference's bits by construction.
 //
-// `rtn_resident_groups`: channel and tall groups.  The tiles of one range (one column tile x one k-group) have
-// consecutive tickets, are loaded at about the same time by different workgroups, and every one of them waits for its
-// siblings' partial ranges before it quantizes: one read of W, no second pass.
+// `rtn_resident_groups`: channel and tall groups of up to 4096 rows.  The tiles of one range (one column tile x one
+// k-group) have consecutive tickets, are loaded at about the same time by different workgroups, and every one of them waits
+// for its siblings' partial ranges before it quantizes: one read of W, no second pass.
+// `rtn_resident_stream`: the same for taller ranges with persistent workgroups and two tile slots: a tile is published
+// into one slot before the workgroup waits for the range of the tile in the other one, and that tile's rows are stored
+// while the next tile's rows are loaded into their place.
 // `rtn_tensor_onepass`: per-tensor.  ONE 8-wave workgroup per CU.  Phase A streams all tiles once (running min / max in
 // registers, no barrier per tile beyond the ticket exchange); a workgroup KEEPS the last two tiles it loaded in registers
 // (two slots written alternately, 128 of its <= 256 registers per lane) and the one before in 128 KB of LDS: 96 MB of the
@@ -44,15 +47,15 @@ constexpr int kResTileRows = kResWaves * kResRows;  // 128, the chunk height of 
 constexpr int kResCols = 256;                     // 64 lanes x 4 columns
 constexpr int kResHeader = 160;
 constexpr int kResMaxTensorTiles = 32768;         // bitmap of kept half tiles + its prefix sums in LDS (8 KB each): 1 G parameters; larger tensors take the three-launch path
-constexpr int kResTensorHeader = 128 + 64 * 32 + 64 * 32;   // tickets / counter, 64 key shards, 64 result replicas (a 128-byte line each)
-constexpr int kResGroupTileRows = 128;            // default tile height of rtn_resident_groups (see groups_tile_rows)
+constexpr int kResTensorHeader = 128 + 64 * 32 + 64 * 32;   // tickets / counter, 512 arrival slots of 16 bytes, 64 result replicas (a 128-byte line each)
+constexpr int kResGroupTileRows = 128;            // tile height of rtn_resident_stream and of rtn_resident_groups<8> (see groups_tile_rows)
 constexpr int kResCtrPad = 32;                   // uint32 words per range counter: a 128-byte line each (hundreds of workgroups poll them)
 #ifndef OQ_RES_A_NT
 #define OQ_RES_A_NT false   /* default-policy loads in phase A keep the lines in the Infinity Cache for phase B: 75 us against 78 with nt */
 #endif
 #ifndef OQ_RES_SLEEP
-#define OQ_RES_SLEEP 8
-#endif                   // uint32 words in front of the arrays: tickets, keys, counter on 128-byte lines of their own
+#define OQ_RES_SLEEP 8   /* s_sleep between two polls of a counter */
+#endif
 
 struct ResidentArgs {
     const float* W;
@@ -64,10 +67,10 @@ struct ResidentArgs {
     QGrid grid;
     int32_t layout;
     uint32_t ncol_tiles, ntiles;
-    uint32_t* key_max;    // [slots] ordered key of the running maximum
-    uint32_t* key_nmin;   // [slots] complement of the ordered key of the running minimum (kept as a maximum)
-    uint32_t* counters;   // groups: one per (column tile, k-group); tensor: [0] = tiles counted
-    uint32_t* tickets;    // [0] phase A, [32] phase B
+    uint32_t* key_max;    // groups: [slots] ordered key of the running maximum; tensor: the arrival slots (16 bytes per workgroup)
+    uint32_t* key_nmin;   // groups: [slots] complement of the ordered key of the running minimum (kept as a maximum); tensor: the replica lines
+    uint32_t* counters;   // groups: one per (column tile, k-group); tensor: [0] = tiles counted + arrivals
+    uint32_t* tickets;    // [0]
     uint32_t* held;       // unused since the kept tiles travel in the arrival slots (kept for the layout of the workspace)
     // Self-cleaning (oq_rtn_quantize_stateful_f32: the caller's `state` is zero when the call starts and zero again when it
     // ends, so no clear launch runs in front of the kernel): every workgroup counts itself out at `done`; the cleaner --
