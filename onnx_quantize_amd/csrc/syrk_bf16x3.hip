@@ -427,7 +427,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (gemm_f16x3_kernel).  gsrc[i]: where this wave's i-th 1 KB piece of stage 0 comes from; a stage further is
 // gsrc[i] + stage_bytes[i >= split ? 1 : 0] (the two operands may have different padded widths).  acc: the wave's 64 x 128
 // tile as 4 x 8 tiles of 16 x 16, zeroed here.
-template <int NDMA>
+// PRODUCTS = 3: hi.hi + hi.lo + lo.hi (22-bit operands).  PRODUCTS = 1: hi.hi only (11-bit operands: the AWQ / clip searches'
+// loss, a sum of 1.7e7 squared dot products whose rounding errors average out far below the searches' resolution); the lo
+// planes are then neither fetched nor read (the waves that would fetch them issue no DMA).
+template <int NDMA, int PRODUCTS = 3>
 __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], const int64_t (&stage_bytes)[8], const int64_t nstages,
                                                  unsigned char* lds, f32x4v (&acc)[4][8]) {
     using G = StageGeom<3>;
@@ -440,9 +443,12 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     uint32_t ldst[8];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) ldst[i] = static_cast<uint32_t>(wave * NDMA + i) * 1024u;
+    static_assert(PRODUCTS == 3 || NDMA == 8, "piece of a wave's DMA pieces: (wave / 2) % 2 with eight per wave");
+    const bool dma_on = PRODUCTS == 3 || ((wave >> 1) & 1) == 0;     // uniform: this wave's pieces are hi planes
     auto stage_dma = [&](int64_t s_rel, int slot, int i) {
-        __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes[i],
-                                         (__attribute__((address_space(3))) void*)(lds + slot * kStageBytes + ldst[i]), 16, 0, 0);
+        if (dma_on)
+            __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes[i],
+                                             (__attribute__((address_space(3))) void*)(lds + slot * kStageBytes + ldst[i]), 16, 0, 0);
     };
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) stage_dma(0, 0, i);
@@ -461,15 +467,15 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     f16x8 a[4][2], b[2][2];
     auto read_a = [&](int slot, int i) {
 #pragma unroll
-        for (int p = PIECES - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_a + p * kPlaneBytes + i * 16 * 16);
+        for (int p = (PRODUCTS == 3 ? PIECES : 1) - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_a + p * kPlaneBytes + i * 16 * 16);
     };
     auto read_b = [&](int slot, int j, int which) {
 #pragma unroll
-        for (int p = 0; p < PIECES; ++p) b[which][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_b + p * kPlaneBytes + j * 16 * 16);
+        for (int p = 0; p < (PRODUCTS == 3 ? PIECES : 1); ++p) b[which][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_b + p * kPlaneBytes + j * 16 * 16);
     };
     auto stage_body = [&](auto phase_tag, int64_t s, int cur, int wr) {
-        constexpr int STRIDE = OQ_SYRK_M16_STRIDE;                       // in 16-cycle MFMA slots
-        constexpr int DMA0 = decltype(phase_tag)::value ? 4 : 0;
+        constexpr int STRIDE = PRODUCTS == 3 ? OQ_SYRK_M16_STRIDE : 2;   // in 16-cycle MFMA slots (32 of them per stage with one product)
+        constexpr int DMA0 = decltype(phase_tag)::value ? (PRODUCTS == 3 ? 4 : 2) : 0;
         const int64_t s_dma = s + 1 < nstages ? s + 1 : nstages - 1;
         int slot = 0;
         auto mm = [&](const f16x8& x, const f16x8& y, f32x4v& c) {
@@ -490,8 +496,10 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
                     __builtin_amdgcn_sched_barrier(0);
                     read_b(cur, j + 1, cb ^ 1);
                 }
-                mm(a[i][1], b[cb][0], c);     // lo . hi
-                mm(a[i][0], b[cb][1], c);     // hi . lo
+                if constexpr (PRODUCTS == 3) {
+                    mm(a[i][1], b[cb][0], c);     // lo . hi
+                    mm(a[i][0], b[cb][1], c);     // hi . lo
+                }
                 mm(a[i][0], b[cb][0], c);     // hi . hi
                 acc[i][j] = c;
             }
@@ -798,7 +806,7 @@ struct PieceGemm {
     int32_t k_to_m = 0;     // A[k][m] = 0 for k > m (upper triangular A^T): a row tile ends its contraction behind its last row
 };
 
-template <int EPI>
+template <int EPI, int PRODUCTS = 3>
 __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int tile, unsigned char* lds) {
     using G = StageGeom<3>;
     constexpr int PIECES = 2, CH = 4, NDMA = G::NDMA;
@@ -824,7 +832,7 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
     }
     f32x4v acc[4][8];
     if (s_end > s_begin) {
-        f16_m16_mainloop<NDMA>(gsrc, stage_bytes, s_end - s_begin, lds, acc);
+        f16_m16_mainloop<NDMA, PRODUCTS>(gsrc, stage_bytes, s_end - s_begin, lds, acc);
     } else {   // block-uniform: nothing to contract
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -886,10 +894,10 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
     }
 }
 
-template <int EPI>
+template <int EPI, int PRODUCTS = 3>
 __global__ __launch_bounds__(kSThreads) void gemm_f16x3_kernel(const PieceGemm g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    gemm_f16x3_body<EPI>(g, static_cast<int>(blockIdx.x), lds);
+    gemm_f16x3_body<EPI, PRODUCTS>(g, static_cast<int>(blockIdx.x), lds);
 }
 
 // many products of one shape in one launch: blockIdx.y = problem (its PieceGemm in device memory: uniform scalar loads)
@@ -1282,9 +1290,10 @@ int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols
 }
 
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
-                          int64_t ldc, float* loss_partial, hipStream_t s) {
+                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only) {
     OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && (C != nullptr) != (loss_partial != nullptr), OQ_ERR_INVALID_ARGUMENT,
                "gemm_f16x3: bad argument");
+    OQ_REQUIRE(!hi_pieces_only || loss_partial, OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the one-product form exists for the loss epilogue only");
     PieceGemm g;
     g.scale_a = static_cast<const float*>(pieces_a);
     g.scale_b = static_cast<const float*>(pieces_b);
@@ -1295,7 +1304,11 @@ int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M,
     const int64_t tiles = (g.Mp / kST) * (g.Np / kST);
     OQ_REQUIRE(tiles < (1 << 30), OQ_ERR_UNSUPPORTED, "gemm_f16x3: too many tiles");
     const int lds_bytes = StageGeom<3>::LDS;
-    if (loss_partial) {
+    if (loss_partial && hi_pieces_only) {
+        OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
+                   OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
+        hipLaunchKernelGGL((gemm_f16x3_kernel<1, 1>), dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
+    } else if (loss_partial) {
         OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
                    OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
         hipLaunchKernelGGL(gemm_f16x3_kernel<1>, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
