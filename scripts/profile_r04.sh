@@ -1,13 +1,13 @@
 #!/bin/bash
 # Round-4 profiles (run on the GPU box through gpurun): every summary that profiles/r04_* is made of.  Kernel traces
 # (--kernel-trace --stats) and PMC passes are separate runs; the program comes directly after `--`.
-#   scripts/profile_r04.sh [rtn] [strategies] [packed] [searches] [gptq]      (default: all)
+#   scripts/profile_r04.sh [rtn] [strategies] [packed] [searches] [awq] [gptq]      (default: all)
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r04
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-WHAT="${*:-rtn strategies packed searches gptq}"
+WHAT="${*:-rtn strategies packed searches awq gptq}"
 trace() { rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1/trace -- "${@:2}" > $OUT/$1.trace.log 2>&1; }
 pmc() { rocprofv3 --pmc $2 --output-format csv -d $OUT/$1/pmc_$2 -- "${@:3}" > $OUT/$1.$2.log 2>&1; }
 for w in $WHAT; do
@@ -18,7 +18,7 @@ for w in $WHAT; do
         trace rtn_$lay $B; pmc rtn_$lay FETCH_SIZE $B; pmc rtn_$lay WRITE_SIZE $B
       done;;
     strategies)
-      P="python3 $R/scripts/quick_strategies.py --reps 100 --shapes 4096x11008"
+      P="python3 $R/scripts/quick_strategies.py --reps 100 --shapes 4096x11008,11008x4096"
       trace strategies $P; pmc strategies FETCH_SIZE $P; pmc strategies WRITE_SIZE $P;;
     packed)
       P="python3 $R/scripts/quick_packed.py"
@@ -26,6 +26,9 @@ for w in $WHAT; do
     searches)
       P="python3 $R/scripts/quick_searches.py"
       trace searches $P;;
+    awq)
+      P="python3 $R/scripts/quick_awq.py"
+      trace awq $P;;
     gptq)
       trace gptq python3 $R/bench_gptq.py --layers 8 --no-cpu-baseline --hessian-methods "" --extra-passes corrected;;
   esac
