@@ -400,11 +400,29 @@ def awq_bench(dev, k: int = 4096, n: int = 4096, t: int = 4096) -> dict:
     wh2 = ops.dequantize(q2, s2, z2, "uint4", mode="group", group=GROUP) / sub[0].reshape(-1, 1)
     ref2 = float(((x64 @ (w.double() - wh2.double())) ** 2).mean())
     ok = abs(float(sub[1].min()) - ref2) <= 2e-3 * ref2
+    # a long calibration set (32768 rows = 16 sequences of 2048 tokens, T = 8 K): the Gram route of awq.hip -- X^T X once per
+    # search on the Hessian kernels, per candidate the quadratic form <D, G D>.  Checked in float64 through the same identity
+    # with a float64 Gram matrix and the winning scale's D from this package's RTN / dequantize kernels.
+    tl = 32768
+    xl = torch.randn((tl, k), generator=gen, device=dev) * (0.1 + 3.9 * torch.rand(k, generator=gen, device=dev))
+    ms_scale_l, (best_l, losses_l) = timed(lambda: ops.awq_scale_search(xl, w, "uint4", "group", GROUP), reps=2)
+    ms_clip_l, _ = timed(lambda: ops.awq_clip_search(xl, w, "uint4", "group", GROUP), reps=2)
+    g64 = torch.zeros((k, k), dtype=torch.float64, device=dev)
+    for r0 in range(0, tl, 4096):
+        xb = xl[r0:r0 + 4096].double()
+        g64 += xb.t() @ xb
+    ql, sl, zl = ops.rtn_quantize(w * best_l.reshape(-1, 1), "uint4", "group", GROUP)
+    dl = w.double() - (ops.dequantize(ql, sl, zl, "uint4", mode="group", group=GROUP) / best_l.reshape(-1, 1)).double()
+    ref_l = float((dl * (g64 @ dl)).sum() / (tl * n))
+    ok_l = abs(float(losses_l.min()) - ref_l) <= 2e-3 * ref_l
     return {"what": "AWQ scale search (20 candidates) and clip search (10 ratios) of one 4096 x 4096 layer with 4096 calibration rows, uint4 g128, "
-                    "device resident; round 2 (torch elementwise + rocBLAS): 23.4 / 11.2 ms",
+                    "device resident; round 2 (torch elementwise + rocBLAS): 23.4 / 11.2 ms; round 3 (22-bit loss product): 7.7 / 3.6 ms",
             "scale_search_ms": round(ms_scale, 3), "clip_search_ms": round(ms_clip, 3), "best_grid_point": i, "best_clip_ratio": best_ratio,
             "loss_at_best": float(losses[i]), "loss_float64_check_rows": 1024, "loss_float64": ref2, "loss_kernel": float(sub[1].min()),
-            "verified": bool(ok)}
+            "long_calibration_set": {"rows": tl, "route": "gram: X^T X once (Hessian kernels), <D, G D> per candidate", "scale_search_ms": round(ms_scale_l, 3),
+                                     "clip_search_ms": round(ms_clip_l, 3), "loss_kernel": float(losses_l.min()), "loss_float64": ref_l,
+                                     "verified": bool(ok_l)},
+            "verified": bool(ok and ok_l)}
 
 
 def search_bench(dev, w) -> dict:

@@ -286,7 +286,22 @@ struct AwqWs {   // carving of the caller's workspace
     float* diff_part;   // absmax partials of awq_diff_kernel
     char* rtn_ws;
     size_t rtn_ws_bytes;
+    // Gram route (T >= kAwqGramRatio K): sum_n ||X d_n||^2 = <D, (X^T X) D>, the K x K Gram matrix made ONCE per search
+    bool gram;
+    float* G;           // [K, K] = (2 / T) X^T X (the GPTQ Hessian kernel, gptq.py:246-260 with n = T)
+    char* pieces_g;     // its fp16 pieces as the product's first operand
+    char* hess_ws;
+    size_t hess_ws_bytes;
 };
+
+// The reference's loss needs two [T, K] x [K, N] products per candidate (awq.py:166-177); here ONE product X D with
+// D = W - W^.  With a long calibration set (T rows >> K channels: 128 sequences of 2048 tokens against K = 4096) even that is
+// T / K times more matrix work than the quadratic form <D, G D> with G = X^T X, which is made once per search by the
+// Hessian kernels: per candidate a [K, K] x [K, N] product whose epilogue takes the dot product with D.  G and D enter with
+// both fp16 pieces (22 bits: rounding G to 11 bits would move every column's loss the same way, nothing averages out).
+// Break-even: three products of 2 K^2 N against one of 2 T K N, plus the Gram matrix over ~20 candidates.
+constexpr int64_t kAwqGramRatio = 6;
+static bool awq_use_gram(int64_t T, int64_t K) { return T >= kAwqGramRatio * K; }
 
 #ifndef OQ_AWQ_HI_ONLY
 #define OQ_AWQ_HI_ONLY 1   /* lab: 0 = the three-product (22-bit) loss of round 3 */
@@ -299,8 +314,13 @@ static int64_t diff_blocks(int64_t K, int64_t N) { return ceil_div(N, 256) * cei
 static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* base) {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
-    char* px = take(gemm_f16x3_pieces_bytes(K, T));
+    const bool gram = awq_use_gram(T, K);
+    char* px = take(gram ? 0 : gemm_f16x3_pieces_bytes(K, T));
     char* pd = take(gemm_f16x3_pieces_bytes(K, N));
+    char* G = take(gram ? static_cast<size_t>(K) * K * 4 : 0);
+    char* pg = take(gram ? gemm_f16x3_pieces_bytes(K, K) : 0);
+    const size_t hess_bytes = gram ? oq_hessian_workspace_bytes(T, K) : 0;
+    char* hws = take(hess_bytes);
     char* Ws = take(static_cast<size_t>(K) * N * 4);
     char* D = take(static_cast<size_t>(K) * N * 4);
     char* q = take(static_cast<size_t>(K) * N);
@@ -310,7 +330,7 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
     char* wsc = take(static_cast<size_t>(K) * 4);
     char* gmax = take(static_cast<size_t>(K) * N * 4 / 16 + static_cast<size_t>(N) * 4 + 1024);
     char* colpart = take(static_cast<size_t>(kColChunks) * K * 4);
-    char* gpart = take(static_cast<size_t>(gemm_f16x3_tiles(T, N)) * 4 + 1024);
+    char* gpart = take(static_cast<size_t>(gemm_f16x3_tiles(gram ? K : T, N)) * 4 + 1024);
     char* dpart = take(static_cast<size_t>(diff_blocks(K, N)) * 4 + 1024);
     const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) + oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
     char* rtn = take(rtn_bytes);
@@ -320,6 +340,7 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
         w->act = reinterpret_cast<float*>(act); w->wsc = reinterpret_cast<float*>(wsc); w->gmax = reinterpret_cast<float*>(gmax);
         w->colpart = reinterpret_cast<float*>(colpart); w->gemm_part = reinterpret_cast<float*>(gpart); w->diff_part = reinterpret_cast<float*>(dpart);
         w->rtn_ws = rtn; w->rtn_ws_bytes = rtn_bytes;
+        w->gram = gram; w->G = reinterpret_cast<float*>(G); w->pieces_g = pg; w->hess_ws = hws; w->hess_ws_bytes = hess_bytes;
     }
     return off + 256;
 }
@@ -360,11 +381,26 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
     // first pieces only: every term of the product carries a relative rounding error <= 2^-10, the loss is a sum of T N
     // squared K-term dot products -- its error (~1e-7 relative, measured against the three-product form) is four orders of
     // magnitude below what separates neighbouring grid points; a third of the matrix work (264 -> ~100 us per candidate)
+    if (w.gram) {
+        // mean((X D)^2) = <D, X^T X D> / (T N) = <D, G D> / (2 N) with G = (2 / T) X^T X
+        st = launch_gemm_f16x3(w.pieces_g, w.pieces_d, K, N, K, 1.0f, 0.0f, w.D, N, w.gemm_part, s, false, true);
+        if (st != OQ_OK) return st;
+        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, w.gemm_part, gemm_f16x3_tiles(K, N), 1.0 / (2.0 * static_cast<double>(N)), loss_out);
+        return check_launch("loss_finish_kernel");
+    }
     st = launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, w.gemm_part, s, kAwqHiPiecesOnly);
     if (st != OQ_OK) return st;
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, w.gemm_part, gemm_f16x3_tiles(T, N), 1.0 / (static_cast<double>(T) * static_cast<double>(N)),
                        loss_out);
     return check_launch("loss_finish_kernel");
+}
+
+// once per search: the activations as the loss product's first operand -- X^T in pieces, or the Gram matrix in pieces
+static int32_t prepare_activations(const AwqWs& w, const float* X, int64_t T, int64_t K, int64_t ldx, void* stream, hipStream_t s) {
+    if (!w.gram) return make_f16x2_pieces(X, K, T, ldx, true, w.pieces_x, s);   // pieces over the contraction index k
+    int32_t st = oq_hessian_accumulate_f32(X, T, K, ldx, 0, T, w.G, OQ_HESSIAN_AUTO, w.hess_ws, w.hess_ws_bytes, stream);
+    if (st != OQ_OK) return st;
+    return make_f16x2_pieces(w.G, K, K, K, false, w.pieces_g, s);
 }
 
 static int32_t check_common(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
@@ -420,8 +456,7 @@ int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ld
     hipLaunchKernelGGL(grid_scales_kernel, dim3(static_cast<uint32_t>(n_grid)), dim3(1024), 0, s, w.act, w.wsc, K, n_grid, scales_out);
     st = check_launch("awq statistics");
     if (st != OQ_OK) return st;
-    // X^T as the GEMM's first operand: pieces over the contraction index k, once
-    st = make_f16x2_pieces(X, K, T, ldx, true, w.pieces_x, s);
+    st = prepare_activations(w, X, T, K, ldx, stream, s);
     if (st != OQ_OK) return st;
     for (int i = 0; i < n_grid; ++i) {
         const float* si = scales_out + static_cast<int64_t>(i) * K;
@@ -447,7 +482,7 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
     hipStream_t s = as_stream(stream);
     AwqWs w;
     awq_workspace(T, K, N, &w, static_cast<char*>(workspace));
-    st = make_f16x2_pieces(X, K, T, ldx, true, w.pieces_x, s);
+    st = prepare_activations(w, X, T, K, ldx, stream, s);
     if (st != OQ_OK) return st;
     for (int i = 0; i < 10; ++i) {
         const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227

@@ -799,7 +799,7 @@ struct PieceGemm {
     float alpha, beta;
     float* C;               // EPI 0: [M, N], leading dimension ldc
     int64_t ldc;
-    float* partial;         // EPI 1: per-block sum of squares of the block's part of A^T B
+    float* partial;         // EPI 1: per-block sum of squares of the block's part of A^T B; EPI 2: per-block sum of (A^T B) o C
     float* Ct = nullptr;    // EPI 0, optional: the same values transposed, Ct[n][m], leading dimension ldct
     int64_t ldct = 0;
     int32_t k_from_n = 0;   // B[k][n] = 0 for k < n (lower triangular B): a column tile starts its contraction at its first column
@@ -869,6 +869,37 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
         };
         if (g.Ct != nullptr) staged_tile_epilogue<true>(acc, lds, rows, cols);
         else staged_tile_epilogue<false>(acc, lds, rows, cols);
+    } else if constexpr (EPI == 2) {
+        // sum over the block's part of (A^T B) o C, C [M, N] read only (the quadratic form <D, G D> of the AWQ searches' Gram
+        // route: A = G, B = D, C = D); the tile goes through LDS so that every lane reads 16 contiguous bytes of C
+        float sum = 0.f;
+        const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0;
+        auto rows = [&](int r, int c4, f32x4v v) -> f32x4v {
+            const int64_t row = m0 + r, col = n0 + c4;
+            if (row >= g.M || col >= g.N) return v;
+            const float* o = g.C + row * g.ldc + col;
+            if (vec_ok && col + 3 < g.N) {
+                const f32x4v d = *reinterpret_cast<const f32x4v*>(o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum += (v[q] * unscale) * d[q];
+            } else {
+                for (int q = 0; q < 4 && col + q < g.N; ++q) sum += (v[q] * unscale) * o[q];
+            }
+            return v;
+        };
+        auto cols = [&](int, int, float) {};
+        staged_tile_epilogue<false>(acc, lds, rows, cols);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        __syncthreads();                                  // the staged tile has been read by everybody
+        float* red = reinterpret_cast<float*>(lds);
+        if (lane == 0) red[wave] = sum;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < kSThreads / 64; ++w) t += red[w];   // fixed order: deterministic
+            g.partial[tile] = t;
+        }
     } else {
         // rows / columns past M / N are zero pieces: their products are exact zeros, no masks
         float sum = 0.f;
@@ -1290,10 +1321,11 @@ int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols
 }
 
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
-                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only) {
-    OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && (C != nullptr) != (loss_partial != nullptr), OQ_ERR_INVALID_ARGUMENT,
+                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only, bool dot_with_c) {
+    OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && ((C != nullptr) != (loss_partial != nullptr) || dot_with_c), OQ_ERR_INVALID_ARGUMENT,
                "gemm_f16x3: bad argument");
-    OQ_REQUIRE(!hi_pieces_only || loss_partial, OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the one-product form exists for the loss epilogue only");
+    OQ_REQUIRE(!hi_pieces_only || (loss_partial && !dot_with_c), OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the one-product form exists for the sum-of-squares epilogue only");
+    OQ_REQUIRE(!dot_with_c || (C && loss_partial && ldc >= N), OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the dot epilogue reads C [M, N] and writes one partial per block");
     PieceGemm g;
     g.scale_a = static_cast<const float*>(pieces_a);
     g.scale_b = static_cast<const float*>(pieces_b);
@@ -1304,7 +1336,11 @@ int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M,
     const int64_t tiles = (g.Mp / kST) * (g.Np / kST);
     OQ_REQUIRE(tiles < (1 << 30), OQ_ERR_UNSUPPORTED, "gemm_f16x3: too many tiles");
     const int lds_bytes = StageGeom<3>::LDS;
-    if (loss_partial && hi_pieces_only) {
+    if (dot_with_c) {
+        OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
+                   OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
+        hipLaunchKernelGGL(gemm_f16x3_kernel<2>, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
+    } else if (loss_partial && hi_pieces_only) {
         OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
                    OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
         hipLaunchKernelGGL((gemm_f16x3_kernel<1, 1>), dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);

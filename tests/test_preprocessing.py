@@ -86,6 +86,28 @@ def test_gpu_awq_searches_follow_the_oracle(qtype, strategy, g, sym):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("t,k,n,qtype,strategy,g", [(2048, 256, 192, "uint4", "group", 32), (8192, 1024, 516, "uint4", "group", 128),
+                                                    (6144, 1024, 256, "int8", "channel", -1), (1024, 128, 64, "uint8", "tensor", -1)])
+def test_gpu_awq_searches_with_long_calibration_sets_follow_the_oracle(t, k, n, qtype, strategy, g):
+    """T >= 6 K rows: the searches take the Gram route (awq.hip: sum_n ||X d_n||^2 = <D, X^T X D>, the Gram matrix made once
+    by the Hessian kernels -- fp32 MFMA below K = 1024, fp16 pieces above).  Same bars as the direct route; outlier channels
+    make the Gram matrix span six orders of magnitude."""
+    from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search
+    x, w = _inputs(11 + k, t, k, n)
+    x[..., ::37] *= 40.0
+    es, el = O.awq_scale_search(x, w, qtype, strategy, g)
+    s, l = awq_scale_search(x, w, QuantType.from_string(qtype), strategy, g)
+    np.testing.assert_allclose(l, el, rtol=2e-3)
+    assert el[int(np.argmin(l))] <= el.min() * (1 + 2e-3)
+    if int(np.argmin(l)) == int(np.argmin(el)):
+        np.testing.assert_allclose(s, es, rtol=1e-5)
+    er, ecl = O.awq_clip_search(x, w, qtype, strategy, g)
+    r, cl = awq_clip_search(x, w, QuantType.from_string(qtype), strategy, g)
+    np.testing.assert_allclose(cl, ecl, rtol=2e-3)
+    assert ecl[int(round((1 - r) * 100))] <= ecl.min() * (1 + 2e-3)
+
+
+@pytest.mark.gpu
 def test_gpu_smooth_quant_scale_matches_oracle():
     from onnx_quantize_amd.preprocessing import smooth_quant_scale
     x, w = _inputs(4, 1024, 384, 128)
