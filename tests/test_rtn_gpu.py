@@ -455,6 +455,30 @@ def test_nan_weights_poison_their_range_like_numpy(strategy, g, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,n,strategy", [(8192, 260, "channel"), (4096, 2048, "tensor"), (6144, 512, "tensor")])
+def test_nan_weights_in_the_ticketed_kernels_for_large_ranges(k, n, strategy):
+    """The same for the streamed channel kernel (ranges taller than 4096 rows) and for the per-tensor kernel with tiles kept
+    in registers / LDS and tiles read twice: the NaN travels through the key atomics (top key) or the arrival slots."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    w = (np.random.default_rng(k + n).standard_normal((k, n)) * 0.1).astype(np.float32)
+    w[k - 7, 5] = np.nan
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            eq, es, ez = O.rtn_quantize(w, "int8", strategy, -1)
+    q, s, z = ops.rtn_quantize(torch.from_numpy(w).cuda(), "int8", strategy, -1)
+    s, z = np.asarray(s.cpu().numpy()).reshape(-1), np.asarray(z.cpu().numpy()).reshape(-1)
+    es, ez = np.asarray(es).reshape(-1), np.asarray(ez).reshape(-1)
+    bad = np.isnan(es)
+    assert bad.any() and np.array_equal(np.isnan(s), bad)
+    assert s[~bad].tobytes() == es[~bad].tobytes() and np.array_equal(z[~bad], ez[~bad])
+    if strategy == "channel":
+        np.testing.assert_array_equal(q.cpu().numpy()[:, ~bad], eq[:, ~bad])
+
+
+@pytest.mark.gpu
 def test_more_than_2_31_elements():
     """Indexing is 64-bit wherever a flat offset can pass 2^31: a 32768 x 69632 weight (2.28e9 elements, 9.1 GB) through
     the blob and the [K, N] kernels; sampled column strips (incl. the last one) against the oracle."""
