@@ -531,6 +531,84 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     }
 }
 
+// The stage loop for the FIRST pieces alone (the AWQ / clip searches' loss product: one MFMA product instead of three).
+// With a third of the matrix work per stage (64 MFMAs per SIMD = 0.5 us) a ring of two stages no longer hides the operand
+// DMA (~1 us from L2 / HBM): the generic loop above ran this product at 143 us per 4096^3, half of it waiting.  Here only
+// the hi planes are staged -- 32 KB per stage, compact in LDS -- in a ring of FOUR, i.e. the DMAs of stage s + 3 are issued
+// while stage s is multiplied and a wave waits for all but its eight youngest (vmcnt(8)) before the barrier.  Every wave
+// fetches four 1 KB pieces per stage.  Global layout of the pieces unchanged ([chunk][2 planes][width] x 16 B).
+constexpr int kHiPlane = 4 * kST * 16;        // [4 chunks][256 columns] x 16 B
+constexpr int kHiStage = 2 * kHiPlane;        // A | B
+constexpr int kHiRing = 4;
+static_assert(kHiRing * kHiStage <= StageGeom<3>::LDS, "the hi-only ring fits the LDS reserved for the generic loop");
+
+__device__ __forceinline__ void f16_hi_mainloop(const char* const (&gsrc)[4], const int64_t (&stage_bytes)[4], const int64_t nstages,
+                                                unsigned char* lds, f32x4v (&acc)[4][8]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kc = lane >> 4, cl = lane & 15;
+    uint32_t ldst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;                     // 32 pieces: operand q / 16, chunk (q / 4) % 4, quarter q % 4
+        ldst[i] = static_cast<uint32_t>((q >> 4) * kHiPlane + (q & 15) * 1024);
+    }
+    auto stage_dma = [&](int64_t s_abs, int slot) {
+        const int64_t sc = s_abs < nstages ? s_abs : nstages - 1;     // past the end: a harmless re-read of the last stage
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(gsrc[i] + sc * stage_bytes[i],
+                                             (__attribute__((address_space(3))) void*)(lds + slot * kHiStage + ldst[i]), 16, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < kHiRing - 1; ++st) stage_dma(st, st);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // stage 0 has landed (stages 1 and 2 may still fly)
+    __builtin_amdgcn_s_barrier();
+    const uint32_t rd_a = static_cast<uint32_t>((kc * kST + wm * 64 + cl) * 16);
+    const uint32_t rd_b = static_cast<uint32_t>(kHiPlane + (kc * kST + wn * 128 + cl) * 16);
+    int cur = 0;
+    f16x8 a[4], b[2];
+    {   // the first operands of stage 0
+        a[0] = *reinterpret_cast<const f16x8*>(lds + rd_a);
+        b[0] = *reinterpret_cast<const f16x8*>(lds + rd_b);
+    }
+    for (int64_t s = 0; s < nstages; ++s) {
+        int wr = cur + kHiRing - 1;
+        wr = wr >= kHiRing ? wr - kHiRing : wr;
+        const unsigned char* base = lds + cur * kHiStage;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) a[i] = *reinterpret_cast<const f16x8*>(base + rd_a + i * 16 * 16);
+        stage_dma(s + kHiRing - 1, wr);                  // slot `wr` was multiplied in stage s - 1: everybody has passed its barrier
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (i == 1 && j < 7) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    b[(j + 1) & 1] = *reinterpret_cast<const f16x8*>(base + rd_b + (j + 1) * 16 * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j & 1], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // stage s + 1 has landed; the DMAs of s + 2 and s + 3 stay in flight
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == kHiRing ? 0 : cur + 1;
+        // the next stage's first operands right behind the barrier (the last stage re-reads a slot that holds a copy of it)
+        a[0] = *reinterpret_cast<const f16x8*>(lds + cur * kHiStage + rd_a);
+        b[0] = *reinterpret_cast<const f16x8*>(lds + cur * kHiStage + rd_b);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-reads past the end: the epilogue reuses the ring
+    __builtin_amdgcn_s_barrier();
+}
+
 // The block's 256 x 256 accumulator tile -> memory through LDS, in four passes of 64 rows (the rows of the waves wm == pass).
 // In the MFMA's C/D layout a store instruction covers 4 rows x 64 bytes and a read-modify-write of C costs 128 loads + 128
 // stores of 4 bytes per lane; short products (the factor's and the GPTQ loop's 512-deep updates: 16 stages, 13 us of matrix
@@ -832,7 +910,22 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
     }
     f32x4v acc[4][8];
     if (s_end > s_begin) {
-        f16_m16_mainloop<NDMA, PRODUCTS>(gsrc, stage_bytes, s_end - s_begin, lds, acc);
+        if constexpr (PRODUCTS == 1) {
+            const char* hsrc[4];
+            int64_t hbytes[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = wave * 4 + i;
+                const int quarter = q & 3, cc = (q >> 2) & 3, op = q >> 4;
+                const int64_t width = op ? g.Np : g.Mp;
+                hbytes[i] = static_cast<int64_t>(CH) * PIECES * width * 16;
+                hsrc[i] = reinterpret_cast<const char*>((op ? g.PB : g.PA) + static_cast<int64_t>(cc) * PIECES * width + (op ? n0 : m0) + quarter * 64 + lane) +
+                          s_begin * hbytes[i];
+            }
+            f16_hi_mainloop(hsrc, hbytes, s_end - s_begin, lds, acc);
+        } else {
+            f16_m16_mainloop<NDMA, PRODUCTS>(gsrc, stage_bytes, s_end - s_begin, lds, acc);
+        }
     } else {   // block-uniform: nothing to contract
 #pragma unroll
         for (int i = 0; i < 4; ++i)
