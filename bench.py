@@ -473,7 +473,7 @@ def search_bench(dev, w) -> dict:
 
 def strategies_bench(dev, ws, rank: int) -> dict:
     """Per-channel and per-tensor int8 RTN of the headline matrix (rtn.py:54-109 with the reference's default QWeightArgs():
-    core/_qconfig.py:232-268) -- `rtn_resident_groups` / `rtn_tensor_onepass` of rtn_resident.hip, W read once.  HIP events on
+    core/_qconfig.py:232-268) -- `rtn_resident_stream` / `rtn_tensor_onepass` of rtn_resident.hip, W read once.  HIP events on
     the launch stream over rotating inputs; algorithmic bytes = W once + one byte per value + the parameters; outputs
     checked against the digests of what the reference itself returned (tests/golden/digests.json, rank 0's matrix)."""
     import torch
@@ -484,7 +484,7 @@ def strategies_bench(dev, ws, rank: int) -> dict:
         digests = json.load(f)
     out = {"what": "int8 RTN of the 4096x11008 matrix with one range per column / per tensor; W read once (rtn_resident.hip); "
                    "rounds 1-3 read it twice in three launches (89 / 94 us)"}
-    for strategy, kernel in (("channel", "oq::rtn_resident_groups"), ("tensor", "oq::rtn_tensor_onepass")):
+    for strategy, kernel in (("channel", "oq::rtn_resident_stream"), ("tensor", "oq::rtn_tensor_onepass")):
         outs = ops.rtn_quantize(ws[0], "int8", strategy, -1)
         for i in range(10):
             ops.rtn_quantize(ws[i % len(ws)], "int8", strategy, -1, out=outs)

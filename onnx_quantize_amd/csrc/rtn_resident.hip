@@ -371,14 +371,24 @@ __device__ __forceinline__ void stream_publish_wave(const ResidentArgs& a, const
 }
 
 // final keys of a complete range -> this lane's four parameter sets; chunk 0 writes them out (rtn.py:98-109 layout: entry n * kgroups + kg)
-__device__ __forceinline__ void stream_params(const ResidentArgs& a, const StreamTile& s, int lane, int wave, ColQ (&cq)[4]) {
-    float mn[4] = {0.f, 0.f, 0.f, 0.f}, mx[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __forceinline__ void stream_keys(const ResidentArgs& a, const StreamTile& s, uint32_t (&kmx)[4], uint32_t (&kmn)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kmx[i] = kmn[i] = 0x80000000u;     // the key of 0.0f for lanes past the last column
     if (s.col_ok) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            mx[i] = max_of_key(agent_load(a.key_max + s.slot0 + i * kWave));
-            mn[i] = min_of_key(agent_load(a.key_nmin + s.slot0 + i * kWave));
+            kmx[i] = agent_load(a.key_max + s.slot0 + i * kWave);
+            kmn[i] = ~agent_load(a.key_nmin + s.slot0 + i * kWave);
         }
+    }
+}
+__device__ __forceinline__ void stream_params(const ResidentArgs& a, const StreamTile& s, int lane, int wave, const uint32_t (&kmx)[4],
+                                              const uint32_t (&kmn)[4], ColQ (&cq)[4]) {
+    float mn[4], mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        mx[i] = okey_inv(kmx[i]);
+        mn[i] = okey_inv(kmn[i]);
     }
     const int32_t bias = a.grid.qmin < 0 ? 128 : 0;
 #pragma unroll
@@ -436,35 +446,54 @@ __device__ __forceinline__ void stream_rows(const ResidentArgs& a, const StreamT
     }
 }
 
-// Wait for the range of the tile in `v`, then quantize and store it while its registers are refilled with the next tile
-// (ticket taken after the wait, so that it is never held across one); the new tile is folded and published before this
-// returns.  Returns the new ticket (>= ntiles: the slot is empty).
-__device__ __forceinline__ uint32_t stream_finish_refill(const ResidentArgs& a, uint32_t t, int lane, int wave, float (&v)[kResRows][4],
-                                                         float4 (&s_mn)[kResWaves][kWave], float4 (&s_mx)[kResWaves][kWave],
-                                                         uint32_t& s_ticket, uint64_t& lap0) {
-    const StreamTile s = stream_tile(a, t, lane, wave);
-    // the poller sits in wave 1: wave 0 may still be draining the key atomics of the tile it has just published
-    if (threadIdx.x == kWave) spin_until(a.counters + s.range * kResCtrPad, static_cast<uint32_t>(a.chunks));
+// One step of the streamed kernel.  On entry slot X (`tx`, `vx`) holds a PUBLISHED tile whose range may or may not be
+// complete, slot Y (`ty`, `vy`, when `y_valid`) a tile whose loads are in flight and which is NOT published yet.  The
+// range of X is polled once without blocking: normally it is complete (X was published a whole tile-load ago), and then
+// X's key loads and the next ticket travel while Y lands, is folded and published; only if the range is incomplete, Y is
+// published FIRST and the workgroup blocks -- it never waits while it holds an unpublished tile, and the ticket is taken
+// behind the wait.  X is then stored row by row while its registers are refilled with the next tile, which leaves X in
+// flight and unpublished: the roles swap.  Returns X's new ticket (>= ntiles: the slot is empty).
+__device__ __forceinline__ uint32_t stream_step(const ResidentArgs& a, uint32_t tx, float (&vx)[kResRows][4], bool y_valid, uint32_t ty,
+                                                float (&vy)[kResRows][4], int lane, int wave, float4 (&s_mn)[kResWaves][kWave],
+                                                float4 (&s_mx)[kResWaves][kWave], uint32_t& s_ticket, uint32_t& s_flag, uint64_t& lap0) {
+    const StreamTile sx = stream_tile(a, tx, lane, wave);
+    const StreamTile sy = stream_tile(a, y_valid ? ty : tx, lane, wave);
+    const uint32_t chunks = static_cast<uint32_t>(a.chunks);
+    // the poller sits in wave 1: wave 0 may still be draining the key atomics of the tile it published last
+    if (threadIdx.x == kWave) s_flag = agent_load(a.counters + sx.range * kResCtrPad) >= chunks ? 1u : 0u;
     __syncthreads();
+    bool y_published = !y_valid;
+    if (s_flag == 0u) {   // uniform, rare
+        if (y_valid) {
+            stream_fold_local(lane, wave, vy, s_mn, s_mx);
+            __syncthreads();
+            if (wave == 0) stream_publish_wave(a, sy, lane, s_mn, s_mx);
+            y_published = true;
+        }
+        if (threadIdx.x == kWave) spin_until(a.counters + sx.range * kResCtrPad, chunks);
+        __syncthreads();
+    }
     OQ_LAP(1, lap0);
     uint32_t pending = 0;
-    if (threadIdx.x == 0) pending = agent_add(a.tickets, 1u);     // travels beside the key loads; published before any wait
-    ColQ cq[4];
-    stream_params(a, s, lane, wave, cq);
-    if (threadIdx.x == 0) s_ticket = pending;
-    __syncthreads();
-    const uint32_t tn = s_ticket;     // the next write of s_ticket lies behind the barrier of the fold below or of the next call
-    OQ_LAP(2, lap0);
-    const bool refill = tn < a.ntiles;                         // uniform
-    const StreamTile n = stream_tile(a, refill ? tn : t, lane, wave);
-    stream_rows(a, s, cq, refill, n, lane, v);
-    OQ_LAP(3, lap0);
-    if (refill) {
-        stream_fold_local(lane, wave, v, s_mn, s_mx);
+    if (threadIdx.x == 0) pending = agent_add(a.tickets, 1u);     // behind every wait of this step; its tile is published before the next one
+    uint32_t kmx[4], kmn[4];
+    stream_keys(a, sx, kmx, kmn);
+    if (!y_published) {   // uniform
+        stream_fold_local(lane, wave, vy, s_mn, s_mx);
         __syncthreads();
-        if (wave == 0) stream_publish_wave(a, n, lane, s_mn, s_mx);
+        if (wave == 0) stream_publish_wave(a, sy, lane, s_mn, s_mx);
     }
     OQ_LAP(4, lap0);
+    ColQ cq[4];
+    stream_params(a, sx, lane, wave, kmx, kmn, cq);
+    if (threadIdx.x == 0) s_ticket = pending;
+    __syncthreads();
+    const uint32_t tn = s_ticket;     // the next write of s_ticket lies behind the first barrier of the next step
+    OQ_LAP(2, lap0);
+    const bool refill = tn < a.ntiles;                         // uniform
+    const StreamTile n = stream_tile(a, refill ? tn : tx, lane, wave);
+    stream_rows(a, sx, cq, refill, n, lane, vx);
+    OQ_LAP(3, lap0);
 #ifdef OQ_TENSOR_STAMPS
     if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + 6] += 1;
 #endif
@@ -474,7 +503,7 @@ __device__ __forceinline__ uint32_t stream_finish_refill(const ResidentArgs& a, 
 __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_resident_stream(const ResidentArgs a) {
     __shared__ float4 s_mn[kResWaves][kWave];
     __shared__ float4 s_mx[kResWaves][kWave];
-    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_ticket, s_flag;
     // the wave index as a scalar: row numbers and row pointers of the tile descriptors stay out of the vector registers
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const uint32_t ntiles = a.ntiles;
@@ -500,21 +529,18 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_resident_stream(const
             __syncthreads();
             if (wave == 0) stream_publish_wave(a, s, lane, s_mn, s_mx);
         }
-        if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // after the publish: no ticket is held unpublished across a barrier that a wait could sit behind
+        if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // behind the publish
         __syncthreads();
         tb = s_ticket;
         __syncthreads();
-        if (tb < ntiles) {
+        if (tb < ntiles) {   // slot 1: in flight, published by the first step
             const StreamTile s = stream_tile(a, tb, lane, wave);
             load_tile<true>(a, s.row0 < s.row_end ? s.row0 : s.row_end - 1, s.row_end, s.tile_col0, lane, v1);
-            stream_fold_local(lane, wave, v1, s_mn, s_mx);
-            __syncthreads();
-            if (wave == 0) stream_publish_wave(a, s, lane, s_mn, s_mx);
         }
-        OQ_LAP(0, lap0);      // prologue: two tiles loaded and published
+        OQ_LAP(0, lap0);
         while (ta < ntiles || tb < ntiles) {
-            if (ta < ntiles) ta = stream_finish_refill(a, ta, lane, wave, v0, s_mn, s_mx, s_ticket, lap0);
-            if (tb < ntiles) tb = stream_finish_refill(a, tb, lane, wave, v1, s_mn, s_mx, s_ticket, lap0);
+            if (ta < ntiles) ta = stream_step(a, ta, v0, tb < ntiles, tb, v1, lane, wave, s_mn, s_mx, s_ticket, s_flag, lap0);
+            if (tb < ntiles) tb = stream_step(a, tb, v1, ta < ntiles, ta, v0, lane, wave, s_mn, s_mx, s_ticket, s_flag, lap0);
         }
     }
 #ifdef OQ_TENSOR_STAMPS
@@ -862,15 +888,17 @@ static int resident_blocks(const void* kernel, size_t dynamic_lds) {
 
 // Which kernel takes a channel / tall-group call (speed only, same bytes).  Measured, int8 per channel, same box
 // (scripts/quick_strategies.py --lib, round 4):
-//                                   4096x11008  4096x4096  8192x8192  11008x4096
-//   rtn_resident_groups, 256 rows      65.3        27.3      103.3       84.4 us
-//   rtn_resident_groups, 128 rows      70          30          -         84
-//   rtn_resident_stream (128 rows)     65.8        33.5       89.0       64.3
-// so columns of up to 4096 rows keep the one-tile-per-workgroup kernel (a range has <= 16 tiles: the streamed kernel's two
-// tiles per workgroup are all it ever loads, and they are loaded one after the other), taller ones are streamed.
+//                                   4096x11008  4096x4096  8192x8192  11008x4096  16384x4096
+//   rtn_resident_groups, 256 rows      65.0        27.7      100        83.7        125.9 us
+//   rtn_resident_groups, 128 rows      70          30          -        84            -
+//   rtn_resident_stream (128 rows)     62.2        31.8       85.5      61.5         90
+// The streamed kernel wins wherever a workgroup refills its slots a few times: taller ranges than 4096 rows, or at least
+// four 128-row tiles per workgroup of a 256-CU device (4096 x 11008: 5.4).  With two tiles per workgroup (4096 x 4096) they
+// are all it ever loads, one after the other, and the one-tile-per-workgroup kernel keeps the call.
 // 64- and 32-row tiles (4 / 7 workgroups per CU) took 92 / 154 us on the first.  OQ_RTN_RES_TILE = 256 | 128 forces
 // rtn_resident_groups with that tile height, OQ_RTN_RES_TILE = 1 the streamed kernel (lab switch).
 constexpr int64_t kResStreamAbove = 4096;
+constexpr int64_t kResStreamTiles = 1024;
 static int forced_tile_rows() {
     static const int forced = [] {
         const char* v = getenv("OQ_RTN_RES_TILE");
@@ -879,19 +907,24 @@ static int forced_tile_rows() {
     }();
     return forced;
 }
-static bool groups_streamed(int64_t g) { return forced_tile_rows() ? forced_tile_rows() == 1 : g > kResStreamAbove; }
-static int groups_tile_rows(int64_t g) {
-    if (forced_tile_rows() > 1) return forced_tile_rows();
-    return groups_streamed(g) ? kResGroupTileRows : 256;
+// `ranges`: column tiles x k-groups of the call
+static bool groups_streamed(int64_t g, int64_t ranges) {
+    if (forced_tile_rows()) return forced_tile_rows() == 1;
+    return g > kResStreamAbove || ranges * ceil_div(g, kResGroupTileRows) >= kResStreamTiles;
 }
+static int groups_tile_rows(int64_t g, int64_t ranges) {
+    if (forced_tile_rows() > 1) return forced_tile_rows();
+    return groups_streamed(g, ranges) ? kResGroupTileRows : 256;
+}
+static int64_t ranges_of(int64_t K, int64_t N, int64_t g) { return ceil_div(N, kResCols) * (K / g); }
 
 // workgroups of the channel / tall-group kernel chosen for `g` that the current device runs at once (cached per device)
-static int groups_resident(int64_t g) {
+static int groups_resident(int64_t g, int64_t ranges) {
     static int cache[3][64];
     static bool filled[3][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    const int which = groups_streamed(g) ? 0 : (groups_tile_rows(g) == 256 ? 1 : 2);
+    const int which = groups_streamed(g, ranges) ? 0 : (groups_tile_rows(g, ranges) == 256 ? 1 : 2);
     if (!filled[which][dev]) {   // benign race: every thread computes the same value
         int cus = 0, per_cu = 0;
         const void* k = which == 0 ? reinterpret_cast<const void*>(rtn_resident_stream)
@@ -906,7 +939,7 @@ static int groups_resident(int64_t g) {
 }
 
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g) {
-    const int64_t kgroups = K / g, chunks = ceil_div(g, groups_tile_rows(g));
+    const int64_t kgroups = K / g, chunks = ceil_div(g, groups_tile_rows(g, ranges_of(K, N, g)));
     const int64_t ncol_tiles = ceil_div(N, kResCols);
     if (strategy == OQ_TENSOR) return static_cast<size_t>(kResTensorHeader + (2 * ncol_tiles * ceil_div(K, kResTileRows) + 31) / 32 + 1) * 4 + 256;
     (void)chunks;
@@ -919,19 +952,19 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
     if (!emit_q || layout != OQ_LAYOUT_KN) return false;
     if ((N % 4) || (ldw % 4) || (reinterpret_cast<uintptr_t>(W) & 15u) || (reinterpret_cast<uintptr_t>(q) & 3u)) return false;
     if (K % g) return false;
-    const int64_t chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g));
+    const int64_t chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g, ranges_of(K, N, g)));
     const int64_t ntiles = ceil_div(N, kResCols) * (K / g) * chunks;
     if (ntiles >= (1LL << 31) || (strategy == OQ_TENSOR && ntiles > kResMaxTensorTiles)) return false;
     // forward progress needs `chunks` running workgroups (see the kernels): at most 3/4 of what THIS device holds of the kernel
     // that would run (192 of one workgroup on each of 256 CUs; a 32-CU partition takes ranges of up to 24 chunks)
-    if (strategy != OQ_TENSOR && chunks > 1 && chunks * 4 > static_cast<int64_t>(groups_resident(g)) * 3) return false;
+    if (strategy != OQ_TENSOR && chunks > 1 && chunks * 4 > static_cast<int64_t>(groups_resident(g, ranges_of(K, N, g))) * 3) return false;
     return workspace_bytes >= rtn_resident_workspace(K, N, strategy, g);
 }
 
 int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
                           float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
     ResidentArgs a;
-    const int tile_rows = groups_tile_rows(g);
+    const int tile_rows = strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g, ranges_of(K, N, g));
     a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = K / g; a.chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : tile_rows);
     a.q = q; a.scale = scale; a.zp = zp; a.grid = grid; a.layout = layout;
     a.ncol_tiles = static_cast<uint32_t>(ceil_div(N, kResCols));
@@ -968,11 +1001,11 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
     a.held = nullptr;
     a.key_max = a.counters + ranges * kResCtrPad;
     a.key_nmin = a.key_max + a.kgroups * static_cast<int64_t>(a.ncol_tiles) * kResCols;
-    if (!groups_streamed(g)) {
+    if (!groups_streamed(g, ranges)) {
         if (tile_rows == 256) hipLaunchKernelGGL((rtn_resident_groups<16, 16, 4>), dim3(a.ntiles), dim3(16 * kWave), 0, s, a);
         else hipLaunchKernelGGL((rtn_resident_groups<8, 16, 4>), dim3(a.ntiles), dim3(8 * kWave), 0, s, a);
     } else {
-        const int resident = groups_resident(g);
+        const int resident = groups_resident(g, ranges);
         // forward progress needs at least `chunks` running workgroups (see the kernel): rtn_resident_eligible has checked it
         OQ_REQUIRE(resident > 0 && (a.chunks <= resident || a.ntiles <= static_cast<uint32_t>(resident)), OQ_ERR_UNSUPPORTED,
                    "rtn: %lld chunks per range need as many resident workgroups, the device holds %d", (long long)a.chunks, resident);
