@@ -284,18 +284,21 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
 
 // ---------------------------------------------------------------------------------------------
 // Channel / tall groups, streamed: ONE persistent 8-wave workgroup per CU with TWO tile slots in registers (the per-tensor
-// kernel's shape).  A workgroup loads, folds and PUBLISHES a tile into one slot and only then waits for the range of the
-// tile in the other slot -- which was published a whole tile-load earlier and is normally complete -- quantizes and stores
-// it, takes the next ticket and refills that slot.  The memory-side round trips of the hand-off no longer stand between a
-// tile's load and its store with nothing else in flight on the CU (rtn_resident_groups: 65 us on 4096 x 11008 int8).
+// kernel's shape).  One slot holds a PUBLISHED tile, the other a tile whose loads are in flight.  A step (stream_step) polls
+// the published tile's range once -- it was published a whole tile-load earlier and is normally complete --, lets the key
+// loads and the next ticket travel while the other tile lands, is folded and published, then stores the finished tile row
+// by row while its registers are refilled with the next one.  The memory-side round trips of the hand-off no longer stand
+// between a tile's load and its store with nothing else in flight on the CU (rtn_resident_groups: 65 us on 4096 x 11008 int8).
 //
-// Forward progress.  A ticket is taken only right in front of its load and is published before the workgroup waits for
-// anything (between take and publish lie the stores of the other slot's tile, a load and a fold: no wait).  Let R be the
-// oldest incomplete range.  If one of R's tickets has not been taken, no later ticket has been taken either, so nobody holds
-// a tile of a younger range and every waiting workgroup waits for R while holding a published tile of R: at most
-// chunks - 1 of them.  Any other running workgroup is loading / storing, or waits for an older, i.e. complete range: it goes
-// on and takes the next ticket, which is R's.  With at least `chunks` workgroups running (the host enforces chunks <= 192
-// against 256 CUs) R completes.  Workgroups that are not resident yet hold no ticket and nobody waits for them.
+// Forward progress.  A workgroup blocks only in the branch of stream_step that has just published the tile it had in
+// flight, and it takes a ticket only behind that branch; the ticket's tile is in flight during the rest of the step and is
+// published in the next step before anything blocks.  So a workgroup never waits while it holds an unpublished tile.
+// Let R be the oldest incomplete range.  If one of R's tickets has not been taken, no later ticket has been taken either, so
+// nobody holds a tile of a younger range and every blocked workgroup waits for R while holding a published tile of R: at
+// most chunks - 1 of them.  Any other running workgroup is loading / storing / publishing, or polls an older, i.e. complete
+// range: it goes on and takes the next ticket, which is R's.  With at least `chunks` workgroups running (the host checks
+// chunks against 3/4 of the workgroups the device holds) R completes.  Workgroups that are not resident yet hold no ticket
+// and nobody waits for them.
 // ---------------------------------------------------------------------------------------------
 #ifdef OQ_TENSOR_STAMPS   // lab build only (scripts/lab_tensor_stamps.py): 100 MHz wall-clock stamps of every workgroup's phases
 __device__ uint64_t g_tensor_stamps[512 * 8];
