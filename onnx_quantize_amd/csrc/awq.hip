@@ -230,8 +230,12 @@ __global__ __launch_bounds__(256) void awq_diff4_kernel(const float* __restrict_
 }
 
 // ---- losses[i] = sum of the GEMM's per-block sums / (T N), in block order
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int64_t nblocks, double inv_count, float* __restrict__ loss) {
+// (one block per candidate: all candidates of a search in ONE launch behind the last product)
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial_all, int64_t nblocks, int64_t stride, double inv_count,
+                                                          float* __restrict__ loss_all) {
     __shared__ double sm[4];
+    const float* partial = partial_all + static_cast<int64_t>(blockIdx.x) * stride;
+    float* loss = loss_all + blockIdx.x;
     double acc = 0.0;
     for (int64_t i = threadIdx.x; i < nblocks; i += 256) acc += static_cast<double>(partial[i]);
 #pragma unroll
@@ -302,6 +306,10 @@ struct AwqWs {   // carving of the caller's workspace
 // Break-even: three products of 2 K^2 N against one of 2 T K N, plus the Gram matrix over ~20 candidates.
 constexpr int64_t kAwqGramRatio = 6;
 static bool awq_use_gram(int64_t T, int64_t K) { return T >= kAwqGramRatio * K; }
+static int64_t loss_tiles(int64_t T, int64_t K, int64_t N) { return gemm_f16x3_tiles(awq_use_gram(T, K) ? K : T, N); }
+static int64_t loss_stride(int64_t T, int64_t K, int64_t N) { return (loss_tiles(T, K, N) + 63) / 64 * 64; }
+// all candidates' partial sums -> their losses, one launch
+static int32_t finish_losses(const float* gemm_part, int n_cand, int64_t T, int64_t K, int64_t N, float* losses_out, hipStream_t s);
 
 #ifndef OQ_AWQ_HI_ONLY
 #define OQ_AWQ_HI_ONLY 1   /* lab: 0 = the three-product (22-bit) loss of round 3 */
@@ -330,7 +338,7 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
     char* wsc = take(static_cast<size_t>(K) * 4);
     char* gmax = take(static_cast<size_t>(K) * N * 4 / 16 + static_cast<size_t>(N) * 4 + 1024);
     char* colpart = take(static_cast<size_t>(kColChunks) * K * 4);
-    char* gpart = take(static_cast<size_t>(gemm_f16x3_tiles(gram ? K : T, N)) * 4 + 1024);
+    char* gpart = take(static_cast<size_t>(kAwqMaxGrid) * loss_stride(T, K, N) * 4 + 1024);   // every candidate its own partial sums
     char* dpart = take(static_cast<size_t>(diff_blocks(K, N)) * 4 + 1024);
     const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) + oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
     char* rtn = take(rtn_bytes);
@@ -355,7 +363,7 @@ static int32_t param_index(int32_t strategy, int64_t K, int64_t g, ParamIndex* p
 // one candidate: quantize `Wq` (the weights as the candidate sees them), D = W - dequant (/ s), loss -> loss_out
 static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const float* Wq, int64_t ldq, const float* row_scale, int64_t T, int64_t K,
                               int64_t N, int32_t qtype, int32_t strategy, int64_t group_size, int64_t g, int32_t symmetric, int32_t reduce_range,
-                              float clip_ratio, float* loss_out, hipStream_t s) {
+                              float clip_ratio, int candidate, hipStream_t s) {
     int32_t st = rtn_impl(Wq, K, N, ldq, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, 0, w.q, w.qscale, w.qzp, OQ_LAYOUT_KN,
                           w.rtn_ws, w.rtn_ws_bytes, s, true);
     if (st != OQ_OK) return st;
@@ -381,17 +389,17 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
     // first pieces only: every term of the product carries a relative rounding error <= 2^-10, the loss is a sum of T N
     // squared K-term dot products -- its error (~1e-7 relative, measured against the three-product form) is four orders of
     // magnitude below what separates neighbouring grid points; a third of the matrix work (264 -> ~100 us per candidate)
-    if (w.gram) {
-        // mean((X D)^2) = <D, X^T X D> / (T N) = <D, G D> / (2 N) with G = (2 / T) X^T X
-        st = launch_gemm_f16x3(w.pieces_g, w.pieces_d, K, N, K, 1.0f, 0.0f, w.D, N, w.gemm_part, s, false, true);
-        if (st != OQ_OK) return st;
-        hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, w.gemm_part, gemm_f16x3_tiles(K, N), 1.0 / (2.0 * static_cast<double>(N)), loss_out);
-        return check_launch("loss_finish_kernel");
-    }
-    st = launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, w.gemm_part, s, kAwqHiPiecesOnly);
-    if (st != OQ_OK) return st;
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, w.gemm_part, gemm_f16x3_tiles(T, N), 1.0 / (static_cast<double>(T) * static_cast<double>(N)),
-                       loss_out);
+    float* part = w.gemm_part + static_cast<int64_t>(candidate) * loss_stride(T, K, N);
+    if (w.gram)   // <D, G D>, see finish_losses
+        return launch_gemm_f16x3(w.pieces_g, w.pieces_d, K, N, K, 1.0f, 0.0f, w.D, N, part, s, false, true);
+    return launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, part, s, kAwqHiPiecesOnly);
+}
+
+static int32_t finish_losses(const float* gemm_part, int n_cand, int64_t T, int64_t K, int64_t N, float* losses_out, hipStream_t s) {
+    // direct: mean((X D)^2) = sum / (T N).  Gram: <D, X^T X D> / (T N) = <D, G D> / (2 N) with G = (2 / T) X^T X
+    const double inv = awq_use_gram(T, K) ? 1.0 / (2.0 * static_cast<double>(N)) : 1.0 / (static_cast<double>(T) * static_cast<double>(N));
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(static_cast<uint32_t>(n_cand)), dim3(256), 0, s, gemm_part, loss_tiles(T, K, N), loss_stride(T, K, N), inv,
+                       losses_out);
     return check_launch("loss_finish_kernel");
 }
 
@@ -462,9 +470,11 @@ int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ld
         const float* si = scales_out + static_cast<int64_t>(i) * K;
         hipLaunchKernelGGL(scale_rows_kernel, dim3(static_cast<uint32_t>(ceil_div(ceil_div(N, 4), 256)), static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw,
                            si, w.Ws);
-        st = candidate_loss(w, W, ldw, w.Ws, N, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, losses_out + i, s);
+        st = candidate_loss(w, W, ldw, w.Ws, N, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, i, s);
         if (st != OQ_OK) return st;
     }
+    st = finish_losses(w.gemm_part, n_grid, T, K, N, losses_out, s);
+    if (st != OQ_OK) return st;
     hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, n_grid, best_out);
     return check_launch("argmin_first_kernel");
 }
@@ -486,9 +496,11 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
     if (st != OQ_OK) return st;
     for (int i = 0; i < 10; ++i) {
         const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227
-        st = candidate_loss(w, W, ldw, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, losses_out + i, s);
+        st = candidate_loss(w, W, ldw, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, i, s);
         if (st != OQ_OK) return st;
     }
+    st = finish_losses(w.gemm_part, 10, T, K, N, losses_out, s);
+    if (st != OQ_OK) return st;
     hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, 10, best_out);
     return check_launch("argmin_first_kernel");
 }
