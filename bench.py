@@ -327,6 +327,27 @@ def model_rtn_bench(dev, layout: str, headline_out, w_headline, layers: int = 32
     loop_ms = l0.elapsed_time(l1)
     del keep
     gbs = alg / (dev_ms * 1e-3) / 1e9
+    # the same 224 weights in the [K, N]-family layouts (what configs 4 / 5 serialise: int4 two columns per byte; and one value
+    # per byte).  A single-matrix launch pays the 5 us parameter-transpose launch per matrix (`other_layout`, `packed_kn_layout`:
+    # 0.55-0.56); in a model-sized call it is one launch per ~1.6e8 parameters.
+    layouts = {}
+    for qt, lay, qbytes in (("int4", "kn_packed4", 0.5), ("int8", "kn", 1.0)):
+        ops.rtn_quantize_many(ws, qt, GROUP, layout=lay)
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        r2 = ops.rtn_quantize_many(ws, qt, GROUP, layout=lay)
+        a1.record()
+        torch.cuda.synchronize()
+        ms2 = a0.elapsed_time(a1)
+        q1, s1, z1 = ops.rtn_quantize(ws[5], qt, "group", GROUP, layout=lay)
+        same = bool(torch.equal(q1.reshape(-1), r2[5][0].reshape(-1)) and torch.equal(s1.reshape(-1), r2[5][1].reshape(-1)) and
+                    torch.equal(z1.reshape(-1), r2[5][2].reshape(-1)))
+        alg2 = params * 4 + int(params * qbytes) + groups * 5
+        layouts[f"{qt}_{lay}"] = {"device_ms": round(ms2, 3), "algorithmic_bytes": alg2, "frac": round(alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "equals_single_matrix_outputs": same}
+        ok = ok and same
+        del r2, q1, s1, z1
     del ws, base
     torch.cuda.empty_cache()
     # the small-matrix regime: gemma-3-270m's 126 MatMul weights (18 layers x {q 640x1024, k / v 640x256, o 1024x640, gate / up
@@ -362,6 +383,7 @@ def model_rtn_bench(dev, layout: str, headline_out, w_headline, layers: int = 32
             "value": round(params / (dev_ms * 1e-3) / 1e6, 1), "unit": "M-param/s",
             "algorithmic_bytes": alg, "achieved_GBs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
             "per_matrix_loop_device_ms": round(loop_ms, 3), "per_matrix_loop_frac": round(alg / (loop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kn_family_layouts": layouts,
             "equals_single_matrix_outputs": ok}
 
 
