@@ -121,10 +121,13 @@ def init_ranks(gpus: int, backend: str = "nccl"):
         dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a collective that a dead peer never joins fails after this many seconds instead of the communicator's ten minutes
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("OQ_BENCH_PG_TIMEOUT", "240")))
         if backend == "gloo" or rehearsal:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=pg_timeout)
     return dev, rank, world
 
 
@@ -893,7 +896,18 @@ def main() -> None:
                                                       "--tokens", str(args.gptq_tokens), "--extra-passes", args.gptq_extra_passes,
                                                       "--gather", args.gptq_gather] +
                                                      (["--no-cpu-baseline"] if args.no_cpu_baseline else []))
-        gptq = bench_gptq.run(gargs, dev, rank, world)
+        if world == 1:
+            gptq = bench_gptq.run(gargs, dev, rank, world)
+        else:
+            # N ranks: the headline above is weak scaling without any exchange; the GPTQ object is the only part of this line
+            # that talks between ranks.  Should its first contact with a real N-GPU node fail, the headline still gets printed,
+            # with the failure in the object instead of a measurement.
+            try:
+                gptq = bench_gptq.run(gargs, dev, rank, world)
+            except Exception as e:   # noqa: BLE001 -- reported, not swallowed
+                import traceback
+                sys.stderr.write(f"[bench] rank {rank}: the gptq object failed at {world} ranks:\n{traceback.format_exc()}\n")
+                gptq = {"error": f"{type(e).__name__}: {e}", "n_gpus": world, "verified": False}
 
     if rank != 0:
         if world > 1:
@@ -962,7 +976,7 @@ def main() -> None:
         result["cpu_baseline"] = base
     else:
         result["cpu_baseline"] = None
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
