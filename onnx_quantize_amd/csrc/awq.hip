@@ -301,9 +301,10 @@ struct AwqWs {   // carving of the caller's workspace
 // The reference's loss needs two [T, K] x [K, N] products per candidate (awq.py:166-177); here ONE product X D with
 // D = W - W^.  With a long calibration set (T rows >> K channels: 128 sequences of 2048 tokens against K = 4096) even that is
 // T / K times more matrix work than the quadratic form <D, G D> with G = X^T X, which is made once per search by the
-// Hessian kernels: per candidate a [K, K] x [K, N] product whose epilogue takes the dot product with D.  G and D enter with
-// both fp16 pieces (22 bits: rounding G to 11 bits would move every column's loss the same way, nothing averages out).
-// Break-even: three products of 2 K^2 N against one of 2 T K N, plus the Gram matrix over ~20 candidates.
+// Hessian kernels: per candidate a [K, K] x [K, N] product whose epilogue takes the dot product with D.  G enters with both
+// fp16 pieces (22 bits: rounding G to 11 bits would move every column's loss the same way, nothing averages out), D with
+// its first (its rounding errors are independent per column): two products.
+// Break-even: two products of 2 K^2 N against one of 2 T K N, plus the Gram matrix over ~20 candidates.
 constexpr int64_t kAwqGramRatio = 6;
 static bool awq_use_gram(int64_t T, int64_t K) { return T >= kAwqGramRatio * K; }
 static int64_t loss_tiles(int64_t T, int64_t K, int64_t N) { return gemm_f16x3_tiles(awq_use_gram(T, K) ? K : T, N); }
@@ -391,7 +392,7 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
     // magnitude below what separates neighbouring grid points; a third of the matrix work (264 -> ~100 us per candidate)
     float* part = w.gemm_part + static_cast<int64_t>(candidate) * loss_stride(T, K, N);
     if (w.gram)   // <D, G D>, see finish_losses
-        return launch_gemm_f16x3(w.pieces_g, w.pieces_d, K, N, K, 1.0f, 0.0f, w.D, N, part, s, false, true);
+        return launch_gemm_f16x3(w.pieces_g, w.pieces_d, K, N, K, 1.0f, 0.0f, w.D, N, part, s, false, true, kAwqHiPiecesOnly);   // G 22 bits, D 11
     return launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, part, s, kAwqHiPiecesOnly);
 }
 

@@ -427,9 +427,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (gemm_f16x3_kernel).  gsrc[i]: where this wave's i-th 1 KB piece of stage 0 comes from; a stage further is
 // gsrc[i] + stage_bytes[i >= split ? 1 : 0] (the two operands may have different padded widths).  acc: the wave's 64 x 128
 // tile as 4 x 8 tiles of 16 x 16, zeroed here.
-// PRODUCTS = 3: hi.hi + hi.lo + lo.hi (22-bit operands).  PRODUCTS = 1: hi.hi only (11-bit operands: the AWQ / clip searches'
-// loss, a sum of 1.7e7 squared dot products whose rounding errors average out far below the searches' resolution); the lo
-// planes are then neither fetched nor read (the waves that would fetch them issue no DMA).
+// PRODUCTS = 3: hi.hi + hi.lo + lo.hi (22-bit operands).  PRODUCTS = 2: hi.hi + lo.hi -- A with both pieces, B with its first
+// piece only (the Gram route of the AWQ searches: a 22-bit G against an 11-bit D whose rounding errors are independent per
+// column); B's lo plane is neither fetched nor read.  PRODUCTS = 1 (hi.hi only) has a stage loop of its own, f16_hi_mainloop.
 template <int NDMA, int PRODUCTS = 3>
 __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], const int64_t (&stage_bytes)[8], const int64_t nstages,
                                                  unsigned char* lds, f32x4v (&acc)[4][8]) {
@@ -443,8 +443,9 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     uint32_t ldst[8];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) ldst[i] = static_cast<uint32_t>(wave * NDMA + i) * 1024u;
-    static_assert(PRODUCTS == 3 || NDMA == 8, "piece of a wave's DMA pieces: (wave / 2) % 2 with eight per wave");
-    const bool dma_on = PRODUCTS == 3 || ((wave >> 1) & 1) == 0;     // uniform: this wave's pieces are hi planes
+    static_assert(PRODUCTS == 3 || NDMA == 8, "operand of a wave's DMA pieces: wave / 4, piece (wave / 2) % 2, with eight per wave");
+    // uniform: PRODUCTS = 1 fetches hi planes only, PRODUCTS = 2 everything but B's lo plane (waves 6 and 7)
+    const bool dma_on = PRODUCTS == 3 || (PRODUCTS == 1 ? ((wave >> 1) & 1) == 0 : wave < 6);
     auto stage_dma = [&](int64_t s_rel, int slot, int i) {
         if (dma_on)
             __builtin_amdgcn_global_load_lds(gsrc[i] + s_rel * stage_bytes[i],
@@ -467,14 +468,14 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
     f16x8 a[4][2], b[2][2];
     auto read_a = [&](int slot, int i) {
 #pragma unroll
-        for (int p = (PRODUCTS == 3 ? PIECES : 1) - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_a + p * kPlaneBytes + i * 16 * 16);
+        for (int p = (PRODUCTS >= 2 ? PIECES : 1) - 1; p >= 0; --p) a[i][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_a + p * kPlaneBytes + i * 16 * 16);
     };
     auto read_b = [&](int slot, int j, int which) {
 #pragma unroll
-        for (int p = 0; p < (PRODUCTS == 3 ? PIECES : 1); ++p) b[which][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_b + p * kPlaneBytes + j * 16 * 16);
+        for (int p = 0; p < (PRODUCTS == 3 ? PIECES : 1); ++p) b[which][p] = *reinterpret_cast<const f16x8*>(lds + slot * kStageBytes + rd_b + p * kPlaneBytes + j * 16 * 16);   // B's first piece only unless all three products run
     };
     auto stage_body = [&](auto phase_tag, int64_t s, int cur, int wr) {
-        constexpr int STRIDE = PRODUCTS == 3 ? OQ_SYRK_M16_STRIDE : 2;   // in 16-cycle MFMA slots (32 of them per stage with one product)
+        constexpr int STRIDE = PRODUCTS == 3 ? OQ_SYRK_M16_STRIDE : PRODUCTS == 2 ? 3 : 2;   // in 16-cycle MFMA slots (32 per product and stage)
         constexpr int DMA0 = decltype(phase_tag)::value ? (PRODUCTS == 3 ? 4 : 2) : 0;
         const int64_t s_dma = s + 1 < nstages ? s + 1 : nstages - 1;
         int slot = 0;
@@ -496,10 +497,8 @@ __device__ __forceinline__ void f16_m16_mainloop(const char* const (&gsrc)[8], c
                     __builtin_amdgcn_sched_barrier(0);
                     read_b(cur, j + 1, cb ^ 1);
                 }
-                if constexpr (PRODUCTS == 3) {
-                    mm(a[i][1], b[cb][0], c);     // lo . hi
-                    mm(a[i][0], b[cb][1], c);     // hi . lo
-                }
+                if constexpr (PRODUCTS >= 2) mm(a[i][1], b[cb][0], c);     // lo . hi
+                if constexpr (PRODUCTS == 3) mm(a[i][0], b[cb][1], c);     // hi . lo
                 mm(a[i][0], b[cb][0], c);     // hi . hi
                 acc[i][j] = c;
             }
@@ -1414,7 +1413,7 @@ int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols
 }
 
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
-                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only, bool dot_with_c) {
+                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only, bool dot_with_c, bool b_first_piece_only) {
     OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && ((C != nullptr) != (loss_partial != nullptr) || dot_with_c), OQ_ERR_INVALID_ARGUMENT,
                "gemm_f16x3: bad argument");
     OQ_REQUIRE(!hi_pieces_only || (loss_partial && !dot_with_c), OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the one-product form exists for the sum-of-squares epilogue only");
@@ -1429,7 +1428,12 @@ int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M,
     const int64_t tiles = (g.Mp / kST) * (g.Np / kST);
     OQ_REQUIRE(tiles < (1 << 30), OQ_ERR_UNSUPPORTED, "gemm_f16x3: too many tiles");
     const int lds_bytes = StageGeom<3>::LDS;
-    if (dot_with_c) {
+    OQ_REQUIRE(!b_first_piece_only || dot_with_c, OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the two-product form exists for the dot epilogue only");
+    if (dot_with_c && b_first_piece_only) {
+        OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
+                   OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
+        hipLaunchKernelGGL((gemm_f16x3_kernel<2, 2>), dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
+    } else if (dot_with_c) {
         OQ_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess,
                    OQ_ERR_LAUNCH, "gemm_f16x3: cannot reserve %d bytes of LDS", lds_bytes);
         hipLaunchKernelGGL(gemm_f16x3_kernel<2>, dim3(static_cast<uint32_t>(tiles)), dim3(kSThreads), lds_bytes, s, g);
