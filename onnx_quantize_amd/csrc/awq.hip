@@ -305,7 +305,10 @@ struct AwqWs {   // carving of the caller's workspace
 // fp16 pieces (22 bits: rounding G to 11 bits would move every column's loss the same way, nothing averages out), D with
 // its first (its rounding errors are independent per column): two products.
 // Break-even: two products of 2 K^2 N against one of 2 T K N, plus the Gram matrix over ~20 candidates.
-constexpr int64_t kAwqGramRatio = 6;
+#ifndef OQ_AWQ_GRAM_RATIO
+#define OQ_AWQ_GRAM_RATIO 3   /* measured on 4096^2 (scripts/lab_awq_routes.py): T = 2 K direct 6.8 / 3.3 ms vs Gram 7.1 / 3.8; T = 3 K 9.0 / 4.4 vs 7.3 / 3.9 */
+#endif
+constexpr int64_t kAwqGramRatio = OQ_AWQ_GRAM_RATIO;
 static bool awq_use_gram(int64_t T, int64_t K) { return T >= kAwqGramRatio * K; }
 static int64_t loss_tiles(int64_t T, int64_t K, int64_t N) { return gemm_f16x3_tiles(awq_use_gram(T, K) ? K : T, N); }
 static int64_t loss_stride(int64_t T, int64_t K, int64_t N) { return (loss_tiles(T, K, N) + 63) / 64 * 64; }

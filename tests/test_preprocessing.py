@@ -89,7 +89,7 @@ def test_gpu_awq_searches_follow_the_oracle(qtype, strategy, g, sym):
 @pytest.mark.parametrize("t,k,n,qtype,strategy,g", [(2048, 256, 192, "uint4", "group", 32), (8192, 1024, 516, "uint4", "group", 128),
                                                     (6144, 1024, 256, "int8", "channel", -1), (1024, 128, 64, "uint8", "tensor", -1)])
 def test_gpu_awq_searches_with_long_calibration_sets_follow_the_oracle(t, k, n, qtype, strategy, g):
-    """T >= 6 K rows: the searches take the Gram route (awq.hip: sum_n ||X d_n||^2 = <D, X^T X D>, the Gram matrix made once
+    """T >= 3 K rows: the searches take the Gram route (awq.hip: sum_n ||X d_n||^2 = <D, X^T X D>, the Gram matrix made once
     by the Hessian kernels -- fp32 MFMA below K = 1024, fp16 pieces above).  Same bars as the direct route; outlier channels
     make the Gram matrix span six orders of magnitude."""
     from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search
