@@ -455,6 +455,30 @@ def test_nan_weights_poison_their_range_like_numpy(strategy, g, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,n", [(4100, 6400), (8200, 3100), (4096, 11008), (130, 200004)])
+def test_per_tensor_kernel_with_dropped_tiles_and_ragged_edges_vs_oracle(k, n):
+    """More than three tiles per CU (tiles are dropped in phase A and read again in phase B), a last row tile whose second
+    half lies entirely past K, a last column tile that is only partly filled, rows of phase B straddling half tiles; twice on
+    the same state buffer."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    rng = np.random.default_rng(k * 7 + n)
+    w = (rng.standard_normal((k, n)) * 0.03).astype(np.float32)
+    w[k - 1, n - 1] = 0.9                       # the maximum sits in the last, ragged tile
+    w[0, 0] = -0.7
+    wd = torch.from_numpy(w).cuda()
+    for qtype, sym in (("int8", False), ("uint8", True)):
+        for _ in range(2):
+            q, s, z = ops.rtn_quantize(wd, qtype, "tensor", -1, sym)
+        eq, es, ez = O.rtn_quantize(w, qtype, "tensor", -1, sym)
+        np.testing.assert_array_equal(q.cpu().numpy(), eq)
+        assert np.asarray(s.cpu().numpy()).tobytes() == np.asarray(es).tobytes() and int(z.cpu().numpy()) == int(ez)
+    state = ops._rtn_state(1, wd.device)
+    torch.cuda.synchronize()
+    assert int(state.count_nonzero()) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k,n,strategy", [(8192, 260, "channel"), (4096, 2048, "tensor"), (6144, 512, "tensor")])
 def test_nan_weights_in_the_ticketed_kernels_for_large_ranges(k, n, strategy):
     """The same for the streamed channel kernel (ranges taller than 4096 rows) and for the per-tensor kernel with tiles kept
