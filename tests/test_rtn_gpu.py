@@ -107,10 +107,12 @@ def test_rtn_two_pass_vs_oracle(ops, strategy, g):
 
 
 @pytest.mark.parametrize("k,n,strategy,g", [(4100, 260, "channel", -1), (8192, 516, "channel", -1), (12288, 300, "channel", -1),
-                                            (16384, 264, "group", 8192), (24576, 68, "channel", -1), (9000, 1028, "group", 4500)])
+                                            (16384, 264, "group", 8192), (24576, 68, "channel", -1), (9000, 1028, "group", 4500),
+                                            (4000, 9000, "channel", -1), (4000, 9000, "group", 2000)])
 def test_streamed_kernel_for_tall_ranges_vs_oracle(ops, k, n, strategy, g):
-    """Ranges taller than 4096 rows run on `rtn_resident_stream` (persistent workgroups, two tile slots, the next tile loaded
-    while the previous one is stored): ragged last chunks, partial column tiles, two k-groups, up to the 192-chunk limit; the
+    """Ranges taller than 4096 rows -- or calls with at least four 128-row tiles per workgroup -- run on `rtn_resident_stream`
+    (persistent workgroups, two tile slots, the next tile loaded while the previous one is stored): ragged last chunks,
+    partial column tiles, two k-groups, up to the 192-chunk limit, short ranges over many columns; the
     state must come back zero (ops.rtn_quantize reuses one state buffer per stream without clearing it)."""
     import torch
     rng = np.random.default_rng(k + n)
