@@ -826,3 +826,15 @@ def test_stateful_entry_point_leaves_its_state_zero_and_equals_the_plain_call(op
         eq, es, ez = O.rtn_quantize(w.cpu().numpy(), "int8", strategy, g)
         np.testing.assert_array_equal(outs[0][0].cpu().numpy(), eq)
     assert lib.oq_rtn_state_bytes(4096, 4096, L.STRATEGY_CODE["group"], 128) == 0       # the fused group kernels keep no state
+
+
+@pytest.mark.gpu
+def test_ticketed_kernels_short_soak():
+    """scripts/soak_resident.py for five seconds: bursts of channel / tensor / tall-group calls over mixed shapes without host
+    synchronisation in between, one state buffer; every result equals the first one for its input, the state ends zero."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_resident.py"), "5"], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "soak ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
