@@ -532,17 +532,16 @@ def strategies_bench(dev, ws, rank: int) -> dict:
             rec["verified_vs_reference_digest"] = bool(sha16(q.cpu().numpy()) == d["q_sha"] and sha16(sc.cpu().numpy()) == d["s_sha"] and
                                                        sha16(z.cpu().numpy()) == d["z_sha"])
         out[strategy] = rec
-    # Llama's down_proj shape (11008 rows per column): ranges taller than 4096 rows run on the streamed kernel
-    # (rtn_resident_stream); its scales are compared with ranges computed by torch (utils.py:258-271 in fp32), the integers
-    # are covered by tests/test_rtn_gpu.py::test_streamed_kernel_for_tall_ranges_vs_oracle
-    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
-    wt = [torch.randn((N_DIM, K_DIM), generator=gen, device=dev) * 0.02 for _ in range(3)]
+    # Llama's down_proj shape (11008 rows per column) on the same kernel; rank 0's last result is checked against the digest of
+    # what the reference returned for that matrix (tests/golden/digests.json: tall_int8_channel, seed 6)
+    dt = digests.get("tall_int8_channel")
+    wt = [torch.from_numpy(np.random.default_rng(6 + 100 * j + 1000 * rank).standard_normal((N_DIM, K_DIM), dtype=np.float32)).to(dev) for j in range(3)]
     outs = ops.rtn_quantize(wt[0], "int8", "channel", -1)
     for i in range(6):
         ops.rtn_quantize(wt[i % 3], "int8", "channel", -1, out=outs)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 60
+    reps = 61                                                   # ends on wt[0]: the digest's matrix on rank 0
     e0.record()
     for i in range(reps):
         ops.rtn_quantize(wt[i % 3], "int8", "channel", -1, out=outs)
@@ -550,14 +549,13 @@ def strategies_bench(dev, ws, rank: int) -> dict:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     alg = K_DIM * N_DIM * 4 + K_DIM * N_DIM + K_DIM * 5
-    q, sc, z = outs                                            # of wt[(reps - 1) % 3]
-    wl = wt[(reps - 1) % 3]
-    mn = torch.minimum(wl.amin(dim=0), torch.zeros((), device=dev)).cpu().numpy()
-    mx = torch.maximum(wl.amax(dim=0), torch.zeros((), device=dev)).cpu().numpy()
-    sc_ref = (mx - mn) / np.float32(255)                       # utils.py:258-271, asymmetric int8: (max - min) / (qmax - qmin), IEEE fp32 on the host
-    out["channel_tall"] = {"shape": f"{N_DIM}x{K_DIM}", "kernel": "oq::rtn_resident_stream", "launch_us": round(us, 2), "algorithmic_bytes": alg,
-                           "achieved_GBs": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4),
-                           "scales_equal_ranges_over_255": bool(np.array_equal(sc.reshape(-1).cpu().numpy(), sc_ref))}
+    rec = {"shape": f"{N_DIM}x{K_DIM}", "kernel": "oq::rtn_resident_stream", "launch_us": round(us, 2), "algorithmic_bytes": alg,
+           "achieved_GBs": round(alg / us / 1e3, 1), "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
+    if rank == 0 and dt is not None:
+        q, sc, z = outs
+        rec["verified_vs_reference_digest"] = bool(sha16(q.cpu().numpy()) == dt["q_sha"] and sha16(sc.cpu().numpy()) == dt["s_sha"] and
+                                                   sha16(z.cpu().numpy()) == dt["z_sha"])
+    out["channel_tall"] = rec
     return out
 
 

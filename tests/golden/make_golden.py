@@ -1079,6 +1079,13 @@ def gen_digests(out):
         d[f"headline_{qtype}_g128_packed"] = dict(k=4096, n=11008, seed=0, kind="normal", qtype=qtype, strategy="group", group_size=128,
                                                   symmetric=False, w_sha=sha16(w), q_sha=sha16(q), packed_sha=sha16(packed),
                                                   packed_bytes=int(packed.size), s_sha=sha16(s), z_sha=sha16(z))
+    # Llama's down_proj shape: columns of 11008 rows (the streamed per-channel kernel; a per-tensor range over 2752 tiles)
+    w = weight("normal", 6, 11008, 4096)
+    for strategy in ("channel", "tensor"):
+        q, s, z = rtn_call(w, "int8", strategy, -1, False, False, 1.0, False)
+        d[f"tall_int8_{strategy}"] = dict(k=11008, n=4096, seed=6, kind="normal", qtype="int8", strategy=strategy, group_size=-1,
+                                          symmetric=False, w_sha=sha16(w), q_sha=sha16(q), s_sha=sha16(np.asarray(s)),
+                                          z_sha=sha16(np.asarray(z)))
     with open(os.path.join(out, "digests.json"), "w") as f:
         json.dump(d, f, indent=1)
     print("digests: ok")

@@ -143,7 +143,8 @@ def test_config1_plumbing(ops):
 
 
 @pytest.mark.parametrize("key", ["config2_asym", "config2_sym", "config2_heavy", "config2_zero_groups",
-                                 "channel_4096", "int4_g128_4096", "headline_int8_channel", "headline_int8_tensor"])
+                                 "channel_4096", "int4_g128_4096", "headline_int8_channel", "headline_int8_tensor",
+                                 "tall_int8_channel", "tall_int8_tensor"])
 def test_full_size_digests(ops, key):
     """BASELINE.json configs[1] (4096x11008 uint4 g128) and friends at full size, against digests
     of what the reference itself produced (tests/golden/make_golden.py::gen_digests)."""
