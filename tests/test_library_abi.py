@@ -202,6 +202,9 @@ full = np.empty((11008, 32, 128), np.uint8); full[..., 0::2] = b & 0x0F; full[..
 out["nbits"] = [sha(full.reshape(11008, 4096).T), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
 q, s, z = ops.rtn_quantize(w, "uint4", "group", 128, layout="kn")
 out["kn"] = [sha(q.cpu().numpy()), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
+for strategy in ("channel", "tensor"):      # the ticketed kernels: OQ_RTN_RES_TILE picks among three of them, OQ_RTN_RESIDENT=0 the three-launch path
+    q, s, z = ops.rtn_quantize(w, "int8", strategy, -1)
+    out[strategy] = [sha(q.cpu().numpy()), sha(s.cpu().numpy()), sha(z.cpu().numpy())]
 # the GPTQ path: Hessian, factor, corrected loop (VERDICT r03 item 7: OQ_HESSIAN_METHOD / OQ_GPTQ_ROWS16 / OQ_SYRK_F16_M16 used to
 # be read by the shipped library; they must now change nothing)
 g = torch.Generator(device="cuda").manual_seed(3)
@@ -214,11 +217,14 @@ out["gptq"] = [sha(h.cpu().numpy()), sha(q.cpu().numpy()), sha(s.cpu().numpy()),
 print(json.dumps(out))
 '''
     with open(os.path.join(root, "tests", "golden", "digests.json")) as f:
-        d = json.load(f)["config2_asym"]
+        dall = json.load(f)
+    d = dall["config2_asym"]
     expect = [d["q_sha"], d["s_sha"], d["z_sha"]]
+    expect_rng = {st: [dall[f"headline_int8_{st}"][k] for k in ("q_sha", "s_sha", "z_sha")] for st in ("channel", "tensor")}
     gptq_bytes = None
     hostile = [dict(OQ_RTN_NT="56"), dict(OQ_RTN_NT="127"), dict(OQ_RTN_NT="120", OQ_RTN_RESIDENT="0", OQ_RTN_RES_TILE="32"),
-               dict(OQ_HESSIAN_METHOD="1", OQ_GPTQ_ROWS16="0", OQ_SYRK_F16_M16="0", OQ_SYRK_SPLITS="1"), dict()]
+               dict(OQ_HESSIAN_METHOD="1", OQ_GPTQ_ROWS16="0", OQ_SYRK_F16_M16="0", OQ_SYRK_SPLITS="1"), dict(OQ_RTN_RES_TILE="1"),
+               dict(OQ_RTN_RES_TILE="128", OQ_RES_SLEEP="0"), dict(OQ_RTN_RES_TILE="256", OQ_AWQ_GRAM_RATIO="1"), dict()]
     for knobs in hostile:
         clean = {k: v for k, v in os.environ.items() if not k.startswith("OQ_")}
         env = dict(clean, PYTHONPATH=root, **knobs)
@@ -226,5 +232,6 @@ print(json.dumps(out))
         assert r.returncode == 0, r.stderr[-2000:]
         got = json.loads(r.stdout.strip().splitlines()[-1])
         assert got["nbits"] == expect and got["kn"] == expect, (knobs, got)
+        assert got["channel"] == expect_rng["channel"] and got["tensor"] == expect_rng["tensor"], (knobs, got)
         gptq_bytes = gptq_bytes or got["gptq"]
         assert got["gptq"] == gptq_bytes, (knobs, got["gptq"], gptq_bytes)     # Hessian, integers, scales, zero points: the same bits
