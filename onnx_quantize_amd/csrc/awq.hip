@@ -229,6 +229,101 @@ __global__ __launch_bounds__(256) void awq_diff4_kernel(const float* __restrict_
     if (threadIdx.x == 0) absmax_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
 }
 
+// ---- group strategy, 16 <= g <= 128 rows: scale rows -> RTN -> W - dequant / s in ONE pass over W.  The three steps of a
+// candidate that only move data -- W s[:, None] written and read back, the integers written and read back, W read a third
+// time for the difference -- fall away: the block of rtn_group_fused (8 waves x 16 rows x 256 columns, the group's range
+// through LDS) keeps its rows in registers from the load to the difference.  Same arithmetic in the same order as the
+// separate kernels (fp32 product w s, utils.py R1 / Q1 / K1 through the helpers of oq_common.hpp, (q - zp) * scale, / s,
+// w - .): the D it writes is theirs bit for bit.
+__global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, int64_t g, QGrid grid, int wpg,
+                                                                const float* __restrict__ row_scale, float* __restrict__ D,
+                                                                float* __restrict__ absmax_partial) {
+    __shared__ float4 s_mn[8][64];
+    __shared__ float4 s_mx[8][64];
+    __shared__ float s_abs[8];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
+    const int wig = wave % wpg, gib = wave / wpg, gpb = 8 / wpg;
+    const int64_t kgroups = K / g, kg = static_cast<int64_t>(blockIdx.y) * gpb + gib;
+    const bool group_ok = kg < kgroups;
+    const int64_t row0 = (group_ok ? kg : 0) * g + static_cast<int64_t>(wig) * 16;   // a surplus group re-reads group 0: loads are never predicated
+    const int64_t tile_col0 = static_cast<int64_t>(blockIdx.x) * 256;
+    const bool col_ok = tile_col0 + lane * 4 < N;
+    const int64_t lcol = col_ok ? tile_col0 + lane * 4 : N - 4;
+    float4 w[16];
+    float sr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        w[r] = *reinterpret_cast<const float4*>(W + (row0 + r) * ldw + lcol);
+        sr[r] = row_scale != nullptr ? row_scale[row0 + r] : 1.0f;     // uniform: scalar loads
+    }
+    auto scaled = [&](int r, int i) -> float {      // what the candidate quantizes: w * s (awq.py:156), or w (the clip search)
+        const float x = i == 0 ? w[r].x : i == 1 ? w[r].y : i == 2 ? w[r].z : w[r].w;
+        return row_scale != nullptr ? x * sr[r] : x;
+    };
+    float mn[4], mx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mn[i] = mx[i] = scaled(0, i);
+#pragma unroll
+    for (int r = 1; r < 16; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = scaled(r, i);
+            mn[i] = nmin(mn[i], x);
+            mx[i] = nmax(mx[i], x);
+        }
+    if (wpg > 1) {   // uniform over the block: the group's waves meet in LDS
+        s_mn[wave][lane] = make_float4(mn[0], mn[1], mn[2], mn[3]);
+        s_mx[wave][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
+        __syncthreads();
+        const int w0 = gib * wpg;
+        for (int v = 0; v < wpg; ++v) {
+            const float4 tn = s_mn[w0 + v][lane], tx = s_mx[w0 + v][lane];
+            mn[0] = nmin(mn[0], tn.x); mn[1] = nmin(mn[1], tn.y); mn[2] = nmin(mn[2], tn.z); mn[3] = nmin(mn[3], tn.w);
+            mx[0] = nmax(mx[0], tx.x); mx[1] = nmax(mx[1], tx.y); mx[2] = nmax(mx[2], tx.z); mx[3] = nmax(mx[3], tx.w);
+        }
+    }
+    ColQ cq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cq[i] = make_colq(qparam_from_minmax(mn[i], mx[i], grid), mn[i], mx[i], 0);
+    const float lo = static_cast<float>(grid.qmin), hi = static_cast<float>(grid.qmax);
+    float m = 0.f;
+    float* out = D + row0 * N + tile_col0 + lane * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float x[4], f[4];
+        bool unsafe = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i] = scaled(r, i);
+            f[i] = quantize_fast_biased(x[i], cq[i], lo, hi, unsafe);
+        }
+        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {   // wave-uniform, rare: redo this row with the IEEE divide
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(x[i], cq[i], grid.qmin, grid.qmax, 0);
+        }
+        const float wv[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
+        float d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float w_hat = (f[i] - cq[i].zpb) * cq[i].scale;          // utils.py:130-132 on exact small integers
+            if (row_scale != nullptr) w_hat = w_hat / sr[r];
+            d[i] = wv[i] - w_hat;
+            m = nmax(m, fabsf(d[i]));
+        }
+        if (col_ok && group_ok) *reinterpret_cast<float4*>(out + r * N) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if (!(col_ok && group_ok)) m = 0.f;
+    m = wave_max(m);
+    if (lane == 0) s_abs[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = s_abs[0];
+#pragma unroll
+        for (int v = 1; v < 8; ++v) t = nmax(t, s_abs[v]);
+        absmax_partial[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = t;
+    }
+}
+
 // ---- losses[i] = sum of the GEMM's per-block sums / (T N), in block order
 // (one block per candidate: all candidates of a search in ONE launch behind the last product)
 __global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial_all, int64_t nblocks, int64_t stride, double inv_count,
@@ -365,25 +460,44 @@ static int32_t param_index(int32_t strategy, int64_t K, int64_t g, ParamIndex* p
 }
 
 // one candidate: quantize `Wq` (the weights as the candidate sees them), D = W - dequant (/ s), loss -> loss_out
-static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const float* Wq, int64_t ldq, const float* row_scale, int64_t T, int64_t K,
+static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const float* row_scale, int64_t T, int64_t K,
                               int64_t N, int32_t qtype, int32_t strategy, int64_t group_size, int64_t g, int32_t symmetric, int32_t reduce_range,
                               float clip_ratio, int candidate, hipStream_t s) {
-    int32_t st = rtn_impl(Wq, K, N, ldq, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, 0, w.q, w.qscale, w.qzp, OQ_LAYOUT_KN,
-                          w.rtn_ws, w.rtn_ws_bytes, s, true);
-    if (st != OQ_OK) return st;
-    ParamIndex pi;
-    param_index(strategy, K, g, &pi);
-    const int32_t is_signed = (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0;
-    const bool vec = N % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 && (strategy != OQ_GROUP || g % 8 == 0);
+    int32_t st;
     int nparts;
-    if (vec) {
-        const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 1024)), static_cast<uint32_t>(ceil_div(K, 8)));
-        hipLaunchKernelGGL(awq_diff4_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, is_signed, row_scale, w.D, w.diff_part);
+    const bool vec = N % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 && (strategy != OQ_GROUP || g % 8 == 0);
+    if (vec && strategy == OQ_GROUP && (g == 16 || g == 32 || g == 64 || g == 128) && K % g == 0) {
+        QGrid grid;
+        st = make_grid(qtype, symmetric, reduce_range, clip_ratio, &grid);
+        if (st != OQ_OK) return st;
+        const int wpg = static_cast<int>(g / 16), gpb = 8 / wpg;
+        const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K / g, gpb)));
+        hipLaunchKernelGGL(awq_group_diff_kernel, dgrid, dim3(512), 0, s, W, K, N, ldw, g, grid, wpg, row_scale, w.D, w.diff_part);
         nparts = static_cast<int>(dgrid.x * dgrid.y);
     } else {
-        const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K, 8)));
-        hipLaunchKernelGGL(awq_diff_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, is_signed, row_scale, w.D, w.diff_part);
-        nparts = static_cast<int>(dgrid.x * dgrid.y);
+        const float* Wq = W;
+        int64_t ldq = ldw;
+        if (row_scale != nullptr) {   // awq.py:156: the candidate's weights, materialised for the general RTN entry point
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(static_cast<uint32_t>(ceil_div(ceil_div(N, 4), 256)), static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N,
+                               ldw, row_scale, w.Ws);
+            Wq = w.Ws;
+            ldq = N;
+        }
+        st = rtn_impl(Wq, K, N, ldq, qtype, strategy, group_size, symmetric, reduce_range, clip_ratio, 0, w.q, w.qscale, w.qzp, OQ_LAYOUT_KN, w.rtn_ws,
+                      w.rtn_ws_bytes, s, true);
+        if (st != OQ_OK) return st;
+        ParamIndex pi;
+        param_index(strategy, K, g, &pi);
+        const int32_t is_signed = (qtype == OQ_INT4 || qtype == OQ_INT8) ? 1 : 0;
+        if (vec) {
+            const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 1024)), static_cast<uint32_t>(ceil_div(K, 8)));
+            hipLaunchKernelGGL(awq_diff4_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, is_signed, row_scale, w.D, w.diff_part);
+            nparts = static_cast<int>(dgrid.x * dgrid.y);
+        } else {
+            const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K, 8)));
+            hipLaunchKernelGGL(awq_diff_kernel, dgrid, dim3(256), 0, s, W, K, N, ldw, w.q, w.qscale, w.qzp, pi, is_signed, row_scale, w.D, w.diff_part);
+            nparts = static_cast<int>(dgrid.x * dgrid.y);
+        }
     }
     st = check_launch("awq_diff_kernel");
     if (st != OQ_OK) return st;
@@ -472,9 +586,7 @@ int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ld
     if (st != OQ_OK) return st;
     for (int i = 0; i < n_grid; ++i) {
         const float* si = scales_out + static_cast<int64_t>(i) * K;
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(static_cast<uint32_t>(ceil_div(ceil_div(N, 4), 256)), static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw,
-                           si, w.Ws);
-        st = candidate_loss(w, W, ldw, w.Ws, N, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, i, s);
+        st = candidate_loss(w, W, ldw, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, i, s);
         if (st != OQ_OK) return st;
     }
     st = finish_losses(w.gemm_part, n_grid, T, K, N, losses_out, s);
@@ -500,7 +612,7 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
     if (st != OQ_OK) return st;
     for (int i = 0; i < 10; ++i) {
         const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227
-        st = candidate_loss(w, W, ldw, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, i, s);
+        st = candidate_loss(w, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, i, s);
         if (st != OQ_OK) return st;
     }
     st = finish_losses(w.gemm_part, 10, T, K, N, losses_out, s);
