@@ -502,7 +502,7 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
     st = check_launch("awq_diff_kernel");
     if (st != OQ_OK) return st;
     // the pieces of D with the scale from awq_diff_kernel's partial maxima (instead of a second pass over D)
-    st = make_f16x2_pieces_from_partials(w.D, K, N, N, w.diff_part, nparts, w.pieces_d, s);
+    st = make_f16x2_pieces_from_partials(w.D, K, N, N, w.diff_part, nparts, w.pieces_d, s, kAwqHiPiecesOnly);   // both routes read D's first pieces only
     if (st != OQ_OK) return st;
     // first pieces only: every term of the product carries a relative rounding error <= 2^-10, the loss is a sum of T N
     // squared K-term dot products -- its error (~1e-7 relative, measured against the three-product form) is four orders of

@@ -122,7 +122,7 @@ int32_t launch_inverse_level_f16x3(const float* Lt, float* X, float* Y, float* S
 size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols);
 int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s);
 int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols, int64_t ldx, const float* absmax_partials, int npart, void* pieces,
-                                        hipStream_t s);   // [Kd, cols] row-major source whose max |x| is already folded into `npart` device partials
+                                        hipStream_t s, bool first_pieces_only = false);   // true: the lo plane is left untouched (consumers that read first pieces only)   // [Kd, cols] row-major source whose max |x| is already folded into `npart` device partials
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
                           int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only = false, bool dot_with_c = false,
                           bool b_first_piece_only = false);

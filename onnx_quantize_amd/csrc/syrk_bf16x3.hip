@@ -175,6 +175,9 @@ __device__ __forceinline__ uint32_t pk_f16(float a, float b) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
+// alpha > 0: the dead-channel guard's factor; alpha <= 0: no guard (callers pass 0 or their product's -1).  The one value
+// kSplitHiOnly: no guard AND the lo plane is not written (a consumer that reads first pieces only).
+constexpr float kSplitHiOnly = -3.0e38f;
 __device__ __forceinline__ void split_f16x2_body(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
                                                  const int64_t Kp, const int64_t nchunks, const float* __restrict__ scale,
                                                  const float alpha, u32x4* __restrict__ P, const int64_t bx, const int64_t by) {
@@ -207,7 +210,7 @@ __device__ __forceinline__ void split_f16x2_body(const float* __restrict__ X, co
         }
         u32x4* o = P + (c * 2) * Kp + k;
         __builtin_nontemporal_store(hi, o);
-        __builtin_nontemporal_store(lo, o + Kp);
+        if (alpha != kSplitHiOnly) __builtin_nontemporal_store(lo, o + Kp);      // kSplitHiOnly: the consumer reads first pieces only
     }
 }
 
@@ -1399,7 +1402,7 @@ int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx,
 // The same for a row-major [Kd, cols] source whose maximum |x| the caller already has as `npart` partial maxima on the
 // device (a producer kernel that folded them while writing X): no second pass over X for the scale.
 int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols, int64_t ldx, const float* absmax_partials, int npart, void* pieces,
-                                        hipStream_t s) {
+                                        hipStream_t s, bool first_pieces_only) {
     OQ_REQUIRE(X && pieces && absmax_partials && npart > 0 && Kd > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT,
                "make_f16x2_pieces_from_partials: bad argument");
     float* scale = static_cast<float*>(pieces);
@@ -1408,7 +1411,7 @@ int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols
     OQ_REQUIRE(ceil_div(nchunks, 4) <= 65535, OQ_ERR_UNSUPPORTED, "make_f16x2_pieces_from_partials: contraction too long (%lld)", (long long)Kd);
     hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, absmax_partials, npart, scale);
     hipLaunchKernelGGL(split_f16x2_kernel, dim3(static_cast<uint32_t>(Cp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4))), dim3(256), 0, s, X, Kd, cols, ldx,
-                       Cp, nchunks, scale, 0.0f, P);
+                       Cp, nchunks, scale, first_pieces_only ? kSplitHiOnly : 0.0f, P);
     return check_launch("split_f16x2 (gemm pieces, given maxima)");
 }
 
