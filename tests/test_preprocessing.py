@@ -69,7 +69,8 @@ def _inputs(seed, t, k, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("qtype,strategy,g,sym", [("uint4", "group", 32, False), ("int8", "channel", -1, True), ("uint8", "tensor", -1, False),
-                                                  ("int4", "group", 128, False)])
+                                                  ("int4", "group", 128, False), ("int8", "group", 64, True), ("uint4", "group", 16, True),
+                                                  ("int4", "group", 256, True)])
 def test_gpu_awq_searches_follow_the_oracle(qtype, strategy, g, sym):
     from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search
     x, w = _inputs(3, 512, 256, 192)
