@@ -989,10 +989,17 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
         a.key_max = base + 128;                  // one 16-byte slot {1, max key, complemented min key} per arrival (<= 512 workgroups)
         a.key_nmin = base + 128 + 64 * 32;       // 64 replicas x 32 words: {go, final max key, final complemented min key}
         a.held = base + kResTensorHeader;
-        // per launch, not once: the attribute belongs to the current device's copy of the kernel
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(rtn_tensor_onepass), hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes) != hipSuccess)
-            return fail(OQ_ERR_LAUNCH, "rtn: %d bytes of LDS refused", kParkBytes);
-        const int resident = resident_blocks(reinterpret_cast<const void*>(rtn_tensor_onepass), kParkBytes);
+        // once per device: the attribute belongs to that device's copy of the kernel; the occupancy does not change either
+        // (two host calls of several microseconds each: a 256 x 512 call is host-bound)
+        static int resident_of[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OQ_ERR_LAUNCH, "rtn: no current device");
+        if (resident_of[dev] == 0) {   // benign race: every thread computes the same value
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(rtn_tensor_onepass), hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes) != hipSuccess)
+                return fail(OQ_ERR_LAUNCH, "rtn: %d bytes of LDS refused", kParkBytes);
+            resident_of[dev] = resident_blocks(reinterpret_cast<const void*>(rtn_tensor_onepass), kParkBytes);
+        }
+        const int resident = resident_of[dev];
         OQ_REQUIRE(resident > 0, OQ_ERR_LAUNCH, "rtn: occupancy query failed");
         uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
         if (blocks > 512u) blocks = 512u;        // the arrival slots (and one slot per thread of the last finisher)
