@@ -19,6 +19,13 @@
  *     core/_algorithms/utils.py:6-26.
  *   - 4-bit results are returned one value per byte (int8/uint8 containers, like the reference's
  *     in-memory ml_dtypes arrays) unless a packed layout is requested.
+ *   - bounds, checked before any arithmetic on an argument (a call outside them returns a negative
+ *     status; it never wraps a product, divides by a wrapped one or truncates a grid): every extent of
+ *     an operand (rows, columns, tokens, leading dimensions) is in [1, 2^31 - 1]; an operand has at
+ *     most 2^40 elements; flat element counts with one thread per element (oq_qparams_*,
+ *     oq_quantize_bias_f32, the packers) at most 2^38; lists and batches at most 65535 entries; the
+ *     width K of a Hessian / factor at most 2^17; running sample counts at most 2^52.  The matching
+ *     *_workspace_bytes query returns 0 (or its 256-byte floor) for a request outside the bounds.
  */
 #ifndef OQ_HIP_H
 #define OQ_HIP_H

@@ -531,7 +531,7 @@ static int32_t prepare_activations(const AwqWs& w, const float* X, int64_t T, in
 
 static int32_t check_common(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
                             int64_t group_size, int64_t* g) {
-    OQ_REQUIRE(X && W && T > 0 && K > 0 && N > 0 && ldx >= K && ldw >= N, OQ_ERR_INVALID_ARGUMENT, "awq: bad argument");
+    OQ_REQUIRE(X && W && matrix_ok(T, K, ldx) && matrix_ok(K, N, ldw), OQ_ERR_INVALID_ARGUMENT, "awq: bad argument");
     OQ_REQUIRE(qtype == OQ_INT4 || qtype == OQ_UINT4 || qtype == OQ_INT8 || qtype == OQ_UINT8, OQ_ERR_UNSUPPORTED, "awq: 4- and 8-bit types only");
     OQ_REQUIRE(strategy == OQ_TENSOR || strategy == OQ_CHANNEL || strategy == OQ_GROUP, OQ_ERR_INVALID_ARGUMENT, "awq: unknown strategy %d", strategy);
     *g = K;
@@ -553,7 +553,7 @@ extern "C" {
 using namespace oq;
 
 size_t oq_awq_workspace_bytes(int64_t T, int64_t K, int64_t N) {
-    if (T <= 0 || K <= 0 || N <= 0) return 0;
+    if (!oq::matrix_ok(T, K, K) || !oq::matrix_ok(K, N, N) || K > 65535) return 0;
     return awq_workspace(T, K, N, nullptr, nullptr);
 }
 
@@ -623,7 +623,7 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
 
 int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, float alpha, float* scale_out,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-    OQ_REQUIRE(X && W && scale_out && T > 0 && K > 0 && N > 0 && ldx >= K && ldw >= N && K <= (int64_t{1} << 31), OQ_ERR_INVALID_ARGUMENT,
+    OQ_REQUIRE(X && W && scale_out && matrix_ok(T, K, ldx) && matrix_ok(K, N, ldw), OQ_ERR_INVALID_ARGUMENT,
                "oq_smooth_quant_scale_f32: bad argument");
     const size_t need = align256(static_cast<size_t>(kColChunks) * K * 4) + 2 * align256(static_cast<size_t>(K) * 4) + 256;
     OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_smooth_quant_scale_f32: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
@@ -643,7 +643,7 @@ int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t 
 }
 
 size_t oq_smooth_quant_workspace_bytes(int64_t K) {
-    if (K <= 0) return 0;
+    if (!oq::extent_ok(K)) return 0;
     return oq::align256(static_cast<size_t>(oq::kColChunks) * K * 4) + 2 * oq::align256(static_cast<size_t>(K) * 4) + 512;
 }
 

@@ -237,7 +237,7 @@ using namespace oq;
 
 int32_t oq_qparams_f32(const float* rmin, const float* rmax, int64_t count, int32_t qtype, int32_t symmetric,
                        int32_t reduce_range, float* scale_out, int32_t* zp_out, void* stream) {
-    OQ_REQUIRE(rmin && rmax && scale_out && zp_out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_qparams_f32: bad argument");
+    OQ_REQUIRE(rmin && rmax && scale_out && zp_out && count_ok(count, kMaxThreads), OQ_ERR_INVALID_ARGUMENT, "oq_qparams_f32: bad argument");
     QGrid grid;
     const int32_t st = make_grid(qtype, symmetric, reduce_range, 1.0f, &grid);
     if (st != OQ_OK) return st;
@@ -248,7 +248,7 @@ int32_t oq_qparams_f32(const float* rmin, const float* rmax, int64_t count, int3
 
 int32_t oq_qparams_f64(const double* rmin, const double* rmax, int64_t count, int32_t qtype, int32_t symmetric,
                        int32_t reduce_range, float* scale_out, int32_t* zp_out, void* stream) {
-    OQ_REQUIRE(rmin && rmax && scale_out && zp_out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_qparams_f64: bad argument");
+    OQ_REQUIRE(rmin && rmax && scale_out && zp_out && count_ok(count, kMaxThreads), OQ_ERR_INVALID_ARGUMENT, "oq_qparams_f64: bad argument");
     QGrid grid;
     const int32_t st = make_grid(qtype, symmetric, reduce_range, 1.0f, &grid);
     if (st != OQ_OK) return st;
@@ -260,7 +260,7 @@ int32_t oq_qparams_f64(const double* rmin, const double* rmax, int64_t count, in
 int32_t oq_quantize_f32(const float* x, int64_t R, int64_t C, int64_t ldx, const float* scale, const int32_t* zp,
                         int64_t row_div, int64_t row_stride, int64_t col_stride, int32_t qtype, int32_t symmetric,
                         int32_t reduce_range, void* q_out, void* stream) {
-    OQ_REQUIRE(x && scale && zp && q_out && R > 0 && C > 0 && ldx >= C && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
+    OQ_REQUIRE(x && scale && zp && q_out && matrix_ok(R, C, ldx) && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
                "oq_quantize_f32: bad argument");
     int64_t qmin, qmax;
     OQ_REQUIRE(qrange_host(qtype, symmetric, reduce_range, &qmin, &qmax), OQ_ERR_INVALID_ARGUMENT,
@@ -298,7 +298,7 @@ int32_t oq_quantize_f32(const float* x, int64_t R, int64_t C, int64_t ldx, const
 int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, const float* scale, const int32_t* zp,
                           int64_t row_div, int64_t row_stride, int64_t col_stride, float* x_out, int64_t ldo,
                           void* stream) {
-    OQ_REQUIRE(q && scale && zp && x_out && R > 0 && C > 0 && ldo >= C && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
+    OQ_REQUIRE(q && scale && zp && x_out && matrix_ok(R, C, ldo) && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
                "oq_dequantize_f32: bad argument");
     OQ_REQUIRE(qtype >= OQ_INT4 && qtype <= OQ_UINT32, OQ_ERR_INVALID_ARGUMENT, "oq_dequantize_f32: unknown type %d", qtype);
     const ParamIndex pi{row_div, row_stride, col_stride};
@@ -330,7 +330,7 @@ int32_t oq_dequantize_f32(const void* q, int64_t R, int64_t C, int32_t qtype, co
 int32_t oq_dequantize_fzp_f32(const void* q, int64_t R, int64_t C, int32_t qtype, const float* scale, const float* zp,
                               int64_t row_div, int64_t row_stride, int64_t col_stride, float* x_out, int64_t ldo,
                               void* stream) {
-    OQ_REQUIRE(q && scale && zp && x_out && R > 0 && C > 0 && ldo >= C && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
+    OQ_REQUIRE(q && scale && zp && x_out && matrix_ok(R, C, ldo) && row_div > 0, OQ_ERR_INVALID_ARGUMENT,
                "oq_dequantize_fzp_f32: bad argument");
     OQ_REQUIRE(qtype >= OQ_INT4 && qtype <= OQ_UINT8, OQ_ERR_UNSUPPORTED, "oq_dequantize_fzp_f32: 4- and 8-bit containers only, got type %d", qtype);
     const ParamIndex pi{row_div, row_stride, col_stride};
@@ -345,7 +345,7 @@ int32_t oq_dequantize_fzp_f32(const void* q, int64_t R, int64_t C, int32_t qtype
 
 int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale, int64_t n_w_scale, float x_scale,
                              int32_t* q_out, float* bias_scale_out, void* stream) {
-    OQ_REQUIRE(bias && w_scale && q_out && bias_scale_out && n > 0, OQ_ERR_INVALID_ARGUMENT, "oq_quantize_bias_f32: bad argument");
+    OQ_REQUIRE(bias && w_scale && q_out && bias_scale_out && count_ok(n, kMaxThreads), OQ_ERR_INVALID_ARGUMENT, "oq_quantize_bias_f32: bad argument");
     OQ_REQUIRE(n_w_scale == 1 || n_w_scale == n, OQ_ERR_INVALID_ARGUMENT,
                "oq_quantize_bias_f32: weight scale must have 1 or %lld entries, got %lld", (long long)n, (long long)n_w_scale);
     hipLaunchKernelGGL(bias_kernel, dim3(static_cast<uint32_t>(ceil_div(n, 256))), dim3(256), 0, as_stream(stream), bias, n,
@@ -354,7 +354,7 @@ int32_t oq_quantize_bias_f32(const float* bias, int64_t n, const float* w_scale,
 }
 
 int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uint8_t* out, void* stream) {
-    OQ_REQUIRE(zp && out && N > 0 && blocks > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_zero_points_u4: bad argument");
+    OQ_REQUIRE(zp && out && extent_ok(N) && extent_ok(blocks) && N * ((blocks + 1) / 2) <= kMaxThreads, OQ_ERR_INVALID_ARGUMENT, "oq_pack_zero_points_u4: bad argument");
     const int64_t work = N * ((blocks + 1) / 2);
     hipLaunchKernelGGL(pack_zp_u4_kernel, dim3(static_cast<uint32_t>(ceil_div(work, 256))), dim3(256), 0, as_stream(stream), zp,
                        N, blocks, out);
@@ -362,7 +362,7 @@ int32_t oq_pack_zero_points_u4(const uint8_t* zp, int64_t N, int64_t blocks, uin
 }
 
 int32_t oq_pack_matmul_nbits(const void* q, int64_t K, int64_t N, int64_t group_size, int32_t bits, uint8_t* out, void* stream) {
-    OQ_REQUIRE(q && out && K > 0 && N > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_matmul_nbits: bad argument");
+    OQ_REQUIRE(q && out && matrix_ok(K, N, N), OQ_ERR_INVALID_ARGUMENT, "oq_pack_matmul_nbits: bad argument");
     OQ_REQUIRE(bits == 4 || bits == 8, OQ_ERR_UNSUPPORTED, "oq_pack_matmul_nbits: 4- or 8-bit values only");
     OQ_REQUIRE(group_size >= 2 && group_size % 2 == 0 && K % group_size == 0, OQ_ERR_INVALID_ARGUMENT,
                "oq_pack_matmul_nbits: group_size must be even and divide K (%lld, %lld)", (long long)group_size, (long long)K);
@@ -373,7 +373,7 @@ int32_t oq_pack_matmul_nbits(const void* q, int64_t K, int64_t N, int64_t group_
 }
 
 int32_t oq_pack_nibbles(const void* values, int64_t count, uint8_t* out, void* stream) {
-    OQ_REQUIRE(values && out && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_pack_nibbles: bad argument");
+    OQ_REQUIRE(values && out && count_ok(count, kMaxThreads), OQ_ERR_INVALID_ARGUMENT, "oq_pack_nibbles: bad argument");
     const bool aligned = (reinterpret_cast<uintptr_t>(values) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0;
     const int64_t vec16 = aligned ? count / 16 : 0;
     const int64_t threads = vec16 + ((count + 1) / 2 - vec16 * 8);

@@ -299,13 +299,13 @@ extern "C" {
 using namespace oq;
 
 size_t oq_gptq_prepare_workspace_bytes(int64_t K, int64_t N, int32_t actorder) {
-    if (!actorder || K <= 0 || N <= 0) return 256;
+    if (!actorder || !matrix_ok(K, N, N) || K > kMaxHessianWidth) return 256;
     return align256(static_cast<size_t>(K) * N * 4) + align256(static_cast<size_t>(K) * K * 4) + 256;
 }
 
 int32_t oq_gptq_prepare_f32(float* W, int64_t K, int64_t N, float* H, int32_t actorder, int32_t* perm_out, void* workspace,
                             size_t workspace_bytes, void* stream) {
-    OQ_REQUIRE(W && H && K > 0 && N > 0, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_prepare_f32: bad argument");
+    OQ_REQUIRE(W && H && matrix_ok(K, N, N) && K <= kMaxHessianWidth, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_prepare_f32: bad argument");
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(dead_channels_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, H);
     int32_t st = check_launch("dead_channels_kernel");
@@ -349,7 +349,7 @@ static size_t inverse_pieces_bytes(int64_t K, int64_t count) {
 }
 
 size_t oq_gptq_factor_batched_workspace_bytes(int64_t K, int64_t count) {
-    if (K <= 0 || count <= 0) return 0;
+    if (K <= 0 || K > kMaxHessianWidth || count <= 0 || count > 65535) return 0;
     return static_cast<size_t>(count) * (4 * factor_matrix_bytes(K) + factor_dinv_bytes(K)) + inverse_pieces_bytes(K, count) + 256;
 }
 
@@ -362,7 +362,7 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
                               int32_t* info, int32_t fix_dead, int32_t method, void* workspace, size_t workspace_bytes, hipStream_t s,
                               const char* who) {
     OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "%s: unknown method %d", who, method);
-    OQ_REQUIRE(H && U_out && info && K > 0 && count > 0 && count <= 65535, OQ_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
+    OQ_REQUIRE(H && U_out && info && K > 0 && K <= kMaxHessianWidth && count > 0 && count <= 65535, OQ_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
     OQ_REQUIRE(count == 1 || (h_stride >= K * K && u_stride >= K * K), OQ_ERR_INVALID_ARGUMENT, "%s: matrices of the batch overlap", who);
     const size_t need = oq_gptq_factor_batched_workspace_bytes(K, count);
     OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "%s: workspace of %zu bytes needed, %zu given", who, need, workspace_bytes);

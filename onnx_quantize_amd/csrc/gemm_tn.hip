@@ -368,10 +368,10 @@ using namespace oq;
 
 // G1  gptq.py:246-260.
 // slab slices the workspace query budgets for: 16 for K <= 8192 (1 GB at 4096), 4 above (1.9 GB at 11008)
-static size_t hessian_slab_budget(int64_t K) { return K <= 0 ? 0 : static_cast<size_t>(K <= 8192 ? 16 : 4) * K * K * sizeof(float); }
+static size_t hessian_slab_budget(int64_t K) { return (K <= 0 || K > kMaxHessianWidth) ? 0 : static_cast<size_t>(K <= 8192 ? 16 : 4) * K * K * sizeof(float); }
 
 size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) {
-    if (T <= 0 || K <= 0) return 256;
+    if (!matrix_ok(T, K, K) || K > kMaxHessianWidth) return 256;
     const size_t f32 = K <= 8192 ? syrk_slab_bytes(T, K) : 0;
     const size_t split = syrk_bf16x3_pieces_bytes(T, K) + hessian_slab_budget(K);
     return (f32 > split ? f32 : split) + 512;
@@ -380,9 +380,11 @@ size_t oq_hessian_workspace_bytes(int64_t T, int64_t K) {
 int32_t oq_hessian_accumulate_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_seen, int64_t n_add, float* H,
                                   int32_t method, void* workspace, size_t workspace_bytes, void* stream) {
     OQ_REQUIRE(X && H && T > 0 && K > 0 && ldx >= K, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: bad argument");
+    OQ_REQUIRE(matrix_ok(T, K, ldx) && K <= kMaxHessianWidth, OQ_ERR_UNSUPPORTED, "oq_hessian_accumulate_f32: operand too large (T=%lld K=%lld ldx=%lld)",
+               (long long)T, (long long)K, (long long)ldx);
     OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: unknown method %d", method);
-    OQ_REQUIRE(n_seen >= 0 && n_add > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_f32: bad sample counts %lld + %lld",
-               (long long)n_seen, (long long)n_add);
+    OQ_REQUIRE(n_seen >= 0 && n_add > 0 && n_seen <= kMaxSamples && n_add <= kMaxSamples, OQ_ERR_INVALID_ARGUMENT,
+               "oq_hessian_accumulate_f32: bad sample counts %lld + %lld", (long long)n_seen, (long long)n_add);
     const int64_t n_total = n_seen + n_add;
     // gptq.py:254  H *= num_samples / (num_samples + num_added): a Python float applied to an fp32 array.
     // The first call of the reference starts from zeros (gptq.py:304): beta = 0, nothing is read.
@@ -419,11 +421,12 @@ int32_t oq_hessian_accumulate_many_f32(const oq_hessian_item* items_host, const 
 
 // G1 in two halves (fp16-piece method): the HBM-bound preparation of a batch and its matrix-core bound product, so that a
 // caller can run the preparation of batch i + 1 on a side stream while the product of batch i occupies the matrix cores.
-size_t oq_hessian_pieces_bytes(int64_t T, int64_t K) { return (T <= 0 || K <= 0) ? 0 : syrk_bf16x3_pieces_bytes(T, K) + 256; }
+size_t oq_hessian_pieces_bytes(int64_t T, int64_t K) { return (!matrix_ok(T, K, K) || K > kMaxHessianWidth) ? 0 : syrk_bf16x3_pieces_bytes(T, K) + 256; }
 size_t oq_hessian_slab_bytes(int64_t K) { return hessian_slab_budget(K) + 256; }
 
 int32_t oq_hessian_prepare_f32(const float* X, int64_t T, int64_t K, int64_t ldx, int64_t n_total, void* pieces, size_t pieces_bytes, void* stream) {
-    OQ_REQUIRE(X && pieces && T > 0 && K > 0 && ldx >= K && n_total > 0, OQ_ERR_INVALID_ARGUMENT, "oq_hessian_prepare_f32: bad argument");
+    OQ_REQUIRE(X && pieces && matrix_ok(T, K, ldx) && K <= kMaxHessianWidth && n_total > 0 && n_total <= 2 * kMaxSamples, OQ_ERR_INVALID_ARGUMENT,
+               "oq_hessian_prepare_f32: bad argument");
     OQ_REQUIRE((reinterpret_cast<uintptr_t>(pieces) & 255u) == 0 && pieces_bytes >= syrk_bf16x3_pieces_bytes(T, K), OQ_ERR_WORKSPACE,
                "oq_hessian_prepare_f32: 256-byte aligned buffer of %zu bytes needed, %zu given", syrk_bf16x3_pieces_bytes(T, K), pieces_bytes);
     const float alpha = static_cast<float>(2.0 / static_cast<double>(n_total));
@@ -432,8 +435,9 @@ int32_t oq_hessian_prepare_f32(const float* X, int64_t T, int64_t K, int64_t ldx
 
 int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_t K, int64_t n_seen, int64_t n_add, float* H, void* slabs,
                                            size_t slab_bytes, void* stream) {
-    OQ_REQUIRE(pieces && H && T > 0 && K > 0 && n_seen >= 0 && n_add > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT,
-               "oq_hessian_accumulate_prepared_f32: bad argument");
+    OQ_REQUIRE(pieces && H && matrix_ok(T, K, K) && K <= kMaxHessianWidth && n_seen >= 0 && n_add > 0 && n_seen <= kMaxSamples && n_add <= kMaxSamples &&
+                   (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0,
+               OQ_ERR_INVALID_ARGUMENT, "oq_hessian_accumulate_prepared_f32: bad argument");
     const int64_t n_total = n_seen + n_add;
     const float beta = n_seen == 0 ? 0.0f : static_cast<float>(static_cast<double>(n_seen) / static_cast<double>(n_total));   // gptq.py:254
     const float alpha = static_cast<float>(2.0 / static_cast<double>(n_total));

@@ -724,7 +724,7 @@ static size_t piece_gemm_bytes(int64_t K, int64_t N, int64_t block_size) {
 }
 
 size_t oq_gptq_loop_workspace_bytes(int64_t K, int64_t N, int64_t block_size) {
-    if (K <= 0 || N <= 0 || block_size <= 0) return 0;
+    if (!matrix_ok(K, N, N) || K > kMaxHessianWidth || block_size <= 0 || block_size > kMaxExtent) return 0;
     // Err [super-block rows, N] + carried (scale, zp) [N] + (mse) per-group parameters of one launch [128, N] x (4 + 1) B
     // + (block_size > 128) the block's working copy [block_size, N] + the MSE search's own workspace for one [group, N] slice
     // + the coefficient images of all launches (rows-over-lanes kernel)
@@ -740,8 +740,9 @@ int32_t oq_gptq_loop_f32(float* W, int64_t K, int64_t N, const float* U, int32_t
                          void* stream) {
     OQ_REQUIRE(W && U && init_scale && init_zp && q_int_out && q_deq_out && K > 0 && N > 0, OQ_ERR_INVALID_ARGUMENT,
                "oq_gptq_loop_f32: bad argument");
+    OQ_REQUIRE(matrix_ok(K, N, N) && K <= kMaxHessianWidth, OQ_ERR_UNSUPPORTED, "oq_gptq_loop_f32: matrix too large (K=%lld N=%lld)", (long long)K, (long long)N);
     OQ_REQUIRE(init_count == 1 || init_count == N, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: init_count must be 1 or N");
-    OQ_REQUIRE(block_size > 0, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: block_size must be positive");
+    OQ_REQUIRE(block_size > 0 && block_size <= kMaxExtent && group_size <= kMaxExtent, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: block_size must be positive");
     OQ_REQUIRE(mode == OQ_GPTQ_PARITY || mode == OQ_GPTQ_CORRECTED || mode == OQ_GPTQ_CORRECTED_COLUMNS, OQ_ERR_INVALID_ARGUMENT,
                "oq_gptq_loop_f32: bad mode %d", mode);
     OQ_REQUIRE(method >= OQ_HESSIAN_AUTO && method <= OQ_HESSIAN_F16X3, OQ_ERR_INVALID_ARGUMENT, "oq_gptq_loop_f32: unknown method %d", method);

@@ -348,7 +348,7 @@ extern "C" {
 using namespace oq;
 
 size_t oq_hqq_workspace_bytes(int64_t K, int64_t N, int64_t group_size) {
-    if (K <= 0 || N <= 0) return 0;
+    if (!oq::matrix_ok(K, N, N)) return 0;
     int64_t g = group_size > K ? K : group_size;
     if (g == -1) g = K;
     if (g <= 0 || K % g != 0) return 0;
@@ -365,7 +365,7 @@ int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
                             const float* scale, const float* zero_point_in, double lp_norm, double beta, double kappa, int32_t iters,
                             int32_t early_stop, int32_t per_round_launches, void* q_out, int32_t layout, float* zero_point_out, int32_t* rounds_out,
                             void* workspace, size_t workspace_bytes, void* stream) {
-    OQ_REQUIRE(W && scale && zero_point_in && zero_point_out && K > 0 && N > 0 && ldw >= N, OQ_ERR_INVALID_ARGUMENT,
+    OQ_REQUIRE(W && scale && zero_point_in && zero_point_out && matrix_ok(K, N, ldw), OQ_ERR_INVALID_ARGUMENT,
                "oq_hqq_optimize_f32: bad argument");
     OQ_REQUIRE(iters >= 0 && beta > 0.0, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: iters >= 0 and beta > 0 needed");
     OQ_REQUIRE(layout == OQ_LAYOUT_KN || layout == OQ_LAYOUT_NBITS, OQ_ERR_INVALID_ARGUMENT, "oq_hqq_optimize_f32: bad layout %d", layout);

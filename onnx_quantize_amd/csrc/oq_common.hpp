@@ -26,6 +26,22 @@ int32_t check_launch(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ------------------------------------------------------------------ argument ranges (host side)
+// Every extent a caller passes is checked against these BEFORE any arithmetic on it, so that no product of two of them can
+// wrap around and no grid dimension can be truncated: hostile arguments end in a status, never in a fault, a division by
+// zero or a silently shortened launch (tests/test_hostile_arguments.py sweeps every entry point).
+constexpr int64_t kMaxExtent = (1LL << 31) - 1;   // rows, columns, leading dimensions, tokens of one operand
+constexpr int64_t kMaxElements = 1LL << 40;       // elements of one operand (4 TiB of fp32: far beyond the 288 GB of one GPU)
+constexpr int64_t kMaxThreads = 1LL << 38;        // one thread per element, 256 per block: the grid's x extent stays below 2^31
+constexpr int64_t kMaxHessianWidth = 1LL << 17;  // K of a [K, K] Hessian / factor: 64 GiB of fp32 at this bound
+constexpr int64_t kMaxSamples = 1LL << 52;        // running sample counts: sums stay exact in a double
+inline bool extent_ok(int64_t v) { return v > 0 && v <= kMaxExtent; }
+inline bool count_ok(int64_t n, int64_t limit = kMaxElements) { return n > 0 && n <= limit; }
+// rows x cols with leading dimension ld (both factors below 2^31: the product cannot overflow)
+inline bool matrix_ok(int64_t rows, int64_t cols, int64_t ld) {
+    return extent_ok(rows) && extent_ok(cols) && ld >= cols && ld <= kMaxExtent && rows * ld <= kMaxElements;
+}
+
 // ------------------------------------------------------------------ quantization grid (T1)
 // core/_dtypes.py:8-30, :61-70.  Host-evaluated once per call and passed to kernels by value.
 struct QGrid {

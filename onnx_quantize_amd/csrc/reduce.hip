@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kRedBlock) void minmax_update(const T* partial, int
 template <typename T>
 static int32_t minmax_collect(const T* x, int64_t count, T* state, double momentum, void* ws, size_t ws_bytes,
                               void* stream) {
-    OQ_REQUIRE(x && state && count > 0, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_collect: bad argument");
+    OQ_REQUIRE(x && state && count_ok(count), OQ_ERR_INVALID_ARGUMENT, "oq_minmax_collect: bad argument");
     OQ_REQUIRE(momentum >= 0.0 && momentum < 1.0, OQ_ERR_INVALID_ARGUMENT, "Momentum must be in the range [0, 1).");
     OQ_REQUIRE((reinterpret_cast<uintptr_t>(x) % sizeof(T)) == 0, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_collect: misaligned input");
     int64_t nblocks = ceil_div(count, static_cast<int64_t>(kRedBlock) * 8);
@@ -335,13 +335,13 @@ int32_t oq_minmax_collect_many_f32(const void* desc, int64_t n, double momentum,
 }
 
 size_t oq_absmax_workspace_bytes(int64_t R, int64_t C, int32_t transposed) {
-    if (transposed || R <= 0 || C <= 0) return 256;
+    if (transposed || !matrix_ok(R, C, C)) return 256;
     return static_cast<size_t>(ceil_div(R, kAbsChunkRows) * C) * sizeof(float) + 256;
 }
 
 int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t transposed, float* out,
                       void* workspace, size_t workspace_bytes, void* stream) {
-    OQ_REQUIRE(x && out && R > 0 && C > 0 && ldx >= C, OQ_ERR_INVALID_ARGUMENT, "oq_absmax_f32: bad argument");
+    OQ_REQUIRE(x && out && matrix_ok(R, C, ldx), OQ_ERR_INVALID_ARGUMENT, "oq_absmax_f32: bad argument");
     const bool vec4 = (C % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
     hipStream_t s = as_stream(stream);
     if (transposed) {
@@ -363,7 +363,7 @@ int32_t oq_absmax_f32(const float* x, int64_t R, int64_t C, int64_t ldx, int32_t
 }
 
 int32_t oq_minmax_rows_f32(const float* x, int64_t R, int64_t C, int64_t ldx, float* min_out, float* max_out, void* stream) {
-    OQ_REQUIRE(x && min_out && max_out && R > 0 && C > 0 && ldx >= C, OQ_ERR_INVALID_ARGUMENT, "oq_minmax_rows_f32: bad argument");
+    OQ_REQUIRE(x && min_out && max_out && matrix_ok(R, C, ldx), OQ_ERR_INVALID_ARGUMENT, "oq_minmax_rows_f32: bad argument");
     const bool vec4 = (C % 4 == 0) && (ldx % 4 == 0) && (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
     hipLaunchKernelGGL(minmax_rows, dim3(static_cast<uint32_t>(ceil_div(R, 4))), dim3(256), 0, as_stream(stream), x, R, C, ldx,
                        vec4, min_out, max_out);

@@ -1290,7 +1290,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     OQ_REQUIRE(W && scale_out && zp_out && (q_out || !emit_q), OQ_ERR_INVALID_ARGUMENT, "rtn: null pointer argument");
     OQ_REQUIRE(K > 0 && N > 0 && ldw >= N, OQ_ERR_INVALID_ARGUMENT, "rtn: bad shape K=%lld N=%lld ldw=%lld",
                (long long)K, (long long)N, (long long)ldw);
-    OQ_REQUIRE(K * N < (1LL << 40), OQ_ERR_UNSUPPORTED, "rtn: matrix too large");
+    OQ_REQUIRE(matrix_ok(K, N, ldw), OQ_ERR_UNSUPPORTED, "rtn: matrix too large (K=%lld N=%lld ldw=%lld)", (long long)K, (long long)N, (long long)ldw);
     OQ_REQUIRE(clip_ratio > 0.0f && clip_ratio <= 1.0f, OQ_ERR_INVALID_ARGUMENT,
                "clip_ratio must be in (0.0, 1.0], got %g", clip_ratio);
     OQ_REQUIRE(layout == OQ_LAYOUT_KN || layout == OQ_LAYOUT_NBITS || layout == OQ_LAYOUT_KN_PACKED4, OQ_ERR_INVALID_ARGUMENT,
@@ -1489,7 +1489,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
 extern "C" {
 
 size_t oq_rtn_workspace_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size, int32_t mse) {
-    if (K <= 0 || N <= 0) return 0;
+    if (!oq::matrix_ok(K, N, N)) return 0;
     int64_t g;
     if (oq::resolve_group(strategy, K, group_size, &g) != OQ_OK) return 0;
     if (strategy == OQ_GROUP && K % g != 0) return 0;
@@ -1511,7 +1511,7 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
 }
 
 size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size) {
-    if (K <= 0 || N <= 0) return 0;
+    if (!oq::matrix_ok(K, N, N)) return 0;
     int64_t g;
     if (oq::resolve_group(strategy, K, group_size, &g) != OQ_OK || K % g != 0) return 0;
     int rpw = 0, wpg = 0;
@@ -1542,7 +1542,7 @@ int32_t oq_rtn_qparams_f32(const float* W, int64_t K, int64_t N, int64_t ldw, in
 }
 
 size_t oq_rtn_batched_workspace_bytes(int64_t batch, int64_t K, int64_t N, int64_t group_size) {
-    if (batch <= 0 || K <= 0 || N <= 0) return 0;
+    if (batch <= 0 || batch > 65535 || !oq::matrix_ok(K, N, N)) return 0;
     int64_t g;
     if (oq::resolve_group(OQ_GROUP, K, group_size, &g) != OQ_OK || K % g != 0) return 0;
     return static_cast<size_t>(batch) * oq::stage_ws(K, N, g) + 512;
@@ -1552,8 +1552,10 @@ int32_t oq_rtn_quantize_batched_f32(const float* W, int64_t batch, int64_t w_str
                                     int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio, void* q_out,
                                     float* scale_out, void* zp_out, int32_t layout, void* workspace, size_t workspace_bytes,
                                     void* stream) {
-    OQ_REQUIRE(batch >= 1 && w_stride >= K * ldw, OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_batched_f32: bad batch %lld / stride %lld",
-               (long long)batch, (long long)w_stride);
+    OQ_REQUIRE(oq::matrix_ok(K, N, ldw), OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_batched_f32: bad shape K=%lld N=%lld ldw=%lld", (long long)K,
+               (long long)N, (long long)ldw);
+    OQ_REQUIRE(batch >= 1 && batch <= 65535 && w_stride >= K * ldw && w_stride <= oq::kMaxElements, OQ_ERR_INVALID_ARGUMENT,
+               "oq_rtn_quantize_batched_f32: bad batch %lld (1 to 65535) / stride %lld", (long long)batch, (long long)w_stride);
     int64_t g;
     int32_t st = oq::resolve_group(OQ_GROUP, K, group_size, &g);
     if (st != OQ_OK) return st;
@@ -1574,8 +1576,10 @@ int32_t oq_rtn_quantize_ptrs_f32(const oq_rtn_ptrs* table_host, const oq_rtn_ptr
                                  int64_t ldw, int32_t qtype, int64_t group_size, int32_t symmetric, int32_t reduce_range, float clip_ratio,
                                  int32_t layout, void* workspace, size_t workspace_bytes, void* stream) {
     static_assert(sizeof(oq::RtnPtrs) == sizeof(oq_rtn_ptrs), "device view of oq_rtn_ptrs");
-    OQ_REQUIRE(K > 0 && N > 0 && count >= 1, OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_ptrs_f32: bad shape K=%lld N=%lld / count %lld",
+    OQ_REQUIRE(K > 0 && N > 0 && count >= 1 && count <= oq::kMaxExtent, OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_ptrs_f32: bad shape K=%lld N=%lld / count %lld",
                (long long)K, (long long)N, (long long)count);
+    OQ_REQUIRE(oq::matrix_ok(K, N, ldw), OQ_ERR_INVALID_ARGUMENT, "oq_rtn_quantize_ptrs_f32: bad shape K=%lld N=%lld ldw=%lld", (long long)K, (long long)N,
+               (long long)ldw);     // before any arithmetic on K * N (matrices_per_launch divides by it)
     const int64_t per_launch = oq::matrices_per_launch(K, N, count);
     OQ_REQUIRE(table_host && (table_device || per_launch == 1) && count >= 1, OQ_ERR_INVALID_ARGUMENT,
                "oq_rtn_quantize_ptrs_f32: bad table / count %lld", (long long)count);

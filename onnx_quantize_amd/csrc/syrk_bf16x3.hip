@@ -1264,9 +1264,13 @@ static size_t syrk_many_item_bytes(int64_t T, int64_t K) {
 static size_t syrk_many_table_bytes(int64_t count) { return (static_cast<size_t>(count) * sizeof(SyrkItem) + 255) / 256 * 256; }
 
 size_t syrk_f16x3_many_workspace_bytes(const int64_t* items_host, int64_t count) {
-    if (items_host == nullptr || count <= 0) return 256;
+    if (items_host == nullptr || count <= 0 || count > 65535) return 256;
     size_t total = syrk_many_table_bytes(count) + 512;
-    for (int64_t m = 0; m < count; ++m) total += syrk_many_item_bytes(items_host[m * 8 + 2], items_host[m * 8 + 3]);
+    for (int64_t m = 0; m < count; ++m) {
+        const int64_t T = items_host[m * 8 + 2], K = items_host[m * 8 + 3];
+        if (!matrix_ok(T, K, K) || K > kMaxHessianWidth) return 256;      // refused by the call itself
+        total += syrk_many_item_bytes(T, K);
+    }
     return total;
 }
 
@@ -1278,6 +1282,8 @@ int32_t launch_syrk_f16x3_many(const int64_t* items_host, const int64_t* items_d
         const int64_t* it = items_host + m * 8;
         OQ_REQUIRE(it[0] != 0 && it[1] != 0 && it[2] > 0 && it[3] > 0 && it[4] >= it[3] && it[5] >= 0 && it[6] > 0, OQ_ERR_INVALID_ARGUMENT,
                    "hessian_many: item %lld: X, H, T > 0, K > 0, ldx >= K, n_seen >= 0, n_add > 0 expected", (long long)m);
+        OQ_REQUIRE(matrix_ok(it[2], it[3], it[4]) && it[3] <= kMaxHessianWidth && it[5] <= kMaxSamples && it[6] <= kMaxSamples, OQ_ERR_UNSUPPORTED,
+                   "hessian_many: item %lld is too large", (long long)m);
         const int64_t Kp = padded_k(it[3]), nchunks = stages_of(it[2], StageGeom<3>::ROWS) * StageGeom<3>::CH, tn = Kp / kST;
         split_blocks += (Kp / 256) * ceil_div(nchunks, 4);
         tiles += tn * (tn + 1) / 2;
