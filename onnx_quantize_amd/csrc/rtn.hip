@@ -65,6 +65,7 @@ struct RtnArgs {
     int32_t nt;       // non-temporal loads of W
     int32_t stage_q;  // NBITS: transpose the block's packed output through LDS (64/128-byte chunks per column)
     int32_t gk;       // order 2: row tiles per id chunk (see the block order in rtn_group_fused)
+    uint32_t xg_log2; // order 2: log2 of the neighbouring column tiles one XCD owns inside a chunk (0 = one)
     FastDiv fd_ncol, fd_band, fd_chunk;  // ncol_tiles, ncol_tiles * gk, 8 * gk (block ids < 2^22, checked by the host)
     int32_t spb_log2;  // wave kernel: log2(strips per block)
     uint32_t pair_owner;  // fused kernel, direct parameter stores: wave (inside its group) that stores pair p, 3 bits each
@@ -125,16 +126,19 @@ __device__ __forceinline__ void tile_of_block(const RtnArgs& a, uint32_t bid, ui
         if (gk_eff == static_cast<uint32_t>(a.gk)) {
             cc = fast_divmod(r, a.fd_chunk, r);
         } else {  // last, shorter band
-            cc = r / (8u * gk_eff);
-            r -= cc * 8u * gk_eff;
+            cc = r / ((8u << a.xg_log2) * gk_eff);
+            r -= cc * (8u << a.xg_log2) * gk_eff;
         }
-        const uint32_t w = min(8u, a.ncol_tiles - cc * 8u);
-        if (w == 8u) {
-            row_tile = b * a.gk + (r >> 3);
-            col_tile = cc * 8u + (r & 7u);
+        // xg_log2 > 0 (lab): an XCD owns 2^xg_log2 NEIGHBOURING column tiles of a chunk instead of one
+        const uint32_t cw = 8u << a.xg_log2;
+        const uint32_t w = min(cw, a.ncol_tiles - cc * cw);
+        if (w == cw) {
+            const uint32_t within = r & (cw - 1u);
+            row_tile = b * a.gk + (r >> (3 + a.xg_log2));
+            col_tile = cc * cw + ((within & 7u) << a.xg_log2) + (within >> 3);
         } else {  // last, narrower chunk of column tiles
             row_tile = b * a.gk + r / w;
-            col_tile = cc * 8u + r % w;
+            col_tile = cc * cw + r % w;
         }
     }
 }
@@ -1133,7 +1137,7 @@ __global__ __launch_bounds__(256) void transpose_qparams(const float* scale_t, c
 
 // Experiment knobs: speed only, every setting produces the same bytes (-1 = the tuned default).
 struct Tuning {
-    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1, wps = -1, resident = -1;
+    int order = -1, gk = -1, nt = -1, stage = -1, stage_q = -1, wavek = -1, gpb = -1, wpb = -1, wps = -1, resident = -1, xg = -1;
     static int env_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
     static Tuning from_env() {
         Tuning t;
@@ -1147,6 +1151,7 @@ struct Tuning {
         t.wpb = env_int("OQ_RTN_WPB");          // wave kernel: waves per block
         t.wps = env_int("OQ_RTN_WPS");          // wave kernel: 0 = the 4-waves-per-SIMD build, 5 = the 92-register build (5 per SIMD)
         t.resident = env_int("OQ_RTN_RESIDENT"); // channel / tensor / tall groups: 0 = the three-launch path that reads W twice
+        t.xg = env_int("OQ_RTN_XG");            // order 2: log2 of the neighbouring column tiles one XCD owns (speed only)
         return t;
     }
 };
@@ -1178,7 +1183,7 @@ static void set_block_order(RtnArgs& a) {
     if (nblk >= (1u << 22)) a.order = 0;
     a.fd_ncol = make_fastdiv(a.ncol_tiles);
     a.fd_band = make_fastdiv(a.ncol_tiles * static_cast<uint32_t>(a.gk));
-    a.fd_chunk = make_fastdiv(8u * static_cast<uint32_t>(a.gk));
+    a.fd_chunk = make_fastdiv((8u << a.xg_log2) * static_cast<uint32_t>(a.gk));
 }
 
 template <bool VEC4, bool EMIT_Q>
@@ -1371,6 +1376,12 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.order = tw.order >= 0 ? tw.order : 2;
             a.gk = tw.gk > 0 ? tw.gk : 4;
             a.nt = (tw.nt >= 0 ? tw.nt : 1) & kNtMask;
+            // Column tiles (512 B of a row) that one XCD owns side by side inside a chunk of the L2-merging order.  One tile per XCD
+            // leaves an XCD a fixed 512-byte residue of every 4 KB of a row band; two neighbours (1 KB) measured 2-5 % faster on
+            // every Llama width but the multiples of 16384 (4096: 18.0 -> 17.2 us, 11008: 40.1 -> 38.8, 28672: 100.4 -> 96.3,
+            // 32000: 122.3 -> 116.4; 16384: 56.9 -> 57.7), eight (4 KB) on rows of 32 KB (8192: 32.3 -> 30.0, 8192 x 8192:
+            // 62.4 -> 56.6): scripts/lab_order_sweep.sh, docs/LAB_NOTES_r05.md.  Speed only.
+            a.xg_log2 = tw.xg >= 0 ? static_cast<uint32_t>(tw.xg > 4 ? 4 : tw.xg) : (N % 16384 == 0 ? 0u : (N % 8192 == 0 ? 3u : 1u));
             set_block_order(a);
             const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(wpb * kWave));
             // the 5-waves-per-SIMD build addresses its outputs with 32-bit offsets and needs blocks of <= 4 waves
@@ -1420,9 +1431,15 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         const bool blob = layout == OQ_LAYOUT_NBITS;
         a.order = tune.order >= 0 ? tune.order : (blob ? 2 : 1);      // KN and KN_PACKED4 alike: plain column-fastest ids
         a.gk = tune.gk > 0 ? tune.gk : 8;
+        // 16 column tiles (N = 4096): with column-fastest ids an XCD owns tiles x and x + 8 of EVERY row band; the L2-merging order
+        // with two neighbouring tiles per XCD measured 25.1 -> 22.3 us (4096 x 4096 [K,N] bytes), 50.7 -> 48.1 (11008 x 4096),
+        // 60.5 -> 57.6 (14336 x 4096); every other width of the sweep keeps the plain order (scripts/lab_order_sweep.sh)
+        const bool sixteen = !blob && a.ncol_tiles == 16 && tune.order < 0;
+        if (sixteen) a.order = 2;
         a.nt = (tune.nt >= 0 ? tune.nt : 1) & kNtMask;
         a.stage_q = ((tune.stage_q != 0) && blob && vec4 && rpw == 16 && a.wpg * a.gpb == kMaxWaves && kgroups % a.gpb == 0) ? 1 : 0;
         a.spb_log2 = 0;
+        a.xg_log2 = tune.xg >= 0 ? static_cast<uint32_t>(tune.xg > 4 ? 4 : tune.xg) : (sixteen ? 1u : 0u);
         set_block_order(a);
         const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
         if (vec4) {
