@@ -184,6 +184,39 @@ def test_nbits_layout_matches_reference_packing(ops):
         assert s2.cpu().numpy().tobytes() == s.cpu().numpy().tobytes()
 
 
+@pytest.mark.parametrize("k,n", [(640, 4096), (640, 4224), (384, 8192), (256, 16384), (1152, 2176), (640, 12288)])
+def test_block_orders_of_wide_matrices_vs_oracle(ops, k, n):
+    """The id -> tile maps of the group kernels are chosen from the width (round 5: an XCD owns 2 / 8 / 1 neighbouring column
+    tiles of a chunk for the blob kernel -- N = 4096, 4224: two, with a narrower last chunk; 8192: eight; 16384: one --, and
+    the [K,N] layouts of 16 column tiles (N = 4096) run on the chunked order as well).  Every map has to visit every tile
+    exactly once whatever the band count (640 rows = 5 k-groups: a short last band of the 4- and 8-group bands): all three
+    layouts against the oracle."""
+    rng = np.random.default_rng(k + n)
+    w = rng.standard_normal((k, n), dtype=np.float32)
+    eq, es, ez = O.rtn_quantize(w, "uint4", "group", 128)
+    eb, es2, _ = O.matmul_nbits_layout(eq, es, ez, 128, 4)
+    wd = dev(w)
+    b, s, z = ops.rtn_quantize(wd, "uint4", "group", 128, layout="nbits")
+    np.testing.assert_array_equal(b.cpu().numpy(), eb)
+    assert s.cpu().numpy().reshape(n, k // 128).tobytes() == es2.tobytes()
+    np.testing.assert_array_equal(z.cpu().numpy().reshape(-1), ez.reshape(-1))
+    q, s, z = ops.rtn_quantize(wd, "uint4", "group", 128)
+    np.testing.assert_array_equal(q.cpu().numpy(), eq)
+    assert s.cpu().numpy().tobytes() == es.tobytes()
+    np.testing.assert_array_equal(z.cpu().numpy(), ez)
+    qp, s, z = ops.rtn_quantize(wd, "uint4", "group", 128, layout="kn_packed4")
+    np.testing.assert_array_equal(qp.cpu().numpy().reshape(-1), O.pack_nibbles(eq))
+    assert s.cpu().numpy().tobytes() == es.tobytes()
+    np.testing.assert_array_equal(z.cpu().numpy(), ez)
+    q8, s8, z8 = ops.rtn_quantize(wd, "int8", "group", 64, True)          # g = 64: sixteen lanes per row piece, two groups per 128 rows
+    e8, es8, ez8 = O.rtn_quantize(w, "int8", "group", 64, True)
+    np.testing.assert_array_equal(q8.cpu().numpy(), e8)
+    assert s8.cpu().numpy().tobytes() == es8.tobytes()
+    b8, _, _ = ops.rtn_quantize(wd, "uint8", "group", 64, layout="nbits")
+    u8, us8, uz8 = O.rtn_quantize(w, "uint8", "group", 64)
+    np.testing.assert_array_equal(b8.cpu().numpy(), O.matmul_nbits_layout(u8, us8, uz8, 64, 8)[0])
+
+
 @pytest.mark.parametrize("qtype,g,sym,rr,clip", [("int4", 128, False, False, 1.0), ("int4", 64, True, False, 0.9),
                                                  ("int8", 128, True, True, 1.0), ("uint8", 32, True, False, 0.75),
                                                  ("uint4", 128, True, False, 1.0), ("int8", 32, False, True, 0.5),
