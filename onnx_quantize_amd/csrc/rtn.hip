@@ -1381,7 +1381,14 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             // every Llama width but the multiples of 16384 (4096: 18.0 -> 17.2 us, 11008: 40.1 -> 38.8, 28672: 100.4 -> 96.3,
             // 32000: 122.3 -> 116.4; 16384: 56.9 -> 57.7), eight (4 KB) on rows of 32 KB (8192: 32.3 -> 30.0, 8192 x 8192:
             // 62.4 -> 56.6): scripts/lab_order_sweep.sh, docs/LAB_NOTES_r05.md.  Speed only.
-            a.xg_log2 = tw.xg >= 0 ? static_cast<uint32_t>(tw.xg > 4 ? 4 : tw.xg) : (N % 16384 == 0 ? 0u : (N % 8192 == 0 ? 3u : 1u));
+            // (g = 128; a tile of the g = 64 / 32 builds is 1 / 2 KB wide already: 4096 x 11008 g = 64 43.1 us with one tile, 44.6 with two)
+            {
+                const int want_log2 = N % 16384 == 0 ? 9 : (N % 8192 == 0 ? 12 : 10);      // bytes of a row one XCD owns side by side
+                int tile_log2 = 6;                                                          // 64 * lpr bytes: four strips of 4 * lpr columns
+                for (int l = lpr; l > 1; l >>= 1) ++tile_log2;
+                const int rule = want_log2 > tile_log2 ? want_log2 - tile_log2 : 0;
+                a.xg_log2 = tw.xg >= 0 ? static_cast<uint32_t>(tw.xg > 4 ? 4 : tw.xg) : static_cast<uint32_t>(rule);
+            }
             set_block_order(a);
             const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(wpb * kWave));
             // the 5-waves-per-SIMD build addresses its outputs with 32-bit offsets and needs blocks of <= 4 waves
