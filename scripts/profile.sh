@@ -1,13 +1,15 @@
 #!/bin/bash
-# Round-4 profiles (run on the GPU box through gpurun): every summary that profiles/r04_* is made of.  Kernel traces
-# (--kernel-trace --stats) and PMC passes are separate runs; the program comes directly after `--`.
-#   scripts/profile_r04.sh [rtn] [strategies] [packed] [searches] [awq] [gptq]      (default: all)
+# The round's profiles (run on the GPU box through gpurun): every summary that profiles/rNN_* is made of (rounds 4 and 5; it was
+# scripts/profile_r04.sh).  Kernel traces (--kernel-trace --stats) and PMC passes are separate runs; the program comes
+# directly after `--`.
+#   ROUND=r05 scripts/profile.sh [rtn] [strategies] [packed] [shapes] [searches] [awq] [gptq]      (default: all)
 set -u
-OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r04
+ROUND=${ROUND:-r05}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-WHAT="${*:-rtn strategies packed searches awq gptq}"
+WHAT="${*:-rtn strategies packed shapes searches awq gptq}"
 trace() { rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$1/trace -- "${@:2}" > $OUT/$1.trace.log 2>&1; }
 pmc() { rocprofv3 --pmc $2 --output-format csv -d $OUT/$1/pmc_$2 -- "${@:3}" > $OUT/$1.$2.log 2>&1; }
 for w in $WHAT; do
@@ -21,8 +23,13 @@ for w in $WHAT; do
       P="python3 $R/scripts/quick_strategies.py --reps 100 --shapes 4096x11008,11008x4096"
       trace strategies $P; pmc strategies FETCH_SIZE $P; pmc strategies WRITE_SIZE $P;;
     packed)
-      P="python3 $R/scripts/quick_packed.py"
+      P="python3 $R/scripts/lab_rtn_shapes.py --layout kn_packed4 --qtype int4 --shapes 4096x11008 --reps 100 --trials 1"
       trace packed $P; pmc packed FETCH_SIZE $P; pmc packed WRITE_SIZE $P;;
+    shapes)     # the widths whose block order changed in round 5, blob and [K,N] bytes
+      P="python3 $R/scripts/lab_rtn_shapes.py --layout nbits --shapes 4096x4096,11008x4096,8192x8192,4096x32000 --reps 100 --trials 1"
+      trace shapes_nbits $P
+      P="python3 $R/scripts/lab_rtn_shapes.py --layout kn --shapes 4096x4096,11008x4096 --reps 100 --trials 1"
+      trace shapes_kn $P;;
     searches)
       P="python3 $R/scripts/quick_searches.py"
       trace searches $P;;
