@@ -113,8 +113,13 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
  *     that fails on the device leaves the state undefined.
  *     Concurrency of the ticketed kernels (both entry points): inside a call a workgroup may wait for other workgroups of the
  *     SAME launch, which is safe on its own (see rtn_resident.hip); two such launches running at the same time on one device
- *     (two streams) compete for the CUs their waiting workgroups hold, so issue per-channel / per-tensor / tall-group calls of
- *     one device on one stream.  The fused group kernels (group_size <= 256) never wait and have no such restriction. */
+ *     would compete for the CUs their waiting workgroups hold and could stop each other for good.  The library therefore
+ *     orders them itself: a per-channel / per-tensor / tall-group call issued on another stream than the previous such call of
+ *     the device first makes its stream wait (on the device, never on the host) for an event recorded behind that call, so
+ *     these kernels never overlap whatever streams and threads they come from (a stream that is being captured into a graph
+ *     is left alone: the graph's edges order its kernels).  What the library cannot order are kernels of ANOTHER PROCESS on
+ *     the same GPU: do not run two processes that issue these calls on one device.  The fused group kernels
+ *     (group_size <= 256) never wait and have no such restriction. */
 size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size);
 int32_t oq_rtn_quantize_stateful_f32(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtype,
                                      int32_t strategy, int64_t group_size, int32_t symmetric,

@@ -35,6 +35,7 @@
 #include "oq_common.hpp"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace oq {
 
@@ -964,8 +965,50 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
     return workspace_bytes >= rtn_resident_workspace(K, N, strategy, g);
 }
 
+// Ticketed kernels of one device never overlap.  Their forward-progress arguments count on the workgroups the occupancy
+// query promised for an otherwise free device: two of them launched from different streams could each hold half of the CUs
+// with workgroups that wait for siblings which the other kernel keeps from ever being dispatched (the per-tensor kernel's
+// `go` needs every workgroup of its grid to arrive) -- a hang of the whole GPU, not an error.  So the launches of one device
+// form a chain: a call on another stream than the previous one first makes its stream wait for the event recorded behind
+// that one (a device-side wait; the host never blocks), and every call records the event behind its own kernel.  Calls of
+// one stream are ordered by the stream itself and pay two short host calls.  (Kernels of OTHER processes on the same GPU
+// are out of reach: include/oq_hip.h says so.)
+struct TicketChain {
+    std::mutex m;
+    hipEvent_t ev = nullptr;
+    hipStream_t last = nullptr;
+    bool any = false;
+};
+static TicketChain g_chain[64];
+
+static int32_t rtn_resident_launch(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
+                                   float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state);
+
 int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
                           float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OQ_ERR_LAUNCH, "rtn: no current device");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone)      // inside a graph capture the graph's own edges order the kernels; no foreign event may enter it
+        return rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
+    TicketChain& c = g_chain[dev];
+    std::lock_guard<std::mutex> lock(c.m);      // launch + record are one step of the chain
+    if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) {
+        c.ev = nullptr;
+        return fail(OQ_ERR_LAUNCH, "rtn: cannot create the event that orders ticketed launches");
+    }
+    if (c.any && c.last != s && hipStreamWaitEvent(s, c.ev, 0) != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+    const int32_t st = rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
+    // recorded even when the launch failed half way (the clear launch may be in the stream): the next call then waits for whatever ran
+    if (hipEventRecord(c.ev, s) != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot record the event that orders ticketed launches");
+    c.last = s;
+    c.any = true;
+    return st;
+}
+
+static int32_t rtn_resident_launch(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
+                                   float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
     ResidentArgs a;
     const int tile_rows = strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g, ranges_of(K, N, g));
     a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = K / g; a.chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : tile_rows);

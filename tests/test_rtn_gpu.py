@@ -873,3 +873,46 @@ def test_ticketed_kernels_short_soak():
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak_resident.py"), "5"], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "soak ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+def test_ticketed_calls_from_threads_on_their_own_streams(ops):
+    """Per-tensor / per-channel RTN wait for sibling workgroups of their own launch; two such launches that overlapped on one
+    device could stop each other for good (include/oq_hip.h).  The library chains them through an event (rtn_resident.hip::
+    TicketChain), so threads on their own streams are safe: three threads, 36 calls each over the three ticketed kernels, every
+    result equal to the single-thread one."""
+    import threading
+    import torch
+    rng = np.random.default_rng(99)
+    cases = [((4096, 2048), "int8", "tensor"), ((4096, 1024), "uint8", "channel"), ((8192, 512), "int8", "channel"), ((2048, 4096), "uint8", "tensor")]
+    ws = [dev(rng.standard_normal(shape, dtype=np.float32)) for shape, _, _ in cases]
+    want = []
+    for w, (_, qtype, strategy) in zip(ws, cases):
+        q, s_, z = ops.rtn_quantize(w, qtype, strategy, -1)
+        want.append((q.cpu().numpy().copy(), s_.cpu().numpy().copy(), z.cpu().numpy().copy()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for it in range(9):
+                    for j in range(len(cases)):
+                        i = (j + tid) % len(cases)
+                        q, s_, z = ops.rtn_quantize(ws[i], cases[i][1], cases[i][2], -1)
+                        if it % 3 == 2:        # a host round trip every third lap only: the other laps keep the streams full
+                            stream.synchronize()
+                            if not (np.array_equal(q.cpu().numpy(), want[i][0]) and s_.cpu().numpy().tobytes() == want[i][1].tobytes()
+                                    and np.array_equal(z.cpu().numpy(), want[i][2])):
+                                errors.append((tid, it, i))
+                stream.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a thread is still waiting for the GPU"
+    assert not errors, errors
