@@ -703,6 +703,21 @@ def main() -> None:
         d = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
         pct = [round(d[10], 2), round(d[50], 2), round(d[90], 2)]
 
+    # the same launches, many of them: the driver's 20 steps are 0.8 ms of device time, over before the GPU's clocks have
+    # settled; 400 launches (16 ms) show what a caller that quantizes a model's worth of matrices one by one sees per launch
+    sustained_us = None
+    if world == 1 and not args.no_extras and not args.qparams_only:
+        for i in range(20):
+            step(i)
+        torch.cuda.synchronize()
+        u0, u1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        u0.record()
+        for i in range(400):
+            step(i)
+        u1.record()
+        torch.cuda.synchronize()
+        sustained_us = u0.elapsed_time(u1) * 1e3 / 400
+
     # the other output layout, shorter run, same buffers (reported next to the headline, never as `value`)
     other = "kn" if args.layout == "nbits" else "nbits"
     other_us = None
@@ -949,6 +964,8 @@ def main() -> None:
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "oq::rtn_group_wave<8,true,5>" if args.layout == "nbits" else "oq::rtn_group_fused<16,true,true,true> + oq::transpose_qparams",
                      "launch_us": round(launch_us, 2), "launch_us_p10_p50_p90": pct,
+                     "launch_us_400_launches": None if sustained_us is None else round(sustained_us, 2),
+                     "frac_400_launches": None if sustained_us is None else round(alg / (sustained_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "frac_outputs_streamed": None if streamed_us is None else round(alg / (streamed_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                      "launch_us_outputs_streamed": None if streamed_us is None else round(streamed_us, 2),
                      "outputs_streamed": None if streamed_us is None else {

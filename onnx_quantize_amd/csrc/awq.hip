@@ -235,12 +235,25 @@ __global__ __launch_bounds__(256) void awq_diff4_kernel(const float* __restrict_
 // through LDS) keeps its rows in registers from the load to the difference.  Same arithmetic in the same order as the
 // separate kernels (fp32 product w s, utils.py R1 / Q1 / K1 through the helpers of oq_common.hpp, (q - zp) * scale, / s,
 // w - .): the D it writes is theirs bit for bit.
+//
+// PIECES (round 5): the difference leaves the kernel as what the loss product reads -- the FIRST fp16 pieces of D in the
+// GEMM's operand layout (gemm_tn.hpp: rows 8c .. 8c + 7 of a column are one 16-byte vector; a lane's 16 rows x 4 columns are
+// eight of them, a wave-instruction writes 4 KB in one piece) -- instead of 64 MB of fp32 that a second kernel re-reads to
+// split: no D, no split launch (27 us per candidate on 4096 x 4096), no partial maxima.  The power-of-two scale of the
+// pieces then has to exist BEFORE the differences do: it comes from an upper bound of |D| (awq_bound_kernel) instead of
+// their maximum, which changes nothing but an exponent as long as no piece leaves fp16's normal range -- same mantissas,
+// same products, same loss bits.
+typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2a __attribute__((ext_vector_type(2)));
+template <bool PIECES>
 __global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, int64_t g, QGrid grid, int wpg,
                                                                 const float* __restrict__ row_scale, float* __restrict__ D,
-                                                                float* __restrict__ absmax_partial) {
+                                                                float* __restrict__ absmax_partial, const float* __restrict__ piece_scale,
+                                                                u32x4a* __restrict__ P, int64_t Np) {
     __shared__ float4 s_mn[8][64];
     __shared__ float4 s_mx[8][64];
     __shared__ float s_abs[8];
+    __shared__ u32x4a s_stage[PIECES ? 8 : 1][PIECES ? 256 : 1];      // PIECES: 4 KB per wave, the store transposition below
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
     const int wig = wave % wpg, gib = wave / wpg, gpb = 8 / wpg;
     const int64_t kgroups = K / g, kg = static_cast<int64_t>(blockIdx.y) * gpb + gib;
@@ -310,7 +323,37 @@ __global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __r
             d[i] = wv[i] - w_hat;
             m = nmax(m, fabsf(d[i]));
         }
-        if (col_ok && group_ok) *reinterpret_cast<float4*>(out + r * N) = make_float4(d[0], d[1], d[2], d[3]);
+        if constexpr (PIECES) w[r] = make_float4(d[0], d[1], d[2], d[3]);      // the row's weights are dead: its differences take their place
+        else if (col_ok && group_ok) *reinterpret_cast<float4*>(out + r * N) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if constexpr (PIECES) {
+        const float sc = piece_scale[0];                         // a power of two: the products are exact
+        // A lane holds the vectors of columns 4 l .. 4 l + 3; stored from there a wave-instruction would write 64 pieces of
+        // 16 bytes, 64 bytes apart (measured: the kernel at 60 us instead of 39).  Through 4 KB of LDS per wave, one chunk
+        // at a time, every instruction writes 1 KB in one piece: lane l takes vector 64 j + l.  Written and read by the same
+        // wave only: no barrier (the compiler's own lgkmcnt waits order a wave's LDS accesses).
+        if (!group_ok) return;                                   // uniform per wave; nothing below synchronises
+        u32x4a* const stage = &s_stage[wave][0];
+        u32x4a* o = P + (row0 / 8) * 2 * Np + tile_col0;        // columns past N (inside the padded width) hold zeros
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u32x4a v;
+#pragma unroll
+                for (int rp = 0; rp < 4; ++rp) {
+                    const float4 a = w[8 * c + 2 * rp], b = w[8 * c + 2 * rp + 1];
+                    const float xa = i == 0 ? a.x : i == 1 ? a.y : i == 2 ? a.z : a.w;
+                    const float xb = i == 0 ? b.x : i == 1 ? b.y : i == 2 ? b.z : b.w;
+                    const f16x2a h2 = {static_cast<_Float16>(col_ok ? xa * sc : 0.f), static_cast<_Float16>(col_ok ? xb * sc : 0.f)};
+                    v[rp] = __builtin_bit_cast(uint32_t, h2);
+                }
+                stage[lane * 4 + i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(stage[j * 64 + lane], o + c * 2 * Np + j * 64 + lane);
+        }
+        return;
     }
     if (!(col_ok && group_ok)) m = 0.f;
     m = wave_max(m);
@@ -369,6 +412,24 @@ __global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict
     if (threadIdx.x == 0) out[k] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
 }
 
+// Upper bound of |D| = |w - dequant(quant(w s)) / s| for one candidate, from two K-vectors: inside a group the quantized
+// value lies in the group's range extended to zero (+ half a step), so |w s - w^| <= 2.07 max_{k' in group} |w_k' s_k'| for
+// every element, and dividing by the row's own s_k gives  |D_kn| <= 2.2 max_{k' in group}(rowmax_k' s_k') / min_{k in group} s_k.
+// One wave per group; bound[kg] feeds set_f16x2_scale_from_bounds.
+__global__ __launch_bounds__(64) void awq_bound_kernel(const float* __restrict__ rowmax, const float* __restrict__ row_scale, int64_t g,
+                                                       float* __restrict__ bound) {
+    const int64_t k0 = static_cast<int64_t>(blockIdx.x) * g;
+    float top = 0.f, smin = INFINITY;
+    for (int64_t k = k0 + threadIdx.x; k < k0 + g; k += 64) {
+        const float sk = row_scale != nullptr ? fabsf(row_scale[k]) : 1.0f;
+        top = nmax(top, rowmax[k] * sk);
+        smin = nmin(smin, sk);
+    }
+    top = wave_max(top);
+    smin = -wave_max(-smin);
+    if (threadIdx.x == 0) bound[blockIdx.x] = 2.2f * top / smin;
+}
+
 struct AwqWs {   // carving of the caller's workspace
     char* pieces_x;     // fp16 pieces of X^T (made once)
     char* pieces_d;     // fp16 pieces of D (per candidate)
@@ -383,6 +444,7 @@ struct AwqWs {   // carving of the caller's workspace
     float* colpart;     // [kColChunks, K]
     float* gemm_part;   // [tiles]
     float* diff_part;   // absmax partials of awq_diff_kernel
+    float* rowmax;      // [K] max |w| of every row, once per search (the bound of the fused pieces route)
     char* rtn_ws;
     size_t rtn_ws_bytes;
     // Gram route (T >= kAwqGramRatio K): sum_n ||X d_n||^2 = <D, (X^T X) D>, the K x K Gram matrix made ONCE per search
@@ -414,6 +476,10 @@ static int32_t finish_losses(const float* gemm_part, int n_cand, int64_t T, int6
 #define OQ_AWQ_HI_ONLY 1   /* lab: 0 = the three-product (22-bit) loss of round 3 */
 #endif
 constexpr bool kAwqHiPiecesOnly = OQ_AWQ_HI_ONLY != 0;
+#ifndef OQ_AWQ_FUSED_PIECES
+#define OQ_AWQ_FUSED_PIECES 1   /* lab: 0 = D in fp32 + the split launch of round 4 */
+#endif
+constexpr bool kAwqFusedPieces = OQ_AWQ_FUSED_PIECES != 0;
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 static int64_t diff_blocks(int64_t K, int64_t N) { return ceil_div(N, 256) * ceil_div(K, 8); }
@@ -439,6 +505,7 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
     char* colpart = take(static_cast<size_t>(kColChunks) * K * 4);
     char* gpart = take(static_cast<size_t>(kAwqMaxGrid) * loss_stride(T, K, N) * 4 + 1024);   // every candidate its own partial sums
     char* dpart = take(static_cast<size_t>(diff_blocks(K, N)) * 4 + 1024);
+    char* rmax = take(static_cast<size_t>(K) * 4 + 256);
     const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) + oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
     char* rtn = take(rtn_bytes);
     if (w) {
@@ -446,6 +513,7 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
         w->q = reinterpret_cast<uint8_t*>(q); w->qscale = reinterpret_cast<float*>(qs); w->qzp = reinterpret_cast<uint8_t*>(qz);
         w->act = reinterpret_cast<float*>(act); w->wsc = reinterpret_cast<float*>(wsc); w->gmax = reinterpret_cast<float*>(gmax);
         w->colpart = reinterpret_cast<float*>(colpart); w->gemm_part = reinterpret_cast<float*>(gpart); w->diff_part = reinterpret_cast<float*>(dpart);
+        w->rowmax = reinterpret_cast<float*>(rmax);
         w->rtn_ws = rtn; w->rtn_ws_bytes = rtn_bytes;
         w->gram = gram; w->G = reinterpret_cast<float*>(G); w->pieces_g = pg; w->hess_ws = hws; w->hess_ws_bytes = hess_bytes;
     }
@@ -457,6 +525,12 @@ static int32_t param_index(int32_t strategy, int64_t K, int64_t g, ParamIndex* p
     else if (strategy == OQ_CHANNEL) *pi = ParamIndex{1, 0, 1};
     else *pi = ParamIndex{g, 1, K / g};   // rtn.py:98-109: entry n * (K / g) + kg
     return OQ_OK;
+}
+
+// the fused route of candidate_loss: direct product (the Gram route reads D itself in its epilogue), first pieces only, and a
+// contraction length that fills its last stage (no zero chunks to write behind the rows)
+static bool pieces_route(const AwqWs& w, int64_t K) {
+    return kAwqFusedPieces && kAwqHiPiecesOnly && !w.gram && gemm_f16x3_chunks(K) * 8 == K;
 }
 
 // one candidate: quantize `Wq` (the weights as the candidate sees them), D = W - dequant (/ s), loss -> loss_out
@@ -472,7 +546,21 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
         if (st != OQ_OK) return st;
         const int wpg = static_cast<int>(g / 16), gpb = 8 / wpg;
         const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K / g, gpb)));
-        hipLaunchKernelGGL(awq_group_diff_kernel, dgrid, dim3(512), 0, s, W, K, N, ldw, g, grid, wpg, row_scale, w.D, w.diff_part);
+        if (pieces_route(w, K)) {
+            // the first pieces of D straight from the quantize-residual kernel (see it); their scale from a bound of |D|
+            hipLaunchKernelGGL(awq_bound_kernel, dim3(static_cast<uint32_t>(K / g)), dim3(64), 0, s, w.rowmax, row_scale, g, w.diff_part);
+            st = set_f16x2_scale_from_bounds(w.diff_part, static_cast<int>(K / g), w.pieces_d, s);
+            if (st != OQ_OK) return st;
+            hipLaunchKernelGGL(awq_group_diff_kernel<true>, dgrid, dim3(512), 0, s, W, K, N, ldw, g, grid, wpg, row_scale, static_cast<float*>(nullptr),
+                               static_cast<float*>(nullptr), reinterpret_cast<const float*>(w.pieces_d),
+                               reinterpret_cast<u32x4a*>(w.pieces_d + gemm_f16x3_header_bytes()), gemm_f16x3_padded_cols(N));
+            st = check_launch("awq_group_diff_kernel (pieces)");
+            if (st != OQ_OK) return st;
+            float* part = w.gemm_part + static_cast<int64_t>(candidate) * loss_stride(T, K, N);
+            return launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, part, s, kAwqHiPiecesOnly);
+        }
+        hipLaunchKernelGGL(awq_group_diff_kernel<false>, dgrid, dim3(512), 0, s, W, K, N, ldw, g, grid, wpg, row_scale, w.D, w.diff_part,
+                           static_cast<const float*>(nullptr), static_cast<u32x4a*>(nullptr), static_cast<int64_t>(0));
         nparts = static_cast<int>(dgrid.x * dgrid.y);
     } else {
         const float* Wq = W;
@@ -584,6 +672,7 @@ int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ld
     if (st != OQ_OK) return st;
     st = prepare_activations(w, X, T, K, ldx, stream, s);
     if (st != OQ_OK) return st;
+    if (pieces_route(w, K)) hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, w.rowmax);
     for (int i = 0; i < n_grid; ++i) {
         const float* si = scales_out + static_cast<int64_t>(i) * K;
         st = candidate_loss(w, W, ldw, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, i, s);
@@ -610,6 +699,7 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
     awq_workspace(T, K, N, &w, static_cast<char*>(workspace));
     st = prepare_activations(w, X, T, K, ldx, stream, s);
     if (st != OQ_OK) return st;
+    if (pieces_route(w, K)) hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, w.rowmax);
     for (int i = 0; i < 10; ++i) {
         const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227
         st = candidate_loss(w, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, i, s);

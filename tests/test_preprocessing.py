@@ -87,6 +87,28 @@ def test_gpu_awq_searches_follow_the_oracle(qtype, strategy, g, sym):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("t,k,n,qtype,g", [(300, 512, 1000, "uint4", 64), (96, 256, 260, "int8", 128), (640, 1024, 768, "uint4", 16), (200, 176, 512, "uint4", 16)])
+def test_gpu_awq_searches_on_the_fused_pieces_route_follow_the_oracle(t, k, n, qtype, g):
+    """Round 5: with groups of 16-128 rows the quantize-residual kernel writes the loss product's first fp16 pieces itself
+    (awq.hip: no fp32 D, no split launch), scaled by an upper BOUND of |D| instead of its maximum.  Widths that are not a
+    multiple of the 256-column tile (zero-filled padding of the pieces), outlier channels (a loose bound: candidate scales that
+    span two orders of magnitude inside a group) and K = 176 (not a whole number of stages: the unfused route) -- same bars."""
+    from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search
+    x, w = _inputs(5 + n, t, k, n)
+    x[..., ::29] *= 80.0
+    es, el = O.awq_scale_search(x, w, qtype, "group", g)
+    s, l = awq_scale_search(x, w, QuantType.from_string(qtype), "group", g)
+    np.testing.assert_allclose(l, el, rtol=2e-3)
+    assert el[int(np.argmin(l))] <= el.min() * (1 + 2e-3)
+    if int(np.argmin(l)) == int(np.argmin(el)):
+        np.testing.assert_allclose(s, es, rtol=1e-5)
+    er, ecl = O.awq_clip_search(x, w, qtype, "group", g)
+    r, cl = awq_clip_search(x, w, QuantType.from_string(qtype), "group", g)
+    np.testing.assert_allclose(cl, ecl, rtol=2e-3)
+    assert ecl[int(round((1 - r) * 100))] <= ecl.min() * (1 + 2e-3)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("t,k,n,qtype,strategy,g", [(2048, 256, 192, "uint4", "group", 32), (8192, 1024, 516, "uint4", "group", 128),
                                                     (6144, 1024, 256, "int8", "channel", -1), (1024, 128, 64, "uint8", "tensor", -1)])
 def test_gpu_awq_searches_with_long_calibration_sets_follow_the_oracle(t, k, n, qtype, strategy, g):
