@@ -441,7 +441,7 @@ def awq_bench(dev, k: int = 4096, n: int = 4096, t: int = 4096) -> dict:
     ref_l = float((dl * (g64 @ dl)).sum() / (tl * n))
     ok_l = abs(float(losses_l.min()) - ref_l) <= 2e-3 * ref_l
     return {"what": "AWQ scale search (20 candidates) and clip search (10 ratios) of one 4096 x 4096 layer with 4096 calibration rows, uint4 g128, "
-                    "device resident; round 2 (torch elementwise + rocBLAS): 23.4 / 11.2 ms; round 3 (22-bit loss product): 7.7 / 3.6 ms",
+                    "device resident; round 2 (torch elementwise + rocBLAS): 23.4 / 11.2 ms; round 3 (22-bit loss product): 7.7 / 3.6 ms; round 4 (first pieces only, fused residual kernel): 3.7 / 1.8 ms; round 5: the residual kernel writes the product's fp16 pieces itself",
             "scale_search_ms": round(ms_scale, 3), "clip_search_ms": round(ms_clip, 3), "best_grid_point": i, "best_clip_ratio": best_ratio,
             "loss_at_best": float(losses[i]), "loss_float64_check_rows": 1024, "loss_float64": ref2, "loss_kernel": float(sub[1].min()),
             "long_calibration_set": {"rows": tl, "route": "gram: X^T X once (Hessian kernels), <D, G D> per candidate", "scale_search_ms": round(ms_scale_l, 3),
