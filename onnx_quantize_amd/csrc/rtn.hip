@@ -1274,7 +1274,12 @@ int32_t launch_quantize_kn(const float* W, int64_t K, int64_t N, int64_t ldw, in
 // of large matrices lose a little again (dirty output lines evicted between another matrix' reads instead of written back
 // in a burst at a kernel's end).  ~1.6e8 parameters per launch sits at or next to the best point of every row.
 static int64_t matrices_per_launch(int64_t K, int64_t N, int64_t count) {
-    int64_t m = 160000000 / (K * N);
+    static const int64_t per_launch = [] {      // OQ_RTN_MPL: parameters per launch in millions (lab; speed only)
+        const char* v = getenv("OQ_RTN_MPL");
+        const long x = v ? atol(v) : 0;
+        return x > 0 ? static_cast<int64_t>(x) * 1000000 : static_cast<int64_t>(160000000);
+    }();
+    int64_t m = per_launch / (K * N);
     if (m > 65535) m = 65535;   // blockIdx.y
     if (m < 1) m = 1;
     return m < count ? m : count;
