@@ -969,9 +969,9 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
 // query promised for an otherwise free device: two of them launched from different streams could each hold half of the CUs
 // with workgroups that wait for siblings which the other kernel keeps from ever being dispatched (the per-tensor kernel's
 // `go` needs every workgroup of its grid to arrive) -- a hang of the whole GPU, not an error.  So the launches of one device
-// form a chain: a call on another stream than the previous one first makes its stream wait for the event recorded behind
-// that one (a device-side wait; the host never blocks), and every call records the event behind its own kernel.  Calls of
-// one stream are ordered by the stream itself and pay two short host calls.  (Kernels of OTHER processes on the same GPU
+// form a chain: a call on another stream than the previous one records an event behind what that stream has queued and
+// makes its own stream wait for it (a device-side wait; the host never blocks).  Calls of one stream are ordered by the
+// stream itself and pay a capture query and a mutex.  (Kernels of OTHER processes on the same GPU
 // are out of reach: include/oq_hip.h says so.)
 struct TicketChain {
     std::mutex m;
@@ -990,6 +990,9 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OQ_ERR_LAUNCH, "rtn: no current device");
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+#ifdef OQ_NO_TICKET_CHAIN      /* lab: what the chain costs a single stream */
+    cap = hipStreamCaptureStatusActive;
+#endif
     if (cap != hipStreamCaptureStatusNone)      // inside a graph capture the graph's own edges order the kernels; no foreign event may enter it
         return rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
     TicketChain& c = g_chain[dev];
@@ -998,11 +1001,19 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
         c.ev = nullptr;
         return fail(OQ_ERR_LAUNCH, "rtn: cannot create the event that orders ticketed launches");
     }
-    if (c.any && c.last != s && hipStreamWaitEvent(s, c.ev, 0) != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+    if (c.any && c.last != s) {
+        // The event is recorded only NOW, behind whatever the previous stream has queued so far (its last ticketed kernel is
+        // in there): recorded behind every launch it cost 2.5-3.5 us per call of a single stream (62.7 -> 66.2 us per
+        // channel call on 4096 x 11008), which pays nothing this way.
+        if (hipEventRecord(c.ev, c.last) != hipSuccess) {
+            (void)hipGetLastError();                          // the previous stream is gone: nothing of it may still run when we go on
+            if (hipDeviceSynchronize() != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+        } else if (hipStreamWaitEvent(s, c.ev, 0) != hipSuccess) {
+            return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+        }
+    }
     const int32_t st = rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
-    // recorded even when the launch failed half way (the clear launch may be in the stream): the next call then waits for whatever ran
-    if (hipEventRecord(c.ev, s) != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot record the event that orders ticketed launches");
-    c.last = s;
+    c.last = s;       // also after a launch that failed half way (its clear launch may be in the stream)
     c.any = true;
     return st;
 }
