@@ -249,7 +249,7 @@ template <bool PIECES>
 __global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, int64_t g, QGrid grid, int wpg,
                                                                 const float* __restrict__ row_scale, float* __restrict__ D,
                                                                 float* __restrict__ absmax_partial, const float* __restrict__ piece_scale,
-                                                                u32x4a* __restrict__ P, int64_t Np) {
+                                                                float* __restrict__ piece_header, u32x4a* __restrict__ P, int64_t Np) {
     __shared__ float4 s_mn[8][64];
     __shared__ float4 s_mx[8][64];
     __shared__ float s_abs[8];
@@ -328,6 +328,9 @@ __global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __r
     }
     if constexpr (PIECES) {
         const float sc = piece_scale[0];                         // a power of two: the products are exact
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {      // the product behind this launch reads its operand's scale from the header
+            piece_header[0] = piece_scale[0]; piece_header[1] = piece_scale[1]; piece_header[2] = piece_scale[2];
+        }
         // A lane holds the vectors of columns 4 l .. 4 l + 3; stored from there a wave-instruction would write 64 pieces of
         // 16 bytes, 64 bytes apart (measured: the kernel at 60 us instead of 39).  Through 4 KB of LDS per wave, one chunk
         // at a time, every instruction writes 1 KB in one piece: lane l takes vector 64 j + l.  Written and read by the same
@@ -412,12 +415,16 @@ __global__ __launch_bounds__(256) void row_absmax_kernel(const float* __restrict
     if (threadIdx.x == 0) out[k] = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
 }
 
-// Upper bound of |D| = |w - dequant(quant(w s)) / s| for one candidate, from two K-vectors: inside a group the quantized
+// Upper bound of |D| = |w - dequant(quant(w s)) / s| for a candidate, from two K-vectors: inside a group the quantized
 // value lies in the group's range extended to zero (+ half a step), so |w s - w^| <= 2.07 max_{k' in group} |w_k' s_k'| for
 // every element, and dividing by the row's own s_k gives  |D_kn| <= 2.2 max_{k' in group}(rowmax_k' s_k') / min_{k in group} s_k.
-// One wave per group; bound[kg] feeds set_f16x2_scale_from_bounds.
-__global__ __launch_bounds__(64) void awq_bound_kernel(const float* __restrict__ rowmax, const float* __restrict__ row_scale, int64_t g,
+// ALL candidates of a search in two launches ahead of the loop (a tiny kernel costs ~5 us of launch each, twice per
+// candidate that was 6 % of the search): blockIdx.y = candidate (row scales at row_scales + y * K; nullptr: the clip
+// search, whose ten candidates share one bound), one wave per group, then one block per candidate folds the groups into
+// the pieces' scale triple [s, 1 / s^2, 1 / s] (the form of syrk_bf16x3.hip::absmax_scale_body).
+__global__ __launch_bounds__(64) void awq_bound_kernel(const float* __restrict__ rowmax, const float* __restrict__ row_scales, int64_t K, int64_t g,
                                                        float* __restrict__ bound) {
+    const float* row_scale = row_scales != nullptr ? row_scales + static_cast<int64_t>(blockIdx.y) * K : nullptr;
     const int64_t k0 = static_cast<int64_t>(blockIdx.x) * g;
     float top = 0.f, smin = INFINITY;
     for (int64_t k = k0 + threadIdx.x; k < k0 + g; k += 64) {
@@ -427,7 +434,31 @@ __global__ __launch_bounds__(64) void awq_bound_kernel(const float* __restrict__
     }
     top = wave_max(top);
     smin = -wave_max(-smin);
-    if (threadIdx.x == 0) bound[blockIdx.x] = 2.2f * top / smin;
+    if (threadIdx.x == 0) bound[static_cast<int64_t>(blockIdx.y) * gridDim.x + blockIdx.x] = 2.2f * top / smin;
+}
+
+__global__ __launch_bounds__(256) void awq_piece_scales_kernel(const float* __restrict__ bound, const int ngroups, float* __restrict__ triples) {
+    __shared__ float sm[4];
+    const float* b = bound + static_cast<int64_t>(blockIdx.x) * ngroups;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < ngroups; i += 256) m = nmax(m, b[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = nmax(nmax(sm[0], sm[1]), nmax(sm[2], sm[3]));
+        int ex = 0;
+        float sc = 1.0f, inv2 = 1.0f;
+        if (m > 0.0f && m < INFINITY) {
+            (void)frexpf(m, &ex);                      // m = f * 2^ex, f in [0.5, 1): s m < 2^15
+            int e = 15 - ex;
+            e = e > 60 ? 60 : (e < -60 ? -60 : e);     // 1 / s^2 must stay a normal float
+            sc = ldexpf(1.0f, e);
+            inv2 = ldexpf(1.0f, -2 * e);
+        }
+        float* t = triples + 4 * blockIdx.x;
+        t[0] = sc; t[1] = inv2; t[2] = 1.0f / sc; t[3] = 0.f;
+    }
 }
 
 struct AwqWs {   // carving of the caller's workspace
@@ -445,6 +476,8 @@ struct AwqWs {   // carving of the caller's workspace
     float* gemm_part;   // [tiles]
     float* diff_part;   // absmax partials of awq_diff_kernel
     float* rowmax;      // [K] max |w| of every row, once per search (the bound of the fused pieces route)
+    float* bounds;      // [candidates][K / g] bounds of |D|, and
+    float* triples;     // [candidates][4] the pieces' scale triples made from them, once per search
     char* rtn_ws;
     size_t rtn_ws_bytes;
     // Gram route (T >= kAwqGramRatio K): sum_n ||X d_n||^2 = <D, (X^T X) D>, the K x K Gram matrix made ONCE per search
@@ -506,6 +539,8 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
     char* gpart = take(static_cast<size_t>(kAwqMaxGrid) * loss_stride(T, K, N) * 4 + 1024);   // every candidate its own partial sums
     char* dpart = take(static_cast<size_t>(diff_blocks(K, N)) * 4 + 1024);
     char* rmax = take(static_cast<size_t>(K) * 4 + 256);
+    char* bnd = take(static_cast<size_t>(kAwqMaxGrid) * (K / 16 + 1) * 4 + 256);
+    char* trp = take(static_cast<size_t>(kAwqMaxGrid) * 16 + 256);
     const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) + oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
     char* rtn = take(rtn_bytes);
     if (w) {
@@ -513,7 +548,7 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
         w->q = reinterpret_cast<uint8_t*>(q); w->qscale = reinterpret_cast<float*>(qs); w->qzp = reinterpret_cast<uint8_t*>(qz);
         w->act = reinterpret_cast<float*>(act); w->wsc = reinterpret_cast<float*>(wsc); w->gmax = reinterpret_cast<float*>(gmax);
         w->colpart = reinterpret_cast<float*>(colpart); w->gemm_part = reinterpret_cast<float*>(gpart); w->diff_part = reinterpret_cast<float*>(dpart);
-        w->rowmax = reinterpret_cast<float*>(rmax);
+        w->rowmax = reinterpret_cast<float*>(rmax); w->bounds = reinterpret_cast<float*>(bnd); w->triples = reinterpret_cast<float*>(trp);
         w->rtn_ws = rtn; w->rtn_ws_bytes = rtn_bytes;
         w->gram = gram; w->G = reinterpret_cast<float*>(G); w->pieces_g = pg; w->hess_ws = hws; w->hess_ws_bytes = hess_bytes;
     }
@@ -529,8 +564,21 @@ static int32_t param_index(int32_t strategy, int64_t K, int64_t g, ParamIndex* p
 
 // the fused route of candidate_loss: direct product (the Gram route reads D itself in its epilogue), first pieces only, and a
 // contraction length that fills its last stage (no zero chunks to write behind the rows)
+static bool group_fused(int32_t strategy, int64_t g, int64_t K, int64_t N, int64_t ldw, const float* W) {      // the fused quantize-residual kernel takes the candidate
+    return N % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0 && strategy == OQ_GROUP && (g == 16 || g == 32 || g == 64 || g == 128) && K % g == 0;
+}
 static bool pieces_route(const AwqWs& w, int64_t K) {
     return kAwqFusedPieces && kAwqHiPiecesOnly && !w.gram && gemm_f16x3_chunks(K) * 8 == K;
+}
+
+// once per search, fused route: row maxima of W, the bounds and the pieces' scales of all candidates (three launches)
+static int32_t prepare_piece_scales(const AwqWs& w, const float* W, int64_t K, int64_t N, int64_t ldw, int64_t g, const float* row_scales, int n_cand,
+                                    hipStream_t s) {
+    hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, w.rowmax);
+    const int nc = row_scales != nullptr ? n_cand : 1;
+    hipLaunchKernelGGL(awq_bound_kernel, dim3(static_cast<uint32_t>(K / g), static_cast<uint32_t>(nc)), dim3(64), 0, s, w.rowmax, row_scales, K, g, w.bounds);
+    hipLaunchKernelGGL(awq_piece_scales_kernel, dim3(static_cast<uint32_t>(nc)), dim3(256), 0, s, w.bounds, static_cast<int>(K / g), w.triples);
+    return check_launch("awq piece scales");
 }
 
 // one candidate: quantize `Wq` (the weights as the candidate sees them), D = W - dequant (/ s), loss -> loss_out
@@ -548,11 +596,9 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
         const dim3 dgrid(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(ceil_div(K / g, gpb)));
         if (pieces_route(w, K)) {
             // the first pieces of D straight from the quantize-residual kernel (see it); their scale from a bound of |D|
-            hipLaunchKernelGGL(awq_bound_kernel, dim3(static_cast<uint32_t>(K / g)), dim3(64), 0, s, w.rowmax, row_scale, g, w.diff_part);
-            st = set_f16x2_scale_from_bounds(w.diff_part, static_cast<int>(K / g), w.pieces_d, s);
-            if (st != OQ_OK) return st;
+            // (prepare_piece_scales: all candidates ahead of the loop)
             hipLaunchKernelGGL(awq_group_diff_kernel<true>, dgrid, dim3(512), 0, s, W, K, N, ldw, g, grid, wpg, row_scale, static_cast<float*>(nullptr),
-                               static_cast<float*>(nullptr), reinterpret_cast<const float*>(w.pieces_d),
+                               static_cast<float*>(nullptr), w.triples + 4 * (row_scale != nullptr ? candidate : 0), reinterpret_cast<float*>(w.pieces_d),
                                reinterpret_cast<u32x4a*>(w.pieces_d + gemm_f16x3_header_bytes()), gemm_f16x3_padded_cols(N));
             st = check_launch("awq_group_diff_kernel (pieces)");
             if (st != OQ_OK) return st;
@@ -560,7 +606,7 @@ static int32_t candidate_loss(const AwqWs& w, const float* W, int64_t ldw, const
             return launch_gemm_f16x3(w.pieces_x, w.pieces_d, T, N, K, 1.0f, 0.0f, nullptr, 0, part, s, kAwqHiPiecesOnly);
         }
         hipLaunchKernelGGL(awq_group_diff_kernel<false>, dgrid, dim3(512), 0, s, W, K, N, ldw, g, grid, wpg, row_scale, w.D, w.diff_part,
-                           static_cast<const float*>(nullptr), static_cast<u32x4a*>(nullptr), static_cast<int64_t>(0));
+                           static_cast<const float*>(nullptr), static_cast<float*>(nullptr), static_cast<u32x4a*>(nullptr), static_cast<int64_t>(0));
         nparts = static_cast<int>(dgrid.x * dgrid.y);
     } else {
         const float* Wq = W;
@@ -672,7 +718,10 @@ int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ld
     if (st != OQ_OK) return st;
     st = prepare_activations(w, X, T, K, ldx, stream, s);
     if (st != OQ_OK) return st;
-    if (pieces_route(w, K)) hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, w.rowmax);
+    if (pieces_route(w, K) && group_fused(strategy, g, K, N, ldw, W)) {
+        st = prepare_piece_scales(w, W, K, N, ldw, g, scales_out, n_grid, s);
+        if (st != OQ_OK) return st;
+    }
     for (int i = 0; i < n_grid; ++i) {
         const float* si = scales_out + static_cast<int64_t>(i) * K;
         st = candidate_loss(w, W, ldw, si, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, i, s);
@@ -699,7 +748,10 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
     awq_workspace(T, K, N, &w, static_cast<char*>(workspace));
     st = prepare_activations(w, X, T, K, ldx, stream, s);
     if (st != OQ_OK) return st;
-    if (pieces_route(w, K)) hipLaunchKernelGGL(row_absmax_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, w.rowmax);
+    if (pieces_route(w, K) && group_fused(strategy, g, K, N, ldw, W)) {
+        st = prepare_piece_scales(w, W, K, N, ldw, g, nullptr, 10, s);
+        if (st != OQ_OK) return st;
+    }
     for (int i = 0; i < 10; ++i) {
         const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227
         st = candidate_loss(w, W, ldw, nullptr, T, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, i, s);

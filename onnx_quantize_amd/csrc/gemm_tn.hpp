@@ -125,13 +125,12 @@ int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx,
 // fp32 matrix to make_f16x2_pieces* (awq.hip: the quantize-residual kernel, round 5).  The eight fp16 of rows 8c .. 8c + 7 of
 // column n (k ascending, each fl16(x * s), round to nearest even) are the 16-byte vector
 //     P[(2 c) * gemm_f16x3_padded_cols(cols) + n],   P = pieces + gemm_f16x3_header_bytes();
-// columns from `cols` to the padded width and chunks from ceil(Kd / 8) to gemm_f16x3_chunks(Kd) must hold zeros.  s = header[0]
-// is set by set_f16x2_scale_from_bounds from `npart` upper bounds of |x| on the device (any bound works: a power of two that
-// maps it below 2^16; fp16 keeps its 11 bits over 29 binades below that).
+// columns from `cols` to the padded width and chunks from ceil(Kd / 8) to gemm_f16x3_chunks(Kd) must hold zeros.  The
+// producer also writes the header's first three floats [s, 1 / s^2, 1 / s] with s a power of two that maps an upper bound of
+// |x| below 2^15 (any bound works: fp16 keeps its 11 bits over 29 binades below that).
 size_t gemm_f16x3_header_bytes();
 int64_t gemm_f16x3_padded_cols(int64_t cols);
 int64_t gemm_f16x3_chunks(int64_t Kd);
-int32_t set_f16x2_scale_from_bounds(const float* bounds, int npart, void* pieces, hipStream_t s);
 int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols, int64_t ldx, const float* absmax_partials, int npart, void* pieces,
                                         hipStream_t s, bool first_pieces_only = false);   // true: the lo plane is left untouched (consumers that read first pieces only)   // [Kd, cols] row-major source whose max |x| is already folded into `npart` device partials
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,

@@ -1424,12 +1424,6 @@ int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols
 size_t gemm_f16x3_header_bytes() { return kScaleHeaderBytes; }
 int64_t gemm_f16x3_padded_cols(int64_t cols) { return padded_k(cols); }
 int64_t gemm_f16x3_chunks(int64_t Kd) { return stages_of(Kd, StageGeom<3>::ROWS) * StageGeom<3>::CH; }
-int32_t set_f16x2_scale_from_bounds(const float* bounds, int npart, void* pieces, hipStream_t s) {
-    OQ_REQUIRE(bounds && pieces && npart > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT, "set_f16x2_scale_from_bounds: bad argument");
-    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, bounds, npart, static_cast<float*>(pieces));
-    return check_launch("absmax_scale_kernel (bounds)");
-}
-
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
                           int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only, bool dot_with_c, bool b_first_piece_only) {
     OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && ((C != nullptr) != (loss_partial != nullptr) || dot_with_c), OQ_ERR_INVALID_ARGUMENT,
