@@ -630,9 +630,13 @@ def test_random_configurations_against_the_oracle():
     """Property test (hypothesis, fixed seed): random shapes, types, strategies, group sizes, symmetric / reduce_range /
     clip_ratio, value distributions with planted zeros, ties and huge / tiny magnitudes -- every output of
     `ops.rtn_quantize` (both layouts where the blob applies) equals the oracle's bit for bit."""
+    import os
     import torch
     from hypothesis import HealthCheck, given, seed, settings, strategies as st
     from onnx_quantize_amd.hip import ops
+    # a longer walk on request (a GPU box with minutes to spare): OQ_TEST_FUZZ_EXAMPLES=5000 OQ_TEST_FUZZ_WIDE=1 [OQ_TEST_FUZZ_SEED=n]
+    fuzz_examples = int(os.environ.get("OQ_TEST_FUZZ_EXAMPLES", "300"))
+    fuzz_wide = os.environ.get("OQ_TEST_FUZZ_WIDE", "0") == "1"
 
     @st.composite
     def case(draw):
@@ -644,6 +648,9 @@ def test_random_configurations_against_the_oracle():
         else:
             g, k = -1, draw(st.integers(1, 400))
         n = draw(st.integers(1, 300))
+        if fuzz_wide and draw(st.integers(0, 3)) == 0:      # OQ_TEST_FUZZ_WIDE=1: widths where the block-order rules of rtn.hip switch
+            n = draw(st.sampled_from([2048, 4096, 4100, 4224, 8192, 8196, 12288, 16384, 16388])) + draw(st.sampled_from([0, 0, 4, 128]))
+            k = min(k, 2 * g) if strategy == "group" else min(k, 64)
         sym, red = draw(st.booleans()), draw(st.booleans())
         clip = draw(st.sampled_from([1.0, 0.9, 0.5, 0.999]))
         kind = draw(st.sampled_from(["normal", "wide", "tiny", "ties", "zeros", "positive"]))
@@ -665,8 +672,8 @@ def test_random_configurations_against_the_oracle():
             w = np.abs(w) + 1
         return w
 
-    @seed(20240601)
-    @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+    @seed(20240601 if fuzz_examples == 300 else int(os.environ.get("OQ_TEST_FUZZ_SEED", "1")))
+    @settings(max_examples=fuzz_examples, deadline=None, suppress_health_check=list(HealthCheck))
     @given(case())
     def run(c):
         qtype, strategy, g, k, n, sym, red, clip, kind, rs = c
