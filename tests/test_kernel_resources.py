@@ -96,9 +96,12 @@ def test_resident_rtn_kernels_keep_their_tiles_in_registers(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("source,kernels", [("rtn_mse.hip", ("mse_rows_reg_kernel",)), ("hqq.hip", ("hqq_rounds_reg_kernel",))])
+@pytest.mark.parametrize("source,kernels", [("rtn_mse.hip", ("mse_rows_reg_kernel",)), ("hqq.hip", ("hqq_rounds_reg_kernel",)),
+                                            ("awq.hip", ("awq_group_diff_kernel",))])
 def test_register_tile_search_kernels_do_not_spill(tmp_path, source, kernels):
-    """The MSE and HQQ searches hold a group's G values in registers across all candidates / rounds.  Left to itself the
+    """(awq.hip: the quantize-residual kernel keeps a block's rows in registers from the load to the difference and, since round 5,
+    through the packing of the loss product's fp16 pieces.)
+    The MSE and HQQ searches hold a group's G values in registers across all candidates / rounds.  Left to itself the
     optimiser interleaves independent chunks until the G = 128 tile spills (1.1 KB of scratch per lane and 3x the time, with
     every parity test still green): the chunks are chained through opaque copies and this test watches the result."""
     from onnx_quantize_amd import _build
