@@ -1421,7 +1421,18 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         const int64_t batch = g_batch.count;
         a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups; a.table = g_batch.table;
         static const Tuning tune_s = Tuning::from_env();
-        const bool want_stage = tune_s.stage >= 0 ? tune_s.stage != 0 : layout != OQ_LAYOUT_NBITS;
+        // [K,N] layouts: the n-major parameters either leave the kernel as they are (4-byte stores 128 bytes apart) or are
+        // staged [K/g, N] and transposed by a second launch (~5 us of kernel + a boundary, whatever the size).  Rounds 1-4
+        // staged always -- tuned on 4096 x 11008, the one Llama width where that is right: its 43 column tiles are odd, so
+        // with column-fastest ids the k-groups of a column run on eight different XCDs and their 4-byte pieces of a line
+        // never meet in one L2.  Round 5 (scripts/lab_knob_sweep.sh, STAGE=0, [K,N] bytes, K = 4096): N = 256 11.6 -> 8.5 us,
+        // 2048 15.0 -> 11.6, 4096 22.4 -> 19.3, 5120 25.7 -> 23.7, 8192 35.0 -> 32.2, 11264 45.4 -> 43.6, 14336 54.4 -> 51.9,
+        // 28672 101.6 -> 99.5; 11008 44.8 -> 46.6, 27648 98.1 -> 100.1, 32000 112.4 -> 124.3.  Direct when the column tiles
+        // are a multiple of eight (every k-group of a column on one XCD), or the parameters are few enough for the fixed
+        // cost of the second launch to dominate.  Speed only.
+        const int64_t nct = ceil_div(N, kColsPerWave), nparams = kgroups * N;
+        const bool direct = nct % 8 == 0 || nparams <= (256 << 10) || (nct % 2 == 0 && nparams <= (512 << 10));
+        const bool want_stage = tune_s.stage >= 0 ? tune_s.stage != 0 : (layout != OQ_LAYOUT_NBITS && !direct);
         const bool staged = want_stage && vec4 && kgroups > 1 && workspace != nullptr &&
                             workspace_bytes >= static_cast<size_t>(batch) * stage_ws(K, N, g) && (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
         if (staged) {
