@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -334,8 +335,11 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
     state = {"wsb": None, "row": 0}
     made = []
 
-    def run(key, idx):
-        """One C call: check the members, allocate their outputs, write and copy their table rows, launch."""
+    pin_np = pin.numpy()                       # the page-locked rows as a NumPy view: filling them costs microseconds, not torch dispatches
+    cur_dev = torch.cuda.current_device()
+
+    def prepare(key, idx):
+        """Check the members of one C call, allocate their outputs, write their table rows (host side only)."""
         (k, n), _strides = key
         if k == 0 or n == 0:
             raise ValueError(f"rtn_quantize_many: weight {idx[0]} is empty ({k} x {n})")
@@ -343,9 +347,16 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
         if g <= 0 or k % g:
             raise ValueError("rtn_quantize_many needs K % group_size == 0 for every weight")
         mats, ldw = [], None
+        st0 = _strides[0]                         # every member of a call shares shape and strides (the grouping key)
+        plain = _strides[1] == 1 and st0 >= n and k > 1
         for i in idx:
-            _require_device(ws[i], "w", torch.float32)
-            w2, ldw = _row_major(ws[i])
+            w = ws[i]
+            if not (w.is_cuda and w.dtype is torch.float32 and w.device.index == cur_dev):
+                _require_device(w, "w", torch.float32)      # raises with the full message
+            if plain:                              # rows contiguous: the tensor as it is (the per-weight helper calls were a third of
+                w2, ldw = w, st0                   # this function's time on a 126-weight model)
+            else:
+                w2, ldw = _row_major(w)
             mats.append(w2)
         cnt, row = len(idx), state["row"]
         q = _q_buffer(layout, (cnt,), k, n, g, qtype, dev)
@@ -354,25 +365,36 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
         need = lib.oq_rtn_batched_workspace_bytes(cnt, k, n, int(group_size))
         if state["wsb"] is None or state["wsb"].numel() < need:
             state["wsb"] = _workspace(need, dev)     # calls on one stream run in order: a later, larger shape may take a new buffer
-        wsb = state["wsb"]
         # output pointers by arithmetic (the per-matrix views the caller gets back are made AFTER the launches)
-        rows = pin[row:row + cnt]
-        rows[:, 0] = torch.tensor([m.data_ptr() for m in mats], dtype=torch.int64)
-        steps = torch.arange(cnt, dtype=torch.int64)
+        rows = pin_np[row:row + cnt]
+        rows[:, 0] = [m.data_ptr() for m in mats]
+        steps = np.arange(cnt, dtype=np.int64)
         rows[:, 1] = q.data_ptr() + steps * (q[0].numel() * q.element_size())
         rows[:, 2] = sc.data_ptr() + steps * (sc[0].numel() * 4)
         rows[:, 3] = zp.data_ptr() + steps * (zp[0].numel() * zp.element_size())
-        dev_rows = table_dev[row:row + cnt]
-        if cnt > 1:
-            with torch.cuda.stream(side):
-                dev_rows.copy_(rows, non_blocking=True)
-                ready = side.record_event()
-            cur.wait_event(ready)
-        L.check(lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(rows.data_ptr()), C.c_void_p(dev_rows.data_ptr() if cnt > 1 else 0), cnt, k, n, ldw,
-                                             L.QTYPE_CODE[qtype], int(group_size), int(symmetric), int(reduce_range), float(clip_ratio), lay,
-                                             _ptr(wsb), wsb.numel(), _stream()))
         made.append((idx, q, sc, zp, mats))      # operands stay referenced until the views are made
         state["row"] = row + cnt
+        return (k, n, ldw, cnt, row, state["wsb"])
+
+    def upload(row, cnt):
+        """Rows [row, row + cnt) of the table to the device on the side stream; the launch stream waits for them."""
+        with torch.cuda.stream(side):
+            table_dev[row:row + cnt].copy_(pin[row:row + cnt], non_blocking=True)
+            ready = side.record_event()
+        cur.wait_event(ready)
+
+    def launch(call):
+        k, n, ldw, cnt, row, wsb = call
+        L.check(lib.oq_rtn_quantize_ptrs_f32(C.c_void_p(pin[row:row + cnt].data_ptr()), C.c_void_p(table_dev[row:row + cnt].data_ptr() if cnt > 1 else 0), cnt,
+                                             k, n, ldw, L.QTYPE_CODE[qtype], int(group_size), int(symmetric), int(reduce_range), float(clip_ratio), lay,
+                                             _ptr(wsb), wsb.numel(), _stream()))
+
+    def run(key, idx):
+        """One C call: prepare, copy its table rows, launch."""
+        call = prepare(key, idx)
+        if call[3] > 1:
+            upload(call[4], call[3])
+        launch(call)
 
     for w in ws[:1]:
         if not isinstance(w, torch.Tensor) or w.dim() != 2:
@@ -382,6 +404,25 @@ def rtn_quantize_many(ws, qtype: str, group_size: int, symmetric=False, reduce_r
     # most parameters among them: the GPU starts after ~50 us of head.  (2) Group everything else by shape while those
     # kernels run.  (3) Shape by shape, fewest matrices first; the first shape in pieces (4, 8, rest) so that every call is
     # prepared in less time than the kernels in front of it take.
+    # A small model (gemma-3-270m: 126 weights, 1e8 parameters, 0.2 ms of kernels) is bound by this function, not by its kernels:
+    # everything is prepared first, the table goes up in ONE copy and the C calls follow back to back (0.90 -> see the bench's
+    # `model_rtn.small_matrices`).  The interleaving below pays from a few hundred million parameters on.
+    if sum(w.shape[0] * w.shape[1] for w in ws if isinstance(w, torch.Tensor) and w.dim() == 2) < (1 << 29):
+        small: dict = {}
+        for i, w in enumerate(ws):
+            if not isinstance(w, torch.Tensor) or w.dim() != 2:
+                _require_device(w, "w", torch.float32)
+                raise ValueError(f"weights must be 2-D [K, N], got shape {tuple(w.shape)}")
+            small.setdefault(key_of(w), []).append(i)
+        calls = [prepare(key, idx) for key, idx in small.items()]
+        if any(c[3] > 1 for c in calls):
+            upload(0, state["row"])
+        for c in calls:
+            launch(c)
+        for idx, q, sc, zp, _mats in made:
+            for j, i in enumerate(idx):
+                out[i] = (q[j], sc[j], zp[j])
+        return out
     early: dict = {}
     for i, w in enumerate(ws[:24]):
         if not isinstance(w, torch.Tensor) or w.dim() != 2:
