@@ -259,7 +259,10 @@ __global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __r
     const int64_t kgroups = K / g, kg = static_cast<int64_t>(blockIdx.y) * gpb + gib;
     const bool group_ok = kg < kgroups;
     const int64_t row0 = (group_ok ? kg : 0) * g + static_cast<int64_t>(wig) * 16;   // a surplus group re-reads group 0: loads are never predicated
-    const int64_t tile_col0 = static_cast<int64_t>(blockIdx.x) * 256;
+    // the column tile rotates with the row of blocks: with a multiple of eight tiles (N = 4096: 16) an XCD -- linear block id
+    // % 8 -- would otherwise own the same tiles in every row of blocks, a fixed residue of the address inside a row
+    // (docs/LAB_NOTES_r05.md; scale search 3.15-3.32 -> 3.08 ms).  A permutation of the tiles per row of blocks: speed only.
+    const int64_t tile_col0 = static_cast<int64_t>((blockIdx.x + blockIdx.y) % gridDim.x) * 256;
     const bool col_ok = tile_col0 + lane * 4 < N;
     const int64_t lcol = col_ok ? tile_col0 + lane * 4 : N - 4;
     float4 w[16];
