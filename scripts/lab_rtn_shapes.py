@@ -33,7 +33,10 @@ def main():
     ap.add_argument("--g", type=int, default=128)
     ap.add_argument("--reps", type=int, default=300)
     ap.add_argument("--trials", type=int, default=3)
+    ap.add_argument("--lib", default=None, help="lab: another build of liboq_hip.so (scripts/lab_build_variant.sh)")
     args = ap.parse_args()
+    if args.lib:
+        L.LIB_PATH = os.path.abspath(args.lib)
     lib = L.load()
     torch.cuda.set_device(0)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
