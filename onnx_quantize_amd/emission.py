@@ -33,6 +33,9 @@ MS_DOMAIN, MS_VERSION = "com.microsoft", 1           # qfunctions/register.py:6
 class EmissionPlan:
     initializers: list                    # [(name, np.ndarray)] in the order `op.initializer` is called
     call: dict                            # {"name", "inputs": [value names | None], "attrs": {...}, "domain", "version"}
+    # {initializer name: ONNX element type} where the NumPy dtype does not say it: 4-bit values travel in int8 / uint8
+    # containers here (no ml_dtypes in the image), `ir.tensor` of the reference's ml_dtypes arrays makes INT4 / UINT4 tensors
+    onnx_types: dict = dataclasses.field(default_factory=dict)
 
 
 def _qdq_name(prefix: str, qconfig: QConfig) -> str:
@@ -97,6 +100,14 @@ class _Tensor:
 
 def plan_node(node_op_type: str, x_name: str, w, out_name: str, qconfig: QConfig, meta=None, bias=None, out=None,
               weight_arrays=None, quantize_bias=None) -> EmissionPlan:
+    """`_plan_node` + the ONNX element types of the initializers whose NumPy container is wider than the type."""
+    types: dict = {}
+    plan = _plan_node(node_op_type, x_name, w, out_name, qconfig, meta, bias, out, weight_arrays, quantize_bias, types)
+    plan.onnx_types = types
+    return plan
+
+
+def _plan_node(node_op_type, x_name, w, out_name, qconfig, meta, bias, out, weight_arrays, quantize_bias, types) -> EmissionPlan:
     """What `QRewriter._rewrite` (qrules/base.py:51-81) emits for one node.
 
     ``w`` / ``bias``: values with ``.name`` and ``.const_value.numpy()``; ``meta``: the node's calibration results
@@ -123,6 +134,10 @@ def plan_node(node_op_type: str, x_name: str, w, out_name: str, qconfig: QConfig
 
     def quantized(value, cfg, with_out, nbits=False):                             # qrules/_common.py:126-142
         q, s, z = weight_arrays(value, cfg, out if with_out else None, nbits)
+        if not nbits and cfg.weights.dtype.bitwidth == 4:                         # `ir.tensor(w_q)` of an ml_dtypes array
+            types[value.name] = int(cfg.weights.dtype.value)
+            if np.asarray(z).dtype.kind in "iu":
+                types[f"{value.name}/zero_point"] = int(cfg.weights.dtype.value)
         return (initializer(value.name, q), initializer(f"{value.name}/scale", s), initializer(f"{value.name}/zero_point", z))
 
     def act_qparams(kind, aargs):                                                 # qrules/base.py:15-40

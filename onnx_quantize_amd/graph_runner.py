@@ -1,0 +1,587 @@
+"""Runs an ONNX graph on torch-ROCm so that calibration activations are born in HBM ("run the
+augmented model on a ROCm / MIGraphX ORT EP (or torch-ROCm)"; reference: core/_calibration/calibrate.py:204-251).
+
+The reference saves the augmented model to a temporary directory, opens an onnxruntime session on it and copies every
+tapped activation of every batch back to the host.  `GraphRunner` walks the parsed graph (`onnx_proto`) node by node on
+the GPU instead: initializers are uploaded once, each batch is one pass, the tapped values are handed to the calibration
+stream as device tensors, and values nobody needs any more are dropped as the walk proceeds (a value dies after its last
+consumer).  Nodes downstream of the last tapped value are not run at all -- the reference gets the same effect by
+replacing the graph outputs (`_augment_model`, calibrate.py:100-124: "beneficial when we dont need the last output").
+
+It is an interpreter for the operators transformer / MLP exports are made of, not an inference engine: an operator it
+does not know raises by name.  It also runs what `quantize()` emits -- Q / DQ, DynamicQuantizeLinear, QLinearMatMul,
+`com.microsoft::MatMulNBits` / `QGemm`, calls into the model's own functions -- which is how the tests execute a quantized
+model end to end.  It fits `calibration_driver.run_calibration`'s runner protocol: ``runner(feed) -> {value name: tensor}``.
+"""
+from __future__ import annotations
+
+from collections.abc import Mapping
+
+import numpy as np
+
+from .onnx_proto import DataType, Message, attribute_value, tensor_to_numpy
+
+__all__ = ["GraphRunner", "UnsupportedOperator"]
+
+
+class UnsupportedOperator(NotImplementedError):
+    pass
+
+
+def _torch_dtype(code: int):
+    import torch
+    table = {DataType.FLOAT: torch.float32, DataType.UINT8: torch.uint8, DataType.INT8: torch.int8, DataType.INT16: torch.int16,
+             DataType.INT32: torch.int32, DataType.INT64: torch.int64, DataType.BOOL: torch.bool, DataType.FLOAT16: torch.float16,
+             DataType.DOUBLE: torch.float64, DataType.BFLOAT16: torch.bfloat16, DataType.UINT4: torch.uint8, DataType.INT4: torch.int8}
+    if code not in table:
+        raise UnsupportedOperator(f"GraphRunner: element type {code}")
+    return table[code]
+
+
+def _ints(t) -> list[int]:
+    """A shape-like operand as Python ints (one sync when it lives on the device; shape arithmetic is kept on the host)."""
+    return [int(v) for v in (t.tolist() if t.ndim else [t.item()])]
+
+
+class GraphRunner:
+    """``GraphRunner(model, outputs=[names], device="cuda")(feed)`` -> ``{name: tensor on the device}``.
+
+    model: a parsed ModelProto (`onnx_proto.parse_model`); outputs: the value names wanted (default: the graph's own
+    outputs); feed: one tensor / array (single-input model) or {input name: tensor / array}."""
+
+    def __init__(self, model: Message, outputs=None, device="cuda"):
+        import torch
+
+        self.model, self.graph = model, model.graph
+        self.device = torch.device(device)
+        self.functions = {(f.domain or "", f.name, f.overload or ""): f for f in model.functions}
+        self.opset = max([int(o.version or 1) for o in model.opset_import if not o.domain] or [1])
+        self.wanted = list(outputs) if outputs is not None else [o.name for o in self.graph.output]
+        init_names = {t.name for t in self.graph.initializer}
+        self.input_names = [i.name for i in self.graph.input if i.name not in init_names]
+        self.constants = {}
+        for t in self.graph.initializer:
+            self.constants[t.name] = self._constant(tensor_to_numpy(t), t.data_type)
+        self.nodes = self._needed_nodes(self.graph.node, self.wanted)
+        # the last node that reads each value: it is dropped right after
+        self.last_use: dict[str, int] = {}
+        for i, n in enumerate(self.nodes):
+            for name in self._reads(n):
+                self.last_use[name] = i
+
+    # ------------------------------------------------------------------------------------------------- preparation
+    def _constant(self, a: np.ndarray, code: int | None = None):
+        import torch
+        if a.dtype == np.uint16 or a.dtype == np.uint32 or a.dtype == np.uint64:
+            a = a.astype(np.int64)
+        t = torch.from_numpy(np.array(a, order="C"))            # a copy: 0-d stays 0-d, and views into the file are read-only
+        # small integer tensors are shape arithmetic: they stay on the host, where Reshape / Slice / Expand read them
+        if t.dtype == torch.int64 and t.numel() <= 64:
+            return t
+        return t.to(self.device)
+
+    def _reads(self, node):
+        names = [n for n in node.input if n]
+        for a in node.attribute:                       # values a sub-graph captures from the enclosing scope
+            if a.has("g"):
+                produced = {o for n in a.g.node for o in n.output} | {i.name for i in a.g.input}
+                names += [i for n in a.g.node for i in n.input if i and i not in produced]
+        return names
+
+    def _needed_nodes(self, nodes, wanted):
+        producer = {}
+        for n in nodes:
+            for o in n.output:
+                if o:
+                    producer[o] = n
+        need, stack = set(), [w for w in wanted]
+        missing = [w for w in wanted if w not in producer and w not in self.constants and w not in self.input_names]
+        if missing:
+            raise KeyError(f"GraphRunner: no value named {missing[0]!r} in the graph")
+        while stack:
+            name = stack.pop()
+            n = producer.get(name)
+            if n is None or id(n) in need:
+                continue
+            need.add(id(n))
+            stack.extend(self._reads(n))
+        return [n for n in nodes if id(n) in need]       # the file's order is a topological order (ONNX requires it)
+
+    # ------------------------------------------------------------------------------------------------- one pass
+    def __call__(self, feed) -> dict:
+        import torch
+
+        if not isinstance(feed, Mapping):
+            if len(self.input_names) != 1:
+                raise ValueError(f"GraphRunner: the model has inputs {self.input_names}; feed them as a dict")
+            feed = {self.input_names[0]: feed}
+        env = dict(self.constants)
+        for name in self.input_names:
+            if name not in feed:
+                raise KeyError(f"GraphRunner: no data for model input '{name}'")
+        for name, v in feed.items():
+            t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, order="C"))
+            env[name] = t.to(self.device, non_blocking=True)
+        keep = set(self.wanted)
+        with torch.no_grad():
+            self._run(self.nodes, env, keep, self.last_use)
+        return {name: env[name] for name in self.wanted}
+
+    def _run(self, nodes, env, keep=(), last_use=None):
+        for i, node in enumerate(nodes):
+            ins = [env[n] if n else None for n in node.input]
+            outs = self._dispatch(node, ins, env)
+            for name, value in zip(node.output, outs):
+                if name:
+                    env[name] = value
+            if last_use is not None:
+                for name in node.input:
+                    if name and last_use.get(name) == i and name not in keep and name not in self.constants:
+                        env.pop(name, None)
+
+    def _dispatch(self, node, ins, env):
+        import torch
+
+        domain = node.domain or ""
+        fn = self.functions.get((domain, node.op_type, node.overload or ""))
+        if fn is not None:
+            return self._call_function(fn, node, ins)
+        if domain not in ("", "ai.onnx", "com.microsoft"):
+            raise UnsupportedOperator(f"GraphRunner: operator {domain}::{node.op_type} (node '{node.name}') and no function of that name in the model")
+        impl = getattr(self, "_op_" + node.op_type, None)
+        if impl is None:
+            raise UnsupportedOperator(f"GraphRunner: operator '{node.op_type}' (node '{node.name}') is not implemented")
+        # shape arithmetic lives on the host; an operator that mixes it with device data takes it to the device
+        devs = {t.device for t in ins if isinstance(t, torch.Tensor)}
+        if len(devs) > 1 and node.op_type not in _HOST_OPERANDS:
+            ins = [t.to(self.device) if isinstance(t, torch.Tensor) else t for t in ins]
+        attrs = {a.name: a for a in node.attribute}
+        out = impl(node, ins, _Attrs(attrs), env)
+        return out if isinstance(out, (tuple, list)) else (out,)
+
+    def _call_function(self, fn, node, ins):
+        if fn.attribute or fn.attribute_proto:
+            given = {a.name for a in node.attribute}
+            if any(r.ref_attr_name for n in fn.node for r in n.attribute):
+                raise UnsupportedOperator(f"GraphRunner: function '{fn.name}' refers to attributes {sorted(given)} of its call")
+        env = {}
+        for name, value in zip(fn.input, ins):
+            env[name] = value
+        for name in list(fn.input)[len(ins):]:
+            env[name] = None
+        self._run(list(fn.node), env)          # a function body sees its inputs only (ONNX functions are closed)
+        return tuple(env[o] for o in fn.output)
+
+    # ------------------------------------------------------------------------------------------------- operators
+    # elementwise
+    def _op_Add(self, n, x, a, e): return x[0] + x[1]
+    def _op_Sub(self, n, x, a, e): return x[0] - x[1]
+    def _op_Mul(self, n, x, a, e): return x[0] * x[1]
+
+    def _op_Div(self, n, x, a, e):
+        import torch
+        if not (x[0].is_floating_point() or x[1].is_floating_point()):
+            return torch.div(x[0], x[1], rounding_mode="trunc")
+        return x[0] / x[1]
+
+    def _op_Pow(self, n, x, a, e):
+        import torch
+        return torch.pow(x[0], x[1].to(x[0].dtype) if x[0].is_floating_point() else x[1])
+
+    def _op_Sqrt(self, n, x, a, e): return x[0].sqrt()
+    def _op_Exp(self, n, x, a, e): return x[0].exp()
+    def _op_Log(self, n, x, a, e): return x[0].log()
+    def _op_Neg(self, n, x, a, e): return -x[0]
+    def _op_Abs(self, n, x, a, e): return x[0].abs()
+    def _op_Erf(self, n, x, a, e): return x[0].erf()
+    def _op_Tanh(self, n, x, a, e): return x[0].tanh()
+    def _op_Sin(self, n, x, a, e): return x[0].sin()
+    def _op_Cos(self, n, x, a, e): return x[0].cos()
+    def _op_Sigmoid(self, n, x, a, e): return x[0].sigmoid()
+    def _op_Relu(self, n, x, a, e): return x[0].relu()
+    def _op_Reciprocal(self, n, x, a, e): return x[0].reciprocal()
+    def _op_Floor(self, n, x, a, e): return x[0].floor()
+    def _op_Ceil(self, n, x, a, e): return x[0].ceil()
+    def _op_Round(self, n, x, a, e): return x[0].round()
+    def _op_Not(self, n, x, a, e): return ~x[0]
+    def _op_And(self, n, x, a, e): return x[0] & x[1]
+    def _op_Or(self, n, x, a, e): return x[0] | x[1]
+    def _op_Equal(self, n, x, a, e): return x[0] == x[1]
+    def _op_Less(self, n, x, a, e): return x[0] < x[1]
+    def _op_Greater(self, n, x, a, e): return x[0] > x[1]
+    def _op_LessOrEqual(self, n, x, a, e): return x[0] <= x[1]
+    def _op_GreaterOrEqual(self, n, x, a, e): return x[0] >= x[1]
+    def _op_Identity(self, n, x, a, e): return x[0]
+    def _op_Dropout(self, n, x, a, e): return (x[0], None)[:len(n.output)] if len(n.output) > 1 else x[0]
+
+    def _op_Where(self, n, x, a, e):
+        import torch
+        return torch.where(x[0], x[1], x[2])
+
+    def _op_Min(self, n, x, a, e):
+        import torch
+        out = x[0]
+        for t in x[1:]:
+            out = torch.minimum(out, t)
+        return out
+
+    def _op_Max(self, n, x, a, e):
+        import torch
+        out = x[0]
+        for t in x[1:]:
+            out = torch.maximum(out, t)
+        return out
+
+    def _op_Sum(self, n, x, a, e):
+        out = x[0]
+        for t in x[1:]:
+            out = out + t
+        return out
+
+    def _op_LeakyRelu(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.leaky_relu(x[0], a.get("alpha", 0.01))
+
+    def _op_Gelu(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.gelu(x[0], approximate=a.get("approximate", "none"))
+
+    def _op_Softplus(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.softplus(x[0])
+
+    def _op_Clip(self, n, x, a, e):
+        lo = x[1] if len(x) > 1 and x[1] is not None else a.get("min", None)
+        hi = x[2] if len(x) > 2 and x[2] is not None else a.get("max", None)
+        out = x[0]
+        if lo is not None:
+            out = out.clamp(min=lo.item() if hasattr(lo, "item") else lo)
+        if hi is not None:
+            out = out.clamp(max=hi.item() if hasattr(hi, "item") else hi)
+        return out
+
+    def _op_Cast(self, n, x, a, e):
+        return x[0].to(_torch_dtype(a["to"]))
+
+    def _op_Softmax(self, n, x, a, e):
+        import torch
+        if self.opset < 13:                                  # older semantics: flatten to 2-D at `axis`
+            axis = a.get("axis", 1)
+            shape = x[0].shape
+            return torch.softmax(x[0].flatten(axis if axis >= 0 else axis + x[0].ndim), -1).reshape(shape) \
+                if axis not in (-1, x[0].ndim - 1) else torch.softmax(x[0], -1)
+        return torch.softmax(x[0], dim=a.get("axis", -1))
+
+    def _op_LogSoftmax(self, n, x, a, e):
+        import torch
+        return torch.log_softmax(x[0], dim=a.get("axis", -1))
+
+    def _op_LayerNormalization(self, n, x, a, e):
+        import torch
+        axis = a.get("axis", -1)
+        t = x[0]
+        axis = axis if axis >= 0 else axis + t.ndim
+        out = torch.nn.functional.layer_norm(t, tuple(t.shape[axis:]), x[1], x[2] if len(x) > 2 else None, a.get("epsilon", 1e-5))
+        if len([o for o in n.output if o]) > 1:
+            raise UnsupportedOperator("GraphRunner: LayerNormalization with Mean / InvStdDev outputs")
+        return out
+
+    def _reduce(self, fn, n, x, a):
+        axes = _ints(x[1]) if len(x) > 1 and x[1] is not None else a.get("axes", None)
+        keep = bool(a.get("keepdims", 1))
+        if not axes:
+            if a.get("noop_with_empty_axes", 0) and len(x) > 1:
+                return x[0]
+            axes = list(range(x[0].ndim))
+        return fn(x[0], axes, keep)
+
+    def _op_ReduceMean(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.mean(dim=ax, keepdim=k), n, x, a)
+    def _op_ReduceSum(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.sum(dim=ax, keepdim=k), n, x, a)
+    def _op_ReduceMax(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.amax(dim=ax, keepdim=k), n, x, a)
+    def _op_ReduceMin(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.amin(dim=ax, keepdim=k), n, x, a)
+
+    # linear algebra
+    def _op_MatMul(self, n, x, a, e):
+        import torch
+        return torch.matmul(x[0], x[1])
+
+    def _op_Gemm(self, n, x, a, e):
+        A = x[0].t() if a.get("transA", 0) else x[0]
+        B = x[1].t() if a.get("transB", 0) else x[1]
+        out = (A @ B) * a.get("alpha", 1.0) if a.get("alpha", 1.0) != 1.0 else A @ B
+        if len(x) > 2 and x[2] is not None:
+            out = out + (x[2] * a.get("beta", 1.0) if a.get("beta", 1.0) != 1.0 else x[2])
+        return out
+
+    # shapes
+    def _op_Shape(self, n, x, a, e):
+        import torch
+        dims = list(x[0].shape)
+        start, end = a.get("start", 0), a.get("end", None)
+        return torch.tensor(dims[start:end], dtype=torch.int64)
+
+    def _op_Size(self, n, x, a, e):
+        import torch
+        return torch.tensor(x[0].numel(), dtype=torch.int64)
+
+    def _op_Constant(self, n, x, a, e):
+        import torch
+        if "value" in a:
+            return self._constant(a["value"])
+        if "value_int" in a:
+            return torch.tensor(a["value_int"], dtype=torch.int64)
+        if "value_ints" in a:
+            return torch.tensor(a["value_ints"], dtype=torch.int64)
+        if "value_float" in a:
+            return torch.tensor(a["value_float"], dtype=torch.float32, device=self.device)
+        if "value_floats" in a:
+            return torch.tensor(a["value_floats"], dtype=torch.float32, device=self.device)
+        raise UnsupportedOperator(f"GraphRunner: Constant node '{n.name}' with none of the value attributes this runner reads")
+
+    def _op_ConstantOfShape(self, n, x, a, e):
+        import torch
+        value = a.get("value", None)
+        shape = _ints(x[0])
+        if value is None:
+            return torch.zeros(shape, dtype=torch.float32, device=self.device)
+        v = torch.from_numpy(np.array(value, order="C")).reshape(-1)[0]
+        out = torch.full(shape, v.item(), dtype=v.dtype)
+        return out if (out.dtype == torch.int64 and out.numel() <= 64) else out.to(self.device)
+
+    def _op_Reshape(self, n, x, a, e):
+        shape = _ints(x[1])
+        if not a.get("allowzero", 0):
+            shape = [x[0].shape[i] if d == 0 else d for i, d in enumerate(shape)]
+        return x[0].reshape(shape)
+
+    def _op_Flatten(self, n, x, a, e):
+        axis = a.get("axis", 1)
+        axis = axis if axis >= 0 else axis + x[0].ndim
+        return x[0].reshape(int(np.prod(x[0].shape[:axis], dtype=np.int64)), -1)
+
+    def _op_Transpose(self, n, x, a, e):
+        perm = a.get("perm", None)
+        return x[0].permute(perm if perm is not None else list(range(x[0].ndim))[::-1])
+
+    def _axes(self, x, a):
+        return _ints(x[1]) if len(x) > 1 and x[1] is not None else a.get("axes", None)
+
+    def _op_Unsqueeze(self, n, x, a, e):
+        axes = self._axes(x, a)
+        rank = x[0].ndim + len(axes)
+        out = x[0]
+        for ax in sorted(ax if ax >= 0 else ax + rank for ax in axes):
+            out = out.unsqueeze(ax)
+        return out
+
+    def _op_Squeeze(self, n, x, a, e):
+        axes = self._axes(x, a)
+        if axes is None:
+            return x[0].squeeze()
+        out = x[0]
+        for ax in sorted((ax if ax >= 0 else ax + x[0].ndim for ax in axes), reverse=True):
+            out = out.squeeze(ax)
+        return out
+
+    def _op_Concat(self, n, x, a, e):
+        import torch
+        return torch.cat([t for t in x if t is not None], dim=a["axis"])
+
+    def _op_Split(self, n, x, a, e):
+        import torch
+        axis = a.get("axis", 0)
+        sizes = _ints(x[1]) if len(x) > 1 and x[1] is not None else a.get("split", None)
+        if sizes is None:
+            parts = a.get("num_outputs", None) or len(n.output)
+            size = -(-x[0].shape[axis] // parts)
+            return torch.split(x[0], size, dim=axis)
+        return torch.split(x[0], sizes, dim=axis)
+
+    def _op_Slice(self, n, x, a, e):
+        t = x[0]
+        if len(x) == 1:                                      # opset < 10: attributes
+            starts, ends, axes, steps = a["starts"], a["ends"], a.get("axes", None), None
+        else:
+            starts, ends = _ints(x[1]), _ints(x[2])
+            axes = _ints(x[3]) if len(x) > 3 and x[3] is not None else None
+            steps = _ints(x[4]) if len(x) > 4 and x[4] is not None else None
+        axes = axes if axes is not None else list(range(len(starts)))
+        steps = steps if steps is not None else [1] * len(starts)
+        index = [slice(None)] * t.ndim
+        flips = []
+        for s, en, ax, st in zip(starts, ends, axes, steps):
+            ax = ax if ax >= 0 else ax + t.ndim
+            dim = t.shape[ax]
+            if st > 0:
+                index[ax] = slice(*slice(s, en, st).indices(dim))
+            else:                                            # torch has no negative steps: take the mirrored range, then flip
+                lo, hi, _ = slice(s, en, st).indices(dim)
+                picked = list(range(lo, hi, st))
+                if not picked:
+                    index[ax] = slice(0, 0)
+                else:
+                    index[ax] = slice(picked[-1], picked[0] + 1, -st)
+                    flips.append(ax)
+        out = t[tuple(index)]
+        return out.flip(flips) if flips else out
+
+    def _op_Gather(self, n, x, a, e):
+        import torch
+        axis = a.get("axis", 0)
+        data, idx = x[0], x[1]
+        idx = idx.to(torch.int64)
+        if data.device != idx.device:
+            idx = idx.to(data.device)
+        idx = torch.where(idx < 0, idx + data.shape[axis], idx)
+        if idx.ndim == 0:
+            return data.index_select(axis, idx.reshape(1)).squeeze(axis)
+        out = data.index_select(axis, idx.reshape(-1))
+        axis = axis if axis >= 0 else axis + data.ndim
+        return out.reshape(*data.shape[:axis], *idx.shape, *data.shape[axis + 1:])
+
+    def _op_Expand(self, n, x, a, e):
+        import torch
+        shape = _ints(x[1])
+        return x[0].expand(torch.broadcast_shapes(tuple(x[0].shape), tuple(shape))).contiguous()
+
+    def _op_Tile(self, n, x, a, e):
+        return x[0].repeat(_ints(x[1]))
+
+    def _op_Range(self, n, x, a, e):
+        import torch
+        return torch.arange(x[0].item(), x[1].item(), x[2].item(), dtype=x[0].dtype, device=self.device)
+
+    def _op_Trilu(self, n, x, a, e):
+        import torch
+        k = int(x[1].item()) if len(x) > 1 and x[1] is not None else 0
+        return torch.triu(x[0], k) if a.get("upper", 1) else torch.tril(x[0], k)
+
+    # quantization operators (ONNX QuantizeLinear / DequantizeLinear / DynamicQuantizeLinear, opset 21 semantics)
+    @staticmethod
+    def _per_axis(p, like, axis):
+        if p.ndim == 1 and like.ndim > 1:
+            shape = [1] * like.ndim
+            shape[axis] = -1
+            return p.reshape(shape)
+        return p
+
+    def _op_DequantizeLinear(self, n, x, a, e):
+        import torch
+        q, scale = x[0], x[1]
+        zp = x[2] if len(x) > 2 and x[2] is not None else None
+        axis, block = a.get("axis", 1), a.get("block_size", 0)
+        axis = axis if axis >= 0 else axis + q.ndim
+        qf = q.to(torch.float32)
+        if block:                                            # blocked along `axis`: parameters repeat `block` times
+            scale = scale.repeat_interleave(block, dim=axis)
+            zpf = zp.to(torch.float32).repeat_interleave(block, dim=axis) if zp is not None else None
+            return ((qf - zpf) if zpf is not None else qf) * scale
+        scale = self._per_axis(scale, q, axis)
+        if zp is not None:
+            qf = qf - self._per_axis(zp.to(torch.float32), q, axis)
+        return qf * scale
+
+    def _quantize(self, t, scale, zp, code=None):
+        import torch
+        dt = zp.dtype if zp is not None else torch.uint8
+        lo, hi = (0, 255) if dt == torch.uint8 else (-128, 127)
+        q = torch.round(t / scale)                           # half to even, like the operator
+        if zp is not None:
+            q = q + zp.to(torch.float32)
+        return q.clamp(lo, hi).to(dt)
+
+    def _op_QuantizeLinear(self, n, x, a, e):
+        zp = x[2] if len(x) > 2 and x[2] is not None else None
+        axis = a.get("axis", 1)
+        axis = axis if axis >= 0 else axis + x[0].ndim
+        if a.get("block_size", 0):
+            raise UnsupportedOperator("GraphRunner: blocked QuantizeLinear")
+        scale = self._per_axis(x[1], x[0], axis)
+        return self._quantize(x[0], scale, None if zp is None else self._per_axis(zp, x[0], axis).to(zp.dtype))
+
+    def _op_DynamicQuantizeLinear(self, n, x, a, e):
+        import torch
+        t = x[0]
+        lo = torch.clamp(t.min(), max=0.0)
+        hi = torch.clamp(t.max(), min=0.0)
+        scale = (hi - lo) / 255.0
+        safe = torch.where(scale == 0, torch.ones_like(scale), scale)
+        zp = torch.round(torch.clamp(-lo / safe, 0, 255)).to(torch.uint8)
+        q = torch.clamp(torch.round(t / safe) + zp.to(torch.float32), 0, 255).to(torch.uint8)
+        return q, scale, zp
+
+    def _op_QLinearMatMul(self, n, x, a, e):
+        import torch
+        A = (x[0].to(torch.float32) - x[2].to(torch.float32)) * x[1]
+        bz = self._per_axis(x[5].to(torch.float32), x[3], x[3].ndim - 1)
+        B = (x[3].to(torch.float32) - bz) * self._per_axis(x[4], x[3], x[3].ndim - 1)
+        return self._quantize(A @ B, x[6], x[7])
+
+    def _op_QGemm(self, n, x, a, e):
+        """com.microsoft::QGemm: A, a_scale, a_zp, B, b_scale, b_zp, C (int32, scale a_scale * b_scale), y_scale, y_zp."""
+        import torch
+        A = (x[0].to(torch.float32) - x[2].to(torch.float32)) * x[1]
+        if a.get("transA", 0):
+            A = A.t()
+        Bq = x[3].t() if a.get("transB", 0) else x[3]
+        bs, bz = x[4], x[5].to(torch.float32)
+        B = (Bq.to(torch.float32) - (bz if bz.ndim == 0 else bz.reshape(1, -1))) * (bs if bs.ndim == 0 else bs.reshape(1, -1))
+        out = (A @ B) * a.get("alpha", 1.0)
+        if len(x) > 6 and x[6] is not None:
+            out = out + x[6].to(torch.float32) * (x[1] * (bs if bs.ndim == 0 else bs.reshape(1, -1)))
+        if len(x) > 7 and x[7] is not None:
+            return self._quantize(out, x[7], x[8] if len(x) > 8 else None)
+        return out
+
+    def _op_MatMulNBits(self, n, x, a, e):
+        """com.microsoft::MatMulNBits: B [N, K/g, g*bits/8] (4-bit: low nibble first), scales [N, K/g] (or flat),
+        zero points packed like B along the block axis (default 2^(bits-1)), optional g_idx (unused by the writer), bias."""
+        import torch
+        K, N, bits, g = a["K"], a["N"], a.get("bits", 4), a["block_size"]
+        blocks = (K + g - 1) // g
+        blob = x[1].reshape(N, blocks, -1).to(torch.uint8)
+        if bits == 4:
+            q = torch.stack([blob & 0x0F, blob >> 4], dim=-1).reshape(N, blocks, g)
+        elif bits == 8:
+            q = blob.reshape(N, blocks, g)
+        else:
+            raise UnsupportedOperator(f"GraphRunner: MatMulNBits with bits = {bits}")
+        scales = x[2].reshape(N, blocks).to(torch.float32)
+        zp = x[3] if len(x) > 3 and x[3] is not None else None
+        if zp is None:
+            zpf = torch.full((N, blocks), float(1 << (bits - 1)), device=q.device)
+        elif zp.is_floating_point():
+            zpf = zp.reshape(N, blocks).to(torch.float32)
+        elif bits == 4:
+            z = zp.reshape(N, -1).to(torch.uint8)
+            zpf = torch.stack([z & 0x0F, z >> 4], dim=-1).reshape(N, -1)[:, :blocks].to(torch.float32)
+        else:
+            zpf = zp.reshape(N, blocks).to(torch.float32)
+        if len(x) > 4 and x[4] is not None:
+            raise UnsupportedOperator("GraphRunner: MatMulNBits with g_idx")
+        w = ((q.to(torch.float32) - zpf[:, :, None]) * scales[:, :, None]).reshape(N, blocks * g)[:, :K]
+        out = x[0] @ w.t()
+        if len(x) > 5 and x[5] is not None:
+            out = out + x[5]
+        return out
+
+
+_HOST_OPERANDS = {"Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split", "ConstantOfShape", "Gather", "Trilu",
+                  "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}
+
+
+class _Attrs:
+    """Attribute access with defaults; values decoded on first use."""
+
+    def __init__(self, protos):
+        self._p = protos
+
+    def __contains__(self, name):
+        return name in self._p
+
+    def __getitem__(self, name):
+        return attribute_value(self._p[name])
+
+    def get(self, name, default=None):
+        return attribute_value(self._p[name]) if name in self._p else default
+

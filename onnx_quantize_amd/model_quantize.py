@@ -1,0 +1,483 @@
+"""`quantize()` on an ONNX file without the `onnx` / `onnx_ir` / `onnxscript` packages.
+
+The reference's pipeline (quantize.py:28-80, pre_passes/__init__.py:47-98) is graph surgery around ONE numeric call per
+node.  With the model held as parsed protobuf messages (`onnx_proto`), the surgery that a MatMul / Gemm model needs is
+small enough to restate, and it lets a GPU box quantize a file end to end with nothing but this package:
+
+  reference step                                         here
+  ------------------------------------------------------ --------------------------------------------------------------
+  ir.from_proto (a copy)                                  `Message.copy()` of the parsed model
+  onnxscript.optimizer.optimize                           NOT restated: constants must already be initializers
+  version_converter.convert_version(target 21)            `_raise_opset`: the adapters a MatMul / Gemm export needs
+                                                          (Reduce* axes, Split num_outputs), anything else refused by name
+  NameFixPass                                             `_name_nodes`: unnamed nodes get names (the ignore patterns and
+                                                          the activation initializers key on names)
+  DuplicateInitializersPass (duplicate_initializer.py)    `_duplicate_shared_initializers`
+  matmul_add_to_gemm_rule (onnxscript)                    `_fuse_matmul_add`: rank-2 operands only, like the rule
+  StandarizeGemm[Bias] (standarize_gemm.py)               `_standardize_gemm`
+  calibrate_model (calibrate.py:310-380)                  `_calibrate`: `GraphRunner` on the GPU -> `ActivationStream`
+  _add_qconfig_to_nodes / get_target_nodes                `_target_nodes`
+  preprocessors (AWQ, SmoothQuant)                        refused (they are rebound inside the reference's own passes:
+                                                          reference_passes.py)
+  rewrite(model, get_qrules(qconfig))                     `emission.plan_node` per node -> initializers + one call
+  model.functions.update / RemoveUnusedFunctionsPass      the functions the calls use (`onnx_functions`)
+  DeduplicateInitializersPass(size_limit=1e9)             `_deduplicate_initializers`
+  ir.to_proto                                             `onnx_proto.serialize`
+
+Every number in the emitted model comes from the device path (`seam.weight_arrays`, `calibration_driver`); `weight_arrays`
+can be injected, which is how the CPU suite drives the bookkeeping with the oracle.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import re
+
+import numpy as np
+
+from .config import QConfig
+from .emission import plan_node
+from .wire_format import _resolve_group_size
+from .onnx_functions import FUNCTION_OPSET, MS_DOMAIN, QUANT_DOMAIN, build_function
+from .onnx_proto import (DataType, Message, attribute_value, load_model, make_attribute, make_node, numpy_to_tensor, parse_model,
+                         save_model, tensor_to_numpy)
+
+__all__ = ["quantize_model", "quantize_file", "as_model"]
+
+logger = logging.getLogger("onnx_quantize")
+
+_MIN_SOURCE_OPSET = 13
+# operators whose node form changed between opset 13 and 21 in a way this module does not adapt (version_converter would)
+_NOT_ADAPTED = {"DFT": 20, "GridSample": 20, "GroupNormalization": 21, "RoiAlign": 16, "Resize": 18, "Pad": 18, "ScatterElements": 18,
+                "ScatterND": 18, "BatchNormalization": 14}
+_REDUCE_AXES_TO_INPUT = {"ReduceMean", "ReduceMax", "ReduceMin", "ReduceProd", "ReduceL1", "ReduceL2", "ReduceLogSum",
+                         "ReduceLogSumExp", "ReduceSumSquare"}                     # opset 18: `axes` moved from attribute to input
+
+
+def as_model(model) -> Message:
+    """bytes / path / parsed ModelProto -> a parsed ModelProto the caller's object is not aliased with."""
+    if isinstance(model, Message):
+        if model._type != "ModelProto":
+            raise TypeError(f"model must be a ModelProto message, got {model._type}")
+        return model.copy()
+    if isinstance(model, (bytes, bytearray, memoryview)):
+        return parse_model(bytes(model))
+    if isinstance(model, (str, os.PathLike)):
+        return load_model(model)
+    raise TypeError(f"model must be ONNX bytes, a path or a parsed ModelProto (onnx_proto.parse_model), got {type(model)}")
+
+
+# ------------------------------------------------------------------------------------------------------------ graph helpers
+class _Const:
+    """What the emission code reads of a constant value: `.name`, `.const_value.numpy()`."""
+
+    def __init__(self, name, array):
+        self.name, self._a = name, array
+        self.const_value = self
+
+    def numpy(self):
+        return self._a
+
+
+class _Graph:
+    """Name-indexed view of a GraphProto that keeps the message lists in step."""
+
+    def __init__(self, graph: Message):
+        self.g = graph
+        self.inits = {t.name: t for t in graph.initializer}
+        self.graph_inputs = {i.name for i in graph.input}
+        self.graph_outputs = {o.name for o in graph.output}
+
+    def array(self, name):
+        t = self.inits.get(name)
+        return None if t is None else tensor_to_numpy(t)
+
+    def set_initializer(self, name, array, data_type=None):
+        t = numpy_to_tensor(name, array, data_type)
+        if name in self.inits:
+            old = self.inits[name]
+            self.g.initializer[[id(x) for x in self.g.initializer].index(id(old))] = t
+        else:
+            self.g.initializer.append(t)
+        self.inits[name] = t
+        if name in self.graph_inputs:                     # IR < 4 files list initializers as inputs: keep the type in step
+            for vi in self.g.input:
+                if vi.name == name and vi.type is not None and vi.type.tensor_type is not None:
+                    vi.type.tensor_type.elem_type = t.data_type
+                    vi.type.tensor_type.shape = Message("TensorShapeProto", dim=[
+                        Message("TensorShapeProto.Dimension", dim_value=int(d)) for d in t.dims])
+        return t
+
+    def uses(self, name):
+        """[(node, input index)] in graph order -- `ir.Value.uses()` for a top-level value."""
+        return [(n, i) for n in self.g.node for i, v in enumerate(n.input) if v == name]
+
+    def rank(self, name):
+        t = self.inits.get(name)
+        if t is not None:
+            return len(t.dims)
+        for vi in list(self.g.input) + list(self.g.value_info) + list(self.g.output):
+            if vi.name == name and vi.type is not None and vi.type.tensor_type is not None and vi.type.tensor_type.shape is not None:
+                return len(vi.type.tensor_type.shape.dim)
+        return None
+
+
+def _attr(node, name, default=None):
+    for a in node.attribute:
+        if a.name == name:
+            return attribute_value(a)
+    return default
+
+
+def _all_nodes(graph):
+    for n in graph.node:
+        yield n
+        for a in n.attribute:
+            if a.has("g"):
+                yield from _all_nodes(a.g)
+            for g in a.graphs:
+                yield from _all_nodes(g)
+
+
+# ------------------------------------------------------------------------------------------------------------ pre passes
+def _raise_opset(model: Message, G: _Graph, target: int = FUNCTION_OPSET) -> None:
+    """quantize.py:55 (`convert_version(model, target_version=op.version)`) for the operators exports of MatMul / Gemm models
+    are made of.  Most of them did not change form between opset 13 and 21; the two that commonly appear and did are adapted;
+    an operator from `_NOT_ADAPTED` that crosses its change is refused by name rather than silently mis-declared."""
+    default = [o for o in model.opset_import if not o.domain or o.domain == "ai.onnx"]
+    if not default:
+        model.opset_import.append(Message("OperatorSetIdProto", domain="", version=target))
+        return
+    current = max(int(o.version or 1) for o in default)
+    if current >= target:
+        return
+    if current < _MIN_SOURCE_OPSET:
+        raise NotImplementedError(f"the model imports opset {current}; this writer raises opsets >= {_MIN_SOURCE_OPSET} to {target} "
+                                  "(older models: run onnx's version converter first)")
+    for n in _all_nodes(model.graph):
+        if n.domain not in (None, "", "ai.onnx"):
+            continue
+        changed = _NOT_ADAPTED.get(n.op_type)
+        if changed is not None and current < changed <= target:
+            raise NotImplementedError(f"node '{n.name}': operator {n.op_type} changed in opset {changed} and this writer has no adapter "
+                                      f"for it (model at opset {current}; run onnx's version converter to {target} first)")
+        if n.op_type in _REDUCE_AXES_TO_INPUT and current < 18:
+            axes = _attr(n, "axes")
+            if axes is not None:
+                name = f"{n.output[0]}/axes"
+                G.set_initializer(name, np.asarray(axes, dtype=np.int64))
+                n.input = list(n.input)[:1] + [name]
+                n.attribute = [a for a in n.attribute if a.name != "axes"]
+        if n.op_type == "Split" and current < 18 and len(n.input) < 2 and _attr(n, "num_outputs") is None:
+            n.attribute = list(n.attribute) + [make_attribute("num_outputs", len(n.output))]
+    for o in default:
+        o.version = target
+    if (model.ir_version or 0) < 10:                      # 4-bit tensors and opset 21 belong to IR version 10
+        model.ir_version = 10
+
+
+def _name_nodes(G: _Graph) -> None:
+    taken = {n.name for n in G.g.node if n.name}
+    for i, n in enumerate(G.g.node):
+        if not n.name:
+            name = f"node_{n.op_type}_{i}"
+            while name in taken:
+                name += "_"
+            n.name = name
+            taken.add(name)
+
+
+def _duplicate_shared_initializers(G: _Graph) -> None:
+    """duplicate_initializer.py:38-68: an initializer read in more than one place keeps its first use; every further use gets
+    a copy named `<name>_<i>` (tied weights: each consumer is then quantized on its own)."""
+    for name in list(G.inits):
+        if name in G.graph_inputs or name in G.graph_outputs:
+            continue
+        uses = G.uses(name)
+        if len(uses) <= 1:
+            continue
+        src = G.inits[name]
+        for i, (node, idx) in enumerate(uses[1:], start=1):
+            new = src.copy()
+            new.name = f"{name}_{i}"
+            G.g.initializer.append(new)
+            G.inits[new.name] = new
+            ins = list(node.input)
+            ins[idx] = new.name
+            node.input = ins
+
+
+def _fuse_matmul_add(G: _Graph) -> None:
+    """onnxscript's `matmul_add_to_gemm_rule` (pre_passes/__init__.py:62): Add(MatMul(a, b), c) -> Gemm(a, b, c) when a and b
+    are known to be matrices (rank 2) and the product feeds nothing else."""
+    producer = {o: n for n in G.g.node for o in n.output if o}
+    consumers: dict = {}
+    for n in G.g.node:
+        for v in n.input:
+            if v:
+                consumers.setdefault(v, []).append(n)
+    drop = set()
+    for add in G.g.node:
+        if add.op_type != "Add" or add.domain or len(add.input) != 2:
+            continue
+        mm = producer.get(add.input[0])
+        if mm is None or mm.op_type != "MatMul" or mm.domain or id(mm) in drop:
+            continue
+        if len(consumers.get(mm.output[0], [])) != 1 or mm.output[0] in G.graph_outputs:
+            continue
+        if G.rank(mm.input[0]) != 2 or G.rank(mm.input[1]) != 2:
+            continue
+        add.op_type = "Gemm"
+        add.input = [mm.input[0], mm.input[1], add.input[1]]
+        add.attribute = []
+        drop.add(id(mm))
+    if drop:
+        G.g.node = [n for n in G.g.node if id(n) not in drop]
+
+
+def _standardize_gemm(G: _Graph) -> None:
+    """standarize_gemm.py:5-57: a Gemm whose weight is constant and whose `transB` is absent or non-zero is re-emitted as
+    Gemm(x, w[, b], transB=0) with the weight transposed when it was `transB = 1`.  As in the reference the re-emitted node
+    carries `transB` ONLY: `alpha`, `beta` and `transA` of the original are not copied (a Gemm with explicit `transB = 0` is
+    left alone, attributes and all)."""
+    for n in G.g.node:
+        if n.op_type != "Gemm" or n.domain or len(n.input) < 2 or n.input[1] not in G.inits:
+            continue
+        trans_b = _attr(n, "transB")
+        if trans_b == 0:
+            continue
+        if trans_b:
+            w = G.array(n.input[1])
+            G.set_initializer(n.input[1], np.ascontiguousarray(w.T))
+        n.input = [v for v in list(n.input)[:3]]
+        n.attribute = [make_attribute("transB", 0)]
+
+
+def _target_nodes(G: _Graph, qconfig: QConfig) -> list:
+    """calibrate.py:48-89 + the `check` methods of the rules (matmul_to_qmatmul.py:31-41, gemm_to_qgemm.py:13-44): op type
+    selected, name not ignored, constant weight (and bias), Gemm with `transB = 0`.  Weights that are not matrices are left
+    alone (the numeric path is defined on [K, N])."""
+    ignores = [re.compile(p) for p in qconfig.ignore]
+    out = []
+    for n in G.g.node:
+        if n.domain or n.op_type not in qconfig.target_op_types or len(n.input) < 2:
+            continue
+        if n.name and any(p.search(n.name) for p in ignores):
+            continue
+        if n.input[1] not in G.inits:
+            continue
+        if len(n.input) > 2 and n.input[2] and n.input[2] not in G.inits:
+            continue
+        if len(n.input) > 2 and not n.input[2]:
+            continue
+        if n.op_type == "Gemm" and _attr(n, "transB") != 0:
+            continue
+        if len(G.inits[n.input[1]].dims) != 2 or G.inits[n.input[1]].data_type != DataType.FLOAT:
+            logger.debug("node '%s': weight '%s' is not a float32 matrix, left as it is", n.name, n.input[1])
+            continue
+        out.append(n)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ calibration
+def _needs_calibration(qconfig: QConfig) -> bool:
+    """pre_passes/__init__.py:31-44."""
+    for a in (qconfig.input_activations, qconfig.output_activations):
+        if a is not None and a.is_static:
+            return True
+    if any(pre.requires_calibration for pre in qconfig.preprocessors):
+        return True
+    return bool(qconfig.weights and qconfig.weights.algorithm.requires_calibration)
+
+
+def _model_inputs(G: _Graph):
+    """[(name, shape with None / str for symbolic dimensions, NumPy dtype)] of the real inputs (initializers excluded)."""
+    from .onnx_proto import _NP_OF
+    out = []
+    for vi in G.g.input:
+        if vi.name in G.inits:
+            continue
+        tt = vi.type.tensor_type if vi.type is not None else None
+        if tt is None or tt.shape is None:
+            raise ValueError(f"model input '{vi.name}' has no tensor shape: calibration data must be given")
+        shape = [int(d.dim_value) if d.dim_value is not None else (d.dim_param or None) for d in tt.shape.dim]
+        out.append((vi.name, shape, np.dtype(_NP_OF[tt.elem_type])))
+    return out
+
+
+def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> dict:
+    """calibrate.py:310-380 with the activations consumed on the device, batch by batch (calibration_driver.py): returns
+    {id(node): meta} with `input_scale` / `input_zero_point` / `output_scale` / `output_zero_point` (0-d arrays) and `input`
+    (a `StreamedGptqInput`: the Hessian of the node's input, shared by the nodes that read the same value)."""
+    from .calibration import get_calibrator
+    from .calibration_driver import ActivationStream, generate_random_calibration_data, run_calibration
+    from .graph_runner import GraphRunner
+    from .reference_passes import StreamedGptqInput
+
+    cal_in = qconfig.input_activations is not None and qconfig.input_activations.is_static
+    cal_out = qconfig.output_activations is not None and qconfig.output_activations.is_static
+    algo = qconfig.weights is not None and qconfig.weights.algorithm.requires_calibration
+    in_names = [n.input[0] for n in targets]
+    out_names = [n.output[0] for n in targets]
+    wanted = list(dict.fromkeys((in_names if (cal_in or algo) else []) + (out_names if cal_out else [])))
+    params = qconfig.calibration_params.model_dump()
+    batch_size, num_samples = params.pop("batch_size"), params.pop("num_samples")
+    params.pop("provider")                                 # the GPU this process owns runs the graph
+    calibrator = get_calibrator(params.pop("method"), **params)
+    inputs = _model_inputs(G)
+    data = qconfig.calibration_data
+    if data is None:
+        data = generate_random_calibration_data(num_samples, inputs)
+    # a model input that a target node reads directly is "produced" by the feed: the runner returns it like any other value
+    runner = GraphRunner(model, outputs=wanted, device=device)
+    stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
+                              hessian_names=in_names if algo else ())
+    run_calibration(runner, data, stream, num_samples=num_samples, batch_size=batch_size, input_names=[i[0] for i in inputs])
+    meta: dict = {id(n): {} for n in targets}
+    for kind, on, names, aargs in (("input", cal_in, in_names, qconfig.input_activations),
+                                   ("output", cal_out, out_names, qconfig.output_activations)):
+        if not on:
+            continue
+        qparams = stream.input_qparams(aargs) if kind == "input" else stream.output_qparams(aargs)
+        for n, name in zip(targets, names):
+            if name in qparams:
+                scale, zp = qparams[name]
+                meta[id(n)][f"{kind}_scale"] = np.asarray(scale).astype(aargs.scale_dtype, copy=False)
+                meta[id(n)][f"{kind}_zero_point"] = np.asarray(zp).astype(aargs.zp_dtype, copy=False)
+    if algo:
+        shared: dict = {}
+        for n, name in zip(targets, in_names):
+            acc = stream.hessians.get(name)
+            if acc is None:
+                continue
+            if name not in shared:
+                shared[name] = StreamedGptqInput(name, acc.h, acc.n, (acc.n, acc.h.shape[0]))
+            meta[id(n)]["input"] = shared[name]
+    return meta
+
+
+# ------------------------------------------------------------------------------------------------------------ post passes
+def _deduplicate_initializers(G: _Graph, size_limit: float = 1e9) -> None:
+    """`DeduplicateInitializersPass(size_limit=1e9)` (quantize.py:75): initializers with the same element type, shape and
+    bytes become one; graph inputs / outputs and string tensors are left alone."""
+    seen: dict = {}
+    rename: dict = {}
+    keep = []
+    for t in G.g.initializer:
+        if t.name in G.graph_inputs or t.name in G.graph_outputs or t.data_type == DataType.STRING or not t.has("raw_data") \
+                or len(t.raw_data) > size_limit:
+            keep.append(t)
+            continue
+        key = (t.data_type, tuple(t.dims), bytes(t.raw_data))
+        first = seen.get(key)
+        if first is None:
+            seen[key] = t.name
+            keep.append(t)
+        else:
+            rename[t.name] = first
+    if not rename:
+        return
+    G.g.initializer = keep
+    for n in _all_nodes(G.g):
+        if any(v in rename for v in n.input):
+            n.input = [rename.get(v, v) for v in n.input]
+    G.inits = {t.name: t for t in keep}
+
+
+def _remove_unused_initializers(G: _Graph) -> None:
+    used = {v for n in _all_nodes(G.g) for v in n.input if v} | G.graph_outputs
+    G.g.initializer = [t for t in G.g.initializer if t.name in used]
+    G.inits = {t.name: t for t in G.g.initializer}
+
+
+# ------------------------------------------------------------------------------------------------------------ the pipeline
+class _Out:
+    """What the seam reads of a node's output value: `out.producer().meta`."""
+
+    def __init__(self, meta):
+        self.meta = meta
+
+    def producer(self):
+        return self
+
+
+def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None) -> Message:
+    """quantize.py:28-80 on a parsed ModelProto / ONNX bytes / a path.  Returns a new parsed ModelProto (`onnx_proto.serialize`
+    gives the file).  `weight_arrays` / `quantize_bias`: the numeric providers (default: the device-resident seam and the HIP
+    bias kernel; tests inject the oracle)."""
+    if not isinstance(qconfig, QConfig):
+        raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
+    model = as_model(model)
+    if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
+        logger.info("No quantization parameters specified in qconfig. Returning original model.")
+        return model
+    if qconfig.preprocessors:
+        raise NotImplementedError(
+            "preprocessors (AWQ / SmoothQuant) rewrite the graph inside the reference's own passes; this writer does not restate "
+            "them.  Use onnx_quantize_amd.quantize() with the reference installed (integration.py), or the searches on their own "
+            "(onnx_quantize_amd.preprocessing).")
+    if model.graph is None:
+        raise ValueError("the model has no graph")
+    G = _Graph(model.graph)
+    _raise_opset(model, G)
+    _name_nodes(G)
+    _duplicate_shared_initializers(G)
+    _fuse_matmul_add(G)
+    _standardize_gemm(G)
+    targets = _target_nodes(G, qconfig)
+    meta = _calibrate(model, G, targets, qconfig, device) if (_needs_calibration(qconfig) and targets) else {}
+
+    used_functions: dict = {}
+    domains = set()
+    for node in targets:
+        x_name, w_name, out_name = node.input[0], node.input[1], node.output[0]
+        has_bias = len(node.input) > 2
+        w = _Const(w_name, G.array(w_name))
+        b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
+        node_meta = meta.get(id(node), {})
+        plan = plan_node(node.op_type, x_name, w, out_name, qconfig, node_meta, bias=b, out=_Out(node_meta),
+                         weight_arrays=weight_arrays, quantize_bias=quantize_bias)
+        for name, array in plan.initializers:
+            G.set_initializer(name, np.asarray(array), plan.onnx_types.get(name))
+        call = plan.call
+        node.op_type, node.domain = call["name"], call["domain"]
+        node.input = ["" if v is None else v for v in call["inputs"]]
+        node.attribute = [make_attribute(k, v) for k, v in call["attrs"].items()]
+        domains.add(call["domain"])
+        if call["domain"] == QUANT_DOMAIN:
+            group = None
+            if call["name"].endswith("WeightsOnlyGrouped"):                       # base.py:72: the group size this weight resolved to
+                group = int(_resolve_group_size(w.numpy().shape[0], qconfig.weights.group_size, w_name))
+            used_functions.setdefault((call["name"], group), []).append(node)
+
+    # qfunctions/__init__.py:11-22 + RemoveUnusedFunctionsPass: the functions the calls use, nothing else
+    four_bit = qconfig.weights is not None and qconfig.weights.dtype.bitwidth == 4
+    group_sizes = sorted({g for (_, g) in used_functions if g is not None})
+    for (name, group), nodes in sorted(used_functions.items(), key=lambda kv: (kv[0][0], kv[0][1] or 0)):
+        fn = build_function(name, group_size=group, four_bit=four_bit)
+        if group is not None and len(group_sizes) > 1:
+            # the reference registers every group size under ONE name and the last one wins (qmatmul.py:218-236 through
+            # qfunctions/__init__.py:17-20), which leaves the other calls with the wrong block size; here each size is its own
+            # overload of the name, so a model whose weights resolve to different group sizes stays correct
+            fn.overload = f"g{group}"
+            for n in nodes:
+                n.overload = fn.overload
+        model.functions.append(fn)
+    have = {o.domain or "" for o in model.opset_import}
+    if QUANT_DOMAIN in domains and QUANT_DOMAIN not in have:
+        model.opset_import.append(Message("OperatorSetIdProto", domain=QUANT_DOMAIN, version=1))
+    uses_ms = MS_DOMAIN in domains or any(n.domain == MS_DOMAIN for f in model.functions for n in f.node)
+    if uses_ms and MS_DOMAIN not in have:
+        model.opset_import.append(Message("OperatorSetIdProto", domain=MS_DOMAIN, version=1))
+
+    _remove_unused_initializers(G)
+    _deduplicate_initializers(G)
+    return model
+
+
+def quantize_file(src, dst, qconfig: QConfig, **kw) -> Message:
+    """Read `src`, quantize, write `dst` (one file, weights inline).  Returns the quantized model."""
+    out = quantize_model(load_model(src), qconfig, **kw)
+    save_model(out, dst)
+    return out
+

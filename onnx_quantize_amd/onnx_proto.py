@@ -1,0 +1,503 @@
+"""ONNX model files without the `onnx` package: a protobuf wire codec for the messages of `onnx.proto` a quantized model is
+made of (the emitted graph).
+
+The reference hands `onnx.ModelProto` / `onnx_ir.Model` objects around (quantize.py:28-80) and serialises through
+`ir.to_proto`; this image has neither package, and a GPU box that only quantizes should not need them.  The wire format
+is small: varints, 32 / 64-bit scalars and length-delimited records, with the field numbers of the published `onnx.proto`
+(IR version 10 / 11 schema, proto2 syntax).  `parse_model(bytes)` gives a tree of `Message` objects with attribute access
+(`model.graph.node[0].op_type`), `serialize(message)` gives the bytes back: fields in field-number order, repeated
+scalars packed exactly where `onnx.proto` says `[packed = true]`, absent optional fields absent, fields this table does
+not know kept verbatim -- a parse / serialize round trip of a file another producer wrote is byte-identical
+(tests/test_onnx_proto.py checks that on files written by torch's C++ exporter).
+
+Tensors: `tensor_to_numpy` / `numpy_to_tensor` cover the element types the path reads and writes, 4-bit types two per
+byte, low nibble first (`core/_pack.py:8-22`; onnx.proto "INT4 / UINT4": the first element in the 4 LSB).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+__all__ = ["Message", "parse", "parse_model", "serialize", "load_model", "save_model", "tensor_to_numpy", "numpy_to_tensor",
+           "make_attribute", "attribute_value", "make_node", "make_value_info", "DataType", "AttributeType", "SCHEMA"]
+
+
+class DataType:
+    """TensorProto.DataType codes."""
+    UNDEFINED, FLOAT, UINT8, INT8, UINT16, INT16, INT32, INT64, STRING, BOOL, FLOAT16, DOUBLE, UINT32, UINT64 = range(14)
+    BFLOAT16 = 16
+    UINT4, INT4 = 21, 22
+
+
+class AttributeType:
+    UNDEFINED, FLOAT, INT, STRING, TENSOR, GRAPH, FLOATS, INTS, STRINGS, TENSORS, GRAPHS = range(11)
+    TYPE_PROTO, TYPE_PROTOS = 13, 14
+
+
+_NP_OF = {DataType.FLOAT: np.float32, DataType.UINT8: np.uint8, DataType.INT8: np.int8, DataType.UINT16: np.uint16,
+          DataType.INT16: np.int16, DataType.INT32: np.int32, DataType.INT64: np.int64, DataType.BOOL: np.bool_,
+          DataType.FLOAT16: np.float16, DataType.DOUBLE: np.float64, DataType.UINT32: np.uint32, DataType.UINT64: np.uint64}
+_CODE_OF = {np.dtype(v): k for k, v in _NP_OF.items()}
+
+# message -> {field number: (name, kind, label)}; kind: a scalar kind or the name of a message; label: "one" | "many" |
+# "packed".  Transcribed from the published onnx.proto; anything else in a file is carried along as raw bytes.
+O, M, P = "one", "many", "packed"
+SCHEMA = {
+    "ModelProto": {1: ("ir_version", "int64", O), 2: ("producer_name", "string", O), 3: ("producer_version", "string", O),
+                   4: ("domain", "string", O), 5: ("model_version", "int64", O), 6: ("doc_string", "string", O),
+                   7: ("graph", "GraphProto", O), 8: ("opset_import", "OperatorSetIdProto", M),
+                   14: ("metadata_props", "StringStringEntryProto", M), 25: ("functions", "FunctionProto", M)},
+    "OperatorSetIdProto": {1: ("domain", "string", O), 2: ("version", "int64", O)},
+    "StringStringEntryProto": {1: ("key", "string", O), 2: ("value", "string", O)},
+    "GraphProto": {1: ("node", "NodeProto", M), 2: ("name", "string", O), 5: ("initializer", "TensorProto", M),
+                   10: ("doc_string", "string", O), 11: ("input", "ValueInfoProto", M), 12: ("output", "ValueInfoProto", M),
+                   13: ("value_info", "ValueInfoProto", M), 16: ("metadata_props", "StringStringEntryProto", M)},
+    "NodeProto": {1: ("input", "string", M), 2: ("output", "string", M), 3: ("name", "string", O), 4: ("op_type", "string", O),
+                  5: ("attribute", "AttributeProto", M), 6: ("doc_string", "string", O), 7: ("domain", "string", O),
+                  8: ("overload", "string", O), 9: ("metadata_props", "StringStringEntryProto", M)},
+    "AttributeProto": {1: ("name", "string", O), 2: ("f", "float", O), 3: ("i", "int64", O), 4: ("s", "bytes", O),
+                       5: ("t", "TensorProto", O), 6: ("g", "GraphProto", O), 7: ("floats", "float", M), 8: ("ints", "int64", M),
+                       9: ("strings", "bytes", M), 10: ("tensors", "TensorProto", M), 11: ("graphs", "GraphProto", M),
+                       13: ("doc_string", "string", O), 14: ("tp", "TypeProto", O), 15: ("type_protos", "TypeProto", M),
+                       20: ("type", "int32", O), 21: ("ref_attr_name", "string", O)},
+    "TensorProto": {1: ("dims", "int64", M), 2: ("data_type", "int32", O), 4: ("float_data", "float", P),
+                    5: ("int32_data", "int32", P), 6: ("string_data", "bytes", M), 7: ("int64_data", "int64", P),
+                    8: ("name", "string", O), 9: ("raw_data", "bytes", O), 10: ("double_data", "double", P),
+                    11: ("uint64_data", "uint64", P), 12: ("doc_string", "string", O),
+                    13: ("external_data", "StringStringEntryProto", M), 14: ("data_location", "int32", O),
+                    16: ("metadata_props", "StringStringEntryProto", M)},
+    "ValueInfoProto": {1: ("name", "string", O), 2: ("type", "TypeProto", O), 3: ("doc_string", "string", O),
+                       4: ("metadata_props", "StringStringEntryProto", M)},
+    "TypeProto": {1: ("tensor_type", "TypeProto.Tensor", O), 6: ("denotation", "string", O)},
+    "TypeProto.Tensor": {1: ("elem_type", "int32", O), 2: ("shape", "TensorShapeProto", O)},
+    "TensorShapeProto": {1: ("dim", "TensorShapeProto.Dimension", M)},
+    "TensorShapeProto.Dimension": {1: ("dim_value", "int64", O), 2: ("dim_param", "string", O), 3: ("denotation", "string", O)},
+    "FunctionProto": {1: ("name", "string", O), 4: ("input", "string", M), 5: ("output", "string", M), 6: ("attribute", "string", M),
+                      7: ("node", "NodeProto", M), 8: ("doc_string", "string", O), 9: ("opset_import", "OperatorSetIdProto", M),
+                      10: ("domain", "string", O), 11: ("attribute_proto", "AttributeProto", M),
+                      12: ("value_info", "ValueInfoProto", M), 13: ("overload", "string", O),
+                      14: ("metadata_props", "StringStringEntryProto", M)},
+}
+_BY_NAME = {msg: {name: (num, kind, label) for num, (name, kind, label) in fields.items()} for msg, fields in SCHEMA.items()}
+_VARINT_KINDS = {"int64", "int32", "uint64", "bool"}
+_WIRE_OF = {"int64": 0, "int32": 0, "uint64": 0, "bool": 0, "double": 1, "float": 5, "string": 2, "bytes": 2}
+_FIXED = {"float": ("<f", 4, np.dtype("<f4")), "double": ("<d", 8, np.dtype("<f8"))}
+
+
+class Message:
+    """One protobuf message: the fields of its type as attributes (absent optional field: None; repeated field: a list,
+    possibly empty), `_unknown` the records this module has no name for, in file order."""
+
+    __slots__ = ("_type", "_values", "_unknown")
+
+    def __init__(self, type_name: str, **fields):
+        if type_name not in SCHEMA:
+            raise KeyError(f"onnx_proto: no message type '{type_name}'")
+        object.__setattr__(self, "_type", type_name)
+        object.__setattr__(self, "_values", {})
+        object.__setattr__(self, "_unknown", [])
+        for k, v in fields.items():
+            setattr(self, k, v)
+
+    def __getattr__(self, name):
+        spec = _BY_NAME[self._type].get(name)
+        if spec is None:
+            raise AttributeError(f"{self._type} has no field '{name}'")
+        if name not in self._values:
+            if spec[2] == O:
+                return None
+            self._values[name] = []
+        return self._values[name]
+
+    def __setattr__(self, name, value):
+        if name not in _BY_NAME[self._type]:
+            raise AttributeError(f"{self._type} has no field '{name}'")
+        if value is None:
+            self._values.pop(name, None)
+        else:
+            self._values[name] = value
+
+    def has(self, name: str) -> bool:
+        v = self._values.get(name)
+        return v is not None and not (isinstance(v, list) and not v)
+
+    def copy(self) -> "Message":
+        """A copy that shares leaf values (bytes, numbers) but no lists or sub-messages."""
+        out = Message(self._type)
+        for k, v in self._values.items():
+            if isinstance(v, list):
+                out._values[k] = [e.copy() if isinstance(e, Message) else e for e in v]
+            else:
+                out._values[k] = v.copy() if isinstance(v, Message) else v
+        out._unknown.extend(self._unknown)
+        return out
+
+    def __repr__(self):
+        def short(v):
+            if isinstance(v, (bytes, memoryview)) and len(v) > 24:
+                return f"<{len(v)} bytes>"
+            if isinstance(v, list) and len(v) > 6:
+                return f"[{len(v)} items]"
+            return repr(v)
+        return f"{self._type}({', '.join(f'{k}={short(v)}' for k, v in self._values.items())})"
+
+
+# --------------------------------------------------------------------------------------------------------------- reading
+def _varint(buf, pos):
+    result = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        result |= (b & 0x7F) << shift
+        if b < 0x80:
+            return result, pos
+        shift += 7
+        if shift > 63:
+            raise ValueError("onnx_proto: varint longer than 10 bytes")
+
+
+def _signed(v: int, kind: str) -> int:
+    if kind in ("int64", "int32"):
+        v &= 0xFFFFFFFFFFFFFFFF
+        return v - (1 << 64) if v >> 63 else v
+    return bool(v) if kind == "bool" else v
+
+
+def _scalar_from_wire(kind, wire, buf, pos):
+    if wire == 0:
+        v, pos = _varint(buf, pos)
+        return _signed(v, kind), pos
+    if wire == 5:
+        return struct.unpack_from("<f", buf, pos)[0], pos + 4
+    if wire == 1:
+        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    raise ValueError(f"onnx_proto: wire type {wire} for a scalar field")
+
+
+def parse(type_name: str, data) -> Message:
+    """Decode one message of type `type_name` from bytes / memoryview (large byte fields stay views into `data`)."""
+    buf = data if isinstance(data, memoryview) else memoryview(data)
+    fields = SCHEMA[type_name]
+    msg = Message(type_name)
+    values = msg._values
+    pos, end = 0, len(buf)
+    while pos < end:
+        key, pos = _varint(buf, pos)
+        num, wire = key >> 3, key & 7
+        spec = fields.get(num)
+        if spec is None:                                   # carried along verbatim
+            start = pos
+            if wire == 0:
+                _, pos = _varint(buf, pos)
+            elif wire == 1:
+                pos += 8
+            elif wire == 5:
+                pos += 4
+            elif wire == 2:
+                n, pos = _varint(buf, pos)
+                pos += n
+            else:
+                raise ValueError(f"onnx_proto: wire type {wire} (groups are not part of onnx.proto)")
+            if pos > end:
+                raise ValueError("onnx_proto: truncated message")
+            msg._unknown.append((key, bytes(buf[start:pos])))
+            continue
+        name, kind, label = spec
+        if wire == 2:
+            n, pos = _varint(buf, pos)
+            if pos + n > end:
+                raise ValueError(f"onnx_proto: field '{name}' of {type_name} runs past the end of its message")
+            chunk = buf[pos:pos + n]
+            pos += n
+            if kind == "string":
+                value = bytes(chunk).decode("utf-8", errors="surrogateescape")
+            elif kind == "bytes":
+                value = chunk if n > 4096 else bytes(chunk)            # raw_data of a large initializer: no copy
+            elif kind in SCHEMA:
+                value = parse(kind, chunk)
+            else:                                                      # a packed run of scalars
+                if label == O:
+                    raise ValueError(f"onnx_proto: length-delimited record for scalar field '{name}'")
+                if kind in _FIXED:
+                    vals = np.frombuffer(chunk, dtype=_FIXED[kind][2]).tolist()
+                else:
+                    vals, p = [], 0
+                    while p < n:
+                        v, p = _varint(chunk, p)
+                        vals.append(_signed(v, kind))
+                values.setdefault(name, []).extend(vals)
+                continue
+        else:
+            if kind in SCHEMA or kind in ("string", "bytes"):
+                raise ValueError(f"onnx_proto: wire type {wire} for field '{name}' of {type_name}")
+            value, pos = _scalar_from_wire(kind, wire, buf, pos)
+            if pos > end:
+                raise ValueError("onnx_proto: truncated message")
+        if label == O:
+            values[name] = value
+        else:
+            values.setdefault(name, []).append(value)
+    return msg
+
+
+def parse_model(data) -> Message:
+    return parse("ModelProto", data)
+
+
+def load_model(path) -> Message:
+    with open(path, "rb") as f:
+        return parse_model(f.read())
+
+
+# --------------------------------------------------------------------------------------------------------------- writing
+def _put_varint(out: bytearray, v: int) -> None:
+    v &= 0xFFFFFFFFFFFFFFFF                                # negative int32 / int64: ten bytes, as protobuf writes them
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+
+
+def _put_scalar(out: bytearray, kind: str, v) -> None:
+    if kind in _VARINT_KINDS:
+        _put_varint(out, int(v))
+    else:
+        out += struct.pack(_FIXED[kind][0], v)
+
+
+def _serialize_into(msg: Message, chunks: list) -> int:
+    """Appends the encoding of `msg` to `chunks` (bytes-like pieces) and returns its length."""
+    fields = SCHEMA[msg._type]
+    by_name = _BY_NAME[msg._type]
+    total = 0
+    for name in sorted(msg._values, key=lambda n: by_name[n][0]):
+        value = msg._values[name]
+        num, kind, label = by_name[name]
+        items = [value] if label == O else value
+        if not items:
+            continue
+        if label == P:
+            body = bytearray()
+            if kind in _FIXED:
+                body += np.asarray(items, dtype=_FIXED[kind][2]).tobytes()
+            else:
+                for v in items:
+                    _put_varint(body, int(v))
+            head = bytearray()
+            _put_varint(head, (num << 3) | 2)
+            _put_varint(head, len(body))
+            chunks += [bytes(head), bytes(body)]
+            total += len(head) + len(body)
+            continue
+        for v in items:
+            head = bytearray()
+            if kind in SCHEMA:
+                sub: list = []
+                n = _serialize_into(v, sub)
+                _put_varint(head, (num << 3) | 2)
+                _put_varint(head, n)
+                chunks.append(bytes(head))
+                chunks += sub
+                total += len(head) + n
+            elif kind in ("string", "bytes"):
+                payload = v.encode("utf-8", errors="surrogateescape") if isinstance(v, str) else v
+                _put_varint(head, (num << 3) | 2)
+                _put_varint(head, len(payload))
+                chunks += [bytes(head), payload]
+                total += len(head) + len(payload)
+            else:
+                _put_varint(head, (num << 3) | _WIRE_OF[kind])
+                _put_scalar(head, kind, v)
+                chunks.append(bytes(head))
+                total += len(head)
+    del fields
+    for key, raw in msg._unknown:
+        head = bytearray()
+        _put_varint(head, key)
+        chunks += [bytes(head), raw]
+        total += len(head) + len(raw)
+    return total
+
+
+def serialize(msg: Message) -> bytes:
+    chunks: list = []
+    _serialize_into(msg, chunks)
+    return b"".join(chunks)
+
+
+def save_model(model: Message, path) -> None:
+    """One file, weights inline.  protobuf caps a message at 2 GiB: larger models must be split by the caller."""
+    chunks: list = []
+    n = _serialize_into(model, chunks)
+    if n >= 1 << 31:
+        raise ValueError(f"onnx_proto: the serialised model is {n} bytes; a protobuf message cannot exceed 2 GiB "
+                         "(external tensor data is not written by this module)")
+    with open(path, "wb") as f:
+        for c in chunks:
+            f.write(c)
+
+
+# --------------------------------------------------------------------------------------------------------------- tensors
+def _unpack_nibbles(raw: np.ndarray, count: int, signed: bool) -> np.ndarray:
+    lo, hi = raw & 0x0F, raw >> 4
+    out = np.empty(raw.size * 2, dtype=np.uint8)
+    out[0::2], out[1::2] = lo, hi
+    out = out[:count]
+    if signed:
+        return ((out ^ 8).astype(np.int16) - 8).astype(np.int8)      # two's-complement nibble -> int8
+    return out
+
+
+def tensor_to_numpy(t: Message) -> np.ndarray:
+    """The array a TensorProto holds (raw_data or the typed fields).  4-bit types come back one value per byte (int8 /
+    uint8 containers).  Tensors whose bytes live in another file (data_location EXTERNAL) are refused: the caller decides
+    where those are."""
+    if t.data_location:
+        raise ValueError(f"onnx_proto: tensor '{t.name}' keeps its data in an external file")
+    dims = [int(d) for d in t.dims]
+    count = int(np.prod(dims, dtype=np.int64)) if dims else 1
+    code = t.data_type
+    if code in (DataType.UINT4, DataType.INT4):
+        if t.has("raw_data"):
+            raw = np.frombuffer(t.raw_data, dtype=np.uint8)
+        else:                                                         # int32_data: one packed byte per entry
+            raw = np.asarray(t.int32_data, dtype=np.int64).astype(np.uint8)
+        if raw.size != (count + 1) // 2:
+            raise ValueError(f"onnx_proto: tensor '{t.name}': {raw.size} bytes for {count} 4-bit values")
+        return _unpack_nibbles(raw, count, code == DataType.INT4).reshape(dims)
+    if code == DataType.BFLOAT16:
+        raise ValueError(f"onnx_proto: tensor '{t.name}' is bfloat16 (no NumPy type here)")
+    if code not in _NP_OF:
+        raise ValueError(f"onnx_proto: tensor '{t.name}' has element type {code}, which this module does not read")
+    dt = np.dtype(_NP_OF[code])
+    if t.has("raw_data"):
+        a = np.frombuffer(t.raw_data, dtype=dt.newbyteorder("<"))
+    elif code == DataType.FLOAT:
+        a = np.asarray(t.float_data, dtype=np.float32)
+    elif code == DataType.DOUBLE:
+        a = np.asarray(t.double_data, dtype=np.float64)
+    elif code == DataType.INT64:
+        a = np.asarray(t.int64_data, dtype=np.int64)
+    elif code in (DataType.UINT32, DataType.UINT64):
+        a = np.asarray(t.uint64_data, dtype=np.uint64).astype(dt)
+    elif code == DataType.FLOAT16:                                     # bit patterns in int32_data
+        a = np.asarray(t.int32_data, dtype=np.int64).astype(np.uint16).view(np.float16)
+    else:                                                              # the other narrow types travel in int32_data
+        a = np.asarray(t.int32_data, dtype=np.int64).astype(dt)
+    if a.size != count:
+        raise ValueError(f"onnx_proto: tensor '{t.name}': {a.size} values for shape {dims}")
+    return a.reshape(dims)
+
+
+def numpy_to_tensor(name: str, array, data_type: int | None = None) -> Message:
+    """A TensorProto with raw_data (what `ir.tensor(...)` serialises to).  `data_type` UINT4 / INT4 packs an int8 / uint8
+    container two values per byte, low nibble first, padding an odd count with a zero nibble."""
+    a = np.asarray(array)
+    if data_type is None:
+        if a.dtype not in _CODE_OF:
+            raise ValueError(f"onnx_proto: no ONNX element type for NumPy dtype {a.dtype}")
+        data_type = _CODE_OF[a.dtype]
+    t = Message("TensorProto", dims=[int(d) for d in a.shape], data_type=int(data_type), name=name)
+    if data_type in (DataType.UINT4, DataType.INT4):
+        flat = np.ascontiguousarray(a).reshape(-1).astype(np.int16)
+        lo_ok, hi_ok = (-8, 7) if data_type == DataType.INT4 else (0, 15)
+        if flat.size and (flat.min() < lo_ok or flat.max() > hi_ok):
+            raise ValueError(f"onnx_proto: tensor '{name}' holds values outside the 4-bit range [{lo_ok}, {hi_ok}]")
+        nib = (flat & 0x0F).astype(np.uint8)
+        if nib.size % 2:
+            nib = np.concatenate([nib, np.zeros(1, dtype=np.uint8)])
+        t.raw_data = (nib[0::2] | (nib[1::2] << 4)).tobytes()
+        return t
+    want = np.dtype(_NP_OF[data_type])
+    if a.dtype != want:
+        raise ValueError(f"onnx_proto: tensor '{name}': array dtype {a.dtype} does not match element type {data_type}")
+    t.raw_data = np.ascontiguousarray(a).astype(want.newbyteorder("<"), copy=False).tobytes()
+    return t
+
+
+# --------------------------------------------------------------------------------------------------------------- helpers
+def make_attribute(name: str, value) -> Message:
+    """int / float / str / bytes / Message(TensorProto | GraphProto) and homogeneous lists of int / float / str."""
+    a = Message("AttributeProto", name=name)
+    if isinstance(value, bool) or isinstance(value, (int, np.integer)):
+        a.i, a.type = int(value), AttributeType.INT
+    elif isinstance(value, (float, np.floating)):
+        a.f, a.type = float(value), AttributeType.FLOAT
+    elif isinstance(value, str):
+        a.s, a.type = value.encode("utf-8"), AttributeType.STRING
+    elif isinstance(value, bytes):
+        a.s, a.type = value, AttributeType.STRING
+    elif isinstance(value, Message) and value._type == "TensorProto":
+        a.t, a.type = value, AttributeType.TENSOR
+    elif isinstance(value, Message) and value._type == "GraphProto":
+        a.g, a.type = value, AttributeType.GRAPH
+    elif isinstance(value, (list, tuple)):
+        if all(isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in value):
+            a.ints, a.type = [int(v) for v in value], AttributeType.INTS
+        elif all(isinstance(v, (int, float, np.integer, np.floating)) for v in value):
+            a.floats, a.type = [float(v) for v in value], AttributeType.FLOATS
+        elif all(isinstance(v, (str, bytes)) for v in value):
+            a.strings, a.type = [v.encode("utf-8") if isinstance(v, str) else v for v in value], AttributeType.STRINGS
+        else:
+            raise TypeError(f"onnx_proto: attribute '{name}': a list of mixed types")
+    else:
+        raise TypeError(f"onnx_proto: attribute '{name}': unsupported value {type(value)}")
+    return a
+
+
+def attribute_value(a: Message):
+    """The Python value of an AttributeProto (strings as str; tensors as NumPy arrays; graphs as messages)."""
+    t = a.type
+    if t == AttributeType.INT:
+        return int(a.i or 0)
+    if t == AttributeType.FLOAT:
+        return float(a.f or 0.0)
+    if t == AttributeType.STRING:
+        return bytes(a.s or b"").decode("utf-8", errors="surrogateescape")
+    if t == AttributeType.TENSOR:
+        return tensor_to_numpy(a.t)
+    if t == AttributeType.GRAPH:
+        return a.g
+    if t == AttributeType.INTS:
+        return [int(v) for v in a.ints]
+    if t == AttributeType.FLOATS:
+        return [float(v) for v in a.floats]
+    if t == AttributeType.STRINGS:
+        return [bytes(s).decode("utf-8", errors="surrogateescape") for s in a.strings]
+    if t in (None, AttributeType.UNDEFINED):                 # writers before IR 3 left `type` out: go by what is set
+        for field in ("i", "f", "s", "t", "g"):
+            if a.has(field):
+                v = getattr(a, field)
+                return bytes(v).decode("utf-8", errors="surrogateescape") if field == "s" else (tensor_to_numpy(v) if field == "t" else v)
+        for field in ("ints", "floats", "strings"):
+            if a.has(field):
+                return list(getattr(a, field))
+    raise ValueError(f"onnx_proto: attribute '{a.name}' of type {t} is not read by this module")
+
+
+def make_node(op_type: str, inputs, outputs, name: str | None = None, domain: str | None = None, **attrs) -> Message:
+    n = Message("NodeProto", input=[("" if i is None else i) for i in inputs], output=list(outputs), op_type=op_type)
+    if name:
+        n.name = name
+    if domain:
+        n.domain = domain
+    if attrs:
+        n.attribute = [make_attribute(k, v) for k, v in attrs.items()]
+    return n
+
+
+def make_value_info(name: str, elem_type: int, shape) -> Message:
+    """`shape`: ints, strs (symbolic) or None entries; None as the shape itself leaves the rank open."""
+    tt = Message("TypeProto.Tensor", elem_type=int(elem_type))
+    if shape is not None:
+        dims = []
+        for d in shape:
+            dim = Message("TensorShapeProto.Dimension")
+            if isinstance(d, (int, np.integer)):
+                dim.dim_value = int(d)
+            elif isinstance(d, str):
+                dim.dim_param = d
+            dims.append(dim)
+        tt.shape = Message("TensorShapeProto", dim=dims)
+    return Message("ValueInfoProto", name=name, type=Message("TypeProto", tensor_type=tt))

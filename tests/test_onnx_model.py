@@ -1,0 +1,497 @@
+"""SURVEY.md 8f rows N4 / N1 on real ONNX files, without the `onnx` package.
+
+* `onnx_proto`: parse / serialize round trips of files written by ANOTHER producer (torch's C++ exporter over the published
+  onnx.proto; tests/golden/make_onnx_fixtures.py) are byte-identical; tensors incl. the 4-bit packing of `core/_pack.py`.
+* `graph_runner`: the parsed graphs run to what the torch modules they were exported from compute.
+* `onnx_functions`: every `quant`-domain function computes what its reference script says (qfunctions/_qdq/*.py,
+  _qlinear/*.py) on plain NumPy restatements of the ONNX operators.
+* `model_quantize`: the reference's pipeline (quantize.py:28-80) on the parsed model -- pre-passes, target selection, the
+  emission of `emission.plan_node` (pinned node by node on the reference's own rule recordings, test_emission.py), functions,
+  opset imports, de-duplication -- with the ORACLE as the numeric provider here; the GPU file runs the same through the
+  device path.
+"""
+import glob
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oq_oracle as O
+from conftest import ROOT
+from onnx_quantize_amd import QActivationArgs, QConfig, QuantType, QWeightArgs, quantize
+from onnx_quantize_amd import onnx_proto as P
+from onnx_quantize_amd.graph_runner import GraphRunner, UnsupportedOperator
+from onnx_quantize_amd.model_quantize import quantize_model
+from onnx_quantize_amd.onnx_functions import build_function, function_names
+
+FIXTURES = os.path.join(ROOT, "tests", "golden", "onnx")
+
+
+def fixture(name):
+    return P.load_model(os.path.join(FIXTURES, name + ".onnx"))
+
+
+def torch_modules():
+    spec = importlib.util.spec_from_file_location("make_onnx_fixtures", os.path.join(ROOT, "tests", "golden", "make_onnx_fixtures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def oracle_weight_arrays(value, cfg, out, nbits):
+    """The numeric provider of the CPU suite: what `seam.weight_arrays` returns, from the oracle."""
+    a = cfg.weights
+    w = value.const_value.numpy()
+    if w.ndim == 1:                                          # QDQ Gemm bias: per-tensor RTN on a vector
+        q, s, z = O.rtn_quantize(w.reshape(1, -1), a.dtype.key, "tensor", -1, a.symmetric, a.reduce_range, a.clip_ratio)
+        return q.reshape(w.shape), s, z
+    x = None if out is None else out.producer().meta.get("input")
+    tag = getattr(a.algorithm, "algorithm_type", "rtn")
+    return O.seam_arrays(w, tag, a.dtype.key, a.strategy.value, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse,
+                         x=x, nbits=nbits)
+
+
+def q_oracle(model, qc):
+    return quantize_model(model, qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
+
+
+# ------------------------------------------------------------------------------------------------------------------ codec
+def test_files_of_another_producer_round_trip_byte_for_byte():
+    paths = sorted(glob.glob(os.path.join(FIXTURES, "*.onnx")))
+    assert len(paths) >= 5
+    for path in paths:
+        data = open(path, "rb").read()
+        model = P.parse_model(data)
+        assert P.serialize(model) == data, path
+        assert P.serialize(model.copy()) == data, path
+
+        def no_unknown(msg):
+            assert not msg._unknown, (path, msg._type)
+            for v in msg._values.values():
+                for e in (v if isinstance(v, list) else [v]):
+                    if isinstance(e, P.Message):
+                        no_unknown(e)
+        no_unknown(model)                                     # every field torch wrote has a name in the schema table
+        assert model.graph.node and model.opset_import[0].version in (17, 21)
+
+
+def test_wire_primitives():
+    t = P.Message("TensorProto", dims=[2, 0, 3], data_type=7, int64_data=[-1, 0, 1 << 40, -(1 << 62)], name="t")
+    back = P.parse("TensorProto", P.serialize(t))
+    assert back.dims == [2, 0, 3] and back.int64_data == [-1, 0, 1 << 40, -(1 << 62)] and back.name == "t"
+    a = P.make_attribute("alpha", 0.25)
+    assert P.attribute_value(P.parse("AttributeProto", P.serialize(a))) == 0.25
+    for value in (7, -3, "text", [1, -2, 3], [0.5, 1.5], ["a", "b"]):
+        got = P.attribute_value(P.parse("AttributeProto", P.serialize(P.make_attribute("v", value))))
+        assert got == value, (value, got)
+    # a field the table has no name for survives a round trip verbatim, after the known ones
+    node = P.make_node("Relu", ["x"], ["y"], name="n")
+    raw = P.serialize(node) + bytes([0x98, 0x06, 0x2A])      # key 99 << 3 | 0 as a two-byte varint, then the value 42
+    back = P.parse("NodeProto", raw)
+    assert back.op_type == "Relu" and len(back._unknown) == 1 and P.serialize(back) == raw
+    with pytest.raises(ValueError, match="past the end|truncated"):
+        P.parse_model(open(os.path.join(FIXTURES, "mlp_gemm.onnx"), "rb").read()[:-7])
+    with pytest.raises(AttributeError):
+        node.no_such_field = 1
+    # present-but-empty optional fields are kept apart from absent ones
+    vi = P.make_value_info("s", P.DataType.FLOAT, [])
+    again = P.parse("ValueInfoProto", P.serialize(vi))
+    assert again.type.tensor_type.shape is not None and again.type.tensor_type.shape.dim == []
+    assert P.parse("ValueInfoProto", P.serialize(P.make_value_info("s", 1, None))).type.tensor_type.shape is None
+
+
+def test_tensors_round_trip_including_four_bit_packing():
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float16, np.float64, np.int8, np.uint8, np.int32, np.int64, np.bool_):
+        a = (rng.standard_normal((3, 5)) * 40).astype(dt)
+        t = P.parse("TensorProto", P.serialize(P.numpy_to_tensor("a", a)))
+        got = P.tensor_to_numpy(t)
+        assert got.dtype == a.dtype and got.shape == a.shape and got.tobytes() == a.tobytes()
+    assert P.tensor_to_numpy(P.numpy_to_tensor("s", np.float32(2.5))).shape == ()
+    for signed, code in ((True, P.DataType.INT4), (False, P.DataType.UINT4)):
+        for shape in ((7,), (3, 5), (4, 6), (1,)):
+            lo, hi = (-8, 8) if signed else (0, 16)
+            a = rng.integers(lo, hi, size=shape).astype(np.int8 if signed else np.uint8)
+            t = P.numpy_to_tensor("q", a, code)
+            assert bytes(t.raw_data) == O.pack_nibbles(a).tobytes()          # core/_pack.py:8-22 (pinned by the reference's KATs)
+            got = P.tensor_to_numpy(P.parse("TensorProto", P.serialize(t)))
+            assert got.dtype == a.dtype and np.array_equal(got, a)
+    with pytest.raises(ValueError, match="4-bit range"):
+        P.numpy_to_tensor("q", np.array([16], dtype=np.uint8), P.DataType.UINT4)
+    # typed fields instead of raw_data (how small tensors are often written)
+    t = P.Message("TensorProto", dims=[3], data_type=P.DataType.FLOAT, float_data=[1.0, 2.5, -3.0], name="f")
+    assert P.tensor_to_numpy(P.parse("TensorProto", P.serialize(t))).tolist() == [1.0, 2.5, -3.0]
+    t = P.Message("TensorProto", dims=[2], data_type=P.DataType.INT8, int32_data=[-5, 7], name="i")
+    assert P.tensor_to_numpy(t).tolist() == [-5, 7] and P.tensor_to_numpy(t).dtype == np.int8
+    ext = P.Message("TensorProto", dims=[2], data_type=1, name="e", data_location=1)
+    with pytest.raises(ValueError, match="external"):
+        P.tensor_to_numpy(ext)
+
+
+# ------------------------------------------------------------------------------------------------------------------ runner
+def test_graph_runner_matches_the_exported_torch_modules():
+    fx = torch_modules()
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(64, 48), torch.nn.ReLU(), torch.nn.Linear(48, 16, bias=False)).eval()
+    torch.manual_seed(1)
+    block = fx.Block().eval()
+    torch.manual_seed(2)
+    tied = fx.Tied().eval()
+    gen = torch.Generator().manual_seed(5)
+    cases = [("mlp_gemm", mlp, torch.randn(7, 64, generator=gen), "y"), ("mlp_matmul", mlp, torch.randn(3, 4, 64, generator=gen), "y"),
+             ("block", block, torch.randn(3, 6, 64, generator=gen), "y"), ("tied", tied, torch.randint(0, 40, (2, 7), generator=gen), "logits")]
+    with torch.no_grad():
+        for name, module, x, out in cases:
+            got = GraphRunner(fixture(name), device="cpu")(x)[out]
+            torch.testing.assert_close(got, module(x), rtol=1e-5, atol=1e-5)
+    # taps: only what the wanted values need is run, and model inputs can be asked for
+    m = fixture("block")
+    r = GraphRunner(m, outputs=["/ln1/LayerNormalization_output_0", "x"], device="cpu")
+    assert len(r.nodes) == 1 and set(r(cases[2][2])) == {"/ln1/LayerNormalization_output_0", "x"}
+    with pytest.raises(KeyError, match="no value named"):
+        GraphRunner(m, outputs=["nope"], device="cpu")
+    bad = m.copy()
+    bad.graph.node[11].op_type = "NoSuchOp"
+    with pytest.raises(UnsupportedOperator, match="NoSuchOp"):
+        GraphRunner(bad, device="cpu")(cases[2][2])
+
+
+# ------------------------------------------------------------------------------------------------------------------ functions
+def _np_dq(q, s, z, axis=1):
+    q, s, z = np.asarray(q, np.float32), np.asarray(s, np.float32), np.asarray(z, np.float32)
+    if s.ndim == 1 and q.ndim > 1:
+        shape = [1] * q.ndim
+        shape[axis] = -1
+        s, z = s.reshape(shape), z.reshape(shape)
+    return (q - z) * s
+
+
+def _np_q(x, s, z):
+    lo, hi = (0, 255) if z.dtype == np.uint8 else (-128, 127)
+    return np.clip(np.rint(x / s) + z.astype(np.float32), lo, hi).astype(z.dtype)
+
+
+def _np_dynq(x):
+    lo, hi = min(float(x.min()), 0.0), max(float(x.max()), 0.0)
+    s = np.float32((hi - lo) / 255.0)
+    z = np.uint8(np.rint(np.clip(-lo / s, 0, 255)))
+    return np.clip(np.rint(x / s) + np.float32(z), 0, 255).astype(np.uint8), s, z
+
+
+def _call(fn, inputs, attrs=None):
+    """Run ONE call of `fn` through the graph runner: a model whose only node is the call."""
+    names = [f"i{k}" for k in range(len(inputs))]
+    node = P.make_node(fn.name, names, ["out"], domain="quant", **(attrs or {}))
+    g = P.Message("GraphProto", node=[node], name="g", input=[P.make_value_info(n, 1, None) for n in names],
+                  output=[P.make_value_info("out", 1, None)])
+    model = P.Message("ModelProto", ir_version=10, graph=g, functions=[fn],
+                      opset_import=[P.Message("OperatorSetIdProto", domain="", version=21), P.Message("OperatorSetIdProto", domain="quant", version=1),
+                                    P.Message("OperatorSetIdProto", domain="com.microsoft", version=1)])
+    model = P.parse_model(P.serialize(model))                 # through the wire, like a file
+    return GraphRunner(model, device="cpu")(dict(zip(names, inputs)))["out"].numpy()
+
+
+def test_every_quant_function_computes_its_reference_script():
+    rng = np.random.default_rng(3)
+    k, n = 32, 12
+    x = rng.standard_normal((5, k)).astype(np.float32)
+    w = (rng.standard_normal((k, n)) * 0.1).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.05).astype(np.float32)
+    wq, ws, wz = O.rtn_quantize(w, "int8", "channel", -1, False)
+    bq, bs, bz = O.rtn_quantize(bias.reshape(1, -1), "int8", "tensor", -1, False)
+    bq = bq.reshape(-1)
+    xs, xz = np.float32(0.03), np.uint8(120)
+    os_, oz = np.float32(0.05), np.uint8(131)
+    wd, bd = _np_dq(wq, ws, wz), _np_dq(bq, bs, bz)
+    seen = set()
+    for name in function_names():
+        if "Grouped" in name or name.startswith("QLinear"):
+            continue
+        gemm = name.startswith("QGemm")
+        fn = build_function(name)
+        static_in, static_out = "x_scale" in fn.input, "out_scale" in fn.input
+        dyn_in = "DynamicInput" in name
+        dyn_out = "DynamicOutput" in name or "DynamicInputOutput" in name
+        args = [x, wq] + ([bq] if gemm else []) + [ws, wz] + ([bs, bz] if gemm else [])
+        args += ([xs, xz] if static_in else []) + ([os_, oz] if static_out else [])
+        assert len(args) == len(fn.input), (name, list(fn.input))
+        xin = x
+        if static_in:
+            xin = _np_dq(_np_q(x, xs, xz), xs, xz)
+        elif dyn_in:
+            q, s, z = _np_dynq(x)
+            xin = _np_dq(q, s, z)
+        want = xin @ wd + (bd if gemm else 0)
+        if static_out:
+            want = _np_dq(_np_q(want, os_, oz), os_, oz)
+        elif dyn_out:
+            q, s, z = _np_dynq(want)
+            want = _np_dq(q, s, z)
+        got = _call(fn, args)
+        # a value on a rounding boundary may fall either way between NumPy and torch: one quantization step of slack
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=(float(os_) if (static_out or dyn_out) else 1e-5) + 1e-5, err_msg=name)
+        seen.add(name)
+    assert len(seen) == 14
+    # grouped: W [K, N] int8 | int4 / uint4 containers, parameters [N*K/g, 1] (rtn.py:106-109)
+    for qtype in ("int8", "int4", "uint4"):
+        g = 8
+        q, s, z = O.rtn_quantize(w, qtype, "group", g, False)
+        wd_g = O.dequantize(q, s, z, rows_of="group", group_size=g)
+        shape_t = np.asarray(w.T.shape, dtype=np.int64)
+        for op in ("MatMul", "Gemm"):
+            fn = build_function(f"Q{op}WeightsOnlyGrouped", group_size=g, four_bit=qtype != "int8")
+            args = [x, q] + ([bq] if op == "Gemm" else []) + [s, z] + ([bs, bz] if op == "Gemm" else []) + [shape_t]
+            got = _call(fn, args, {"num_bits": 8})
+            np.testing.assert_allclose(got, x @ wd_g + (bd if op == "Gemm" else 0), rtol=1e-5, atol=1e-5)
+    # QLinear: integer operators between Q and DQ
+    wq8, ws8, wz8 = O.rtn_quantize(w, "int8", "tensor", -1, True)
+    acc = (_np_q(x, xs, xz).astype(np.float32) - np.float32(xz)) * xs @ _np_dq(wq8, ws8, wz8)
+    got = _call(build_function("QLinearMatMul"), [x, wq8, ws8, wz8, xs, xz, os_, oz])
+    np.testing.assert_allclose(got, _np_dq(_np_q(acc, os_, oz), os_, oz), rtol=1e-5, atol=float(os_) + 1e-5)
+    b32, _, _ = O.quantize_bias(bias, xs, ws8)
+    got = _call(build_function("QLinearGemm"), [x, wq8, b32, ws8, wz8, xs, xz, os_, oz])
+    acc_b = acc + b32.astype(np.float32) * (xs * ws8)
+    np.testing.assert_allclose(got, _np_dq(_np_q(acc_b, os_, oz), os_, oz), rtol=1e-5, atol=float(os_) + 1e-5)
+    with pytest.raises(KeyError):
+        build_function("QNothing")
+    with pytest.raises(ValueError, match="group size"):
+        build_function("QMatMulWeightsOnlyGrouped")
+
+
+# ------------------------------------------------------------------------------------------------------------------ pipeline
+CONFIGS = {
+    "int8_tensor_sym": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, symmetric=True)),          # BASELINE config 1
+    "uint4_g32": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=32)),                # config 2's shape of rule
+    "int4_g32": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=32)),
+    "int8_channel": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, group_size=-1)),
+    "uint8_g16": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QUInt8, group_size=16)),
+}
+
+
+def _weights_of(model):
+    """{node name: (op, weight [K, N] with transB applied, bias | None)} of the float model's MatMul / Gemm nodes."""
+    inits = {t.name: t for t in model.graph.initializer}
+    out = {}
+    for n in model.graph.node:
+        if n.op_type in ("MatMul", "Gemm") and len(n.input) > 1 and n.input[1] in inits:
+            w = P.tensor_to_numpy(inits[n.input[1]])
+            if n.op_type == "Gemm" and any(a.name == "transB" and a.i for a in n.attribute):
+                w = w.T
+            b = P.tensor_to_numpy(inits[n.input[2]]) if len(n.input) > 2 and n.input[2] in inits else None
+            out[n.name] = (n.op_type, np.ascontiguousarray(w), b)
+    return out
+
+
+@pytest.mark.parametrize("cfg", sorted(CONFIGS))
+@pytest.mark.parametrize("name", ["mlp_gemm", "mlp_matmul", "block", "wide_matmul", "tied"])
+def test_quantized_model_structure_and_numbers(name, cfg):
+    src = fixture(name)
+    before = P.serialize(src)
+    qc = CONFIGS[cfg]()
+    a = qc.weights
+    out = P.parse_model(P.serialize(q_oracle(src, qc)))       # through the wire
+    assert P.serialize(src) == before                         # the caller's model is not touched (ir.from_proto copies)
+    floats = _weights_of(src)
+    inits = {t.name: t for t in out.graph.initializer}
+    assert len(inits) == len(out.graph.initializer)           # unique names
+    by_name = {n.name: n for n in out.graph.node}
+    assert {o.domain or "": o.version for o in out.opset_import}[""] == 21 and out.ir_version >= 10
+    used_domains, used_fns = set(), set()
+    for node_name, (op, w, b) in floats.items():
+        n = by_name[node_name]
+        k = w.shape[0]
+        g = O.resolve_group_size(k, a.group_size) if a.strategy.value == "group" else a.group_size
+        nbits = O.matmul_nbits_compatible(a.dtype.key, a.strategy.value, g)
+        wname = n.input[1]
+        q, s, z = O.seam_arrays(w, "rtn", a.dtype.key, a.strategy.value, g, a.symmetric, a.reduce_range, a.clip_ratio, a.mse, nbits=nbits)
+        # parameters by position in the call: byte-identical initializers of different weights are ONE initializer after
+        # DeduplicateInitializersPass (quantize.py:75), e.g. the 0-d zero point 0 of every symmetric weight
+        gemm_call = n.op_type.startswith("QGemm")
+        sname, zname = (n.input[3], n.input[4]) if gemm_call else (n.input[2], n.input[3])
+        got_q, got_s, got_z = (P.tensor_to_numpy(inits[v]) for v in (wname, sname, zname))
+        assert np.array_equal(got_q, q) and got_s.tobytes() == np.asarray(s).tobytes() and np.array_equal(got_z, z), (node_name, cfg)
+        if nbits:
+            assert (n.op_type, n.domain) == ("MatMulNBits", "com.microsoft")
+            attrs = {x.name: P.attribute_value(x) for x in n.attribute}
+            assert attrs == dict(K=k, N=w.shape[1], bits=a.dtype.bitwidth, block_size=g)
+            assert list(n.input)[:5] == [n.input[0], wname, sname, zname, ""]
+            assert inits[wname].data_type == P.DataType.UINT8
+            if b is not None:
+                assert len(n.input) == 6 and inits[n.input[5]].data_type == P.DataType.FLOAT        # the bias stays float
+        else:
+            assert n.domain == "quant"
+            want_code = {"int8": P.DataType.INT8, "uint8": P.DataType.UINT8, "int4": P.DataType.INT4, "uint4": P.DataType.UINT4}[a.dtype.key]
+            assert inits[wname].data_type == want_code and inits[zname].data_type == want_code
+            family = "Gemm" if (op == "Gemm" and b is not None) else "MatMul"
+            grouped = a.strategy.value == "group"
+            assert n.op_type == f"Q{family}WeightsOnly" + ("Grouped" if grouped else "QDQ")
+            assert {x.name: P.attribute_value(x) for x in n.attribute} == {"num_bits": a.dtype.bitwidth}
+            if grouped:
+                assert P.tensor_to_numpy(inits[n.input[-1]]).tolist() == [w.shape[1], w.shape[0]]
+            if family == "Gemm":
+                # the bias config passes `is_symmetric=`, a keyword QWeightArgs ignores (gemm_to_qgemm.py:47-62): asymmetric always
+                bq, bs, bz = O.rtn_quantize(b.reshape(1, -1), a.dtype.key, "tensor", -1, False, a.reduce_range, a.clip_ratio)
+                assert np.array_equal(P.tensor_to_numpy(inits[n.input[2]]), bq.reshape(-1))
+                assert inits[n.input[2]].data_type == want_code
+            used_fns.add((n.op_type, n.overload or ""))
+        used_domains.add(n.domain)
+    # functions: exactly the ones the calls use; opset imports: exactly the domains in use
+    assert {(f.name, f.overload or "") for f in out.functions} == used_fns
+    assert all(f.domain == "quant" for f in out.functions)
+    assert {o.domain for o in out.opset_import if o.domain} == used_domains
+    # no leftovers of the float weights, and nothing dangling
+    produced = {o for n in out.graph.node for o in n.output} | set(inits) | {i.name for i in out.graph.input}
+    assert all(v in produced for n in out.graph.node for v in n.input if v)
+    assert not [n.name for n in out.graph.node if n.domain and inits[n.input[1]].data_type == P.DataType.FLOAT]
+    # the quantized model computes the float model with every weight replaced by its dequantized value
+    gen = torch.Generator().manual_seed(11)
+    feed = {"mlp_gemm": torch.randn(5, 64, generator=gen), "mlp_matmul": torch.randn(2, 3, 64, generator=gen),
+            "block": torch.randn(2, 6, 64, generator=gen), "wide_matmul": torch.randn(2, 3, 256, generator=gen),
+            "tied": torch.randint(0, 40, (2, 7), generator=gen)}[name]
+    fake = src.copy()
+    for n in list(fake.graph.node):
+        if n.name in floats:
+            op, w, b = floats[n.name]
+            g = O.resolve_group_size(w.shape[0], a.group_size) if a.strategy.value == "group" else a.group_size
+            q, s, z = O.rtn_quantize(w, a.dtype.key, a.strategy.value, g if g is not None else -1, a.symmetric, a.reduce_range, a.clip_ratio)
+            wd = O.dequantize(q, s, z, rows_of=a.strategy.value, group_size=g if g is not None else -1).astype(np.float32)
+            transposed = n.op_type == "Gemm" and any(x.name == "transB" and x.i for x in n.attribute)
+            new_name = f"{n.input[1]}@{n.name}"                     # tied weights: each consumer has its own dequantized copy
+            fake.graph.initializer.append(P.numpy_to_tensor(new_name, np.ascontiguousarray(wd.T if transposed else wd)))
+            ins = list(n.input)
+            ins[1] = new_name
+            nbits = O.matmul_nbits_compatible(a.dtype.key, a.strategy.value, g)
+            if op == "Gemm" and b is not None and not nbits:
+                bq, bs, bz = O.rtn_quantize(b.reshape(1, -1), a.dtype.key, "tensor", -1, False, a.reduce_range, a.clip_ratio)
+                bname = f"{n.input[2]}@{n.name}"
+                fake.graph.initializer.append(P.numpy_to_tensor(bname, ((bq.astype(np.float32) - np.float32(bz)) * bs).reshape(-1).astype(np.float32)))
+                ins[2] = bname
+            n.input = ins
+    want = GraphRunner(fake, device="cpu")(feed)
+    got = GraphRunner(out, device="cpu")(feed)
+    for key in want:
+        torch.testing.assert_close(got[key], want[key], rtol=2e-5, atol=2e-5)
+
+
+def test_pre_passes_follow_the_reference():
+    # StandarizeGemm: transB = 1 becomes transB = 0 with the weight transposed; the re-emitted node carries transB only
+    src = fixture("mlp_gemm")
+    w_before = P.tensor_to_numpy(next(t for t in src.graph.initializer if t.name == "0.weight"))
+    assert w_before.shape == (48, 64)
+    out = q_oracle(src, CONFIGS["int8_channel"]())
+    gemm = out.graph.node[0]
+    assert gemm.op_type == "QGemmWeightsOnlyQDQ" and P.tensor_to_numpy(next(t for t in out.graph.initializer if t.name == "0.weight")).shape == (64, 48)
+    # DuplicateInitializersPass: the second consumer of a tied matrix gets `<name>_1` and is quantized on its own ...
+    import onnx_quantize_amd.model_quantize as MQ
+    tied = MQ.as_model(fixture("tied"))
+    MQ._duplicate_shared_initializers(MQ._Graph(tied.graph))
+    assert [n.input[1] for n in tied.graph.node if n.op_type == "MatMul"] == ["w", "w_1"]
+    assert [t.name for t in tied.graph.initializer] == ["w", "emb.weight", "w_1"]
+    # ... and DeduplicateInitializersPass folds what is byte-identical afterwards: same weight -> same q, scale and zero point
+    out = q_oracle(fixture("tied"), CONFIGS["int8_tensor_sym"]())
+    mm = [n for n in out.graph.node if n.domain == "quant"]
+    names = [t.name for t in out.graph.initializer]
+    assert "w" in names and "w_1" not in names and "w_1/scale" not in names
+    assert [list(n.input[1:]) for n in mm] == [["w", "w/scale", "w/zero_point"]] * 2
+    # `ignore`: regular expressions searched in node names (calibrate.py:63-70)
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), ignore=[r"/(q|k)/MatMul$", "down"])
+    out = q_oracle(fixture("block"), qc)
+    kept = {n.name for n in out.graph.node if n.op_type == "MatMul"}
+    assert {"/q/MatMul", "/k/MatMul", "/down/MatMul"} <= kept and "/v/MatMul" not in kept
+    # target_op_types: Gemm only
+    out = q_oracle(fixture("mlp_gemm"), QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), target_op_types=["Gemm"]))
+    assert [n.op_type for n in out.graph.node] == ["QGemmWeightsOnlyQDQ", "Relu", "MatMul"]
+    # MatMul + Add on matrices -> Gemm (onnxscript's matmul_add_to_gemm_rule), then quantized as a Gemm with bias
+    x2 = P.make_value_info("x", 1, ["batch", 64])
+    w = np.random.default_rng(0).standard_normal((64, 8)).astype(np.float32)
+    b = np.linspace(-1, 1, 8, dtype=np.float32)
+    g = P.Message("GraphProto", name="g", input=[x2], output=[P.make_value_info("y", 1, ["batch", 8])],
+                  node=[P.make_node("MatMul", ["x", "w"], ["mm"], name="mm"), P.make_node("Add", ["mm", "b"], ["y"], name="add")],
+                  initializer=[P.numpy_to_tensor("w", w), P.numpy_to_tensor("b", b)])
+    model = P.Message("ModelProto", ir_version=8, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=17)])
+    out = q_oracle(model, CONFIGS["int8_channel"]())
+    assert [n.op_type for n in out.graph.node] == ["QGemmWeightsOnlyQDQ"] and list(out.graph.node[0].input)[:3] == ["x", "w", "b"]
+    x = torch.randn(3, 64)
+    torch.testing.assert_close(GraphRunner(out, device="cpu")(x)["y"], GraphRunner(model, device="cpu")(x)["y"], rtol=0.05, atol=0.05)
+    # rank-3 input: the rule does not apply, MatMul and Add stay apart
+    g.input = [P.make_value_info("x", 1, ["batch", 4, 64])]
+    out = q_oracle(model, CONFIGS["int8_channel"]())
+    assert [n.op_type for n in out.graph.node] == ["QMatMulWeightsOnlyQDQ", "Add"]
+
+
+def test_opset_is_raised_with_adapters_or_refused_by_name():
+    x = P.make_value_info("x", 1, ["batch", 16])
+    w = np.random.default_rng(1).standard_normal((16, 4)).astype(np.float32)
+
+    def model(extra_nodes, opset):
+        g = P.Message("GraphProto", name="g", input=[x], output=[P.make_value_info("y", 1, None)],
+                      node=[P.make_node("MatMul", ["x", "w"], ["h"], name="fc")] + extra_nodes, initializer=[P.numpy_to_tensor("w", w)])
+        return P.Message("ModelProto", ir_version=7, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=opset)])
+
+    m = model([P.make_node("ReduceMean", ["h"], ["y"], name="rm", axes=[-1], keepdims=0)], 13)
+    out = q_oracle(m, CONFIGS["int8_channel"]())
+    rm = out.graph.node[1]
+    assert rm.op_type == "ReduceMean" and len(rm.input) == 2 and [a.name for a in rm.attribute] == ["keepdims"]
+    assert P.tensor_to_numpy(next(t for t in out.graph.initializer if t.name == rm.input[1])).tolist() == [-1]
+    xin = torch.randn(5, 16)
+    torch.testing.assert_close(GraphRunner(out, device="cpu")(xin)["y"], GraphRunner(m, device="cpu")(xin)["y"], rtol=0.05, atol=0.05)
+    m = model([P.make_node("Split", ["h"], ["y", "y2"], name="sp", axis=1)], 13)
+    out = q_oracle(m, CONFIGS["int8_channel"]())
+    assert {a.name: P.attribute_value(a) for a in out.graph.node[1].attribute} == {"axis": 1, "num_outputs": 2}
+    with pytest.raises(NotImplementedError, match="Resize"):
+        q_oracle(model([P.make_node("Resize", ["h", "", "s"], ["y"], name="rs")], 13), CONFIGS["int8_channel"]())
+    with pytest.raises(NotImplementedError, match="opset 11"):
+        q_oracle(model([P.make_node("Relu", ["h"], ["y"], name="r")], 11), CONFIGS["int8_channel"]())
+    out = q_oracle(model([P.make_node("Relu", ["h"], ["y"], name="r")], 22), CONFIGS["int8_channel"]())
+    assert out.opset_import[0].version == 22                  # newer models keep their opset
+
+
+def test_mixed_group_sizes_stay_correct_as_overloads():
+    """qmatmul.py:218-236 registers one function per group size under ONE name and qfunctions/__init__.py:17-20 keeps the
+    last: a model whose weights resolve to different group sizes (base.py:72) would call it with the wrong block size.  The
+    writer emits one overload per size."""
+    out = q_oracle(fixture("mlp_matmul"), CONFIGS["int4_g32"]())          # K = 64 -> g 32; K = 48 -> g 48
+    fns = {(f.name, f.overload) for f in out.functions}
+    assert fns == {("QMatMulWeightsOnlyGrouped", "g32"), ("QMatMulWeightsOnlyGrouped", "g48")}
+    calls = [(n.overload, n.input[1]) for n in out.graph.node if n.domain == "quant"]
+    assert [c[0] for c in calls] == ["g32", "g48"]
+    out = q_oracle(fixture("block"), CONFIGS["int4_g32"]())               # one size: no overload, the reference's shape
+    assert [(f.name, f.overload) for f in out.functions] == [("QMatMulWeightsOnlyGrouped", None)]
+
+
+def test_quantize_entry_point_routes_bytes_paths_and_parsed_models(tmp_path, monkeypatch):
+    import onnx_quantize_amd.model_quantize as MQ
+    real = MQ.quantize_model
+    monkeypatch.setattr(MQ, "quantize_model", lambda m, qc, **kw: real(m, qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias))
+    path = os.path.join(FIXTURES, "mlp_matmul.onnx")
+    data = open(path, "rb").read()
+    qc = CONFIGS["int8_channel"]()
+    out_bytes = quantize(data, qc)
+    assert isinstance(out_bytes, bytes) and P.parse_model(out_bytes).functions[0].name == "QMatMulWeightsOnlyQDQ"
+    out_msg = quantize(path, qc)
+    assert isinstance(out_msg, P.Message) and P.serialize(out_msg) == out_bytes
+    assert P.serialize(quantize(P.parse_model(data), qc)) == out_bytes
+    assert quantize(data, QConfig()) is data                             # nothing to quantize: the model comes back as it is
+    dst = tmp_path / "q.onnx"
+    MQ.quantize_file(path, dst, qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
+    assert dst.read_bytes() == out_bytes
+    with pytest.raises(NotImplementedError, match="preprocessors"):
+        from onnx_quantize_amd import SmoothQuantConfig
+        quantize(data, QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), preprocessors=[SmoothQuantConfig()]))
+    with pytest.raises(TypeError):
+        MQ.as_model(3.5)
+    with pytest.raises(TypeError, match="QConfig"):
+        real(data, {"weights": None})
+
+
+def test_static_and_gptq_configurations_need_the_device(monkeypatch):
+    """Calibration runs through the HIP library (no CPU fallback): without a GPU the call fails loudly, it does not quantize
+    with something else."""
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_onnx_model_gpu.py runs these configurations")
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=QActivationArgs(dtype=QuantType.QUInt8))
+    with pytest.raises(Exception) as e:
+        q_oracle(fixture("mlp_matmul"), qc)
+    assert not isinstance(e.value, (AssertionError, KeyError)), e.value
