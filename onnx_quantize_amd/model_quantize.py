@@ -401,10 +401,11 @@ class _Out:
         return self
 
 
-def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None) -> Message:
+def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None, calibrate=None) -> Message:
     """quantize.py:28-80 on a parsed ModelProto / ONNX bytes / a path.  Returns a new parsed ModelProto (`onnx_proto.serialize`
-    gives the file).  `weight_arrays` / `quantize_bias`: the numeric providers (default: the device-resident seam and the HIP
-    bias kernel; tests inject the oracle)."""
+    gives the file).  `weight_arrays` / `quantize_bias` / `calibrate`: the numeric providers (default: the device-resident
+    seam, the HIP bias kernel and the on-device calibration walk `_calibrate`; tests inject the oracle).  `calibrate(model,
+    graph view, target nodes, qconfig, device)` returns {id(node): meta} like `_calibrate`."""
     if not isinstance(qconfig, QConfig):
         raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
     model = as_model(model)
@@ -425,7 +426,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     _fuse_matmul_add(G)
     _standardize_gemm(G)
     targets = _target_nodes(G, qconfig)
-    meta = _calibrate(model, G, targets, qconfig, device) if (_needs_calibration(qconfig) and targets) else {}
+    meta = (calibrate or _calibrate)(model, G, targets, qconfig, device) if (_needs_calibration(qconfig) and targets) else {}
 
     used_functions: dict = {}
     domains = set()

@@ -45,8 +45,13 @@ def upload(a: np.ndarray):
     when this returns the bytes have left ``a`` (and any temporary made of it)."""
     import torch
 
+    import warnings
+
     src = np.ascontiguousarray(a, dtype=np.float32)
-    return torch.from_numpy(src).to(_device(), non_blocking=False)
+    with warnings.catch_warnings():
+        # a read-only source (a view into the bytes of a model file, model_quantize.py) is only read here
+        warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+        return torch.from_numpy(src).to(_device(), non_blocking=False)
 
 
 def download(t, dtype=None) -> np.ndarray:

@@ -23,14 +23,9 @@ from conftest import ROOT
 from onnx_quantize_amd import QActivationArgs, QConfig, QuantType, QWeightArgs, quantize
 from onnx_quantize_amd import onnx_proto as P
 from onnx_quantize_amd.graph_runner import GraphRunner, UnsupportedOperator
-from onnx_quantize_amd.model_quantize import quantize_model
 from onnx_quantize_amd.onnx_functions import build_function, function_names
 
-FIXTURES = os.path.join(ROOT, "tests", "golden", "onnx")
-
-
-def fixture(name):
-    return P.load_model(os.path.join(FIXTURES, name + ".onnx"))
+from onnx_model_helpers import FIXTURES, fixture, oracle_calibrate, oracle_weight_arrays, q_oracle
 
 
 def torch_modules():
@@ -38,23 +33,6 @@ def torch_modules():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
-
-
-def oracle_weight_arrays(value, cfg, out, nbits):
-    """The numeric provider of the CPU suite: what `seam.weight_arrays` returns, from the oracle."""
-    a = cfg.weights
-    w = value.const_value.numpy()
-    if w.ndim == 1:                                          # QDQ Gemm bias: per-tensor RTN on a vector
-        q, s, z = O.rtn_quantize(w.reshape(1, -1), a.dtype.key, "tensor", -1, a.symmetric, a.reduce_range, a.clip_ratio)
-        return q.reshape(w.shape), s, z
-    x = None if out is None else out.producer().meta.get("input")
-    tag = getattr(a.algorithm, "algorithm_type", "rtn")
-    return O.seam_arrays(w, tag, a.dtype.key, a.strategy.value, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse,
-                         x=x, nbits=nbits)
-
-
-def q_oracle(model, qc):
-    return quantize_model(model, qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
 
 
 # ------------------------------------------------------------------------------------------------------------------ codec
@@ -486,12 +464,120 @@ def test_quantize_entry_point_routes_bytes_paths_and_parsed_models(tmp_path, mon
         real(data, {"weights": None})
 
 
-def test_static_and_gptq_configurations_need_the_device(monkeypatch):
+def test_calibrated_configurations_need_the_device_by_default():
     """Calibration runs through the HIP library (no CPU fallback): without a GPU the call fails loudly, it does not quantize
     with something else."""
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: tests/test_onnx_model_gpu.py runs these configurations")
+    from onnx_quantize_amd.model_quantize import quantize_model
     qc = QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=QActivationArgs(dtype=QuantType.QUInt8))
     with pytest.raises(Exception) as e:
-        q_oracle(fixture("mlp_matmul"), qc)
+        quantize_model(fixture("mlp_matmul"), qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
     assert not isinstance(e.value, (AssertionError, KeyError)), e.value
+
+
+def _act(dt, static=True):
+    return QActivationArgs(dtype=QuantType.from_string(dt), is_static=static)
+
+
+CALIBRATED = {
+    # BASELINE config 3: static int8 activations on both sides, QDQ
+    "static_qdq": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=_act("int8"), output_activations=_act("int8")),
+    "static_input_only": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QUInt8, group_size=-1), input_activations=_act("uint8")),
+    "static_output_momentum": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, symmetric=True), output_activations=_act("uint8"),
+                                              calibration_params={"momentum": 0.5, "num_samples": 24, "batch_size": 6}),
+    "dynamic_in_out": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=_act("uint8", False),
+                                      output_activations=_act("uint8", False)),
+    "qlinear": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, symmetric=True), format="qlinear",
+                               input_activations=_act("uint8"), output_activations=_act("uint8")),
+}
+
+
+def _feeds(name, gen):
+    return {"mlp_gemm": lambda: torch.randn(5, 64, generator=gen), "mlp_matmul": lambda: torch.randn(2, 3, 64, generator=gen),
+            "block": lambda: torch.randn(2, 6, 64, generator=gen)}[name]()
+
+
+@pytest.mark.parametrize("cfg", sorted(CALIBRATED))
+@pytest.mark.parametrize("name", ["mlp_gemm", "mlp_matmul", "block"])
+def test_calibrated_configurations_with_the_oracle_as_provider(name, cfg):
+    """calibrate.py:310-380 + `_get_activation_qparams` (qrules/base.py:15-40): initializers `<node output>/<kind>/scale` and
+    `/zero_point` hold what the calibrator computed for the node's input / output value; the call takes them in the order
+    of the function's signature."""
+    qc = CALIBRATED[cfg]()
+    gen = torch.Generator().manual_seed(21)
+    data = torch.randn(30, *_feeds(name, gen).shape[1:], generator=gen).numpy()
+    qc.calibration_data = data
+    src = fixture(name)
+    out = P.parse_model(P.serialize(q_oracle(src, qc)))
+    inits = {t.name: t for t in out.graph.initializer}
+    # the expected ranges, straight from the oracle on the float model's activations
+    targets = [n for n in src.graph.node if n.op_type in ("MatMul", "Gemm") and n.input[1] in {t.name for t in src.graph.initializer}]
+    params = qc.calibration_params
+    batches = O.prepare_calibration_data(data, params.batch_size, params.num_samples)
+    names = list(dict.fromkeys([n.input[0] for n in targets] + [n.output[0] for n in targets]))
+    runner = GraphRunner(src, outputs=names, device="cpu")
+    acts = [{k: v.numpy() for k, v in runner(torch.from_numpy(np.ascontiguousarray(b))).items()} for b in batches]
+    cal_in = qc.input_activations is not None and qc.input_activations.is_static
+    cal_out = qc.output_activations is not None and qc.output_activations.is_static
+    key = lambda a: (a.dtype.key, a.symmetric, a.reduce_range)      # noqa: E731
+    flow = O.calibrate_flow([{k: b[k] for k in ([n.input[0] for n in targets] if cal_in else []) + ([n.output[0] for n in targets] if cal_out else [])}
+                             for b in acts], [n.input[0] for n in targets] if cal_in else [], [n.output[0] for n in targets] if cal_out else [],
+                            params.momentum, key(qc.input_activations) if cal_in else None, key(qc.output_activations) if cal_out else None)
+    by_name = {n.name: n for n in out.graph.node}
+    for t in targets:
+        n = by_name[t.name]
+        assert n.domain == "quant"
+        fn = next(f for f in out.functions if f.name == n.op_type)
+        assert len(n.input) == len(fn.input), (n.op_type, list(n.input), list(fn.input))
+        for kind, on, value in (("input", cal_in, t.input[0]), ("output", cal_out, t.output[0])):
+            if not on:
+                assert f"{t.output[0]}/{kind}/scale" not in inits
+                continue
+            s, z = flow[(kind, value)]
+            prefix = "x" if kind == "input" else "out"
+            s_name, z_name = (n.input[list(fn.input).index(f"{prefix}_{p}")] for p in ("scale", "zero_point"))
+            # (names may have been folded by DeduplicateInitializersPass: read through the call)
+            assert P.tensor_to_numpy(inits[s_name]).tobytes() == np.asarray(s, np.float32).tobytes(), (t.name, kind)
+            got_z = P.tensor_to_numpy(inits[z_name])
+            assert got_z.dtype == getattr(qc, f"{kind}_activations").dtype.np_dtype and int(got_z) == int(z)
+            assert f"{t.output[0]}/{kind}/scale" in inits or s_name != f"{t.output[0]}/{kind}/scale"
+    if cfg == "qlinear":
+        assert {n.op_type for n in out.graph.node if n.domain} == ({"QLinearMatMul", "QLinearGemm"} if name == "mlp_gemm" else {"QLinearMatMul"})
+        if name == "mlp_gemm":
+            gemm = by_name["/0/Gemm"]
+            assert inits[gemm.input[2]].data_type == P.DataType.INT32            # bias / (x_scale * w_scale) (_qlinear/gemm_to_qgemm.py:48-57)
+            assert {o.domain for o in out.opset_import} >= {"quant", "com.microsoft"}
+    # the quantized model still computes the model: 8-bit everywhere, a few percent
+    feed = _feeds(name, gen)
+    want, got = GraphRunner(src, device="cpu")(feed), GraphRunner(out, device="cpu")(feed)
+    for k in want:
+        rel = ((got[k] - want[k]).norm() / want[k].norm()).item()
+        assert rel < (0.25 if "momentum" in cfg else 0.08), (name, cfg, rel)     # an EMA of batch ranges clips the tails
+
+
+def test_gptq_configuration_with_the_oracle_as_provider():
+    """BASELINE config 4's rule path (int4, groups, GPTQ): every node's weight comes from `_gptq` on the concatenated calibration
+    input of THAT node (calibrate.py:288-307); q / k / v read the same value and get the same input."""
+    from onnx_quantize_amd import GPTQConfig
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=32, algorithm=GPTQConfig(block_size=16)),
+                 calibration_params={"num_samples": 16, "batch_size": 4})
+    gen = torch.Generator().manual_seed(33)
+    data = torch.randn(16, 6, 64, generator=gen).numpy()
+    qc.calibration_data = data
+    src = fixture("block")
+    out = P.parse_model(P.serialize(q_oracle(src, qc)))
+    inits = {t.name: t for t in out.graph.initializer}
+    runner = GraphRunner(src, outputs=["/ln1/LayerNormalization_output_0"], device="cpu")
+    x = np.concatenate([runner(torch.from_numpy(np.ascontiguousarray(b)))["/ln1/LayerNormalization_output_0"].numpy()
+                        for b in O.prepare_calibration_data(data, 4, 16)], axis=0)
+    for node_name in ("/q/MatMul", "/k/MatMul", "/v/MatMul"):
+        n = next(m for m in out.graph.node if m.name == node_name)
+        w = P.tensor_to_numpy(next(t for t in src.graph.initializer if t.name == n.input[1]))
+        q, s, z = O.seam_arrays(w, "gptq", "int4", "group", 32, False, False, 1.0, False, x=x, nbits=False, block_size=16, percdamp=0.01, actorder=False)
+        assert n.op_type == "QMatMulWeightsOnlyGrouped" and inits[n.input[1]].data_type == P.DataType.INT4
+        assert np.array_equal(P.tensor_to_numpy(inits[n.input[1]]), q)
+        assert P.tensor_to_numpy(inits[n.input[2]]).tobytes() == np.asarray(s).tobytes()
+    feed = torch.randn(2, 6, 64, generator=gen)
+    want, got = GraphRunner(src, device="cpu")(feed)["y"], GraphRunner(out, device="cpu")(feed)["y"]
+    assert ((got - want).norm() / want.norm()).item() < 0.08
