@@ -357,9 +357,23 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> 
 
 
 # ------------------------------------------------------------------------------------------------------------ post passes
+def _same_bytes(a, b) -> bool:
+    """Content equality of two byte buffers, cheap when they differ: a few samples first, the whole only when those agree
+    (weights of one shape are legion in a transformer and never equal; hashing them all would read the whole model)."""
+    n = len(a)
+    if n != len(b):
+        return False
+    if n > 4096:
+        step = max(1, n // 64)
+        for off in list(range(0, n - 64, step)) + [n - 64]:
+            if a[off:off + 64] != b[off:off + 64]:
+                return False
+    return a == b
+
+
 def _deduplicate_initializers(G: _Graph, size_limit: float = 1e9) -> None:
     """`DeduplicateInitializersPass(size_limit=1e9)` (quantize.py:75): initializers with the same element type, shape and
-    bytes become one; graph inputs / outputs and string tensors are left alone."""
+    bytes become one (the first in graph order stays); graph inputs / outputs and string tensors are left alone."""
     seen: dict = {}
     rename: dict = {}
     keep = []
@@ -368,10 +382,11 @@ def _deduplicate_initializers(G: _Graph, size_limit: float = 1e9) -> None:
                 or len(t.raw_data) > size_limit:
             keep.append(t)
             continue
-        key = (t.data_type, tuple(t.dims), bytes(t.raw_data))
-        first = seen.get(key)
+        raw = t.raw_data if isinstance(t.raw_data, memoryview) else memoryview(t.raw_data)
+        candidates = seen.setdefault((t.data_type, tuple(t.dims), len(raw)), [])
+        first = next((name for name, other in candidates if _same_bytes(raw, other)), None)
         if first is None:
-            seen[key] = t.name
+            candidates.append((t.name, raw))
             keep.append(t)
         else:
             rename[t.name] = first
@@ -476,9 +491,15 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     return model
 
 
-def quantize_file(src, dst, qconfig: QConfig, **kw) -> Message:
-    """Read `src`, quantize, write `dst` (one file, weights inline).  Returns the quantized model."""
+def quantize_file(src, dst, qconfig: QConfig, external_data="auto", **kw) -> Message:
+    """Read `src` (tensors in side files are memory-mapped, not read), quantize, write `dst`.  `external_data`: a file name
+    next to `dst` for the tensors, None for one file with everything inline, "auto" (default): `<dst name>.data` when the
+    source kept its tensors outside or the result would pass 1 GiB, inline otherwise.  Returns the quantized model."""
+    src_model = load_model(src, load_external_data=False)
+    had_external = any(t.data_location for t in src_model.graph.initializer)
     out = quantize_model(load_model(src), qconfig, **kw)
-    save_model(out, dst)
+    if external_data == "auto":
+        size = sum(len(t.raw_data) for t in out.graph.initializer if t.has("raw_data"))
+        external_data = os.path.basename(os.fspath(dst)) + ".data" if (had_external or size > 1 << 30) else None
+    save_model(out, dst, external_data=external_data)
     return out
-

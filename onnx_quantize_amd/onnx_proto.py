@@ -8,19 +8,22 @@ is small: varints, 32 / 64-bit scalars and length-delimited records, with the fi
 (`model.graph.node[0].op_type`), `serialize(message)` gives the bytes back: fields in field-number order, repeated
 scalars packed exactly where `onnx.proto` says `[packed = true]`, absent optional fields absent, fields this table does
 not know kept verbatim -- a parse / serialize round trip of a file another producer wrote is byte-identical
-(tests/test_onnx_proto.py checks that on files written by torch's C++ exporter).
+(tests/test_onnx_model.py checks that on files written by torch's C++ exporter).  Tensors kept in side files (`external_data`,
+what every model past protobuf's 2 GiB limit uses) are memory-mapped on load and can be written back the same way.
 
 Tensors: `tensor_to_numpy` / `numpy_to_tensor` cover the element types the path reads and writes, 4-bit types two per
 byte, low nibble first (`core/_pack.py:8-22`; onnx.proto "INT4 / UINT4": the first element in the 4 LSB).
 """
 from __future__ import annotations
 
+import os
 import struct
 
 import numpy as np
 
-__all__ = ["Message", "parse", "parse_model", "serialize", "load_model", "save_model", "tensor_to_numpy", "numpy_to_tensor",
-           "make_attribute", "attribute_value", "make_node", "make_value_info", "DataType", "AttributeType", "SCHEMA"]
+__all__ = ["Message", "parse", "parse_model", "serialize", "load_model", "save_model", "resolve_external_data", "tensor_to_numpy",
+           "numpy_to_tensor", "make_attribute", "attribute_value", "make_node", "make_value_info", "DataType", "AttributeType",
+           "SCHEMA"]
 
 
 class DataType:
@@ -245,9 +248,58 @@ def parse_model(data) -> Message:
     return parse("ModelProto", data)
 
 
-def load_model(path) -> Message:
+def load_model(path, load_external_data: bool = True) -> Message:
+    """Parse the file at `path`.  Tensors whose bytes live in side files (data_location EXTERNAL: every model past protobuf's
+    2 GiB limit) are mapped, not read: `raw_data` becomes a read-only view of an `np.memmap` window, paged in when something
+    touches it (`load_external_data=False` leaves the references as they are)."""
     with open(path, "rb") as f:
-        return parse_model(f.read())
+        model = parse_model(f.read())
+    if load_external_data:
+        resolve_external_data(model, os.path.dirname(os.path.abspath(path)))
+    return model
+
+
+def _tensors_of(graph):
+    yield from graph.initializer
+    for n in graph.node:
+        for a in n.attribute:
+            if a.has("t"):
+                yield a.t
+            yield from a.tensors
+            if a.has("g"):
+                yield from _tensors_of(a.g)
+            for g in a.graphs:
+                yield from _tensors_of(g)
+
+
+def resolve_external_data(model: Message, base_dir) -> int:
+    """Point every externally stored tensor of `model` at a memory map of its file (keys `location`, `offset`, `length` of
+    onnx.proto's external_data; the location must stay inside `base_dir`).  Returns the number of tensors mapped."""
+    maps: dict = {}
+    count = 0
+    base_dir = os.path.abspath(base_dir)
+    for t in ([] if model.graph is None else _tensors_of(model.graph)):
+        if not t.data_location:
+            continue
+        info = {e.key: e.value for e in t.external_data}
+        location = info.get("location")
+        if not location:
+            raise ValueError(f"onnx_proto: tensor '{t.name}' is external but names no location")
+        path = os.path.abspath(os.path.join(base_dir, location))
+        if os.path.commonpath([base_dir, path]) != base_dir:
+            raise ValueError(f"onnx_proto: tensor '{t.name}': external data location '{location}' leaves the model's directory")
+        if path not in maps:
+            maps[path] = np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+        offset = int(info.get("offset", 0))
+        length = int(info["length"]) if "length" in info else len(maps[path]) - offset
+        if offset < 0 or length < 0 or offset + length > len(maps[path]):
+            raise ValueError(f"onnx_proto: tensor '{t.name}': bytes [{offset}, {offset + length}) are outside '{location}' "
+                             f"({len(maps[path])} bytes)")
+        t.raw_data = memoryview(maps[path][offset:offset + length])
+        t.external_data = []
+        t.data_location = None
+        count += 1
+    return count
 
 
 # --------------------------------------------------------------------------------------------------------------- writing
@@ -326,16 +378,55 @@ def serialize(msg: Message) -> bytes:
     return b"".join(chunks)
 
 
-def save_model(model: Message, path) -> None:
-    """One file, weights inline.  protobuf caps a message at 2 GiB: larger models must be split by the caller."""
-    chunks: list = []
-    n = _serialize_into(model, chunks)
-    if n >= 1 << 31:
-        raise ValueError(f"onnx_proto: the serialised model is {n} bytes; a protobuf message cannot exceed 2 GiB "
-                         "(external tensor data is not written by this module)")
-    with open(path, "wb") as f:
-        for c in chunks:
-            f.write(c)
+def save_model(model: Message, path, external_data: str | None = None, size_threshold: int = 1024) -> None:
+    """Write `model` to `path`.  With `external_data` (a file name next to `path`, e.g. "model.onnx.data") every tensor of at
+    least `size_threshold` bytes goes to that file -- offsets aligned to 4096 bytes for tensors of a megabyte and more (what
+    memory-mapping loaders ask for), 64 otherwise -- and the model file keeps the references.  Without it everything is
+    inline, which protobuf caps at 2 GiB: a larger model is refused rather than written unreadable.  `model` itself is not
+    modified."""
+    if external_data is None:
+        chunks: list = []
+        n = _serialize_into(model, chunks)
+        if n >= 1 << 31:
+            raise ValueError(f"onnx_proto: the serialised model is {n} bytes; a protobuf message cannot exceed 2 GiB: pass "
+                             "external_data='<file name>' to keep the tensors in a side file")
+        with open(path, "wb") as f:
+            for c in chunks:
+                f.write(c)
+        return
+    if os.path.basename(external_data) != external_data:
+        raise ValueError("onnx_proto: external_data is a file name next to the model, not a path")
+    base = os.path.dirname(os.path.abspath(path))
+    swapped = []                                           # (tensor, raw_data) put back when the file is written
+    try:
+        with open(os.path.join(base, external_data), "wb") as data:
+            pos = 0
+            for t in _tensors_of(model.graph):
+                if t.data_location or not t.has("raw_data") or len(t.raw_data) < size_threshold:
+                    continue
+                raw = t.raw_data
+                align = 4096 if len(raw) >= 1 << 20 else 64
+                pad = -pos % align
+                if pad:
+                    data.write(b"\0" * pad)
+                    pos += pad
+                data.write(raw)
+                swapped.append((t, raw))
+                t.raw_data = None
+                t.data_location = 1
+                t.external_data = [Message("StringStringEntryProto", key=k, value=v)
+                                   for k, v in (("location", external_data), ("offset", str(pos)), ("length", str(len(raw))))]
+                pos += len(raw)
+        chunks = []
+        n = _serialize_into(model, chunks)
+        if n >= 1 << 31:
+            raise ValueError(f"onnx_proto: {n} bytes remain inline; lower size_threshold")
+        with open(path, "wb") as f:
+            for c in chunks:
+                f.write(c)
+    finally:
+        for t, raw in swapped:
+            t.raw_data, t.data_location, t.external_data = raw, None, []
 
 
 # --------------------------------------------------------------------------------------------------------------- tensors

@@ -108,6 +108,53 @@ def test_tensors_round_trip_including_four_bit_packing():
         P.tensor_to_numpy(ext)
 
 
+def test_external_tensor_data_is_mapped_on_load_and_written_back(tmp_path):
+    """Models past protobuf's 2 GiB limit keep their tensors in side files (onnx.proto `external_data`: location / offset /
+    length).  They are memory-mapped on load; `save_model(..., external_data=name)` writes them back, large tensors on
+    4096-byte boundaries; the in-memory model is left as it was."""
+    src = fixture("block")
+    inline = P.serialize(src)
+    path = tmp_path / "m.onnx"
+    P.save_model(src, path, external_data="m.onnx.data", size_threshold=128)
+    assert P.serialize(src) == inline                                     # the model in memory is untouched
+    assert path.stat().st_size < 12000 and (tmp_path / "m.onnx.data").stat().st_size > 130000
+    refs = P.load_model(path, load_external_data=False)
+    for t in refs.graph.initializer:
+        assert t.data_location == 1 and not t.has("raw_data")
+        info = {e.key: e.value for e in t.external_data}
+        assert info["location"] == "m.onnx.data" and int(info["offset"]) % 64 == 0
+    with pytest.raises(ValueError, match="external"):
+        P.tensor_to_numpy(refs.graph.initializer[0])
+    back = P.load_model(path)
+    assert P.serialize(back) == inline and isinstance(back.graph.initializer[-1].raw_data, memoryview)
+    # large tensors are aligned for memory-mapping loaders
+    big = P.Message("ModelProto", ir_version=10, graph=P.Message("GraphProto", name="g", initializer=[
+        P.numpy_to_tensor("small", np.arange(300, dtype=np.float32)), P.numpy_to_tensor("big", np.ones((512, 1024), dtype=np.float32))]))
+    P.save_model(big, tmp_path / "b.onnx", external_data="b.data")
+    offs = {t.name: int({e.key: e.value for e in t.external_data}["offset"]) for t in P.load_model(tmp_path / "b.onnx", False).graph.initializer}
+    assert offs == {"small": 0, "big": 4096}
+    assert np.array_equal(P.tensor_to_numpy(P.load_model(tmp_path / "b.onnx").graph.initializer[1]), np.ones((512, 1024), dtype=np.float32))
+    # references that leave the model's directory or the file are refused
+    evil = P.load_model(path, load_external_data=False)
+    evil.graph.initializer[0].external_data[0].value = "../m.onnx.data"
+    with pytest.raises(ValueError, match="leaves the model's directory"):
+        P.resolve_external_data(evil, tmp_path)
+    evil = P.load_model(path, load_external_data=False)
+    next(e for e in evil.graph.initializer[0].external_data if e.key == "length").value = str(1 << 40)
+    with pytest.raises(ValueError, match="outside"):
+        P.resolve_external_data(evil, tmp_path)
+    with pytest.raises(ValueError, match="file name"):
+        P.save_model(src, path, external_data="sub/m.data")
+    # quantize_file: a source with side files gives a result with a side file; the quantized tensors are the inline run's
+    import onnx_quantize_amd.model_quantize as MQ
+    qc = CONFIGS["uint4_g32"]()
+    out = MQ.quantize_file(path, tmp_path / "q.onnx", qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
+    assert (tmp_path / "q.onnx.data").exists()
+    assert P.serialize(P.load_model(tmp_path / "q.onnx")) == P.serialize(out) == P.serialize(q_oracle(fixture("block"), qc))
+    MQ.quantize_file(os.path.join(FIXTURES, "block.onnx"), tmp_path / "q2.onnx", qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
+    assert not (tmp_path / "q2.onnx.data").exists() and (tmp_path / "q2.onnx").read_bytes() == P.serialize(out)
+
+
 # ------------------------------------------------------------------------------------------------------------------ runner
 def test_graph_runner_matches_the_exported_torch_modules():
     fx = torch_modules()
