@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""End-to-end file path: an ONNX file of Llama-2-7B-shaped decoder MLP / projection weights
+-> `quantize_file` -> an ONNX file, on one GPU, with the phases timed apart.
+
+This is NOT the headline bench (bench.py times the kernels with inputs resident in HBM).  It is the PCIe- and file-
+inclusive rate of the path a user of the reference's `quantize(model, qconfig)` takes: parse + memory-map the source, one
+upload per weight, the kernels, one download of the wire-format arrays, serialisation.  The model is synthetic (random
+weights, `--layers` decoder layers of 4096 / 11008 width: q, k, v, o, gate, up, down as MatMuls joined by elementwise
+operators so that the graph runs), written by this package's own writer with its tensors in a side file.
+
+    python bench_model.py --layers 4 --config uint4_g128          # weight-only, MatMulNBits (BASELINE config 2's rule)
+    python bench_model.py --layers 2 --config static_int8         # calibrated on the GPU (config 3's rule), random data
+"""
+import argparse
+import json
+import os
+import shutil
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+from onnx_quantize_amd import GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
+from onnx_quantize_amd import onnx_proto as P
+from onnx_quantize_amd.model_quantize import quantize_model
+
+
+def build_model(layers: int, hidden: int, ffn: int, seed: int = 0) -> P.Message:
+    gen = torch.Generator().manual_seed(seed)
+    nodes, inits = [], []
+
+    def weight(name, k, n):
+        w = (torch.randn(k, n, generator=gen) * (1.0 / k ** 0.5)).numpy()
+        inits.append(P.numpy_to_tensor(name, w))
+        return name
+
+    x = "x"
+    for i in range(layers):
+        p = f"/layers.{i}"
+        for proj in ("q", "k", "v"):
+            nodes.append(P.make_node("MatMul", [x, weight(f"layers.{i}.{proj}.weight", hidden, hidden)], [f"{p}/{proj}/out"], name=f"{p}/{proj}/MatMul"))
+        nodes.append(P.make_node("Add", [f"{p}/q/out", f"{p}/k/out"], [f"{p}/qk"], name=f"{p}/Add_qk"))
+        nodes.append(P.make_node("Add", [f"{p}/qk", f"{p}/v/out"], [f"{p}/qkv"], name=f"{p}/Add_qkv"))
+        nodes.append(P.make_node("Tanh", [f"{p}/qkv"], [f"{p}/mix"], name=f"{p}/Tanh"))
+        nodes.append(P.make_node("MatMul", [f"{p}/mix", weight(f"layers.{i}.o.weight", hidden, hidden)], [f"{p}/o/out"], name=f"{p}/o/MatMul"))
+        nodes.append(P.make_node("Add", [x, f"{p}/o/out"], [f"{p}/h"], name=f"{p}/Add_h"))
+        nodes.append(P.make_node("MatMul", [f"{p}/h", weight(f"layers.{i}.gate.weight", hidden, ffn)], [f"{p}/gate/out"], name=f"{p}/gate/MatMul"))
+        nodes.append(P.make_node("MatMul", [f"{p}/h", weight(f"layers.{i}.up.weight", hidden, ffn)], [f"{p}/up/out"], name=f"{p}/up/MatMul"))
+        nodes.append(P.make_node("Sigmoid", [f"{p}/gate/out"], [f"{p}/gate/act"], name=f"{p}/Sigmoid"))
+        nodes.append(P.make_node("Mul", [f"{p}/gate/act", f"{p}/up/out"], [f"{p}/ffn"], name=f"{p}/Mul"))
+        nodes.append(P.make_node("MatMul", [f"{p}/ffn", weight(f"layers.{i}.down.weight", ffn, hidden)], [f"{p}/down/out"], name=f"{p}/down/MatMul"))
+        nodes.append(P.make_node("Add", [f"{p}/h", f"{p}/down/out"], [f"{p}/out"], name=f"{p}/Add_out"))
+        x = f"{p}/out"
+    nodes.append(P.make_node("Identity", [x], ["y"], name="/Identity"))
+    graph = P.Message("GraphProto", name="decoder_weights", node=nodes, initializer=inits,
+                      input=[P.make_value_info("x", P.DataType.FLOAT, ["batch", "seq", hidden])],
+                      output=[P.make_value_info("y", P.DataType.FLOAT, ["batch", "seq", hidden])])
+    return P.Message("ModelProto", ir_version=10, producer_name="onnx_quantize_amd.bench_model", graph=graph,
+                     opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+
+
+def configs(name, data):
+    act = lambda dt: QActivationArgs(dtype=QuantType.from_string(dt), is_static=True)      # noqa: E731
+    cal = {"num_samples": data.shape[0], "batch_size": max(1, data.shape[0] // 4)}
+    return {
+        "int8_tensor": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, symmetric=True)),
+        "uint4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=128)),
+        "int4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=128)),
+        "static_int8": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=act("int8"), output_activations=act("int8"),
+                                       calibration_data=data, calibration_params=cal),
+        "gptq_int4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=128, algorithm=GPTQConfig(mode="corrected")),
+                                          calibration_data=data, calibration_params=cal),
+    }[name]()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--hidden", type=int, default=4096)
+    ap.add_argument("--ffn", type=int, default=11008)
+    ap.add_argument("--config", default="uint4_g128")
+    ap.add_argument("--samples", type=int, default=8, help="calibration sequences (calibrated configurations)")
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--dir", default=None, help="where the files go (default: a temporary directory, removed afterwards)")
+    ap.add_argument("--repeat", type=int, default=2, help="quantize passes over the same source (the first one pages the file in)")
+    args = ap.parse_args()
+    work = args.dir or tempfile.mkdtemp(prefix="oq_bench_model_")
+    os.makedirs(work, exist_ok=True)
+    src, dst = os.path.join(work, "model.onnx"), os.path.join(work, "model_q.onnx")
+    t0 = time.perf_counter()
+    model = build_model(args.layers, args.hidden, args.ffn)
+    params = sum(int(np.prod(t.dims)) for t in model.graph.initializer)
+    P.save_model(model, src, external_data="model.onnx.data")
+    del model
+    t_build = time.perf_counter() - t0
+    data = torch.randn(args.samples, args.seq, args.hidden, generator=torch.Generator().manual_seed(1)).numpy()
+    torch.cuda.init()
+    torch.zeros(1, device="cuda")
+    runs = []
+    for r in range(args.repeat):
+        t0 = time.perf_counter()
+        loaded = P.load_model(src)
+        t1 = time.perf_counter()
+        out = quantize_model(loaded, configs(args.config, data))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        P.save_model(out, dst, external_data="model_q.onnx.data")
+        t3 = time.perf_counter()
+        runs.append({"load_s": round(t1 - t0, 4), "quantize_s": round(t2 - t1, 4), "save_s": round(t3 - t2, 4), "total_s": round(t3 - t0, 4)})
+        del loaded
+    out_bytes = os.path.getsize(dst) + os.path.getsize(dst + ".data")
+    calls = sorted({(n.op_type, n.domain) for n in out.graph.node if n.domain})
+    best = min(runs, key=lambda r: r["total_s"])
+    line = {"bench": "model_file", "config": args.config, "layers": args.layers, "weights": 7 * args.layers, "params": params,
+            "source_bytes": os.path.getsize(src) + os.path.getsize(src + ".data"), "result_bytes": out_bytes, "calls": calls,
+            "build_source_s": round(t_build, 2), "runs": runs, "best": best,
+            "mparam_per_s_file_to_file": round(params / best["total_s"] / 1e6, 1),
+            "source_gb_per_s_quantize_phase": round(params * 4 / best["quantize_s"] / 1e9, 2)}
+    print(json.dumps(line))
+    if args.dir is None:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

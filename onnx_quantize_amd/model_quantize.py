@@ -17,8 +17,8 @@ small enough to restate, and it lets a GPU box quantize a file end to end with n
   StandarizeGemm[Bias] (standarize_gemm.py)               `_standardize_gemm`
   calibrate_model (calibrate.py:310-380)                  `_calibrate`: `GraphRunner` on the GPU -> `ActivationStream`
   _add_qconfig_to_nodes / get_target_nodes                `_target_nodes`
-  preprocessors (AWQ, SmoothQuant)                        refused (they are rebound inside the reference's own passes:
-                                                          reference_passes.py)
+  preprocessors: AwqPass, SmoothQuantPass                 `_preprocess`: the searches on the GPU (`DeviceSearches`), the Mul /
+                                                          initializer surgery here; then the post-calibration
   rewrite(model, get_qrules(qconfig))                     `emission.plan_node` per node -> initializers + one call
   model.functions.update / RemoveUnusedFunctionsPass      the functions the calls use (`onnx_functions`)
   DeduplicateInitializersPass(size_limit=1e9)             `_deduplicate_initializers`
@@ -305,10 +305,13 @@ def _model_inputs(G: _Graph):
     return out
 
 
-def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> dict:
+def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, keep_inputs: bool = False) -> dict:
     """calibrate.py:310-380 with the activations consumed on the device, batch by batch (calibration_driver.py): returns
-    {id(node): meta} with `input_scale` / `input_zero_point` / `output_scale` / `output_zero_point` (0-d arrays) and `input`
-    (a `StreamedGptqInput`: the Hessian of the node's input, shared by the nodes that read the same value)."""
+    {id(node): meta} with `input_scale` / `input_zero_point` / `output_scale` / `output_zero_point` (0-d arrays) and `input`:
+    a `StreamedGptqInput` (the Hessian of the node's input) when only the weight algorithm needs the activations, or -- with
+    `keep_inputs`, ahead of AWQ / SmoothQuant, which read and rescale the activations themselves -- the batches concatenated in
+    HBM (calibrate.py:296-307).  Nodes that read the same value share ONE object either way, as they share one array in the
+    reference."""
     from .calibration import get_calibrator
     from .calibration_driver import ActivationStream, generate_random_calibration_data, run_calibration
     from .graph_runner import GraphRunner
@@ -319,7 +322,8 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> 
     algo = qconfig.weights is not None and qconfig.weights.algorithm.requires_calibration
     in_names = [n.input[0] for n in targets]
     out_names = [n.output[0] for n in targets]
-    wanted = list(dict.fromkeys((in_names if (cal_in or algo) else []) + (out_names if cal_out else [])))
+    pre = any(p.requires_calibration for p in qconfig.preprocessors)
+    wanted = list(dict.fromkeys((in_names if (cal_in or algo or pre) else []) + (out_names if cal_out else [])))
     params = qconfig.calibration_params.model_dump()
     batch_size, num_samples = params.pop("batch_size"), params.pop("num_samples")
     params.pop("provider")                                 # the GPU this process owns runs the graph
@@ -331,7 +335,8 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> 
     # a model input that a target node reads directly is "produced" by the feed: the runner returns it like any other value
     runner = GraphRunner(model, outputs=wanted, device=device)
     stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
-                              hessian_names=in_names if algo else ())
+                              hessian_names=in_names if (algo and not keep_inputs) else (),
+                              keep_names=in_names if keep_inputs else ())
     run_calibration(runner, data, stream, num_samples=num_samples, batch_size=batch_size, input_names=[i[0] for i in inputs])
     meta: dict = {id(n): {} for n in targets}
     for kind, on, names, aargs in (("input", cal_in, in_names, qconfig.input_activations),
@@ -344,7 +349,13 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> 
                 scale, zp = qparams[name]
                 meta[id(n)][f"{kind}_scale"] = np.asarray(scale).astype(aargs.scale_dtype, copy=False)
                 meta[id(n)][f"{kind}_zero_point"] = np.asarray(zp).astype(aargs.zp_dtype, copy=False)
-    if algo:
+    if keep_inputs:
+        kept: dict = {}
+        for n, name in zip(targets, in_names):
+            if name not in kept:
+                kept[name] = stream.kept(name)
+            meta[id(n)]["input"] = kept[name]
+    elif algo:
         shared: dict = {}
         for n, name in zip(targets, in_names):
             acc = stream.hessians.get(name)
@@ -354,6 +365,100 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device) -> 
                 shared[name] = StreamedGptqInput(name, acc.h, acc.n, (acc.n, acc.h.shape[0]))
             meta[id(n)]["input"] = shared[name]
     return meta
+
+
+# ------------------------------------------------------------------------------------------------------------ AWQ / SmoothQuant
+class DeviceSearches:
+    """The numeric cores of the two pre-processing passes on the GPU (hip/ops.py: `oq_smooth_quant_scale_f32`,
+    `oq_awq_scale_search_f32`, `oq_awq_clip_search_f32`).  `x`: the node's calibration input in HBM, `w`: the weight [K, N]
+    as NumPy (uploaded once per node)."""
+
+    def __init__(self):
+        self._w = (None, None)
+
+    def _dev(self, w):
+        from .staging import upload
+        if self._w[0] is not w:
+            self._w = (w, upload(w))
+        return self._w[1]
+
+    @staticmethod
+    def _args(a):
+        return a.dtype.key, a.strategy.value, a.group_size, bool(a.symmetric), bool(a.reduce_range)
+
+    def smooth_quant_scale(self, x, w, alpha):
+        from .hip import ops
+        from .staging import download
+        return download(ops.smooth_quant_scale(x, self._dev(w), float(alpha)))
+
+    def awq_scale_search(self, x, w, a):
+        from .hip import ops
+        from .staging import download
+        best, _losses = ops.awq_scale_search(x, self._dev(w), *self._args(a))
+        return download(best)
+
+    def awq_clip_search(self, x, w, a):
+        from .hip import ops
+        ratio, _losses = ops.awq_clip_search(x, self._dev(w), *self._args(a))
+        return float(ratio)
+
+
+def _divide_in_place(x, scale: np.ndarray) -> None:
+    """`node.meta["input"] /= scale.reshape((1, -1))` (smooth_quant.py:121, awq.py:191): IN PLACE on the array the nodes that
+    read one value share -- the next consumer of that value (k after q, up after gate) searches on inputs already divided
+    by its neighbour's scale.  That is the reference as written; the shared object keeps it so."""
+    if isinstance(x, np.ndarray):
+        x /= scale.reshape((1, -1))
+        return
+    import torch
+    x.div_(torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32)).to(x.device).reshape(1, -1))
+
+
+def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> dict:
+    """pre_passes/__init__.py:72-83: every preprocessor's pass over the target nodes in graph order.  Both passes do the same
+    surgery around different searches (smooth_quant.py:91-134, awq.py:114-204): the scale is folded into the weight's rows,
+    a `Mul` by 1 / scale goes in front of the node (initializer `<node output>_scale`), the node's calibration input is
+    divided by the scale.  AWQ's clip search (awq.py:206-259) leaves a per-node `clip_ratio`.  Returns {id(node): QConfig}
+    for the nodes whose configuration changed."""
+    per_node: dict = {}
+    if len([p for p in qconfig.preprocessors if p.preprocessing_type in ("awq", "smooth_quant")]) > 1:
+        raise NotImplementedError("more than one rescaling preprocessor: both would register the initializer '<output>_scale'")
+    for pre in qconfig.preprocessors:
+        kind = pre.preprocessing_type
+        if kind not in ("awq", "smooth_quant"):
+            raise NotImplementedError(f"preprocessor '{kind}' has no restatement in this writer")
+        for node in targets:
+            node_meta = meta.get(id(node), {})
+            if "input" not in node_meta:
+                continue                                     # a node the calibration data never reached
+            x = node_meta["input"]
+            w_name, out_name = node.input[1], node.output[0]
+            w = G.array(w_name)
+            cfg = per_node.get(id(node), qconfig)
+            if kind == "smooth_quant":
+                scale = np.asarray(searches.smooth_quant_scale(x, w, pre.alpha), dtype=np.float32)
+            else:
+                scale = np.asarray(searches.awq_scale_search(x, w, cfg.weights), dtype=np.float32)
+            updated = np.multiply(scale.reshape(-1, 1), w)
+            name = f"{out_name}_scale"
+            if name in G.inits:
+                raise ValueError(f"an initializer named '{name}' exists already")
+            G.set_initializer(name, (1.0 / scale).astype(np.float32))
+            _divide_in_place(x, scale)
+            mul_out = f"{out_name}_scaled_input"
+            mul = make_node("Mul", [node.input[0], name], [mul_out], name=f"{node.name}/scale_input")
+            nodes = list(G.g.node)
+            nodes.insert([id(n) for n in nodes].index(id(node)), mul)
+            G.g.node = nodes
+            node.input = [mul_out] + list(node.input)[1:]
+            G.set_initializer(w_name, updated.astype(np.float32, copy=False))
+            if kind == "awq" and pre.clip_search:
+                ratio = searches.awq_clip_search(x, updated, cfg.weights)
+                changed = cfg.model_copy()
+                changed.weights = cfg.weights.model_copy()
+                changed.weights.clip_ratio = ratio
+                per_node[id(node)] = changed
+    return per_node
 
 
 # ------------------------------------------------------------------------------------------------------------ post passes
@@ -416,22 +521,19 @@ class _Out:
         return self
 
 
-def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None, calibrate=None) -> Message:
+def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None, calibrate=None,
+                   searches=None) -> Message:
     """quantize.py:28-80 on a parsed ModelProto / ONNX bytes / a path.  Returns a new parsed ModelProto (`onnx_proto.serialize`
-    gives the file).  `weight_arrays` / `quantize_bias` / `calibrate`: the numeric providers (default: the device-resident
-    seam, the HIP bias kernel and the on-device calibration walk `_calibrate`; tests inject the oracle).  `calibrate(model,
-    graph view, target nodes, qconfig, device)` returns {id(node): meta} like `_calibrate`."""
+    gives the file).  `weight_arrays` / `quantize_bias` / `calibrate` / `searches`: the numeric providers (default: the
+    device-resident seam, the HIP bias kernel, the on-device calibration walk `_calibrate` and `DeviceSearches`; tests inject
+    the oracle).  `calibrate(model, graph view, target nodes, qconfig, device, keep_inputs=False)` returns {id(node): meta}
+    like `_calibrate`."""
     if not isinstance(qconfig, QConfig):
         raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
     model = as_model(model)
     if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
         logger.info("No quantization parameters specified in qconfig. Returning original model.")
         return model
-    if qconfig.preprocessors:
-        raise NotImplementedError(
-            "preprocessors (AWQ / SmoothQuant) rewrite the graph inside the reference's own passes; this writer does not restate "
-            "them.  Use onnx_quantize_amd.quantize() with the reference installed (integration.py), or the searches on their own "
-            "(onnx_quantize_amd.preprocessing).")
     if model.graph is None:
         raise ValueError("the model has no graph")
     G = _Graph(model.graph)
@@ -441,7 +543,17 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     _fuse_matmul_add(G)
     _standardize_gemm(G)
     targets = _target_nodes(G, qconfig)
-    meta = (calibrate or _calibrate)(model, G, targets, qconfig, device) if (_needs_calibration(qconfig) and targets) else {}
+    calibrate = calibrate or _calibrate
+    per_node: dict = {}
+    meta: dict = {}
+    if _needs_calibration(qconfig) and targets:
+        meta = calibrate(model, G, targets, qconfig, device, keep_inputs=bool(qconfig.preprocessors))
+    if qconfig.preprocessors and targets:                   # pre_passes/__init__.py:72-88
+        per_node = _preprocess(G, targets, qconfig, meta, searches or DeviceSearches())
+        _name_nodes(G)
+        if any(p.requires_post_calibration for p in qconfig.preprocessors):
+            logger.info("Re-calibrating the model after pre-processing...")
+            meta = calibrate(model, G, targets, qconfig, device, keep_inputs=False)
 
     used_functions: dict = {}
     domains = set()
@@ -451,7 +563,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
         w = _Const(w_name, G.array(w_name))
         b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
         node_meta = meta.get(id(node), {})
-        plan = plan_node(node.op_type, x_name, w, out_name, qconfig, node_meta, bias=b, out=_Out(node_meta),
+        plan = plan_node(node.op_type, x_name, w, out_name, per_node.get(id(node), qconfig), node_meta, bias=b, out=_Out(node_meta),
                          weight_arrays=weight_arrays, quantize_bias=quantize_bias)
         for name, array in plan.initializers:
             G.set_initializer(name, np.asarray(array), plan.onnx_types.get(name))

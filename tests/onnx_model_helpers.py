@@ -36,13 +36,13 @@ def oracle_calibrate(runner_device="cpu"):
     """calibrate.py:310-380 restated on the oracle: the activations of each batch from a `GraphRunner` on `runner_device`
     (downloaded: the reference's list of NumPy dicts), `O.calibrate_flow` for the ranges, `O.gptq_inputs` for the GPTQ inputs."""
 
-    def calibrate(model, G, targets, qconfig, device):
+    def calibrate(model, G, targets, qconfig, device, keep_inputs=False):
         from onnx_quantize_amd.calibration_driver import generate_random_calibration_data
         from onnx_quantize_amd.model_quantize import _model_inputs
 
         cal_in = qconfig.input_activations is not None and qconfig.input_activations.is_static
         cal_out = qconfig.output_activations is not None and qconfig.output_activations.is_static
-        algo = qconfig.weights.algorithm.requires_calibration
+        algo = qconfig.weights.algorithm.requires_calibration or any(p.requires_calibration for p in qconfig.preprocessors)
         in_names, out_names = [n.input[0] for n in targets], [n.output[0] for n in targets]
         wanted = list(dict.fromkeys((in_names if (cal_in or algo) else []) + (out_names if cal_out else [])))
         params = qconfig.calibration_params
@@ -75,6 +75,25 @@ def oracle_calibrate(runner_device="cpu"):
     return calibrate
 
 
+class OracleSearches:
+    """pre_passes/smooth_quant.py:62-113 and awq.py:114-259 from the oracle (NumPy inputs)."""
+
+    @staticmethod
+    def _np(x):
+        return x if isinstance(x, np.ndarray) else x.cpu().numpy()
+
+    def smooth_quant_scale(self, x, w, alpha):
+        return O.smooth_quant_scale(self._np(x), w, alpha)
+
+    def awq_scale_search(self, x, w, a):
+        best, _losses = O.awq_scale_search(self._np(x), w, a.dtype.key, a.strategy.value, a.group_size, a.symmetric, a.reduce_range)
+        return best
+
+    def awq_clip_search(self, x, w, a):
+        ratio, _losses = O.awq_clip_search(self._np(x), w, a.dtype.key, a.strategy.value, a.group_size, a.symmetric, a.reduce_range)
+        return ratio
+
+
 def q_oracle(model, qc, runner_device="cpu"):
     return quantize_model(model, qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias,
-                          calibrate=oracle_calibrate(runner_device))
+                          calibrate=oracle_calibrate(runner_device), searches=OracleSearches())

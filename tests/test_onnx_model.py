@@ -502,9 +502,6 @@ def test_quantize_entry_point_routes_bytes_paths_and_parsed_models(tmp_path, mon
     dst = tmp_path / "q.onnx"
     MQ.quantize_file(path, dst, qc, weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
     assert dst.read_bytes() == out_bytes
-    with pytest.raises(NotImplementedError, match="preprocessors"):
-        from onnx_quantize_amd import SmoothQuantConfig
-        quantize(data, QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), preprocessors=[SmoothQuantConfig()]))
     with pytest.raises(TypeError):
         MQ.as_model(3.5)
     with pytest.raises(TypeError, match="QConfig"):
@@ -628,3 +625,82 @@ def test_gptq_configuration_with_the_oracle_as_provider():
     feed = torch.randn(2, 6, 64, generator=gen)
     want, got = GraphRunner(src, device="cpu")(feed)["y"], GraphRunner(out, device="cpu")(feed)["y"]
     assert ((got - want).norm() / want.norm()).item() < 0.08
+
+
+# ------------------------------------------------------------------------------------------------------------------ AWQ / SmoothQuant
+def _pre_cfg(kind, **weights):
+    from onnx_quantize_amd import AwqConfig, SmoothQuantConfig
+    pre = {"smooth": lambda: SmoothQuantConfig(alpha=0.5), "awq": lambda: AwqConfig(), "awq_clip": lambda: AwqConfig(clip_search=True)}[kind]()
+    return QConfig(weights=QWeightArgs(**weights), preprocessors=[pre], calibration_params={"num_samples": 16, "batch_size": 4})
+
+
+@pytest.mark.parametrize("kind,weights", [("smooth", dict(dtype=QuantType.QInt8, group_size=-1)),
+                                          ("awq", dict(dtype=QuantType.QUInt4, group_size=32)),
+                                          ("awq_clip", dict(dtype=QuantType.QInt4, group_size=32))])
+def test_preprocessors_rewrite_the_graph_like_the_reference_passes(kind, weights):
+    """smooth_quant.py:91-134 / awq.py:114-259: per target node a `Mul` by 1 / scale in front (initializer `<output>_scale`),
+    the scale folded into the weight's rows, the shared calibration input divided IN PLACE (so k searches on what q left),
+    AWQ's clip ratio per node; then the model is calibrated again (pre_passes/__init__.py:85-88)."""
+    gen = torch.Generator().manual_seed(8)
+    data = (torch.randn(16, 6, 64, generator=gen) * torch.linspace(0.2, 4.0, 64)).numpy()
+    qc = _pre_cfg(kind, **weights)
+    qc.calibration_data = data
+    src = fixture("block")
+    out = P.parse_model(P.serialize(q_oracle(src, qc)))
+    inits = {t.name: t for t in out.graph.initializer}
+    src_inits = {t.name: P.tensor_to_numpy(t) for t in src.graph.initializer}
+    nodes = list(out.graph.node)
+    by_name = {n.name: n for n in nodes}
+    a = qc.weights
+    # the reference's walk restated on the float model: q, k, v share ONE input array, divided in place as the walk proceeds
+    taps = {n.name: n.input[0] for n in src.graph.node if n.op_type == "MatMul" and n.input[1] in src_inits}
+    runner = GraphRunner(src, outputs=list(dict.fromkeys(taps.values())), device="cpu")
+    acts = [{k: v.numpy() for k, v in runner(torch.from_numpy(np.ascontiguousarray(b))).items()} for b in O.prepare_calibration_data(data, 4, 16)]
+    shared = O.gptq_inputs(acts)
+    for t in [n for n in src.graph.node if n.name in taps]:
+        x, w = shared[t.input[0]], src_inits[t.input[1]]
+        if kind == "smooth":
+            scale = O.smooth_quant_scale(x, w, 0.5)
+        else:
+            scale, _ = O.awq_scale_search(x, w, a.dtype.key, "group", 32, a.symmetric, a.reduce_range)
+        scale = scale.astype(np.float32)
+        x /= scale.reshape(1, -1)
+        updated = np.multiply(scale.reshape(-1, 1), w)
+        call = by_name[t.name]
+        mul = nodes[nodes.index(call) - 1]
+        assert mul.op_type == "Mul" and list(mul.input) == [t.input[0], f"{t.output[0]}_scale"] and call.input[0] == mul.output[0]
+        assert P.tensor_to_numpy(inits[f"{t.output[0]}_scale"]).tobytes() == (1.0 / scale).astype(np.float32).tobytes()
+        clip = 1.0
+        if kind == "awq_clip":
+            clip, _ = O.awq_clip_search(x, updated, a.dtype.key, "group", 32, a.symmetric, a.reduce_range)
+        g = O.resolve_group_size(w.shape[0], a.group_size) if a.strategy.value == "group" else a.group_size
+        nbits = O.matmul_nbits_compatible(a.dtype.key, a.strategy.value, g)
+        q, s, z = O.seam_arrays(updated, "rtn", a.dtype.key, a.strategy.value, g, a.symmetric, a.reduce_range, clip, a.mse, nbits=nbits)
+        assert np.array_equal(P.tensor_to_numpy(inits[call.input[1]]), q), t.name
+        assert P.tensor_to_numpy(inits[call.input[2]]).tobytes() == np.asarray(s).tobytes(), t.name
+    assert len([n for n in nodes if n.op_type == "Mul" and n.name.endswith("/scale_input")]) == 6
+    # the rescaled model is the same function; with the quantization error on top it stays close
+    feed = torch.from_numpy(data[:3])
+    want, got = GraphRunner(src, device="cpu")(feed)["y"], GraphRunner(out, device="cpu")(feed)["y"]
+    assert ((got - want).norm() / want.norm()).item() < (0.02 if kind == "smooth" else 0.12)
+
+
+def test_static_activations_are_recalibrated_after_preprocessing():
+    """pre_passes/__init__.py:85-88: the input ranges of a smoothed node are those of the Mul's output."""
+    from onnx_quantize_amd import SmoothQuantConfig
+    gen = torch.Generator().manual_seed(9)
+    data = (torch.randn(12, 3, 64, generator=gen) * torch.linspace(0.2, 4.0, 64)).numpy()
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=QActivationArgs(dtype=QuantType.QUInt8),
+                 preprocessors=[SmoothQuantConfig(alpha=0.6)], calibration_params={"num_samples": 12, "batch_size": 4}, calibration_data=data)
+    out = q_oracle(fixture("mlp_matmul"), qc)
+    first = next(n for n in out.graph.node if n.domain == "quant")
+    mul = next(n for n in out.graph.node if n.op_type == "Mul")
+    assert first.input[0] == mul.output[0] and first.op_type == "QMatMulWeightStaticInputQDQ"
+    inits = {t.name: P.tensor_to_numpy(t) for t in out.graph.initializer}
+    smoothed = data.reshape(-1, 64) * inits[mul.input[1]]
+    batches = O.prepare_calibration_data(smoothed.reshape(12, 3, 64), 4, 12)
+    cal = O.MinMaxOracle()
+    for b in batches:
+        cal.collect("v", b)
+    s, z = O.qparams(*cal.compute_range("v"), "uint8", False, False)
+    assert inits[first.input[4]].tobytes() == np.asarray(s, np.float32).tobytes() and int(inits[first.input[5]]) == int(z)
