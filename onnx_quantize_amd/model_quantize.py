@@ -112,15 +112,6 @@ class _Graph:
         """[(node, input index)] in graph order -- `ir.Value.uses()` for a top-level value."""
         return [(n, i) for n in self.g.node for i, v in enumerate(n.input) if v == name]
 
-    def rank(self, name):
-        t = self.inits.get(name)
-        if t is not None:
-            return len(t.dims)
-        for vi in list(self.g.input) + list(self.g.value_info) + list(self.g.output):
-            if vi.name == name and vi.type is not None and vi.type.tensor_type is not None and vi.type.tensor_type.shape is not None:
-                return len(vi.type.tensor_type.shape.dim)
-        return None
-
 
 def _attr(node, name, default=None):
     for a in node.attribute:
@@ -207,9 +198,57 @@ def _duplicate_shared_initializers(G: _Graph) -> None:
             node.input = ins
 
 
+_SAME_RANK = {"Relu", "Tanh", "Sigmoid", "Erf", "Sqrt", "Exp", "Log", "Neg", "Abs", "Cast", "Identity", "Dropout", "Softmax",
+              "LogSoftmax", "LayerNormalization", "Transpose", "LeakyRelu", "Gelu", "Clip", "Softplus", "Reciprocal", "Floor",
+              "Ceil", "Round", "Not", "Sin", "Cos", "Trilu", "Concat", "Slice", "Tile", "Expand"}
+_BROADCAST = {"Add", "Sub", "Mul", "Div", "Pow", "Min", "Max", "Sum", "Where", "Equal", "Less", "Greater", "LessOrEqual",
+              "GreaterOrEqual", "And", "Or"}
+
+
+def _infer_ranks(G: _Graph) -> dict:
+    """Ranks of the values a MatMul / Add chain can be fed from, by one walk in graph order (the reference has them from the
+    shape inference inside `onnxscript.optimizer.optimize`): declared types, then the rank rules of the common operators;
+    a value this does not cover has no entry and the rule that asks for it does not fire."""
+    ranks: dict = {name: len(t.dims) for name, t in G.inits.items()}
+    for vi in list(G.g.input) + list(G.g.value_info) + list(G.g.output):
+        tt = vi.type.tensor_type if vi.type is not None else None
+        if tt is not None and tt.shape is not None:
+            ranks.setdefault(vi.name, len(tt.shape.dim))
+    for n in G.g.node:
+        if n.domain or not n.output or n.output[0] in ranks:
+            continue
+        ins = [ranks.get(v) for v in n.input if v]
+        r = None
+        if n.op_type == "Gemm":
+            r = 2
+        elif n.op_type == "MatMul" and len(ins) == 2 and None not in ins:
+            a, b = ins
+            r = 0 if (a == 1 and b == 1) else (b - 1 if a == 1 else (a - 1 if b == 1 else max(a, b)))
+        elif n.op_type in _SAME_RANK and ins and ins[0] is not None:
+            r = ins[0]
+        elif n.op_type in _BROADCAST and ins and None not in ins:
+            r = max(ins)
+        elif n.op_type == "Flatten":
+            r = 2
+        elif n.op_type == "Reshape" and len(n.input) > 1 and n.input[1] in G.inits:
+            r = int(G.inits[n.input[1]].dims[0]) if G.inits[n.input[1]].dims else None
+        elif n.op_type in ("Unsqueeze", "Squeeze") and ins and ins[0] is not None:
+            axes = _attr(n, "axes")
+            if axes is None and len(n.input) > 1 and n.input[1] in G.inits:
+                axes = G.array(n.input[1]).reshape(-1).tolist()
+            if axes is not None:
+                r = ins[0] + (len(axes) if n.op_type == "Unsqueeze" else -len(axes))
+        elif n.op_type == "Gather" and len(ins) == 2 and None not in ins:
+            r = ins[0] + ins[1] - 1
+        if r is not None:
+            ranks[n.output[0]] = r
+    return ranks
+
+
 def _fuse_matmul_add(G: _Graph) -> None:
     """onnxscript's `matmul_add_to_gemm_rule` (pre_passes/__init__.py:62): Add(MatMul(a, b), c) -> Gemm(a, b, c) when a and b
     are known to be matrices (rank 2) and the product feeds nothing else."""
+    ranks = _infer_ranks(G)
     producer = {o: n for n in G.g.node for o in n.output if o}
     consumers: dict = {}
     for n in G.g.node:
@@ -225,7 +264,7 @@ def _fuse_matmul_add(G: _Graph) -> None:
             continue
         if len(consumers.get(mm.output[0], [])) != 1 or mm.output[0] in G.graph_outputs:
             continue
-        if G.rank(mm.input[0]) != 2 or G.rank(mm.input[1]) != 2:
+        if ranks.get(mm.input[0]) != 2 or ranks.get(mm.input[1]) != 2:
             continue
         add.op_type = "Gemm"
         add.input = [mm.input[0], mm.input[1], add.input[1]]

@@ -23,7 +23,7 @@ def oracle_weight_arrays(value, cfg, out, nbits):
     a = cfg.weights
     w = value.const_value.numpy()
     if w.ndim == 1:                                          # QDQ Gemm bias: per-tensor RTN on a vector
-        q, s, z = O.rtn_quantize(w.reshape(1, -1), a.dtype.key, "tensor", -1, a.symmetric, a.reduce_range, a.clip_ratio)
+        q, s, z = O.rtn_quantize(w.reshape(1, -1), a.dtype.key, "tensor", -1, a.symmetric, a.reduce_range, a.clip_ratio, a.mse)
         return q.reshape(w.shape), s, z
     x = None if out is None else out.producer().meta.get("input")
     tag = getattr(a.algorithm, "algorithm_type", "rtn")

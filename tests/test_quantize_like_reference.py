@@ -1,0 +1,154 @@
+"""The reference's own end-to-end tests of `quantize()` (test/test_quantize.py:29-330), on this package's writer.
+
+Same four toy models (MatMul chain; Gemm with `transB = 1` and bias; MatMul + Add on matrices, which the pre-passes fuse to
+Gemm; one activation read by two quantized nodes), the same configuration grids and the same two assertions -- every node
+of the result lives in the `quant` / `com.microsoft` domains, and for 8-bit weights the quantized model's outputs are
+within 1e-1 of the float model's (test_quantize.py:105-139) -- with `GraphRunner` in place of an onnxruntime session.
+
+* CPU (`-m "not gpu"`): the oracle as numeric provider: the writer's bookkeeping over the whole grid.
+* GPU: the product's providers (device-resident seam, HIP bias kernel, on-device calibration walk); for everything but
+  GPTQ the emitted file must equal, byte for byte, the oracle-provider file computed on the same activations.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from onnx_model_helpers import q_oracle
+from onnx_quantize_amd import GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
+from onnx_quantize_amd import onnx_proto as P
+from onnx_quantize_amd.graph_runner import GraphRunner
+from onnx_quantize_amd.model_quantize import quantize_model
+
+DTYPES = {"uint8": QuantType.QUInt8, "int8": QuantType.QInt8, "uint4": QuantType.QUInt4, "int4": QuantType.QInt4}
+
+
+def _truncated_normal(rng, shape, scale=0.1, clip=2.5):
+    x = rng.normal(0.0, scale, size=shape)
+    return np.clip(x, -clip * scale, clip * scale).astype(np.float32)
+
+
+def _model(nodes, inits, outputs=("Y",), opset=21):
+    g = P.Message("GraphProto", name="test_model", node=nodes, initializer=[P.numpy_to_tensor(k, v) for k, v in inits.items()],
+                  input=[P.make_value_info("X", P.DataType.FLOAT, ["N", 32])],
+                  output=[P.make_value_info(o, P.DataType.FLOAT, ["N", None]) for o in outputs])
+    return P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=opset)])
+
+
+def matmul_model(rng):                                                        # test_quantize.py:29-44
+    return _model([P.make_node("MatMul", ["X", "W1"], ["x1"]), P.make_node("MatMul", ["x1", "W2"], ["Y"])],
+                  {"W1": _truncated_normal(rng, (32, 64)), "W2": _truncated_normal(rng, (64, 128))})
+
+
+def gemm_model(rng):                                                          # :47-66
+    return _model([P.make_node("Gemm", ["X", "W1", "B1"], ["x1"], transB=1), P.make_node("Gemm", ["x1", "W2"], ["Y"])],
+                  {"W1": _truncated_normal(rng, (64, 32)), "B1": _truncated_normal(rng, (64,)), "W2": _truncated_normal(rng, (64, 128))}, opset=20)
+
+
+def matmul_add_model(rng):                                                    # :69-87
+    return _model([P.make_node("MatMul", ["X", "W1"], ["x1"]), P.make_node("Add", ["x1", "B1"], ["x2"]),
+                   P.make_node("MatMul", ["x2", "W2"], ["x3"]), P.make_node("Add", ["x3", "B2"], ["Y"])],
+                  {"W1": _truncated_normal(rng, (32, 64)), "W2": _truncated_normal(rng, (64, 128)),
+                   "B1": _truncated_normal(rng, (64,)), "B2": _truncated_normal(rng, (128,))}, opset=20)
+
+
+def shared_activation_model(rng):                                             # :90-110
+    return _model([P.make_node("MatMul", ["X", "W0"], ["h"]), P.make_node("MatMul", ["h", "W1"], ["Y1"]),
+                   P.make_node("MatMul", ["h", "W2"], ["Y2"])],
+                  {"W0": _truncated_normal(rng, (32, 64)), "W1": _truncated_normal(rng, (64, 128)), "W2": _truncated_normal(rng, (64, 128))},
+                  outputs=("Y1", "Y2"))
+
+
+MODELS = {"matmul": matmul_model, "gemm": gemm_model, "matmul_add": matmul_add_model, "shared_activation": shared_activation_model}
+THREE = ["matmul", "gemm", "matmul_add"]
+STRATEGIES = [("tensor", None), ("channel", None), ("group", 16), ("group", 8)]
+
+
+def _check(model, qmodel, qconfig, samples, device):
+    """test_quantize.py:113-139."""
+    qmodel = P.parse_model(P.serialize(qmodel))                               # what a session would be handed: the file
+    assert all(n.domain in ("com.microsoft", "quant") for n in qmodel.graph.node), [(n.op_type, n.domain) for n in qmodel.graph.node]
+    if qconfig.weights.dtype.bitwidth > 4:
+        x = torch.from_numpy(samples)
+        want, got = GraphRunner(model, device=device)(x), GraphRunner(qmodel, device=device)(x)
+        for k in want:
+            np.testing.assert_allclose(got[k].cpu().numpy(), want[k].cpu().numpy(), atol=1e-1)
+
+
+def _weights_only(model_fn, strategy, group_size, dtype, symmetric, mse):     # :142-169
+    return QConfig(weights=QWeightArgs(dtype=DTYPES[dtype], strategy=strategy, group_size=group_size, symmetric=symmetric, mse=mse))
+
+
+def _gptq(strategy, group_size, dtype, data):                                 # :172-200
+    return QConfig(weights=QWeightArgs(dtype=DTYPES[dtype], strategy=strategy, group_size=group_size, algorithm=GPTQConfig(block_size=16)),
+                   calibration_data=data)
+
+
+def _acts(kind, is_static, dtype, symmetric, data, fmt="qdq", strategy="tensor"):     # :203-330
+    act = lambda: QActivationArgs(dtype=DTYPES[dtype], is_static=is_static)   # noqa: E731
+    kw = {}
+    if kind in ("in", "both"):
+        kw["input_activations"] = act()
+    if kind in ("out", "both"):
+        kw["output_activations"] = act()
+    return QConfig(weights=QWeightArgs(dtype=DTYPES[dtype], strategy=strategy, symmetric=symmetric), calibration_data=data, format=fmt, **kw)
+
+
+WEIGHT_GRID = list(itertools.product(THREE, STRATEGIES, ["uint8", "int8", "uint4", "int4"], [True, False], [False, True]))
+GPTQ_GRID = list(itertools.product(THREE, STRATEGIES, ["uint8", "int8", "int4", "uint4"]))
+ACT_GRID = ([(m, "in", st, dt, sym) for m in THREE for st, dt in ((True, "int8"), (True, "uint8"), (False, "uint8")) for sym in (True, False)] +
+            [(m, "out", st, dt, True) for m in THREE for st, dt in ((True, "int8"), (True, "uint8"), (False, "uint8"))] +
+            [(m, "both", st, dt, sym) for m in MODELS for st, dt in ((True, "int8"), (True, "uint8"), (False, "uint8")) for sym in (True, False)])
+QLINEAR_GRID = list(itertools.product(MODELS, ["int8", "uint8"], ["tensor", "channel"], [True, False]))
+
+
+def _run_grid(provider, device):
+    """Every case of the reference's five test functions.  `provider(model, qconfig)` quantizes; returns what it compared."""
+    count = 0
+    rng = np.random.default_rng(1234)
+    for name, (strategy, g), dtype, sym, mse in WEIGHT_GRID:
+        model = MODELS[name](rng)
+        qc = _weights_only(name, strategy, g, dtype, sym, mse)
+        _check(model, provider(model, qc, None), qc, _truncated_normal(rng, (2, 32)), device)
+        count += 1
+    for name, (strategy, g), dtype in GPTQ_GRID:
+        model = MODELS[name](rng)
+        data = _truncated_normal(rng, (2, 32))
+        qc = _gptq(strategy, g, dtype, data)
+        _check(model, provider(model, qc, "gptq"), qc, data, device)
+        count += 1
+    for name, kind, is_static, dtype, sym in ACT_GRID:
+        model = MODELS[name](rng)
+        data = _truncated_normal(rng, (2, 32)) if is_static else None
+        qc = _acts(kind, is_static, dtype, sym, data)
+        _check(model, provider(model, qc, None), qc, data if data is not None else _truncated_normal(rng, (2, 32)), device)
+        count += 1
+    for name, dtype, strategy, sym in QLINEAR_GRID:
+        model = MODELS[name](rng)
+        data = _truncated_normal(rng, (2, 32))
+        qc = _acts("both", True, dtype, sym, data, fmt="qlinear", strategy=strategy)
+        _check(model, provider(model, qc, None), qc, data, device)
+        count += 1
+    return count
+
+
+def test_the_reference_grids_with_the_oracle_as_provider():
+    n = _run_grid(lambda model, qc, tag: q_oracle(model, qc), "cpu")
+    assert n == len(WEIGHT_GRID) + len(GPTQ_GRID) + len(ACT_GRID) + len(QLINEAR_GRID) == 192 + 48 + 51 + 32
+
+
+@pytest.mark.gpu
+def test_the_reference_grids_on_the_device_path():
+    exact = {"n": 0}
+
+    def provider(model, qc, tag):
+        got = quantize_model(model, qc)
+        if tag != "gptq":                                                     # same activations -> the same file, byte for byte
+            twin = qc.model_copy()
+            assert P.serialize(got) == P.serialize(q_oracle(model, twin, runner_device="cuda")), qc
+            exact["n"] += 1
+        return got
+
+    n = _run_grid(provider, "cuda")
+    assert n == 323 and exact["n"] == 323 - len(GPTQ_GRID)
