@@ -1,8 +1,9 @@
 """Pre-processing configurations (reference: pre_passes/awq.py:24-37, pre_passes/smooth_quant.py:20-35) and the
 device-resident numeric cores of their passes -- SURVEY.md 8f, row N2.
 
-The passes themselves are graph surgery (Mul insertion, initializer replacement) and stay the reference's code:
-``build_pass`` hands over to it when the ONNX stack is importable and raises otherwise.  What runs on the GPU is
+The passes themselves are graph surgery (Mul insertion, initializer replacement): ``build_pass`` hands over to the
+reference's pass classes when the ONNX stack is importable (and raises otherwise); on ONNX bytes / files this package's
+own writer does the same surgery (`model_quantize._preprocess`).  What runs on the GPU in both is
 the arithmetic inside them -- the AWQ 20-point scale grid and 10-point clip search, the SmoothQuant scale -- exposed
 as ``awq_scale_search`` / ``awq_clip_search`` / ``smooth_quant_scale`` (NumPy in / out, device resident in between).
 """
