@@ -456,6 +456,132 @@ class GraphRunner:
         k = int(x[1].item()) if len(x) > 1 and x[1] is not None else 0
         return torch.triu(x[0], k) if a.get("upper", 1) else torch.tril(x[0], k)
 
+    # com.microsoft contrib operators that onnxruntime-genai's model builder (the reference's gemma3 example) and the
+    # transformer optimizer emit around the MatMuls: enough of them to calibrate such a graph.  Prefill and decode alike:
+    # positions and masks follow `seqlens_k` (valid length - 1 per batch entry) as onnxruntime's CPU kernels do.
+    def _rms(self, t, weight, eps):
+        import torch
+        var = t.to(torch.float32).pow(2).mean(dim=-1, keepdim=True)
+        return (t * torch.rsqrt(var + eps)).to(t.dtype) * weight
+
+    def _op_SimplifiedLayerNormalization(self, n, x, a, e):
+        axis = a.get("axis", -1)
+        if axis not in (-1, x[0].ndim - 1):
+            raise UnsupportedOperator("GraphRunner: SimplifiedLayerNormalization over more than the last axis")
+        return (self._rms(x[0], x[1], a.get("epsilon", 1e-5)),) + (None,) * (len(n.output) - 1)
+
+    def _op_SkipSimplifiedLayerNormalization(self, n, x, a, e):
+        s = x[0] + x[1]
+        if len(x) > 3 and x[3] is not None:
+            s = s + x[3]
+        out = (self._rms(s, x[2], a.get("epsilon", 1e-5)), None, None, s)
+        return out[:max(1, len(n.output))]
+
+    def _op_SkipLayerNormalization(self, n, x, a, e):
+        import torch
+        s = x[0] + x[1]
+        if len(x) > 4 and x[4] is not None:
+            s = s + x[4]
+        y = torch.nn.functional.layer_norm(s, (s.shape[-1],), x[2], x[3] if len(x) > 3 else None, a.get("epsilon", 1e-5))
+        return (y, None, None, s)[:max(1, len(n.output))]
+
+    def _op_FastGelu(self, n, x, a, e):
+        import torch
+        t = x[0] + x[1] if len(x) > 1 and x[1] is not None else x[0]
+        return torch.nn.functional.gelu(t, approximate="tanh")
+
+    def _op_BiasGelu(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.gelu(x[0] + x[1])
+
+    def _op_QuickGelu(self, n, x, a, e):
+        import torch
+        return x[0] * torch.sigmoid(a.get("alpha", 1.702) * x[0])
+
+    @staticmethod
+    def _rotate(t, cos, sin, interleaved):
+        """t [B, H, S, D]; cos / sin [B, S, R/2] for the first R of the D channels."""
+        import torch
+        r = cos.shape[-1] * 2
+        rot, rest = t[..., :r], t[..., r:]
+        c, s_ = cos[:, None, :, :], sin[:, None, :, :]
+        if interleaved:
+            x1, x2 = rot[..., 0::2], rot[..., 1::2]
+            out = torch.stack((x1 * c - x2 * s_, x2 * c + x1 * s_), dim=-1).flatten(-2)
+        else:
+            x1, x2 = rot[..., : r // 2], rot[..., r // 2:]
+            out = torch.cat((x1 * c - x2 * s_, x2 * c + x1 * s_), dim=-1)
+        return torch.cat((out, rest), dim=-1) if rest.shape[-1] else out
+
+    def _op_RotaryEmbedding(self, n, x, a, e):
+        """com.microsoft::RotaryEmbedding(input [B, S, H*D] | [B, H, S, D], position_ids [B, S] | [1], cos_cache, sin_cache)."""
+        import torch
+        t, pos, cos_c, sin_c = x[0], x[1].to(torch.int64), x[2], x[3]
+        packed = t.ndim == 3
+        if packed:
+            heads = a.get("num_heads", 0)
+            d = cos_c.shape[-1] * 2 if not heads else t.shape[-1] // heads
+            heads = heads or t.shape[-1] // d
+            t = t.reshape(t.shape[0], t.shape[1], heads, d).transpose(1, 2)
+        b, s_len = t.shape[0], t.shape[2]
+        if pos.numel() == 1:
+            pos = pos.reshape(1, 1) + torch.arange(s_len, device=pos.device).reshape(1, -1)
+        pos = pos.expand(b, s_len).to(cos_c.device)
+        out = self._rotate(t, cos_c[pos], sin_c[pos], bool(a.get("interleaved", 0)))
+        if a.get("scale", 1.0) != 1.0:
+            out = out * a.get("scale", 1.0)
+        return out.transpose(1, 2).reshape(b, s_len, -1) if packed else out
+
+    def _op_GroupQueryAttention(self, n, x, a, e):
+        """com.microsoft::GroupQueryAttention: query (or packed QKV), key, value, past_key, past_value [B, Hkv, P, D], seqlens_k
+        [B] (valid total length - 1), total_sequence_length, cos_cache, sin_cache -> output, present_key, present_value."""
+        import torch
+        x = list(x) + [None] * (9 - len(x))
+        q, k, v, past_k, past_v, seqlens, _total, cos_c, sin_c = x[:9]
+        if any(t is not None for t in x[9:]):
+            raise UnsupportedOperator("GraphRunner: GroupQueryAttention with position_ids / attention_bias inputs")
+        heads, kv_heads = a["num_heads"], a["kv_num_heads"]
+        b, s_len = q.shape[0], q.shape[1]
+        if k is None:                                          # packed QKV
+            d = q.shape[-1] // (heads + 2 * kv_heads)
+            q, k, v = torch.split(q, [heads * d, kv_heads * d, kv_heads * d], dim=-1)
+        d = q.shape[-1] // heads
+        q = q.reshape(b, s_len, heads, d).transpose(1, 2)
+        k = k.reshape(b, s_len, kv_heads, d).transpose(1, 2)
+        v = v.reshape(b, s_len, kv_heads, d).transpose(1, 2)
+        dev = q.device
+        past_len = 0 if past_k is None else past_k.shape[2]       # the past holds exactly the tokens seen so far (no shared buffer)
+        pos = (past_len + torch.arange(s_len, device=dev)).reshape(1, -1).expand(b, s_len)     # absolute positions of the new tokens
+        if a.get("do_rotary", 0):
+            inter = bool(a.get("rotary_interleaved", 0))
+            cos, sin = cos_c.to(dev)[pos], sin_c.to(dev)[pos]
+            q, k = self._rotate(q, cos, sin, inter), self._rotate(k, cos, sin, inter)
+        if past_len:
+            k = torch.cat((past_k.to(k.dtype), k), dim=2)
+            v = torch.cat((past_v.to(v.dtype), v), dim=2)
+        total = past_len + s_len
+        key_pos = torch.arange(total, device=dev).reshape(1, 1, -1)
+        qpos = pos.reshape(b, s_len, 1)
+        allowed = key_pos <= qpos                                 # causal
+        window = a.get("local_window_size", -1)
+        if window is not None and window > 0:
+            allowed = allowed & (key_pos >= qpos - window)        # the token itself and `window` tokens to its left
+        if seqlens is not None:                                   # right-padded prompts: keys past a row's valid length
+            valid = seqlens.to(dev).to(torch.int64).reshape(b, 1, 1) + 1
+            allowed = allowed & (key_pos < valid)
+        scale = a.get("scale", 0.0) or 1.0 / (d ** 0.5)
+        rep = heads // kv_heads
+        kk, vv = k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1)
+        scores = torch.matmul(q, kk.transpose(-1, -2)) * scale
+        softcap = a.get("softcap", 0.0)
+        if softcap:
+            scores = softcap * torch.tanh(scores / softcap)
+        scores = scores.masked_fill(~allowed[:, None, :, :], float("-inf"))
+        probs = torch.softmax(scores, dim=-1)
+        probs = torch.nan_to_num(probs)                           # rows of padding queries have no key at all
+        out = torch.matmul(probs, vv).transpose(1, 2).reshape(b, s_len, heads * d)
+        return (out, k, v)[:max(1, len(n.output))]
+
     # quantization operators (ONNX QuantizeLinear / DequantizeLinear / DynamicQuantizeLinear, opset 21 semantics)
     @staticmethod
     def _per_axis(p, like, axis):

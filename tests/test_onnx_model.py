@@ -704,3 +704,106 @@ def test_static_activations_are_recalibrated_after_preprocessing():
         cal.collect("v", b)
     s, z = O.qparams(*cal.compute_range("v"), "uint8", False, False)
     assert inits[first.input[4]].tobytes() == np.asarray(s, np.float32).tobytes() and int(inits[first.input[5]]) == int(z)
+
+
+# ------------------------------------------------------------------------------------------------------------------ contrib operators
+def _gqa_model(b, s, heads, kv, d, window=None):
+    hid = heads * d
+    gen = torch.Generator().manual_seed(0)
+    w = {n: torch.randn(hid, width, generator=gen) * 0.1 for n, width in (("wq", hid), ("wk", kv * d), ("wv", kv * d))}
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    fr = torch.outer(torch.arange(64).float(), inv)
+    attrs = dict(num_heads=heads, kv_num_heads=kv, do_rotary=1)
+    if window:
+        attrs["local_window_size"] = window
+    nodes = [P.make_node("MatMul", ["x", "wq"], ["q"]), P.make_node("MatMul", ["x", "wk"], ["k"]), P.make_node("MatMul", ["x", "wv"], ["v"]),
+             P.make_node("GroupQueryAttention", ["q", "k", "v", "pk", "pv", "seqlens", "total", "cos", "sin"], ["y", "prk", "prv"],
+                         domain="com.microsoft", **attrs)]
+    inits = [P.numpy_to_tensor(n, a.numpy()) for n, a in list(w.items()) + [("cos", fr.cos()), ("sin", fr.sin())]]
+    g = P.Message("GraphProto", name="g", node=nodes, initializer=inits, output=[P.make_value_info("y", 1, None)],
+                  input=[P.make_value_info("x", 1, [b, s, hid]), P.make_value_info("pk", 1, [b, kv, "p", d]), P.make_value_info("pv", 1, [b, kv, "p", d]),
+                         P.make_value_info("seqlens", 6, [b]), P.make_value_info("total", 6, [])])
+    model = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21),
+                                                                           P.Message("OperatorSetIdProto", domain="com.microsoft", version=1)])
+    return model, w, fr.cos(), fr.sin()
+
+
+def test_contrib_operators_of_genai_style_exports():
+    """`com.microsoft::GroupQueryAttention` (rotary inside, grouped heads, causal + sliding window + right padding, prefill
+    and decode), `RotaryEmbedding`, the RMS-norm family and the Gelu variants against plain torch restatements."""
+    b, s, heads, kv, d = 2, 7, 4, 2, 16
+    hid = heads * d
+    model, w, cos, sin = _gqa_model(b, s, heads, kv, d)
+    x = torch.randn(b, s, hid, generator=torch.Generator().manual_seed(1))
+    empty = torch.zeros(b, kv, 0, d)
+
+    def feed(xs, pk=empty, pv=empty, valid=None):
+        total = pk.shape[2] + xs.shape[1]
+        lens = torch.full((b,), total - 1, dtype=torch.int32) if valid is None else torch.tensor(valid, dtype=torch.int32) - 1
+        return {"x": xs, "pk": pk, "pv": pv, "seqlens": lens, "total": torch.tensor(total, dtype=torch.int32)}
+
+    def rope(t, n):                                                        # HF `rotate_half` convention = non-interleaved
+        c, s_ = torch.cat((cos[:n], cos[:n]), -1)[None, None], torch.cat((sin[:n], sin[:n]), -1)[None, None]
+        return t * c + torch.cat((-t[..., d // 2:], t[..., : d // 2]), -1) * s_
+
+    def reference(xs, mask):
+        n = xs.shape[1]
+        q = rope((xs @ w["wq"]).view(b, n, heads, d).transpose(1, 2), n)
+        k = rope((xs @ w["wk"]).view(b, n, kv, d).transpose(1, 2), n).repeat_interleave(heads // kv, 1)
+        v = (xs @ w["wv"]).view(b, n, kv, d).transpose(1, 2).repeat_interleave(heads // kv, 1)
+        return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(b, n, hid)
+
+    causal = torch.ones(s, s, dtype=torch.bool).tril()
+    run = GraphRunner(model, outputs=["y", "prk", "prv"], device="cpu")
+    full = run(feed(x))
+    torch.testing.assert_close(full["y"], reference(x, causal), rtol=1e-5, atol=1e-5)
+    assert full["prk"].shape == (b, kv, s, d)
+    # decode: the last token against the cache of the first s - 1 equals the last row of the prefill
+    pre = run(feed(x[:, : s - 1]))
+    dec = run(feed(x[:, s - 1:], pre["prk"], pre["prv"]))
+    torch.testing.assert_close(dec["y"][:, 0], full["y"][:, -1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dec["prk"], full["prk"], rtol=1e-5, atol=1e-5)
+    # sliding window: the token itself and `window` tokens to its left
+    wmodel, *_ = _gqa_model(b, s, heads, kv, d, window=2)
+    idx = torch.arange(s)
+    band = causal & (idx[None, :] >= idx[:, None] - 2)
+    torch.testing.assert_close(GraphRunner(wmodel, device="cpu")(feed(x))["y"], reference(x, band), rtol=1e-5, atol=1e-5)
+    # right padding: row 1 has 4 valid tokens; its first 4 outputs are those of the 4-token prompt
+    padded = run(feed(x, valid=[s, 4]))
+    short = run(feed(x[:, :4]))
+    torch.testing.assert_close(padded["y"][1, :4], short["y"][1], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(padded["y"][0], full["y"][0], rtol=1e-5, atol=1e-5)
+
+    def one(op, inputs, outputs=("y",), domain="com.microsoft", **attrs):
+        names = [f"i{k}" for k in range(len(inputs))]
+        g = P.Message("GraphProto", name="g", node=[P.make_node(op, names, list(outputs), domain=domain, **attrs)],
+                      input=[P.make_value_info(n, 1, None) for n in names], output=[P.make_value_info(o, 1, None) for o in outputs if o])
+        m = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+        return GraphRunner(m, device="cpu")(dict(zip(names, inputs)))
+
+    t, skip, gamma = torch.randn(2, 5, 32), torch.randn(2, 5, 32), torch.rand(32) + 0.5
+    rms = lambda v: v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma      # noqa: E731
+    torch.testing.assert_close(one("SimplifiedLayerNormalization", [t, gamma], domain="", epsilon=1e-6, axis=-1)["y"], rms(t))
+    got = one("SkipSimplifiedLayerNormalization", [t, skip, gamma], outputs=("y", "", "", "sum"), epsilon=1e-6)
+    torch.testing.assert_close(got["y"], rms(t + skip))
+    torch.testing.assert_close(got["sum"], t + skip)
+    beta = torch.randn(32)
+    got = one("SkipLayerNormalization", [t, skip, gamma, beta], outputs=("y", "", "", "sum"), epsilon=1e-5)
+    torch.testing.assert_close(got["y"], torch.nn.functional.layer_norm(t + skip, (32,), gamma, beta, 1e-5))
+    torch.testing.assert_close(one("FastGelu", [t, beta])["y"], torch.nn.functional.gelu(t + beta, approximate="tanh"))
+    torch.testing.assert_close(one("BiasGelu", [t, beta])["y"], torch.nn.functional.gelu(t + beta))
+    torch.testing.assert_close(one("QuickGelu", [t], alpha=1.702)["y"], t * torch.sigmoid(1.702 * t))
+    # RotaryEmbedding on [B, S, H * D] with explicit positions, both layouts
+    pos = torch.arange(3, 3 + s).reshape(1, s).expand(b, s).contiguous()
+    xq = (x @ w["wq"])
+    for inter in (0, 1):
+        got = one("RotaryEmbedding", [xq, pos, cos, sin], interleaved=inter, num_heads=heads)["y"].view(b, s, heads, d).transpose(1, 2)
+        th = xq.view(b, s, heads, d).transpose(1, 2)
+        c, s_ = cos[pos][:, None], sin[pos][:, None]
+        if inter:
+            x1, x2 = th[..., 0::2], th[..., 1::2]
+            want = torch.stack((x1 * c - x2 * s_, x2 * c + x1 * s_), -1).flatten(-2)
+        else:
+            x1, x2 = th[..., : d // 2], th[..., d // 2:]
+            want = torch.cat((x1 * c - x2 * s_, x2 * c + x1 * s_), -1)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
