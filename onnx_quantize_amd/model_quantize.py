@@ -108,10 +108,6 @@ class _Graph:
                         Message("TensorShapeProto.Dimension", dim_value=int(d)) for d in t.dims])
         return t
 
-    def uses(self, name):
-        """[(node, input index)] in graph order -- `ir.Value.uses()` for a top-level value."""
-        return [(n, i) for n in self.g.node for i, v in enumerate(n.input) if v == name]
-
 
 def _attr(node, name, default=None):
     for a in node.attribute:
@@ -181,10 +177,15 @@ def _name_nodes(G: _Graph) -> None:
 def _duplicate_shared_initializers(G: _Graph) -> None:
     """duplicate_initializer.py:38-68: an initializer read in more than one place keeps its first use; every further use gets
     a copy named `<name>_<i>` (tied weights: each consumer is then quantized on its own)."""
+    all_uses: dict = {}
+    for n in G.g.node:                                     # `ir.Value.uses()` of every top-level value, in graph order
+        for i, v in enumerate(n.input):
+            if v in G.inits:
+                all_uses.setdefault(v, []).append((n, i))
     for name in list(G.inits):
         if name in G.graph_inputs or name in G.graph_outputs:
             continue
-        uses = G.uses(name)
+        uses = all_uses.get(name, ())
         if len(uses) <= 1:
             continue
         src = G.inits[name]
@@ -200,7 +201,7 @@ def _duplicate_shared_initializers(G: _Graph) -> None:
 
 _SAME_RANK = {"Relu", "Tanh", "Sigmoid", "Erf", "Sqrt", "Exp", "Log", "Neg", "Abs", "Cast", "Identity", "Dropout", "Softmax",
               "LogSoftmax", "LayerNormalization", "Transpose", "LeakyRelu", "Gelu", "Clip", "Softplus", "Reciprocal", "Floor",
-              "Ceil", "Round", "Not", "Sin", "Cos", "Trilu", "Concat", "Slice", "Tile", "Expand"}
+              "Ceil", "Round", "Not", "Sin", "Cos", "Trilu", "Concat", "Slice", "Tile"}
 _BROADCAST = {"Add", "Sub", "Mul", "Div", "Pow", "Min", "Max", "Sum", "Where", "Equal", "Less", "Greater", "LessOrEqual",
               "GreaterOrEqual", "And", "Or"}
 
