@@ -7,7 +7,8 @@ small enough to restate, and it lets a GPU box quantize a file end to end with n
   reference step                                         here
   ------------------------------------------------------ --------------------------------------------------------------
   ir.from_proto (a copy)                                  `Message.copy()` of the parsed model
-  onnxscript.optimizer.optimize                           NOT restated: constants must already be initializers
+  onnxscript.optimizer.optimize                           NOT restated, except that `Constant` nodes feeding weight / bias
+                                                          slots become initializers (`_lift_constant_weights`); no folding
   version_converter.convert_version(target 21)            `_raise_opset`: the adapters a MatMul / Gemm export needs
                                                           (Reduce* axes, Split num_outputs), anything else refused by name
   NameFixPass                                             `_name_nodes`: unnamed nodes get names (the ignore patterns and
@@ -172,6 +173,27 @@ def _name_nodes(G: _Graph) -> None:
                 name += "_"
             n.name = name
             taken.add(name)
+
+
+def _lift_constant_weights(G: _Graph) -> None:
+    """`ir.convenience.get_const_tensor` (the constant check of every rule and of `get_target_nodes`, calibrate.py:75-85) also
+    sees a value that a `Constant` node produces.  Such a node feeding the weight or bias slot of a MatMul / Gemm becomes an
+    initializer of the same name here, so that everything downstream deals with initializers only."""
+    wanted = {v for n in G.g.node if n.op_type in ("MatMul", "Gemm") and not n.domain for v in list(n.input)[1:3] if v}
+    drop = set()
+    for n in G.g.node:
+        if n.op_type != "Constant" or n.domain or not n.output or n.output[0] not in wanted:
+            continue
+        value = next((a for a in n.attribute if a.name == "value" and a.has("t")), None)
+        if value is None or n.output[0] in G.inits:
+            continue
+        t = value.t.copy()
+        t.name = n.output[0]
+        G.g.initializer.append(t)
+        G.inits[t.name] = t
+        drop.add(id(n))
+    if drop:
+        G.g.node = [n for n in G.g.node if id(n) not in drop]
 
 
 def _duplicate_shared_initializers(G: _Graph) -> None:
@@ -579,6 +601,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     G = _Graph(model.graph)
     _raise_opset(model, G)
     _name_nodes(G)
+    _lift_constant_weights(G)
     _duplicate_shared_initializers(G)
     _fuse_matmul_add(G)
     _standardize_gemm(G)

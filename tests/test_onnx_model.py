@@ -446,6 +446,22 @@ def test_pre_passes_follow_the_reference():
     assert [n.op_type for n in out.graph.node] == ["QMatMulWeightsOnlyQDQ", "Add"]
 
 
+def test_weights_produced_by_constant_nodes_are_quantized_too():
+    """`ir.convenience.get_const_tensor` accepts a value a Constant node produces (calibrate.py:75-85, matmul_to_qmatmul.py:38)."""
+    w = np.random.default_rng(2).standard_normal((16, 8)).astype(np.float32)
+    b = np.linspace(-1, 1, 8, dtype=np.float32)
+    g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["n", 16])], output=[P.make_value_info("y", 1, None)],
+                  node=[P.make_node("Constant", [], ["w"], name="cw", value=P.numpy_to_tensor("", w)),
+                        P.make_node("Constant", [], ["b"], name="cb", value=P.numpy_to_tensor("", b)),
+                        P.make_node("Gemm", ["x", "w", "b"], ["y"], name="fc")])
+    model = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+    out = q_oracle(model, CONFIGS["int8_channel"]())
+    assert [n.op_type for n in out.graph.node] == ["QGemmWeightsOnlyQDQ"]
+    q, s, z = O.rtn_quantize(w, "int8", "channel", -1, False)
+    inits = {t.name: P.tensor_to_numpy(t) for t in out.graph.initializer}
+    assert np.array_equal(inits["w"], q) and inits["w/scale"].tobytes() == s.tobytes()
+
+
 def test_opset_is_raised_with_adapters_or_refused_by_name():
     x = P.make_value_info("x", 1, ["batch", 16])
     w = np.random.default_rng(1).standard_normal((16, 4)).astype(np.float32)
