@@ -212,7 +212,7 @@ class GraphRunner:
     def _op_LessOrEqual(self, n, x, a, e): return x[0] <= x[1]
     def _op_GreaterOrEqual(self, n, x, a, e): return x[0] >= x[1]
     def _op_Identity(self, n, x, a, e): return x[0]
-    def _op_Dropout(self, n, x, a, e): return (x[0], None)[:len(n.output)] if len(n.output) > 1 else x[0]
+    def _op_Dropout(self, n, x, a, e): return (x[0], None)[:max(1, len(n.output))]      # inference: identity (+ an unused mask)
 
     def _op_Where(self, n, x, a, e):
         import torch
@@ -265,12 +265,11 @@ class GraphRunner:
 
     def _op_Softmax(self, n, x, a, e):
         import torch
-        if self.opset < 13:                                  # older semantics: flatten to 2-D at `axis`
-            axis = a.get("axis", 1)
-            shape = x[0].shape
-            return torch.softmax(x[0].flatten(axis if axis >= 0 else axis + x[0].ndim), -1).reshape(shape) \
-                if axis not in (-1, x[0].ndim - 1) else torch.softmax(x[0], -1)
-        return torch.softmax(x[0], dim=a.get("axis", -1))
+        if self.opset >= 13:
+            return torch.softmax(x[0], dim=a.get("axis", -1))
+        axis = a.get("axis", 1)                              # before opset 13: over everything from `axis` on, flattened
+        axis = axis if axis >= 0 else axis + x[0].ndim
+        return torch.softmax(x[0].flatten(axis), dim=-1).reshape(x[0].shape)
 
     def _op_LogSoftmax(self, n, x, a, e):
         import torch

@@ -149,7 +149,10 @@ class Message:
 # --------------------------------------------------------------------------------------------------------------- reading
 def _varint(buf, pos):
     result = shift = 0
+    end = len(buf)
     while True:
+        if pos >= end:
+            raise ValueError("onnx_proto: truncated varint")
         b = buf[pos]
         pos += 1
         result |= (b & 0x7F) << shift
@@ -171,15 +174,22 @@ def _scalar_from_wire(kind, wire, buf, pos):
     if wire == 0:
         v, pos = _varint(buf, pos)
         return _signed(v, kind), pos
-    if wire == 5:
-        return struct.unpack_from("<f", buf, pos)[0], pos + 4
-    if wire == 1:
-        return struct.unpack_from("<d", buf, pos)[0], pos + 8
+    if wire in (1, 5):
+        size = 4 if wire == 5 else 8
+        if pos + size > len(buf):
+            raise ValueError("onnx_proto: truncated fixed-width field")
+        return struct.unpack_from("<f" if wire == 5 else "<d", buf, pos)[0], pos + size
     raise ValueError(f"onnx_proto: wire type {wire} for a scalar field")
 
 
-def parse(type_name: str, data) -> Message:
-    """Decode one message of type `type_name` from bytes / memoryview (large byte fields stay views into `data`)."""
+_MAX_DEPTH = 64          # sub-graphs inside attributes nest; a file that nests deeper than any real model is refused, not recursed into
+
+
+def parse(type_name: str, data, _depth: int = 0) -> Message:
+    """Decode one message of type `type_name` from bytes / memoryview (large byte fields stay views into `data`).  Malformed
+    input of any kind is a ValueError."""
+    if _depth > _MAX_DEPTH:
+        raise ValueError(f"onnx_proto: messages nested deeper than {_MAX_DEPTH}")
     buf = data if isinstance(data, memoryview) else memoryview(data)
     fields = SCHEMA[type_name]
     msg = Message(type_name)
@@ -218,11 +228,13 @@ def parse(type_name: str, data) -> Message:
             elif kind == "bytes":
                 value = chunk if n > 4096 else bytes(chunk)            # raw_data of a large initializer: no copy
             elif kind in SCHEMA:
-                value = parse(kind, chunk)
+                value = parse(kind, chunk, _depth + 1)
             else:                                                      # a packed run of scalars
                 if label == O:
                     raise ValueError(f"onnx_proto: length-delimited record for scalar field '{name}'")
                 if kind in _FIXED:
+                    if n % _FIXED[kind][1]:
+                        raise ValueError(f"onnx_proto: packed field '{name}' of {type_name} is {n} bytes long")
                     vals = np.frombuffer(chunk, dtype=_FIXED[kind][2]).tolist()
                 else:
                     vals, p = [], 0

@@ -80,6 +80,55 @@ def test_wire_primitives():
     assert P.parse("ValueInfoProto", P.serialize(P.make_value_info("s", 1, None))).type.tensor_type.shape is None
 
 
+def test_malformed_files_are_value_errors():
+    """A model file is input from outside: whatever a mutated file does to the parser, it ends in ValueError (or parses) --
+    no IndexError / struct.error / RecursionError, no hang.  4000 random mutations of a real file + a nesting bomb."""
+    import random
+    data = open(os.path.join(FIXTURES, "mlp_matmul.onnx"), "rb").read()
+    rng = random.Random(0)
+    parsed = 0
+    for _ in range(4000):
+        b = bytearray(data)
+        for _ in range(rng.randint(1, 6)):
+            op, pos = rng.random(), rng.randrange(len(b))
+            if op < 0.5:
+                b[pos] = rng.randrange(256)
+            elif op < 0.75:
+                del b[pos:pos + rng.randint(1, 40)]
+            else:
+                b[pos:pos] = bytes(rng.randrange(256) for _ in range(rng.randint(1, 12)))
+        try:
+            m = P.parse_model(bytes(b))
+        except ValueError:
+            continue
+        parsed += 1
+        for t in ([] if m.graph is None else m.graph.initializer):
+            try:
+                P.tensor_to_numpy(t)
+            except ValueError:
+                pass
+        P.serialize(m)
+    assert 100 < parsed < 3000
+    # graph -> node -> attribute -> graph -> ... 500 levels deep
+    inner = b""
+    for _ in range(500):
+        a = bytearray()
+        P._put_varint(a, (6 << 3) | 2)
+        P._put_varint(a, len(inner))
+        a += inner                                                           # AttributeProto { g: inner }
+        n = bytearray()
+        P._put_varint(n, (5 << 3) | 2)
+        P._put_varint(n, len(a))
+        n += a                                                               # NodeProto { attribute: ... }
+        gph = bytearray()
+        P._put_varint(gph, (1 << 3) | 2)
+        P._put_varint(gph, len(n))
+        gph += n                                                             # GraphProto { node: ... }
+        inner = bytes(gph)
+    with pytest.raises(ValueError, match="nested deeper"):
+        P.parse("GraphProto", inner)
+
+
 def test_tensors_round_trip_including_four_bit_packing():
     rng = np.random.default_rng(0)
     for dt in (np.float32, np.float16, np.float64, np.int8, np.uint8, np.int32, np.int64, np.bool_):
