@@ -49,11 +49,20 @@ class GraphRunner:
     model: a parsed ModelProto (`onnx_proto.parse_model`); outputs: the value names wanted (default: the graph's own
     outputs); feed: one tensor / array (single-input model) or {input name: tensor / array}."""
 
-    def __init__(self, model: Message, outputs=None, device="cuda"):
+    def __init__(self, model: Message, outputs=None, device="cuda", capture: bool = False):
         import torch
 
         self.model, self.graph = model, model.graph
         self.device = torch.device(device)
+        # capture: a calibration walk is the same few hundred small launches per batch, bound by their dispatch (~40 us per
+        # node from Python).  With `capture` the second pass over a given input signature is recorded into a HIP graph and
+        # every later one is a replay; a pass that cannot be recorded (a host read of device data, a host -> device copy in
+        # the middle) or whose replay does not reproduce the eager pass bit for bit simply stays eager.
+        self.capture = bool(capture) and self.device.type == "cuda"
+        self._graphs: dict = {}              # input signature -> (graph, static inputs, static outputs) | None (stays eager)
+        self._seen: set = set()
+        self._moved: dict = {}               # id(host constant) -> (the constant, its copy on the device)
+        self._const_nodes: dict = {}         # id(Constant node) -> its value (one object per node, so `_moved` can key on it)
         self.functions = {(f.domain or "", f.name, f.overload or ""): f for f in model.functions}
         self.opset = max([int(o.version or 1) for o in model.opset_import if not o.domain] or [1])
         self.wanted = list(outputs) if outputs is not None else [o.name for o in self.graph.output]
@@ -115,17 +124,61 @@ class GraphRunner:
             if len(self.input_names) != 1:
                 raise ValueError(f"GraphRunner: the model has inputs {self.input_names}; feed them as a dict")
             feed = {self.input_names[0]: feed}
-        env = dict(self.constants)
         for name in self.input_names:
             if name not in feed:
                 raise KeyError(f"GraphRunner: no data for model input '{name}'")
+        inputs = {}
         for name, v in feed.items():
             t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, order="C"))
-            env[name] = t.to(self.device, non_blocking=True)
-        keep = set(self.wanted)
+            inputs[name] = t.to(self.device, non_blocking=True)
+        if not self.capture:
+            return self._eager(inputs)
+        key = tuple(sorted((name, tuple(t.shape), str(t.dtype)) for name, t in inputs.items()))
+        entry = self._graphs.get(key, False)
+        if entry:
+            graph, static_in, static_out = entry
+            for name, t in inputs.items():
+                static_in[name].copy_(t)
+            graph.replay()
+            return {name: t.clone() for name, t in static_out.items()}      # the static buffers are overwritten by the next replay
+        if entry is None or key not in self._seen:                           # first sight of a signature (or not recordable): eager
+            self._seen.add(key)
+            return self._eager(inputs)
+        return self._record(key, inputs)
+
+    def _eager(self, inputs) -> dict:
+        import torch
+        env = dict(self.constants)
+        env.update(inputs)
         with torch.no_grad():
-            self._run(self.nodes, env, keep, self.last_use)
+            self._run(self.nodes, env, set(self.wanted), self.last_use)
         return {name: env[name] for name in self.wanted}
+
+    def _record(self, key, inputs) -> dict:
+        """Record one pass into a HIP graph, check one replay of it against the eager pass on the same inputs, keep it only
+        if every tapped value is bit-identical.  Returns this batch's values either way."""
+        import torch
+        eager = self._eager(inputs)
+        self._graphs[key] = None
+        if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in eager.values()):
+            return eager
+        static_in = {name: t.clone() for name, t in inputs.items()}
+        graph = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph):
+                static_out = self._eager(static_in)
+            graph.replay()
+            torch.cuda.synchronize()
+            same = all(torch.equal(static_out[name], eager[name]) for name in eager)
+        except Exception as exc:                                           # noqa: BLE001 -- whatever refused the recording: stay eager
+            import logging
+            logging.getLogger("onnx_quantize").debug("GraphRunner: pass not recordable (%s); staying eager", str(exc).splitlines()[0][:120])
+            torch.cuda.synchronize()
+            return eager
+        if same:
+            self._graphs[key] = (graph, static_in, static_out)
+        return eager
 
     def _run(self, nodes, env, keep=(), last_use=None):
         for i, node in enumerate(nodes):
@@ -152,12 +205,28 @@ class GraphRunner:
         if impl is None:
             raise UnsupportedOperator(f"GraphRunner: operator '{node.op_type}' (node '{node.name}') is not implemented")
         # shape arithmetic lives on the host; an operator that mixes it with device data takes it to the device
-        devs = {t.device for t in ins if isinstance(t, torch.Tensor)}
+        devs = {t.device.type for t in ins if isinstance(t, torch.Tensor)}
         if len(devs) > 1 and node.op_type not in _HOST_OPERANDS:
-            ins = [t.to(self.device) if isinstance(t, torch.Tensor) else t for t in ins]
+            ins = [self._to_device(t, node.op_type) if isinstance(t, torch.Tensor) else t for t in ins]
         attrs = {a.name: a for a in node.attribute}
         out = impl(node, ins, _Attrs(attrs), env)
         return out if isinstance(out, (tuple, list)) else (out,)
+
+    def _to_device(self, t, op_type):
+        """A host operand of an operator that also has device operands.  One-element shape arithmetic joins elementwise
+        arithmetic as a Python number (no copy at all: the value is a property of the input shapes); a constant is copied
+        once and the copy reused; anything else is copied now."""
+        if t.device.type == self.device.type:
+            return t
+        if t.numel() == 1 and op_type in _SCALAR_FRIENDLY:
+            return t.item()
+        hit = self._moved.get(id(t))
+        if hit is not None and hit[0] is t:
+            return hit[1]
+        moved = t.to(self.device)
+        if any(t is c for c in self.constants.values()) or any(t is c for c in self._const_nodes.values()):
+            self._moved[id(t)] = (t, moved)
+        return moved
 
     def _call_function(self, fn, node, ins):
         if fn.attribute or fn.attribute_proto:
@@ -180,13 +249,20 @@ class GraphRunner:
 
     def _op_Div(self, n, x, a, e):
         import torch
-        if not (x[0].is_floating_point() or x[1].is_floating_point()):
-            return torch.div(x[0], x[1], rounding_mode="trunc")
+        floating = [t.is_floating_point() if isinstance(t, torch.Tensor) else isinstance(t, float) for t in x[:2]]
+        if not any(floating):                                 # integer division truncates towards zero
+            return torch.div(x[0], x[1], rounding_mode="trunc") if isinstance(x[0], torch.Tensor) else \
+                torch.div(torch.tensor(x[0], device=x[1].device), x[1], rounding_mode="trunc")
         return x[0] / x[1]
 
     def _op_Pow(self, n, x, a, e):
         import torch
-        return torch.pow(x[0], x[1].to(x[0].dtype) if x[0].is_floating_point() else x[1])
+        base, exp = x[0], x[1]
+        if not isinstance(base, torch.Tensor):                 # a host scalar raised to a device tensor
+            base = torch.full_like(exp, base, dtype=exp.dtype if exp.is_floating_point() else torch.float32)
+        if isinstance(exp, torch.Tensor) and base.is_floating_point():
+            exp = exp.to(base.dtype)
+        return torch.pow(base, exp)
 
     def _op_Sqrt(self, n, x, a, e): return x[0].sqrt()
     def _op_Exp(self, n, x, a, e): return x[0].exp()
@@ -324,6 +400,12 @@ class GraphRunner:
         return torch.tensor(x[0].numel(), dtype=torch.int64)
 
     def _op_Constant(self, n, x, a, e):
+        hit = self._const_nodes.get(id(n))
+        if hit is None:
+            hit = self._const_nodes[id(n)] = self._constant_value(n, a)
+        return hit
+
+    def _constant_value(self, n, a):
         import torch
         if "value" in a:
             return self._constant(a["value"])
@@ -691,7 +773,8 @@ class GraphRunner:
         return out
 
 
-_HOST_OPERANDS = {"Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split", "ConstantOfShape", "Gather", "Trilu",
+_SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
+_HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split", "ConstantOfShape", "Gather", "Trilu",
                   "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}
 
 

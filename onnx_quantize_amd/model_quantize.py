@@ -395,7 +395,7 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
     if data is None:
         data = generate_random_calibration_data(num_samples, inputs)
     # a model input that a target node reads directly is "produced" by the feed: the runner returns it like any other value
-    runner = GraphRunner(model, outputs=wanted, device=device)
+    runner = GraphRunner(model, outputs=wanted, device=device, capture=True)      # batches of one shape replay a recorded pass
     stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
                               hessian_names=in_names if (algo and not keep_inputs) else (),
                               keep_names=in_names if keep_inputs else ())
@@ -614,7 +614,11 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     if qconfig.preprocessors and targets:                   # pre_passes/__init__.py:72-88
         per_node = _preprocess(G, targets, qconfig, meta, searches or DeviceSearches())
         _name_nodes(G)
-        if any(p.requires_post_calibration for p in qconfig.preprocessors):
+        consumed = any(a is not None and a.is_static for a in (qconfig.input_activations, qconfig.output_activations)) or \
+            bool(qconfig.weights.algorithm.requires_calibration)
+        if any(p.requires_post_calibration for p in qconfig.preprocessors) and consumed:
+            # pre_passes/__init__.py:85-88 calibrates again unconditionally; with weight-only RTN behind the preprocessor
+            # nothing reads what that walk collects (no static activation, no Hessian), so it is not run
             logger.info("Re-calibrating the model after pre-processing...")
             meta = calibrate(model, G, targets, qconfig, device, keep_inputs=False)
 

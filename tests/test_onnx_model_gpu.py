@@ -255,3 +255,45 @@ def test_awq_improves_on_rtn_through_the_file_path():
     y0 = GraphRunner(src, device="cuda")(feed)["y"]
     err = lambda m: ((GraphRunner(m, device="cuda")(feed)["y"] - y0).norm() / y0.norm()).item()      # noqa: E731
     assert err(awq) < err(rtn), (err(awq), err(rtn))
+
+
+def test_recorded_calibration_passes_reproduce_the_eager_ones():
+    """`GraphRunner(capture=True)`: the second pass over an input signature is recorded into a HIP graph, later ones replay it.
+    Every replayed value must be bit-identical to the eager pass (the runner checks one replay itself before it keeps a graph);
+    a new signature starts over; a graph that cannot be recorded stays eager."""
+    src = fixture("block")
+    taps = ["/ln1/LayerNormalization_output_0", "/up/MatMul_output_0", "/Softmax_output_0", "y"]
+    eager = GraphRunner(src, outputs=taps, device="cuda")
+    rec = GraphRunner(src, outputs=taps, device="cuda", capture=True)
+    gen = torch.Generator().manual_seed(0)
+    for i in range(5):
+        x = torch.randn(4, 6, 64, generator=gen)
+        a, b = eager(x), rec(x)
+        for k in taps:
+            assert torch.equal(a[k], b[k]), (i, k)
+    key = next(iter(rec._graphs))
+    assert rec._graphs[key] is not None, "the block's pass (shape arithmetic on the host, constants cached on the device) is recordable"
+    held = rec(torch.randn(4, 6, 64, generator=gen))                # results are copies: a later replay must not change them
+    snapshot = {k: v.clone() for k, v in held.items()}
+    rec(torch.randn(4, 6, 64, generator=gen))
+    assert all(torch.equal(held[k], snapshot[k]) for k in taps)
+    x2 = torch.randn(2, 6, 64, generator=gen)                       # another batch size: its own signature
+    for _ in range(3):
+        a, b = eager(x2), rec(x2)
+        assert all(torch.equal(a[k], b[k]) for k in taps)
+    assert len(rec._graphs) == 2
+    # the genai-style graph (GroupQueryAttention, empty key / value caches, int64 inputs)
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gemma3_onnx_file", os.path.join(ROOT, "examples", "gemma3_shapes", "gemma3_onnx_file.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    model = ex.build_model(layers=2, vocab=256)
+    wanted = ["/model/layers.1/mlp/Mul/out", "logits"]
+    e2, r2 = GraphRunner(model, outputs=wanted, device="cuda"), GraphRunner(model, outputs=wanted, device="cuda", capture=True)
+    data = ex.make_calibration_data(2, 256, 6, 16)
+    for i in range(6):
+        feed = {k: torch.from_numpy(v[i:i + 1]) for k, v in data.items()}
+        a, b = e2(feed), r2(feed)
+        assert all(torch.equal(a[k], b[k]) for k in wanted), i
+    assert next(iter(r2._graphs.values())) is not None
