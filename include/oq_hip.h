@@ -415,7 +415,7 @@ int32_t oq_hqq_optimize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
  *     (rtn.py:54-109 with the given type / strategy / group size).  The loss is evaluated as || X (W - W^_i) ||^2 / (T N) by
  *     ONE product per candidate on the matrix cores (fp16 pieces of fp32 operands, fp32 accumulate) whose epilogue squares
  *     and sums: no [T, N] product is written.  Outputs (device): scales_out [n_grid, K], losses_out [n_grid], best_out =
- *     the first minimum (awq.py:178).  4- / 8-bit types; group strategy needs group_size >= 16 dividing K.
+ *     the first minimum (awq.py:178).  4- / 8-bit types; group strategy needs group_size >= 4 dividing K (16, 32, 64, 128 run the fused kernel).
  *     Workspace (256-byte aligned): oq_awq_workspace_bytes(T, K, N). */
 size_t oq_awq_workspace_bytes(int64_t T, int64_t K, int64_t N);
 int32_t oq_awq_scale_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw,

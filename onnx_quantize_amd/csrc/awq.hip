@@ -518,6 +518,10 @@ constexpr bool kAwqHiPiecesOnly = OQ_AWQ_HI_ONLY != 0;
 constexpr bool kAwqFusedPieces = OQ_AWQ_FUSED_PIECES != 0;
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
+// Smallest group the searches take (the reference's own AWQ tests use 8, test/pre_passes/test_awq.py:68); the parameter
+// buffers of the workspace are sized for it.
+constexpr int kAwqMinGroup = 4;
+
 static int64_t diff_blocks(int64_t K, int64_t N) { return ceil_div(N, 256) * ceil_div(K, 8); }
 
 static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* base) {
@@ -533,18 +537,20 @@ static size_t awq_workspace(int64_t T, int64_t K, int64_t N, AwqWs* w, char* bas
     char* Ws = take(static_cast<size_t>(K) * N * 4);
     char* D = take(static_cast<size_t>(K) * N * 4);
     char* q = take(static_cast<size_t>(K) * N);
-    char* qs = take(static_cast<size_t>(K) * N / 1 * 0 + static_cast<size_t>(K) * N * 4 / 16 + static_cast<size_t>(N) * 4 + 1024);   // groups of >= 16 rows
-    char* qz = take(static_cast<size_t>(K) * N / 16 + static_cast<size_t>(N) + 1024);
+    // parameters of the general route: one per group of >= kAwqMinGroup rows (the fused route needs 16 and more)
+    char* qs = take(static_cast<size_t>(K) * N * 4 / kAwqMinGroup + static_cast<size_t>(N) * 4 + 1024);
+    char* qz = take(static_cast<size_t>(K) * N / kAwqMinGroup + static_cast<size_t>(N) + 1024);
     char* act = take(static_cast<size_t>(K) * 4);
     char* wsc = take(static_cast<size_t>(K) * 4);
-    char* gmax = take(static_cast<size_t>(K) * N * 4 / 16 + static_cast<size_t>(N) * 4 + 1024);
+    char* gmax = take(static_cast<size_t>(K) * N * 4 / kAwqMinGroup + static_cast<size_t>(N) * 4 + 1024);
     char* colpart = take(static_cast<size_t>(kColChunks) * K * 4);
     char* gpart = take(static_cast<size_t>(kAwqMaxGrid) * loss_stride(T, K, N) * 4 + 1024);   // every candidate its own partial sums
     char* dpart = take(static_cast<size_t>(diff_blocks(K, N)) * 4 + 1024);
     char* rmax = take(static_cast<size_t>(K) * 4 + 256);
     char* bnd = take(static_cast<size_t>(kAwqMaxGrid) * (K / 16 + 1) * 4 + 256);
     char* trp = take(static_cast<size_t>(kAwqMaxGrid) * 16 + 256);
-    const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) + oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
+    const size_t rtn_bytes = oq_rtn_workspace_bytes(K, N, OQ_GROUP, kAwqMinGroup, 0) + oq_rtn_workspace_bytes(K, N, OQ_GROUP, 16, 0) +
+                             oq_rtn_workspace_bytes(K, N, OQ_TENSOR, -1, 0) + 1024;
     char* rtn = take(rtn_bytes);
     if (w) {
         w->pieces_x = px; w->pieces_d = pd; w->Ws = reinterpret_cast<float*>(Ws); w->D = reinterpret_cast<float*>(D);
@@ -675,8 +681,8 @@ static int32_t check_common(const float* X, int64_t T, int64_t K, int64_t ldx, c
     if (strategy == OQ_GROUP) {
         int64_t gs = group_size > K ? K : group_size;
         if (gs == -1) gs = K;
-        OQ_REQUIRE(gs >= 16 && K % gs == 0, OQ_ERR_UNSUPPORTED, "awq: group_size must divide K and be >= 16 (got %lld for K = %lld)", (long long)group_size,
-                   (long long)K);
+        OQ_REQUIRE(gs >= kAwqMinGroup && K % gs == 0, OQ_ERR_UNSUPPORTED, "awq: group_size must divide K and be >= %d (got %lld for K = %lld)", kAwqMinGroup,
+                   (long long)group_size, (long long)K);
         *g = gs;
     }
     OQ_REQUIRE(ceil_div(K, 8) <= 65535 && K <= 65535 && ceil_div(K, *g) <= 65535, OQ_ERR_UNSUPPORTED, "awq: K too large");

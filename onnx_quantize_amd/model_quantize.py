@@ -43,7 +43,7 @@ from .onnx_functions import FUNCTION_OPSET, MS_DOMAIN, QUANT_DOMAIN, build_funct
 from .onnx_proto import (DataType, Message, attribute_value, load_model, make_attribute, make_node, numpy_to_tensor, parse_model,
                          save_model, tensor_to_numpy)
 
-__all__ = ["quantize_model", "quantize_file", "as_model"]
+__all__ = ["quantize_model", "quantize_file", "apply_pre_passes", "as_model"]
 
 logger = logging.getLogger("onnx_quantize")
 
@@ -583,19 +583,20 @@ class _Out:
         return self
 
 
-def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None, calibrate=None,
-                   searches=None) -> Message:
-    """quantize.py:28-80 on a parsed ModelProto / ONNX bytes / a path.  Returns a new parsed ModelProto (`onnx_proto.serialize`
-    gives the file).  `weight_arrays` / `quantize_bias` / `calibrate` / `searches`: the numeric providers (default: the
-    device-resident seam, the HIP bias kernel, the on-device calibration walk `_calibrate` and `DeviceSearches`; tests inject
-    the oracle).  `calibrate(model, graph view, target nodes, qconfig, device, keep_inputs=False)` returns {id(node): meta}
-    like `_calibrate`."""
-    if not isinstance(qconfig, QConfig):
-        raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
+class Prepared:
+    """A model after the pre-passes: the graph view, the nodes to quantize, their calibration results and the per-node
+    configurations a preprocessor changed (AWQ's clip ratio)."""
+
+    def __init__(self, model, graph, targets, meta, per_node):
+        self.model, self.graph, self.targets, self.meta, self.per_node = model, graph, targets, meta, per_node
+
+
+def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, searches=None, post_calibration="if_read") -> Prepared:
+    """quantize.py:50-59 + pre_passes/__init__.py:47-98: opset, names, duplicated initializers, MatMul + Add -> Gemm, Gemm with
+    `transB = 0`, calibration, the preprocessors' passes and the calibration after them.  `post_calibration`: "if_read" skips
+    the second calibration walk when nothing downstream reads its results (weight-only RTN behind AWQ / SmoothQuant: no static
+    activation, no Hessian); "always" runs it whenever a preprocessor asks for it, as the reference does."""
     model = as_model(model)
-    if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
-        logger.info("No quantization parameters specified in qconfig. Returning original model.")
-        return model
     if model.graph is None:
         raise ValueError("the model has no graph")
     G = _Graph(model.graph)
@@ -614,13 +615,28 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     if qconfig.preprocessors and targets:                   # pre_passes/__init__.py:72-88
         per_node = _preprocess(G, targets, qconfig, meta, searches or DeviceSearches())
         _name_nodes(G)
-        consumed = any(a is not None and a.is_static for a in (qconfig.input_activations, qconfig.output_activations)) or \
+        read = any(a is not None and a.is_static for a in (qconfig.input_activations, qconfig.output_activations)) or \
             bool(qconfig.weights.algorithm.requires_calibration)
-        if any(p.requires_post_calibration for p in qconfig.preprocessors) and consumed:
-            # pre_passes/__init__.py:85-88 calibrates again unconditionally; with weight-only RTN behind the preprocessor
-            # nothing reads what that walk collects (no static activation, no Hessian), so it is not run
+        if any(p.requires_post_calibration for p in qconfig.preprocessors) and (read or post_calibration == "always"):
             logger.info("Re-calibrating the model after pre-processing...")
-            meta = calibrate(model, G, targets, qconfig, device, keep_inputs=False)
+            meta = calibrate(model, G, targets, qconfig, device, keep_inputs=post_calibration == "always" and not read)
+    return Prepared(model, G, targets, meta, per_node)
+
+
+def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None, calibrate=None,
+                   searches=None) -> Message:
+    """quantize.py:28-80 on a parsed ModelProto / ONNX bytes / a path.  Returns a new parsed ModelProto (`onnx_proto.serialize`
+    gives the file).  `weight_arrays` / `quantize_bias` / `calibrate` / `searches`: the numeric providers (default: the
+    device-resident seam, the HIP bias kernel, the on-device calibration walk `_calibrate` and `DeviceSearches`; tests inject
+    the oracle).  `calibrate(model, graph view, target nodes, qconfig, device, keep_inputs=False)` returns {id(node): meta}
+    like `_calibrate`."""
+    if not isinstance(qconfig, QConfig):
+        raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
+    if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
+        logger.info("No quantization parameters specified in qconfig. Returning original model.")
+        return as_model(model)
+    prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
+    model, G, targets, meta, per_node = prepared.model, prepared.graph, prepared.targets, prepared.meta, prepared.per_node
 
     used_functions: dict = {}
     domains = set()

@@ -27,7 +27,8 @@ def oracle_weight_arrays(value, cfg, out, nbits):
         return q.reshape(w.shape), s, z
     x = None if out is None else out.producer().meta.get("input")
     tag = getattr(a.algorithm, "algorithm_type", "rtn")
-    algo = {k: getattr(a.algorithm, k) for k in ("block_size", "percdamp", "actorder") if hasattr(a.algorithm, k)}
+    algo = {k: getattr(a.algorithm, k) for k in ("block_size", "percdamp", "actorder", "lp_norm", "beta", "kappa", "iters", "early_stop")
+            if hasattr(a.algorithm, k)}
     return O.seam_arrays(w, tag, a.dtype.key, a.strategy.value, a.group_size, a.symmetric, a.reduce_range, a.clip_ratio, a.mse,
                          x=x, nbits=nbits, **algo)
 

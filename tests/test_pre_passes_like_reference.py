@@ -1,0 +1,178 @@
+"""The reference's tests of its pre-passes (test/pre_passes/test_awq.py, test_smooth_quant.py, test_duplicate_initializer.py,
+test_standarize_gemm.py) on this package's restatement of them (`model_quantize.apply_pre_passes` and its steps).
+
+Same toy models, same parameter grids, same assertions: number of inserted `Mul` nodes, the pre-processed FLOAT model computes
+what the original computes (atol 5e-5), each node's calibration input after the in-place rescale equals what a fresh
+calibration of the rewritten model collects (atol 1e-5), initializer duplication by consumer count, every Gemm with
+`transB = 0`.  `GraphRunner` stands in for onnxruntime.  CPU: the oracle's searches; GPU: the HIP searches.
+"""
+import numpy as np
+import pytest
+import torch
+
+from onnx_model_helpers import OracleSearches, oracle_calibrate
+from onnx_quantize_amd import AwqConfig, QConfig, QWeightArgs, SmoothQuantConfig
+from onnx_quantize_amd import onnx_proto as P
+from onnx_quantize_amd.graph_runner import GraphRunner
+from onnx_quantize_amd.model_quantize import _duplicate_shared_initializers, _Graph, _standardize_gemm, apply_pre_passes, as_model
+
+
+def _model(nodes, inits, inputs=(("X", ["N", 32]),), outputs=("Y",), opset=21):
+    g = P.Message("GraphProto", name="test_model", node=nodes, initializer=[P.numpy_to_tensor(k, v) for k, v in inits.items()],
+                  input=[P.make_value_info(n, P.DataType.FLOAT, shape) for n, shape in inputs],
+                  output=[P.make_value_info(o, P.DataType.FLOAT, None) for o in outputs])
+    return P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=opset)])
+
+
+def matmul_model(rng):                                                         # test_awq.py:27-43
+    return _model([P.make_node("MatMul", ["X", "W1"], ["Y"])], {"W1": rng.normal(size=(32, 64)).astype(np.float32)})
+
+
+def gemm_model(rng, second_transb=True):                                       # test_awq.py:46-65 / test_smooth_quant.py:40-64
+    second = dict(transB=0) if second_transb else {}
+    return _model([P.make_node("Gemm", ["X", "W1", "B1"], ["x1"], transB=0), P.make_node("Gemm", ["x1", "W2"], ["Y"], **second)],
+                  {"W1": rng.normal(size=(32, 64)).astype(np.float32), "B1": rng.normal(size=(64,)).astype(np.float32),
+                   "W2": rng.normal(size=(64, 128)).astype(np.float32)})
+
+
+def _providers(device):
+    if device == "cpu":
+        return dict(calibrate=oracle_calibrate("cpu"), searches=OracleSearches())
+    return {}
+
+
+def _run_pass_checks(device, model, qconfig, expected_num_mul, rng):
+    """test_awq.py:75-117 / test_smooth_quant.py:67-110."""
+    prepared = apply_pre_passes(model, qconfig, device=device, **_providers(device))
+    out = prepared.model
+    assert sum(n.op_type == "Mul" for n in out.graph.node) == expected_num_mul
+    samples = torch.from_numpy(rng.normal(size=(1, 32)).astype(np.float32))
+    want, got = GraphRunner(model, device=device)(samples)["Y"], GraphRunner(P.parse_model(P.serialize(out)), device=device)(samples)["Y"]
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=5e-5)
+    # the inputs left in the nodes' metadata are those a calibration of the rewritten model collects
+    cal = _providers(device).get("calibrate")
+    if cal is None:
+        from onnx_quantize_amd.model_quantize import _calibrate as cal
+    fresh = cal(out, _Graph(out.graph), prepared.targets, qconfig, device, keep_inputs=True)
+    seen = 0
+    for node in prepared.targets:
+        a, b = prepared.meta[id(node)].get("input"), fresh[id(node)].get("input")
+        if a is not None and b is not None:
+            to_np = lambda t: t if isinstance(t, np.ndarray) else t.cpu().numpy()      # noqa: E731
+            np.testing.assert_allclose(to_np(a), to_np(b), atol=1e-5)
+            seen += 1
+    assert seen == expected_num_mul
+    return prepared
+
+
+AWQ_GRID = [(s, g, c, m, k) for s, g in (("tensor", None), ("channel", -1), ("group", 8)) for c in (False, True)
+            for m, k in ((matmul_model, 1), (gemm_model, 2))]
+SMOOTH_GRID = [(a, m, k) for a in (0.0, 0.5, 1.0) for m, k in ((matmul_model, 1), (lambda r: gemm_model(r, second_transb=False), 2))]
+
+
+def _awq_case(device, strategy, group_size, clip_search, model_fn, expected, seed):
+    rng = np.random.default_rng(seed)
+    data = rng.normal(size=(1, 32)).astype(np.float32)
+    qc = QConfig(preprocessors=[AwqConfig(clip_search=clip_search)], calibration_data=data, weights=QWeightArgs(strategy=strategy, group_size=group_size))
+    prepared = _run_pass_checks(device, model_fn(rng), qc, expected, rng)
+    if clip_search:                                                            # awq.py:255-257: a clip ratio from the grid, per node
+        assert len(prepared.per_node) == expected
+        assert all(round((1 - c.weights.clip_ratio) * 100) in range(10) for c in prepared.per_node.values())
+    else:
+        assert not prepared.per_node
+
+
+def _smooth_case(device, alpha, model_fn, expected, seed):
+    rng = np.random.default_rng(seed)
+    data = rng.normal(size=(1, 32)).astype(np.float32)
+    qc = QConfig(preprocessors=[SmoothQuantConfig(alpha=alpha)], calibration_data=data, weights=QWeightArgs())
+    _run_pass_checks(device, model_fn(rng), qc, expected, rng)
+
+
+@pytest.mark.parametrize("case", range(len(AWQ_GRID)))
+def test_awq_pass(case):
+    _awq_case("cpu", *AWQ_GRID[case], seed=100 + case)
+
+
+@pytest.mark.parametrize("case", range(len(SMOOTH_GRID)))
+def test_smooth_quant_pass(case):
+    _smooth_case("cpu", *SMOOTH_GRID[case], seed=200 + case)
+
+
+@pytest.mark.gpu
+def test_awq_and_smooth_quant_passes_on_the_device():
+    for case, args in enumerate(AWQ_GRID):
+        _awq_case("cuda", *args, seed=100 + case)
+    for case, args in enumerate(SMOOTH_GRID):
+        _smooth_case("cuda", *args, seed=200 + case)
+
+
+# --------------------------------------------------------------------------------------------- test_duplicate_initializer.py
+def _shared_weight_model(rng, consumers):
+    weight = rng.normal(size=(4, 8)).astype(np.float32)
+    nodes = [P.make_node("MatMul", [f"X{i}", "W"], [f"Y{i}"]) for i in range(consumers)]
+    model = _model(nodes, {"W": weight}, inputs=[(f"X{i}", ["N", 4]) for i in range(consumers)], outputs=[f"Y{i}" for i in range(consumers)])
+    return model, weight
+
+
+def _duplicate(model):
+    model = as_model(model)
+    before = len(model.graph.initializer)
+    _duplicate_shared_initializers(_Graph(model.graph))
+    return model, len(model.graph.initializer) != before
+
+
+def test_unshared_initializer_is_not_modified():                               # :29-35
+    model, modified = _duplicate(_shared_weight_model(np.random.default_rng(0), 1)[0])
+    assert modified is False and len(model.graph.initializer) == 1
+
+
+def test_two_consumers_produce_one_duplicate():                                # :38-55
+    src, weight = _shared_weight_model(np.random.default_rng(1), 2)
+    model, modified = _duplicate(src)
+    inits = {t.name: P.tensor_to_numpy(t) for t in model.graph.initializer}
+    assert modified and set(inits) == {"W", "W_1"}
+    assert [n.input[1] for n in model.graph.node if n.op_type == "MatMul"] == ["W", "W_1"]
+    np.testing.assert_array_equal(inits["W"], weight)
+    np.testing.assert_array_equal(inits["W_1"], weight)
+
+
+def test_three_consumers_produce_two_duplicates():                             # :58-68
+    model, modified = _duplicate(_shared_weight_model(np.random.default_rng(2), 3)[0])
+    assert modified and {t.name for t in model.graph.initializer} == {"W", "W_1", "W_2"}
+    assert [n.input[1] for n in model.graph.node] == ["W", "W_1", "W_2"]
+
+
+def test_skips_initializer_that_is_a_graph_output():                           # :71-88
+    rng = np.random.default_rng(3)
+    model = _model([P.make_node("MatMul", ["X", "W"], ["Y"]), P.make_node("MatMul", ["X", "W"], ["Y2"])], {"W": rng.normal(size=(4, 8)).astype(np.float32)},
+                   inputs=[("X", ["N", 4])], outputs=["Y", "Y2", "W"])
+    model, modified = _duplicate(model)
+    assert modified is False and {t.name for t in model.graph.initializer} == {"W"}
+
+
+def test_forward_output_is_unchanged():                                        # :91-108
+    rng = np.random.default_rng(4)
+    src, _ = _shared_weight_model(rng, 2)
+    model, modified = _duplicate(src)
+    assert modified
+    feed = {"X0": torch.from_numpy(rng.normal(size=(2, 4)).astype(np.float32)), "X1": torch.from_numpy(rng.normal(size=(2, 4)).astype(np.float32))}
+    a, b = GraphRunner(src, device="cpu")(feed), GraphRunner(P.parse_model(P.serialize(model)), device="cpu")(feed)
+    for k in a:
+        assert torch.equal(a[k], b[k])
+
+
+# --------------------------------------------------------------------------------------------- test_standarize_gemm.py
+def test_standarize_gemm():                                                    # :9-39
+    rng = np.random.default_rng(5)
+    inits = {"W1": rng.standard_normal((64, 32)).astype(np.float32), "B1": rng.standard_normal(64).astype(np.float32),
+             "W2": rng.standard_normal((64, 128)).astype(np.float32), "W3": rng.standard_normal((128, 256)).astype(np.float32)}
+    src = _model([P.make_node("Gemm", ["X", "W1", "B1"], ["x1"], transB=1), P.make_node("Gemm", ["x1", "W2"], ["x2"]),
+                  P.make_node("Gemm", ["x2", "W3"], ["Y"], transB=0)], inits, opset=20)
+    model = as_model(src)
+    _standardize_gemm(_Graph(model.graph))
+    for node in model.graph.node:
+        assert {a.name: P.attribute_value(a) for a in node.attribute}["transB"] == 0
+    assert P.tensor_to_numpy(model.graph.initializer[0]).shape == (32, 64)      # transposed with the attribute
+    x = torch.from_numpy(rng.standard_normal((3, 32)).astype(np.float32))
+    torch.testing.assert_close(GraphRunner(model, device="cpu")(x)["Y"], GraphRunner(src, device="cpu")(x)["Y"])

@@ -70,7 +70,10 @@ def _inputs(seed, t, k, n):
 @pytest.mark.gpu
 @pytest.mark.parametrize("qtype,strategy,g,sym", [("uint4", "group", 32, False), ("int8", "channel", -1, True), ("uint8", "tensor", -1, False),
                                                   ("int4", "group", 128, False), ("int8", "group", 64, True), ("uint4", "group", 16, True),
-                                                  ("int4", "group", 256, True)])
+                                                  ("int4", "group", 256, True),
+                                                  # groups below the fused kernel's 16 rows (the reference's own AWQ tests use 8,
+                                                  # test/pre_passes/test_awq.py:68): general route, vector and scalar residual kernels
+                                                  ("int8", "group", 8, False), ("uint4", "group", 4, False), ("int4", "group", 8, True)])
 def test_gpu_awq_searches_follow_the_oracle(qtype, strategy, g, sym):
     from onnx_quantize_amd.preprocessing import awq_clip_search, awq_scale_search
     x, w = _inputs(3, 512, 256, 192)

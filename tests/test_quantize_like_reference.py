@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from onnx_model_helpers import q_oracle
-from onnx_quantize_amd import GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
+from onnx_quantize_amd import AwqConfig, GPTQConfig, HqqConfig, QActivationArgs, QConfig, QuantType, QWeightArgs, SmoothQuantConfig
 from onnx_quantize_amd import onnx_proto as P
 from onnx_quantize_amd.graph_runner import GraphRunner
 from onnx_quantize_amd.model_quantize import quantize_model
@@ -130,12 +130,92 @@ def _run_grid(provider, device):
         qc = _acts("both", True, dtype, sym, data, fmt="qlinear", strategy=strategy)
         _check(model, provider(model, qc, None), qc, data, device)
         count += 1
+    # test_quantize.py:346-377: uint4 / uint8 groups of 16 -> every node a MatMulNBits, RTN and GPTQ (GPTQ on RANDOM calibration
+    # data: none is given, calibrate.py:127-147)
+    for name, dtype, algo in itertools.product(THREE, ["uint4", "uint8"], [None, "gptq"]):
+        model = MODELS[name](rng)
+        kw = {"algorithm": GPTQConfig()} if algo else {}
+        qc = QConfig(weights=QWeightArgs(dtype=DTYPES[dtype], strategy="group", group_size=16, **kw))
+        out = provider(model, qc, algo)
+        assert all(n.op_type == "MatMulNBits" for n in out.graph.node)
+        _check(model, out, _Eight(qc), _truncated_normal(rng, (2, 32)), device)          # the reference compares outputs for uint4 too here
+        count += 1
+    # :380-459: HQQ (uint4 groups; custom parameters; MatMulNBits with float zero points)
+    hqq_cases = [(name, g, {}) for g in (16, 32, 64) for name in THREE] + \
+        [("matmul", 32, p) for p in ({"lp_norm": 0.7, "beta": 10.0, "iters": 20}, {"lp_norm": 0.5, "beta": 5.0, "iters": 10, "early_stop": False},
+                                     {"lp_norm": 1.0, "beta": 15.0, "kappa": 1.05, "iters": 15})]
+    for name, g, params in hqq_cases:
+        model = MODELS[name](rng)
+        qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, strategy="group", group_size=g, symmetric=False, algorithm=HqqConfig(**params)))
+        out = provider(model, qc, "hqq")
+        assert all(n.op_type == "MatMulNBits" for n in out.graph.node)
+        _check(model, out, _Eight(qc), _truncated_normal(rng, (2, 32)), device)
+        count += 1
+    # :462-481 SmoothQuant in front of static input quantization: the result runs
+    model = matmul_model(rng)
+    qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt8, strategy="tensor", symmetric=True),
+                 input_activations=QActivationArgs(dtype=QuantType.QUInt8, is_static=True), preprocessors=[SmoothQuantConfig(alpha=0.5)])
+    out = P.parse_model(P.serialize(provider(model, qc, "search")))
+    assert [n.op_type for n in out.graph.node] == ["Mul", "QMatMulWeightStaticInputQDQ", "Mul", "QMatMulWeightStaticInputQDQ"]
+    GraphRunner(out, device=device)(torch.from_numpy(_truncated_normal(rng, (2, 32))))
+    count += 1
+    # :484-531 `ignore`: a matching node stays in the default domain under its own name; all ignored -> nothing changes
+    for fmt in ("qdq", "qlinear"):
+        model = matmul_model(rng)
+        model.graph.node[0].name, model.graph.node[1].name = "lm_head.MatMul", "layers.0.fc.MatMul"
+        qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt8, strategy="tensor", symmetric=True), input_activations=QActivationArgs(is_static=True),
+                     output_activations=QActivationArgs(is_static=True), ignore=["lm_head"], format=fmt)
+        out = provider(model, qc, None)
+        domains = {n.name: (n.domain or "") for n in out.graph.node}
+        assert domains["lm_head.MatMul"] == "" and domains["layers.0.fc.MatMul"] == "quant"
+        count += 1
+    model = matmul_model(rng)
+    for i, n in enumerate(model.graph.node):
+        n.name = f"layer{i}"
+    out = provider(model, QConfig(weights=QWeightArgs(dtype=QuantType.QUInt8, strategy="tensor", symmetric=True), ignore=[r"^layer\d+$"]), None)
+    assert all(not n.domain for n in out.graph.node)
+    count += 1
+    # :534-571 `target_op_types`
+    for targets in (("Gemm",), ("MatMul",)):
+        model = _model([P.make_node("MatMul", ["X", "W1"], ["x1"]), P.make_node("Gemm", ["x1", "W2"], ["Y"])],
+                       {"W1": _truncated_normal(rng, (32, 64)), "W2": _truncated_normal(rng, (64, 128))})
+        qc = QConfig(weights=QWeightArgs(dtype=QuantType.QUInt8, strategy="tensor", symmetric=True), target_op_types=targets)
+        out = provider(model, qc, None)
+        assert len(out.graph.node) == 2
+        for before, after in zip(model.graph.node, out.graph.node):
+            assert (after.domain == "quant") == (before.op_type in targets)
+        GraphRunner(P.parse_model(P.serialize(out)), device=device)(torch.from_numpy(_truncated_normal(rng, (2, 32))))
+        count += 1
+    # :574-600 AWQ in front of int8 RTN, with and without the clip search
+    for name, (strategy, g), clip in itertools.product(["matmul", "gemm"], [("tensor", None), ("channel", None), ("group", 16)], [False, True]):
+        model = MODELS[name](rng)
+        data = _truncated_normal(rng, (2, 32))
+        qc = QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, strategy=strategy, group_size=g), preprocessors=[AwqConfig(clip_search=clip)],
+                     calibration_data=data)
+        out = P.parse_model(P.serialize(provider(model, qc, "search")))
+        x = torch.from_numpy(_truncated_normal(rng, (2, 32)))
+        want, got = GraphRunner(model, device=device)(x)["Y"], GraphRunner(out, device=device)(x)["Y"]
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=1e-1)
+        count += 1
     return count
+
+
+class _Eight:
+    """`_check` compares outputs when the weights have more than 4 bits; these reference tests compare them regardless."""
+
+    def __init__(self, qc):
+        self.weights = self
+
+    class dtype:                                                             # noqa: N801
+        bitwidth = 8
+
+
+TOTAL = 192 + 48 + 51 + 32 + 12 + 12 + 1 + 2 + 1 + 2 + 12
 
 
 def test_the_reference_grids_with_the_oracle_as_provider():
     n = _run_grid(lambda model, qc, tag: q_oracle(model, qc), "cpu")
-    assert n == len(WEIGHT_GRID) + len(GPTQ_GRID) + len(ACT_GRID) + len(QLINEAR_GRID) == 192 + 48 + 51 + 32
+    assert n == TOTAL == 365
 
 
 @pytest.mark.gpu
@@ -144,11 +224,13 @@ def test_the_reference_grids_on_the_device_path():
 
     def provider(model, qc, tag):
         got = quantize_model(model, qc)
-        if tag != "gptq":                                                     # same activations -> the same file, byte for byte
+        if tag is None:                                                       # same activations -> the same file, byte for byte
             twin = qc.model_copy()
             assert P.serialize(got) == P.serialize(q_oracle(model, twin, runner_device="cuda")), qc
             exact["n"] += 1
         return got
 
     n = _run_grid(provider, "cuda")
-    assert n == 323 and exact["n"] == 323 - len(GPTQ_GRID)
+    # not compared as bytes: GPTQ (48 + 6: the Hessian is accumulated in fp16 pieces), HQQ (12: an iterative fp32 solve), the
+    # AWQ / SmoothQuant searches (12 + 1)
+    assert n == TOTAL and exact["n"] == TOTAL - 48 - 6 - 12 - 13
