@@ -267,6 +267,33 @@ def _call(fn, inputs, attrs=None):
     return GraphRunner(model, device="cpu")(dict(zip(names, inputs)))["out"].numpy()
 
 
+def _check_function(fn):
+    """What `onnx.checker.check_function` checks of a FunctionProto's structure (qfunctions tests call it on every function):
+    a name and a domain, unique inputs / outputs, nodes in SSA form that only read inputs or earlier outputs (a function
+    body is closed), every output produced, every operator domain imported."""
+    assert fn.name and fn.domain == "quant"
+    assert len(set(fn.input)) == len(fn.input) and len(set(fn.output)) == len(fn.output)
+    known, written = set(fn.input), set()
+    imported = {o.domain or "" for o in fn.opset_import}
+    for n in fn.node:
+        assert n.op_type and (n.domain or "") in imported, (fn.name, n.op_type, n.domain)
+        for v in n.input:
+            assert v == "" or v in known, (fn.name, n.op_type, v)
+        for o in n.output:
+            assert o and o not in written and o not in fn.input, (fn.name, o)
+            written.add(o)
+            known.add(o)
+    assert all(o in written for o in fn.output), fn.name
+    assert {o.domain or "": o.version for o in fn.opset_import}[""] == 21            # opset.py:4
+
+
+def test_function_protos_are_well_formed():
+    for name in function_names():
+        grouped = "Grouped" in name
+        for four_bit in ((False, True) if grouped else (False,)):
+            _check_function(build_function(name, group_size=8 if grouped else None, four_bit=four_bit))
+
+
 def test_every_quant_function_computes_its_reference_script():
     rng = np.random.default_rng(3)
     k, n = 32, 12
