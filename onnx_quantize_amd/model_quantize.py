@@ -40,7 +40,7 @@ from .config import QConfig
 from .emission import plan_node
 from .wire_format import _resolve_group_size
 from .onnx_functions import FUNCTION_OPSET, MS_DOMAIN, QUANT_DOMAIN, build_function
-from .onnx_proto import (DataType, Message, attribute_value, load_model, make_attribute, make_node, numpy_to_tensor, parse_model,
+from .onnx_proto import (DataType, Message, attribute_value, check_model, load_model, make_attribute, make_node, numpy_to_tensor, parse_model,
                          save_model, tensor_to_numpy)
 
 __all__ = ["quantize_model", "quantize_file", "apply_pre_passes", "as_model"]
@@ -683,6 +683,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
 
     _remove_unused_initializers(G)
     _deduplicate_initializers(G)
+    check_model(model)                                      # what leaves is structurally sound, or the caller hears why not
     return model
 
 

@@ -23,7 +23,7 @@ import numpy as np
 
 __all__ = ["Message", "parse", "parse_model", "serialize", "load_model", "save_model", "resolve_external_data", "tensor_to_numpy",
            "numpy_to_tensor", "make_attribute", "attribute_value", "make_node", "make_value_info", "DataType", "AttributeType",
-           "SCHEMA"]
+           "SCHEMA", "check_model"]
 
 
 class DataType:
@@ -517,6 +517,90 @@ def numpy_to_tensor(name: str, array, data_type: int | None = None) -> Message:
         raise ValueError(f"onnx_proto: tensor '{name}': array dtype {a.dtype} does not match element type {data_type}")
     t.raw_data = np.ascontiguousarray(a).astype(want.newbyteorder("<"), copy=False).tobytes()
     return t
+
+
+# --------------------------------------------------------------------------------------------------------------- checking
+_ITEM_BITS = {DataType.FLOAT: 32, DataType.UINT8: 8, DataType.INT8: 8, DataType.UINT16: 16, DataType.INT16: 16, DataType.INT32: 32,
+              DataType.INT64: 64, DataType.BOOL: 8, DataType.FLOAT16: 16, DataType.DOUBLE: 64, DataType.UINT32: 32, DataType.UINT64: 64,
+              DataType.BFLOAT16: 16, DataType.UINT4: 4, DataType.INT4: 4}
+
+
+def _check_tensor(t: Message, where: str) -> None:
+    if not t.name:
+        raise ValueError(f"check_model: {where}: a tensor without a name")
+    if any(int(d) < 0 for d in t.dims):
+        raise ValueError(f"check_model: tensor '{t.name}' has a negative dimension")
+    bits = _ITEM_BITS.get(t.data_type)
+    if bits is not None and t.has("raw_data") and not t.data_location:
+        count = 1
+        for d in t.dims:
+            count *= int(d)
+        want = (count * bits + 7) // 8
+        if len(t.raw_data) != want:
+            raise ValueError(f"check_model: tensor '{t.name}': {len(t.raw_data)} bytes of raw data for shape {list(t.dims)} "
+                             f"of element type {t.data_type} ({want} expected)")
+
+
+def _check_graph(graph: Message, outer: set, imported: set, functions: set, where: str) -> None:
+    known = set(outer)
+    names = set()
+    for t in graph.initializer:
+        _check_tensor(t, where)
+        if t.name in names:
+            raise ValueError(f"check_model: {where}: two initializers named '{t.name}'")
+        names.add(t.name)
+    known |= names | {i.name for i in graph.input}
+    produced = set()
+    for n in graph.node:
+        label = f"{where}: node '{n.name or n.op_type}'"
+        if not n.op_type:
+            raise ValueError(f"check_model: {label} has no operator type")
+        domain = "" if n.domain in (None, "ai.onnx") else n.domain
+        if domain not in imported:
+            raise ValueError(f"check_model: {label} uses domain '{domain}', which the model does not import")
+        if domain == "quant" and (domain, n.op_type, n.overload or "") not in functions:
+            raise ValueError(f"check_model: {label} calls {domain}::{n.op_type}, which the model does not define")
+        for v in n.input:
+            if v and v not in known:
+                raise ValueError(f"check_model: {label} reads '{v}' before anything produces it")
+        for a in n.attribute:
+            for g in ([a.g] if a.has("g") else []) + list(a.graphs):
+                _check_graph(g, known, imported, functions, f"{label} / sub-graph")
+            for t in ([a.t] if a.has("t") else []):
+                if t.name:
+                    _check_tensor(t, label)
+        for o in n.output:
+            if o:
+                if o in produced or o in names:
+                    raise ValueError(f"check_model: {label} writes '{o}', which already has a producer")
+                produced.add(o)
+                known.add(o)
+    for o in graph.output:
+        if o.name not in known:
+            raise ValueError(f"check_model: {where}: graph output '{o.name}' is never produced")
+
+
+def check_model(model: Message) -> None:
+    """The structural part of `onnx.checker.check_model` (the package is not here): an IR version and a default opset, unique
+    initializers whose byte counts fit their shapes, nodes in topological order in SSA form, every operator domain imported,
+    every `quant`-domain call defined by a function of the model, closed and well-formed function bodies, graph outputs
+    produced.  Raises ValueError naming the first offender."""
+    if model._type != "ModelProto" or model.graph is None:
+        raise ValueError("check_model: not a model with a graph")
+    if not model.ir_version:
+        raise ValueError("check_model: no ir_version")
+    imported = {("" if o.domain in (None, "ai.onnx") else o.domain) for o in model.opset_import}
+    if "" not in imported:
+        raise ValueError("check_model: the default operator set is not imported")
+    functions = {(f.domain or "", f.name, f.overload or "") for f in model.functions}
+    if len(functions) != len(model.functions):
+        raise ValueError("check_model: two functions with the same domain, name and overload")
+    for f in model.functions:
+        f_imports = {("" if o.domain in (None, "ai.onnx") else o.domain) for o in f.opset_import}
+        body = Message("GraphProto", node=list(f.node), input=[Message("ValueInfoProto", name=i) for i in f.input],
+                       output=[Message("ValueInfoProto", name=o) for o in f.output])
+        _check_graph(body, set(), f_imports, functions, f"function {f.domain}::{f.name}")
+    _check_graph(model.graph, set(), imported, functions, "graph")
 
 
 # --------------------------------------------------------------------------------------------------------------- helpers

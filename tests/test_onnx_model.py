@@ -129,6 +129,40 @@ def test_malformed_files_are_value_errors():
         P.parse("GraphProto", inner)
 
 
+def test_structural_model_checker():
+    """`onnx_proto.check_model`: the structural half of `onnx.checker.check_model`, run on every model the writer emits."""
+    for path in sorted(glob.glob(os.path.join(FIXTURES, "*.onnx"))):
+        P.check_model(P.load_model(path))
+    good = fixture("mlp_matmul")
+
+    def broken(mutate, match):
+        m = good.copy()
+        mutate(m)
+        with pytest.raises(ValueError, match=match):
+            P.check_model(m)
+
+    broken(lambda m: setattr(m, "ir_version", None), "ir_version")
+    broken(lambda m: setattr(m, "opset_import", []), "default operator set")
+    broken(lambda m: m.graph.node.reverse(), "before anything produces it")
+    broken(lambda m: setattr(m.graph.node[1], "output", list(m.graph.node[0].output)), "already has a producer")
+    broken(lambda m: m.graph.initializer.append(m.graph.initializer[0].copy()), "two initializers")
+    broken(lambda m: setattr(m.graph.initializer[0], "dims", [3, 5]), "bytes of raw data")
+    broken(lambda m: setattr(m.graph.node[0], "domain", "com.microsoft"), "does not import")
+    broken(lambda m: setattr(m.graph.output[0], "name", "nowhere"), "never produced")
+
+    def undefined_call(m):
+        m.opset_import.append(P.Message("OperatorSetIdProto", domain="quant", version=1))
+        m.graph.node[0].domain, m.graph.node[0].op_type = "quant", "QMatMulWeightsOnlyQDQ"
+    broken(undefined_call, "does not define")
+
+    def open_function(m):
+        undefined_call(m)
+        fn = build_function("QMatMulWeightsOnlyQDQ")
+        fn.node[0].input = ["W", "w_scale", "not_an_input"]
+        m.functions.append(fn)
+    broken(open_function, "function quant::QMatMulWeightsOnlyQDQ.*before anything produces it")
+
+
 def test_tensors_round_trip_including_four_bit_packing():
     rng = np.random.default_rng(0)
     for dt in (np.float32, np.float16, np.float64, np.int8, np.uint8, np.int32, np.int64, np.bool_):
