@@ -78,6 +78,25 @@ class GraphRunner:
             for name in self._reads(n):
                 self.last_use[name] = i
 
+    @classmethod
+    def evaluator(cls, opset: int):
+        """A runner without a model: `evaluate(node, arrays)` applies ONE operator on the host (what a constant folder needs)."""
+        import torch
+        self = cls.__new__(cls)
+        self.model = self.graph = None
+        self.device = torch.device("cpu")
+        self.functions, self.opset, self.wanted, self.input_names, self.constants, self.nodes, self.last_use = {}, opset, [], [], {}, [], {}
+        self.capture, self._graphs, self._seen, self._moved, self._const_nodes = False, {}, set(), {}, {}
+        return self
+
+    def evaluate(self, node, arrays) -> list:
+        """The outputs (NumPy) of `node` on the given input arrays (None for an absent optional input)."""
+        import torch
+        ins = [None if a is None else torch.from_numpy(np.array(a, order="C")) for a in arrays]
+        with torch.no_grad():
+            outs = self._dispatch(node, ins, {})
+        return [None if o is None else (o.numpy() if isinstance(o, torch.Tensor) else np.asarray(o)) for o in outs]
+
     # ------------------------------------------------------------------------------------------------- preparation
     def _constant(self, a: np.ndarray, code: int | None = None):
         import torch

@@ -7,8 +7,10 @@ small enough to restate, and it lets a GPU box quantize a file end to end with n
   reference step                                         here
   ------------------------------------------------------ --------------------------------------------------------------
   ir.from_proto (a copy)                                  `Message.copy()` of the parsed model
-  onnxscript.optimizer.optimize                           NOT restated, except that `Constant` nodes feeding weight / bias
-                                                          slots become initializers (`_lift_constant_weights`); no folding
+  onnxscript.optimizer.optimize                           the part that decides which weights are constant: Identity
+                                                          elimination, `Constant` nodes in weight / bias slots lifted, constant
+                                                          folding with the folder's size limits (Transpose always); its other
+                                                          rewrites are not restated
   version_converter.convert_version(target 21)            `_raise_opset`: the adapters a MatMul / Gemm export needs
                                                           (Reduce* axes, Split num_outputs), anything else refused by name
   NameFixPass                                             `_name_nodes`: unnamed nodes get names (the ignore patterns and
@@ -173,6 +175,59 @@ def _name_nodes(G: _Graph) -> None:
                 name += "_"
             n.name = name
             taken.add(name)
+
+
+# what `onnxscript.optimizer.optimize` (quantize.py:52) does to constants, as far as it decides WHICH nodes have a constant weight
+# or bias: Identity nodes are removed, and a node whose inputs are all constants is replaced by its value -- always for
+# Transpose, otherwise only when every input has at most 8192 elements and the result at most 512 * 512 (the folder's defaults)
+_FOLD_INPUT_LIMIT, _FOLD_OUTPUT_LIMIT = 8192, 512 * 512
+_FOLD_ALWAYS = {"Transpose"}
+_FOLDABLE = {"Transpose", "Reshape", "Cast", "Unsqueeze", "Squeeze", "Concat", "Slice", "Gather", "Add", "Sub", "Mul", "Div", "Neg", "Sqrt",
+             "Pow", "Flatten", "Expand", "Where", "Equal", "Not", "Shape", "Tile", "Abs", "Exp", "Log", "Reciprocal", "ReduceSum", "ReduceMean",
+             "ReduceMax", "ReduceMin"}
+
+
+def _eliminate_identities(G: _Graph) -> None:
+    """`y = Identity(x)`: the readers of y read x (exporters write these for tensors they found to be equal, e.g. the zero
+    bias of one layer as the Identity of another's).  An Identity that produces a graph output stays."""
+    rename, drop = {}, set()
+    for n in G.g.node:
+        if n.op_type == "Identity" and not n.domain and len(n.input) == 1 and n.output and n.output[0] not in G.graph_outputs:
+            rename[n.output[0]] = rename.get(n.input[0], n.input[0])
+            drop.add(id(n))
+    if not drop:
+        return
+    G.g.node = [n for n in G.g.node if id(n) not in drop]
+    for n in _all_nodes(G.g):
+        if any(v in rename for v in n.input):
+            n.input = [rename.get(v, v) for v in n.input]
+
+
+def _fold_constants(model: Message, G: _Graph) -> None:
+    from .graph_runner import GraphRunner, UnsupportedOperator
+    default = [int(o.version or 1) for o in model.opset_import if not o.domain or o.domain == "ai.onnx"]
+    evaluator = GraphRunner.evaluator(max(default or [1]))
+    keep = []
+    for n in G.g.node:
+        foldable = (not n.domain and n.op_type in _FOLDABLE and n.input and all(v in G.inits for v in n.input if v)
+                    and not any(a.has("g") or a.graphs for a in n.attribute) and not any(o in G.graph_outputs for o in n.output))
+        if foldable and n.op_type not in _FOLD_ALWAYS:
+            foldable = all(int(np.prod(G.inits[v].dims, dtype=np.int64)) <= _FOLD_INPUT_LIMIT for v in n.input if v)
+        if not foldable:
+            keep.append(n)
+            continue
+        try:
+            values = evaluator.evaluate(n, [G.array(v) if v else None for v in n.input])
+        except (UnsupportedOperator, ValueError, RuntimeError, TypeError):
+            keep.append(n)
+            continue
+        if n.op_type not in _FOLD_ALWAYS and any(v is not None and v.size > _FOLD_OUTPUT_LIMIT for v in values):
+            keep.append(n)
+            continue
+        for name, value in zip(n.output, values):
+            if name and value is not None:
+                G.set_initializer(name, np.ascontiguousarray(value))
+    G.g.node = keep
 
 
 def _lift_constant_weights(G: _Graph) -> None:
@@ -602,7 +657,9 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
     G = _Graph(model.graph)
     _raise_opset(model, G)
     _name_nodes(G)
+    _eliminate_identities(G)
     _lift_constant_weights(G)
+    _fold_constants(model, G)
     _duplicate_shared_initializers(G)
     _fuse_matmul_add(G)
     _standardize_gemm(G)

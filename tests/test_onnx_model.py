@@ -572,6 +572,40 @@ def test_weights_produced_by_constant_nodes_are_quantized_too():
     assert np.array_equal(inits["w"], q) and inits["w/scale"].tobytes() == s.tobytes()
 
 
+def test_constants_are_folded_like_the_optimizer_does():
+    """quantize.py:52 (`onnxscript.optimizer.optimize`) decides which weights are constants by the time the rules look: Identity
+    nodes are gone, `MatMul(x, Transpose(W))` reads a folded initializer (Transpose folds at any size), other constant
+    expressions fold only under the folder's size limits (8192 input elements, 512 * 512 output elements)."""
+    rng = np.random.default_rng(6)
+    wt = rng.standard_normal((96, 128)).astype(np.float32)                   # stored [N, K], 12288 elements > 8192
+    zeros = np.zeros(96, dtype=np.float32)
+    small, big = rng.standard_normal((16, 96)).astype(np.float32), rng.standard_normal((96, 100)).astype(np.float32)
+    g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["n", 128])], output=[P.make_value_info("y", 1, None), P.make_value_info("z", 1, None)],
+                  node=[P.make_node("Transpose", ["wt"], ["w"], name="t", perm=[1, 0]),
+                        P.make_node("Identity", ["zeros"], ["bias"], name="alias"),
+                        P.make_node("Gemm", ["x", "w", "bias"], ["h"], name="fc", transB=0),
+                        P.make_node("Mul", ["small", "two"], ["small2"], name="scale_small"),          # 1536 elements: folds
+                        P.make_node("Mul", ["big", "two"], ["big2"], name="scale_big"),                # 9600 elements: stays
+                        P.make_node("MatMul", ["h", "small2t"], ["y"], name="fc_small"),
+                        P.make_node("MatMul", ["h", "big2"], ["z"], name="fc_big")],
+                  initializer=[P.numpy_to_tensor("wt", wt), P.numpy_to_tensor("zeros", zeros), P.numpy_to_tensor("small", small),
+                               P.numpy_to_tensor("big", big), P.numpy_to_tensor("two", np.float32(2.0)), P.numpy_to_tensor("small2t", small.T.copy() * 2)])
+    model = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+    out = q_oracle(model, CONFIGS["int8_channel"]())
+    ops = {n.name: (n.op_type, n.domain or "") for n in out.graph.node}
+    assert "t" not in ops and "alias" not in ops and "scale_small" not in ops           # folded / eliminated (scale_small: unused after folding)
+    assert ops["fc"] == ("QGemmWeightsOnlyQDQ", "quant")                                # weight from the folded Transpose, bias through the alias
+    assert ops["fc_small"][1] == "quant"
+    assert ops["scale_big"] == ("Mul", "") and ops["fc_big"] == ("MatMul", "")          # over the input limit: not a constant weight
+    inits = {t.name: P.tensor_to_numpy(t) for t in out.graph.initializer}
+    q, s, z = O.rtn_quantize(np.ascontiguousarray(wt.T), "int8", "channel", -1, False)
+    assert np.array_equal(inits["w"], q) and inits["w/scale"].tobytes() == s.tobytes()
+    x = torch.randn(4, 128)
+    for k, v in GraphRunner(model, device="cpu")(x).items():
+        got = GraphRunner(out, device="cpu")(x)[k]
+        assert ((got - v).norm() / v.norm()).item() < 0.03
+
+
 def test_opset_is_raised_with_adapters_or_refused_by_name():
     x = P.make_value_info("x", 1, ["batch", 16])
     w = np.random.default_rng(1).standard_normal((16, 4)).astype(np.float32)
