@@ -13,6 +13,8 @@ node names, `/lm_head/MatMul` -- with random weights, and then runs the referenc
   gemma3_awq.py   QConfig(weights=QWeightArgs(dtype="uint4", strategy="group", group_size=128), preprocessors=[AwqConfig()],
                           calibration_data={input_ids, attention_mask, empty past_key_values}, CalibrationParams(batch_size=1,
                           num_samples=64), ignore=["lm_head"])
+  BASELINE #3     static int8 weights and activations (QDQ), 512 calibration sequences (the configuration this repository's
+                  BASELINE.json names for the gemma3 example)
 
 Everything numeric happens on the GPU: the AWQ calibration runs the graph itself on torch-ROCm (`GraphRunner`), the 126
 searches and the quantization run in the HIP library, and the result is written with its tensors in a side file.
@@ -157,7 +159,7 @@ def make_calibration_data(layers, vocab, num_samples, block_size, seed=1):
     return data
 
 
-def main(layers=18, vocab=262144, samples=64, block=256, work=None, verbose=True) -> dict:
+def main(layers=18, vocab=262144, samples=64, block=256, work=None, verbose=True, static_samples=512) -> dict:
     keep = work is not None
     work = work or tempfile.mkdtemp(prefix="oq_gemma3_onnx_")
     os.makedirs(work, exist_ok=True)
@@ -176,6 +178,13 @@ def main(layers=18, vocab=262144, samples=64, block=256, work=None, verbose=True
                                           calibration_data=make_calibration_data(layers, vocab, samples, block),
                                           calibration_params=CalibrationParams(batch_size=1, num_samples=samples), ignore=["lm_head"]),
     }
+    if static_samples:
+        # BASELINE.json configs[2]: "gemma3 example ONNX, static QInt8 weights + activations with 512-sample calibration"
+        from onnx_quantize_amd import QActivationArgs
+        configs[f"static_int8_{static_samples}"] = lambda: QConfig(
+            weights=QWeightArgs(dtype="int8"), input_activations=QActivationArgs(dtype="int8", is_static=True),
+            output_activations=QActivationArgs(dtype="int8", is_static=True), calibration_data=make_calibration_data(layers, vocab, static_samples, block),
+            calibration_params=CalibrationParams(batch_size=16, num_samples=static_samples), ignore=["lm_head"])
     for name, make in configs.items():
         dst = os.path.join(work, f"qgemma_{name}.onnx")
         t0 = time.perf_counter()
@@ -209,5 +218,6 @@ if __name__ == "__main__":
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--block", type=int, default=256)
     ap.add_argument("--dir", default=None)
+    ap.add_argument("--static-samples", type=int, default=512, help="calibration sequences of the static int8 configuration (0: skip it)")
     a = ap.parse_args()
-    main(a.layers, a.vocab, a.samples, a.block, a.dir)
+    main(a.layers, a.vocab, a.samples, a.block, a.dir, static_samples=a.static_samples)

@@ -40,10 +40,12 @@ def test_gemma3_onnx_file_example_runs_the_references_two_configurations(tmp_pat
     spec = importlib.util.spec_from_file_location("gemma3_onnx_file", os.path.join(ROOT, "examples", "gemma3_shapes", "gemma3_onnx_file.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    report = mod.main(layers=2, vocab=512, samples=4, block=32, work=str(tmp_path), verbose=False)
+    report = mod.main(layers=2, vocab=512, samples=4, block=32, work=str(tmp_path), verbose=False, static_samples=8)
     rtn, awq = report["rtn_int8_g128"], report["awq_uint4_g128"]
     assert rtn["calls"] == {"QMatMulWeightsOnlyGrouped": 14} and rtn["lm_head_left_float"] and rtn["logits_rel_err"] < 0.05
     assert awq["calls"] == {"MatMulNBits": 14} and awq["lm_head_left_float"] and awq["logits_rel_err"] < 0.35
+    static = report["static_int8_8"]
+    assert static["calls"] == {"QMatMulWeightStaticInputOutputQDQ": 14} and static["logits_rel_err"] < 0.2
     q = P.load_model(tmp_path / "qgemma_awq_uint4_g128.onnx")
     muls = [n for n in q.graph.node if n.op_type == "Mul" and n.name.endswith("/scale_input")]
     assert len(muls) == 14                                     # awq.py:73-88: one Mul per quantized node
