@@ -407,6 +407,42 @@ class GraphRunner:
             out = out + (x[2] * a.get("beta", 1.0) if a.get("beta", 1.0) != 1.0 else x[2])
         return out
 
+    def _op_Einsum(self, n, x, a, e):
+        import torch
+        return torch.einsum(a["equation"], *x)
+
+    def _op_CumSum(self, n, x, a, e):
+        import torch
+        axis = int(x[1].item())
+        t = x[0].flip(axis) if a.get("reverse", 0) else x[0]
+        out = torch.cumsum(t, dim=axis)
+        if a.get("exclusive", 0):
+            out = out - t
+        return out.flip(axis) if a.get("reverse", 0) else out
+
+    def _op_ArgMax(self, n, x, a, e):
+        import torch
+        return torch.argmax(x[0], dim=a.get("axis", 0), keepdim=bool(a.get("keepdims", 1)))
+
+    def _op_GatherElements(self, n, x, a, e):
+        import torch
+        axis = a.get("axis", 0)
+        idx = x[1].to(torch.int64)
+        return torch.gather(x[0], axis, torch.where(idx < 0, idx + x[0].shape[axis], idx))
+
+    def _op_IsNaN(self, n, x, a, e): return x[0].isnan()
+    def _op_IsInf(self, n, x, a, e): return x[0].isinf()
+    def _op_Sign(self, n, x, a, e): return x[0].sign()
+    def _op_Mod(self, n, x, a, e):
+        import torch
+        return torch.fmod(x[0], x[1]) if a.get("fmod", 0) else torch.remainder(x[0], x[1])
+
+    def _op_HardSigmoid(self, n, x, a, e): return (x[0] * a.get("alpha", 0.2) + a.get("beta", 0.5)).clamp(0, 1)
+
+    def _op_Elu(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.elu(x[0], a.get("alpha", 1.0))
+
     # shapes
     def _op_Shape(self, n, x, a, e):
         import torch
@@ -793,7 +829,7 @@ class GraphRunner:
 
 
 _SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
-_HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split", "ConstantOfShape", "Gather", "Trilu",
+_HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split", "ConstantOfShape", "Gather", "Trilu",
                   "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}
 
 
