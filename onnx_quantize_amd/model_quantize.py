@@ -45,7 +45,7 @@ from .onnx_functions import FUNCTION_OPSET, MS_DOMAIN, QUANT_DOMAIN, build_funct
 from .onnx_proto import (DataType, Message, attribute_value, check_model, load_model, make_attribute, make_node, numpy_to_tensor, parse_model,
                          save_model, tensor_to_numpy)
 
-__all__ = ["quantize_model", "quantize_file", "apply_pre_passes", "as_model"]
+__all__ = ["quantize_model", "quantize_model_sharded", "quantize_file", "apply_pre_passes", "as_model"]
 
 logger = logging.getLogger("onnx_quantize")
 
@@ -693,18 +693,29 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
         logger.info("No quantization parameters specified in qconfig. Returning original model.")
         return as_model(model)
     prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
-    model, G, targets, meta, per_node = prepared.model, prepared.graph, prepared.targets, prepared.meta, prepared.per_node
+    return _emit(prepared, qconfig, weight_arrays, quantize_bias)
+
+
+def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bias):
+    G = prepared.graph
+    has_bias = len(node.input) > 2
+    w = _Const(node.input[1], G.array(node.input[1]))
+    b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
+    node_meta = prepared.meta.get(id(node), {})
+    return plan_node(node.op_type, node.input[0], w, node.output[0], prepared.per_node.get(id(node), qconfig), node_meta, bias=b,
+                     out=_Out(node_meta), weight_arrays=weight_arrays, quantize_bias=quantize_bias)
+
+
+def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) -> Message:
+    """quantize.py:60-78: the rules' rewrites node by node, the functions, the opset imports, the post passes."""
+    model, G, targets = prepared.model, prepared.graph, prepared.targets
 
     used_functions: dict = {}
     domains = set()
     for node in targets:
-        x_name, w_name, out_name = node.input[0], node.input[1], node.output[0]
-        has_bias = len(node.input) > 2
-        w = _Const(w_name, G.array(w_name))
-        b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
-        node_meta = meta.get(id(node), {})
-        plan = plan_node(node.op_type, x_name, w, out_name, per_node.get(id(node), qconfig), node_meta, bias=b, out=_Out(node_meta),
-                         weight_arrays=weight_arrays, quantize_bias=quantize_bias)
+        w_name = node.input[1]
+        in_channels = int(G.inits[w_name].dims[0])
+        plan = _plan(prepared, node, qconfig, weight_arrays, quantize_bias)
         for name, array in plan.initializers:
             G.set_initializer(name, np.asarray(array), plan.onnx_types.get(name))
         call = plan.call
@@ -715,7 +726,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
         if call["domain"] == QUANT_DOMAIN:
             group = None
             if call["name"].endswith("WeightsOnlyGrouped"):                       # base.py:72: the group size this weight resolved to
-                group = int(_resolve_group_size(w.numpy().shape[0], qconfig.weights.group_size, w_name))
+                group = int(_resolve_group_size(in_channels, qconfig.weights.group_size, w_name))
             used_functions.setdefault((call["name"], group), []).append(node)
 
     # qfunctions/__init__.py:11-22 + RemoveUnusedFunctionsPass: the functions the calls use, nothing else
@@ -742,6 +753,58 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     _deduplicate_initializers(G)
     check_model(model)                                      # what leaves is structurally sound, or the caller hears why not
     return model
+
+
+def quantize_model_sharded(model, qconfig: QConfig, *, group=None, device="cuda", weight_arrays=None, quantize_bias=None,
+                           calibrate=None, searches=None):
+    """`quantize_model` with the weights of the model spread over the ranks of a process group (BASELINE.json's
+    last configuration): every rank parses the file (its tensors are memory-mapped, a rank only touches the weights it
+    quantizes) and runs the pre-passes and the calibration walk for itself -- they decide WHAT is quantized and with which
+    statistics, and replicating them needs no exchange --, then each rank runs the numeric seam for the nodes a cost-balanced
+    plan gives it (`sharding.plan_lpt`: nodes that read one value stay together, so a Hessian is factored once), the three
+    arrays of every weight are gathered on rank 0 (`sharding.quantize_sharded`: one gather at the end, RCCL over xGMI on a GPU
+    node), and rank 0 emits the model.  Returns the model on rank 0, None on the other ranks.  Without an initialised process
+    group it is `quantize_model`."""
+    from .sharding import LayerSpec, quantize_sharded
+
+    if not isinstance(qconfig, QConfig):
+        raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
+    if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
+        return as_model(model)
+    prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
+    if weight_arrays is None:
+        from .seam import weight_arrays
+    needs_hessian = bool(qconfig.weights.algorithm.requires_calibration)
+    specs = []
+    for node in prepared.targets:
+        t = prepared.graph.inits[node.input[1]]
+        got = prepared.meta.get(id(node), {}).get("input")
+        specs.append(LayerSpec(node.input[1], int(t.dims[0]), int(t.dims[1]), tokens=int(getattr(got, "n", 0) or 0) if needs_hessian else 0,
+                               hessian_key=node.input[0] if needs_hessian else ""))
+
+    def on_this_rank(i, _spec):
+        captured = []
+
+        def recording(value, cfg, out, nbits):
+            arrays = weight_arrays(value, cfg, out, nbits)
+            if np.asarray(value.const_value.numpy()).ndim == 2:
+                captured.append(arrays)
+            return arrays
+
+        _plan(prepared, prepared.targets[i], qconfig, recording, quantize_bias)
+        (arrays,) = captured                                 # one matrix per node: its weight (a bias is a vector)
+        return tuple(np.asarray(a) for a in arrays)
+
+    gathered = quantize_sharded(specs, on_this_rank, group=group)
+    if gathered is None:
+        return None
+
+    def from_the_ranks(value, cfg, out, nbits):
+        if np.asarray(value.const_value.numpy()).ndim == 2:
+            return gathered[value.name]
+        return weight_arrays(value, cfg, out, nbits)           # the per-tensor bias of a QDQ Gemm: a vector, quantized here
+
+    return _emit(prepared, qconfig, from_the_ranks, quantize_bias)
 
 
 def quantize_file(src, dst, qconfig: QConfig, external_data="auto", **kw) -> Message:
