@@ -84,7 +84,22 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--dir", default=None, help="where the files go (default: a temporary directory, removed afterwards)")
     ap.add_argument("--repeat", type=int, default=2, help="quantize passes over the same source (the first one pages the file in)")
+    ap.add_argument("--phases", action="store_true", help="also report the wall time of the calibration walk(s), the searches and the emission")
     args = ap.parse_args()
+    phases: dict = {}
+    if args.phases:
+        import onnx_quantize_amd.model_quantize as MQ
+
+        def timed(name, fn):
+            def wrapper(*a, **kw):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                out = fn(*a, **kw)
+                torch.cuda.synchronize()
+                phases[name] = round(phases.get(name, 0.0) + time.perf_counter() - t, 4)
+                return out
+            return wrapper
+        MQ._calibrate, MQ._preprocess, MQ.plan_node = timed("calibrate_s", MQ._calibrate), timed("searches_s", MQ._preprocess), timed("seam_s", MQ.plan_node)
     work = args.dir or tempfile.mkdtemp(prefix="oq_bench_model_")
     os.makedirs(work, exist_ok=True)
     src, dst = os.path.join(work, "model.onnx"), os.path.join(work, "model_q.onnx")
@@ -107,7 +122,8 @@ def main():
         t2 = time.perf_counter()
         P.save_model(out, dst, external_data="model_q.onnx.data")
         t3 = time.perf_counter()
-        runs.append({"load_s": round(t1 - t0, 4), "quantize_s": round(t2 - t1, 4), "save_s": round(t3 - t2, 4), "total_s": round(t3 - t0, 4)})
+        runs.append({"load_s": round(t1 - t0, 4), "quantize_s": round(t2 - t1, 4), "save_s": round(t3 - t2, 4), "total_s": round(t3 - t0, 4), **phases})
+        phases.clear()
         del loaded
     out_bytes = os.path.getsize(dst) + os.path.getsize(dst + ".data")
     calls = sorted({(n.op_type, n.domain) for n in out.graph.node if n.domain})

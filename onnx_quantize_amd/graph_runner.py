@@ -102,6 +102,11 @@ class GraphRunner:
         import torch
         if a.dtype == np.uint16 or a.dtype == np.uint32 or a.dtype == np.uint64:
             a = a.astype(np.int64)
+        if a.nbytes >= 1 << 20 and a.flags.c_contiguous and a.ndim:
+            import warnings
+            with warnings.catch_warnings():                     # a large read-only view into the (memory-mapped) file: it is only
+                warnings.filterwarnings("ignore", message="The given NumPy array is not writable")      # read, by the upload below
+                return torch.from_numpy(a).to(self.device)
         t = torch.from_numpy(np.array(a, order="C"))            # a copy: 0-d stays 0-d, and views into the file are read-only
         # small integer tensors are shape arithmetic: they stay on the host, where Reshape / Slice / Expand read them
         if t.dtype == torch.int64 and t.numel() <= 64:
@@ -829,8 +834,8 @@ class GraphRunner:
 
 
 _SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
-_HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split", "ConstantOfShape", "Gather", "Trilu",
-                  "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}
+_HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split",
+                  "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}
 
 
 class _Attrs:

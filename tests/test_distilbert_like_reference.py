@@ -11,7 +11,6 @@ writer emits with the oracle as numeric provider on the same activations.
 import io
 import warnings
 
-import numpy as np
 import pytest
 import torch
 

@@ -25,7 +25,7 @@ from onnx_quantize_amd import onnx_proto as P
 from onnx_quantize_amd.graph_runner import GraphRunner, UnsupportedOperator
 from onnx_quantize_amd.onnx_functions import build_function, function_names
 
-from onnx_model_helpers import FIXTURES, fixture, oracle_calibrate, oracle_weight_arrays, q_oracle
+from onnx_model_helpers import FIXTURES, fixture, oracle_weight_arrays, q_oracle
 
 
 def torch_modules():
