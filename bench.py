@@ -31,6 +31,8 @@ Prints ONE JSON line (contract in the task description) with these extra objects
                 seam (seam.py: one upload, fused blob kernel, one download), digest-checked
   calibration   BASELINE config 3 stand-in from the same run (bench_calib.run): 51 batches x 72 activation tensors through
                 MinMaxCalibrator.collect_many, `roofline` of oq::minmax_partial, a CPU baseline, `verified`
+  model_file    next rows N4 / N1: an ONNX file (14 Llama-2-7B-width weights, 1.6 GB, tensors in a side file) -> quantize_file
+                (uint4 g128 -> MatMulNBits) -> an ONNX file (bench_model.run): load / quantize / save seconds, `verified`
   awq           the AWQ scale / clip searches of one 4096 x 4096 layer on own kernels (next row N2), verified in float64
   searches      the MSE range search (row M1) and HQQ's zero-point optimisation (next row N2) on the headline matrix, each
                 verified through the error it is meant to lower
@@ -581,6 +583,7 @@ def main() -> None:
     ap.add_argument("--no-seam", action="store_true", help="skip the `seam` object")
     ap.add_argument("--no-model-rtn", action="store_true", help="skip the `model_rtn` object (224 Llama-2-7B weights in one call)")
     ap.add_argument("--no-awq", action="store_true", help="skip the `awq` object (AWQ scale / clip searches of one layer)")
+    ap.add_argument("--no-model-file", action="store_true", help="skip the `model_file` object (an ONNX file quantized file to file, bench_model.py)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the `calibration` object (config 3 stand-in)")
     ap.add_argument("--gptq-extra-passes", default="corrected,f32",
                     help="further whole-model GPTQ passes of the `gptq` object (bench_gptq.py --extra-passes)")
@@ -900,6 +903,16 @@ def main() -> None:
     if world == 1 and not args.no_awq and not args.no_extras:
         awq = awq_bench(dev)
         torch.cuda.empty_cache()
+    # ---- the file path: an ONNX file of two Llama-2-7B-width decoder layers -> quantize_file -> an ONNX file
+    model_file = None
+    if world == 1 and not args.no_model_file and not args.no_extras:
+        import bench_model
+
+        try:
+            model_file = bench_model.run(bench_model.build_parser().parse_args(["--layers", "2", "--config", "uint4_g128"]))
+        except OSError as e:                                  # no room for the 1.6 GB source where temporary files go
+            model_file = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     # ---- configs 4 / 5: GPTQ of a Llama-2-7B-shaped model from the same run (all ranks take part)
     gptq = None
     if not args.no_gptq and not args.no_extras:
@@ -979,6 +992,7 @@ def main() -> None:
         "seam": seam,
         "gather": gather,
         "calibration": calibration,
+        "model_file": model_file,
         "awq": awq,
         "searches": searches,
         "gptq": gptq,

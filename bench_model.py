@@ -74,7 +74,7 @@ def configs(name, data):
     }[name]()
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--hidden", type=int, default=4096)
@@ -85,7 +85,12 @@ def main():
     ap.add_argument("--dir", default=None, help="where the files go (default: a temporary directory, removed afterwards)")
     ap.add_argument("--repeat", type=int, default=2, help="quantize passes over the same source (the first one pages the file in)")
     ap.add_argument("--phases", action="store_true", help="also report the wall time of the calibration walk(s), the searches and the emission")
-    args = ap.parse_args()
+    return ap
+
+
+def run(args) -> dict:
+    """One file -> file measurement (also the `model_file` object of bench.py's line).  The result is verified: one weight's
+    MatMulNBits blob / grouped integers in the emitted file against the kernels' own output on the same weight."""
     phases: dict = {}
     if args.phases:
         import onnx_quantize_amd.model_quantize as MQ
@@ -133,9 +138,26 @@ def main():
             "build_source_s": round(t_build, 2), "runs": runs, "best": best,
             "mparam_per_s_file_to_file": round(params / best["total_s"] / 1e6, 1),
             "source_gb_per_s_quantize_phase": round(params * 4 / best["quantize_s"] / 1e9, 2)}
-    print(json.dumps(line))
+    if args.config in ("uint4_g128", "int4_g128", "int8_tensor"):              # the file holds what the kernels produce on that weight
+        from onnx_quantize_amd.hip import ops
+        source = P.load_model(src)
+        name = "layers.0.down.weight"
+        w = torch.from_numpy(np.array(P.tensor_to_numpy(next(t for t in source.graph.initializer if t.name == name)))).cuda()
+        got = torch.from_numpy(np.array(P.tensor_to_numpy(next(t for t in out.graph.initializer if t.name == name))))
+        if args.config == "uint4_g128":
+            want, _, _ = ops.rtn_quantize(w, "uint4", "group", 128, layout="nbits")
+        elif args.config == "int4_g128":
+            want, _, _ = ops.rtn_quantize(w, "int4", "group", 128)
+        else:
+            want, _, _ = ops.rtn_quantize(w, "int8", "tensor", -1, True)
+        line["verified"] = bool(torch.equal(got.view(torch.uint8).reshape(-1), want.cpu().view(torch.uint8).reshape(-1)))
     if args.dir is None:
         shutil.rmtree(work, ignore_errors=True)
+    return line
+
+
+def main():
+    print(json.dumps(run(build_parser().parse_args())))
 
 
 if __name__ == "__main__":
