@@ -412,6 +412,77 @@ class GraphRunner:
             out = out + (x[2] * a.get("beta", 1.0) if a.get("beta", 1.0) != 1.0 else x[2])
         return out
 
+    # convolutional front ends of models whose classifier is a Gemm / MatMul (the calibration walk has to get through them)
+    @staticmethod
+    def _pads(a, spatial, x_shape=None, kernel=None, strides=None, dilations=None):
+        pads = a.get("pads", None)
+        auto = a.get("auto_pad", "NOTSET")
+        if auto in ("SAME_UPPER", "SAME_LOWER"):
+            total = []
+            for i in range(spatial):
+                size, k, st, d = x_shape[2 + i], kernel[i], strides[i], dilations[i]
+                out = -(-size // st)
+                total.append(max(0, (out - 1) * st + (k - 1) * d + 1 - size))
+            begin = [t // 2 if auto == "SAME_UPPER" else t - t // 2 for t in total]
+            return begin, [t - b for t, b in zip(total, begin)]
+        if pads is None or auto == "VALID":
+            return [0] * spatial, [0] * spatial
+        return list(pads[:spatial]), list(pads[spatial:])
+
+    def _op_Conv(self, n, x, a, e):
+        import torch
+        t, w = x[0], x[1]
+        bias = x[2] if len(x) > 2 else None
+        spatial = t.ndim - 2
+        strides, dilations = a.get("strides", [1] * spatial), a.get("dilations", [1] * spatial)
+        begin, end = self._pads(a, spatial, t.shape, list(w.shape[2:]), strides, dilations)
+        if begin != end:
+            pad = []
+            for b, en in zip(reversed(begin), reversed(end)):
+                pad += [b, en]
+            t, begin = torch.nn.functional.pad(t, pad), [0] * spatial
+        fn = {1: torch.nn.functional.conv1d, 2: torch.nn.functional.conv2d, 3: torch.nn.functional.conv3d}[spatial]
+        return fn(t, w, bias, stride=strides, padding=begin, dilation=dilations, groups=a.get("group", 1))
+
+    def _pool(self, n, x, a, kind):
+        import torch
+        t = x[0]
+        spatial = t.ndim - 2
+        kernel = a["kernel_shape"]
+        strides, dilations = a.get("strides", [1] * spatial), a.get("dilations", [1] * spatial)
+        begin, end = self._pads(a, spatial, t.shape, kernel, strides, dilations)
+        ceil = bool(a.get("ceil_mode", 0))
+        if begin != end:
+            raise UnsupportedOperator(f"GraphRunner: {kind} with asymmetric padding")
+        if kind == "MaxPool":
+            fn = {1: torch.nn.functional.max_pool1d, 2: torch.nn.functional.max_pool2d, 3: torch.nn.functional.max_pool3d}[spatial]
+            return fn(t, kernel, strides, begin, dilations, ceil_mode=ceil)
+        fn = {1: torch.nn.functional.avg_pool1d, 2: torch.nn.functional.avg_pool2d, 3: torch.nn.functional.avg_pool3d}[spatial]
+        return fn(t, kernel, strides, begin, ceil_mode=ceil, count_include_pad=bool(a.get("count_include_pad", 0)))
+
+    def _op_MaxPool(self, n, x, a, e):
+        if len([o for o in n.output if o]) > 1:
+            raise UnsupportedOperator("GraphRunner: MaxPool with the Indices output")
+        return self._pool(n, x, a, "MaxPool")
+
+    def _op_AveragePool(self, n, x, a, e): return self._pool(n, x, a, "AveragePool")
+    def _op_GlobalAveragePool(self, n, x, a, e): return x[0].mean(dim=tuple(range(2, x[0].ndim)), keepdim=True)
+    def _op_GlobalMaxPool(self, n, x, a, e): return x[0].amax(dim=tuple(range(2, x[0].ndim)), keepdim=True)
+
+    def _op_BatchNormalization(self, n, x, a, e):
+        import torch
+        if a.get("training_mode", 0):
+            raise UnsupportedOperator("GraphRunner: BatchNormalization in training mode")
+        return torch.nn.functional.batch_norm(x[0], x[3], x[4], x[1], x[2], False, 0.0, a.get("epsilon", 1e-5))
+
+    def _op_HardSwish(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.hardswish(x[0])
+
+    def _op_PRelu(self, n, x, a, e):
+        import torch
+        return torch.where(x[0] >= 0, x[0], x[0] * x[1])
+
     def _op_Einsum(self, n, x, a, e):
         import torch
         return torch.einsum(a["equation"], *x)

@@ -967,3 +967,37 @@ def test_contrib_operators_of_genai_style_exports():
             x1, x2 = th[..., : d // 2], th[..., d // 2:]
             want = torch.cat((x1 * c - x2 * s_, x2 * c + x1 * s_), -1)
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_graph_runner_gets_through_a_convolutional_front_end():
+    """A CNN whose classifier is a Gemm: Conv (groups, strides, padding, bias), BatchNormalization, MaxPool / AveragePool /
+    GlobalAveragePool, HardSwish, Flatten -- exported by torch, run against the module, quantized (the classifier only)."""
+    import io
+    import warnings
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    onnx_proto_utils._add_onnxscript_fn = lambda proto, _ops: proto
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(
+        torch.nn.Conv2d(3, 8, 3, stride=2, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.MaxPool2d(2),
+        torch.nn.Conv2d(8, 16, 3, padding=1, groups=4, bias=False), torch.nn.Hardswish(), torch.nn.AvgPool2d(2, padding=1),
+        torch.nn.AdaptiveAvgPool2d(1), torch.nn.Flatten(), torch.nn.Linear(16, 10)).eval()
+    with torch.no_grad():
+        net[1].running_mean.normal_()
+        net[1].running_var.uniform_(0.5, 2.0)
+    f = io.BytesIO()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        torch.onnx.export(net, (torch.randn(2, 3, 32, 32),), f, dynamo=False, opset_version=17, input_names=["image"], output_names=["scores"],
+                          dynamic_axes={"image": {0: "batch"}, "scores": {0: "batch"}}, do_constant_folding=False)
+    data = f.getvalue()
+    model = P.parse_model(data)
+    assert P.serialize(model) == data
+    assert {"Conv", "MaxPool", "AveragePool", "GlobalAveragePool", "HardSwish", "Gemm"} <= {n.op_type for n in model.graph.node}
+    x = torch.randn(5, 3, 32, 32)
+    with torch.no_grad():
+        torch.testing.assert_close(GraphRunner(model, device="cpu")(x)["scores"], net(x), rtol=1e-4, atol=1e-5)
+    out = q_oracle(model, CONFIGS["int8_channel"]())
+    assert [n.op_type for n in out.graph.node if n.domain] == ["QGemmWeightsOnlyQDQ"]
+    assert sum(n.op_type == "Conv" for n in out.graph.node) == 2
+    got, want = GraphRunner(out, device="cpu")(x)["scores"], GraphRunner(model, device="cpu")(x)["scores"]
+    assert ((got - want).norm() / want.norm()).item() < 0.02
