@@ -55,7 +55,9 @@ SCHEMA = {
     "StringStringEntryProto": {1: ("key", "string", O), 2: ("value", "string", O)},
     "GraphProto": {1: ("node", "NodeProto", M), 2: ("name", "string", O), 5: ("initializer", "TensorProto", M),
                    10: ("doc_string", "string", O), 11: ("input", "ValueInfoProto", M), 12: ("output", "ValueInfoProto", M),
-                   13: ("value_info", "ValueInfoProto", M), 16: ("metadata_props", "StringStringEntryProto", M)},
+                   13: ("value_info", "ValueInfoProto", M), 15: ("sparse_initializer", "SparseTensorProto", M),
+                   16: ("metadata_props", "StringStringEntryProto", M)},
+    "SparseTensorProto": {1: ("values", "TensorProto", O), 2: ("indices", "TensorProto", O), 3: ("dims", "int64", M)},
     "NodeProto": {1: ("input", "string", M), 2: ("output", "string", M), 3: ("name", "string", O), 4: ("op_type", "string", O),
                   5: ("attribute", "AttributeProto", M), 6: ("doc_string", "string", O), 7: ("domain", "string", O),
                   8: ("overload", "string", O), 9: ("metadata_props", "StringStringEntryProto", M)},
@@ -549,7 +551,7 @@ def _check_graph(graph: Message, outer: set, imported: set, functions: set, wher
         if t.name in names:
             raise ValueError(f"check_model: {where}: two initializers named '{t.name}'")
         names.add(t.name)
-    known |= names | {i.name for i in graph.input}
+    known |= names | {i.name for i in graph.input} | {t.values.name for t in graph.sparse_initializer if t.values is not None}
     produced = set()
     for n in graph.node:
         label = f"{where}: node '{n.name or n.op_type}'"
