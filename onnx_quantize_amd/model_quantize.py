@@ -96,7 +96,10 @@ class _Graph:
         return None if t is None else tensor_to_numpy(t)
 
     def set_initializer(self, name, array, data_type=None):
-        t = numpy_to_tensor(name, array, data_type)
+        return self.set_tensor(numpy_to_tensor(name, array, data_type))
+
+    def set_tensor(self, t):
+        name = t.name
         if name in self.inits:
             old = self.inits[name]
             self.g.initializer[[id(x) for x in self.g.initializer].index(id(old))] = t
@@ -628,6 +631,27 @@ def _remove_unused_initializers(G: _Graph) -> None:
 
 
 # ------------------------------------------------------------------------------------------------------------ the pipeline
+class _PackedSeam:
+    """The device seam as the writer's default provider: the same three arrays, except that 4-bit integers of a matrix come back
+    already nibble-packed from the device (`seam.weight_arrays(..., packed4=True)`) and go into the TensorProto as they are --
+    packing 6.5 G values in NumPy was a third of a 7B-model GPTQ run.  The emission code reads shapes and dtypes only, so it is
+    handed a zero-stride placeholder of the right shape in their place."""
+
+    def __init__(self):
+        self.packed: dict = {}
+
+    def __call__(self, value, cfg, out, nbits):
+        from .seam import weight_arrays
+        a = cfg.weights
+        w = value.const_value.numpy()
+        algorithm = getattr(a.algorithm, "algorithm_type", None)
+        if nbits or a.dtype.bitwidth != 4 or w.ndim != 2 or algorithm not in ("rtn", "gptq", "hqq"):
+            return weight_arrays(value, cfg, out, nbits)
+        q, s, z = weight_arrays(value, cfg, out, nbits, packed4=True)
+        self.packed[value.name] = (q, tuple(w.shape))
+        return np.broadcast_to(np.zeros((), dtype=a.dtype.np_dtype), w.shape), s, z
+
+
 class _Out:
     """What the seam reads of a node's output value: `out.producer().meta`."""
 
@@ -693,7 +717,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
         logger.info("No quantization parameters specified in qconfig. Returning original model.")
         return as_model(model)
     prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
-    return _emit(prepared, qconfig, weight_arrays, quantize_bias)
+    return _emit(prepared, qconfig, weight_arrays if weight_arrays is not None else _PackedSeam(), quantize_bias)
 
 
 def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bias):
@@ -716,8 +740,14 @@ def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) ->
         w_name = node.input[1]
         in_channels = int(G.inits[w_name].dims[0])
         plan = _plan(prepared, node, qconfig, weight_arrays, quantize_bias)
+        packed = getattr(weight_arrays, "packed", {})
         for name, array in plan.initializers:
-            G.set_initializer(name, np.asarray(array), plan.onnx_types.get(name))
+            if name in packed:                                # 4-bit integers packed on the device (`_PackedSeam`)
+                raw, shape = packed.pop(name)
+                G.set_tensor(Message("TensorProto", dims=[int(d) for d in shape], data_type=int(plan.onnx_types[name]), name=name,
+                                     raw_data=memoryview(np.ascontiguousarray(raw).reshape(-1)).cast("B")))
+            else:
+                G.set_initializer(name, np.asarray(array), plan.onnx_types.get(name))
         call = plan.call
         node.op_type, node.domain = call["name"], call["domain"]
         node.input = ["" if v is None else v for v in call["inputs"]]

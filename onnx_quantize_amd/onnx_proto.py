@@ -505,19 +505,23 @@ def numpy_to_tensor(name: str, array, data_type: int | None = None) -> Message:
         data_type = _CODE_OF[a.dtype]
     t = Message("TensorProto", dims=[int(d) for d in a.shape], data_type=int(data_type), name=name)
     if data_type in (DataType.UINT4, DataType.INT4):
-        flat = np.ascontiguousarray(a).reshape(-1).astype(np.int16)
+        if a.dtype not in (np.dtype(np.int8), np.dtype(np.uint8)):
+            raise ValueError(f"onnx_proto: tensor '{name}': 4-bit values travel in int8 / uint8 containers, not {a.dtype}")
+        u = np.ascontiguousarray(a).reshape(-1).view(np.uint8)          # two's-complement nibbles: the low four bits as they are
         lo_ok, hi_ok = (-8, 7) if data_type == DataType.INT4 else (0, 15)
-        if flat.size and (flat.min() < lo_ok or flat.max() > hi_ok):
+        bad = ((u + np.uint8(8)) & np.uint8(0xF0)).any() if data_type == DataType.INT4 and a.dtype == np.int8 else (u & np.uint8(0xF0)).any()
+        if bad:
             raise ValueError(f"onnx_proto: tensor '{name}' holds values outside the 4-bit range [{lo_ok}, {hi_ok}]")
-        nib = (flat & 0x0F).astype(np.uint8)
-        if nib.size % 2:
-            nib = np.concatenate([nib, np.zeros(1, dtype=np.uint8)])
-        t.raw_data = (nib[0::2] | (nib[1::2] << 4)).tobytes()
+        if u.size % 2:
+            u = np.concatenate([u, np.zeros(1, dtype=np.uint8)])
+        t.raw_data = ((u[0::2] & np.uint8(0x0F)) | (u[1::2] << np.uint8(4))).tobytes()
         return t
     want = np.dtype(_NP_OF[data_type])
     if a.dtype != want:
         raise ValueError(f"onnx_proto: tensor '{name}': array dtype {a.dtype} does not match element type {data_type}")
-    t.raw_data = np.ascontiguousarray(a).astype(want.newbyteorder("<"), copy=False).tobytes()
+    body = np.ascontiguousarray(a).astype(want.newbyteorder("<"), copy=False).reshape(-1)
+    # a large array is referenced, not copied (the memoryview keeps it alive; writers stream it out as it is)
+    t.raw_data = memoryview(body).cast("B") if body.nbytes >= 1 << 20 else body.tobytes()
     return t
 
 

@@ -158,11 +158,12 @@ def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool):
     return None
 
 
-def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False):
+def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False, packed4: bool = False):
     """The three NumPy arrays `qrules/_common.py:133-137` produces for weight value ``w``: what
     ``algorithm.quantize_weights`` returns (rtn.py:106-109 shapes: q [K, N]; scale / zero point 0-d | [N] | [N*K/g, 1]) or,
     with ``is_matmul_nbits_compatible``, what `_prepare_for_matmul_nbits` makes of it (B uint8 [N, K/g, g*bits/8], scales
-    [N, K/g], zero points uint8 [N, ceil(K/g / 2)] nibble-packed | [N, K/g])."""
+    [N, K/g], zero points uint8 [N, ceil(K/g / 2)] nibble-packed | [N, K/g]).  ``packed4`` (an extension for writers): 4-bit
+    integers of the plain route come back nibble-packed, flat uint8 [ceil(K N / 2)], instead of one per byte."""
     from .hip import ops
 
     a = qconfig.weights
@@ -181,6 +182,10 @@ def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False
     q, s, z, is_blob = res
     qdt = a.dtype.np_dtype
     if not is_matmul_nbits_compatible:
+        if packed4 and a.dtype.bitwidth == 4:
+            # for a writer that serialises the integers as an ONNX INT4 / UINT4 tensor (core/_pack.py:8-22: two values per byte
+            # in flat order): packed on the device, half the download, no NumPy pass over the values on the host
+            return _host(ops.pack_nibbles(q)), _host(s, a.scale_dtype), _host(z, a.zp_dtype)
         return _host(q, qdt), _host(s, a.scale_dtype), _host(z, a.zp_dtype)
 
     # qrules/_common.py:65-123 on the device
