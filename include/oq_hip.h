@@ -329,6 +329,21 @@ int32_t oq_hessian_prepare_f32(const float* X, int64_t T, int64_t K, int64_t ldx
 int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_t K, int64_t n_seen, int64_t n_add,
                                            float* H, void* slabs, size_t slab_bytes, void* stream);
 
+/* N1  calibrate.py:244-251 runs the augmented model in an onnxruntime session; on the device the large products of that
+ *     run (activations [M, Kd] times a constant weight [Kd, N]) can take the Hessian's route through the fp16 matrix
+ *     cores: both operands split into two fp16 pieces under a power-of-two scale (22 significand bits), three products,
+ *     fp32 accumulate.
+ *       oq_matmul_pieces_bytes(Kd, cols)   size of the piece buffer of one operand with `cols` rows / columns (0: too large)
+ *       oq_matmul_prepare_f32              operand -> pieces (256-byte aligned).  contraction_is_fast_axis != 0: the source is
+ *                                          [cols, Kd] row-major (activations X [M, Kd]); 0: [Kd, cols] row-major (a weight
+ *                                          W [Kd, N], prepared once).  ldx: leading dimension of the source.
+ *       oq_matmul_pieces_f32               C [M, N] (ldc) = beta C + alpha A B from the two piece buffers. */
+size_t oq_matmul_pieces_bytes(int64_t Kd, int64_t cols);
+int32_t oq_matmul_prepare_f32(const float* X, int64_t Kd, int64_t cols, int64_t ldx, int32_t contraction_is_fast_axis,
+                              void* pieces, size_t pieces_bytes, void* stream);
+int32_t oq_matmul_pieces_f32(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha,
+                             float beta, float* C, int64_t ldc, void* stream);
+
 /* G3 prologue  gptq.py:118-127: dead = diag(H) == 0 -> H[d,d] = 1, W[d,:] = 0 (both in place);
  *     when actorder: perm_out = argsort(diag(H)) reversed (ties: larger index first) and W, H are
  *     permuted in place (Wtmp/Htmp-free: uses the workspace).  perm_out may be NULL otherwise. */

@@ -451,4 +451,30 @@ int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_
                               reinterpret_cast<float*>(sl), slab_bytes, 3, 2, as_stream(stream));
 }
 
+// N1  the calibration walk's large products (calibrate.py:244-251 runs them in onnxruntime): Y = X W on the fp16 matrix cores
+// with two-piece operands (22 significand bits, fp32 accumulate) -- the Hessian's arithmetic class, ~5 x an fp32 GEMM.
+size_t oq_matmul_pieces_bytes(int64_t Kd, int64_t cols) {
+    if (!extent_ok(Kd) || !extent_ok(cols) || !count_ok(Kd * cols, kMaxElements) || Kd > 8 * 65535 * 4) return 0;
+    return gemm_f16x3_pieces_bytes(Kd, cols);
+}
+
+int32_t oq_matmul_prepare_f32(const float* X, int64_t Kd, int64_t cols, int64_t ldx, int32_t contraction_is_fast_axis, void* pieces,
+                              size_t pieces_bytes, void* stream) {
+    OQ_REQUIRE(X && pieces && extent_ok(Kd) && extent_ok(cols) && count_ok(Kd * cols, kMaxElements) && extent_ok(ldx) &&
+               ldx >= (contraction_is_fast_axis ? Kd : cols), OQ_ERR_INVALID_ARGUMENT, "oq_matmul_prepare_f32: bad argument");
+    const size_t need = oq_matmul_pieces_bytes(Kd, cols);
+    OQ_REQUIRE(need != 0, OQ_ERR_UNSUPPORTED, "oq_matmul_prepare_f32: contraction of %lld too long", (long long)Kd);
+    OQ_REQUIRE(pieces_bytes >= need && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_WORKSPACE,
+               "oq_matmul_prepare_f32: a 256-byte aligned buffer of %zu bytes is needed, %zu given", need, pieces_bytes);
+    return make_f16x2_pieces(X, Kd, cols, ldx, contraction_is_fast_axis != 0, pieces, as_stream(stream));
+}
+
+int32_t oq_matmul_pieces_f32(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
+                             int64_t ldc, void* stream) {
+    OQ_REQUIRE(pieces_a && pieces_b && C && matrix_ok(M, N, ldc) && extent_ok(Kd) && oq_matmul_pieces_bytes(Kd, M) != 0 &&
+               oq_matmul_pieces_bytes(Kd, N) != 0 && (reinterpret_cast<uintptr_t>(pieces_a) & 255u) == 0 &&
+               (reinterpret_cast<uintptr_t>(pieces_b) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT, "oq_matmul_pieces_f32: bad argument");
+    return launch_gemm_f16x3(pieces_a, pieces_b, M, N, Kd, alpha, beta, C, ldc, nullptr, as_stream(stream));
+}
+
 }  // extern "C"

@@ -49,7 +49,7 @@ class GraphRunner:
     model: a parsed ModelProto (`onnx_proto.parse_model`); outputs: the value names wanted (default: the graph's own
     outputs); feed: one tensor / array (single-input model) or {input name: tensor / array}."""
 
-    def __init__(self, model: Message, outputs=None, device="cuda", capture: bool = False):
+    def __init__(self, model: Message, outputs=None, device="cuda", capture: bool = False, matmul: str = "torch"):
         import torch
 
         self.model, self.graph = model, model.graph
@@ -63,6 +63,13 @@ class GraphRunner:
         self._seen: set = set()
         self._moved: dict = {}               # id(host constant) -> (the constant, its copy on the device)
         self._const_nodes: dict = {}         # id(Constant node) -> its value (one object per node, so `_moved` can key on it)
+        # matmul = "pieces": products of fp32 activations with a LARGE constant weight go through the library's fp16-piece GEMM
+        # (`ops.matmul_pieces`: the Hessian kernels' arithmetic, 22-bit operands, fp32 accumulate: ~3 x torch's fp32 GEMM at these
+        # sizes and closer to float64); the weight's pieces are made once.  Small products and everything else stay with torch.
+        if matmul not in ("torch", "pieces"):
+            raise ValueError(f"GraphRunner: matmul must be 'torch' or 'pieces', got {matmul!r}")
+        self.matmul = matmul if self.device.type == "cuda" else "torch"
+        self._weight_pieces: dict = {}       # id(constant weight) -> (the weight, its MatmulOperand)
         self.functions = {(f.domain or "", f.name, f.overload or ""): f for f in model.functions}
         self.opset = max([int(o.version or 1) for o in model.opset_import if not o.domain] or [1])
         self.wanted = list(outputs) if outputs is not None else [o.name for o in self.graph.output]
@@ -157,6 +164,8 @@ class GraphRunner:
             inputs[name] = t.to(self.device, non_blocking=True)
         if not self.capture:
             return self._eager(inputs)
+        if sum(t.numel() for t in inputs.values()) > _CAPTURE_MAX_INPUT_ELEMENTS:
+            return self._eager(inputs)                        # a pass of this size is bound by its kernels, not by their dispatch
         key = tuple(sorted((name, tuple(t.shape), str(t.dtype)) for name, t in inputs.items()))
         entry = self._graphs.get(key, False)
         if entry:
@@ -402,7 +411,17 @@ class GraphRunner:
     # linear algebra
     def _op_MatMul(self, n, x, a, e):
         import torch
-        return torch.matmul(x[0], x[1])
+        w = x[1]
+        if (self.matmul == "pieces" and w.ndim == 2 and w.dtype == torch.float32 and x[0].dtype == torch.float32 and x[0].is_cuda
+                and min(w.shape) >= _PIECES_MIN_WIDTH and x[0].numel() // max(1, w.shape[0]) >= _PIECES_MIN_ROWS and x[0].ndim >= 2):
+            hit = self._weight_pieces.get(id(w))
+            if hit is None and any(w is c for c in self.constants.values()):
+                from .hip import ops
+                hit = self._weight_pieces[id(w)] = (w, ops.matmul_prepare(w, False))
+            if hit is not None and hit[0] is w:
+                from .hip import ops
+                return ops.matmul_pieces(x[0], hit[1])
+        return torch.matmul(x[0], w)
 
     def _op_Gemm(self, n, x, a, e):
         A = x[0].t() if a.get("transA", 0) else x[0]
@@ -904,6 +923,8 @@ class GraphRunner:
         return out
 
 
+_CAPTURE_MAX_INPUT_ELEMENTS = 1 << 20      # recording pays when a pass is hundreds of small launches (one short sequence), not above
+_PIECES_MIN_WIDTH, _PIECES_MIN_ROWS = 512, 256
 _SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
 _HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split",
                   "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}

@@ -745,6 +745,55 @@ def pack_nibbles(values: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ----------------------------------------------------------------------------- N1: the calibration walk's large products
+class MatmulOperand:
+    """One operand of `matmul_pieces` split into fp16 pieces on the device (`oq_matmul_prepare_f32`).  A constant weight is
+    prepared once and reused for every batch of the calibration walk."""
+
+    __slots__ = ("pieces", "kd", "cols")
+
+    def __init__(self, pieces, kd, cols):
+        self.pieces, self.kd, self.cols = pieces, kd, cols
+
+
+def _aligned_bytes(nbytes: int, device) -> torch.Tensor:
+    buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    off = (-buf.data_ptr()) % 256
+    return buf[off:off + nbytes]
+
+
+def matmul_prepare(t: torch.Tensor, contraction_is_fast_axis: bool) -> MatmulOperand:
+    """``t`` [cols, Kd] (activations: contraction on the fast axis) or [Kd, cols] (a weight) -> its fp16 pieces."""
+    _require_device(t, "operand", torch.float32)
+    if t.dim() != 2:
+        raise ValueError(f"matmul_prepare takes a matrix, got {tuple(t.shape)}")
+    t2, ld = _row_major(t)
+    cols, kd = (t2.shape[0], t2.shape[1]) if contraction_is_fast_axis else (t2.shape[1], t2.shape[0])
+    lib = L.load()
+    need = lib.oq_matmul_pieces_bytes(kd, cols)
+    if need == 0:
+        raise ValueError(f"matmul_prepare: an operand of {kd} x {cols} is too large for the piece kernels")
+    pieces = _aligned_bytes(need, t2.device)
+    L.check(lib.oq_matmul_prepare_f32(_ptr(t2), kd, cols, ld, 1 if contraction_is_fast_axis else 0, _ptr(pieces), need, _stream()))
+    return MatmulOperand(pieces, kd, cols)
+
+
+def matmul_pieces(x: torch.Tensor, w: MatmulOperand | torch.Tensor) -> torch.Tensor:
+    """``x`` [..., Kd] fp32 times a weight [Kd, N] (a tensor, or its `matmul_prepare(w, False)` pieces) on the fp16 matrix
+    cores with two-piece operands: 22 significand bits per operand, fp32 accumulate -- the arithmetic of the Hessian
+    kernels.  Returns [..., N] fp32."""
+    _require_device(x, "x", torch.float32)
+    if not isinstance(w, MatmulOperand):
+        w = matmul_prepare(w, False)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.shape[1] != w.kd:
+        raise ValueError(f"matmul_pieces: x has {x2.shape[1]} columns, the weight {w.kd} rows")
+    a = matmul_prepare(x2, True)
+    out = torch.empty((x2.shape[0], w.cols), dtype=torch.float32, device=x.device)
+    L.check(L.load().oq_matmul_pieces_f32(_ptr(a.pieces), _ptr(w.pieces), x2.shape[0], w.cols, w.kd, 1.0, 0.0, _ptr(out), w.cols, _stream()))
+    return out.reshape(*x.shape[:-1], w.cols)
+
+
 # ----------------------------------------------------------------------------- G1 - G4
 def hessian_accumulate(x: torch.Tensor, h: torch.Tensor, n_seen: int, method: str | None = None) -> int:
     """gptq.py:246-260, in place on ``h`` [K, K]; ``x`` [n_add, ..., K] fp32.  Returns the new sample

@@ -453,7 +453,8 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
     if data is None:
         data = generate_random_calibration_data(num_samples, inputs)
     # a model input that a target node reads directly is "produced" by the feed: the runner returns it like any other value
-    runner = GraphRunner(model, outputs=wanted, device=device, capture=True)      # batches of one shape replay a recorded pass
+    # batches of one (small) shape replay a recorded pass; large products with constant weights take the fp16-piece GEMM
+    runner = GraphRunner(model, outputs=wanted, device=device, capture=True, matmul="pieces")
     stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
                               hessian_names=in_names if (algo and not keep_inputs) else (),
                               keep_names=in_names if keep_inputs else ())

@@ -297,3 +297,31 @@ def test_recorded_calibration_passes_reproduce_the_eager_ones():
         a, b = e2(feed), r2(feed)
         assert all(torch.equal(a[k], b[k]) for k in wanted), i
     assert next(iter(r2._graphs.values())) is not None
+
+
+def test_large_products_of_the_calibration_walk_take_the_fp16_piece_gemm():
+    """`GraphRunner(matmul="pieces")` (what `_calibrate` uses): activations x a large constant weight through `ops.matmul_pieces`
+    -- 22-bit operands, fp32 accumulate -- at least as close to float64 as torch's fp32 GEMM; small products stay with torch."""
+    from onnx_quantize_amd.hip import ops
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(4, 96, 1024, generator=gen, device="cuda") * (torch.rand(1024, generator=gen, device="cuda") * 3)
+    w = torch.randn(1024, 768, generator=gen, device="cuda") / 32
+    ref = x.double() @ w.double()
+    err = lambda y: ((y.double() - ref).norm() / ref.norm()).item()      # noqa: E731
+    got = ops.matmul_pieces(x, w)
+    assert got.shape == (4, 96, 768) and err(got) < 2e-6 and err(got) <= 1.5 * err(x @ w)
+    ragged = ops.matmul_pieces(x[:, :37, :1000].contiguous(), w[:1000, :515].contiguous())          # nothing a multiple of a tile
+    ref2 = x[:, :37, :1000].double() @ w[:1000, :515].double()
+    assert ((ragged.double() - ref2).norm() / ref2.norm()).item() < 2e-6
+    # in the runner: one big MatMul (pieces) feeding one small (torch)
+    g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["b", "t", 1024])], output=[P.make_value_info("y", 1, None)],
+                  node=[P.make_node("MatMul", ["x", "w"], ["h"], name="big"), P.make_node("MatMul", ["h", "v"], ["y"], name="small")],
+                  initializer=[P.numpy_to_tensor("w", w.cpu().numpy()), P.numpy_to_tensor("v", (torch.randn(768, 16) / 28).numpy())])
+    model = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+    fast, plain = GraphRunner(model, outputs=["h", "y"], device="cuda", matmul="pieces"), GraphRunner(model, outputs=["h", "y"], device="cuda")
+    a, b = fast(x), plain(x)
+    assert len(fast._weight_pieces) == 1 and not plain._weight_pieces
+    assert err(a["h"]) < 2e-6 and not torch.equal(a["h"], b["h"])
+    torch.testing.assert_close(a["y"], b["y"], rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError, match="matmul must be"):
+        GraphRunner(model, device="cuda", matmul="fast")
