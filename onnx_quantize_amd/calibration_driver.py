@@ -269,7 +269,15 @@ def run_calibration(runner: Callable, calibration_data, stream: ActivationStream
     n_batches = len(next(iter(batched.values())))
     for i in range(n_batches):
         feed = {name: data[i].cuda(non_blocking=True) for name, data in batched.items()}
-        stream.feed(runner(next(iter(feed.values())) if bare else feed))
+        arg = next(iter(feed.values())) if bare else feed
+        if getattr(runner, "takes_sink", False):
+            # a runner that can hand each tapped value over as it is produced (GraphRunner): consumed one by one, the tapped
+            # activations of a batch never coexist in HBM
+            left = runner(arg, sink=lambda name, t: stream.feed({name: t}))
+            if left:
+                stream.feed(left)
+        else:
+            stream.feed(runner(arg))
     return stream
 
 

@@ -49,6 +49,8 @@ class GraphRunner:
     model: a parsed ModelProto (`onnx_proto.parse_model`); outputs: the value names wanted (default: the graph's own
     outputs); feed: one tensor / array (single-input model) or {input name: tensor / array}."""
 
+    takes_sink = True        # `runner(feed, sink=...)` hands every wanted value over as it is produced (calibration_driver.run_calibration)
+
     def __init__(self, model: Message, outputs=None, device="cuda", capture: bool = False, matmul: str = "torch"):
         import torch
 
@@ -148,7 +150,11 @@ class GraphRunner:
         return [n for n in nodes if id(n) in need]       # the file's order is a topological order (ONNX requires it)
 
     # ------------------------------------------------------------------------------------------------- one pass
-    def __call__(self, feed) -> dict:
+    def __call__(self, feed, sink=None) -> dict:
+        """One pass.  Without `sink` the wanted values come back as a dict.  With `sink(name, tensor)` every wanted value is handed
+        over the moment it exists and is not held any longer than the graph itself needs it (a 7B-width walk taps ~50 GB of
+        activations per batch; consumed one by one they never coexist); the dict returned is then empty.  Recorded passes (small
+        inputs) always produce the dict and hand it to the sink afterwards."""
         import torch
 
         if not isinstance(feed, Mapping):
@@ -162,10 +168,16 @@ class GraphRunner:
         for name, v in feed.items():
             t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, order="C"))
             inputs[name] = t.to(self.device, non_blocking=True)
-        if not self.capture:
-            return self._eager(inputs)
-        if sum(t.numel() for t in inputs.values()) > _CAPTURE_MAX_INPUT_ELEMENTS:
-            return self._eager(inputs)                        # a pass of this size is bound by its kernels, not by their dispatch
+        if not self.capture or sum(t.numel() for t in inputs.values()) > _CAPTURE_MAX_INPUT_ELEMENTS:
+            return self._eager(inputs, sink)                  # (a large pass is bound by its kernels, not by their dispatch)
+        out = self._recorded(inputs)
+        if sink is None:
+            return out
+        for name, t in out.items():
+            sink(name, t)
+        return {}
+
+    def _recorded(self, inputs) -> dict:
         key = tuple(sorted((name, tuple(t.shape), str(t.dtype)) for name, t in inputs.items()))
         entry = self._graphs.get(key, False)
         if entry:
@@ -179,13 +191,21 @@ class GraphRunner:
             return self._eager(inputs)
         return self._record(key, inputs)
 
-    def _eager(self, inputs) -> dict:
+    def _eager(self, inputs, sink=None) -> dict:
         import torch
         env = dict(self.constants)
         env.update(inputs)
+        if sink is None:
+            with torch.no_grad():
+                self._run(self.nodes, env, set(self.wanted), self.last_use)
+            return {name: env[name] for name in self.wanted}
+        pending = set(self.wanted)
+        for name in [w for w in self.wanted if w in env]:      # model inputs / constants that are themselves wanted
+            sink(name, env[name])
+            pending.discard(name)
         with torch.no_grad():
-            self._run(self.nodes, env, set(self.wanted), self.last_use)
-        return {name: env[name] for name in self.wanted}
+            self._run(self.nodes, env, (), self.last_use, sink=sink, pending=pending)
+        return {}
 
     def _record(self, key, inputs) -> dict:
         """Record one pass into a HIP graph, check one replay of it against the eager pass on the same inputs, keep it only
@@ -213,13 +233,17 @@ class GraphRunner:
             self._graphs[key] = (graph, static_in, static_out)
         return eager
 
-    def _run(self, nodes, env, keep=(), last_use=None):
+    def _run(self, nodes, env, keep=(), last_use=None, sink=None, pending=()):
         for i, node in enumerate(nodes):
             ins = [env[n] if n else None for n in node.input]
             outs = self._dispatch(node, ins, env)
             for name, value in zip(node.output, outs):
                 if name:
                     env[name] = value
+                    if name in pending:                       # consumed now; it lives on only as long as later nodes read it
+                        sink(name, value)
+                        if last_use is not None and name not in last_use:
+                            del env[name]
             if last_use is not None:
                 for name in node.input:
                     if name and last_use.get(name) == i and name not in keep and name not in self.constants:

@@ -72,10 +72,11 @@ def as_model(model) -> Message:
 
 # ------------------------------------------------------------------------------------------------------------ graph helpers
 class _Const:
-    """What the emission code reads of a constant value: `.name`, `.const_value.numpy()`."""
+    """What the emission code reads of a constant value: `.name`, `.const_value.numpy()`; `device_value`: the same weight in
+    HBM when the calibration walk left it there (the seam then skips its upload)."""
 
-    def __init__(self, name, array):
-        self.name, self._a = name, array
+    def __init__(self, name, array, device_value=None):
+        self.name, self._a, self.device_value = name, array, device_value
         self.const_value = self
 
     def numpy(self):
@@ -88,6 +89,7 @@ class _Graph:
     def __init__(self, graph: Message):
         self.g = graph
         self.inits = {t.name: t for t in graph.initializer}
+        self.device_values: dict = {}                     # initializer name -> the tensor the calibration walk uploaded (read-only)
         self.graph_inputs = {i.name for i in graph.input}
         self.graph_outputs = {o.name for o in graph.output}
 
@@ -100,6 +102,7 @@ class _Graph:
 
     def set_tensor(self, t):
         name = t.name
+        self.device_values.pop(name, None)                # the copy in HBM, if any, is of the old contents
         if name in self.inits:
             old = self.inits[name]
             self.g.initializer[[id(x) for x in self.g.initializer].index(id(old))] = t
@@ -459,6 +462,7 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
                               hessian_names=in_names if (algo and not keep_inputs) else (),
                               keep_names=in_names if keep_inputs else ())
     run_calibration(runner, data, stream, num_samples=num_samples, batch_size=batch_size, input_names=[i[0] for i in inputs])
+    G.device_values = {name: t for name, t in runner.constants.items() if t.is_cuda and t.ndim == 2}
     meta: dict = {id(n): {} for n in targets}
     for kind, on, names, aargs in (("input", cal_in, in_names, qconfig.input_activations),
                                    ("output", cal_out, out_names, qconfig.output_activations)):
@@ -724,7 +728,7 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
 def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bias):
     G = prepared.graph
     has_bias = len(node.input) > 2
-    w = _Const(node.input[1], G.array(node.input[1]))
+    w = _Const(node.input[1], G.array(node.input[1]), G.device_values.get(node.input[1]))
     b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
     node_meta = prepared.meta.get(id(node), {})
     return plan_node(node.op_type, node.input[0], w, node.output[0], prepared.per_node.get(id(node), qconfig), node_meta, bias=b,
@@ -734,6 +738,15 @@ def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bi
 def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) -> Message:
     """quantize.py:60-78: the rules' rewrites node by node, the functions, the opset imports, the post passes."""
     model, G, targets = prepared.model, prepared.graph, prepared.targets
+
+    algorithm = qconfig.weights.algorithm
+    if getattr(algorithm, "algorithm_type", None) == "gptq" and isinstance(weight_arrays, _PackedSeam):
+        from .reference_passes import StreamedGptqInput
+        from .seam import prefactor_streamed
+
+        streamed = [m["input"] for m in prepared.meta.values() if isinstance(m.get("input"), StreamedGptqInput)]
+        if streamed:                                          # all inverse factors of the model in batched chains, ahead of the nodes
+            prefactor_streamed(streamed, float(algorithm.percdamp), bool(algorithm.actorder))
 
     used_functions: dict = {}
     domains = set()

@@ -81,10 +81,11 @@ class StreamedGptqInput:
     the sample count, both already on the device.  Nodes that read the same value share ONE object, as they share one
     array in the reference (calibrate.py:301-307); the seam factors it once (`seam._hessian_and_factor`)."""
 
-    __slots__ = ("name", "h", "n", "shape")
+    __slots__ = ("name", "h", "n", "shape", "factors")
 
     def __init__(self, name, h, n, shape):
         self.name, self.h, self.n, self.shape = name, h, int(n), tuple(shape)
+        self.factors = {}        # (percdamp, actorder, Hessian method, device) -> what `_gptq` derives from H alone (seam.prefactor_streamed)
 
     def __repr__(self):  # pragma: no cover
         return f"StreamedGptqInput({self.name!r}, K={self.h.shape[0]}, n={self.n})"

@@ -258,6 +258,12 @@ def test_graph_runner_matches_the_exported_torch_modules():
     m = fixture("block")
     r = GraphRunner(m, outputs=["/ln1/LayerNormalization_output_0", "x"], device="cpu")
     assert len(r.nodes) == 1 and set(r(cases[2][2])) == {"/ln1/LayerNormalization_output_0", "x"}
+    # a sink gets every wanted value the moment it exists (same tensors as the dictionary form), nothing is returned
+    taps = ["x", "/ln1/LayerNormalization_output_0", "/up/MatMul_output_0", "y"]
+    whole = GraphRunner(m, outputs=taps, device="cpu")(cases[2][2])
+    seen = {}
+    assert GraphRunner(m, outputs=taps, device="cpu")(cases[2][2], sink=lambda name, t: seen.__setitem__(name, t.clone())) == {}
+    assert list(seen) == ["x", "/ln1/LayerNormalization_output_0", "/up/MatMul_output_0", "y"] and all(torch.equal(seen[k], whole[k]) for k in taps)
     with pytest.raises(KeyError, match="no value named"):
         GraphRunner(m, outputs=["nope"], device="cpu")
     bad = m.copy()
