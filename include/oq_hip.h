@@ -445,6 +445,23 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
                                size_t workspace_bytes, void* stream);
 /* N2  pre_passes/smooth_quant.py:62-74, 104-113: scale_out[k] = max(max_t |x[t,k]|, 1e-5)^alpha /
  *     (max_n |w[k,n]| + 1e-9)^(1 - alpha). */
+/* N2 from streamed statistics: a calibration walk that consumes its batches as they come does not hold X.  The searches need
+ *     of it only  act_sum [K] = sum_t |x[t, k]|  (oq_abs_sum_cols_f32, a running sum over batches; awq.py:47-50 divides by T)  and
+ *     G [K, K] = (2 / T) X^T X  (oq_hessian_accumulate_f32 with n counting ROWS) -- the loss is <D, G D> / (2 N), the form long
+ *     calibration sets take anyway.  Same outputs as the searches above.  The in-place rescale of the reference
+ *     (`node.meta["input"] /= scale`, awq.py:191) becomes act_sum / scale and G / (scale scale^T) on the caller's side. */
+size_t oq_awq_stats_workspace_bytes(int64_t K, int64_t N);
+int32_t oq_awq_scale_search_stats_f32(const float* act_sum, const float* G, int64_t T, int64_t K, const float* W, int64_t N, int64_t ldw,
+                                      int32_t qtype, int32_t strategy, int64_t group_size, int32_t symmetric, int32_t reduce_range,
+                                      int32_t n_grid, float* scales_out, float* losses_out, int32_t* best_out, void* workspace,
+                                      size_t workspace_bytes, void* stream);
+int32_t oq_awq_clip_search_stats_f32(const float* G, int64_t T, int64_t K, const float* W, int64_t N, int64_t ldw, int32_t qtype,
+                                     int32_t strategy, int64_t group_size, int32_t symmetric, int32_t reduce_range, float* losses_out,
+                                     int32_t* best_out, void* workspace, size_t workspace_bytes, void* stream);
+size_t oq_abs_sum_cols_workspace_bytes(int64_t K);
+int32_t oq_abs_sum_cols_f32(const float* X, int64_t T, int64_t K, int64_t ldx, float* sum_inout, int32_t accumulate, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 size_t oq_smooth_quant_workspace_bytes(int64_t K);
 int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N,
                                   int64_t ldw, float alpha, float* scale_out, void* workspace,

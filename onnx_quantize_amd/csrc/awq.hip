@@ -53,6 +53,14 @@ __global__ __launch_bounds__(256) void col_abs_finish_kernel(const float* __rest
     out[k] = MAX ? acc : acc * inv_count;
 }
 
+__global__ __launch_bounds__(256) void col_abs_accumulate_kernel(const float* __restrict__ partial, int chunks, int64_t K, int accumulate, float* __restrict__ out) {
+    const int64_t k = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += partial[static_cast<int64_t>(c) * K + k];
+    out[k] = accumulate ? out[k] + acc : acc;
+}
+
 // ---- awq.py:52-72: |w| / absmax of its quantization group, mean over the output channels -> ws[k].
 // gmax[kg][n] = absmax over rows [kg g, kg g + g) of column n (g = K: one row of maxima per column).
 __global__ __launch_bounds__(256) void group_absmax_kernel(const float* __restrict__ W, int64_t K, int64_t N, int64_t ldw, int64_t g, float* __restrict__ gmax) {
@@ -770,6 +778,113 @@ int32_t oq_awq_clip_search_f32(const float* X, int64_t T, int64_t K, int64_t ldx
     if (st != OQ_OK) return st;
     hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, 10, best_out);
     return check_launch("argmin_first_kernel");
+}
+
+// ---- the searches from STREAMED statistics (next row N1 x N2): a calibration walk that consumes its batches as they come cannot
+// hand X over, and does not have to -- the loss is <D, G D> with G = (2 / T) X^T X (the Gram route above, which long calibration sets
+// take anyway) and the candidate scales need mean |x| per input channel only.  Both are running sums over batches.
+static int64_t stats_rows(int64_t K) { return kAwqGramRatio * K; }   // a row count that selects the Gram layout of the workspace
+
+size_t oq_awq_stats_workspace_bytes(int64_t K, int64_t N) {
+    if (!oq::matrix_ok(K, N, N) || K > 65535 || !oq::extent_ok(stats_rows(K))) return 0;
+    return awq_workspace(stats_rows(K), K, N, nullptr, nullptr);
+}
+
+// act_sum[k] = sum over all T calibration rows of |x[t, k]|; G [K, K] = (2 / T) X^T X (oq_hessian_accumulate_f32 with n counting rows)
+static int32_t stats_begin(const float* act_sum, const float* G, int64_t T, int64_t K, const float* W, int64_t N, int64_t ldw, int32_t qtype,
+                           int32_t strategy, int64_t group_size, int64_t* g, void* workspace, size_t workspace_bytes, AwqWs* w, hipStream_t s,
+                           const char* who) {
+    OQ_REQUIRE(G && W && T > 0 && count_ok(T, kMaxSamples) && matrix_ok(K, K, K) && matrix_ok(K, N, ldw), OQ_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
+    OQ_REQUIRE(qtype == OQ_INT4 || qtype == OQ_UINT4 || qtype == OQ_INT8 || qtype == OQ_UINT8, OQ_ERR_UNSUPPORTED, "awq: 4- and 8-bit types only");
+    OQ_REQUIRE(strategy == OQ_TENSOR || strategy == OQ_CHANNEL || strategy == OQ_GROUP, OQ_ERR_INVALID_ARGUMENT, "awq: unknown strategy %d", strategy);
+    *g = K;
+    if (strategy == OQ_GROUP) {
+        int64_t gs = group_size > K ? K : group_size;
+        if (gs == -1) gs = K;
+        OQ_REQUIRE(gs >= kAwqMinGroup && K % gs == 0, OQ_ERR_UNSUPPORTED, "awq: group_size must divide K and be >= %d (got %lld for K = %lld)", kAwqMinGroup,
+                   (long long)group_size, (long long)K);
+        *g = gs;
+    }
+    OQ_REQUIRE(ceil_div(K, 8) <= 65535 && K <= 65535 && ceil_div(K, *g) <= 65535, OQ_ERR_UNSUPPORTED, "awq: K too large");
+    const size_t need = oq_awq_stats_workspace_bytes(K, N);
+    OQ_REQUIRE(need != 0 && workspace && workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0, OQ_ERR_WORKSPACE,
+               "%s: 256-byte aligned workspace of %zu bytes needed, %zu given", who, need, workspace_bytes);
+    awq_workspace(stats_rows(K), K, N, w, static_cast<char*>(workspace));
+    OQ_REQUIRE(w->gram, OQ_ERR_LAUNCH, "%s: the Gram layout was not selected", who);
+    OQ_REQUIRE(hipMemcpyAsync(w->G, G, static_cast<size_t>(K) * K * 4, hipMemcpyDeviceToDevice, s) == hipSuccess, OQ_ERR_LAUNCH, "%s: copy of G failed", who);
+    if (act_sum != nullptr)   // awq.py:47-50: mean |x| per input channel
+        hipLaunchKernelGGL(col_abs_finish_kernel<false>, dim3(static_cast<uint32_t>(ceil_div(K, 256))), dim3(256), 0, s, act_sum, 1, K,
+                           static_cast<float>(1.0 / static_cast<double>(T)), w->act);
+    return make_f16x2_pieces(w->G, K, K, K, false, w->pieces_g, s);
+}
+
+int32_t oq_awq_scale_search_stats_f32(const float* act_sum, const float* G, int64_t T, int64_t K, const float* W, int64_t N, int64_t ldw, int32_t qtype,
+                                      int32_t strategy, int64_t group_size, int32_t symmetric, int32_t reduce_range, int32_t n_grid, float* scales_out,
+                                      float* losses_out, int32_t* best_out, void* workspace, size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(act_sum && scales_out && losses_out && best_out && n_grid >= 1 && n_grid <= kAwqMaxGrid, OQ_ERR_INVALID_ARGUMENT,
+               "oq_awq_scale_search_stats_f32: bad argument");
+    hipStream_t s = as_stream(stream);
+    AwqWs w;
+    int64_t g;
+    int32_t st = stats_begin(act_sum, G, T, K, W, N, ldw, qtype, strategy, group_size, &g, workspace, workspace_bytes, &w, s, "oq_awq_scale_search_stats_f32");
+    if (st != OQ_OK) return st;
+    const int64_t Tg = stats_rows(K), kgroups = K / g;
+    hipLaunchKernelGGL(group_absmax_kernel, dim3(static_cast<uint32_t>(ceil_div(N, 256)), static_cast<uint32_t>(kgroups)), dim3(256), 0, s, W, K, N, ldw, g, w.gmax);
+    if (strategy == OQ_TENSOR) hipLaunchKernelGGL(fold_to_scalar_kernel, dim3(1), dim3(1024), 0, s, w.gmax, N);
+    hipLaunchKernelGGL(weight_scale_rows_kernel, dim3(static_cast<uint32_t>(K)), dim3(256), 0, s, W, K, N, ldw, g, w.gmax, w.wsc);
+    hipLaunchKernelGGL(grid_scales_kernel, dim3(static_cast<uint32_t>(n_grid)), dim3(1024), 0, s, w.act, w.wsc, K, n_grid, scales_out);
+    st = check_launch("awq statistics");
+    if (st != OQ_OK) return st;
+    for (int i = 0; i < n_grid; ++i) {
+        st = candidate_loss(w, W, ldw, scales_out + static_cast<int64_t>(i) * K, Tg, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, 1.0f, i, s);
+        if (st != OQ_OK) return st;
+    }
+    st = finish_losses(w.gemm_part, n_grid, Tg, K, N, losses_out, s);
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, n_grid, best_out);
+    return check_launch("argmin_first_kernel");
+}
+
+int32_t oq_awq_clip_search_stats_f32(const float* G, int64_t T, int64_t K, const float* W, int64_t N, int64_t ldw, int32_t qtype, int32_t strategy,
+                                     int64_t group_size, int32_t symmetric, int32_t reduce_range, float* losses_out, int32_t* best_out, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(losses_out && best_out, OQ_ERR_INVALID_ARGUMENT, "oq_awq_clip_search_stats_f32: bad argument");
+    hipStream_t s = as_stream(stream);
+    AwqWs w;
+    int64_t g;
+    int32_t st = stats_begin(nullptr, G, T, K, W, N, ldw, qtype, strategy, group_size, &g, workspace, workspace_bytes, &w, s, "oq_awq_clip_search_stats_f32");
+    if (st != OQ_OK) return st;
+    const int64_t Tg = stats_rows(K);
+    for (int i = 0; i < 10; ++i) {
+        const float ratio = static_cast<float>(1.0 - static_cast<double>(i) / 100.0);   // awq.py:227
+        st = candidate_loss(w, W, ldw, nullptr, Tg, K, N, qtype, strategy, group_size, g, symmetric, reduce_range, ratio, i, s);
+        if (st != OQ_OK) return st;
+    }
+    st = finish_losses(w.gemm_part, 10, Tg, K, N, losses_out, s);
+    if (st != OQ_OK) return st;
+    hipLaunchKernelGGL(argmin_first_kernel, dim3(1), dim3(64), 0, s, losses_out, 10, best_out);
+    return check_launch("argmin_first_kernel");
+}
+
+// sum over the T rows of |x[t, k]| added to `sum_inout` [K] (a running statistic over calibration batches; awq.py:47-50 divides by T)
+size_t oq_abs_sum_cols_workspace_bytes(int64_t K) {
+    if (!oq::extent_ok(K)) return 0;
+    return oq::align256(static_cast<size_t>(oq::kColChunks) * K * 4) + 512;
+}
+
+int32_t oq_abs_sum_cols_f32(const float* X, int64_t T, int64_t K, int64_t ldx, float* sum_inout, int32_t accumulate, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    OQ_REQUIRE(X && sum_inout && matrix_ok(T, K, ldx), OQ_ERR_INVALID_ARGUMENT, "oq_abs_sum_cols_f32: bad argument");
+    const size_t need = oq_abs_sum_cols_workspace_bytes(K);
+    OQ_REQUIRE(workspace && workspace_bytes >= need, OQ_ERR_WORKSPACE, "oq_abs_sum_cols_f32: workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    hipStream_t s = as_stream(stream);
+    char* base = static_cast<char*>(workspace);
+    base += (256 - reinterpret_cast<uintptr_t>(base) % 256) % 256;
+    float* colpart = reinterpret_cast<float*>(base);
+    const dim3 cgrid(static_cast<uint32_t>(ceil_div(K, 256)), static_cast<uint32_t>(T < kColChunks ? T : kColChunks));
+    hipLaunchKernelGGL(col_abs_partial_kernel<false>, cgrid, dim3(256), 0, s, X, T, K, ldx, colpart);
+    hipLaunchKernelGGL(col_abs_accumulate_kernel, dim3(cgrid.x), dim3(256), 0, s, colpart, static_cast<int>(cgrid.y), K, accumulate, sum_inout);
+    return check_launch("col_abs_accumulate_kernel");
 }
 
 int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N, int64_t ldw, float alpha, float* scale_out,

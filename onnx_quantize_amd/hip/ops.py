@@ -696,6 +696,88 @@ def awq_clip_search(x: torch.Tensor, w: torch.Tensor, qtype: str, strategy: str,
     return 1 - int(best.item()) / 100, losses.double().cpu().numpy()
 
 
+class SearchStatistics:
+    """What the AWQ / SmoothQuant searches need of a calibration input, as running statistics over its batches (no batch is
+    held): `gram` = (2 / rows) X^T X (the Hessian update rule of gptq.py:246-260 with n counting ROWS), `abs_sum[k]` = sum_t |x[t, k]|
+    (awq.py:47-50 divides by the rows), `absmax[k]` = max_t |x[t, k]| (smooth_quant.py:62-69), `rows`.  `divide(scale)` is the
+    reference's in-place rescale of the stored input (`node.meta["input"] /= scale`, awq.py:191 / smooth_quant.py:121) in these
+    terms: the next consumer of the same value searches on what the previous one left."""
+
+    def __init__(self, k: int, device):
+        self.gram = torch.zeros((k, k), dtype=torch.float32, device=device)
+        self.abs_sum = torch.zeros(k, dtype=torch.float32, device=device)
+        self.absmax = torch.zeros(k, dtype=torch.float32, device=device)
+        self.rows = 0
+
+    def add(self, x: torch.Tensor) -> None:
+        x2 = _flat_inputs(x if x.dtype == torch.float32 else x.to(torch.float32))
+        x2, ldx = _row_major(x2)
+        t, k = x2.shape
+        lib = L.load()
+        ws = _workspace(lib.oq_abs_sum_cols_workspace_bytes(k), x2.device)
+        L.check(lib.oq_abs_sum_cols_f32(_ptr(x2), t, k, ldx, _ptr(self.abs_sum), 1, _ptr(ws), ws.numel(), _stream()))
+        self.absmax = torch.maximum(self.absmax, absmax(x2))
+        self.rows = hessian_accumulate(x2, self.gram, self.rows)            # rows as samples: gram = (2 / rows) X^T X
+
+    def divide(self, scale: torch.Tensor) -> None:
+        s = scale.to(self.gram.device, torch.float32).reshape(-1)
+        self.abs_sum /= s
+        self.absmax /= s
+        self.gram /= s.reshape(-1, 1)
+        self.gram /= s.reshape(1, -1)
+
+
+def _stats_args(stats: "SearchStatistics", w, qtype, group_size):
+    _require_device(w, "w", torch.float32)
+    k = stats.gram.shape[0]
+    if w.dim() != 2 or w.shape[0] != k:
+        raise ValueError(f"weights must be [K, N] with K = {k}, got {tuple(w.shape)}")
+    if stats.rows <= 0:
+        raise ValueError("the statistics hold no calibration rows")
+    if BITS[qtype] > 8:
+        raise NotImplementedError("the AWQ searches take 4- and 8-bit types")
+    w2, ldw = _row_major(w)
+    return w2, ldw, k, w2.shape[1], (-1 if group_size is None else int(group_size))
+
+
+def awq_scale_search_stats(stats: "SearchStatistics", w: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
+                           reduce_range=False, n_grid: int = 20):
+    """`awq_scale_search` from running statistics (oq_awq_scale_search_stats_f32): (best_scale [K] on device, losses[n_grid])."""
+    w2, ldw, k, n, gs = _stats_args(stats, w, qtype, group_size)
+    lib = L.load()
+    dev = w2.device
+    scales = torch.empty((n_grid, k), dtype=torch.float32, device=dev)
+    losses = torch.empty(n_grid, dtype=torch.float32, device=dev)
+    best = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.oq_awq_stats_workspace_bytes(k, n) + 256, dev)
+    off = (-ws.data_ptr()) % 256
+    L.check(lib.oq_awq_scale_search_stats_f32(_ptr(stats.abs_sum), _ptr(stats.gram), stats.rows, k, _ptr(w2), n, ldw, L.QTYPE_CODE[qtype],
+                                              L.STRATEGY_CODE[strategy], gs, int(symmetric), int(reduce_range), int(n_grid), _ptr(scales),
+                                              _ptr(losses), _ptr(best), C.c_void_p(ws.data_ptr() + off), ws.numel() - off, _stream()))
+    return scales[int(best.item())], losses.double().cpu().numpy()
+
+
+def awq_clip_search_stats(stats: "SearchStatistics", w: torch.Tensor, qtype: str, strategy: str, group_size, symmetric=False,
+                          reduce_range=False):
+    """`awq_clip_search` from running statistics (oq_awq_clip_search_stats_f32): (best clip_ratio, losses[10])."""
+    w2, ldw, k, n, gs = _stats_args(stats, w, qtype, group_size)
+    lib = L.load()
+    dev = w2.device
+    losses = torch.empty(10, dtype=torch.float32, device=dev)
+    best = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _workspace(lib.oq_awq_stats_workspace_bytes(k, n) + 256, dev)
+    off = (-ws.data_ptr()) % 256
+    L.check(lib.oq_awq_clip_search_stats_f32(_ptr(stats.gram), stats.rows, k, _ptr(w2), n, ldw, L.QTYPE_CODE[qtype], L.STRATEGY_CODE[strategy],
+                                             gs, int(symmetric), int(reduce_range), _ptr(losses), _ptr(best), C.c_void_p(ws.data_ptr() + off),
+                                             ws.numel() - off, _stream()))
+    return 1 - int(best.item()) / 100, losses.double().cpu().numpy()
+
+
+def smooth_quant_scale_stats(stats: "SearchStatistics", w: torch.Tensor, alpha: float) -> torch.Tensor:
+    """`smooth_quant_scale` from the running per-channel absmax: the kernel's column absmax of a one-row matrix is that row."""
+    return smooth_quant_scale(stats.absmax.reshape(1, -1), w, alpha)
+
+
 def smooth_quant_scale(x: torch.Tensor, w: torch.Tensor, alpha: float) -> torch.Tensor:
     """pre_passes/smooth_quant.py:62-74, :111-113 (oq_smooth_quant_scale_f32): the smoothing scale [K] on the device."""
     x2, ldx = _row_major(_flat_inputs(x))

@@ -166,3 +166,40 @@ def test_gpu_searches_against_the_reference_passes_outputs():
             assert r == c["clip_ratio"]
         for alpha in (0.5, 0.8):
             np.testing.assert_allclose(1.0 / smooth_quant_scale(x, w, alpha), G[key + f"_sq{int(alpha * 10)}_inv_scale"], rtol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qtype,strategy,g,sym", [("uint4", "group", 32, False), ("int8", "channel", -1, True), ("uint8", "tensor", -1, False),
+                                                  ("int4", "group", 128, False), ("int8", "group", 8, False)])
+def test_gpu_searches_from_streamed_statistics_follow_the_oracle(qtype, strategy, g, sym):
+    """`ops.SearchStatistics` (running Gram matrix, |x| sums and maxima over batches) in place of the activations themselves:
+    the losses are the oracle's on the concatenated batches, the SmoothQuant scale is the array route's, and `divide(scale)` is
+    the reference's in-place rescale of the stored input (awq.py:191)."""
+    import torch
+
+    from onnx_quantize_amd.hip import ops
+    x, w = _inputs(5, 768, 256, 192)
+    xd, wd = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    stats = ops.SearchStatistics(256, "cuda")
+    for part in (xd[:1], xd[1:3], xd[3:]):                                  # three uneven batches
+        stats.add(part)
+    assert stats.rows == 768
+    es, el = O.awq_scale_search(x, w, qtype, strategy, g, sym)
+    s, l = ops.awq_scale_search_stats(stats, wd, qtype, strategy, g, sym)
+    np.testing.assert_allclose(l, el, rtol=2e-3)
+    assert el[int(np.argmin(l))] <= el.min() * (1 + 2e-3)
+    if int(np.argmin(l)) == int(np.argmin(el)):
+        np.testing.assert_allclose(s.cpu().numpy(), es, rtol=2e-5)
+    er, ecl = O.awq_clip_search(x, w, qtype, strategy, g, sym)
+    r, cl = ops.awq_clip_search_stats(stats, wd, qtype, strategy, g, sym)
+    np.testing.assert_allclose(cl, ecl, rtol=2e-3)
+    assert ecl[int(round((1 - r) * 100))] <= ecl.min() * (1 + 2e-3)
+    assert torch.equal(ops.smooth_quant_scale_stats(stats, wd, 0.5), ops.smooth_quant_scale(xd, wd, 0.5))
+    # the in-place rescale: statistics of x / scale
+    scale = torch.rand(256, device="cuda") + 0.5
+    scaled = ops.SearchStatistics(256, "cuda")
+    scaled.add(xd / scale)
+    stats.divide(scale)
+    torch.testing.assert_close(stats.abs_sum, scaled.abs_sum, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(stats.absmax, scaled.absmax, rtol=1e-6, atol=0)
+    torch.testing.assert_close(stats.gram, scaled.gram, rtol=2e-4, atol=2e-5 * float(scaled.gram.abs().max()))
