@@ -21,7 +21,7 @@ import time
 import numpy as np
 import torch
 
-from onnx_quantize_amd import GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
+from onnx_quantize_amd import AwqConfig, GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
 from onnx_quantize_amd import onnx_proto as P
 from onnx_quantize_amd.model_quantize import quantize_model
 
@@ -69,6 +69,8 @@ def configs(name, data):
         "int4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=128)),
         "static_int8": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=act("int8"), output_activations=act("int8"),
                                        calibration_data=data, calibration_params=cal),
+        "awq_uint4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=128), preprocessors=[AwqConfig()],
+                                          calibration_data=data, calibration_params=cal),
         "gptq_int4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=128, algorithm=GPTQConfig(mode="corrected")),
                                           calibration_data=data, calibration_params=cal),
     }[name]()

@@ -91,11 +91,15 @@ class ActivationStream:
 
     def __init__(self, *, calibrator=None, input_names: Iterable[str] = (), output_names: Iterable[str] = (),
                  hessian_names: Iterable[str] = (), absmax_names: Iterable[str] = (), keep_names: Iterable[str] = (),
-                 hessian_streams: int = 0):
+                 hessian_streams: int = 0, statistics_names: Iterable[str] = ()):
         self.calibrator = calibrator if calibrator is not None else MinMaxCalibrator()
         self.input_names, self.output_names = list(dict.fromkeys(input_names)), list(dict.fromkeys(output_names))
         self.hessian_names, self.absmax_names = set(hessian_names), set(absmax_names)
         self.keep_names = set(keep_names)
+        # statistics_names: what the AWQ / SmoothQuant searches need of a value, as running statistics (`ops.SearchStatistics`:
+        # Gram matrix, |x| sums and maxima) instead of the activations themselves -- `keep_names` without the memory
+        self.statistics_names = set(statistics_names)
+        self.statistics: dict = {}
         self.hessians: dict[str, HessianAccumulator] = {}
         # 0 (default): the Hessian updates of a batch in one grouped launch chain (per-tensor calls on 4 side streams when a
         # Hessian method the grouped chain does not run is selected); n > 0: per-tensor calls on n side streams
@@ -171,6 +175,11 @@ class ActivationStream:
             x = activations[name]
             cur = ops.absmax(x if x.dtype == torch.float32 else x.to(torch.float32))
             self.absmax[name] = cur if name not in self.absmax else torch.maximum(self.absmax[name], cur)
+        for name in self.statistics_names & activations.keys():
+            x = activations[name]
+            if name not in self.statistics:
+                self.statistics[name] = ops.SearchStatistics(x.shape[-1], x.device)
+            self.statistics[name].add(x)
         for name in self.keep_names & activations.keys():
             self._kept.setdefault(name, []).append(activations[name])
         self.batches += 1

@@ -433,8 +433,9 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
     {id(node): meta} with `input_scale` / `input_zero_point` / `output_scale` / `output_zero_point` (0-d arrays) and `input`:
     a `StreamedGptqInput` (the Hessian of the node's input) when only the weight algorithm needs the activations, or -- with
     `keep_inputs`, ahead of AWQ / SmoothQuant, which read and rescale the activations themselves -- the batches concatenated in
-    HBM (calibrate.py:296-307).  Nodes that read the same value share ONE object either way, as they share one array in the
-    reference."""
+    HBM (calibrate.py:296-307), or, with `keep_inputs="statistics"` (the default of the device searches), what those searches
+    need of them as running statistics (`ops.SearchStatistics`: Gram matrix, |x| sums and maxima; no batch is held).  Nodes that
+    read the same value share ONE object either way, as they share one array in the reference."""
     from .calibration import get_calibrator
     from .calibration_driver import ActivationStream, generate_random_calibration_data, run_calibration
     from .graph_runner import GraphRunner
@@ -460,7 +461,8 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
     runner = GraphRunner(model, outputs=wanted, device=device, capture=True, matmul="pieces")
     stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
                               hessian_names=in_names if (algo and not keep_inputs) else (),
-                              keep_names=in_names if keep_inputs else ())
+                              keep_names=in_names if keep_inputs is True else (),
+                              statistics_names=in_names if keep_inputs == "statistics" else ())
     run_calibration(runner, data, stream, num_samples=num_samples, batch_size=batch_size, input_names=[i[0] for i in inputs])
     G.device_values = {name: t for name, t in runner.constants.items() if t.is_cuda and t.ndim == 2}
     meta: dict = {id(n): {} for n in targets}
@@ -474,7 +476,11 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
                 scale, zp = qparams[name]
                 meta[id(n)][f"{kind}_scale"] = np.asarray(scale).astype(aargs.scale_dtype, copy=False)
                 meta[id(n)][f"{kind}_zero_point"] = np.asarray(zp).astype(aargs.zp_dtype, copy=False)
-    if keep_inputs:
+    if keep_inputs == "statistics":
+        for n, name in zip(targets, in_names):
+            if name in stream.statistics:
+                meta[id(n)]["input"] = stream.statistics[name]      # one object per value name: shared by its consumers
+    elif keep_inputs:
         kept: dict = {}
         for n, name in zip(targets, in_names):
             if name not in kept:
@@ -511,20 +517,25 @@ class DeviceSearches:
     def _args(a):
         return a.dtype.key, a.strategy.value, a.group_size, bool(a.symmetric), bool(a.reduce_range)
 
+    wants = "statistics"     # what `_calibrate` should leave in `meta["input"]`: running statistics instead of the activations
+
     def smooth_quant_scale(self, x, w, alpha):
         from .hip import ops
         from .staging import download
-        return download(ops.smooth_quant_scale(x, self._dev(w), float(alpha)))
+        fn = ops.smooth_quant_scale_stats if isinstance(x, ops.SearchStatistics) else ops.smooth_quant_scale
+        return download(fn(x, self._dev(w), float(alpha)))
 
     def awq_scale_search(self, x, w, a):
         from .hip import ops
         from .staging import download
-        best, _losses = ops.awq_scale_search(x, self._dev(w), *self._args(a))
+        fn = ops.awq_scale_search_stats if isinstance(x, ops.SearchStatistics) else ops.awq_scale_search
+        best, _losses = fn(x, self._dev(w), *self._args(a))
         return download(best)
 
     def awq_clip_search(self, x, w, a):
         from .hip import ops
-        ratio, _losses = ops.awq_clip_search(x, self._dev(w), *self._args(a))
+        fn = ops.awq_clip_search_stats if isinstance(x, ops.SearchStatistics) else ops.awq_clip_search
+        ratio, _losses = fn(x, self._dev(w), *self._args(a))
         return float(ratio)
 
 
@@ -536,7 +547,11 @@ def _divide_in_place(x, scale: np.ndarray) -> None:
         x /= scale.reshape((1, -1))
         return
     import torch
-    x.div_(torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32)).to(x.device).reshape(1, -1))
+    s = torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32))
+    if hasattr(x, "divide"):                                # ops.SearchStatistics: the same rescale on the running statistics
+        x.divide(s)
+        return
+    x.div_(s.to(x.device).reshape(1, -1))
 
 
 def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> dict:
@@ -696,10 +711,12 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
     calibrate = calibrate or _calibrate
     per_node: dict = {}
     meta: dict = {}
+    searches = searches or DeviceSearches()
     if _needs_calibration(qconfig) and targets:
-        meta = calibrate(model, G, targets, qconfig, device, keep_inputs=bool(qconfig.preprocessors))
+        keep = (getattr(searches, "wants", True) if calibrate is _calibrate else True) if qconfig.preprocessors else False
+        meta = calibrate(model, G, targets, qconfig, device, keep_inputs=keep)
     if qconfig.preprocessors and targets:                   # pre_passes/__init__.py:72-88
-        per_node = _preprocess(G, targets, qconfig, meta, searches or DeviceSearches())
+        per_node = _preprocess(G, targets, qconfig, meta, searches)
         _name_nodes(G)
         read = any(a is not None and a.is_static for a in (qconfig.input_activations, qconfig.output_activations)) or \
             bool(qconfig.weights.algorithm.requires_calibration)
