@@ -513,6 +513,11 @@ class DeviceSearches:
             self._w = (w, upload(w))
         return self._w[1]
 
+    def resident(self, w, tensor) -> None:
+        """`tensor` is `w` in HBM already (same shape, fp32, contiguous): searched on as it is."""
+        if tuple(tensor.shape) == tuple(w.shape) and tensor.is_cuda and tensor.is_contiguous() and str(tensor.dtype) == "torch.float32":
+            self._w = (w, tensor)
+
     @staticmethod
     def _args(a):
         return a.dtype.key, a.strategy.value, a.group_size, bool(a.symmetric), bool(a.reduce_range)
@@ -537,6 +542,17 @@ class DeviceSearches:
         fn = ops.awq_clip_search_stats if isinstance(x, ops.SearchStatistics) else ops.awq_clip_search
         ratio, _losses = fn(x, self._dev(w), *self._args(a))
         return float(ratio)
+
+    def scale_rows(self, w, scale):
+        """awq.py:187 / smooth_quant.py:114 (`scale.reshape(-1, 1) * weights`) on the copy of the weight the search already
+        uploaded: (the product on the host, the same product in HBM for the seam -- no second upload, no pass over the weight in
+        NumPy).  One fp32 multiply per element either way: the same bits."""
+        import torch
+        from .staging import download
+        updated = self._dev(w) * torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32)).to(self._dev(w).device).reshape(-1, 1)
+        host = download(updated)
+        self._w = (host, updated)                             # the clip search that may follow runs on the updated weight
+        return host, updated
 
 
 def _divide_in_place(x, scale: np.ndarray) -> None:
@@ -575,11 +591,17 @@ def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> d
             w_name, out_name = node.input[1], node.output[0]
             w = G.array(w_name)
             cfg = per_node.get(id(node), qconfig)
+            if hasattr(searches, "resident") and G.device_values.get(w_name) is not None:
+                searches.resident(w, G.device_values[w_name])           # the calibration walk left this weight in HBM
             if kind == "smooth_quant":
                 scale = np.asarray(searches.smooth_quant_scale(x, w, pre.alpha), dtype=np.float32)
             else:
                 scale = np.asarray(searches.awq_scale_search(x, w, cfg.weights), dtype=np.float32)
-            updated = np.multiply(scale.reshape(-1, 1), w)
+            resident = None
+            if hasattr(searches, "scale_rows"):
+                updated, resident = searches.scale_rows(w, scale)
+            else:
+                updated = np.multiply(scale.reshape(-1, 1), w)
             name = f"{out_name}_scale"
             if name in G.inits:
                 raise ValueError(f"an initializer named '{name}' exists already")
@@ -592,6 +614,8 @@ def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> d
             G.g.node = nodes
             node.input = [mul_out] + list(node.input)[1:]
             G.set_initializer(w_name, updated.astype(np.float32, copy=False))
+            if resident is not None:
+                G.device_values[w_name] = resident            # the seam quantizes this copy instead of uploading the weight again
             if kind == "awq" and pre.clip_search:
                 ratio = searches.awq_clip_search(x, updated, cfg.weights)
                 changed = cfg.model_copy()
