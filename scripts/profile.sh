@@ -2,7 +2,7 @@
 # The round's profiles (run on the GPU box through gpurun): every summary that profiles/rNN_* is made of (rounds 4 and 5; it was
 # scripts/profile_r04.sh).  Kernel traces (--kernel-trace --stats) and PMC passes are separate runs; the program comes
 # directly after `--`.
-#   ROUND=r05 scripts/profile.sh [rtn] [strategies] [packed] [shapes] [searches] [awq] [gptq]      (default: all)
+#   ROUND=r05 scripts/profile.sh [rtn] [strategies] [packed] [shapes] [searches] [awq] [gptq] [file]      (default: all but file)
 set -u
 ROUND=${ROUND:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
@@ -38,6 +38,9 @@ for w in $WHAT; do
       trace awq $P;;
     gptq)
       trace gptq python3 $R/bench_gptq.py --layers 8 --no-cpu-baseline --hessian-methods "" --extra-passes corrected;;
+    file)       # the file path: calibration walk on torch-ROCm + own GEMM, Hessians, factors, loops, packs
+      trace file_gptq python3 $R/bench_model.py --layers 4 --config gptq_int4_g128 --samples 16 --seq 2048 --repeat 1
+      trace file_awq python3 $R/bench_model.py --layers 4 --config awq_uint4_g128 --samples 16 --seq 2048 --repeat 1;;
   esac
   python3 $R/scripts/summarize_kernels.py $OUT/$w* > /dev/null 2>&1
   echo "$w done"
