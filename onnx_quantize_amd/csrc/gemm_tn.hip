@@ -466,7 +466,7 @@ int32_t oq_matmul_prepare_f32(const float* X, int64_t Kd, int64_t cols, int64_t 
     OQ_REQUIRE(need != 0, OQ_ERR_UNSUPPORTED, "oq_matmul_prepare_f32: contraction of %lld too long", (long long)Kd);
     OQ_REQUIRE(pieces_bytes >= need && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_WORKSPACE,
                "oq_matmul_prepare_f32: a 256-byte aligned buffer of %zu bytes is needed, %zu given", need, pieces_bytes);
-    return make_f16x2_pieces(X, Kd, cols, ldx, contraction_is_fast_axis != 0, pieces, as_stream(stream));
+    return make_f16x2_pieces(X, Kd, cols, ldx, contraction_is_fast_axis != 0, pieces, as_stream(stream), true);
 }
 
 int32_t oq_matmul_pieces_f32(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,

@@ -120,7 +120,8 @@ int32_t launch_inverse_level_f16x3(const float* Lt, float* X, float* Y, float* S
 //                          (the quadratic form <D, G D> of the searches' Gram route); with b_first_piece_only two products
 //                          instead of three: A with both pieces against B's first.
 size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols);
-int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s);
+int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s,
+                          bool wide_range = false);   // wide_range: a scale over the whole fp32 exponent range (plain GEMM operands; 1 / s^2 unset)
 // For a producer that writes the FIRST (hi) fp16 pieces of a row-major [Kd, cols] operand itself instead of handing a
 // fp32 matrix to make_f16x2_pieces* (awq.hip: the quantize-residual kernel, round 5).  The eight fp16 of rows 8c .. 8c + 7 of
 // column n (k ascending, each fl16(x * s), round to nearest even) are the 16-byte vector

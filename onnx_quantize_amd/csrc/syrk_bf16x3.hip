@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256) void absmax_partial_kernel(const float* __rest
 }
 
 // partial maxima -> scale[0] = s = 2^(15 - exponent of max) (1 for an all-zero or non-finite batch), scale[1] = 1 / s^2, scale[2] = 1 / s
+template <int CLAMP = 60>
 __device__ __forceinline__ void absmax_scale_body(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
     float m = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) m = nmax(m, partial[i]);
@@ -156,9 +157,9 @@ __device__ __forceinline__ void absmax_scale_body(const float* __restrict__ part
         if (m > 0.0f && m < INFINITY) {
             (void)frexpf(m, &ex);                      // m = f * 2^ex, f in [0.5, 1)
             int e = 15 - ex;
-            e = e > 60 ? 60 : (e < -60 ? -60 : e);     // 1 / s^2 must stay a normal float
+            e = e > CLAMP ? CLAMP : (e < -CLAMP ? -CLAMP : e);     // 60: 1 / s^2 must stay a normal float (the consumers that read it)
             s = ldexpf(1.0f, e);
-            inv2 = ldexpf(1.0f, -2 * e);
+            inv2 = CLAMP <= 60 ? ldexpf(1.0f, -2 * e) : 0.0f;       // wide range (plain GEMM operands): 1 / s^2 is not read
         }
         scale[0] = s;
         scale[1] = inv2;
@@ -168,6 +169,12 @@ __device__ __forceinline__ void absmax_scale_body(const float* __restrict__ part
 
 __global__ __launch_bounds__(256) void absmax_scale_kernel(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
     absmax_scale_body(partial, n, scale);
+}
+
+// the same over (nearly) the whole exponent range of fp32: for operands of a plain product C = A B, whose epilogue applies 1 / s_a
+// and 1 / s_b one after the other (an operand whose largest magnitude is 1e-30 or 1e30 must not vanish or overflow in the pieces)
+__global__ __launch_bounds__(256) void absmax_scale_wide_kernel(const float* __restrict__ partial, const int n, float* __restrict__ scale) {
+    absmax_scale_body<110>(partial, n, scale);
 }
 
 __device__ __forceinline__ uint32_t pk_f16(float a, float b) {
@@ -936,7 +943,9 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
     }
     const float unscale = g.scale_a[2] * g.scale_b[2];   // 1 / (s_a s_b): exact, powers of two
     if constexpr (EPI == 0) {
-        const float alpha = g.alpha * unscale;
+        // the two powers of two one after the other (alpha 2^-b, then 2^-a on the sum): the same bits as alpha 2^-(a + b) whenever
+        // that product is a normal float, and no vanishing / overflowing factor when the operands' scales are far apart or extreme
+        const float alpha = g.alpha * g.scale_b[2], ua = g.scale_a[2];
         const bool vec_ok = (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15u) == 0;
         auto rows = [&](int r, int c4, f32x4v v) -> f32x4v {
             const int64_t row = m0 + r, col = n0 + c4;
@@ -951,7 +960,7 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
             f32x4v val;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float x = alpha * v[q];
+                float x = alpha * (v[q] * ua);
                 if (g.beta != 0.0f) x = g.beta * old[q] + x;
                 val[q] = x;
             }
@@ -1386,7 +1395,8 @@ size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols) {
     return static_cast<size_t>(stages_of(Kd, StageGeom<3>::ROWS)) * StageGeom<3>::CH * 2 * padded_k(cols) * 16 + kScaleHeaderBytes;
 }
 
-int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s) {
+int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s,
+                          bool wide_range) {
     OQ_REQUIRE(X && pieces && Kd > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT, "make_f16x2_pieces: bad argument");
     float* scale = static_cast<float*>(pieces);
     u32x4* P = reinterpret_cast<u32x4*>(static_cast<unsigned char*>(pieces) + kScaleHeaderBytes);
@@ -1396,7 +1406,8 @@ int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx,
     const int64_t rows = contraction_is_fast_axis ? cols : Kd, rowlen = contraction_is_fast_axis ? Kd : cols;
     const int nb = static_cast<int>(rows < kAbsmaxBlocks ? rows : kAbsmaxBlocks);
     hipLaunchKernelGGL(absmax_partial_kernel, dim3(static_cast<uint32_t>(nb)), dim3(256), 0, s, X, rows, rowlen, ldx, scale + 4);
-    hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
+    if (wide_range) hipLaunchKernelGGL(absmax_scale_wide_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
+    else hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
     const dim3 grid(static_cast<uint32_t>(Cp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4)));
     if (contraction_is_fast_axis)
         hipLaunchKernelGGL(split_f16x2_fast_axis_kernel, grid, dim3(256), 0, s, X, cols, Kd, ldx, Cp, nchunks, scale, P);

@@ -863,7 +863,9 @@ def matmul_prepare(t: torch.Tensor, contraction_is_fast_axis: bool) -> MatmulOpe
 def matmul_pieces(x: torch.Tensor, w: MatmulOperand | torch.Tensor) -> torch.Tensor:
     """``x`` [..., Kd] fp32 times a weight [Kd, N] (a tensor, or its `matmul_prepare(w, False)` pieces) on the fp16 matrix
     cores with two-piece operands: 22 significand bits per operand, fp32 accumulate -- the arithmetic of the Hessian
-    kernels.  Returns [..., N] fp32."""
+    kernels.  Returns [..., N] fp32.  Each operand is scaled as a whole by a power of two (any magnitude fp32 can hold), so the
+    22 bits hold for elements within ~2^18 of the operand's largest; far smaller ones keep fewer (fp16's exponent range) --
+    activations with their outliers are well inside, a row 10^10 times smaller than another one of the same batch is not."""
     _require_device(x, "x", torch.float32)
     if not isinstance(w, MatmulOperand):
         w = matmul_prepare(w, False)

@@ -313,6 +313,11 @@ def test_large_products_of_the_calibration_walk_take_the_fp16_piece_gemm():
     ragged = ops.matmul_pieces(x[:, :37, :1000].contiguous(), w[:1000, :515].contiguous())          # nothing a multiple of a tile
     ref2 = x[:, :37, :1000].double() @ w[:1000, :515].double()
     assert ((ragged.double() - ref2).norm() / ref2.norm()).item() < 2e-6
+    # operands at the ends of the fp32 exponent range, and all zeros
+    for factor in (1e-30, 1e30):
+        big = ops.matmul_pieces(x * factor, w)
+        assert (((big.double() - ref * factor).norm() / (ref * factor).norm()).item()) < 2e-6, factor
+    assert ops.matmul_pieces(torch.zeros_like(x), w).abs().max().item() == 0.0
     # in the runner: one big MatMul (pieces) feeding one small (torch)
     g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["b", "t", 1024])], output=[P.make_value_info("y", 1, None)],
                   node=[P.make_node("MatMul", ["x", "w"], ["h"], name="big"), P.make_node("MatMul", ["h", "v"], ["y"], name="small")],
