@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""`ops.matmul_pieces` at the edges: all-zero operands, one huge element next to a row 10^10 times smaller (what a per-operand scale
+costs), operands at 1e-30 / 1e30 (the whole fp32 exponent range must work)."""
 import sys; sys.path.insert(0, "/root/repo")
 import torch
 from onnx_quantize_amd.hip import ops
