@@ -857,7 +857,8 @@ def quantize_model_sharded(model, qconfig: QConfig, *, group=None, device="cuda"
     if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
         return as_model(model)
     prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
-    if weight_arrays is None:
+    device_default = weight_arrays is None
+    if device_default:
         from .seam import weight_arrays
     needs_hessian = bool(qconfig.weights.algorithm.requires_calibration)
     specs = []
@@ -869,11 +870,13 @@ def quantize_model_sharded(model, qconfig: QConfig, *, group=None, device="cuda"
 
     def on_this_rank(i, _spec):
         captured = []
+        seam = _PackedSeam() if device_default else None        # 4-bit integers travel nibble-packed: half the gather
 
         def recording(value, cfg, out, nbits):
-            arrays = weight_arrays(value, cfg, out, nbits)
+            arrays = seam(value, cfg, out, nbits) if seam is not None else weight_arrays(value, cfg, out, nbits)
             if np.asarray(value.const_value.numpy()).ndim == 2:
-                captured.append(arrays)
+                packed = None if seam is None else seam.packed.pop(value.name, None)
+                captured.append((packed[0],) + tuple(arrays[1:]) if packed is not None else arrays)
             return arrays
 
         _plan(prepared, prepared.targets[i], qconfig, recording, quantize_bias)
@@ -884,12 +887,24 @@ def quantize_model_sharded(model, qconfig: QConfig, *, group=None, device="cuda"
     if gathered is None:
         return None
 
-    def from_the_ranks(value, cfg, out, nbits):
-        if np.asarray(value.const_value.numpy()).ndim == 2:
-            return gathered[value.name]
-        return weight_arrays(value, cfg, out, nbits)           # the per-tensor bias of a QDQ Gemm: a vector, quantized here
+    class FromTheRanks:
+        """The gathered arrays as the emission's provider; integers that arrived nibble-packed go into their TensorProto as they are
+        (`packed`, the protocol of `_PackedSeam`)."""
 
-    return _emit(prepared, qconfig, from_the_ranks, quantize_bias)
+        def __init__(self):
+            self.packed: dict = {}
+
+        def __call__(self, value, cfg, out, nbits):
+            w = np.asarray(value.const_value.numpy())
+            if w.ndim != 2:
+                return weight_arrays(value, cfg, out, nbits)       # the per-tensor bias of a QDQ Gemm: a vector, quantized here
+            q, s, z = gathered[value.name]
+            if device_default and not nbits and cfg.weights.dtype.bitwidth == 4 and q.ndim == 1:
+                self.packed[value.name] = (q, tuple(w.shape))
+                return np.broadcast_to(np.zeros((), dtype=cfg.weights.dtype.np_dtype), w.shape), s, z
+            return q, s, z
+
+    return _emit(prepared, qconfig, FromTheRanks(), quantize_bias)
 
 
 def quantize_file(src, dst, qconfig: QConfig, external_data="auto", **kw) -> Message:
