@@ -330,3 +330,33 @@ def test_large_products_of_the_calibration_walk_take_the_fp16_piece_gemm():
     torch.testing.assert_close(a["y"], b["y"], rtol=1e-4, atol=1e-4)
     with pytest.raises(ValueError, match="matmul must be"):
         GraphRunner(model, device="cuda", matmul="fast")
+
+
+def test_calibration_through_the_piece_gemm_agrees_with_the_fp32_walk():
+    """A model wide enough for `_calibrate`'s walk to take `ops.matmul_pieces` (>= 512 x 512 weights, >= 256 rows per batch): the
+    calibrated file against the oracle-provider file whose activations came from torch's fp32 matmul -- same integers everywhere,
+    activation scales within 1e-5 (the two GEMMs differ from float64 by ~1e-6 each), zero points equal."""
+    rng = np.random.default_rng(0)
+    w1, w2 = (rng.standard_normal((512, 1024)) / 22).astype(np.float32), (rng.standard_normal((1024, 512)) / 32).astype(np.float32)
+    g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["b", "t", 512])], output=[P.make_value_info("y", 1, None)],
+                  node=[P.make_node("MatMul", ["x", "w1"], ["h"], name="up"), P.make_node("Tanh", ["h"], ["a"], name="act"),
+                        P.make_node("MatMul", ["a", "w2"], ["y"], name="down")],
+                  initializer=[P.numpy_to_tensor("w1", w1), P.numpy_to_tensor("w2", w2)])
+    model = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+    data = (rng.standard_normal((8, 300, 512)) * rng.uniform(0.2, 3.0, 512)).astype(np.float32)
+    make = lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, group_size=-1), input_activations=_act("uint8"),      # noqa: E731
+                           output_activations=_act("int8"), calibration_data=data, calibration_params={"num_samples": 8, "batch_size": 2})
+    got, want = quantize_model(model, make()), q_oracle(model, make(), runner_device="cuda")
+    a = {t.name: P.tensor_to_numpy(t) for t in got.graph.initializer}
+    b = {t.name: P.tensor_to_numpy(t) for t in want.graph.initializer}
+    assert list(a) == list(b)
+    scales = 0
+    for name in a:
+        if a[name].dtype.kind in "iu":
+            assert np.array_equal(a[name], b[name]), name
+        elif name.endswith("/scale") and "/input/" in name or "/output/" in name:
+            np.testing.assert_allclose(a[name], b[name], rtol=1e-5, err_msg=name)
+            scales += 1
+        else:
+            assert a[name].tobytes() == b[name].tobytes(), name
+    assert scales == 4
