@@ -1007,3 +1007,29 @@ def test_graph_runner_gets_through_a_convolutional_front_end():
     assert sum(n.op_type == "Conv" for n in out.graph.node) == 2
     got, want = GraphRunner(out, device="cpu")(x)["scores"], GraphRunner(model, device="cpu")(x)["scores"]
     assert ((got - want).norm() / want.norm()).item() < 0.02
+
+
+def test_bench_and_example_models_are_well_formed_and_quantize():
+    """The synthetic models of bench_model.py and examples/gemma3_shapes/gemma3_onnx_file.py (toy sizes): structurally sound, run in
+    the graph runner, and go through the writer (oracle providers) with `lm_head` ignored like in the reference's examples."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench_model
+    model = bench_model.build_model(2, 64, 128)
+    P.check_model(model)
+    x = torch.randn(2, 5, 64)
+    out = q_oracle(model, CONFIGS["uint4_g32"]())
+    assert sum(n.op_type == "MatMulNBits" for n in out.graph.node) == 14
+    assert ((GraphRunner(out, device="cpu")(x)["y"] - GraphRunner(model, device="cpu")(x)["y"]).norm()).item() > 0
+    spec = importlib.util.spec_from_file_location("gemma3_onnx_file", os.path.join(ROOT, "examples", "gemma3_shapes", "gemma3_onnx_file.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    g = ex.build_model(layers=2, vocab=128, max_positions=64)
+    P.check_model(g)
+    feed = {k: torch.from_numpy(v) for k, v in ex.make_calibration_data(2, 128, 2, 9).items()}
+    want = GraphRunner(g, outputs=["logits", "present.1.key"], device="cpu")(feed)
+    assert want["logits"].shape == (2, 9, 128) and want["present.1.key"].shape == (2, 1, 9, 256)
+    q = q_oracle(g, QConfig(weights=QWeightArgs(dtype="int8", strategy="group", group_size=128), ignore=["lm_head"]))
+    assert sum(n.domain == "quant" for n in q.graph.node) == 14 and any(n.name == "/lm_head/MatMul" and not n.domain for n in q.graph.node)
+    got = GraphRunner(q, outputs=["logits"], device="cpu")(feed)["logits"]
+    assert ((got - want["logits"]).norm() / want["logits"].norm()).item() < 0.05
