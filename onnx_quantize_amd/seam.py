@@ -152,10 +152,11 @@ def _host(t, dtype=None):
     return download(t, dtype)
 
 
-def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool):
+def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool, want_packed4: bool = False):
     """Run the configured algorithm on the device.  Returns (q, scale, zp, is_blob) as device tensors -- q is the
     MatMulNBits blob when the algorithm's kernel wrote it directly -- or None for an algorithm this package has no
-    kernels for."""
+    kernels for.  ``want_packed4``: 4-bit integers of the plain route as [K, N/2] nibble pairs straight from the kernel's
+    epilogue where it has one (RTN groups, the GPTQ loop; `is_blob` is then the string "packed4")."""
     import torch
 
     from .hip import ops
@@ -168,9 +169,11 @@ def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool):
     k = w_dev.shape[0]
     if tag == "rtn":
         blob = want_blob and not a.mse and k % ops.resolve_group(st, k, g) == 0
+        packed = (want_packed4 and not blob and not a.mse and a.dtype.bitwidth == 4 and st == "group" and w_dev.shape[1] % 2 == 0
+                  and k % ops.resolve_group(st, k, g) == 0)
         q, s, z = ops.rtn_quantize(w_dev, qt, st, g, bool(a.symmetric), bool(a.reduce_range), float(a.clip_ratio), bool(a.mse),
-                                   layout="nbits" if blob else "kn")
-        return q, s, z, blob
+                                   layout="nbits" if blob else ("kn_packed4" if packed else "kn"))
+        return q, s, z, ("packed4" if packed else blob)
     if tag == "hqq":
         assert a.zp_dtype == a.scale_dtype                                          # hqq.py:175
         if qt != "uint4":
@@ -185,12 +188,14 @@ def _device_algorithm(w_dev, name, qconfig, out, want_blob: bool):
         node = out.producer()
         assert "input" in node.meta, "GPTQ requires calibration data in node meta."    # gptq.py:56
         h, shared = _hessian_and_factor(node.meta["input"], k, w_dev.device, float(algo.percdamp), bool(algo.actorder))
+        packed = want_packed4 and not want_blob and a.dtype.bitwidth == 4 and w_dev.shape[1] % 2 == 0 and not bool(algo.actorder)
         q, s, z, info = ops.gptq_quantize(w_dev, h, qt, st, a.group_size, bool(a.symmetric), bool(a.reduce_range),
                                           float(a.clip_ratio), int(algo.block_size), float(algo.percdamp), bool(algo.actorder),
-                                          bool(a.mse), mode=getattr(algo, "mode", "parity"), shared=shared)
+                                          bool(a.mse), mode=getattr(algo, "mode", "parity"), shared=shared,
+                                          layout="kn_packed4" if packed else "kn")
         if int(info.item()) != 0:                                                     # gptq.py:143-150
             logger.warning(_GPTQ_FALLBACK_WARNING)
-        return q, s, z, False
+        return q, s, z, ("packed4" if packed else False)
     return None
 
 
@@ -210,7 +215,8 @@ def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False
         if resident is not None and (tuple(resident.shape) != tuple(w_np.shape) or str(resident.dtype) != "torch.float32"   # calibration walk)
                                      or not resident.is_cuda or not resident.is_contiguous()):
             resident = None
-        res = _device_algorithm(resident if resident is not None else _upload(w.name, w_np), w.name, qconfig, out, is_matmul_nbits_compatible)
+        res = _device_algorithm(resident if resident is not None else _upload(w.name, w_np), w.name, qconfig, out, is_matmul_nbits_compatible,
+                                want_packed4=packed4 and not is_matmul_nbits_compatible)
     if res is None:        # an algorithm plugin without kernels here: its own NumPy route, then the wire format on the GPU
         w_q, w_scale, w_zp = a.algorithm.quantize_weights(w, qconfig, out=out)
         if is_matmul_nbits_compatible:
@@ -224,8 +230,11 @@ def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False
     if not is_matmul_nbits_compatible:
         if packed4 and a.dtype.bitwidth == 4:
             # for a writer that serialises the integers as an ONNX INT4 / UINT4 tensor (core/_pack.py:8-22: two values per byte
-            # in flat order): packed on the device, half the download, no NumPy pass over the values on the host
-            return _host(ops.pack_nibbles(q)), _host(s, a.scale_dtype), _host(z, a.zp_dtype)
+            # in flat order; with an even N the [K, N/2] pairs of the kernels' epilogue ARE that order): packed on the device --
+            # by the RTN / GPTQ kernel itself where it has the epilogue, else by oq_pack_nibbles --, half the download, no NumPy
+            # pass over the values on the host
+            q_packed = q.reshape(-1) if is_blob == "packed4" else ops.pack_nibbles(q)
+            return _host(q_packed), _host(s, a.scale_dtype), _host(z, a.zp_dtype)
         return _host(q, qdt), _host(s, a.scale_dtype), _host(z, a.zp_dtype)
 
     # qrules/_common.py:65-123 on the device
