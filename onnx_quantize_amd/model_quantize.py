@@ -747,6 +747,7 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
         if any(p.requires_post_calibration for p in qconfig.preprocessors) and (read or post_calibration == "always"):
             logger.info("Re-calibrating the model after pre-processing...")
             meta = calibrate(model, G, targets, qconfig, device, keep_inputs=post_calibration == "always" and not read)
+    qconfig.calibration_data = None                         # pre_passes/__init__.py:90: the caller's configuration lets go of the data
     return Prepared(model, G, targets, meta, per_node)
 
 

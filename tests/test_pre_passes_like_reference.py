@@ -43,7 +43,10 @@ def _providers(device):
 
 def _run_pass_checks(device, model, qconfig, expected_num_mul, rng):
     """test_awq.py:75-117 / test_smooth_quant.py:67-110."""
+    data = qconfig.calibration_data
     prepared = apply_pre_passes(model, qconfig, device=device, **_providers(device))
+    assert qconfig.calibration_data is None                  # pre_passes/__init__.py:90
+    qconfig.calibration_data = data                           # (the reference's test builds a new configuration for the second calibration)
     out = prepared.model
     assert sum(n.op_type == "Mul" for n in out.graph.node) == expected_num_mul
     samples = torch.from_numpy(rng.normal(size=(1, 32)).astype(np.float32))

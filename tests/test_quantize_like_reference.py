@@ -223,9 +223,9 @@ def test_the_reference_grids_on_the_device_path():
     exact = {"n": 0}
 
     def provider(model, qc, tag):
+        twin = qc.model_copy()                                                # (quantize() drops the caller's calibration data, like the reference)
         got = quantize_model(model, qc)
         if tag is None:                                                       # same activations -> the same file, byte for byte
-            twin = qc.model_copy()
             assert P.serialize(got) == P.serialize(q_oracle(model, twin, runner_device="cuda")), qc
             exact["n"] += 1
         return got
