@@ -1033,3 +1033,59 @@ def test_bench_and_example_models_are_well_formed_and_quantize():
     assert sum(n.domain == "quant" for n in q.graph.node) == 14 and any(n.name == "/lm_head/MatMul" and not n.domain for n in q.graph.node)
     got = GraphRunner(q, outputs=["logits"], device="cpu")(feed)["logits"]
     assert ((got - want["logits"]).norm() / want["logits"].norm()).item() < 0.05
+
+
+def _run_one(op, inputs, n_out=1, **attrs):
+    names = [f"i{k}" for k in range(len(inputs))]
+    outs = [f"o{k}" for k in range(n_out)]
+    g = P.Message("GraphProto", name="g", node=[P.make_node(op, names, outs, **attrs)],
+                  input=[P.make_value_info(n, 1, None) for n in names], output=[P.make_value_info(o, 1, None) for o in outs])
+    m = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+    got = GraphRunner(P.parse_model(P.serialize(m)), device="cpu")(dict(zip(names, inputs)))
+    return [got[o] for o in outs] if n_out > 1 else got["o0"]
+
+
+def test_single_operators_of_the_runner_against_torch():
+    """The operators no exported fixture happens to contain, one node at a time against their torch / ONNX-spec meaning."""
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 5, generator=gen)
+    i64 = lambda *v: torch.tensor(v, dtype=torch.int64)                       # noqa: E731
+    torch.testing.assert_close(_run_one("CumSum", [x, i64(1).reshape(())]), x.cumsum(1))
+    torch.testing.assert_close(_run_one("CumSum", [x, i64(2).reshape(())], exclusive=1, reverse=1), x.flip(2).cumsum(2).flip(2) - x)
+    assert torch.equal(_run_one("ArgMax", [x], axis=2, keepdims=0), x.argmax(2))
+    idx = torch.randint(-4, 4, (3, 2, 5), generator=gen)
+    assert torch.equal(_run_one("GatherElements", [x, idx], axis=1), torch.gather(x, 1, idx % 4))
+    assert torch.equal(_run_one("Mod", [i64(-7, 7, 5), i64(3, -3, 3)]), i64(2, -2, 2))                 # the divisor's sign
+    assert torch.equal(_run_one("Mod", [i64(-7, 7, 5), i64(3, -3, 3)], fmod=1), i64(-1, 1, 2))        # the dividend's sign
+    assert torch.equal(_run_one("Div", [i64(-7, 7), i64(2, -2)]), i64(-3, -3))                         # integers truncate towards zero
+    torch.testing.assert_close(_run_one("HardSigmoid", [x], alpha=0.25, beta=0.4), (x * 0.25 + 0.4).clamp(0, 1))
+    torch.testing.assert_close(_run_one("Elu", [x], alpha=1.5), torch.nn.functional.elu(x, 1.5))
+    torch.testing.assert_close(_run_one("PRelu", [x, torch.tensor(0.2)]), torch.where(x >= 0, x, 0.2 * x))
+    torch.testing.assert_close(_run_one("Einsum", [x, x.transpose(1, 2).contiguous()], equation="bij,bjk->bik"), x @ x.transpose(1, 2))
+    a, b = _run_one("Split", [x, i64(1, 3)], n_out=2, axis=1)
+    assert a.shape == (3, 1, 5) and torch.equal(b, x[:, 1:])
+    a, b, c = _run_one("Split", [torch.arange(7.0)], n_out=3, axis=0, num_outputs=3)                   # uneven: the last chunk is shorter
+    assert [t.numel() for t in (a, b, c)] == [3, 3, 1]
+    torch.testing.assert_close(_run_one("Slice", [x, i64(3), i64(-5), i64(2), i64(-1)]), x[:, :, [3, 2, 1]])          # a negative step
+    torch.testing.assert_close(_run_one("Slice", [x, i64(1, 0), i64(3, 4), i64(0, 2), i64(1, 2)]), x[1:3, :, 0:4:2])
+    assert _run_one("Expand", [torch.ones(4, 1), i64(3, 1, 5)]).shape == (3, 4, 5)
+    assert torch.equal(_run_one("Trilu", [x, i64(1).reshape(())], upper=1), x.triu(1))
+    torch.testing.assert_close(_run_one("ReduceMean", [x, i64(0, 2)], keepdims=0), x.mean((0, 2)))
+    torch.testing.assert_close(_run_one("ReduceSum", [x]), x.sum().reshape(1, 1, 1))
+    assert torch.equal(_run_one("ReduceMax", [x, torch.zeros(0, dtype=torch.int64)], noop_with_empty_axes=1), x)
+    torch.testing.assert_close(_run_one("Clip", [x, torch.tensor(-0.5), torch.tensor(0.25)]), x.clamp(-0.5, 0.25))
+    assert torch.equal(_run_one("Where", [x > 0, x, torch.zeros(())]), torch.where(x > 0, x, torch.zeros(())))
+    assert torch.equal(_run_one("Unsqueeze", [x, i64(0, -1)]), x[None, ..., None])
+    assert _run_one("Squeeze", [torch.ones(1, 3, 1), i64(0)]).shape == (3, 1)
+    assert torch.equal(_run_one("ConstantOfShape", [i64(2, 3)], value=P.numpy_to_tensor("", np.array([7], dtype=np.int64))), torch.full((2, 3), 7))
+    assert torch.equal(_run_one("Range", [i64(2).reshape(()), i64(11).reshape(()), i64(3).reshape(())]), torch.arange(2, 11, 3))
+    assert torch.equal(_run_one("Shape", [x], start=1), i64(4, 5)) and int(_run_one("Size", [x])) == 60
+    torch.testing.assert_close(_run_one("Gemm", [x[0], x[1], torch.ones(4)], transB=1, alpha=0.5, beta=2.0), 0.5 * x[0] @ x[1].T + 2.0)
+    q = torch.randint(0, 255, (6, 8), generator=gen).to(torch.uint8)
+    s, z = torch.rand(6, 2, generator=gen) + 0.1, torch.randint(0, 255, (6, 2), generator=gen).to(torch.uint8)
+    want = (q.float().reshape(6, 2, 4) - z.float()[:, :, None]) * s[:, :, None]
+    torch.testing.assert_close(_run_one("DequantizeLinear", [q, s, z], axis=1, block_size=4), want.reshape(6, 8))     # blocked along the last axis
+    ch = (q.float() - z[:, 0].float()[:, None]) * s[:, 0][:, None]
+    torch.testing.assert_close(_run_one("DequantizeLinear", [q, s[:, 0].contiguous(), z[:, 0].contiguous()], axis=0), ch)
+    got = _run_one("QuantizeLinear", [torch.tensor([0.5, 1.5, 2.5, -300.0, 300.0]), torch.tensor(1.0), torch.tensor(0, dtype=torch.int8)])
+    assert got.tolist() == [0, 2, 2, -128, 127]                                # half to even, saturated
