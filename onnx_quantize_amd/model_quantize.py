@@ -45,7 +45,7 @@ from .onnx_functions import FUNCTION_OPSET, MS_DOMAIN, QUANT_DOMAIN, build_funct
 from .onnx_proto import (DataType, Message, attribute_value, check_model, load_model, make_attribute, make_node, numpy_to_tensor, parse_model,
                          save_model, tensor_to_numpy)
 
-__all__ = ["quantize_model", "quantize_model_sharded", "quantize_file", "apply_pre_passes", "as_model"]
+__all__ = ["quantize_model", "quantize_model_sharded", "quantize_file", "apply_pre_passes", "target_nodes", "as_model"]
 
 logger = logging.getLogger("onnx_quantize")
 
@@ -706,6 +706,32 @@ class _Out:
         return self
 
 
+def target_nodes(model, qconfig: QConfig) -> list:
+    """Which nodes `quantize()` would rewrite, without touching a GPU: the structural pre-passes (opset, names, Identity / constant
+    folding, duplicated initializers, MatMul + Add -> Gemm, Gemm with `transB = 0`) followed by the selection of
+    `get_target_nodes` (calibrate.py:48-89) and the rules' checks.  Returns [(node name, op type, weight name, [K, N])] in graph
+    order; the caller's model is not modified."""
+    model = as_model(model)
+    if model.graph is None:
+        raise ValueError("the model has no graph")
+    G = _structural_passes(model)
+    return [(n.name, n.op_type, n.input[1], [int(d) for d in G.inits[n.input[1]].dims]) for n in _target_nodes(G, qconfig)]
+
+
+def _structural_passes(model: Message) -> _Graph:
+    """quantize.py:50-55 + the standard passes of pre_passes/__init__.py:58-65, in the reference's order."""
+    G = _Graph(model.graph)
+    _raise_opset(model, G)
+    _name_nodes(G)
+    _eliminate_identities(G)
+    _lift_constant_weights(G)
+    _fold_constants(model, G)
+    _duplicate_shared_initializers(G)
+    _fuse_matmul_add(G)
+    _standardize_gemm(G)
+    return G
+
+
 class Prepared:
     """A model after the pre-passes: the graph view, the nodes to quantize, their calibration results and the per-node
     configurations a preprocessor changed (AWQ's clip ratio)."""
@@ -722,15 +748,7 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
     model = as_model(model)
     if model.graph is None:
         raise ValueError("the model has no graph")
-    G = _Graph(model.graph)
-    _raise_opset(model, G)
-    _name_nodes(G)
-    _eliminate_identities(G)
-    _lift_constant_weights(G)
-    _fold_constants(model, G)
-    _duplicate_shared_initializers(G)
-    _fuse_matmul_add(G)
-    _standardize_gemm(G)
+    G = _structural_passes(model)
     targets = _target_nodes(G, qconfig)
     calibrate = calibrate or _calibrate
     per_node: dict = {}

@@ -612,6 +612,17 @@ def test_constants_are_folded_like_the_optimizer_does():
         assert ((got - v).norm() / v.norm()).item() < 0.03
 
 
+def test_target_nodes_lists_what_would_be_quantized_without_a_gpu():
+    from onnx_quantize_amd.model_quantize import target_nodes
+    src = fixture("block")
+    before = P.serialize(src)
+    got = target_nodes(src, QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), ignore=["down"]))
+    assert [t[0] for t in got] == ["/q/MatMul", "/k/MatMul", "/v/MatMul", "/o/MatMul", "/up/MatMul"] and got[-1][1:] == ("MatMul", "onnx::MatMul_111", [64, 128])
+    assert P.serialize(src) == before
+    assert [t[:2] for t in target_nodes(fixture("mlp_gemm"), QConfig(weights=QWeightArgs(), target_op_types=["Gemm"]))] == [("/0/Gemm", "Gemm")]
+    assert target_nodes(fixture("mlp_gemm"), QConfig(weights=QWeightArgs()))[0][3] == [64, 48]      # transB = 1 standardised: [K, N]
+
+
 def test_opset_is_raised_with_adapters_or_refused_by_name():
     x = P.make_value_info("x", 1, ["batch", 16])
     w = np.random.default_rng(1).standard_normal((16, 4)).astype(np.float32)
