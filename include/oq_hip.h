@@ -336,13 +336,16 @@ int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_
  *       oq_matmul_pieces_bytes(Kd, cols)   size of the piece buffer of one operand with `cols` rows / columns (0: too large)
  *       oq_matmul_prepare_f32              operand -> pieces (256-byte aligned).  contraction_is_fast_axis != 0: the source is
  *                                          [cols, Kd] row-major (activations X [M, Kd]); 0: [Kd, cols] row-major (a weight
- *                                          W [Kd, N], prepared once).  ldx: leading dimension of the source.
- *       oq_matmul_pieces_f32               C [M, N] (ldc) = beta C + alpha A B from the two piece buffers. */
+ *                                          W [Kd, N], prepared once).  ldx: leading dimension of the source.  per_row_scales != 0
+ *                                          (fast-axis sources only): one power-of-two scale per source row instead of one for the
+ *                                          whole operand -- rows of very different magnitude each keep their 22 bits.
+ *       oq_matmul_pieces_f32               C [M, N] (ldc) = beta C + alpha A B from the two piece buffers; a_per_row_scales: how
+ *                                          A was prepared. */
 size_t oq_matmul_pieces_bytes(int64_t Kd, int64_t cols);
 int32_t oq_matmul_prepare_f32(const float* X, int64_t Kd, int64_t cols, int64_t ldx, int32_t contraction_is_fast_axis,
-                              void* pieces, size_t pieces_bytes, void* stream);
+                              int32_t per_row_scales, void* pieces, size_t pieces_bytes, void* stream);
 int32_t oq_matmul_pieces_f32(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha,
-                             float beta, float* C, int64_t ldc, void* stream);
+                             float beta, float* C, int64_t ldc, int32_t a_per_row_scales, void* stream);
 
 /* G3 prologue  gptq.py:118-127: dead = diag(H) == 0 -> H[d,d] = 1, W[d,:] = 0 (both in place);
  *     when actorder: perm_out = argsort(diag(H)) reversed (ties: larger index first) and W, H are

@@ -455,26 +455,35 @@ int32_t oq_hessian_accumulate_prepared_f32(const void* pieces, int64_t T, int64_
 // with two-piece operands (22 significand bits, fp32 accumulate) -- the Hessian's arithmetic class, ~5 x an fp32 GEMM.
 size_t oq_matmul_pieces_bytes(int64_t Kd, int64_t cols) {
     if (!extent_ok(Kd) || !extent_ok(cols) || !count_ok(Kd * cols, kMaxElements) || Kd > 8 * 65535 * 4) return 0;
-    return gemm_f16x3_pieces_bytes(Kd, cols);
+    return gemm_f16x3_pieces_bytes(Kd, cols) + ((static_cast<size_t>(cols) * 8 + 255) / 256) * 256;   // + room for one scale pair per row
 }
 
-int32_t oq_matmul_prepare_f32(const float* X, int64_t Kd, int64_t cols, int64_t ldx, int32_t contraction_is_fast_axis, void* pieces,
-                              size_t pieces_bytes, void* stream) {
+// the per-row scales of an operand live behind its pieces: [cols] s_t, [cols] 1 / s_t
+static float* matmul_row_scales(void* pieces, int64_t Kd, int64_t cols) {
+    return reinterpret_cast<float*>(static_cast<unsigned char*>(pieces) + gemm_f16x3_pieces_bytes(Kd, cols));
+}
+
+int32_t oq_matmul_prepare_f32(const float* X, int64_t Kd, int64_t cols, int64_t ldx, int32_t contraction_is_fast_axis, int32_t per_row_scales,
+                              void* pieces, size_t pieces_bytes, void* stream) {
     OQ_REQUIRE(X && pieces && extent_ok(Kd) && extent_ok(cols) && count_ok(Kd * cols, kMaxElements) && extent_ok(ldx) &&
                ldx >= (contraction_is_fast_axis ? Kd : cols), OQ_ERR_INVALID_ARGUMENT, "oq_matmul_prepare_f32: bad argument");
+    OQ_REQUIRE(!per_row_scales || contraction_is_fast_axis, OQ_ERR_INVALID_ARGUMENT,
+               "oq_matmul_prepare_f32: per-row scales are for sources with the contraction on the fast axis (activations [M, Kd])");
     const size_t need = oq_matmul_pieces_bytes(Kd, cols);
     OQ_REQUIRE(need != 0, OQ_ERR_UNSUPPORTED, "oq_matmul_prepare_f32: contraction of %lld too long", (long long)Kd);
     OQ_REQUIRE(pieces_bytes >= need && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_WORKSPACE,
                "oq_matmul_prepare_f32: a 256-byte aligned buffer of %zu bytes is needed, %zu given", need, pieces_bytes);
-    return make_f16x2_pieces(X, Kd, cols, ldx, contraction_is_fast_axis != 0, pieces, as_stream(stream), true);
+    return make_f16x2_pieces(X, Kd, cols, ldx, contraction_is_fast_axis != 0, pieces, as_stream(stream), true,
+                             per_row_scales ? matmul_row_scales(pieces, Kd, cols) : nullptr);
 }
 
 int32_t oq_matmul_pieces_f32(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
-                             int64_t ldc, void* stream) {
+                             int64_t ldc, int32_t a_per_row_scales, void* stream) {
     OQ_REQUIRE(pieces_a && pieces_b && C && matrix_ok(M, N, ldc) && extent_ok(Kd) && oq_matmul_pieces_bytes(Kd, M) != 0 &&
                oq_matmul_pieces_bytes(Kd, N) != 0 && (reinterpret_cast<uintptr_t>(pieces_a) & 255u) == 0 &&
                (reinterpret_cast<uintptr_t>(pieces_b) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT, "oq_matmul_pieces_f32: bad argument");
-    return launch_gemm_f16x3(pieces_a, pieces_b, M, N, Kd, alpha, beta, C, ldc, nullptr, as_stream(stream));
+    const float* unscale = a_per_row_scales ? matmul_row_scales(const_cast<void*>(pieces_a), Kd, M) + M : nullptr;
+    return launch_gemm_f16x3(pieces_a, pieces_b, M, N, Kd, alpha, beta, C, ldc, nullptr, as_stream(stream), false, false, false, unscale);
 }
 
 }  // extern "C"

@@ -121,7 +121,8 @@ int32_t launch_inverse_level_f16x3(const float* Lt, float* X, float* Y, float* S
 //                          instead of three: A with both pieces against B's first.
 size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols);
 int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s,
-                          bool wide_range = false);   // wide_range: a scale over the whole fp32 exponent range (plain GEMM operands; 1 / s^2 unset)
+                          bool wide_range = false,    // wide_range: a scale over the whole fp32 exponent range (plain GEMM operands; 1 / s^2 unset)
+                          float* row_scales = nullptr);   // [2 cols] (fast-axis sources only): one power-of-two scale per source row instead of one per operand
 // For a producer that writes the FIRST (hi) fp16 pieces of a row-major [Kd, cols] operand itself instead of handing a
 // fp32 matrix to make_f16x2_pieces* (awq.hip: the quantize-residual kernel, round 5).  The eight fp16 of rows 8c .. 8c + 7 of
 // column n (k ascending, each fl16(x * s), round to nearest even) are the 16-byte vector
@@ -136,7 +137,7 @@ int32_t make_f16x2_pieces_from_partials(const float* X, int64_t Kd, int64_t cols
                                         hipStream_t s, bool first_pieces_only = false);   // true: the lo plane is left untouched (consumers that read first pieces only)   // [Kd, cols] row-major source whose max |x| is already folded into `npart` device partials
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
                           int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only = false, bool dot_with_c = false,
-                          bool b_first_piece_only = false);
+                          bool b_first_piece_only = false, const float* row_unscale_a = nullptr);   // row_unscale_a [M]: A was split with per-row scales
 int64_t gemm_f16x3_tiles(int64_t M, int64_t N);
 
 }  // namespace oq

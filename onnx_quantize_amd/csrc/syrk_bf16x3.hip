@@ -883,6 +883,7 @@ struct PieceGemm {
     int64_t M, N, Mp, Np, nstages;
     const float* scale_a;   // device: [s, 1 / s^2, 1 / s] of A (absmax_scale_kernel)
     const float* scale_b;
+    const float* row_unscale_a = nullptr;   // optional: 1 / s_m per row m of the result (A split with one scale per column of A = row of its source)
     float alpha, beta;
     float* C;               // EPI 0: [M, N], leading dimension ldc
     int64_t ldc;
@@ -958,9 +959,10 @@ __device__ __forceinline__ void gemm_f16x3_body(const PieceGemm& g, const int ti
                 else for (int q = 0; q < 4 && col + q < g.N; ++q) old[q] = o[q];
             }
             f32x4v val;
+            const float ua_row = g.row_unscale_a != nullptr ? g.row_unscale_a[row] : ua;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float x = alpha * (v[q] * ua);
+                float x = alpha * (v[q] * ua_row);
                 if (g.beta != 0.0f) x = g.beta * old[q] + x;
                 val[q] = x;
             }
@@ -1117,15 +1119,40 @@ __global__ void inverse_level_plan_kernel(const InverseLevel lv, unsigned char* 
     gemms[n + q] = g2;
 }
 
+// One power-of-two scale per ROW of a [T, K] row-major source (one wave per row): s_t = 2^(15 - exponent of the row's largest
+// magnitude), clamped to 2^+-110; 1 for an all-zero or non-finite row.  scales[t] = s_t, scales[T + t] = 1 / s_t (exact).
+__global__ __launch_bounds__(256) void row_pow2_scales_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
+                                                              float* __restrict__ scales) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = X + t * ldx;
+    float m = 0.f;
+    for (int64_t k = lane; k < K; k += 64) m = nmax(m, fabsf(src[k]));
+    m = wave_max(m);
+    if (lane == 0) {
+        float sc = 1.0f;
+        if (m > 0.0f && m < INFINITY) {
+            int ex = 0;
+            (void)frexpf(m, &ex);
+            int e = 15 - ex;
+            e = e > 110 ? 110 : (e < -110 ? -110 : e);
+            sc = ldexpf(1.0f, e);
+        }
+        scales[t] = sc;
+        scales[T + t] = 1.0f / sc;
+    }
+}
+
 // Source with the contraction index as its FAST axis (X [T, K] row-major used as A = X^T: contraction over k, columns t):
 // pieces P[k / 8][piece][t padded to 256].  A thread takes one row t and 8 consecutive k (32 contiguous bytes).
 __global__ __launch_bounds__(256) void split_f16x2_fast_axis_kernel(const float* __restrict__ X, const int64_t T, const int64_t K, const int64_t ldx,
                                                                     const int64_t Tp, const int64_t nchunks, const float* __restrict__ scale,
-                                                                    u32x4* __restrict__ P) {
+                                                                    u32x4* __restrict__ P, const float* __restrict__ row_scale = nullptr) {
     const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     const bool ok = t < T;
     const float* src = X + (ok ? t : T - 1) * ldx;
-    const float sc = scale[0];
+    const float sc = row_scale != nullptr ? row_scale[ok ? t : T - 1] : scale[0];   // one power of two per row (plain GEMM operands) or per operand
     for (int64_t c = static_cast<int64_t>(blockIdx.y) * 4; c < nchunks && c < static_cast<int64_t>(blockIdx.y) * 4 + 4; ++c) {
         float v[8];
 #pragma unroll
@@ -1396,7 +1423,7 @@ size_t gemm_f16x3_pieces_bytes(int64_t Kd, int64_t cols) {
 }
 
 int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx, bool contraction_is_fast_axis, void* pieces, hipStream_t s,
-                          bool wide_range) {
+                          bool wide_range, float* row_scales) {
     OQ_REQUIRE(X && pieces && Kd > 0 && cols > 0 && (reinterpret_cast<uintptr_t>(pieces) & 255u) == 0, OQ_ERR_INVALID_ARGUMENT, "make_f16x2_pieces: bad argument");
     float* scale = static_cast<float*>(pieces);
     u32x4* P = reinterpret_cast<u32x4*>(static_cast<unsigned char*>(pieces) + kScaleHeaderBytes);
@@ -1409,8 +1436,14 @@ int32_t make_f16x2_pieces(const float* X, int64_t Kd, int64_t cols, int64_t ldx,
     if (wide_range) hipLaunchKernelGGL(absmax_scale_wide_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
     else hipLaunchKernelGGL(absmax_scale_kernel, dim3(1), dim3(256), 0, s, scale + 4, nb, scale);
     const dim3 grid(static_cast<uint32_t>(Cp / 256), static_cast<uint32_t>(ceil_div(nchunks, 4)));
+    if (row_scales != nullptr) {   // one scale per row of the source (= per row of the product): row_scales[t] = s_t, [cols + t] = 1 / s_t
+        OQ_REQUIRE(contraction_is_fast_axis, OQ_ERR_INVALID_ARGUMENT, "make_f16x2_pieces: per-row scales need the contraction on the fast axis");
+        hipLaunchKernelGGL(row_pow2_scales_kernel, dim3(static_cast<uint32_t>(ceil_div(cols, 4))), dim3(256), 0, s, X, cols, Kd, ldx, row_scales);
+        hipLaunchKernelGGL(split_f16x2_fast_axis_kernel, grid, dim3(256), 0, s, X, cols, Kd, ldx, Cp, nchunks, scale, P, static_cast<const float*>(row_scales));
+        return check_launch("split_f16x2 (gemm pieces, per-row scales)");
+    }
     if (contraction_is_fast_axis)
-        hipLaunchKernelGGL(split_f16x2_fast_axis_kernel, grid, dim3(256), 0, s, X, cols, Kd, ldx, Cp, nchunks, scale, P);
+        hipLaunchKernelGGL(split_f16x2_fast_axis_kernel, grid, dim3(256), 0, s, X, cols, Kd, ldx, Cp, nchunks, scale, P, static_cast<const float*>(nullptr));
     else   // alpha = 0: no dead-channel guard (only the Hessian needs a vanishing sample to stay visible)
         hipLaunchKernelGGL(split_f16x2_kernel, grid, dim3(256), 0, s, X, Kd, cols, ldx, Cp, nchunks, scale, 0.0f, P);
     return check_launch("split_f16x2 (gemm pieces)");
@@ -1436,7 +1469,8 @@ size_t gemm_f16x3_header_bytes() { return kScaleHeaderBytes; }
 int64_t gemm_f16x3_padded_cols(int64_t cols) { return padded_k(cols); }
 int64_t gemm_f16x3_chunks(int64_t Kd) { return stages_of(Kd, StageGeom<3>::ROWS) * StageGeom<3>::CH; }
 int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M, int64_t N, int64_t Kd, float alpha, float beta, float* C,
-                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only, bool dot_with_c, bool b_first_piece_only) {
+                          int64_t ldc, float* loss_partial, hipStream_t s, bool hi_pieces_only, bool dot_with_c, bool b_first_piece_only,
+                          const float* row_unscale_a) {
     OQ_REQUIRE(pieces_a && pieces_b && M > 0 && N > 0 && Kd > 0 && ((C != nullptr) != (loss_partial != nullptr) || dot_with_c), OQ_ERR_INVALID_ARGUMENT,
                "gemm_f16x3: bad argument");
     OQ_REQUIRE(!hi_pieces_only || (loss_partial && !dot_with_c), OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: the one-product form exists for the sum-of-squares epilogue only");
@@ -1448,6 +1482,8 @@ int32_t launch_gemm_f16x3(const void* pieces_a, const void* pieces_b, int64_t M,
     g.PB = reinterpret_cast<const u32x4*>(static_cast<const unsigned char*>(pieces_b) + kScaleHeaderBytes);
     g.M = M; g.N = N; g.Mp = padded_k(M); g.Np = padded_k(N); g.nstages = stages_of(Kd, StageGeom<3>::ROWS);
     g.alpha = alpha; g.beta = beta; g.C = C; g.ldc = ldc; g.partial = loss_partial;
+    OQ_REQUIRE(row_unscale_a == nullptr || (C != nullptr && loss_partial == nullptr), OQ_ERR_INVALID_ARGUMENT, "gemm_f16x3: per-row scales exist for the store form only");
+    g.row_unscale_a = row_unscale_a;
     const int64_t tiles = (g.Mp / kST) * (g.Np / kST);
     OQ_REQUIRE(tiles < (1 << 30), OQ_ERR_UNSUPPORTED, "gemm_f16x3: too many tiles");
     const int lds_bytes = StageGeom<3>::LDS;

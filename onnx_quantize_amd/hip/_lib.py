@@ -63,8 +63,8 @@ PROTOTYPES = {
     "oq_hessian_prepare_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _p, _sz, _p]),
     "oq_hessian_accumulate_prepared_f32": (_i32, [_p, _i64, _i64, _i64, _i64, _p, _p, _sz, _p]),
     "oq_matmul_pieces_bytes": (_sz, [_i64, _i64]),
-    "oq_matmul_prepare_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _p, _sz, _p]),
-    "oq_matmul_pieces_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _f32, _p, _i64, _p]),
+    "oq_matmul_prepare_f32": (_i32, [_p, _i64, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "oq_matmul_pieces_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _f32, _p, _i64, _i32, _p]),
     "oq_awq_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "oq_awq_scale_search_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _sz, _p]),
     "oq_awq_clip_search_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),

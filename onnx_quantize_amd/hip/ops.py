@@ -832,10 +832,10 @@ class MatmulOperand:
     """One operand of `matmul_pieces` split into fp16 pieces on the device (`oq_matmul_prepare_f32`).  A constant weight is
     prepared once and reused for every batch of the calibration walk."""
 
-    __slots__ = ("pieces", "kd", "cols")
+    __slots__ = ("pieces", "kd", "cols", "per_row")
 
-    def __init__(self, pieces, kd, cols):
-        self.pieces, self.kd, self.cols = pieces, kd, cols
+    def __init__(self, pieces, kd, cols, per_row=False):
+        self.pieces, self.kd, self.cols, self.per_row = pieces, kd, cols, per_row
 
 
 def _aligned_bytes(nbytes: int, device) -> torch.Tensor:
@@ -844,8 +844,9 @@ def _aligned_bytes(nbytes: int, device) -> torch.Tensor:
     return buf[off:off + nbytes]
 
 
-def matmul_prepare(t: torch.Tensor, contraction_is_fast_axis: bool) -> MatmulOperand:
-    """``t`` [cols, Kd] (activations: contraction on the fast axis) or [Kd, cols] (a weight) -> its fp16 pieces."""
+def matmul_prepare(t: torch.Tensor, contraction_is_fast_axis: bool, per_row: bool = False) -> MatmulOperand:
+    """``t`` [cols, Kd] (activations: contraction on the fast axis) or [Kd, cols] (a weight) -> its fp16 pieces.  ``per_row``
+    (activations only): one power-of-two scale per row instead of one for the operand."""
     _require_device(t, "operand", torch.float32)
     if t.dim() != 2:
         raise ValueError(f"matmul_prepare takes a matrix, got {tuple(t.shape)}")
@@ -856,25 +857,26 @@ def matmul_prepare(t: torch.Tensor, contraction_is_fast_axis: bool) -> MatmulOpe
     if need == 0:
         raise ValueError(f"matmul_prepare: an operand of {kd} x {cols} is too large for the piece kernels")
     pieces = _aligned_bytes(need, t2.device)
-    L.check(lib.oq_matmul_prepare_f32(_ptr(t2), kd, cols, ld, 1 if contraction_is_fast_axis else 0, _ptr(pieces), need, _stream()))
-    return MatmulOperand(pieces, kd, cols)
+    L.check(lib.oq_matmul_prepare_f32(_ptr(t2), kd, cols, ld, 1 if contraction_is_fast_axis else 0, 1 if per_row else 0, _ptr(pieces), need,
+                                      _stream()))
+    return MatmulOperand(pieces, kd, cols, bool(per_row))
 
 
 def matmul_pieces(x: torch.Tensor, w: MatmulOperand | torch.Tensor) -> torch.Tensor:
     """``x`` [..., Kd] fp32 times a weight [Kd, N] (a tensor, or its `matmul_prepare(w, False)` pieces) on the fp16 matrix
     cores with two-piece operands: 22 significand bits per operand, fp32 accumulate -- the arithmetic of the Hessian
-    kernels.  Returns [..., N] fp32.  Each operand is scaled as a whole by a power of two (any magnitude fp32 can hold), so the
-    22 bits hold for elements within ~2^18 of the operand's largest; far smaller ones keep fewer (fp16's exponent range) --
-    activations with their outliers are well inside, a row 10^10 times smaller than another one of the same batch is not."""
+    kernels.  Returns [..., N] fp32.  The weight is scaled as a whole and every ROW of ``x`` on its own by a power of two (any
+    magnitude fp32 can hold): the 22 bits hold for elements within ~2^18 of their row's (the weight's) largest, whatever the other
+    rows of the batch hold."""
     _require_device(x, "x", torch.float32)
     if not isinstance(w, MatmulOperand):
         w = matmul_prepare(w, False)
     x2 = x.reshape(-1, x.shape[-1])
     if x2.shape[1] != w.kd:
         raise ValueError(f"matmul_pieces: x has {x2.shape[1]} columns, the weight {w.kd} rows")
-    a = matmul_prepare(x2, True)
+    a = matmul_prepare(x2, True, per_row=True)               # every row (token) keeps its own 22 bits, whatever its neighbours hold
     out = torch.empty((x2.shape[0], w.cols), dtype=torch.float32, device=x.device)
-    L.check(L.load().oq_matmul_pieces_f32(_ptr(a.pieces), _ptr(w.pieces), x2.shape[0], w.cols, w.kd, 1.0, 0.0, _ptr(out), w.cols, _stream()))
+    L.check(L.load().oq_matmul_pieces_f32(_ptr(a.pieces), _ptr(w.pieces), x2.shape[0], w.cols, w.kd, 1.0, 0.0, _ptr(out), w.cols, 1, _stream()))
     return out.reshape(*x.shape[:-1], w.cols)
 
 

@@ -318,6 +318,13 @@ def test_large_products_of_the_calibration_walk_take_the_fp16_piece_gemm():
         big = ops.matmul_pieces(x * factor, w)
         assert (((big.double() - ref * factor).norm() / (ref * factor).norm()).item()) < 2e-6, factor
     assert ops.matmul_pieces(torch.zeros_like(x), w).abs().max().item() == 0.0
+    # rows of very different magnitude in one batch: every row is scaled on its own, so each keeps its bits
+    mixed = x.reshape(-1, 1024).clone()
+    mixed[7] *= 1e-9
+    mixed[11, 3] = 5e4
+    ref3 = mixed.double() @ w.double()
+    rows = ((ops.matmul_pieces(mixed, w).double() - ref3).norm(dim=1) / ref3.norm(dim=1))
+    assert rows.max().item() < 2e-6, rows.max().item()
     # in the runner: one big MatMul (pieces) feeding one small (torch)
     g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["b", "t", 1024])], output=[P.make_value_info("y", 1, None)],
                   node=[P.make_node("MatMul", ["x", "w"], ["h"], name="big"), P.make_node("MatMul", ["h", "v"], ["y"], name="small")],
