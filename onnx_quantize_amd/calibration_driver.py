@@ -91,7 +91,7 @@ class ActivationStream:
 
     def __init__(self, *, calibrator=None, input_names: Iterable[str] = (), output_names: Iterable[str] = (),
                  hessian_names: Iterable[str] = (), absmax_names: Iterable[str] = (), keep_names: Iterable[str] = (),
-                 hessian_streams: int = 0, statistics_names: Iterable[str] = ()):
+                 hessian_streams: int = 0, statistics_names: Iterable[str] = (), statistics_after_bytes: int = 8 << 30):
         self.calibrator = calibrator if calibrator is not None else MinMaxCalibrator()
         self.input_names, self.output_names = list(dict.fromkeys(input_names)), list(dict.fromkeys(output_names))
         self.hessian_names, self.absmax_names = set(hessian_names), set(absmax_names)
@@ -100,6 +100,13 @@ class ActivationStream:
         # Gram matrix, |x| sums and maxima) instead of the activations themselves -- `keep_names` without the memory
         self.statistics_names = set(statistics_names)
         self.statistics: dict = {}
+        # ... but only once it matters: up to `statistics_after_bytes` of them the batches are simply held (a small model's
+        # walk costs nothing that way and the searches see the reference's arrays); past it, what is held is folded into the
+        # statistics and every later batch goes straight there
+        self.statistics_after_bytes = int(statistics_after_bytes)
+        self._held_for_search: dict[str, list] = {}
+        self._held_bytes = 0
+        self._search_inputs: dict = {}
         self.hessians: dict[str, HessianAccumulator] = {}
         # 0 (default): the Hessian updates of a batch in one grouped launch chain (per-tensor calls on 4 side streams when a
         # Hessian method the grouped chain does not run is selected); n > 0: per-tensor calls on n side streams
@@ -175,11 +182,24 @@ class ActivationStream:
             x = activations[name]
             cur = ops.absmax(x if x.dtype == torch.float32 else x.to(torch.float32))
             self.absmax[name] = cur if name not in self.absmax else torch.maximum(self.absmax[name], cur)
-        for name in self.statistics_names & activations.keys():
-            x = activations[name]
-            if name not in self.statistics:
-                self.statistics[name] = ops.SearchStatistics(x.shape[-1], x.device)
-            self.statistics[name].add(x)
+        names = sorted(self.statistics_names & activations.keys())
+        if names and not self.statistics and self._held_bytes <= self.statistics_after_bytes:
+            for name in names:
+                self._held_for_search.setdefault(name, []).append(activations[name])
+                self._held_bytes += activations[name].numel() * activations[name].element_size()
+            if self._held_bytes > self.statistics_after_bytes:         # too much to hold: fold what is there, stream from now on
+                held, self._held_for_search = self._held_for_search, {}
+                for name, batches in held.items():
+                    self.statistics[name] = ops.SearchStatistics(batches[0].shape[-1], batches[0].device)
+                for i in range(max(len(b) for b in held.values())):
+                    part = [n for n in held if i < len(held[n])]
+                    ops.SearchStatistics.add_many([self.statistics[n] for n in part], [held[n][i] for n in part])
+        elif names:
+            for name in names:
+                if name not in self.statistics:
+                    x = activations[name]
+                    self.statistics[name] = ops.SearchStatistics(x.shape[-1], x.device)
+            ops.SearchStatistics.add_many([self.statistics[n] for n in names], [activations[n] for n in names])
         for name in self.keep_names & activations.keys():
             self._kept.setdefault(name, []).append(activations[name])
         self.batches += 1
@@ -212,6 +232,20 @@ class ActivationStream:
         for per_batch in self._extrema:                                  # the second walk, from the recorded extrema
             self.calibrator.collect_many({n: st[:2] for n, st in per_batch.items()})
         self._extrema = []
+
+    def search_input(self, name: str):
+        """What the AWQ / SmoothQuant searches get for the value `name` (`statistics_names`): its batches concatenated along axis
+        0 while the walk could hold them (calibrate.py:301-302), its `ops.SearchStatistics` once it could not.  One object per
+        name, whoever asks."""
+        if name not in self._search_inputs:
+            import torch
+            if name in self.statistics:
+                self._search_inputs[name] = self.statistics[name]
+            elif name in self._held_for_search:
+                self._search_inputs[name] = torch.cat(self._held_for_search.pop(name), dim=0)
+            else:
+                raise KeyError(name)
+        return self._search_inputs[name]
 
     def kept(self, name: str):
         """calibrate.py:301-302: the batches of one kept activation concatenated along axis 0 (on the device)."""

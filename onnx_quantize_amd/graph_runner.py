@@ -154,7 +154,8 @@ class GraphRunner:
         """One pass.  Without `sink` the wanted values come back as a dict.  With `sink(name, tensor)` every wanted value is handed
         over the moment it exists and is not held any longer than the graph itself needs it (a 7B-width walk taps ~50 GB of
         activations per batch; consumed one by one they never coexist); the dict returned is then empty.  Recorded passes (small
-        inputs) always produce the dict and hand it to the sink afterwards."""
+        inputs) return the dictionary whatever `sink` is: their values are small, and consumers that take a whole batch of
+        tensors in one grouped launch (`collect_many`, `hessian_accumulate_many`) are better served by it."""
         import torch
 
         if not isinstance(feed, Mapping):
@@ -170,12 +171,7 @@ class GraphRunner:
             inputs[name] = t.to(self.device, non_blocking=True)
         if not self.capture or sum(t.numel() for t in inputs.values()) > _CAPTURE_MAX_INPUT_ELEMENTS:
             return self._eager(inputs, sink)                  # (a large pass is bound by its kernels, not by their dispatch)
-        out = self._recorded(inputs)
-        if sink is None:
-            return out
-        for name, t in out.items():
-            sink(name, t)
-        return {}
+        return self._recorded(inputs)                         # small passes: the whole dictionary at once (one grouped launch for its consumers)
 
     def _recorded(self, inputs) -> dict:
         key = tuple(sorted((name, tuple(t.shape), str(t.dtype)) for name, t in inputs.items()))

@@ -719,6 +719,27 @@ class SearchStatistics:
         self.absmax = torch.maximum(self.absmax, absmax(x2))
         self.rows = hessian_accumulate(x2, self.gram, self.rows)            # rows as samples: gram = (2 / rows) X^T X
 
+    @staticmethod
+    def add_many(stats: "list[SearchStatistics]", xs) -> None:
+        """`add` for several values of one batch: the Gram updates in ONE grouped launch chain (`hessian_accumulate_many`: a batch of
+        a small model is dozens of small products, launch-bound one at a time)."""
+        flat = []
+        for x in xs:
+            x2 = _flat_inputs(x if x.dtype == torch.float32 else x.to(torch.float32))
+            flat.append(_row_major(x2)[0])
+        lib = L.load()
+        for st, x2 in zip(stats, flat):
+            t, k = x2.shape
+            ws = _workspace(lib.oq_abs_sum_cols_workspace_bytes(k), x2.device)
+            L.check(lib.oq_abs_sum_cols_f32(_ptr(x2), t, k, x2.stride(0), _ptr(st.abs_sum), 1, _ptr(ws), ws.numel(), _stream()))
+            st.absmax = torch.maximum(st.absmax, absmax(x2))
+        if hessian_method() in ("auto", "f16x3"):
+            for st, n in zip(stats, hessian_accumulate_many(flat, [st.gram for st in stats], [st.rows for st in stats])):
+                st.rows = n
+        else:
+            for st, x2 in zip(stats, flat):
+                st.rows = hessian_accumulate(x2, st.gram, st.rows)
+
     def divide(self, scale: torch.Tensor) -> None:
         s = scale.to(self.gram.device, torch.float32).reshape(-1)
         self.abs_sum /= s

@@ -49,6 +49,9 @@ __all__ = ["quantize_model", "quantize_model_sharded", "quantize_file", "apply_p
 
 logger = logging.getLogger("onnx_quantize")
 
+# AWQ / SmoothQuant: how much of the tapped activations a calibration walk holds before it folds them into running statistics
+# (`ActivationStream.statistics_after_bytes`); a small model stays on the reference's arrays, a 7B-class model could not hold them
+STATISTICS_AFTER_BYTES = 8 << 30
 _MIN_SOURCE_OPSET = 13
 # operators whose node form changed between opset 13 and 21 in a way this module does not adapt (version_converter would)
 _NOT_ADAPTED = {"DFT": 20, "GridSample": 20, "GroupNormalization": 21, "RoiAlign": 16, "Resize": 18, "Pad": 18, "ScatterElements": 18,
@@ -434,7 +437,8 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
     a `StreamedGptqInput` (the Hessian of the node's input) when only the weight algorithm needs the activations, or -- with
     `keep_inputs`, ahead of AWQ / SmoothQuant, which read and rescale the activations themselves -- the batches concatenated in
     HBM (calibrate.py:296-307), or, with `keep_inputs="statistics"` (the default of the device searches), what those searches
-    need of them as running statistics (`ops.SearchStatistics`: Gram matrix, |x| sums and maxima; no batch is held).  Nodes that
+    need of them as running statistics (`ops.SearchStatistics`: Gram matrix, |x| sums and maxima) once the walk has tapped more
+    than it should hold (`ActivationStream.statistics_after_bytes`, 8 GiB; below that the batches themselves).  Nodes that
     read the same value share ONE object either way, as they share one array in the reference."""
     from .calibration import get_calibrator
     from .calibration_driver import ActivationStream, generate_random_calibration_data, run_calibration
@@ -462,7 +466,7 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
     stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
                               hessian_names=in_names if (algo and not keep_inputs) else (),
                               keep_names=in_names if keep_inputs is True else (),
-                              statistics_names=in_names if keep_inputs == "statistics" else ())
+                              statistics_names=in_names if keep_inputs == "statistics" else (), statistics_after_bytes=STATISTICS_AFTER_BYTES)
     run_calibration(runner, data, stream, num_samples=num_samples, batch_size=batch_size, input_names=[i[0] for i in inputs])
     G.device_values = {name: t for name, t in runner.constants.items() if t.is_cuda and t.ndim == 2}
     meta: dict = {id(n): {} for n in targets}
@@ -478,8 +482,10 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
                 meta[id(n)][f"{kind}_zero_point"] = np.asarray(zp).astype(aargs.zp_dtype, copy=False)
     if keep_inputs == "statistics":
         for n, name in zip(targets, in_names):
-            if name in stream.statistics:
-                meta[id(n)]["input"] = stream.statistics[name]      # one object per value name: shared by its consumers
+            try:
+                meta[id(n)]["input"] = stream.search_input(name)    # one object per value name: shared by its consumers
+            except KeyError:
+                pass                                                # a value the calibration data never reached
     elif keep_inputs:
         kept: dict = {}
         for n, name in zip(targets, in_names):
@@ -564,7 +570,7 @@ def _divide_in_place(x, scale: np.ndarray) -> None:
         return
     import torch
     s = torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32))
-    if hasattr(x, "divide"):                                # ops.SearchStatistics: the same rescale on the running statistics
+    if hasattr(x, "abs_sum"):                               # ops.SearchStatistics: the same rescale on the running statistics
         x.divide(s)
         return
     x.div_(s.to(x.device).reshape(1, -1))

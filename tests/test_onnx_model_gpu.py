@@ -242,6 +242,34 @@ def test_preprocessed_files_follow_the_oracle_files(kind, weights):
     assert abs(err(got) - err(want)) < 0.02 and err(got) < (0.02 if kind == "smooth" else 0.12)
 
 
+@pytest.mark.parametrize("kind,weights", [("smooth", dict(dtype=QuantType.QInt8, group_size=-1)), ("awq_clip", dict(dtype=QuantType.QInt4, group_size=32))])
+def test_searches_from_running_statistics_decide_like_the_searches_on_the_arrays(kind, weights, monkeypatch):
+    """Past `STATISTICS_AFTER_BYTES` of tapped activations the walk folds them into `ops.SearchStatistics` (Gram matrix, |x| sums
+    and maxima) and the searches run on those: the same scales (to the tolerance between the Gram and the direct loss), the same
+    clip ratios, the same file up to the integers a slightly different scale moves."""
+    import onnx_quantize_amd.model_quantize as MQ
+    gen = torch.Generator().manual_seed(8)
+    data = (torch.randn(32, 6, 64, generator=gen) * torch.linspace(0.2, 4.0, 64)).numpy()
+    src = fixture("block")
+    on_arrays = quantize_model(src, _pre_cfg(kind, data, **weights))
+    monkeypatch.setattr(MQ, "STATISTICS_AFTER_BYTES", 100_000)               # the second batch already goes over: held ones are folded
+    on_statistics = quantize_model(src, _pre_cfg(kind, data, **weights))
+    a, b = _calls_and_scales(on_arrays), _calls_and_scales(on_statistics)
+    assert list(a) == list(b) and len(a) == 6
+    same = 0
+    for name in a:
+        (na, sa, qa, pa), (nb, sb, qb, pb) = a[name], b[name]
+        assert (na.op_type, list(na.input)) == (nb.op_type, list(nb.input))
+        if np.allclose(sa, sb, rtol=2e-5):
+            same += 1
+            assert (qa != qb).mean() < 0.01, name
+    assert same >= (6 if kind == "smooth" else 4), (kind, same)
+    feed = torch.from_numpy(data[:4])
+    y0 = GraphRunner(src, device="cuda")(feed)["y"]
+    err = lambda m: ((GraphRunner(m, device="cuda")(feed)["y"] - y0).norm() / y0.norm()).item()      # noqa: E731
+    assert abs(err(on_arrays) - err(on_statistics)) < 0.02
+
+
 def test_awq_improves_on_rtn_through_the_file_path():
     """Outlier input channels (the situation AWQ is for): the AWQ file is closer to the float model than the RTN file."""
     gen = torch.Generator().manual_seed(12)
