@@ -10,6 +10,11 @@ operators so that the graph runs), written by this package's own writer with its
 
     python bench_model.py --layers 4 --config uint4_g128          # weight-only, MatMulNBits (BASELINE config 2's rule)
     python bench_model.py --layers 2 --config static_int8         # calibrated on the GPU (config 3's rule), random data
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench_model.py --layers 32 --config gptq_int4_g128
+                                                                  # one rank per GPU: `quantize_model_sharded` (BASELINE config 5's shape:
+                                                                  # every rank maps the file and walks it, the weights are spread, rank 0
+                                                                  # gathers and writes).  OQ_BENCH_REHEARSAL=1: the ranks share cuda:0 over
+                                                                  # gloo (the code path on a one-GPU box, not a scaling measurement)
 """
 import argparse
 import json
@@ -107,31 +112,57 @@ def run(args) -> dict:
                 return out
             return wrapper
         MQ._calibrate, MQ._preprocess, MQ.plan_node = timed("calibrate_s", MQ._calibrate), timed("searches_s", MQ._preprocess), timed("seam_s", MQ.plan_node)
-    work = args.dir or tempfile.mkdtemp(prefix="oq_bench_model_")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    rehearsal = os.environ.get("OQ_BENCH_REHEARSAL", "0") == "1"
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(0 if rehearsal else local)
+        dist.init_process_group("gloo" if rehearsal else "nccl")
+    work = args.dir or (tempfile.mkdtemp(prefix="oq_bench_model_") if world == 1 else os.path.join(tempfile.gettempdir(), "oq_bench_model_ranks"))
     os.makedirs(work, exist_ok=True)
     src, dst = os.path.join(work, "model.onnx"), os.path.join(work, "model_q.onnx")
     t0 = time.perf_counter()
-    model = build_model(args.layers, args.hidden, args.ffn)
-    params = sum(int(np.prod(t.dims)) for t in model.graph.initializer)
-    P.save_model(model, src, external_data="model.onnx.data")
-    del model
+    params = 0
+    if rank == 0:                                              # one source file for all ranks (they memory-map it)
+        model = build_model(args.layers, args.hidden, args.ffn)
+        params = sum(int(np.prod(t.dims)) for t in model.graph.initializer)
+        P.save_model(model, src, external_data="model.onnx.data")
+        del model
     t_build = time.perf_counter() - t0
     data = torch.randn(args.samples, args.seq, args.hidden, generator=torch.Generator().manual_seed(1)).numpy()
     torch.cuda.init()
     torch.zeros(1, device="cuda")
+    if world > 1:
+        dist.barrier()
     runs = []
     for r in range(args.repeat):
         t0 = time.perf_counter()
         loaded = P.load_model(src)
         t1 = time.perf_counter()
-        out = quantize_model(loaded, configs(args.config, data))
+        if world > 1:
+            from onnx_quantize_amd.model_quantize import quantize_model_sharded
+            out = quantize_model_sharded(loaded, configs(args.config, data))
+        else:
+            out = quantize_model(loaded, configs(args.config, data))
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t2 = time.perf_counter()
-        P.save_model(out, dst, external_data="model_q.onnx.data")
+        if rank == 0:
+            P.save_model(out, dst, external_data="model_q.onnx.data")
         t3 = time.perf_counter()
         runs.append({"load_s": round(t1 - t0, 4), "quantize_s": round(t2 - t1, 4), "save_s": round(t3 - t2, 4), "total_s": round(t3 - t0, 4), **phases})
         phases.clear()
         del loaded
+    if world > 1:
+        times = [None] * world
+        dist.all_gather_object(times, runs)
+        runs = [{k: max(t[i][k] for t in times) for k in runs[i]} for i in range(len(runs))]        # the slowest rank's clock
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return None
     out_bytes = os.path.getsize(dst) + os.path.getsize(dst + ".data")
     calls = sorted({(n.op_type, n.domain) for n in out.graph.node if n.domain})
     best = min(runs, key=lambda r: r["total_s"])
@@ -139,7 +170,9 @@ def run(args) -> dict:
             "source_bytes": os.path.getsize(src) + os.path.getsize(src + ".data"), "result_bytes": out_bytes, "calls": calls,
             "build_source_s": round(t_build, 2), "runs": runs, "best": best,
             "mparam_per_s_file_to_file": round(params / best["total_s"] / 1e6, 1),
-            "source_gb_per_s_quantize_phase": round(params * 4 / best["quantize_s"] / 1e9, 2)}
+            "source_gb_per_s_quantize_phase": round(params * 4 / best["quantize_s"] / 1e9, 2), "n_gpus": world}
+    if world > 1 and rehearsal:
+        line["rehearsal"] = "ranks share one GPU, collectives on gloo: the multi-rank code path executed, NOT a scaling measurement"
     if args.config in ("uint4_g128", "int4_g128", "int8_tensor"):              # the file holds what the kernels produce on that weight
         from onnx_quantize_amd.hip import ops
         source = P.load_model(src)
@@ -159,7 +192,9 @@ def run(args) -> dict:
 
 
 def main():
-    print(json.dumps(run(build_parser().parse_args())))
+    line = run(build_parser().parse_args())
+    if line is not None:
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":
