@@ -291,7 +291,7 @@ def resolve_external_data(model: Message, base_dir) -> int:
     onnx.proto's external_data; the location must stay inside `base_dir`).  Returns the number of tensors mapped."""
     maps: dict = {}
     count = 0
-    base_dir = os.path.abspath(base_dir)
+    base_dir = os.path.realpath(base_dir)
     for t in ([] if model.graph is None else _tensors_of(model.graph)):
         if not t.data_location:
             continue
@@ -299,7 +299,7 @@ def resolve_external_data(model: Message, base_dir) -> int:
         location = info.get("location")
         if not location:
             raise ValueError(f"onnx_proto: tensor '{t.name}' is external but names no location")
-        path = os.path.abspath(os.path.join(base_dir, location))
+        path = os.path.realpath(os.path.join(base_dir, location))       # symbolic links resolved: the bytes must live inside the directory
         if os.path.commonpath([base_dir, path]) != base_dir:
             raise ValueError(f"onnx_proto: tensor '{t.name}': external data location '{location}' leaves the model's directory")
         if path not in maps:

@@ -222,6 +222,13 @@ def test_external_tensor_data_is_mapped_on_load_and_written_back(tmp_path):
     evil.graph.initializer[0].external_data[0].value = "../m.onnx.data"
     with pytest.raises(ValueError, match="leaves the model's directory"):
         P.resolve_external_data(evil, tmp_path)
+    outside = tmp_path.parent / f"{tmp_path.name}_outside.data"
+    outside.write_bytes(b"\0" * 4096)
+    (tmp_path / "link.data").symlink_to(outside)                          # a link out of the directory is a way out of it
+    evil = P.load_model(path, load_external_data=False)
+    evil.graph.initializer[0].external_data[0].value = "link.data"
+    with pytest.raises(ValueError, match="leaves the model's directory"):
+        P.resolve_external_data(evil, tmp_path)
     evil = P.load_model(path, load_external_data=False)
     next(e for e in evil.graph.initializer[0].external_data if e.key == "length").value = str(1 << 40)
     with pytest.raises(ValueError, match="outside"):
