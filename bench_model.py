@@ -97,7 +97,18 @@ def build_parser():
 
 def run(args) -> dict:
     """One file -> file measurement (also the `model_file` object of bench.py's line).  The result is verified: one weight's
-    MatMulNBits blob / grouped integers in the emitted file against the kernels' own output on the same weight."""
+    MatMulNBits blob / grouped integers in the emitted file against the kernels' own output on the same weight.  The temporary
+    directory with the (multi-GB) source goes away whatever happens."""
+    made: list = []
+    try:
+        return _run(args, made)
+    finally:
+        if args.dir is None and int(os.environ.get("RANK", "0")) == 0:
+            for d in made:
+                shutil.rmtree(d, ignore_errors=True)
+
+
+def _run(args, made) -> dict:
     phases: dict = {}
     if args.phases:
         import onnx_quantize_amd.model_quantize as MQ
@@ -121,6 +132,7 @@ def run(args) -> dict:
         dist.init_process_group("gloo" if rehearsal else "nccl")
     work = args.dir or (tempfile.mkdtemp(prefix="oq_bench_model_") if world == 1 else os.path.join(tempfile.gettempdir(), "oq_bench_model_ranks"))
     os.makedirs(work, exist_ok=True)
+    made.append(work)
     src, dst = os.path.join(work, "model.onnx"), os.path.join(work, "model_q.onnx")
     t0 = time.perf_counter()
     params = 0
@@ -186,8 +198,6 @@ def run(args) -> dict:
         else:
             want, _, _ = ops.rtn_quantize(w, "int8", "tensor", -1, True)
         line["verified"] = bool(torch.equal(got.view(torch.uint8).reshape(-1), want.cpu().view(torch.uint8).reshape(-1)))
-    if args.dir is None:
-        shutil.rmtree(work, ignore_errors=True)
     return line
 
 
