@@ -514,6 +514,70 @@ class GraphRunner:
             raise UnsupportedOperator("GraphRunner: BatchNormalization in training mode")
         return torch.nn.functional.batch_norm(x[0], x[3], x[4], x[1], x[2], False, 0.0, a.get("epsilon", 1e-5))
 
+    def _op_Pad(self, n, x, a, e):
+        import torch
+        t = x[0]
+        pads = a["pads"] if len(x) < 2 else _ints(x[1])                          # opset < 11: attributes
+        value = a.get("value", 0.0) if len(x) < 2 else (x[2].item() if len(x) > 2 and x[2] is not None and x[2].numel() else 0)
+        axes = _ints(x[3]) if len(x) > 3 and x[3] is not None else list(range(t.ndim))
+        mode = a.get("mode", "constant")
+        begin, end = [0] * t.ndim, [0] * t.ndim
+        for j, ax in enumerate(axes):
+            begin[ax], end[ax] = pads[j], pads[len(axes) + j]
+        for ax in range(t.ndim):                                                 # negative pads crop
+            lo, hi = max(0, -begin[ax]), t.shape[ax] - max(0, -end[ax])
+            if lo or hi != t.shape[ax]:
+                t = t.narrow(ax, lo, max(0, hi - lo))
+        begin, end = [max(0, b) for b in begin], [max(0, b) for b in end]
+        if not any(begin) and not any(end):
+            return t
+        flat = [v for ax in reversed(range(t.ndim)) for v in (begin[ax], end[ax])]   # torch: last axis first
+        if mode == "constant":
+            return torch.nn.functional.pad(t, flat, value=value)
+        torch_mode = {"reflect": "reflect", "edge": "replicate", "wrap": "circular"}.get(mode)
+        padded = [ax for ax in range(t.ndim) if begin[ax] or end[ax]]
+        if torch_mode is None or not padded or padded[0] < t.ndim - 3 or t.ndim < 2:
+            raise UnsupportedOperator(f"GraphRunner: Pad (node '{n.name}') with mode '{mode}' on axes {padded} of a rank-{t.ndim} value")
+        spatial = t.ndim - padded[0]                                             # torch pads the last 1-3 axes of a batched value
+        lead = t.shape[:t.ndim - spatial]
+        out = torch.nn.functional.pad(t.reshape(1, -1, *t.shape[t.ndim - spatial:]), flat[:2 * spatial], mode=torch_mode)
+        return out.reshape(*lead, *out.shape[2:])
+
+    def _op_Resize(self, n, x, a, e):
+        import torch
+        t = x[0]
+        scales = x[2] if len(x) > 2 and x[2] is not None and x[2].numel() else None
+        sizes = _ints(x[3]) if len(x) > 3 and x[3] is not None and x[3].numel() else None
+        if a.get("axes", None) is not None or a.get("antialias", 0) or a.get("keep_aspect_ratio_policy", "stretch") != "stretch":
+            raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') with axes / antialias / keep_aspect_ratio_policy")
+        if sizes is None:
+            if scales is None:
+                raise ValueError(f"node '{n.name}': Resize needs scales or sizes")
+            factors = [float(v) for v in scales.tolist()]
+            sizes = [int(d * f) for d, f in zip(t.shape, factors)]              # floor, like the operator
+        else:
+            factors = None
+        if t.ndim < 3 or list(sizes[:2]) != list(t.shape[:2]):
+            raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') of the batch or channel axis")
+        mode, coord = a.get("mode", "nearest"), a.get("coordinate_transformation_mode", "half_pixel")
+        out_size = sizes[2:]
+        if mode == "nearest":
+            if coord == "asymmetric" and a.get("nearest_mode", "round_prefer_floor") == "floor":
+                # torch's "nearest" is floor(i * scale); it must be handed the operator's scale, not the ratio of the sizes
+                kw = dict(scale_factor=factors[2:], recompute_scale_factor=False) if factors else dict(size=out_size)
+                return torch.nn.functional.interpolate(t, mode="nearest", **kw)
+            raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') nearest with {coord} / {a.get('nearest_mode', 'round_prefer_floor')}")
+        if mode in ("linear", "cubic"):
+            torch_mode = {("linear", 1): "linear", ("linear", 2): "bilinear", ("linear", 3): "trilinear", ("cubic", 2): "bicubic"}.get((mode, t.ndim - 2))
+            if torch_mode is None or coord not in ("half_pixel", "pytorch_half_pixel", "align_corners") or \
+                    (mode == "cubic" and abs(a.get("cubic_coeff_a", -0.75) + 0.75) > 1e-6):
+                raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') {mode} with {coord} on {t.ndim - 2} axes")
+            if coord == "pytorch_half_pixel" and any(v == 1 for v in out_size):
+                raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') pytorch_half_pixel to a length of one")
+            kw = dict(scale_factor=factors[2:], recompute_scale_factor=False) if factors and coord != "align_corners" else dict(size=out_size)
+            return torch.nn.functional.interpolate(t, mode=torch_mode, align_corners=coord == "align_corners", **kw)
+        raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') with mode '{mode}'")
+
     def _op_HardSwish(self, n, x, a, e):
         import torch
         return torch.nn.functional.hardswish(x[0])
@@ -947,7 +1011,7 @@ _CAPTURE_MAX_INPUT_ELEMENTS = 1 << 20      # recording pays when a pass is hundr
 _PIECES_MIN_WIDTH, _PIECES_MIN_ROWS = 512, 256
 _SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
 _HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split",
-                  "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip"}
+                  "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip", "Pad", "Resize"}
 
 
 class _Attrs:

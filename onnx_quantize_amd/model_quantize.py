@@ -53,9 +53,10 @@ logger = logging.getLogger("onnx_quantize")
 # (`ActivationStream.statistics_after_bytes`); a small model stays on the reference's arrays, a 7B-class model could not hold them
 STATISTICS_AFTER_BYTES = 8 << 30
 _MIN_SOURCE_OPSET = 13
-# operators whose node form changed between opset 13 and 21 in a way this module does not adapt (version_converter would)
-_NOT_ADAPTED = {"DFT": 20, "GridSample": 20, "GroupNormalization": 21, "RoiAlign": 16, "Resize": 18, "Pad": 18, "ScatterElements": 18,
-                "ScatterND": 18, "BatchNormalization": 14}
+# operators whose node form changed between opset 13 and 21 in a way this module does not adapt (version_converter would):
+# GroupNormalization's scale and bias went from one value per group to one per channel, which needs the channel count
+_NOT_ADAPTED = {"GroupNormalization": 21}
+_GRID_SAMPLE_MODES = {"bilinear": "linear", "bicubic": "cubic"}                   # opset 20 renamed them
 _REDUCE_AXES_TO_INPUT = {"ReduceMean", "ReduceMax", "ReduceMin", "ReduceProd", "ReduceL1", "ReduceL2", "ReduceLogSum",
                          "ReduceLogSumExp", "ReduceSumSquare"}                     # opset 18: `axes` moved from attribute to input
 
@@ -141,8 +142,11 @@ def _all_nodes(graph):
 # ------------------------------------------------------------------------------------------------------------ pre passes
 def _raise_opset(model: Message, G: _Graph, target: int = FUNCTION_OPSET) -> None:
     """quantize.py:55 (`convert_version(model, target_version=op.version)`) for the operators exports of MatMul / Gemm models
-    are made of.  Most of them did not change form between opset 13 and 21; the two that commonly appear and did are adapted;
-    an operator from `_NOT_ADAPTED` that crosses its change is refused by name rather than silently mis-declared."""
+    are made of.  Most of them did not change form between opset 13 and 21 (new optional inputs and attributes, wider type
+    lists: Pad, Resize, Scatter*, Cast, Reshape ...: nothing to do); the ones that did are adapted the way onnx's converter
+    does it -- Reduce* `axes` and DFT `axis` from attribute to input, Split `num_outputs`, RoiAlign's old default coordinate
+    mode made explicit, GridSample's renamed modes, BatchNormalization with its single inference output --; an operator
+    from `_NOT_ADAPTED` that crosses its change is refused by name rather than silently mis-declared."""
     default = [o for o in model.opset_import if not o.domain or o.domain == "ai.onnx"]
     if not default:
         model.opset_import.append(Message("OperatorSetIdProto", domain="", version=target))
@@ -169,6 +173,18 @@ def _raise_opset(model: Message, G: _Graph, target: int = FUNCTION_OPSET) -> Non
                 n.attribute = [a for a in n.attribute if a.name != "axes"]
         if n.op_type == "Split" and current < 18 and len(n.input) < 2 and _attr(n, "num_outputs") is None:
             n.attribute = list(n.attribute) + [make_attribute("num_outputs", len(n.output))]
+        if n.op_type == "BatchNormalization" and current < 14 and len([o for o in n.output if o]) > 1:
+            raise NotImplementedError(f"node '{n.name}': BatchNormalization with training outputs changed in opset 14 and this writer "
+                                      f"has no adapter for it (model at opset {current})")
+        if n.op_type == "RoiAlign" and current < 16 and _attr(n, "coordinate_transformation_mode") is None:
+            n.attribute = list(n.attribute) + [make_attribute("coordinate_transformation_mode", "output_half_pixel")]
+        if n.op_type == "GridSample" and current < 20 and _attr(n, "mode") in _GRID_SAMPLE_MODES:
+            n.attribute = [a for a in n.attribute if a.name != "mode"] + [make_attribute("mode", _GRID_SAMPLE_MODES[_attr(n, "mode")])]
+        if n.op_type == "DFT" and current < 20:
+            name = f"{n.output[0]}/axis"
+            G.set_initializer(name, np.asarray(_attr(n, "axis", 1), dtype=np.int64))
+            n.input = (list(n.input) + [""])[:2] + [name]
+            n.attribute = [a for a in n.attribute if a.name != "axis"]
     for o in default:
         o.version = target
     if (model.ir_version or 0) < 10:                      # 4-bit tensors and opset 21 belong to IR version 10

@@ -634,8 +634,8 @@ def test_opset_is_raised_with_adapters_or_refused_by_name():
     x = P.make_value_info("x", 1, ["batch", 16])
     w = np.random.default_rng(1).standard_normal((16, 4)).astype(np.float32)
 
-    def model(extra_nodes, opset):
-        g = P.Message("GraphProto", name="g", input=[x], output=[P.make_value_info("y", 1, None)],
+    def model(extra_nodes, opset, more_inputs=()):
+        g = P.Message("GraphProto", name="g", input=[x] + [P.make_value_info(v, 1, None) for v in more_inputs], output=[P.make_value_info("y", 1, None)],
                       node=[P.make_node("MatMul", ["x", "w"], ["h"], name="fc")] + extra_nodes, initializer=[P.numpy_to_tensor("w", w)])
         return P.Message("ModelProto", ir_version=7, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=opset)])
 
@@ -649,8 +649,24 @@ def test_opset_is_raised_with_adapters_or_refused_by_name():
     m = model([P.make_node("Split", ["h"], ["y", "y2"], name="sp", axis=1)], 13)
     out = q_oracle(m, CONFIGS["int8_channel"]())
     assert {a.name: P.attribute_value(a) for a in out.graph.node[1].attribute} == {"axis": 1, "num_outputs": 2}
-    with pytest.raises(NotImplementedError, match="Resize"):
-        q_oracle(model([P.make_node("Resize", ["h", "", "s"], ["y"], name="rs")], 13), CONFIGS["int8_channel"]())
+    with pytest.raises(NotImplementedError, match="GroupNormalization"):
+        q_oracle(model([P.make_node("GroupNormalization", ["h", "s", "b"], ["y"], name="gn", num_groups=2)], 18, ("s", "b")), CONFIGS["int8_channel"]())
+    with pytest.raises(NotImplementedError, match="BatchNormalization"):
+        q_oracle(model([P.make_node("BatchNormalization", ["h", "s", "b", "m", "v"], ["y", "m2", "v2"], name="bn")], 13, ("s", "b", "m", "v")),
+                 CONFIGS["int8_channel"]())
+    # the converter's other adapters between 13 and 21: an attribute made explicit, renamed, or moved to an input
+    out = q_oracle(model([P.make_node("RoiAlign", ["h", "rois", "idx"], ["y"], name="roi")], 15, ("rois", "idx")), CONFIGS["int8_channel"]())
+    assert {a.name: P.attribute_value(a) for a in out.graph.node[1].attribute} == {"coordinate_transformation_mode": "output_half_pixel"}
+    nodes = [P.make_node("GridSample", ["h", "grid"], ["gs"], name="gs", mode="bilinear"), P.make_node("DFT", ["gs"], ["y"], name="dft", axis=2, onesided=1)]
+    out = q_oracle(model(nodes, 17, ("grid",)), CONFIGS["int8_channel"]())
+    gs, dft = out.graph.node[1:3]
+    assert {a.name: P.attribute_value(a) for a in gs.attribute} == {"mode": "linear"}
+    assert list(dft.input)[:2] == ["gs", ""] and [a.name for a in dft.attribute] == ["onesided"]
+    axis = next(t for t in out.graph.initializer if t.name == dft.input[2])
+    assert list(axis.dims) == [] and axis.data_type == P.DataType.INT64 and int(P.tensor_to_numpy(axis)) == 2
+    out = q_oracle(model([P.make_node("RoiAlign", ["h", "rois", "idx"], ["y"], name="roi", coordinate_transformation_mode="half_pixel")], 16, ("rois", "idx")),
+                   CONFIGS["int8_channel"]())
+    assert {a.name: P.attribute_value(a) for a in out.graph.node[1].attribute} == {"coordinate_transformation_mode": "half_pixel"}
     with pytest.raises(NotImplementedError, match="opset 11"):
         q_oracle(model([P.make_node("Relu", ["h"], ["y"], name="r")], 11), CONFIGS["int8_channel"]())
     out = q_oracle(model([P.make_node("Relu", ["h"], ["y"], name="r")], 22), CONFIGS["int8_channel"]())
@@ -1025,6 +1041,53 @@ def test_graph_runner_gets_through_a_convolutional_front_end():
     assert sum(n.op_type == "Conv" for n in out.graph.node) == 2
     got, want = GraphRunner(out, device="cpu")(x)["scores"], GraphRunner(model, device="cpu")(x)["scores"]
     assert ((got - want).norm() / want.norm()).item() < 0.02
+
+
+@pytest.mark.parametrize("opset", [13, 17])
+def test_pad_and_resize_exports_run_and_cross_the_opset_change(opset):
+    """Pad and Resize only gained optional inputs / attributes between opset 13 and 21: such nodes pass `_raise_opset` as they are,
+    and the runner computes what torch computes for the forms torch's exporter writes."""
+    import io
+    import warnings
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    onnx_proto_utils._add_onnxscript_fn = lambda proto, _ops: proto
+    F = torch.nn.functional
+    pads = {"reflect": lambda x: F.pad(x, (1, 2, 2, 1), mode="reflect"), "constant": lambda x: F.pad(x, (1, 2, 0, 1), value=0.5),
+            "replicate": lambda x: F.pad(x, (2, 0, 1, 1), mode="replicate"), "crop": lambda x: F.pad(x, (-1, 2, 1, -2))}
+    resizes = {"nearest": lambda x: F.interpolate(x, scale_factor=2.0, mode="nearest"),     # (a scale like 1.7 is stored as float32: other pixels at exact multiples)
+               "bilinear": lambda x: F.interpolate(x, scale_factor=1.5, mode="bilinear", align_corners=False),
+               "corners": lambda x: F.interpolate(x, size=(9, 11), mode="bilinear", align_corners=True),
+               "bicubic": lambda x: F.interpolate(x, scale_factor=2.0, mode="bicubic", align_corners=False)}
+
+    class Net(torch.nn.Module):
+        def __init__(self, pad, resize):
+            super().__init__()
+            self.pad, self.resize, self.conv, self.fc = pad, resize, torch.nn.Conv2d(3, 4, 3), torch.nn.Linear(4, 16)
+
+        def forward(self, x):
+            return self.fc(self.resize(self.conv(self.pad(x))).mean((2, 3)))
+
+    for (pname, pad), (rname, resize) in zip(pads.items(), resizes.items()):
+        torch.manual_seed(0)
+        net = Net(pad, resize).eval()
+        f = io.BytesIO()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.onnx.export(net, (torch.randn(2, 3, 8, 10),), f, dynamo=False, opset_version=opset, input_names=["x"], output_names=["y"],
+                              dynamic_axes={"x": {0: "b"}})
+        model = P.parse_model(f.getvalue())
+        assert {"Pad", "Resize"} <= {n.op_type for n in model.graph.node}, (pname, rname)
+        x = torch.randn(3, 3, 8, 10)
+        with torch.no_grad():
+            torch.testing.assert_close(GraphRunner(model, device="cpu")(x)["y"], net(x), rtol=1e-5, atol=1e-6)
+        out = q_oracle(model, CONFIGS["int8_channel"]())
+        assert [n.op_type for n in out.graph.node if n.domain] == ["QGemmWeightsOnlyQDQ"] and out.opset_import[0].version == 21
+        got, want = GraphRunner(out, device="cpu")(x)["y"], GraphRunner(model, device="cpu")(x)["y"]
+        assert ((got - want).norm() / want.norm()).item() < 0.02
+    # forms the runner does not compute are refused by name
+    with pytest.raises(UnsupportedOperator, match="Resize"):
+        _run_one("Resize", [np.zeros((1, 1, 4, 4), np.float32), np.zeros(0, np.float32), np.array([1, 1, 2, 2], np.float32)], mode="nearest",
+                 coordinate_transformation_mode="half_pixel")
 
 
 def test_bench_and_example_models_are_well_formed_and_quantize():
