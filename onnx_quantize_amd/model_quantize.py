@@ -791,6 +791,19 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
     return Prepared(model, G, targets, meta, per_node)
 
 
+def _on(device):
+    """The kernels run on torch's CURRENT device (hip/ops.py refuses tensors of another one): `device="cuda:1"` makes that GPU
+    current for the duration of the call."""
+    import contextlib
+    if isinstance(device, str) and not device.startswith("cuda"):
+        return contextlib.nullcontext()
+    import torch
+    dev = torch.device(device)
+    if dev.type != "cuda" or dev.index is None:
+        return contextlib.nullcontext()
+    return torch.cuda.device(dev.index)
+
+
 def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None, quantize_bias=None, calibrate=None,
                    searches=None) -> Message:
     """quantize.py:28-80 on a parsed ModelProto / ONNX bytes / a path.  Returns a new parsed ModelProto (`onnx_proto.serialize`
@@ -803,8 +816,9 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
     if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
         logger.info("No quantization parameters specified in qconfig. Returning original model.")
         return as_model(model)
-    prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
-    return _emit(prepared, qconfig, weight_arrays if weight_arrays is not None else _PackedSeam(), quantize_bias)
+    with _on(device):
+        prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
+        return _emit(prepared, qconfig, weight_arrays if weight_arrays is not None else _PackedSeam(), quantize_bias)
 
 
 def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bias):
@@ -891,12 +905,17 @@ def quantize_model_sharded(model, qconfig: QConfig, *, group=None, device="cuda"
     arrays of every weight are gathered on rank 0 (`sharding.quantize_sharded`: one gather at the end, RCCL over xGMI on a GPU
     node), and rank 0 emits the model.  Returns the model on rank 0, None on the other ranks.  Without an initialised process
     group it is `quantize_model`."""
-    from .sharding import LayerSpec, quantize_sharded
-
     if not isinstance(qconfig, QConfig):
         raise TypeError(f"qconfig must be a QConfig, got {type(qconfig)}")
     if qconfig.weights is None and qconfig.input_activations is None and qconfig.output_activations is None:
         return as_model(model)
+    with _on(device):
+        return _quantize_sharded(model, qconfig, group, device, weight_arrays, quantize_bias, calibrate, searches)
+
+
+def _quantize_sharded(model, qconfig, group, device, weight_arrays, quantize_bias, calibrate, searches):
+    from .sharding import LayerSpec, quantize_sharded
+
     prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
     device_default = weight_arrays is None
     if device_default:

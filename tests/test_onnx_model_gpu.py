@@ -177,6 +177,17 @@ def test_quantize_entry_point_on_bytes_and_files(tmp_path):
         dict(K=64, N=128, bits=4, block_size=64)
 
 
+def test_an_explicit_device_index_is_made_current_for_the_call():
+    """`device="cuda:0"` / `torch.device("cuda", 0)`: the same files as the default, weight-only and calibrated."""
+    model = fixture("block")
+    for make in (WEIGHT_ONLY["config2_uint4_g128"], CALIBRATED["config3_static_qdq"]):       # (calibration data: the seeded default)
+        want = P.serialize(quantize_model(model, make()))
+        for device in ("cuda:0", torch.device("cuda", 0)):
+            assert P.serialize(quantize_model(model, make(), device=device)) == want
+    with pytest.raises((RuntimeError, ValueError, AssertionError)):
+        quantize_model(model, WEIGHT_ONLY["config2_uint4_g128"](), device=f"cuda:{torch.cuda.device_count()}")     # no such GPU: loud
+
+
 def test_graph_runner_keeps_activations_on_the_device_and_frees_dead_values():
     src = fixture("block")
     taps = ["/ln1/LayerNormalization_output_0", "/up/MatMul_output_0"]
