@@ -211,6 +211,8 @@ class GraphRunner:
         self._graphs[key] = None
         if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in eager.values()):
             return eager
+        if all(name in inputs or name in self.constants for name in self.wanted):
+            return eager                                                   # nothing is computed for these: nothing to record
         static_in = {name: t.clone() for name, t in inputs.items()}
         graph = torch.cuda.CUDAGraph()
         try:
