@@ -971,9 +971,10 @@ def quantize_file(src, dst, qconfig: QConfig, external_data="auto", **kw) -> Mes
     """Read `src` (tensors in side files are memory-mapped, not read), quantize, write `dst`.  `external_data`: a file name
     next to `dst` for the tensors, None for one file with everything inline, "auto" (default): `<dst name>.data` when the
     source kept its tensors outside or the result would pass 1 GiB, inline otherwise.  Returns the quantized model."""
+    from .onnx_proto import resolve_external_data
     src_model = load_model(src, load_external_data=False)
-    had_external = any(t.data_location for t in src_model.graph.initializer)
-    out = quantize_model(load_model(src), qconfig, **kw)
+    had_external = resolve_external_data(src_model, os.path.dirname(os.path.abspath(os.fspath(src)))) > 0
+    out = quantize_model(src_model, qconfig, **kw)
     if external_data == "auto":
         size = sum(len(t.raw_data) for t in out.graph.initializer if t.has("raw_data"))
         external_data = os.path.basename(os.fspath(dst)) + ".data" if (had_external or size > 1 << 30) else None
