@@ -45,6 +45,8 @@ def quantize(model, qconfig: QConfig):
     try:
         import onnx
     except ImportError as e:
+        if not type(model).__module__.split(".")[0].startswith("onnx"):      # quantize.py:38-41: not a model of any kind
+            raise TypeError(f"model must be ONNX bytes, a path, a parsed ModelProto, an onnx.ModelProto or an onnx_ir.Model, got {type(model)}") from None
         raise ImportError(
             "quantize() takes ONNX bytes, a path or a model parsed by onnx_quantize_amd.onnx_proto.parse_model; an object of "
             f"type {type(model).__name__} needs the `onnx` / `onnx_ir` packages, which are not installed here") from e

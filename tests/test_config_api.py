@@ -279,7 +279,10 @@ def test_quantize_entry_point_fails_loudly_without_onnx():
         pytest.skip("onnx is installed here")
     except ImportError:
         pass
+    stand_in = type("ModelProto", (), {"__module__": "onnx.onnx_ml_pb2"})()       # an object of the absent package's kind
     with pytest.raises(ImportError, match="needs the `onnx`"):
+        oq.quantize(stand_in, QConfig(weights=QWeightArgs()))
+    with pytest.raises(TypeError, match="model must be"):                        # quantize.py:38-41: anything that is no model
         oq.quantize(object(), QConfig(weights=QWeightArgs()))
 
 

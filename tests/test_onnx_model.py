@@ -704,6 +704,9 @@ def test_quantize_entry_point_routes_bytes_paths_and_parsed_models(tmp_path, mon
     assert dst.read_bytes() == out_bytes
     with pytest.raises(TypeError):
         MQ.as_model(3.5)
+    for not_a_model in (3.5, None, ["model.onnx"], {"graph": None}):       # quantize.py:38-41
+        with pytest.raises(TypeError, match="model must be"):
+            quantize(not_a_model, qc)
     with pytest.raises(TypeError, match="QConfig"):
         real(data, {"weights": None})
 
