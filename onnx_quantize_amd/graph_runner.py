@@ -433,6 +433,128 @@ class GraphRunner:
     def _op_ReduceMax(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.amax(dim=ax, keepdim=k), n, x, a)
     def _op_ReduceMin(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.amin(dim=ax, keepdim=k), n, x, a)
 
+    def _op_ReduceProd(self, n, x, a, e):
+        def prod(t, axes, keep):
+            for ax in sorted((ax % t.ndim for ax in axes), reverse=True):
+                t = t.prod(dim=ax, keepdim=keep)
+            return t
+        return self._reduce(prod, n, x, a)
+
+    def _op_ReduceL1(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.abs().sum(dim=ax, keepdim=k), n, x, a)
+    def _op_ReduceL2(self, n, x, a, e): return self._reduce(lambda t, ax, k: (t * t).sum(dim=ax, keepdim=k).sqrt(), n, x, a)
+    def _op_ReduceSumSquare(self, n, x, a, e): return self._reduce(lambda t, ax, k: (t * t).sum(dim=ax, keepdim=k), n, x, a)
+    def _op_ReduceLogSum(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.sum(dim=ax, keepdim=k).log(), n, x, a)
+    def _op_ReduceLogSumExp(self, n, x, a, e): return self._reduce(lambda t, ax, k: t.logsumexp(dim=ax, keepdim=k), n, x, a)
+
+    def _op_ArgMin(self, n, x, a, e):
+        if a.get("select_last_index", 0):
+            raise UnsupportedOperator("GraphRunner: ArgMin with select_last_index")
+        return x[0].argmin(dim=a.get("axis", 0), keepdim=bool(a.get("keepdims", 1)))
+
+    def _op_TopK(self, n, x, a, e):
+        import torch
+        k = _ints(x[1])[0] if len(x) > 1 else a["k"]
+        values, indices = torch.topk(x[0], k, dim=a.get("axis", -1), largest=bool(a.get("largest", 1)), sorted=True)
+        return values, indices
+
+    def _op_NonZero(self, n, x, a, e):
+        return x[0].nonzero().t().contiguous()              # (a data-dependent shape: such a pass is never recorded)
+
+    def _op_OneHot(self, n, x, a, e):
+        import torch
+        depth = _ints(x[1])[0]
+        axis = a.get("axis", -1)
+        idx = x[0].to(torch.int64)
+        idx = torch.where(idx < 0, idx + depth, idx)
+        hot = torch.nn.functional.one_hot(idx.clamp(0, depth - 1), depth).to(torch.bool) & ((idx >= 0) & (idx < depth)).unsqueeze(-1)
+        values = x[2].to(x[0].device) if x[2].device != x[0].device else x[2]
+        out = torch.where(hot, values[1], values[0])
+        if axis not in (-1, idx.ndim):
+            out = out.movedim(-1, axis if axis >= 0 else axis + idx.ndim + 1)
+        return out
+
+    def _op_ScatterElements(self, n, x, a, e):
+        import torch
+        t, idx, upd = x[0], x[1].to(torch.int64), x[2]
+        axis = a.get("axis", 0)
+        idx = torch.where(idx < 0, idx + t.shape[axis], idx)
+        reduction = a.get("reduction", "none")
+        if reduction == "none":
+            return t.scatter(axis, idx, upd)
+        how = {"add": "sum", "mul": "prod", "max": "amax", "min": "amin"}.get(reduction)
+        if how is None:
+            raise UnsupportedOperator(f"GraphRunner: ScatterElements with reduction '{reduction}'")
+        return t.scatter_reduce(axis, idx, upd, how, include_self=True)
+
+    def _op_ScatterND(self, n, x, a, e):
+        import torch
+        t, idx, upd = x[0].clone(), x[1].to(torch.int64), x[2]
+        reduction = a.get("reduction", "none")
+        if reduction not in ("none", "add"):
+            raise UnsupportedOperator(f"GraphRunner: ScatterND with reduction '{reduction}'")
+        last = idx.shape[-1]
+        flat = idx.reshape(-1, last)
+        flat = torch.where(flat < 0, flat + torch.tensor(t.shape[:last], device=flat.device), flat)
+        t.index_put_(tuple(flat[:, j] for j in range(last)), upd.reshape(flat.shape[0], *t.shape[last:]), accumulate=reduction == "add")
+        return t
+
+    def _op_GatherND(self, n, x, a, e):
+        import torch
+        t, idx = x[0], x[1].to(torch.int64)
+        b = a.get("batch_dims", 0)
+        if b:
+            raise UnsupportedOperator("GraphRunner: GatherND with batch_dims")
+        last = idx.shape[-1]
+        flat = idx.reshape(-1, last)
+        flat = torch.where(flat < 0, flat + torch.tensor(t.shape[:last], device=flat.device), flat)
+        return t[tuple(flat[:, j] for j in range(last))].reshape(*idx.shape[:-1], *t.shape[last:])
+
+    def _op_DepthToSpace(self, n, x, a, e):
+        t, bs = x[0], a["blocksize"]
+        b, c, h, w = t.shape
+        if a.get("mode", "DCR") == "DCR":
+            t = t.reshape(b, bs, bs, c // (bs * bs), h, w).permute(0, 3, 4, 1, 5, 2)
+        else:
+            t = t.reshape(b, c // (bs * bs), bs, bs, h, w).permute(0, 1, 4, 2, 5, 3)
+        return t.reshape(b, c // (bs * bs), h * bs, w * bs)
+
+    def _op_SpaceToDepth(self, n, x, a, e):
+        t, bs = x[0], a["blocksize"]
+        b, c, h, w = t.shape
+        return t.reshape(b, c, h // bs, bs, w // bs, bs).permute(0, 3, 5, 1, 2, 4).reshape(b, c * bs * bs, h // bs, w // bs)
+
+    def _op_InstanceNormalization(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.instance_norm(x[0], weight=x[1], bias=x[2], eps=a.get("epsilon", 1e-5))
+
+    def _op_GroupNormalization(self, n, x, a, e):
+        import torch
+        if self.opset < 21:                                  # one scale / bias per group before opset 21
+            raise UnsupportedOperator("GraphRunner: GroupNormalization before opset 21")
+        return torch.nn.functional.group_norm(x[0], a["num_groups"], x[1], x[2], a.get("epsilon", 1e-5))
+
+    def _op_LpNormalization(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.normalize(x[0], p=float(a.get("p", 2)), dim=a.get("axis", -1), eps=0.0)
+
+    def _op_ConvTranspose(self, n, x, a, e):
+        import torch
+        t, w = x[0], x[1]
+        bias = x[2] if len(x) > 2 else None
+        spatial = t.ndim - 2
+        strides, dilations = a.get("strides", [1] * spatial), a.get("dilations", [1] * spatial)
+        if a.get("auto_pad", "NOTSET") != "NOTSET" or a.get("output_shape", None) is not None:
+            raise UnsupportedOperator("GraphRunner: ConvTranspose with auto_pad / output_shape")
+        pads = a.get("pads", [0] * (2 * spatial))
+        begin, end = list(pads[:spatial]), list(pads[spatial:])
+        out_pad = list(a.get("output_padding", [0] * spatial))
+        fn = {1: torch.nn.functional.conv_transpose1d, 2: torch.nn.functional.conv_transpose2d, 3: torch.nn.functional.conv_transpose3d}[spatial]
+        if begin == end:
+            return fn(t, w, bias, stride=strides, padding=begin, output_padding=out_pad, groups=a.get("group", 1), dilation=dilations)
+        out = fn(t, w, bias, stride=strides, padding=0, output_padding=out_pad, groups=a.get("group", 1), dilation=dilations)
+        index = [slice(None)] * 2 + [slice(b, out.shape[2 + i] - en) for i, (b, en) in enumerate(zip(begin, end))]
+        return out[tuple(index)]
+
     # linear algebra
     def _op_MatMul(self, n, x, a, e):
         import torch
@@ -582,6 +704,39 @@ class GraphRunner:
             kw = dict(scale_factor=factors[2:], recompute_scale_factor=False) if factors and coord != "align_corners" else dict(size=out_size)
             return torch.nn.functional.interpolate(t, mode=torch_mode, align_corners=coord == "align_corners", **kw)
         raise UnsupportedOperator(f"GraphRunner: Resize (node '{n.name}') with mode '{mode}'")
+
+    def _op_Selu(self, n, x, a, e):
+        import torch
+        alpha, gamma = a.get("alpha", 1.6732632423543772), a.get("gamma", 1.0507009873554805)
+        return gamma * torch.where(x[0] > 0, x[0], alpha * (x[0].exp() - 1))
+
+    def _op_Celu(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.celu(x[0], a.get("alpha", 1.0))
+
+    def _op_Mish(self, n, x, a, e):
+        import torch
+        return torch.nn.functional.mish(x[0])
+
+    def _op_Softsign(self, n, x, a, e): return x[0] / (1 + x[0].abs())
+
+    def _op_ThresholdedRelu(self, n, x, a, e):
+        import torch
+        return torch.where(x[0] > a.get("alpha", 1.0), x[0], torch.zeros_like(x[0]))
+
+    def _op_Shrink(self, n, x, a, e):
+        import torch
+        lambd, bias = a.get("lambd", 0.5), a.get("bias", 0.0)
+        return torch.where(x[0] < -lambd, x[0] + bias, torch.where(x[0] > lambd, x[0] - bias, torch.zeros_like(x[0])))
+
+    def _op_Xor(self, n, x, a, e): return x[0] ^ x[1]
+    def _op_Tan(self, n, x, a, e): return x[0].tan()
+    def _op_Atan(self, n, x, a, e): return x[0].atan()
+    def _op_Asin(self, n, x, a, e): return x[0].asin()
+    def _op_Acos(self, n, x, a, e): return x[0].acos()
+    def _op_Sinh(self, n, x, a, e): return x[0].sinh()
+    def _op_Cosh(self, n, x, a, e): return x[0].cosh()
+    def _op_Mean(self, n, x, a, e): return sum(x[1:], x[0]) / len(x)
 
     def _op_HardSwish(self, n, x, a, e):
         import torch
@@ -1016,7 +1171,7 @@ _CAPTURE_MAX_INPUT_ELEMENTS = 1 << 20      # recording pays when a pass is hundr
 _PIECES_MIN_WIDTH, _PIECES_MIN_ROWS = 512, 256
 _SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
 _HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split",
-                  "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip", "Pad", "Resize"}
+                  "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip", "Pad", "Resize", "TopK", "OneHot"}
 
 
 class _Attrs:

@@ -1093,6 +1093,103 @@ def test_pad_and_resize_exports_run_and_cross_the_opset_change(opset):
                  coordinate_transformation_mode="half_pixel")
 
 
+def test_more_operators_against_torch_exports_and_their_definitions():
+    """Operators around MatMul / Gemm heads that a calibration walk has to get through: each computed by the runner from torch's
+    own export of the torch function, or -- where the exporter writes other operators for it -- from the operator's definition."""
+    import io
+    import warnings
+    from torch.onnx._internal.torchscript_exporter import onnx_proto_utils
+    onnx_proto_utils._add_onnxscript_fn = lambda proto, _ops: proto
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(0)
+    r = lambda *sh: torch.randn(*sh, generator=g)                             # noqa: E731
+
+    class M(torch.nn.Module):
+        def __init__(self, fn, mods=()):
+            super().__init__()
+            self.fn, self.mods = fn, torch.nn.ModuleList(mods)
+
+        def forward(self, *xs):
+            return self.fn(self.mods, *xs)
+
+    cases = {
+        "ReduceProd": (lambda m, x: x.prod(dim=1), (r(3, 4, 5),)),
+        "ReduceL2": (lambda m, x: x.norm(dim=(1, 2)), (r(3, 4, 5),)),
+        "ReduceL1": (lambda m, x: x.norm(p=1, dim=2), (r(3, 4, 5),)),
+        "ReduceLogSumExp": (lambda m, x: x.logsumexp(dim=2), (r(3, 4, 5),)),
+        "ArgMin": (lambda m, x: x.argmin(dim=1), (r(3, 4, 5),)),
+        "TopK": (lambda m, x: torch.topk(x, 3, dim=2)[0] + torch.topk(x, 3, dim=2)[1], (r(3, 4, 5),)),
+        "NonZero": (lambda m, x: (x > 0).nonzero(), (r(3, 4),)),
+        "OneHot": (lambda m, x: F.one_hot(x, 7).float(), (torch.randint(0, 7, (3, 4), generator=g),)),
+        "ScatterElements": (lambda m, x, i, u: x.scatter(1, i, u), (r(3, 6), torch.randint(0, 6, (3, 2), generator=g), r(3, 2))),
+        "ScatterND": (lambda m, x, u: x.index_put((torch.tensor([0, 2]), torch.tensor([1, 3])), u), (r(3, 4, 5), r(2, 5))),
+        "DepthToSpace": (lambda m, x: F.pixel_shuffle(x, 2), (r(2, 8, 3, 3),)),
+        "InstanceNormalization": (lambda m, x: m[0](x), (r(2, 4, 5, 5),), [torch.nn.InstanceNorm2d(4, affine=True)]),
+        "ConvTranspose": (lambda m, x: m[0](x) + m[1](x[:, :, 0]).sum(), (r(2, 4, 5, 5),),
+                          [torch.nn.ConvTranspose2d(4, 6, 3, stride=2, padding=1, output_padding=1), torch.nn.ConvTranspose1d(4, 4, 4, stride=2, groups=2, bias=False)]),
+        "Selu": (lambda m, x: F.selu(x), (r(3, 4),)),
+        "Celu": (lambda m, x: F.celu(x, 1.3), (r(3, 4),)),
+        "Atan": (lambda m, x: x.atan() + x.tan() + (x * 0.5).asin() + (x * 0.5).acos(), (r(3, 4).clamp(-1, 1),)),
+        "Xor": (lambda m, x, y: (x > 0) ^ (y > 0), (r(3, 4), r(3, 4))),
+    }
+    for name, case in cases.items():
+        fn, args = case[:2]
+        net = M(fn, case[2] if len(case) > 2 else ()).eval()
+        f = io.BytesIO()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.onnx.export(net, args, f, dynamo=False, opset_version=17, input_names=[f"x{i}" for i in range(len(args))], output_names=["y"])
+        model = P.parse_model(f.getvalue())
+        assert name in {n.op_type for n in model.graph.node}, name
+        got = GraphRunner(model, device="cpu")({f"x{i}": a for i, a in enumerate(args)})["y"]
+        with torch.no_grad():
+            want = net(*args)
+        assert got.shape == want.shape and got.dtype == want.dtype, name
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6, msg=name)
+
+    # by definition (onnx/defs): operators the exporter writes differently
+    x = r(2, 8, 4, 6).numpy()
+    b, c, h, w = x.shape
+    np.testing.assert_array_equal(_run_one("SpaceToDepth", [x], blocksize=2).numpy(),
+                                  x.reshape(b, c, h // 2, 2, w // 2, 2).transpose(0, 3, 5, 1, 2, 4).reshape(b, c * 4, h // 2, w // 2))
+    back = _run_one("DepthToSpace", [_run_one("SpaceToDepth", [x], blocksize=2).numpy()], blocksize=2, mode="DCR")
+    np.testing.assert_array_equal(back.numpy(), x)
+    crd = x.reshape(b, c // 4, 2, 2, h, w).transpose(0, 1, 4, 2, 5, 3).reshape(b, c // 4, h * 2, w * 2)
+    np.testing.assert_array_equal(_run_one("DepthToSpace", [x], blocksize=2, mode="CRD").numpy(), crd)
+    v = r(3, 5).numpy()
+    np.testing.assert_allclose(_run_one("Mish", [v]).numpy(), v * np.tanh(np.log1p(np.exp(v))), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_run_one("Softsign", [v]).numpy(), v / (1 + np.abs(v)), rtol=1e-6)
+    np.testing.assert_array_equal(_run_one("ThresholdedRelu", [v], alpha=0.3).numpy(), np.where(v > 0.3, v, 0).astype(np.float32))
+    np.testing.assert_allclose(_run_one("Shrink", [v], lambd=0.4, bias=0.1).numpy(), np.where(v < -0.4, v + 0.1, np.where(v > 0.4, v - 0.1, 0)), rtol=1e-6)
+    np.testing.assert_allclose(_run_one("ReduceSumSquare", [v, np.array([1])], keepdims=0).numpy(), (v * v).sum(1), rtol=1e-5)
+    np.testing.assert_allclose(_run_one("ReduceLogSum", [np.abs(v), np.array([0])], keepdims=1).numpy(), np.log(np.abs(v).sum(0, keepdims=True)), rtol=1e-5)
+    np.testing.assert_allclose(_run_one("Sinh", [v]).numpy() + _run_one("Cosh", [v]).numpy(), np.exp(v), rtol=1e-5)
+    np.testing.assert_allclose(_run_one("Mean", [v, 2 * v, 3 * v]).numpy(), 2 * v, rtol=1e-6)
+    np.testing.assert_allclose(_run_one("LpNormalization", [v], axis=1, p=2).numpy(), v / np.sqrt((v * v).sum(1, keepdims=True)), rtol=1e-5)
+    np.testing.assert_allclose(_run_one("LpNormalization", [v], axis=0, p=1).numpy(), v / np.abs(v).sum(0, keepdims=True), rtol=1e-5)
+    data = r(4, 5, 6).numpy()
+    idx = np.array([[0, 1], [3, -1], [-2, 2]], dtype=np.int64)
+    np.testing.assert_array_equal(_run_one("GatherND", [data, idx]).numpy(), np.stack([data[0, 1], data[3, 4], data[2, 2]]))
+    upd = r(3, 6).numpy()
+    want = data.copy()
+    want[0, 1], want[3, 4], want[2, 2] = upd
+    np.testing.assert_array_equal(_run_one("ScatterND", [data, idx, upd]).numpy(), want)
+    added = data.copy()
+    for (i, j), u in zip(idx, upd):
+        added[i, j] += u
+    np.testing.assert_allclose(_run_one("ScatterND", [data, idx, upd], reduction="add").numpy(), added, rtol=1e-6)
+    gn = r(2, 6, 3, 3).numpy()
+    scale, bias = r(6).numpy(), r(6).numpy()
+    grouped = gn.reshape(2, 3, -1)
+    normed = ((grouped - grouped.mean(-1, keepdims=True)) / np.sqrt(grouped.var(-1, keepdims=True) + 1e-5)).reshape(gn.shape)
+    np.testing.assert_allclose(_run_one("GroupNormalization", [gn, scale, bias], num_groups=3).numpy(),
+                               normed * scale[None, :, None, None] + bias[None, :, None, None], rtol=1e-4, atol=1e-5)
+    hot = _run_one("OneHot", [np.array([[1, -1], [5, 2]], dtype=np.int64), np.array([4], dtype=np.int64), np.array([-1.0, 2.0], dtype=np.float32)], axis=1)
+    want_hot = np.full((2, 4, 2), -1.0, np.float32)
+    want_hot[0, 1, 0] = want_hot[0, 3, 1] = want_hot[1, 2, 1] = 2.0                  # index 5 is out of range: its row stays "off"
+    np.testing.assert_array_equal(hot.numpy(), want_hot)
+
+
 def test_bench_and_example_models_are_well_formed_and_quantize():
     """The synthetic models of bench_model.py and examples/gemma3_shapes/gemma3_onnx_file.py (toy sizes): structurally sound, run in
     the graph runner, and go through the writer (oracle providers) with `lm_head` ignored like in the reference's examples."""
