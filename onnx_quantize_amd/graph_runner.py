@@ -570,6 +570,15 @@ class GraphRunner:
                 return ops.matmul_pieces(x[0], hit[1])
         return torch.matmul(x[0], w)
 
+    def _op_FusedMatMul(self, n, x, a, e):                  # com.microsoft: alpha * op(A) @ op(B), the transposes on the last two axes
+        import torch
+        if a.get("transBatchA", 0) or a.get("transBatchB", 0):
+            raise UnsupportedOperator("GraphRunner: FusedMatMul with transBatchA / transBatchB")
+        A = x[0].transpose(-1, -2) if a.get("transA", 0) and x[0].ndim > 1 else x[0]
+        B = x[1].transpose(-1, -2) if a.get("transB", 0) and x[1].ndim > 1 else x[1]
+        out = torch.matmul(A, B)
+        return out * a.get("alpha", 1.0) if a.get("alpha", 1.0) != 1.0 else out
+
     def _op_Gemm(self, n, x, a, e):
         A = x[0].t() if a.get("transA", 0) else x[0]
         B = x[1].t() if a.get("transB", 0) else x[1]

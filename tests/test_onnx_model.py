@@ -1167,6 +1167,8 @@ def test_more_operators_against_torch_exports_and_their_definitions():
     np.testing.assert_allclose(_run_one("Mean", [v, 2 * v, 3 * v]).numpy(), 2 * v, rtol=1e-6)
     np.testing.assert_allclose(_run_one("LpNormalization", [v], axis=1, p=2).numpy(), v / np.sqrt((v * v).sum(1, keepdims=True)), rtol=1e-5)
     np.testing.assert_allclose(_run_one("LpNormalization", [v], axis=0, p=1).numpy(), v / np.abs(v).sum(0, keepdims=True), rtol=1e-5)
+    fa, fb = r(2, 5, 3).numpy(), r(2, 5, 4).numpy()
+    np.testing.assert_allclose(_run_one("FusedMatMul", [fa, fb], transA=1, alpha=0.5).numpy(), 0.5 * np.matmul(fa.transpose(0, 2, 1), fb), rtol=1e-5, atol=1e-6)
     data = r(4, 5, 6).numpy()
     idx = np.array([[0, 1], [3, -1], [-2, 2]], dtype=np.int64)
     np.testing.assert_array_equal(_run_one("GatherND", [data, idx]).numpy(), np.stack([data[0, 1], data[3, 4], data[2, 2]]))
