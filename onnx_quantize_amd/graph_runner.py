@@ -19,7 +19,7 @@ from collections.abc import Mapping
 
 import numpy as np
 
-from .onnx_proto import DataType, Message, attribute_value, tensor_to_numpy
+from .onnx_proto import _NP_OF, DataType, Message, attribute_value, tensor_to_numpy
 
 __all__ = ["GraphRunner", "UnsupportedOperator"]
 
@@ -36,6 +36,15 @@ def _torch_dtype(code: int):
     if code not in table:
         raise UnsupportedOperator(f"GraphRunner: element type {code}")
     return table[code]
+
+
+def _numpy_dtype(t):
+    """NumPy's name for a tensor's element type (None for the types NumPy has no name for)."""
+    import torch
+    try:
+        return torch.empty(0, dtype=t.dtype).numpy().dtype
+    except TypeError:
+        return None
 
 
 def _ints(t) -> list[int]:
@@ -77,6 +86,11 @@ class GraphRunner:
         self.wanted = list(outputs) if outputs is not None else [o.name for o in self.graph.output]
         init_names = {t.name for t in self.graph.initializer}
         self.input_names = [i.name for i in self.graph.input if i.name not in init_names]
+        self.input_types = {}                                # declared element types: a feed of another type is refused, like a session does
+        for i in self.graph.input:
+            tt = i.type.tensor_type if i.type is not None else None
+            if i.name not in init_names and tt is not None and tt.elem_type in _NP_OF:
+                self.input_types[i.name] = np.dtype(_NP_OF[tt.elem_type])
         self.constants = {}
         for t in self.graph.initializer:
             self.constants[t.name] = self._constant(tensor_to_numpy(t), t.data_type)
@@ -167,7 +181,12 @@ class GraphRunner:
                 raise KeyError(f"GraphRunner: no data for model input '{name}'")
         inputs = {}
         for name, v in feed.items():
+            if name not in self.input_names:
+                raise ValueError(f"GraphRunner: '{name}' is not an input of the model (inputs: {self.input_names})")
             t = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.array(v, order="C"))
+            declared = self.input_types.get(name)
+            if declared is not None and _numpy_dtype(t) != declared:
+                raise TypeError(f"GraphRunner: model input '{name}' is declared {declared}, the data handed in is {t.dtype}")
             inputs[name] = t.to(self.device, non_blocking=True)
         if not self.capture or sum(t.numel() for t in inputs.values()) > _CAPTURE_MAX_INPUT_ELEMENTS:
             return self._eager(inputs, sink)                  # (a large pass is bound by its kernels, not by their dispatch)

@@ -301,12 +301,17 @@ def _np_dynq(x):
     return np.clip(np.rint(x / s) + np.float32(z), 0, 255).astype(np.uint8), s, z
 
 
+def _declared(names, inputs):
+    """graph inputs typed like the data that will be fed (the runner refuses a feed of another type, like a session)."""
+    code = lambda v: P._CODE_OF[np.dtype(v.numpy().dtype if isinstance(v, torch.Tensor) else np.asarray(v).dtype)]      # noqa: E731
+    return [P.make_value_info(n, code(v), None) for n, v in zip(names, inputs)]
+
+
 def _call(fn, inputs, attrs=None):
     """Run ONE call of `fn` through the graph runner: a model whose only node is the call."""
     names = [f"i{k}" for k in range(len(inputs))]
     node = P.make_node(fn.name, names, ["out"], domain="quant", **(attrs or {}))
-    g = P.Message("GraphProto", node=[node], name="g", input=[P.make_value_info(n, 1, None) for n in names],
-                  output=[P.make_value_info("out", 1, None)])
+    g = P.Message("GraphProto", node=[node], name="g", input=_declared(names, inputs), output=[P.make_value_info("out", 1, None)])
     model = P.Message("ModelProto", ir_version=10, graph=g, functions=[fn],
                       opset_import=[P.Message("OperatorSetIdProto", domain="", version=21), P.Message("OperatorSetIdProto", domain="quant", version=1),
                                     P.Message("OperatorSetIdProto", domain="com.microsoft", version=1)])
@@ -980,7 +985,7 @@ def test_contrib_operators_of_genai_style_exports():
     def one(op, inputs, outputs=("y",), domain="com.microsoft", **attrs):
         names = [f"i{k}" for k in range(len(inputs))]
         g = P.Message("GraphProto", name="g", node=[P.make_node(op, names, list(outputs), domain=domain, **attrs)],
-                      input=[P.make_value_info(n, 1, None) for n in names], output=[P.make_value_info(o, 1, None) for o in outputs if o])
+                      input=_declared(names, inputs), output=[P.make_value_info(o, 1, None) for o in outputs if o])
         m = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
         return GraphRunner(m, device="cpu")(dict(zip(names, inputs)))
 
@@ -1192,6 +1197,23 @@ def test_more_operators_against_torch_exports_and_their_definitions():
     np.testing.assert_array_equal(hot.numpy(), want_hot)
 
 
+def test_feeds_are_checked_like_a_session_checks_them():
+    """calibrate.py:204-251 hands the user's arrays to an onnxruntime session, which refuses unknown names and other element types;
+    so does the runner (a float feed used as token ids would otherwise run to nonsense)."""
+    runner = GraphRunner(fixture("tied"), device="cpu")
+    assert runner.input_names == ["ids"]
+    ids = np.zeros((2, 7), np.int64)
+    assert runner(ids)["logits"].shape == (2, 7, 32)
+    with pytest.raises(TypeError, match="declared int64"):
+        runner(ids.astype(np.float32))
+    with pytest.raises(TypeError, match="declared int64"):
+        runner({"ids": torch.zeros(2, 7, dtype=torch.int32)})
+    with pytest.raises(ValueError, match="not an input of the model"):
+        runner({"ids": ids, "mask": ids})
+    with pytest.raises(KeyError, match="no data for model input"):
+        runner({})
+
+
 def test_bench_and_example_models_are_well_formed_and_quantize():
     """The synthetic models of bench_model.py and examples/gemma3_shapes/gemma3_onnx_file.py (toy sizes): structurally sound, run in
     the graph runner, and go through the writer (oracle providers) with `lm_head` ignored like in the reference's examples."""
@@ -1222,7 +1244,7 @@ def _run_one(op, inputs, n_out=1, **attrs):
     names = [f"i{k}" for k in range(len(inputs))]
     outs = [f"o{k}" for k in range(n_out)]
     g = P.Message("GraphProto", name="g", node=[P.make_node(op, names, outs, **attrs)],
-                  input=[P.make_value_info(n, 1, None) for n in names], output=[P.make_value_info(o, 1, None) for o in outs])
+                  input=_declared(names, inputs), output=[P.make_value_info(o, 1, None) for o in outs])
     m = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
     got = GraphRunner(P.parse_model(P.serialize(m)), device="cpu")(dict(zip(names, inputs)))
     return [got[o] for o in outs] if n_out > 1 else got["o0"]
