@@ -415,7 +415,7 @@ def _target_nodes(G: _Graph, qconfig: QConfig) -> list:
         if n.op_type == "Gemm" and _attr(n, "transB") != 0:
             continue
         if len(G.inits[n.input[1]].dims) != 2 or G.inits[n.input[1]].data_type != DataType.FLOAT:
-            logger.debug("node '%s': weight '%s' is not a float32 matrix, left as it is", n.name, n.input[1])
+            logger.warning("node '%s': weight '%s' is not a float32 matrix (the numeric path is defined on fp32 [K, N]); left as it is", n.name, n.input[1])
             continue
         out.append(n)
     return out
