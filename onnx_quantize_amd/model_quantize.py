@@ -846,8 +846,18 @@ def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) ->
 
     used_functions: dict = {}
     domains = set()
+    readers: dict = {}
+    for n in _all_nodes(G.g):
+        for v in n.input:
+            if v:
+                readers[v] = readers.get(v, 0) + 1
     for node in targets:
         w_name = node.input[1]
+        if readers[w_name] > 1 or w_name in G.graph_outputs:
+            # an initializer that `_duplicate_shared_initializers` had to leave shared (it is a graph input or output,
+            # duplicate_initializer.py:47-52): its integers would replace it under the other readers' feet
+            raise ValueError(f"node '{node.name}': its weight '{w_name}' is a graph output or is read elsewhere and could not be duplicated "
+                             "(it is listed among the graph's inputs / outputs); remove it from there or ignore this node")
         in_channels = int(G.inits[w_name].dims[0])
         plan = _plan(prepared, node, qconfig, weight_arrays, quantize_bias)
         packed = getattr(weight_arrays, "packed", {})

@@ -1197,6 +1197,20 @@ def test_more_operators_against_torch_exports_and_their_definitions():
     np.testing.assert_array_equal(hot.numpy(), want_hot)
 
 
+def test_a_shared_weight_that_cannot_be_duplicated_is_refused_at_its_second_consumer():
+    w = np.random.default_rng(0).standard_normal((8, 8)).astype(np.float32)
+    g = P.Message("GraphProto", name="g", input=[P.make_value_info("x", 1, ["n", 8])], output=[P.make_value_info("y", 1, None), P.make_value_info("w", 1, [8, 8])],
+                  node=[P.make_node("MatMul", ["x", "w"], ["h"], name="a"), P.make_node("MatMul", ["h", "w"], ["y"], name="b")], initializer=[P.numpy_to_tensor("w", w)])
+    model = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
+    with pytest.raises(ValueError, match="could not be duplicated"):
+        q_oracle(model, CONFIGS["int8_channel"]())
+    with pytest.raises(ValueError, match="could not be duplicated"):          # the other reader is not a target: it would read the integers
+        q_oracle(model, QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), ignore=["^b$"]))
+    g.output = [g.output[0]]                                                  # no longer an output: duplicated, both quantized
+    out = q_oracle(model, CONFIGS["int8_channel"]())
+    assert [n.op_type for n in out.graph.node] == ["QMatMulWeightsOnlyQDQ"] * 2
+
+
 def test_feeds_are_checked_like_a_session_checks_them():
     """calibrate.py:204-251 hands the user's arrays to an onnxruntime session, which refuses unknown names and other element types;
     so does the runner (a float feed used as token ids would otherwise run to nonsense)."""
