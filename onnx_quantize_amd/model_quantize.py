@@ -862,6 +862,9 @@ def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) ->
         plan = _plan(prepared, node, qconfig, weight_arrays, quantize_bias)
         packed = getattr(weight_arrays, "packed", {})
         for name, array in plan.initializers:
+            if name != w_name and name in G.inits and (readers.get(name, 0) > 1 or name in G.graph_outputs):
+                raise ValueError(f"node '{node.name}': the initializer '{name}' it rewrites is a graph output or is read elsewhere and could "
+                                 "not be duplicated; remove it from the graph's inputs / outputs or ignore this node")
             if name in packed:                                # 4-bit integers packed on the device (`_PackedSeam`)
                 raw, shape = packed.pop(name)
                 G.set_tensor(Message("TensorProto", dims=[int(d) for d in shape], data_type=int(plan.onnx_types[name]), name=name,
