@@ -1085,6 +1085,38 @@ class GraphRunner:
         out = torch.matmul(probs, vv).transpose(1, 2).reshape(b, s_len, heads * d)
         return (out, k, v)[:max(1, len(n.output))]
 
+    def _op_MultiHeadAttention(self, n, x, a, e):
+        """com.microsoft::MultiHeadAttention in the form the genai builder writes for models without grouped heads: query, key,
+        value [B, S, N D] (three separate tensors), bias [3 N D], -, attention_bias [B | 1, N | 1, S, T] (added to the scores),
+        past_key, past_value [B, N, P, D] -> output, present_key, present_value.  `unidirectional`: causal over the absolute
+        positions.  Packed QKV / KV, key_padding_mask and the cache-indirection inputs are refused."""
+        import torch
+        x = list(x) + [None] * (8 - len(x))
+        q, k, v, bias, padding, attn_bias, past_k, past_v = x[:8]
+        if k is None or v is None or q.ndim != 3 or k.ndim != 3 or padding is not None or any(t is not None for t in x[8:]):
+            raise UnsupportedOperator(f"GraphRunner: MultiHeadAttention (node '{n.name}') with packed inputs, key_padding_mask or cache indirection")
+        heads = a["num_heads"]
+        if bias is not None:
+            bq, bk, bv = torch.split(bias, [q.shape[-1], k.shape[-1], v.shape[-1]])
+            q, k, v = q + bq, k + bk, v + bv
+        b, s_len, t_len = q.shape[0], q.shape[1], k.shape[1]
+        d, dv = q.shape[-1] // heads, v.shape[-1] // heads
+        q = q.reshape(b, s_len, heads, d).transpose(1, 2)
+        k = k.reshape(b, t_len, heads, d).transpose(1, 2)
+        v = v.reshape(b, t_len, heads, dv).transpose(1, 2)
+        if past_k is not None:
+            k, v = torch.cat((past_k.to(k.dtype), k), dim=2), torch.cat((past_v.to(v.dtype), v), dim=2)
+        total = k.shape[2]
+        scale = a.get("scale", 0.0) or 1.0 / (d ** 0.5)
+        scores = torch.matmul(q, k.transpose(-1, -2)) * scale
+        if attn_bias is not None:
+            scores = scores + attn_bias
+        if a.get("unidirectional", 0):
+            qpos = (total - s_len + torch.arange(s_len, device=q.device)).reshape(-1, 1)
+            scores = scores.masked_fill(torch.arange(total, device=q.device).reshape(1, -1) > qpos, float("-inf"))
+        out = torch.matmul(torch.softmax(scores, dim=-1), v).transpose(1, 2).reshape(b, s_len, heads * dv)
+        return (out, k, v)[:max(1, len(n.output))]
+
     # quantization operators (ONNX QuantizeLinear / DequantizeLinear / DynamicQuantizeLinear, opset 21 semantics)
     @staticmethod
     def _per_axis(p, like, axis):

@@ -983,11 +983,25 @@ def test_contrib_operators_of_genai_style_exports():
     torch.testing.assert_close(padded["y"][0], full["y"][0], rtol=1e-5, atol=1e-5)
 
     def one(op, inputs, outputs=("y",), domain="com.microsoft", **attrs):
-        names = [f"i{k}" for k in range(len(inputs))]
+        names = ["" if v is None else f"i{k}" for k, v in enumerate(inputs)]           # None: an optional input left out
+        given = [(n, v) for n, v in zip(names, inputs) if v is not None]
         g = P.Message("GraphProto", name="g", node=[P.make_node(op, names, list(outputs), domain=domain, **attrs)],
-                      input=_declared(names, inputs), output=[P.make_value_info(o, 1, None) for o in outputs if o])
+                      input=_declared(*zip(*given)), output=[P.make_value_info(o, 1, None) for o in outputs if o])
         m = P.Message("ModelProto", ir_version=10, graph=g, opset_import=[P.Message("OperatorSetIdProto", domain="", version=21)])
-        return GraphRunner(m, device="cpu")(dict(zip(names, inputs)))
+        return GraphRunner(m, device="cpu")(dict(given))
+
+    # MultiHeadAttention: separate q / k / v with a bias, an additive attention bias, a past, causal
+    mh, md = 4, 8
+    mq, mk, mv, mb = torch.randn(2, 3, 32), torch.randn(2, 3, 32), torch.randn(2, 3, 32), torch.randn(96)
+    pk, pv, ab = torch.randn(2, mh, 5, md), torch.randn(2, mh, 5, md), torch.randn(1, mh, 3, 8)
+    got = one("MultiHeadAttention", [mq, mk, mv, mb, None, ab, pk, pv], outputs=("y", "pk", "pv"), num_heads=mh, unidirectional=1)
+    split = lambda t, o: (t + mb[o:o + 32]).reshape(2, 3, mh, md).transpose(1, 2)          # noqa: E731
+    kk, vv = torch.cat((pk, split(mk, 32)), 2), torch.cat((pv, split(mv, 64)), 2)
+    sc = split(mq, 0) @ kk.transpose(-1, -2) / md ** 0.5 + ab
+    sc = sc.masked_fill(torch.arange(8).reshape(1, -1) > (5 + torch.arange(3)).reshape(-1, 1), float("-inf"))
+    torch.testing.assert_close(got["y"], (torch.softmax(sc, -1) @ vv).transpose(1, 2).reshape(2, 3, 32), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(got["pk"], kk)
+    torch.testing.assert_close(got["pv"], vv)
 
     t, skip, gamma = torch.randn(2, 5, 32), torch.randn(2, 5, 32), torch.rand(32) + 0.5
     rms = lambda v: v * torch.rsqrt(v.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma      # noqa: E731
