@@ -398,22 +398,30 @@ def save_model(model: Message, path, external_data: str | None = None, size_thre
     memory-mapping loaders ask for), 64 otherwise -- and the model file keeps the references.  Without it everything is
     inline, which protobuf caps at 2 GiB: a larger model is refused rather than written unreadable.  `model` itself is not
     modified."""
-    if external_data is None:
-        chunks: list = []
+    path = os.fspath(path)
+    model_tmp = f"{path}.tmp{os.getpid()}"                 # both files are written under temporary names and renamed when complete:
+    if external_data is None:                              # a reader never sees half a file, and a model whose tensors are mapped
+        chunks: list = []                                  # from the very files being replaced (dst == src) keeps its old bytes
         n = _serialize_into(model, chunks)
         if n >= 1 << 31:
             raise ValueError(f"onnx_proto: the serialised model is {n} bytes; a protobuf message cannot exceed 2 GiB: pass "
                              "external_data='<file name>' to keep the tensors in a side file")
-        with open(path, "wb") as f:
-            for c in chunks:
-                f.write(c)
+        try:
+            with open(model_tmp, "wb") as f:
+                for c in chunks:
+                    f.write(c)
+            os.replace(model_tmp, path)
+        finally:
+            _remove_quietly(model_tmp)
         return
     if os.path.basename(external_data) != external_data:
         raise ValueError("onnx_proto: external_data is a file name next to the model, not a path")
     base = os.path.dirname(os.path.abspath(path))
+    data_path = os.path.join(base, external_data)
+    data_tmp = f"{data_path}.tmp{os.getpid()}"
     swapped = []                                           # (tensor, raw_data) put back when the file is written
     try:
-        with open(os.path.join(base, external_data), "wb") as data:
+        with open(data_tmp, "wb") as data:
             pos = 0
             for t in _tensors_of(model.graph):
                 if t.data_location or not t.has("raw_data") or len(t.raw_data) < size_threshold:
@@ -435,12 +443,23 @@ def save_model(model: Message, path, external_data: str | None = None, size_thre
         n = _serialize_into(model, chunks)
         if n >= 1 << 31:
             raise ValueError(f"onnx_proto: {n} bytes remain inline; lower size_threshold")
-        with open(path, "wb") as f:
+        with open(model_tmp, "wb") as f:
             for c in chunks:
                 f.write(c)
+        os.replace(data_tmp, data_path)
+        os.replace(model_tmp, path)
     finally:
         for t, raw in swapped:
             t.raw_data, t.data_location, t.external_data = raw, None, []
+        _remove_quietly(data_tmp)
+        _remove_quietly(model_tmp)
+
+
+def _remove_quietly(path) -> None:
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
 
 
 # --------------------------------------------------------------------------------------------------------------- tensors

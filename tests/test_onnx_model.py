@@ -1225,6 +1225,28 @@ def test_a_shared_weight_that_cannot_be_duplicated_is_refused_at_its_second_cons
     assert [n.op_type for n in out.graph.node] == ["QMatMulWeightsOnlyQDQ"] * 2
 
 
+def test_a_model_can_be_written_over_the_files_its_tensors_are_mapped_from(tmp_path):
+    """Both files are written under temporary names and renamed: quantizing a file onto itself does not truncate the side file under
+    the live memory maps, and no partial file is ever visible under the final names."""
+    import onnx_quantize_amd.model_quantize as MQ
+    src = tmp_path / "m.onnx"
+    P.save_model(fixture("block"), src, external_data="m.onnx.data", size_threshold=16)
+    loaded = P.load_model(src)                                                   # tensors mapped from m.onnx.data
+    before = {t.name: P.tensor_to_numpy(t).copy() for t in loaded.graph.initializer}
+    P.save_model(loaded, src, external_data="m.onnx.data", size_threshold=16)    # onto itself
+    again = P.load_model(src)
+    assert all(np.array_equal(before[t.name], P.tensor_to_numpy(t)) for t in again.graph.initializer)
+    assert all(np.array_equal(before[t.name], P.tensor_to_numpy(t)) for t in loaded.graph.initializer)      # the old maps read the old inode
+    want = P.serialize(q_oracle(fixture("block"), CONFIGS["int8_channel"]()))
+    MQ.quantize_file(src, src, CONFIGS["int8_channel"](), external_data="m.onnx.data", weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias)
+    out = P.load_model(src)
+    assert sum(bool(n.domain) for n in out.graph.node) > 0
+    got = {t.name: P.tensor_to_numpy(t) for t in out.graph.initializer}
+    ref = {t.name: P.tensor_to_numpy(t) for t in P.parse_model(want).graph.initializer}
+    assert set(got) == set(ref) and all(np.array_equal(got[k], ref[k]) for k in ref)
+    assert sorted(os.listdir(tmp_path)) == ["m.onnx", "m.onnx.data"]             # no temporary file left behind
+
+
 def test_feeds_are_checked_like_a_session_checks_them():
     """calibrate.py:204-251 hands the user's arrays to an onnxruntime session, which refuses unknown names and other element types;
     so does the runner (a float feed used as token ids would otherwise run to nonsense)."""
