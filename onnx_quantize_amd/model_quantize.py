@@ -94,12 +94,28 @@ class _Graph:
         self.g = graph
         self.inits = {t.name: t for t in graph.initializer}
         self.device_values: dict = {}                     # initializer name -> the tensor the calibration walk uploaded (read-only)
+        # initializer name -> device tensor that IS the initializer's current value while its TensorProto still holds the old bytes
+        # (weights AWQ / SmoothQuant rescaled in HBM: the seam quantizes the device copy, so the fp32 host copy -- 26 GB for a 7B
+        # model -- is only made if something asks for it; nothing is serialised before `materialize()`)
+        self.pending_host: dict = {}
         self.graph_inputs = {i.name for i in graph.input}
         self.graph_outputs = {o.name for o in graph.output}
 
     def array(self, name):
+        self.materialize(name)
         t = self.inits.get(name)
         return None if t is None else tensor_to_numpy(t)
+
+    def materialize(self, name=None) -> None:
+        """Bring the put-off host copies up to date (one name, or all of them)."""
+        for nm in ([name] if name is not None else list(self.pending_host)):
+            value = self.pending_host.pop(nm, None)
+            if value is not None:
+                from .staging import download
+                resident = self.device_values.get(nm)
+                self.set_initializer(nm, download(value))
+                if resident is not None:
+                    self.device_values[nm] = resident
 
     def set_initializer(self, name, array, data_type=None):
         return self.set_tensor(numpy_to_tensor(name, array, data_type))
@@ -107,6 +123,7 @@ class _Graph:
     def set_tensor(self, t):
         name = t.name
         self.device_values.pop(name, None)                # the copy in HBM, if any, is of the old contents
+        self.pending_host.pop(name, None)
         if name in self.inits:
             old = self.inits[name]
             self.g.initializer[[id(x) for x in self.g.initializer].index(id(old))] = t
@@ -565,16 +582,23 @@ class DeviceSearches:
         ratio, _losses = fn(x, self._dev(w), *self._args(a))
         return float(ratio)
 
-    def scale_rows(self, w, scale):
+    def scale_rows(self, w, scale, want_host=True):
         """awq.py:187 / smooth_quant.py:114 (`scale.reshape(-1, 1) * weights`) on the copy of the weight the search already
         uploaded: (the product on the host, the same product in HBM for the seam -- no second upload, no pass over the weight in
         NumPy).  One fp32 multiply per element either way: the same bits."""
         import torch
         from .staging import download
         updated = self._dev(w) * torch.from_numpy(np.ascontiguousarray(scale, dtype=np.float32)).to(self._dev(w).device).reshape(-1, 1)
-        host = download(updated)
+        host = download(updated) if want_host else _OnDevice(updated)       # (a stand-in the clip search is handed back)
         self._w = (host, updated)                             # the clip search that may follow runs on the updated weight
         return host, updated
+
+
+class _OnDevice:
+    """A rescaled weight that exists in HBM only (its host copy has been put off, `_Graph.pending_host`)."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
 
 
 def _divide_in_place(x, scale: np.ndarray) -> None:
@@ -592,7 +616,7 @@ def _divide_in_place(x, scale: np.ndarray) -> None:
     x.div_(s.to(x.device).reshape(1, -1))
 
 
-def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> dict:
+def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches, defer_host: bool = False) -> dict:
     """pre_passes/__init__.py:72-83: every preprocessor's pass over the target nodes in graph order.  Both passes do the same
     surgery around different searches (smooth_quant.py:91-134, awq.py:114-204): the scale is folded into the weight's rows,
     a `Mul` by 1 / scale goes in front of the node (initializer `<node output>_scale`), the node's calibration input is
@@ -621,7 +645,7 @@ def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> d
                 scale = np.asarray(searches.awq_scale_search(x, w, cfg.weights), dtype=np.float32)
             resident = None
             if hasattr(searches, "scale_rows"):
-                updated, resident = searches.scale_rows(w, scale)
+                updated, resident = searches.scale_rows(w, scale, want_host=not defer_host)
             else:
                 updated = np.multiply(scale.reshape(-1, 1), w)
             name = f"{out_name}_scale"
@@ -635,7 +659,10 @@ def _preprocess(G: _Graph, targets, qconfig: QConfig, meta: dict, searches) -> d
             nodes.insert([id(n) for n in nodes].index(id(node)), mul)
             G.g.node = nodes
             node.input = [mul_out] + list(node.input)[1:]
-            G.set_initializer(w_name, updated.astype(np.float32, copy=False))
+            if isinstance(updated, _OnDevice):
+                G.pending_host[w_name] = resident             # the TensorProto keeps the old bytes until somebody asks (`_Graph.array`)
+            else:
+                G.set_initializer(w_name, updated.astype(np.float32, copy=False))
             if resident is not None:
                 G.device_values[w_name] = resident            # the seam quantizes this copy instead of uploading the weight again
             if kind == "awq" and pre.clip_search:
@@ -762,7 +789,8 @@ class Prepared:
         self.model, self.graph, self.targets, self.meta, self.per_node = model, graph, targets, meta, per_node
 
 
-def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, searches=None, post_calibration="if_read") -> Prepared:
+def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, searches=None, post_calibration="if_read",
+                     _defer_host_copies: bool = False) -> Prepared:
     """quantize.py:50-59 + pre_passes/__init__.py:47-98: opset, names, duplicated initializers, MatMul + Add -> Gemm, Gemm with
     `transB = 0`, calibration, the preprocessors' passes and the calibration after them.  `post_calibration`: "if_read" skips
     the second calibration walk when nothing downstream reads its results (weight-only RTN behind AWQ / SmoothQuant: no static
@@ -780,14 +808,17 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
         keep = (getattr(searches, "wants", True) if calibrate is _calibrate else True) if qconfig.preprocessors else False
         meta = calibrate(model, G, targets, qconfig, device, keep_inputs=keep)
     if qconfig.preprocessors and targets:                   # pre_passes/__init__.py:72-88
-        per_node = _preprocess(G, targets, qconfig, meta, searches)
+        per_node = _preprocess(G, targets, qconfig, meta, searches, defer_host=_defer_host_copies)
         _name_nodes(G)
         read = any(a is not None and a.is_static for a in (qconfig.input_activations, qconfig.output_activations)) or \
             bool(qconfig.weights.algorithm.requires_calibration)
         if any(p.requires_post_calibration for p in qconfig.preprocessors) and (read or post_calibration == "always"):
             logger.info("Re-calibrating the model after pre-processing...")
+            G.materialize()                                  # the walk reads the rescaled weights from the model
             meta = calibrate(model, G, targets, qconfig, device, keep_inputs=post_calibration == "always" and not read)
     qconfig.calibration_data = None                         # pre_passes/__init__.py:90: the caller's configuration lets go of the data
+    if not _defer_host_copies:
+        G.materialize()
     return Prepared(model, G, targets, meta, per_node)
 
 
@@ -817,17 +848,26 @@ def quantize_model(model, qconfig: QConfig, *, device="cuda", weight_arrays=None
         logger.info("No quantization parameters specified in qconfig. Returning original model.")
         return as_model(model)
     with _on(device):
-        prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
+        prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches, _defer_host_copies=weight_arrays is None)
         return _emit(prepared, qconfig, weight_arrays if weight_arrays is not None else _PackedSeam(), quantize_bias)
 
 
-def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bias):
+def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bias, on_device: bool = False):
     G = prepared.graph
     has_bias = len(node.input) > 2
-    w = _Const(node.input[1], G.array(node.input[1]), G.device_values.get(node.input[1]))
+    name = node.input[1]
+    resident = G.device_values.get(name)
+    cfg = prepared.per_node.get(id(node), qconfig)
+    dims = tuple(int(d) for d in G.inits[name].dims)
+    if (on_device and name in G.pending_host and resident is not None and tuple(resident.shape) == dims
+            and getattr(cfg.weights.algorithm, "algorithm_type", None) in ("rtn", "hqq", "gptq")):
+        host = np.broadcast_to(np.float32(0), dims)           # the seam reads the shape only: it quantizes the copy in HBM
+    else:
+        host = G.array(name)
+    w = _Const(name, host, resident)
     b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
     node_meta = prepared.meta.get(id(node), {})
-    return plan_node(node.op_type, node.input[0], w, node.output[0], prepared.per_node.get(id(node), qconfig), node_meta, bias=b,
+    return plan_node(node.op_type, node.input[0], w, node.output[0], cfg, node_meta, bias=b,
                      out=_Out(node_meta), weight_arrays=weight_arrays, quantize_bias=quantize_bias)
 
 
@@ -859,7 +899,7 @@ def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) ->
             raise ValueError(f"node '{node.name}': its weight '{w_name}' is a graph output or is read elsewhere and could not be duplicated "
                              "(it is listed among the graph's inputs / outputs); remove it from there or ignore this node")
         in_channels = int(G.inits[w_name].dims[0])
-        plan = _plan(prepared, node, qconfig, weight_arrays, quantize_bias)
+        plan = _plan(prepared, node, qconfig, weight_arrays, quantize_bias, on_device=isinstance(weight_arrays, _PackedSeam) or getattr(weight_arrays, "on_device", False))
         packed = getattr(weight_arrays, "packed", {})
         for name, array in plan.initializers:
             if name != w_name and name in G.inits and (readers.get(name, 0) > 1 or name in G.graph_outputs):
@@ -902,6 +942,7 @@ def _emit(prepared: Prepared, qconfig: QConfig, weight_arrays, quantize_bias) ->
     if uses_ms and MS_DOMAIN not in have:
         model.opset_import.append(Message("OperatorSetIdProto", domain=MS_DOMAIN, version=1))
 
+    G.materialize()                                         # (a rescaled weight no rewrite replaced: its host copy is due now)
     _remove_unused_initializers(G)
     _deduplicate_initializers(G)
     check_model(model)                                      # what leaves is structurally sound, or the caller hears why not
@@ -929,7 +970,7 @@ def quantize_model_sharded(model, qconfig: QConfig, *, group=None, device="cuda"
 def _quantize_sharded(model, qconfig, group, device, weight_arrays, quantize_bias, calibrate, searches):
     from .sharding import LayerSpec, quantize_sharded
 
-    prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches)
+    prepared = apply_pre_passes(model, qconfig, device=device, calibrate=calibrate, searches=searches, _defer_host_copies=weight_arrays is None)
     device_default = weight_arrays is None
     if device_default:
         from .seam import weight_arrays
@@ -952,7 +993,7 @@ def _quantize_sharded(model, qconfig, group, device, weight_arrays, quantize_bia
                 captured.append((packed[0],) + tuple(arrays[1:]) if packed is not None else arrays)
             return arrays
 
-        _plan(prepared, prepared.targets[i], qconfig, recording, quantize_bias)
+        _plan(prepared, prepared.targets[i], qconfig, recording, quantize_bias, on_device=device_default)
         (arrays,) = captured                                 # one matrix per node: its weight (a bias is a vector)
         return tuple(np.asarray(a) for a in arrays)
 
@@ -963,6 +1004,8 @@ def _quantize_sharded(model, qconfig, group, device, weight_arrays, quantize_bia
     class FromTheRanks:
         """The gathered arrays as the emission's provider; integers that arrived nibble-packed go into their TensorProto as they are
         (`packed`, the protocol of `_PackedSeam`)."""
+
+        on_device = device_default                       # (reads shapes only: a weight that lives in HBM alone stays there)
 
         def __init__(self):
             self.packed: dict = {}

