@@ -76,6 +76,8 @@ def configs(name, data):
                                        calibration_data=data, calibration_params=cal),
         "awq_uint4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QUInt4, group_size=128), preprocessors=[AwqConfig()],
                                           calibration_data=data, calibration_params=cal),
+        "awq_static_int8": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8, strategy="channel"), input_activations=act("int8"),
+                                           preprocessors=[AwqConfig()], calibration_data=data, calibration_params=cal),     # two walks: the ranges come from the second
         "gptq_int4_g128": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=128, algorithm=GPTQConfig(mode="corrected")),
                                           calibration_data=data, calibration_params=cal),
     }[name]()

@@ -60,7 +60,10 @@ class GraphRunner:
 
     takes_sink = True        # `runner(feed, sink=...)` hands every wanted value over as it is produced (calibration_driver.run_calibration)
 
-    def __init__(self, model: Message, outputs=None, device="cuda", capture: bool = False, matmul: str = "torch"):
+    def __init__(self, model: Message, outputs=None, device="cuda", capture: bool = False, matmul: str = "torch", constants=None):
+        """`constants`: {initializer name: tensor on the device} for initializers the caller already holds in HBM (a second
+        calibration walk over the weights the first one uploaded; a weight that was rescaled on the device and whose TensorProto
+        still has the old bytes): used as they are instead of the file's bytes when device, element type and shape fit."""
         import torch
 
         self.model, self.graph = model, model.graph
@@ -93,7 +96,12 @@ class GraphRunner:
                 self.input_types[i.name] = np.dtype(_NP_OF[tt.elem_type])
         self.constants = {}
         for t in self.graph.initializer:
-            self.constants[t.name] = self._constant(tensor_to_numpy(t), t.data_type)
+            held = None if constants is None else constants.get(t.name)
+            if (held is not None and held.device.type == self.device.type and tuple(held.shape) == tuple(int(d) for d in t.dims)
+                    and _numpy_dtype(held) == np.dtype(_NP_OF.get(t.data_type, np.void))):
+                self.constants[t.name] = held
+            else:
+                self.constants[t.name] = self._constant(tensor_to_numpy(t), t.data_type)
         self.nodes = self._needed_nodes(self.graph.node, self.wanted)
         # the last node that reads each value: it is dropped right after
         self.last_use: dict[str, int] = {}

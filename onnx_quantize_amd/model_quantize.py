@@ -495,7 +495,9 @@ def _calibrate(model: Message, G: _Graph, targets, qconfig: QConfig, device, kee
         data = generate_random_calibration_data(num_samples, inputs)
     # a model input that a target node reads directly is "produced" by the feed: the runner returns it like any other value
     # batches of one (small) shape replay a recorded pass; large products with constant weights take the fp16-piece GEMM
-    runner = GraphRunner(model, outputs=wanted, device=device, capture=True, matmul="pieces")
+    # weights an earlier walk (or a rescale on the device) left in HBM are run on as they are: `G.device_values` is dropped for a
+    # name whenever its initializer is set, so what it holds is current -- also where the TensorProto is not (`pending_host`)
+    runner = GraphRunner(model, outputs=wanted, device=device, capture=True, matmul="pieces", constants=dict(G.device_values))
     stream = ActivationStream(calibrator=calibrator, input_names=in_names if cal_in else (), output_names=out_names if cal_out else (),
                               hessian_names=in_names if (algo and not keep_inputs) else (),
                               keep_names=in_names if keep_inputs is True else (),
@@ -814,7 +816,8 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
             bool(qconfig.weights.algorithm.requires_calibration)
         if any(p.requires_post_calibration for p in qconfig.preprocessors) and (read or post_calibration == "always"):
             logger.info("Re-calibrating the model after pre-processing...")
-            G.materialize()                                  # the walk reads the rescaled weights from the model
+            if calibrate is not _calibrate:
+                G.materialize()                              # a provider that reads the rescaled weights from the model's bytes
             meta = calibrate(model, G, targets, qconfig, device, keep_inputs=post_calibration == "always" and not read)
     qconfig.calibration_data = None                         # pre_passes/__init__.py:90: the caller's configuration lets go of the data
     if not _defer_host_copies:
