@@ -591,8 +591,11 @@ class GraphRunner:
             hit = self._weight_pieces.get(id(w))
             if hit is None and any(w is c for c in self.constants.values()):
                 from .hip import ops
-                hit = self._weight_pieces[id(w)] = (w, ops.matmul_prepare(w, False))
-            if hit is not None and hit[0] is w:
+                # the pieces are a second copy of the weight (two fp16 halves): kept only while HBM has room for them and the
+                # activations of a pass; past that the product stays with torch's fp32 GEMM on the weight itself
+                free = torch.cuda.mem_get_info(w.device)[0] + torch.cuda.memory_reserved(w.device) - torch.cuda.memory_allocated(w.device)
+                hit = self._weight_pieces[id(w)] = (w, ops.matmul_prepare(w, False) if free > _PIECES_HEADROOM * w.numel() * 4 else None)
+            if hit is not None and hit[0] is w and hit[1] is not None:
                 from .hip import ops
                 return ops.matmul_pieces(x[0], hit[1])
         return torch.matmul(x[0], w)
@@ -1237,6 +1240,7 @@ class GraphRunner:
 
 _CAPTURE_MAX_INPUT_ELEMENTS = 1 << 20      # recording pays when a pass is hundreds of small launches (one short sequence), not above
 _PIECES_MIN_WIDTH, _PIECES_MIN_ROWS = 512, 256
+_PIECES_HEADROOM = 8                      # free HBM, in sizes of the weight, below which its fp16 pieces are not kept
 _SCALAR_FRIENDLY = {"Add", "Sub", "Mul", "Div", "Pow"}
 _HOST_OPERANDS = {"GroupQueryAttention", "RotaryEmbedding", "CumSum", "Reshape", "Expand", "Slice", "Tile", "Unsqueeze", "Squeeze", "Split",
                   "ConstantOfShape", "Gather", "Trilu", "ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Range", "Clip", "Pad", "Resize", "TopK", "OneHot"}

@@ -376,6 +376,16 @@ def test_large_products_of_the_calibration_walk_take_the_fp16_piece_gemm():
     torch.testing.assert_close(a["y"], b["y"], rtol=1e-4, atol=1e-4)
     with pytest.raises(ValueError, match="matmul must be"):
         GraphRunner(model, device="cuda", matmul="fast")
+    # a nearly full HBM: the second copy of the weight is not made, the product stays with torch's GEMM on the weight itself
+    import onnx_quantize_amd.graph_runner as GR
+    headroom = GR._PIECES_HEADROOM
+    try:
+        GR._PIECES_HEADROOM = 1 << 40
+        tight = GraphRunner(model, outputs=["h", "y"], device="cuda", matmul="pieces")
+        c = tight(x)
+        assert [v[1] for v in tight._weight_pieces.values()] == [None] and torch.equal(c["h"], b["h"])
+    finally:
+        GR._PIECES_HEADROOM = headroom
 
 
 def test_calibration_through_the_piece_gemm_agrees_with_the_fp32_walk():
