@@ -22,7 +22,7 @@ def _free_port():
 
 
 def _configs():
-    from onnx_quantize_amd import GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
+    from onnx_quantize_amd import AwqConfig, GPTQConfig, QActivationArgs, QConfig, QuantType, QWeightArgs
     import numpy as np
     data = np.random.default_rng(5).standard_normal((16, 6, 64)).astype(np.float32)
     return {
@@ -31,6 +31,9 @@ def _configs():
         "static_int8": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt8), input_activations=QActivationArgs(dtype=QuantType.QInt8),
                                        output_activations=QActivationArgs(dtype=QuantType.QInt8), calibration_data=data,
                                        calibration_params={"num_samples": 16, "batch_size": 4}),
+        # the rescaled weights live in HBM only on every rank (`_Graph.pending_host`); int4: the grouped QDQ route, packed nibbles
+        "awq_clip_int4_g32": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=32), preprocessors=[AwqConfig(clip_search=True)],
+                                             calibration_data=data, calibration_params={"num_samples": 16, "batch_size": 4}),
         "gptq_int4_g32": lambda: QConfig(weights=QWeightArgs(dtype=QuantType.QInt4, group_size=32, algorithm=GPTQConfig(block_size=16)),
                                          calibration_data=data, calibration_params={"num_samples": 16, "batch_size": 4}),
     }
@@ -54,8 +57,8 @@ def _worker(rank, world, port, q, device):
     providers = {}
     if device == "cpu":
         import oq_oracle as O
-        from onnx_model_helpers import oracle_calibrate, oracle_weight_arrays
-        providers = dict(weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias, calibrate=oracle_calibrate("cpu"))
+        from onnx_model_helpers import OracleSearches, oracle_calibrate, oracle_weight_arrays
+        providers = dict(weight_arrays=oracle_weight_arrays, quantize_bias=O.quantize_bias, calibrate=oracle_calibrate("cpu"), searches=OracleSearches())
     seen = []
     if "weight_arrays" in providers:
         inner = providers["weight_arrays"]
