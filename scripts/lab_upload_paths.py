@@ -12,6 +12,7 @@ and how fast results come back into FRESH NumPy arrays (`staging.download`: ever
   huge        the same after madvise(MADV_HUGEPAGE) on the new array           2 MiB first-touch faults where the kernel allows them
   populated   ... and madvise(MADV_POPULATE_WRITE)                             all first-touch faults in one call, before the copy
   pinned      torch.empty(pin_memory=True) per result                          page-locked destination
+  populated by N threads                                                       the first-touch faults taken by N threads at once
   reused      one destination for all                                          the ceiling
 
     python scripts/lab_upload_paths.py [--gib 8] [--chunk-mib 172] [--down-mib 22]
@@ -199,8 +200,22 @@ def downloads(a, libc, page):
         advise(out, MADV_POPULATE_WRITE)
         return out
 
+    pools = {k: ThreadPoolExecutor(k) for k in (2, 4, 8)}
+
+    def populated_by(threads):
+        def make():
+            out = np.empty(n, dtype=np.uint8)
+            addr = out.ctypes.data
+            lo, hi = addr + (-addr % page), addr + n - (addr + n) % page
+            step = -(-(hi - lo) // threads)
+            step += -step % page
+            list(pools[threads].map(lambda a: libc.madvise(a, min(step, hi - a), MADV_POPULATE_WRITE), range(lo, hi, step)))
+            return out
+        return make
+
     one = np.empty(n, dtype=np.uint8)
-    for name, make in (("fresh", fresh), ("huge", huge), ("populated", populated), ("populated, 4 KiB pages", populated_small),
+    for name, make in (("fresh", fresh), ("populated by 2 threads", populated_by(2)), ("populated by 4 threads", populated_by(4)),
+                       ("populated by 8 threads", populated_by(8)), ("huge", huge), ("populated", populated), ("populated, 4 KiB pages", populated_small),
                        ("pinned", lambda: torch.empty(n, dtype=torch.uint8, pin_memory=True).numpy()), ("reused", lambda: one), ("fresh", fresh)):
         run(name, make)
 
