@@ -23,28 +23,38 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 
 import numpy as np
 
 _PREFAULT_MIN_BYTES = 4 << 20
 _PREFAULT_THREADS = 4
 _MADV_POPULATE_WRITE = 23                                  # Linux >= 5.14; refused (EINVAL) by older kernels: then the copy faults as before
+_prefault_lock = threading.Lock()
 _prefault_state: dict = {}                                 # {"pid", "pool", "madvise", "page"} of THIS process (a forked child makes its own)
+
+
+def _prefault_setup(st: dict) -> None:
+    if st.get("pid") == os.getpid():                       # another thread got here first
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        madvise = ctypes.CDLL(None, use_errno=True).madvise
+        madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        madvise.restype = ctypes.c_int
+    except (OSError, AttributeError):
+        madvise = None
+    st.update(pool=ThreadPoolExecutor(_PREFAULT_THREADS, thread_name_prefix="oq-prefault"), madvise=madvise,
+              page=os.sysconf("SC_PAGE_SIZE"), works=madvise is not None)
+    st["pid"] = os.getpid()                                # last: the state is complete when a reader sees its own pid
 
 
 def _prefault(out: np.ndarray) -> None:
     """Touch the pages of a fresh C-contiguous array from several threads so that the copy into it does not fault one page at a time."""
     st = _prefault_state
     if st.get("pid") != os.getpid():
-        from concurrent.futures import ThreadPoolExecutor
-        try:
-            madvise = ctypes.CDLL(None, use_errno=True).madvise
-            madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-            madvise.restype = ctypes.c_int
-        except (OSError, AttributeError):
-            madvise = None
-        st.update(pid=os.getpid(), pool=ThreadPoolExecutor(_PREFAULT_THREADS, thread_name_prefix="oq-prefault"), madvise=madvise,
-                  page=os.sysconf("SC_PAGE_SIZE"), works=madvise is not None)
+        with _prefault_lock:
+            _prefault_setup(st)
     if not st["works"]:
         return
     page, addr = st["page"], out.ctypes.data
