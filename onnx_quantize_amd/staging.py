@@ -27,6 +27,8 @@ import threading
 
 import numpy as np
 
+__all__ = ["upload", "download", "content_mark"]
+
 _PREFAULT_MIN_BYTES = 4 << 20
 _PREFAULT_THREADS = 4
 _MADV_POPULATE_WRITE = 23                                  # Linux >= 5.14; refused (EINVAL) by older kernels: then the copy faults as before
@@ -66,8 +68,6 @@ def _prefault(out: np.ndarray) -> None:
     rcs = list(st["pool"].map(lambda a: st["madvise"](a, min(step, hi - a), _MADV_POPULATE_WRITE), range(lo, hi, step)))
     if any(rcs):
         st["works"] = False                                # this kernel does not know the advice: stop asking
-
-__all__ = ["upload", "download", "content_mark"]
 
 
 def content_mark(a: np.ndarray):
