@@ -114,10 +114,13 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
  *     Concurrency of the ticketed kernels (both entry points): inside a call a workgroup may wait for other workgroups of the
  *     SAME launch, which is safe on its own (see rtn_resident.hip); two such launches running at the same time on one device
  *     would compete for the CUs their waiting workgroups hold and could stop each other for good.  The library therefore
- *     orders them itself: a per-channel / per-tensor / tall-group call issued on another stream than the previous such call of
- *     the device first makes its stream wait (on the device, never on the host) for an event recorded behind that call, so
- *     these kernels never overlap whatever streams and threads they come from (a stream that is being captured into a graph
- *     is left alone: the graph's edges order its kernels).  What the library cannot order are kernels of ANOTHER PROCESS on
+ *     orders them itself.  While every such call of a device comes from one stream, the stream orders them.  The first call from
+ *     a second stream blocks the HOST once (a device synchronisation: the library keeps no handle of a caller's stream, so a
+ *     stream that was destroyed in between cannot hurt); from then on every such call makes its stream wait, on the device, for
+ *     an event recorded behind the previous one, on the calling stream itself (2.5-3.5 us per call).  So these
+ *     kernels never overlap whatever LIVE streams and threads they come from.  A stream that is being CAPTURED into a graph
+ *     never runs them: such a call takes the three-launch path (W read twice, no tickets; it needs the workspace
+ *     oq_rtn_workspace_bytes states), because replays of a graph are ordered against nothing the library can see.  What the library cannot order are kernels of ANOTHER PROCESS on
  *     the same GPU: do not run two processes that issue these calls on one device.  The fused group kernels
  *     (group_size <= 256) never wait and have no such restriction. */
 size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_size);

@@ -1237,6 +1237,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
 namespace oq {
 bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, const void* q, int32_t strategy, int64_t g, int32_t layout,
                            bool emit_q, size_t workspace_bytes);
+bool rtn_stream_is_capturing(hipStream_t s);
 int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
                           float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state);
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
@@ -1486,9 +1487,12 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
     // columns taller than 16384 rows) runs on the three launches below
     {
         static const Tuning tr = Tuning::from_env();
-        if (tr.resident != 0 && g_state.state != nullptr && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, g_state.bytes))
+        // a stream under capture takes the three launches below: the ticketed kernels must never overlap one another, and a
+        // replayed graph is ordered against nothing the library sees
+        const bool ticketed_ok = tr.resident != 0 && !rtn_stream_is_capturing(s);
+        if (ticketed_ok && g_state.state != nullptr && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, g_state.bytes))
             return rtn_resident_impl(W, K, N, ldw, grid, strategy, g, q8, scale_out, zp8, layout, g_state.state, g_state.bytes, s, true);
-        if (tr.resident != 0 && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, workspace ? workspace_bytes : 0))
+        if (ticketed_ok && rtn_resident_eligible(K, N, ldw, W, q_out, strategy, g, layout, emit_q, workspace ? workspace_bytes : 0))
             return rtn_resident_impl(W, K, N, ldw, grid, strategy, g, q8, scale_out, zp8, layout, workspace, workspace_bytes, s, false);
     }
 

@@ -972,17 +972,33 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
 // query promised for an otherwise free device: two of them launched from different streams could each hold half of the CUs
 // with workgroups that wait for siblings which the other kernel keeps from ever being dispatched (the per-tensor kernel's
 // `go` needs every workgroup of its grid to arrive) -- a hang of the whole GPU, not an error.  So the launches of one device
-// form a chain: a call on another stream than the previous one records an event behind what that stream has queued and
-// makes its own stream wait for it (a device-side wait; the host never blocks).  Calls of one stream are ordered by the
-// stream itself and pay a capture query and a mutex.  (Kernels of OTHER processes on the same GPU
-// are out of reach: include/oq_hip.h says so.)
+// form a chain.  The chain never keeps a caller's stream HANDLE (a destroyed stream's handle is a dangling
+// pointer); it keeps the handle's VALUE as an opaque key that is compared and never handed to HIP again, and the only stream
+// the chain ever touches is the one of the call in progress.  (`hipStreamGetId` would be the cleaner key; the libamdhip64 that
+// torch 2.10+rocm7.0 loads does not export it.  A new stream at a destroyed stream's address compares equal: the runtime frees
+// a queue object only after the queue has drained, so the address cannot come back while the old stream's kernel still runs.)
+//   * as long as every ticketed call of the device came from ONE stream, the stream itself orders them: a call pays a
+//     capture query and a mutex, no event (recorded behind every launch it cost 2.5-3.5 us per call: 62.7 ->
+//     66.2 us per channel call on 4096 x 11008);
+//   * the first call from a SECOND stream blocks the host once (`hipDeviceSynchronize`: whatever the first stream queued has
+//     ended, whether or not that stream still exists) and switches the device to the eager form for good;
+//   * eager form: every call makes its stream wait (device side) for the event of the previous ticketed launch and records
+//     the event behind its own launch -- on its own, live stream.
+// A capturing stream never gets here (rtn.hip takes the three-launch path, which has no tickets: a replayed graph is ordered
+// against nothing the library can see).  Kernels of OTHER processes on the same GPU are out of reach: include/oq_hip.h says so.
 struct TicketChain {
     std::mutex m;
     hipEvent_t ev = nullptr;
-    hipStream_t last = nullptr;
-    bool any = false;
+    uintptr_t last_id = 0;
+    bool any = false, eager = false, recorded = false;
 };
 static TicketChain g_chain[64];
+
+bool rtn_stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cap != hipStreamCaptureStatusNone;
+}
 
 static int32_t rtn_resident_launch(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
                                    float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state);
@@ -991,32 +1007,36 @@ int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, con
                           float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OQ_ERR_LAUNCH, "rtn: no current device");
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
 #ifdef OQ_NO_TICKET_CHAIN      /* lab: what the chain costs a single stream */
-    cap = hipStreamCaptureStatusActive;
+    return rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
 #endif
-    if (cap != hipStreamCaptureStatusNone)      // inside a graph capture the graph's own edges order the kernels; no foreign event may enter it
-        return rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
+    OQ_REQUIRE(!rtn_stream_is_capturing(s), OQ_ERR_UNSUPPORTED, "rtn: a ticketed kernel cannot be captured into a graph (its replays would be ordered against nothing)");
+    const uintptr_t id = reinterpret_cast<uintptr_t>(s);      // an opaque key from here on
     TicketChain& c = g_chain[dev];
-    std::lock_guard<std::mutex> lock(c.m);      // launch + record are one step of the chain
-    if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) {
-        c.ev = nullptr;
-        return fail(OQ_ERR_LAUNCH, "rtn: cannot create the event that orders ticketed launches");
+    std::lock_guard<std::mutex> lock(c.m);      // wait + launch + record are one step of the chain
+    if (c.any && !c.eager && c.last_id != id) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+        c.eager = true;
     }
-    if (c.any && c.last != s) {
-        // The event is recorded only NOW, behind whatever the previous stream has queued so far (its last ticketed kernel is
-        // in there): recorded behind every launch it cost 2.5-3.5 us per call of a single stream (62.7 -> 66.2 us per
-        // channel call on 4096 x 11008), which pays nothing this way.
-        if (hipEventRecord(c.ev, c.last) != hipSuccess) {
-            (void)hipGetLastError();                          // the previous stream is gone: nothing of it may still run when we go on
-            if (hipDeviceSynchronize() != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
-        } else if (hipStreamWaitEvent(s, c.ev, 0) != hipSuccess) {
-            return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+    if (c.eager) {
+        if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) {
+            c.ev = nullptr;
+            return fail(OQ_ERR_LAUNCH, "rtn: cannot create the event that orders ticketed launches");
         }
+        if (c.recorded && c.last_id != id && hipStreamWaitEvent(s, c.ev, 0) != hipSuccess)
+            return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
     }
     const int32_t st = rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
-    c.last = s;       // also after a launch that failed half way (its clear launch may be in the stream)
+    if (c.eager) {      // also after a launch that failed half way (its clear launch may be in the stream)
+        if (hipEventRecord(c.ev, s) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();       // nothing of this call may still run when the next one starts
+            c.recorded = false;
+        } else {
+            c.recorded = true;
+        }
+    }
+    c.last_id = id;
     c.any = true;
     return st;
 }

@@ -35,6 +35,26 @@ _MADV_POPULATE_WRITE = 23                                  # Linux >= 5.14; refu
 _prefault_lock = threading.Lock()
 _prefault_state: dict = {}                                 # {"pid", "pool", "madvise", "page"} of THIS process (a forked child makes its own)
 
+# THE INVARIANT OF THIS MODULE (tests/test_seam.py holds it): no GPU call, copy or stream is ever issued from a helper
+# thread.  The helper threads run `_populate` and nothing else -- one `madvise` system call on host memory that the calling
+# thread allocated and still owns; they see no tensor, no stream, no device pointer.  Both copies are issued by the CALLING
+# thread, blocking, after the helpers have returned (`pool.map` is consumed before the copy starts).
+
+
+def _populate(madvise, addr: int, length: int) -> int:
+    """What a helper thread runs: fault in `length` bytes of host memory at `addr`.  Host memory only."""
+    return madvise(addr, length, _MADV_POPULATE_WRITE)
+
+
+def _prefault_reset_in_child() -> None:
+    """A forked child inherits neither the parent's helper threads nor a lock some other parent thread may have held."""
+    global _prefault_lock
+    _prefault_lock = threading.Lock()
+    _prefault_state.clear()
+
+
+os.register_at_fork(after_in_child=_prefault_reset_in_child)
+
 
 def _prefault_setup(st: dict) -> None:
     if st.get("pid") == os.getpid():                       # another thread got here first
@@ -65,7 +85,8 @@ def _prefault(out: np.ndarray) -> None:
         return
     step = -(-(hi - lo) // _PREFAULT_THREADS)
     step += -step % page
-    rcs = list(st["pool"].map(lambda a: st["madvise"](a, min(step, hi - a), _MADV_POPULATE_WRITE), range(lo, hi, step)))
+    starts = range(lo, hi, step)
+    rcs = list(st["pool"].map(_populate, [st["madvise"]] * len(starts), starts, [min(step, hi - a) for a in starts]))
     if any(rcs):
         st["works"] = False                                # this kernel does not know the advice: stop asking
 

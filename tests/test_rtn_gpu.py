@@ -923,3 +923,30 @@ def test_ticketed_calls_from_threads_on_their_own_streams(ops):
         t.join(timeout=120)
     assert not any(t.is_alive() for t in threads), "a thread is still waiting for the GPU"
     assert not errors, errors
+
+
+def test_ticketed_strategies_under_graph_capture_take_the_three_launch_path(ops):
+    """a captured ticketed kernel would be replayed unordered against every other ticketed launch of the device
+    (an overlap is a hung GPU).  A capturing stream therefore gets the three-launch path (no tickets): same bits, and the
+    graph can be replayed at will next to eager ticketed calls on other streams."""
+    import torch
+    rng = np.random.default_rng(7)
+    w = dev(rng.standard_normal((2048, 1024), dtype=np.float32))
+    for qtype, strategy in (("int8", "channel"), ("uint8", "tensor")):
+        q0, s0, z0 = ops.rtn_quantize(w, qtype, strategy, -1)                       # eager: the ticketed kernels
+        out = (torch.empty_like(q0), torch.empty_like(s0).reshape(-1), torch.empty_like(z0).reshape(-1))
+        ops.rtn_quantize(w, qtype, strategy, -1, out=out)                           # workspaces exist before the capture
+        torch.cuda.synchronize()
+        for o in out:
+            o.zero_()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        with torch.cuda.graph(graph):
+            ops.rtn_quantize(w, qtype, strategy, -1, out=out)
+        for _ in range(3):
+            graph.replay()
+            with torch.cuda.stream(side):                                           # an eager ticketed call next to the replay
+                q1, s1, z1 = ops.rtn_quantize(w, qtype, strategy, -1)
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], q0) and out[1].cpu().numpy().tobytes() == s0.cpu().numpy().tobytes() and torch.equal(out[2].reshape(z0.shape), z0)
+        assert torch.equal(q1, q0) and torch.equal(z1, z0)
