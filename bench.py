@@ -133,6 +133,75 @@ def init_ranks(gpus: int, backend: str = "nccl"):
     return dev, rank, world
 
 
+def selftest_main(args) -> None:
+    """`--nccl-selftest`: the process group comes up first -- `init_process_group("nccl", device_id=...)` is the first GPU call of
+    this process --, then `sharding.collectives_selftest`.  One JSON line; exit code 1 with the message when a step fails.  The
+    program is never replaced and nothing is retried."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+    timeout = datetime.timedelta(seconds=int(os.environ.get("OQ_BENCH_PG_TIMEOUT", "120")))
+    t0 = time.perf_counter()
+    if args.selftest_backend == "gloo":
+        dev = None
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timeout)
+    else:
+        if torch.cuda.device_count() <= local_rank:       # counting devices does not initialise the GPU
+            raise SystemExit(f"rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=timeout)
+        torch.cuda.set_device(dev)
+    init_ms = (time.perf_counter() - t0) * 1e3
+    from onnx_quantize_amd.sharding import collectives_selftest
+
+    rec = collectives_selftest(dev, timeout_s=90.0)
+    rec["init_process_group_ms"] = round(init_ms, 1)
+    rec["device"] = None if dev is None else torch.cuda.get_device_name(dev)
+    if rank == 0:
+        print(json.dumps({"rccl_selftest": rec}), flush=True)
+    if rec["ok"]:
+        dist.destroy_process_group()
+        return
+    sys.stderr.write(f"[bench] rank {rank}: collectives self-test failed: {rec['error']}\n")
+    sys.stderr.flush()
+    os._exit(1)         # a stuck communicator must not keep the interpreter's shutdown waiting
+
+
+def run_selftest_child(timeout_s: float = 150.0) -> dict:
+    """`bench.py --gpus 1 --nccl-selftest` as a CHILD process (started, waited for, never exec'ed) and its record."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--nccl-selftest"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"ok": False, "error": f"the self-test child gave no answer within {timeout_s:.0f} s", "command": " ".join(cmd[1:])}
+    rec = None
+    for line in r.stdout.splitlines():
+        if line.startswith('{"rccl_selftest"'):
+            rec = json.loads(line)["rccl_selftest"]
+    if rec is None:
+        rec = {"ok": False, "error": f"exit code {r.returncode}: {r.stderr.strip()[-600:]}"}
+    rec["exit_code"] = r.returncode
+    rec["child_wall_s"] = round(time.perf_counter() - t0, 1)
+    rec["what"] = ("child process `bench.py --gpus 1 --nccl-selftest`: init_process_group('nccl', world_size=1, device_id=cuda:0) before any "
+                   "other GPU call, then sharding.collectives_selftest on device tensors (ms per step); not a scaling measurement")
+    return rec
+
+
 def stub_main(args) -> None:
     """`--stub`: the launch / barrier / max-over-ranks / one-JSON-line plumbing with a no-op step on gloo, no GPU.  Exists
     for the CPU test of the multi-rank path; its line says so and carries no measurement."""
@@ -592,12 +661,27 @@ def main() -> None:
     ap.add_argument("--gptq-tokens", type=int, default=128 * 2048)
     ap.add_argument("--qparams-only", action="store_true", help="diagnostic: scales/zero-points only (read path ceiling)")
     ap.add_argument("--stub", action="store_true", help="plumbing test on gloo without a GPU (tests/test_bench_launch.py)")
+    ap.add_argument("--nccl-selftest", action="store_true",
+                    help="bring up an RCCL communicator of `--gpus` ranks (1: a one-rank communicator on cuda:0) BEFORE any other GPU call, "
+                         "run every kind of exchange the multi-rank path issues once (sharding.collectives_selftest), print its record as "
+                         "one JSON line and exit 0 / 1.  With --backend gloo: the same steps on the CPU (tests)")
+    ap.add_argument("--selftest-backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--no-rccl-selftest", action="store_true", help="skip the `rccl_selftest` object (a child process running --nccl-selftest)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:          # before anything touches a GPU
         raise SystemExit(self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
     if args.stub:
         return stub_main(args)
+    if args.nccl_selftest:
+        return selftest_main(args)
+
+    # ---- first contact with RCCL, in a child of its own (N = 1, before this process touches the GPU): a one-rank communicator
+    # on cuda:0 and every kind of exchange the N-rank path issues.  Never the measured thing; a failure or a
+    # hang of the child is reported inside the object and the headline still goes out.
+    rccl_selftest = None
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_extras and not args.no_rccl_selftest and not args.qparams_only:
+        rccl_selftest = run_selftest_child()
 
     import torch
     import torch.distributed as dist
@@ -992,6 +1076,7 @@ def main() -> None:
         "packed_kn_layout": packed_kn,
         "strategies": strategies,
         "seam": seam,
+        "rccl_selftest": rccl_selftest,
         "gather": gather,
         "calibration": calibration,
         "model_file": model_file,

@@ -135,18 +135,20 @@ def llama2_7b_specs(tokens: int = 0, layers: int = 32, hidden: int = 4096, ffn: 
     return specs
 
 
-def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], mine: dict, *, group=None):
+def gather_device_results(specs: Sequence[LayerSpec], plan: list[list[int]], mine: dict, *, group=None, always_exchange: bool = False):
     """End-of-run exchange for results that live in HBM: ``mine[i] = (q, scale, zp)`` torch tensors on this
     rank's GPU.  Each rank flattens its results into ONE byte tensor, sizes are exchanged with a tiny
     all_gather, and a single padded ``gather`` (RCCL over xGMI with backend nccl) brings everything to rank 0.
-    Returns ``({name: (q, scale, zp)} on rank 0 | None, bytes_gathered)``."""
+    Returns ``({name: (q, scale, zp)} on rank 0 | None, bytes_gathered)``.  ``always_exchange``: run the collectives even
+    in a process group of ONE rank (`collectives_selftest`: the packing, the size exchange, the padded gather and the
+    unpacking meet the communicator on a one-GPU box)."""
     import torch
     import torch.distributed as dist
 
     distributed = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if distributed else 1
     rank = dist.get_rank(group) if distributed else 0
-    if world == 1:
+    if world == 1 and not (always_exchange and distributed):
         return {specs[i].name: mine[i] for i in sorted(mine)}, 0
     order = plan[rank]
     parts, meta = [], []
@@ -356,7 +358,7 @@ class PeersMissing(RuntimeError):
         self.missing = list(missing)
 
 
-def await_all_ranks(tag: str = "oq", *, timeout_s: float = 120.0, group=None) -> int:
+def await_all_ranks(tag: str = "oq", *, timeout_s: float = 120.0, group=None, always_exchange: bool = False) -> int:
     """Bounded "is everybody here?" that does not touch the data-path communicator: every rank writes one key into the
     process group's key-value store and waits -- at most ``timeout_s`` -- for the keys of all ranks.  Returns the number of
     ranks seen (= world size) or raises `PeersMissing` naming the absent ranks.  First contact with a real multi-GPU node
@@ -369,7 +371,7 @@ def await_all_ranks(tag: str = "oq", *, timeout_s: float = 120.0, group=None) ->
     if not (dist.is_available() and dist.is_initialized()):
         return 1
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not always_exchange:
         return 1
     from torch.distributed import distributed_c10d as c10d
 
@@ -552,14 +554,14 @@ def rtn_quantize_column_shard(w_cols, qtype: str, strategy: str, group_size=-1, 
     return kernels.quantize_tensor(w_cols, lo, hi, qtype, symmetric, reduce_range)
 
 
-def hessian_all_reduce(h_local, n_local: int, *, group=None):
+def hessian_all_reduce(h_local, n_local: int, *, group=None, always_exchange: bool = False):
     """Hessians accumulated on disjoint samples (gptq.py:246-260 on each rank's batches: H_r = (2 / n_r) sum X^T X) ->
     the Hessian of all samples, H = sum_r (n_r / n) H_r, on every rank: one all_reduce(sum) of [K, K] floats (plus one of
-    the sample counts).  Returns (H, n)."""
+    the sample counts).  Returns (H, n).  ``always_exchange``: as in `gather_device_results`."""
     import torch
 
     dist, on, world, _ = _dist(group)
-    if not on or world == 1:
+    if not on or (world == 1 and not always_exchange):
         return h_local, int(n_local)
     n = torch.tensor([float(n_local)], dtype=torch.float64, device=h_local.device)
     dist.all_reduce(n, group=group)
@@ -614,3 +616,131 @@ def gather_column_shards(local, ranges, strategy: str, *, group=None):
     if strategy == "tensor":
         return q, parts[0][1], parts[0][2]
     return q, torch.cat([p[1] for p in parts], dim=0), torch.cat([p[2] for p in parts], dim=0)
+
+
+def collectives_selftest(device, *, group=None, timeout_s: float = 90.0, self_p2p: bool = True) -> dict:
+    """Every kind of exchange the multi-rank path issues, once, on DEVICE tensors, in the process group that is up -- which
+    may have ONE rank: with backend "nccl" that is a real RCCL communicator on a one-GPU box (before this,
+    the first `nccl` call of this code base would have happened on the driver's 8-GPU node).  Steps, each checked and timed:
+    the key-value rendezvous (`await_all_ranks`), the all_reduces the benches use (int32 SUM, float64 MAX, int64 sizes),
+    `all_gather_object`, the padded gather of real kernel results (`gather_device_results`: pack, size exchange, gather, unpack),
+    the Hessian all_reduce (`hessian_all_reduce`), `StreamedGather.push / finish`, the rank-0 handshake (`connect_to_rank0`; in
+    a group of one nccl rank a grouped send + receive of rank 0 with itself, the same `batch_isend_irecv` call), a barrier.
+    Runs on a helper thread joined for at most ``timeout_s`` (a transport that does not come up must end in a message).
+    Returns {"ok": bool, "backend", "world", "steps": {name: ms}, "error": str | None}; never raises for a failing step."""
+    import threading
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    rec = {"ok": False, "backend": None, "world": 1, "steps": {}, "error": None}
+    if not (dist.is_available() and dist.is_initialized()):
+        rec["error"] = "no process group is up"
+        return rec
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rec["backend"], rec["world"] = dist.get_backend(group), world
+    on_device = device is not None and torch.device(device).type == "cuda"
+    comm_dev = torch.device(device) if rec["backend"] == "nccl" else torch.device("cpu")
+
+    def timed(name, fn):
+        t0 = time.perf_counter()
+        fn()
+        if on_device:
+            torch.cuda.synchronize(device)
+        rec["steps"][name] = round((time.perf_counter() - t0) * 1e3, 2)
+
+    def body():
+        if on_device:
+            torch.cuda.set_device(device)
+
+        def reduces():
+            a = torch.ones(1, dtype=torch.int32, device=comm_dev)
+            dist.all_reduce(a, group=group)
+            b = torch.tensor([1.5 + rank, 2.5], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(b, op=dist.ReduceOp.MAX, group=group)
+            c = torch.zeros(world, dtype=torch.int64, device=comm_dev)
+            c[rank] = 1000 + rank
+            dist.all_reduce(c, group=group)
+            assert int(a.item()) == world and float(b[0]) == 0.5 + world and c.tolist() == [1000 + r for r in range(world)]
+
+        def objects():
+            got = [None] * world
+            dist.all_gather_object(got, ("rank", rank, (1, 2)), group=group)
+            assert got == [("rank", r, (1, 2)) for r in range(world)]
+
+        def padded_gather():
+            gen = torch.Generator(device="cpu").manual_seed(100 + rank)
+            specs = [LayerSpec(f"selftest.r{r}.w{j}", 64 * (j + 1), 96) for r in range(world) for j in range(2)]
+            plan = [[2 * r, 2 * r + 1] for r in range(world)]
+            mine = {}
+            for i in plan[rank]:
+                k, n = specs[i].k, specs[i].n
+                mine[i] = (torch.randint(0, 255, (k, n), generator=gen, dtype=torch.uint8).to(device if on_device else "cpu"),
+                           torch.rand((n * k // 32, 1), generator=gen).to(device if on_device else "cpu"),
+                           torch.randint(0, 15, (n * k // 32 + 3,), generator=gen, dtype=torch.uint8).to(device if on_device else "cpu"))   # odd length: the 16-byte padding
+            got, nbytes = gather_device_results(specs, plan, mine, group=group, always_exchange=True)
+            if rank == 0:
+                assert nbytes > 0 and list(got) == [s_.name for s_ in specs]
+                for i in plan[0]:
+                    assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(got[specs[i].name], mine[i]))
+
+        def hessian():
+            h = torch.full((128, 128), float(rank + 1), dtype=torch.float32, device=comm_dev)
+            out, n = hessian_all_reduce(h, 4 * (rank + 1), group=group, always_exchange=True)
+            total = sum(4 * (r + 1) for r in range(world))
+            want = sum((4 * (r + 1) / total) * (r + 1) for r in range(world))
+            assert n == total and abs(float(out[5, 7]) - want) < 1e-5
+
+        def streamed():
+            specs = [LayerSpec(f"selftest.s{r}", 64, 32) for r in range(world)]
+            bundles = [[[r]] for r in range(world)]
+            layout = lambda sp: [(torch.uint8, (sp.k, sp.n)), (torch.float32, (sp.n, 1)), (torch.uint8, (sp.n,))]   # noqa: E731
+            sg = StreamedGather(specs, bundles, layout, device=comm_dev, group=group)
+            res = (torch.full((64, 32), rank, dtype=torch.uint8, device=comm_dev), torch.full((32, 1), float(rank), device=comm_dev),
+                   torch.full((32,), rank, dtype=torch.uint8, device=comm_dev))
+            sg.push(0, {rank: res})
+            got, _ = sg.finish()
+            if rank == 0:
+                assert [int(got[f"selftest.s{r}"][0][0, 0]) for r in range(world)] == list(range(world))
+
+        def handshake():
+            if world > 1:
+                connect_to_rank0(comm_dev, group=group, timeout_s=timeout_s)
+                return
+            src = torch.arange(4096, dtype=torch.uint8, device=comm_dev)
+            dst = torch.zeros(4096, dtype=torch.uint8, device=comm_dev)
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0, group), dist.P2POp(dist.irecv, dst, 0, group)]):
+                w.wait()
+            if on_device:
+                torch.cuda.synchronize(device)
+            assert torch.equal(src, dst)
+
+        try:
+            timed("store_rendezvous", lambda: await_all_ranks("oq/selftest", timeout_s=timeout_s, group=group, always_exchange=True))
+            timed("all_reduce_x3", reduces)
+            timed("all_gather_object", objects)
+            timed("padded_gather", padded_gather)
+            timed("hessian_all_reduce", hessian)
+            timed("streamed_gather", streamed)
+            if world > 1:
+                timed("rank0_handshake", handshake)
+            elif self_p2p and rec["backend"] == "nccl":
+                # no rank of a real run sends to itself: a transport that refuses this is noted, not counted as a failure
+                try:
+                    timed("self_send_recv", handshake)
+                except Exception as e:      # noqa: BLE001
+                    rec["self_send_recv_error"] = f"{type(e).__name__}: {e}"
+            timed("barrier", lambda: dist.barrier(group=group))
+            rec["ok"] = True
+        except BaseException as e:      # noqa: BLE001 -- reported in the record
+            import traceback
+            rec["error"] = f"{type(e).__name__}: {e}"
+            rec["traceback"] = traceback.format_exc()[-1500:]
+
+    t = threading.Thread(target=body, name="oq-selftest", daemon=True)
+    t.start()
+    t.join(timeout_s)
+    if t.is_alive():
+        rec["error"] = f"no answer within {timeout_s:.0f} s after steps {list(rec['steps'])}"
+    return rec

@@ -36,3 +36,17 @@ def test_bench_single_rank_stub_line():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1
+
+
+def test_collectives_selftest_on_gloo_one_and_two_ranks():
+    """`--nccl-selftest` with the CPU backend: every kind of exchange the multi-rank path issues, in a group
+    of ONE rank (forced through the collectives) and of two (bench.py starts the ranks itself)."""
+    for gpus in (1, 2):
+        r = _run(["--gpus", str(gpus), "--nccl-selftest", "--selftest-backend", "gloo"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"rccl_selftest"')]
+        assert len(lines) == 1, r.stdout
+        rec = json.loads(lines[0])["rccl_selftest"]
+        assert rec["ok"] and rec["world"] == gpus and rec["backend"] == "gloo" and rec["error"] is None
+        want = {"store_rendezvous", "all_reduce_x3", "all_gather_object", "padded_gather", "hessian_all_reduce", "streamed_gather", "barrier"}
+        assert want <= set(rec["steps"]) and ("rank0_handshake" in rec["steps"]) == (gpus > 1)

@@ -126,3 +126,22 @@ def test_rtn_model_sharded_by_layers_uses_one_list_call_per_rank(world):
         assert p.exitcode == 0
     ok, moved = q.get(timeout=5)
     assert ok == [True] * 7 and moved
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_communicator_runs_every_exchange_of_the_multi_rank_path():
+    """First contact with RCCL: a child process brings up `init_process_group("nccl", world_size=1,
+    device_id=cuda:0)` before any other GPU call and runs `sharding.collectives_selftest` on device tensors: the rendezvous,
+    the all_reduces, `all_gather_object`, the padded gather of `gather_device_results` (forced through the collectives),
+    the Hessian all_reduce, `StreamedGather.push / finish`, a barrier; then tears the group down.  Exit code 0 and ok = true."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--nccl-selftest"], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"rccl_selftest"')][0])["rccl_selftest"]
+    assert rec["ok"] and rec["backend"] == "nccl" and rec["world"] == 1 and rec["error"] is None, rec
+    assert {"all_reduce_x3", "all_gather_object", "padded_gather", "hessian_all_reduce", "streamed_gather", "barrier"} <= set(rec["steps"])
