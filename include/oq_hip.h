@@ -468,6 +468,13 @@ size_t oq_abs_sum_cols_workspace_bytes(int64_t K);
 int32_t oq_abs_sum_cols_f32(const float* X, int64_t T, int64_t K, int64_t ldx, float* sum_inout, int32_t accumulate, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* (b)  seam: `node.meta["input"]` is one array per value name, shared by its consumers (calibrate.py:301-307); everything `_gptq`
+ *     derives from it alone (gptq.py:118-150, :246-260) is kept for the next consumer, keyed by CONTENT: out[0] = a 64-bit
+ *     fingerprint of `nbytes` bytes at `data` (device memory, 16-byte aligned; `out` device memory, 8-byte aligned), one pass
+ *     at the HBM rate.  Sum modulo 2^64 of a bijective mix of every 16-byte word chained with its index, plus the length:
+ *     any edit of the bytes changes it except with probability 2^-64. */
+int32_t oq_fingerprint64(const void* data, int64_t nbytes, uint64_t* out, void* stream);
+
 size_t oq_smooth_quant_workspace_bytes(int64_t K);
 int32_t oq_smooth_quant_scale_f32(const float* X, int64_t T, int64_t K, int64_t ldx, const float* W, int64_t N,
                                   int64_t ldw, float alpha, float* scale_out, void* workspace,

@@ -291,11 +291,62 @@ __global__ __launch_bounds__(256) void minmax_rows(const float* x, int64_t R, in
     if (lane == 0) { mn_out[r] = mn; mx_out[r] = mx; }
 }
 
+// 64-bit content fingerprint of a byte range in HBM (seam.py: is this calibration input the one whose Hessian is cached?).
+// Every 16-byte word w at index i contributes mix(i, w) to a sum modulo 2^64, so the order in which lanes and blocks add is
+// irrelevant and one agent-scope atomic per wave ends the kernel.  mix = the splitmix64 finaliser over the four lanes of the
+// word chained with its index: an edit of any bit of any word changes its term (the finaliser is a bijection of the chained
+// state), so two contents collide with probability 2^-64, position swaps included.  The tail (< 16 bytes) is read byte by byte.
+__device__ __forceinline__ uint64_t fp_mix(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kRedBlock) void fingerprint_kernel(const uint4* x, int64_t nvec, const uint8_t* tail, int ntail, int64_t nbytes,
+                                                                 unsigned long long* out) {
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kRedBlock;
+    uint64_t acc = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kRedBlock + threadIdx.x; i < nvec; i += stride) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(x) + i);
+        uint64_t h = fp_mix(static_cast<uint64_t>(i) + 0x9E3779B97F4A7C15ull);
+        h = fp_mix(h ^ (static_cast<uint64_t>(w[0]) | (static_cast<uint64_t>(w[1]) << 32)));
+        h = fp_mix(h ^ (static_cast<uint64_t>(w[2]) | (static_cast<uint64_t>(w[3]) << 32)));
+        acc += h;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t h = fp_mix(static_cast<uint64_t>(nbytes) ^ 0xD1B54A32D192ED03ull);      // the length is part of the content
+        for (int j = 0; j < ntail; ++j) h = fp_mix(h ^ (static_cast<uint64_t>(tail[j]) + 0x100ull * static_cast<uint64_t>(j + 1)));
+        acc += h;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(acc)), off, 64));
+        const uint32_t hi = static_cast<uint32_t>(__shfl_xor(static_cast<int>(static_cast<uint32_t>(acc >> 32)), off, 64));
+        acc += static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32);
+    }
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, static_cast<unsigned long long>(acc));
+}
+
 }  // namespace oq
 
 extern "C" {
 
 using namespace oq;
+
+int32_t oq_fingerprint64(const void* data, int64_t nbytes, uint64_t* out, void* stream) {
+    OQ_REQUIRE(data && out && nbytes > 0 && nbytes <= kMaxElements, OQ_ERR_INVALID_ARGUMENT, "oq_fingerprint64: bad argument (1 <= nbytes <= 2^40)");
+    OQ_REQUIRE((reinterpret_cast<uintptr_t>(data) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, OQ_ERR_INVALID_ARGUMENT,
+               "oq_fingerprint64: data must be 16-byte aligned, out 8-byte aligned");
+    hipStream_t s = as_stream(stream);
+    if (hipMemsetAsync(out, 0, sizeof(uint64_t), s) != hipSuccess) return fail(OQ_ERR_LAUNCH, "oq_fingerprint64: cannot clear the result");
+    const int64_t nvec = nbytes / 16;
+    int64_t nblocks = ceil_div(nvec > 0 ? nvec : 1, static_cast<int64_t>(kRedBlock) * 8);
+    if (nblocks > kRedMaxBlocks) nblocks = kRedMaxBlocks;
+    hipLaunchKernelGGL(fingerprint_kernel, dim3(static_cast<uint32_t>(nblocks)), dim3(kRedBlock), 0, s, static_cast<const uint4*>(data), nvec,
+                       static_cast<const uint8_t*>(data) + nvec * 16, static_cast<int>(nbytes - nvec * 16), nbytes,
+                       reinterpret_cast<unsigned long long*>(out));
+    return check_launch("fingerprint_kernel");
+}
 
 size_t oq_minmax_workspace_bytes(int64_t count) {
     (void)count;

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "oq_awq_clip_search_stats_f32": (_i32, [_p, _i64, _i64, _p, _i64, _i64, _i32, _i32, _i64, _i32, _i32, _p, _p, _p, _sz, _p]),
     "oq_abs_sum_cols_workspace_bytes": (_sz, [_i64]),
     "oq_abs_sum_cols_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i32, _p, _sz, _p]),
+    "oq_fingerprint64": (_i32, [_p, _i64, _p, _p]),
     "oq_smooth_quant_workspace_bytes": (_sz, [_i64]),
     "oq_smooth_quant_scale_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i64, _f32, _p, _p, _sz, _p]),
     "oq_rtn_state_bytes": (_sz, [_i64, _i64, _i32, _i64]),

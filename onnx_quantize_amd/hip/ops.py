@@ -193,6 +193,22 @@ def rtn_quantize(w: torch.Tensor, qtype: str, strategy: str, group_size=-1, symm
     return q, scale.reshape(shape), zp.reshape(shape)
 
 
+def fingerprint64(t: torch.Tensor) -> int:
+    """64-bit content fingerprint of a contiguous device tensor's bytes (`oq_fingerprint64`, one pass at the HBM rate).  Synchronises
+    (eight bytes come back): it decides what the host does next (seam.py: reuse a cached Hessian or compute it)."""
+    _require_device(t, "t")
+    if not t.is_contiguous():
+        raise ValueError("fingerprint64 needs a contiguous tensor")
+    nbytes = t.numel() * t.element_size()
+    if nbytes == 0:
+        raise ValueError("fingerprint64 of an empty tensor")
+    if t.data_ptr() % 16:
+        t = t.clone()
+    out = torch.empty(1, dtype=torch.int64, device=t.device)
+    L.check(L.load().oq_fingerprint64(_ptr(t), nbytes, _ptr(out), _stream()))
+    return int(out.item()) & 0xFFFFFFFFFFFFFFFF
+
+
 def hqq_quantize(w: torch.Tensor, group_size: int, reduce_range=False, clip_ratio=1.0, mse=False, lp_norm=0.7, beta=1e1,
                  kappa=1.01, iters=20, early_stop=True, emit_q: bool = True, layout: str = "kn", per_round_launches: bool = False):
     """hqq.py:147-213 on the GPU: uint4 / asymmetric / group with float zero points.  ``w`` [K, N] fp32 in HBM.

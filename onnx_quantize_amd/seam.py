@@ -34,9 +34,13 @@ _GPTQ_FALLBACK_WARNING = (
 
 # Nodes that read the same value (q / k / v, gate / up) carry the SAME calibration array in `node.meta["input"]`
 # (calibrate.py:301-307 concatenates once per value name and hands that object to every consumer).  Everything `_gptq`
-# derives from the input alone -- the upload of X, the Hessian, dead channels, permutation, inverse factor (gptq.py:118-150,
-# :246-260) -- is computed once per such object and kept for the next nodes; consumers of one value are neighbours in graph
-# order, so two entries are enough.  The entry holds the array itself: its id cannot be reused while it is cached.
+# derives from the input alone -- the Hessian, dead channels, permutation, inverse factor (gptq.py:118-150, :246-260) -- is
+# computed once per CONTENT and kept for the next nodes; consumers of one value are neighbours in graph order, so two entries
+# are enough.  An array input is uploaded (it has to be in HBM for the Hessian anyway) and fingerprinted there in one pass at
+# the HBM rate (`oq_fingerprint64`: 64 bits over every byte, shape and dtype beside it in the key): an array rewritten in
+# place between two nodes -- the reference's AWQ pass does exactly that to this object, awq.py:191 -- is a different content
+# and is computed afresh, wherever the edit sits (rounds 3-5 compared a 512-element host sample).  A Hessian streamed by the
+# calibration walk (`StreamedGptqInput`) is keyed by the object: nothing rewrites it.
 _SHARED_INPUTS: "OrderedDict[tuple, tuple]" = None
 _SHARED_KEEP = 2
 shared_input_stats = {"hits": 0, "misses": 0}
@@ -62,16 +66,23 @@ def _hessian_and_factor(x, k, device, percdamp, actorder):
     if _SHARED_INPUTS is None:
         _SHARED_INPUTS = OrderedDict()
     streamed = isinstance(x, StreamedGptqInput)       # the calibration walk already accumulated H on the device
-    cacheable = streamed or isinstance(x, (np.ndarray, torch.Tensor))
-    key = (id(x), int(k), str(device), float(percdamp), bool(actorder), ops.hessian_method())
-    mark = None
-    if isinstance(x, np.ndarray):
-        from .staging import content_mark
+    tail = (int(k), str(device), float(percdamp), bool(actorder), ops.hessian_method())
+    key, x_dev = None, None
+    if streamed:
+        key = ("streamed", id(x), *tail)
+    elif isinstance(x, (np.ndarray, torch.Tensor)):
+        if isinstance(x, np.ndarray):
+            from .staging import upload
 
-        mark = content_mark(x)              # shape, dtype and a content SAMPLE (see staging.content_mark for its limits)
-    if cacheable:
+            with torch.cuda.device(device):
+                x_dev = upload(x)
+        else:
+            x_dev = x.to(device, torch.float32).contiguous()
+        if x_dev.numel():
+            key = ("content", tuple(x.shape), str(x.dtype), ops.fingerprint64(x_dev), *tail)
+    if key is not None:
         hit = _SHARED_INPUTS.get(key)
-        if hit is not None and hit[0] is x and hit[3] == mark:
+        if hit is not None and (not streamed or hit[0] is x):
             _SHARED_INPUTS.move_to_end(key)
             shared_input_stats["hits"] += 1
             return hit[1], hit[2]
@@ -87,13 +98,16 @@ def _hessian_and_factor(x, k, device, percdamp, actorder):
     else:
         h = torch.zeros((k, k), dtype=torch.float32, device=device)
         n = 0
-        batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
-        for b in batches:
-            xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
-            n = ops.hessian_accumulate(xb.to(device, torch.float32), h, n)
+        if x_dev is not None:
+            n = ops.hessian_accumulate(x_dev, h, n)
+        else:
+            batches = x if isinstance(x, (list, tuple)) or hasattr(x, "__next__") else [x]
+            for b in batches:
+                xb = b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32))
+                n = ops.hessian_accumulate(xb.to(device, torch.float32), h, n)
     shared = ops.gptq_shared_factor(h, percdamp, actorder)
-    if cacheable:
-        _SHARED_INPUTS[key] = (x, h, shared, mark)
+    if key is not None:
+        _SHARED_INPUTS[key] = (x if streamed else None, h, shared)     # a content entry does not keep the caller's array alive
         while len(_SHARED_INPUTS) > _SHARED_KEEP:
             _SHARED_INPUTS.popitem(last=False)
     return h, shared

@@ -27,7 +27,7 @@ import threading
 
 import numpy as np
 
-__all__ = ["upload", "download", "content_mark"]
+__all__ = ["upload", "download"]
 
 _PREFAULT_MIN_BYTES = 4 << 20
 _PREFAULT_THREADS = 4
@@ -89,17 +89,6 @@ def _prefault(out: np.ndarray) -> None:
     rcs = list(st["pool"].map(_populate, [st["madvise"]] * len(starts), starts, [min(step, hi - a) for a in starts]))
     if any(rcs):
         st["works"] = False                                # this kernel does not know the advice: stop asking
-
-
-def content_mark(a: np.ndarray):
-    """Cheap fingerprint used to decide whether a cached device-side derivative of ``a`` (seam._SHARED_INPUTS: Hessian and
-    inverse factor of a calibration input) still belongs to it: shape, dtype, a strided sample of 512 elements, the
-    first and last 64 elements and the last one.  It is a SAMPLE, not a checksum: an in-place edit that misses every
-    sampled element is not noticed (a full pass over a 4 GB calibration array would cost more than the upload it saves);
-    callers that rewrite calibration inputs in place between nodes must call ``seam.clear_shared_inputs()``."""
-    flat = a.reshape(-1) if a.flags.c_contiguous else np.ascontiguousarray(a).reshape(-1)
-    step = max(1, flat.size // 512)
-    return (a.shape, a.dtype.str, flat[::step][:512].tobytes(), flat[:64].tobytes(), flat[-64:].tobytes())
 
 
 def _device():

@@ -62,6 +62,15 @@ def main():
             print(json.dumps(row), flush=True)
         del ws
         torch.cuda.empty_cache()
+    try:        # a -DOQ_SPIN_LIMIT lab build counts the spins that gave up (results are garbage then)
+        import ctypes
+        from onnx_quantize_amd.hip import _lib as L_
+        n = ctypes.c_uint32(0)
+        if ctypes.CDLL(L_.LIB_PATH).oq_lab_spin_timeouts(ctypes.byref(n), 0) == 0:
+            out["spin_timeouts"] = n.value
+            print(json.dumps({"spin_timeouts": n.value}), flush=True)
+    except AttributeError:
+        pass
     if args.json:
         with open(args.json, "w") as f:
             json.dump(out, f, indent=1)

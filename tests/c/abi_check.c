@@ -17,7 +17,7 @@ int main(void) {
     TAKE(oq_hessian_pieces_bytes); TAKE(oq_hessian_slab_bytes); TAKE(oq_hessian_prepare_f32); TAKE(oq_hessian_accumulate_prepared_f32);
     TAKE(oq_matmul_pieces_bytes); TAKE(oq_matmul_prepare_f32); TAKE(oq_matmul_pieces_f32);
     TAKE(oq_awq_stats_workspace_bytes); TAKE(oq_awq_scale_search_stats_f32); TAKE(oq_awq_clip_search_stats_f32);
-    TAKE(oq_abs_sum_cols_workspace_bytes); TAKE(oq_abs_sum_cols_f32);
+    TAKE(oq_abs_sum_cols_workspace_bytes); TAKE(oq_abs_sum_cols_f32); TAKE(oq_fingerprint64);
     TAKE(oq_awq_workspace_bytes); TAKE(oq_awq_scale_search_f32); TAKE(oq_awq_clip_search_f32);
     TAKE(oq_smooth_quant_workspace_bytes); TAKE(oq_smooth_quant_scale_f32); TAKE(oq_rtn_qparams_f32); TAKE(oq_qparams_f32); TAKE(oq_qparams_f64);
     TAKE(oq_minmax_rows_f32); TAKE(oq_quantize_f32); TAKE(oq_dequantize_f32); TAKE(oq_dequantize_fzp_f32); TAKE(oq_quantize_bias_f32);

@@ -120,6 +120,43 @@ def test_function_names_cover_every_branch_of_the_factories():
     assert qfunction_name("MatMul", g) == "QMatMulWeightsOnlyGrouped" and qfunction_name("Gemm", g) == "QGemmWeightsOnlyGrouped"
 
 
+def test_function_formal_inputs_are_the_positional_lists_the_reference_rules_pass():
+    """The one structural fact of the `quant`-domain function bodies this image can pin: the rewrite rules
+    pass their arguments POSITIONALLY (qrules/_qdq/*.py, _qlinear/*.py), and tests/golden/emit.json holds, for 14 rule paths
+    (two of them grouped, at group sizes 128 and 32), the argument list the reference's own rule classes handed to `op.<Function>`
+    on make_golden.py's recording tape.  Each recorded actual has ONE role, told by the name the reference gives it
+    (`w`, `w/scale`, `w/zero_point`, `…/original_transposed_shape`: qrules/_common.py:140-142, _qdq/matmul_to_qmatmul.py:46-49;
+    `{out}/{input|output}/{scale|zero_point}`: qrules/base.py:34-40): the formal inputs of `onnx_functions.build_function(name)`
+    must be those roles in that order -- same arity, same positions."""
+    from onnx_quantize_amd.onnx_functions import build_function
+
+    def role(actual):
+        table = {"X": "X", "fc.weight": "W", "fc.bias": "B", "fc.weight/scale": "w_scale", "fc.weight/zero_point": "w_zero_point",
+                 "fc.bias/scale": "b_scale", "fc.bias/zero_point": "b_zero_point", "fc.weight/original_transposed_shape": "original_transposed_shape",
+                 "fc/out/input/scale": "x_scale", "fc/out/input/zero_point": "x_zero_point", "fc/out/output/scale": "out_scale",
+                 "fc/out/output/zero_point": "out_zero_point"}
+        return table[actual]
+
+    seen = set()
+    for c in CASES:
+        call = c["call"]
+        if call["attrs"]["_domain"] != "quant":
+            continue
+        g = c["weights"].get("group_size")
+        fn = build_function(call["name"], group_size=g, four_bit=c["weights"]["dtype"] in ("int4", "uint4"))
+        assert list(fn.input) == [role(a) for a in call["inputs"]], (c["id"], list(fn.input), call["inputs"])
+        assert len(fn.output) == 1 and fn.domain == "quant" and fn.name == call["name"]
+        # every formal input is consumed by the body, and the body reads nothing it does not produce or receive
+        made = set(fn.input)
+        for nd in fn.node:
+            assert all(i in made for i in nd.input if i), (c["id"], nd.op_type, list(nd.input))
+            made.update(nd.output)
+        used = {i for nd in fn.node for i in nd.input}
+        assert set(fn.input) <= used and fn.output[0] in made
+        seen.add((call["name"], g))
+    assert len(seen) == 11 and {("QMatMulWeightsOnlyGrouped", 128), ("QMatMulWeightsOnlyGrouped", 32), ("QGemmWeightsOnlyGrouped", 32)} <= seen
+
+
 @pytest.mark.gpu
 def test_emission_plan_from_the_device_path():
     G = load_npz("emit.npz")
