@@ -653,6 +653,8 @@ def main() -> None:
     ap.add_argument("--no-model-rtn", action="store_true", help="skip the `model_rtn` object (224 Llama-2-7B weights in one call)")
     ap.add_argument("--no-awq", action="store_true", help="skip the `awq` object (AWQ scale / clip searches of one layer)")
     ap.add_argument("--no-model-file", action="store_true", help="skip the `model_file` object (an ONNX file quantized file to file, bench_model.py)")
+    ap.add_argument("--no-model-file-7b", action="store_true",
+                    help="skip the `model_file_7b` object (north_star's sentence: a 7B-shaped ONNX file -> GPTQ int4 g128 -> file, ~1 min)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the `calibration` object (config 3 stand-in)")
     ap.add_argument("--gptq-extra-passes", default="corrected,f32",
                     help="further whole-model GPTQ passes of the `gptq` object (bench_gptq.py --extra-passes)")
@@ -999,6 +1001,27 @@ def main() -> None:
             sys.stderr.write(f"[bench] the model_file object failed:\n{traceback.format_exc()}\n")
             model_file = {"error": f"{type(e).__name__}: {e}", "verified": False}
         torch.cuda.empty_cache()
+    # ---- north_star's sentence, file to file: ALL MatMul weights of a 7B-shaped ONNX file (32 decoder layers of Llama-2-7B's widths,
+    # 224 weights, 6.48 G parameters, 25.9 GB of fp32 in a side file) -> quantize_file-equivalent GPTQ QInt4 g128 -> an ONNX file.
+    # 65 536 calibration tokens run through the graph on this GPU, Hessians streamed, both modes (the reference's loop as written =
+    # `parity`, the default; and `corrected`), phases apart, one weight of each file verified against the per-layer device path.
+    # PCIe- and file-inclusive: never `value`.
+    model_file_7b = None
+    if world == 1 and not args.no_model_file and not args.no_model_file_7b and not args.no_extras:
+        import bench_model
+
+        try:
+            model_file_7b = bench_model.run(bench_model.build_parser().parse_args(
+                ["--layers", "32", "--config", "gptq_int4_g128_parity,gptq_int4_g128", "--samples", "32", "--seq", "2048", "--repeat", "1", "--phases"]))
+            model_file_7b["what"] = ("7B-shaped ONNX file (32 layers x q/k/v/o/gate/up/down, random weights, written by this package) -> GPTQ QInt4 "
+                                     "group_size=128 of all 224 MatMul weights -> ONNX file, one pass per mode on one GPU; calibration: 32 sequences "
+                                     "of 2048 random tokens walked through the graph in 4 batches (graph_runner on torch-ROCm, products on "
+                                     "oq_matmul_pieces_f32), Hessians streamed; PCIe, page cache and file writing included")
+        except Exception as e:   # noqa: BLE001 -- reported in the object (e.g. no room for the 26 GB source); the headline line still goes out
+            import traceback
+            sys.stderr.write(f"[bench] the model_file_7b object failed:\n{traceback.format_exc()}\n")
+            model_file_7b = {"error": f"{type(e).__name__}: {e}", "verified": False}
+        torch.cuda.empty_cache()
     # ---- configs 4 / 5: GPTQ of a Llama-2-7B-shaped model from the same run (all ranks take part)
     gptq = None
     if not args.no_gptq and not args.no_extras:
@@ -1080,6 +1103,7 @@ def main() -> None:
         "gather": gather,
         "calibration": calibration,
         "model_file": model_file,
+        "model_file_7b": model_file_7b,
         "awq": awq,
         "searches": searches,
         "gptq": gptq,

@@ -331,15 +331,8 @@ struct StreamTile {          // everything uniform over the workgroup except slo
 __device__ __forceinline__ StreamTile stream_tile(const ResidentArgs& a, uint32_t t, int lane, int wave) {
     StreamTile s;
     const uint32_t chunks = static_cast<uint32_t>(a.chunks), kgroups = static_cast<uint32_t>(a.kgroups);
-#ifdef OQ_LAB_COLFAST      /* lab (results wrong unless OQ_LAB_NOHANDOFF too): consecutive tickets walk along a row band, not down a strip */
-    { const uint32_t nr = a.ntiles / chunks; const uint32_t band = nr < OQ_LAB_COLFAST ? nr : OQ_LAB_COLFAST;   // ranges per band
-      const uint32_t per = band * chunks, g0 = t / per, r = t - g0 * per;
-      const uint32_t bw = (g0 + 1) * band <= nr ? band : nr - g0 * band;
-      s.c = r / bw; s.range = g0 * band + (r - s.c * bw); }
-#else
     s.range = t / chunks;
     s.c = t - s.range * chunks;
-#endif
     const uint32_t col_tile = s.range / kgroups;
     s.kg = s.range - col_tile * kgroups;
     s.row_end = min(static_cast<int64_t>(s.kg) * a.g + a.g, a.K);
@@ -482,11 +475,7 @@ __device__ __forceinline__ uint32_t stream_step(const ResidentArgs& a, uint32_t 
     const StreamTile sy = stream_tile(a, y_valid ? ty : tx, lane, wave);
     const uint32_t chunks = static_cast<uint32_t>(a.chunks);
     // the poller sits in wave 1: wave 0 may still be draining the key atomics of the tile it published last
-#ifdef OQ_LAB_NOHANDOFF    /* lab: never wait for a range (the integers are wrong): what does the hand-off cost? */
-    if (threadIdx.x == kWave) s_flag = (agent_load(a.counters + sx.range * kResCtrPad), 1u);
-#else
     if (threadIdx.x == kWave) s_flag = agent_load(a.counters + sx.range * kResCtrPad) >= chunks ? 1u : 0u;
-#endif
     __syncthreads();
     bool y_published = !y_valid;
     if (s_flag == 0u) {   // uniform, rare
@@ -574,250 +563,6 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_resident_stream(const
 #endif
     if (a.done != nullptr) {   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
         if (first) clean_state(a, gridDim.x - 1u, kResWaves * kWave);
-        else if (threadIdx.x == 0) agent_add(a.done, 1u);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Channel / tall groups, streamed, with a COMMUNICATION WAVE (round 6).  Lap counters of rtn_resident_stream on 4096 x 11008
-// (scripts/lab_stream_laps.py, per tile): poll of the range 1.9 us, key loads + ticket 0.8, row loop 4.7, fold + publish 1.5
-// -- only the row loop moves the matrix; the other 4.2 us are memory-side round trips (a poll, a ticket, eight key atomics and
-// their drain, eight key loads) that stand IN FRONT of it because the waves that issue them also carry the tile: their
-// `s_waitcnt vmcnt` would wait for the tile's own loads.  Here wave 0 carries no rows.  It owns every round trip of the
-// hand-off -- publish (fold of the seven partials from LDS, key atomics, drain, counter add), the poll of the next range,
-// its key loads and the next ticket -- and runs that chain BESIDE the row loop of the seven compute waves (16 rows each:
-// tiles of 112 rows).  The waves meet once per step, at one barrier, through double-buffered LDS words:
-//
-//   compute waves, step k:  fold Y_k (the tile in flight) -> partials[k & 1] | barrier | keys + ticket of X_k from LDS ->
-//                           parameters -> store X_k row by row, refilling every row with tile Z_k of that ticket
-//   wave 0, step k:         poll range(X_k) until complete (or until all compute waves wait at the barrier) -> key loads +
-//                           ticket -> LDS[k & 1] | barrier | publish Y_k (= X_{k+1}) from partials[k & 1]
-//
-// Double buffers: what one side writes for step k before the barrier of step k is read by the other side between the
-// barriers of steps k and k + 1, and rewritten for step k + 2 only behind the barrier of step k + 1.
-//
-// Forward progress (the argument of rtn_resident_stream, restated for two roles).  The workgroup blocks without bound in ONE
-// place: wave 0's spin in the branch behind the barrier that has just published Y_k, taken when the poll in front of the
-// barrier did not see range(X_k) complete.  The poll in front of the barrier is bounded -- it ends when the seven compute
-// waves have arrived (`arrived[k & 1]`), i.e. as soon as somebody would wait for it -- and a ticket is taken only behind a
-// successful poll or behind the spin.  So the workgroup never blocks while it holds an unpublished tile or an unused ticket:
-// Z_k's ticket is taken when no wait of step k is left, Z_k is in flight during the row loop and published behind the
-// barrier of step k + 1 before anything blocks.  (The second ticket of the prologue is taken while the first tile loads;
-// both tiles are published before the first spin can happen.)  From there the argument is the old one: let R be the oldest
-// incomplete range; an untaken ticket of R means no younger ticket is taken, every blocked workgroup waits for R holding a
-// published tile of R (at most chunks - 1 of them), any other running workgroup goes on and takes R's next ticket; with at
-// least `chunks` workgroups running (checked on the host) R completes.
-// ---------------------------------------------------------------------------------------------
-#ifndef OQ_S2_FIRST_SLEEP
-#define OQ_S2_FIRST_SLEEP 4      /* x s_sleep(16) = 1024 cycles each (~0.45 us) before the first poll of a range */
-#endif
-#ifndef OQ_S2_POLL_SLEEP
-#define OQ_S2_POLL_SLEEP 2       /* x s_sleep(16) between two polls */
-#endif
-#ifdef OQ_TENSOR_STAMPS   /* lab: per-workgroup sums of the 100 MHz clock; wave 0 (thread 0) and the first compute wave (thread 64) keep their own clocks */
-#define S2_LAP(i) do { if (threadIdx.x == 0) { const uint64_t now_ = wall_clock64(); g_tensor_stamps[blockIdx.x * 8 + (i)] += now_ - s2_t0; s2_t0 = now_; } } while (0)
-#define S2_LAPC(i) do { if (threadIdx.x == 64) { const uint64_t now_ = wall_clock64(); g_tensor_stamps[blockIdx.x * 8 + (i)] += now_ - s2_t0; s2_t0 = now_; } } while (0)
-#define S2_COUNT(i) do { g_tensor_stamps[blockIdx.x * 8 + (i)] += 1; } while (0)
-#else
-#define S2_LAP(i) do { } while (0)
-#define S2_LAPC(i) do { } while (0)
-#define S2_COUNT(i) do { } while (0)
-#endif
-constexpr int kS2Compute = 7;                               // compute waves (waves 1..7); wave 0 communicates
-constexpr int kS2TileRows = kS2Compute * kResRows;          // 112
-constexpr int kS2Waves = kS2Compute + 1;
-
-struct S2Shared {
-    float4 mn[2][kS2Compute][kWave];
-    float4 mx[2][kS2Compute][kWave];
-    uint32_t keys[2][8][kWave];      // [step parity][max keys of the lane's four columns, then min keys][lane]
-    uint32_t ticket[2], flag[2], arrived[2];
-};
-
-__device__ __forceinline__ StreamTile stream2_tile(const ResidentArgs& a, uint32_t t, int lane, int cw) {
-    StreamTile s;
-    const uint32_t chunks = static_cast<uint32_t>(a.chunks), kgroups = static_cast<uint32_t>(a.kgroups);
-    s.range = t / chunks;
-    s.c = t - s.range * chunks;
-    const uint32_t col_tile = s.range / kgroups;
-    s.kg = s.range - col_tile * kgroups;
-    s.row_end = min(static_cast<int64_t>(s.kg) * a.g + a.g, a.K);
-    s.row0 = static_cast<int64_t>(s.kg) * a.g + static_cast<int64_t>(s.c) * kS2TileRows + cw * kResRows;
-    s.tile_col0 = static_cast<int64_t>(col_tile) * kResCols;
-    s.slot0 = (static_cast<int64_t>(s.kg) * a.ncol_tiles + col_tile) * kResCols + lane;
-    s.col_ok = s.tile_col0 + lane * 4 < a.N;
-    return s;
-}
-
-// wave 0: the workgroup's partials of a tile (buffer b) -> key atomics, drain, counter add.  Never waits for another workgroup.
-__device__ __forceinline__ void s2_publish(const ResidentArgs& a, const StreamTile& s, int lane, S2Shared& sh, int b) {
-    float4 tn = sh.mn[b][0][lane], tx = sh.mx[b][0][lane];
-    float mn[4] = {tn.x, tn.y, tn.z, tn.w}, mx[4] = {tx.x, tx.y, tx.z, tx.w};
-#pragma unroll
-    for (int w = 1; w < kS2Compute; ++w) {
-        tn = sh.mn[b][w][lane]; tx = sh.mx[b][w][lane];
-        mn[0] = nmin(mn[0], tn.x); mn[1] = nmin(mn[1], tn.y); mn[2] = nmin(mn[2], tn.z); mn[3] = nmin(mn[3], tn.w);
-        mx[0] = nmax(mx[0], tx.x); mx[1] = nmax(mx[1], tx.y); mx[2] = nmax(mx[2], tx.z); mx[3] = nmax(mx[3], tx.w);
-    }
-    if (s.col_ok) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            agent_max(a.key_max + s.slot0 + i * kWave, key_of_max(mx[i]));
-            agent_max(a.key_nmin + s.slot0 + i * kWave, key_of_min(mn[i]));
-        }
-    }
-    drain_vmem();                                        // this wave's key atomics are performed (nothing else of it is in flight) ...
-    if (lane == 0) agent_add(a.counters + s.range * kResCtrPad, 1u);    // ... before the range counts this tile
-}
-
-// wave 0: final keys of the complete range of tile `s` and the next ticket -> LDS buffer b
-__device__ __forceinline__ void s2_fetch(const ResidentArgs& a, const StreamTile& s, int lane, S2Shared& sh, int b) {
-    uint32_t pending = 0;
-    if (lane == 0) pending = agent_add(a.tickets, 1u);
-    uint32_t kmx[4], kmn[4];
-    stream_keys(a, s, kmx, kmn);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sh.keys[b][i][lane] = kmx[i];
-        sh.keys[b][4 + i][lane] = kmn[i];
-    }
-    if (lane == 0) sh.ticket[b] = pending;
-}
-
-// One step (see the block comment).  X (`tx`, `vx`): a published tile; Y (`ty`, `vy`, when `y_valid`): in flight, unpublished.
-// Returns X's new ticket (>= ntiles: the slot is empty).
-__device__ __forceinline__ uint32_t stream2_step(const ResidentArgs& a, uint32_t step, uint32_t tx, float (&vx)[kResRows][4], bool y_valid,
-                                                 uint32_t ty, float (&vy)[kResRows][4], int lane, int wave, S2Shared& sh, uint64_t& s2_t0) {
-    const int b = static_cast<int>(step & 1u);
-    const int cw = wave - 1;
-    const bool comm = wave == 0;                                       // uniform over the wave
-    const StreamTile sx = stream2_tile(a, tx, lane, comm ? 0 : cw);
-    const StreamTile sy = stream2_tile(a, y_valid ? ty : tx, lane, comm ? 0 : cw);
-    const uint32_t chunks = static_cast<uint32_t>(a.chunks);
-    if (comm) {
-        uint32_t ok = 0;
-        S2_LAP(4);                                                     // (publish of the previous step ends here)
-        if (lane == 0) {
-            const uint32_t* ctr = a.counters + sx.range * kResCtrPad;
-            const volatile uint32_t* arrived = &sh.arrived[b];
-            // The range was published by THIS workgroup a moment ago; its siblings need about a tile's load to follow.  Polls are
-            // memory-side reads of a line that up to `chunks` workgroups watch: few of them, far apart (the first build polled
-            // every 60 ns and ran 10-25 % behind the kernel without a communication wave).
-            for (int w = 0; w < OQ_S2_FIRST_SLEEP && *arrived < static_cast<uint32_t>(kS2Compute); ++w) __builtin_amdgcn_s_sleep(16);
-            for (;;) {
-                S2_COUNT(6);
-                if (agent_load(ctr) >= chunks) { ok = 1u; break; }
-                if (*arrived >= static_cast<uint32_t>(kS2Compute)) break;    // everybody waits for this wave: publish Y first
-                for (int w = 0; w < OQ_S2_POLL_SLEEP && *arrived < static_cast<uint32_t>(kS2Compute); ++w) __builtin_amdgcn_s_sleep(16);
-            }
-        }
-        ok = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(ok)));
-        S2_LAP(1);
-        if (ok) s2_fetch(a, sx, lane, sh, b);                          // no wait of this step is left: the ticket may be taken
-        if (lane == 0) sh.flag[b] = ok;
-        S2_LAP(2);
-    } else {
-        if (y_valid) {
-            float mn[4], mx[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mn[i] = mx[i] = vy[0][i];
-#pragma unroll
-            for (int r = 1; r < kResRows; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    mn[i] = nmin(mn[i], vy[r][i]);
-                    mx[i] = nmax(mx[i], vy[r][i]);
-                }
-            sh.mn[b][cw][lane] = make_float4(mn[0], mn[1], mn[2], mn[3]);
-            sh.mx[b][cw][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
-        }
-        if (lane == 0) atomicAdd(&sh.arrived[b], 1u);
-        S2_LAPC(0);                                                    // landing of Y + fold
-    }
-    __syncthreads();                                                   // the step's barrier
-    if (!comm) S2_LAPC(7); else S2_LAP(5);                             // waiting for the other role
-    const uint32_t ok = sh.flag[b];                                    // uniform over the workgroup
-    if (comm) {
-        if (lane == 0) sh.arrived[b] = 0u;                             // next touched two steps on, behind the next barrier
-        if (y_valid) s2_publish(a, sy, lane, sh, b);
-        if (!ok) {                                                     // rare: Y is published, now the workgroup may block
-            if (lane == 0) spin_until(a.counters + sx.range * kResCtrPad, chunks);
-            s2_fetch(a, sx, lane, sh, b);                              // the ticket behind the wait
-        }
-    }
-    if (!ok) __syncthreads();                                          // uniform
-    const uint32_t tn = sh.ticket[b];
-    if (!comm) {
-        uint32_t kmx[4], kmn[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            kmx[i] = sh.keys[b][i][lane];
-            kmn[i] = sh.keys[b][4 + i][lane];
-        }
-        ColQ cq[4];
-        stream_params(a, sx, lane, cw, kmx, kmn, cq);
-        const bool refill = tn < a.ntiles;                             // uniform
-        const StreamTile n = stream2_tile(a, refill ? tn : tx, lane, cw);
-        stream_rows(a, sx, cq, refill, n, lane, vx);
-        S2_LAPC(3);                                                    // parameters + row loop
-    }
-    return tn;
-}
-
-__global__ __launch_bounds__(kS2Waves* kWave, 2) void rtn_resident_stream2(const ResidentArgs a) {
-    __shared__ S2Shared sh;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6));
-    const bool comm = wave == 0;
-    const int cw = wave - 1;
-    const uint32_t ntiles = a.ntiles;
-    float v0[kResRows][4], v1[kResRows][4];
-    uint64_t s2_t0 = 0;
-#ifdef OQ_TENSOR_STAMPS
-    if (threadIdx.x < 8) g_tensor_stamps[blockIdx.x * 8 + threadIdx.x] = 0;
-    s2_t0 = wall_clock64();
-#endif
-    if (threadIdx.x < 2) { sh.arrived[threadIdx.x] = 0u; sh.flag[threadIdx.x] = 0u; }
-    if (threadIdx.x == 0) sh.ticket[0] = agent_add(a.tickets, 1u);
-    __syncthreads();
-    uint32_t ta = sh.ticket[0], tb = ntiles;
-    const bool first = ta == 0;
-    if (ta < ntiles) {   // uniform
-        const StreamTile s = stream2_tile(a, ta, lane, comm ? 0 : cw);
-        if (comm) {
-            if (lane == 0) sh.ticket[1] = agent_add(a.tickets, 1u);    // travels while the first tile loads; both tiles are published before any spin
-        } else {
-            // a wave whose rows all lie past the range's end (last chunk of a ragged range) repeats the range's last row
-            load_tile<true>(a, s.row0 < s.row_end ? s.row0 : s.row_end - 1, s.row_end, s.tile_col0, lane, v0);
-            float mn[4], mx[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mn[i] = mx[i] = v0[0][i];
-#pragma unroll
-            for (int r = 1; r < kResRows; ++r)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    mn[i] = nmin(mn[i], v0[r][i]);
-                    mx[i] = nmax(mx[i], v0[r][i]);
-                }
-            sh.mn[1][cw][lane] = make_float4(mn[0], mn[1], mn[2], mn[3]);   // buffer 1: step 0 uses buffer 0 for its own Y
-            sh.mx[1][cw][lane] = make_float4(mx[0], mx[1], mx[2], mx[3]);
-        }
-        __syncthreads();
-        tb = sh.ticket[1];
-        if (comm) {
-            s2_publish(a, s, lane, sh, 1);
-        } else if (tb < ntiles) {   // slot 1: in flight, published by the first step
-            const StreamTile s1 = stream2_tile(a, tb, lane, cw);
-            load_tile<true>(a, s1.row0 < s1.row_end ? s1.row0 : s1.row_end - 1, s1.row_end, s1.tile_col0, lane, v1);
-        }
-        __syncthreads();            // buffer 1 of the partials is free again before step 1 writes it
-        uint32_t step = 0;
-        while (ta < ntiles || tb < ntiles) {
-            if (ta < ntiles) ta = stream2_step(a, step++, ta, v0, tb < ntiles, tb, v1, lane, wave, sh, s2_t0);
-            if (tb < ntiles) tb = stream2_step(a, step++, tb, v1, ta < ntiles, ta, v0, lane, wave, sh, s2_t0);
-        }
-    }
-    if (a.done != nullptr) {   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
-        if (first) clean_state(a, gridDim.x - 1u, kS2Waves * kWave);
         else if (threadIdx.x == 0) agent_add(a.done, 1u);
     }
 }
@@ -1173,25 +918,17 @@ static int forced_tile_rows() {
     static const int forced = [] {
         const char* v = getenv("OQ_RTN_RES_TILE");
         const int r = v ? atoi(v) : 0;
-        return (r == 256 || r == 128 || r == 1 || r == 2) ? r : 0;      // 1: rtn_resident_stream, 2: rtn_resident_stream2
+        return (r == 256 || r == 128 || r == 1) ? r : 0;
     }();
     return forced;
 }
 // `ranges`: column tiles x k-groups of the call
 static bool groups_streamed(int64_t g, int64_t ranges) {
-    if (forced_tile_rows()) return forced_tile_rows() <= 2;
+    if (forced_tile_rows()) return forced_tile_rows() == 1;
     return g > kResStreamAbove || ranges * ceil_div(g, kResGroupTileRows) >= kResStreamTiles;
 }
-// the streamed kernel with a communication wave (tiles of 112 rows): wherever the streamed kernel runs and the ragged last
-// tile of a range wastes little (4096 rows: 37 tiles, 1.2 % past the end; 11008: 0.7 %; 1024: 9 % -- stays on 128-row tiles)
-static bool groups_stream2(int64_t g, int64_t ranges) {
-    if (!groups_streamed(g, ranges)) return false;
-    if (forced_tile_rows()) return forced_tile_rows() == 2;
-    return (ceil_div(g, kS2TileRows) * kS2TileRows - g) * 25 <= g;
-}
 static int groups_tile_rows(int64_t g, int64_t ranges) {
-    if (forced_tile_rows() > 2) return forced_tile_rows();
-    if (groups_stream2(g, ranges)) return kS2TileRows;
+    if (forced_tile_rows() > 1) return forced_tile_rows();
     if (groups_streamed(g, ranges)) return kResGroupTileRows;
     // a call of fewer 256-row tiles than the device has CUs leaves CUs idle: 128-row tiles then (4096 x 2048 int8 per channel:
     // 128 tiles 20.1 us, 256 tiles of 128 rows 17.0; at 256 tiles -- 4096 x 4096, 2048 x 8192 -- the taller tiles win: 27.3 / 24.9 against 30 / 28.0)
@@ -1201,15 +938,14 @@ static int64_t ranges_of(int64_t K, int64_t N, int64_t g) { return ceil_div(N, k
 
 // workgroups of the channel / tall-group kernel chosen for `g` that the current device runs at once (cached per device)
 static int groups_resident(int64_t g, int64_t ranges) {
-    static int cache[4][64];
-    static bool filled[4][64];
+    static int cache[3][64];
+    static bool filled[3][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    const int which = groups_stream2(g, ranges) ? 3 : groups_streamed(g, ranges) ? 0 : (groups_tile_rows(g, ranges) == 256 ? 1 : 2);
+    const int which = groups_streamed(g, ranges) ? 0 : (groups_tile_rows(g, ranges) == 256 ? 1 : 2);
     if (!filled[which][dev]) {   // benign race: every thread computes the same value
         int cus = 0, per_cu = 0;
         const void* k = which == 0 ? reinterpret_cast<const void*>(rtn_resident_stream)
-                      : which == 3 ? reinterpret_cast<const void*>(rtn_resident_stream2)
                       : which == 1 ? reinterpret_cast<const void*>(rtn_resident_groups<16, 16, 4>) : reinterpret_cast<const void*>(rtn_resident_groups<8, 16, 4>);
         const int threads = which == 1 ? 16 * kWave : kResWaves * kWave;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -1372,8 +1108,7 @@ static int32_t rtn_resident_launch(const float* W, int64_t K, int64_t N, int64_t
         OQ_REQUIRE(resident > 0 && (a.chunks <= resident || a.ntiles <= static_cast<uint32_t>(resident)), OQ_ERR_UNSUPPORTED,
                    "rtn: %lld chunks per range need as many resident workgroups, the device holds %d", (long long)a.chunks, resident);
         const uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
-        if (groups_stream2(g, ranges)) hipLaunchKernelGGL(rtn_resident_stream2, dim3(blocks), dim3(kS2Waves * kWave), 0, s, a);
-        else hipLaunchKernelGGL(rtn_resident_stream, dim3(blocks), dim3(kResWaves * kWave), 0, s, a);
+        hipLaunchKernelGGL(rtn_resident_stream, dim3(blocks), dim3(kResWaves * kWave), 0, s, a);
     }
     return check_launch("rtn_resident_groups");
 }

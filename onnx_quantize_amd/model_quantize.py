@@ -79,8 +79,9 @@ class _Const:
     """What the emission code reads of a constant value: `.name`, `.const_value.numpy()`; `device_value`: the same weight in
     HBM when the calibration walk left it there (the seam then skips its upload)."""
 
-    def __init__(self, name, array, device_value=None):
+    def __init__(self, name, array, device_value=None, placeholder=False):
         self.name, self._a, self.device_value = name, array, device_value
+        self.placeholder = placeholder       # `array` carries the shape only (zeros): the values live in `device_value` and nowhere else
         self.const_value = self
 
     def numpy(self):
@@ -174,6 +175,7 @@ def _raise_opset(model: Message, G: _Graph, target: int = FUNCTION_OPSET) -> Non
     if current < _MIN_SOURCE_OPSET:
         raise NotImplementedError(f"the model imports opset {current}; this writer raises opsets >= {_MIN_SOURCE_OPSET} to {target} "
                                   "(older models: run onnx's version converter first)")
+    taken_axes_names: set = set()
     for n in _all_nodes(model.graph):
         if n.domain not in (None, "", "ai.onnx"):
             continue
@@ -184,7 +186,11 @@ def _raise_opset(model: Message, G: _Graph, target: int = FUNCTION_OPSET) -> Non
         if n.op_type in _REDUCE_AXES_TO_INPUT and current < 18:
             axes = _attr(n, "axes")
             if axes is not None:
-                name = f"{n.output[0]}/axes"
+                name, k = f"{n.output[0]}/axes", 0
+                while name in G.inits or name in taken_axes_names:      # If branches reuse output names; an initializer of that name may exist
+                    k += 1
+                    name = f"{n.output[0]}/axes_{k}"
+                taken_axes_names.add(name)
                 G.set_initializer(name, np.asarray(axes, dtype=np.int64))
                 n.input = list(n.input)[:1] + [name]
                 n.attribute = [a for a in n.attribute if a.name != "axes"]
@@ -802,6 +808,14 @@ def apply_pre_passes(model, qconfig: QConfig, *, device="cuda", calibrate=None, 
         raise ValueError("the model has no graph")
     G = _structural_passes(model)
     targets = _target_nodes(G, qconfig)
+    if not targets:
+        # an fp16 / bf16 export (the usual half-precision form) has constant MatMul / Gemm weights and not one fp32
+        # matrix among them; returning it untouched with a success status would look like a quantized model
+        halves = [n.input[1] for n in G.g.node if not n.domain and n.op_type in qconfig.target_op_types and len(n.input) > 1 and n.input[1] in G.inits
+                  and len(G.inits[n.input[1]].dims) == 2 and G.inits[n.input[1]].data_type in (DataType.FLOAT16, DataType.BFLOAT16)]
+        if halves:
+            raise NotImplementedError(f"none of the model's {len(halves)} constant MatMul / Gemm weights is float32 (e.g. '{halves[0]}' is half precision): "
+                                      "the numeric path is defined on fp32 [K, N] matrices -- convert the weights to float32 first")
     calibrate = calibrate or _calibrate
     per_node: dict = {}
     meta: dict = {}
@@ -865,9 +879,11 @@ def _plan(prepared: Prepared, node, qconfig: QConfig, weight_arrays, quantize_bi
     if (on_device and name in G.pending_host and resident is not None and tuple(resident.shape) == dims
             and getattr(cfg.weights.algorithm, "algorithm_type", None) in ("rtn", "hqq", "gptq")):
         host = np.broadcast_to(np.float32(0), dims)           # the seam reads the shape only: it quantizes the copy in HBM
+        placeholder = True
     else:
         host = G.array(name)
-    w = _Const(name, host, resident)
+        placeholder = False
+    w = _Const(name, host, resident, placeholder=placeholder)
     b = _Const(node.input[2], G.array(node.input[2])) if has_bias else None
     node_meta = prepared.meta.get(id(node), {})
     return plan_node(node.op_type, node.input[0], w, node.output[0], cfg, node_meta, bias=b,

@@ -173,6 +173,8 @@ def _signed(v: int, kind: str) -> int:
 
 
 def _scalar_from_wire(kind, wire, buf, pos):
+    if wire != _WIRE_OF.get(kind, wire):                   # the schema says what a field's wire type is: a float sent as varint is malformed input
+        raise ValueError(f"onnx_proto: wire type {wire} for a field of kind '{kind}' (the schema says {_WIRE_OF[kind]})")
     if wire == 0:
         v, pos = _varint(buf, pos)
         return _signed(v, kind), pos

@@ -229,9 +229,13 @@ def weight_arrays(w, qconfig, out=None, is_matmul_nbits_compatible: bool = False
         if resident is not None and (tuple(resident.shape) != tuple(w_np.shape) or str(resident.dtype) != "torch.float32"   # calibration walk)
                                      or not resident.is_cuda or not resident.is_contiguous()):
             resident = None
+        if resident is None and getattr(w, "placeholder", False):      # the host array of such a value is zeros that carry the shape
+            raise RuntimeError(f"'{w.name}': the weight lives in HBM only and its device copy cannot be used ({'missing' if getattr(w, 'device_value', None) is None else 'not contiguous fp32 of the declared shape'})")
         res = _device_algorithm(resident if resident is not None else _upload(w.name, w_np), w.name, qconfig, out, is_matmul_nbits_compatible,
                                 want_packed4=packed4 and not is_matmul_nbits_compatible)
     if res is None:        # an algorithm plugin without kernels here: its own NumPy route, then the wire format on the GPU
+        if getattr(w, "placeholder", False):
+            raise RuntimeError(f"'{w.name}': the weight lives in HBM only; the NumPy route of this algorithm plugin would read a placeholder")
         w_q, w_scale, w_zp = a.algorithm.quantize_weights(w, qconfig, out=out)
         if is_matmul_nbits_compatible:
             from .wire_format import _prepare_for_matmul_nbits

@@ -80,6 +80,41 @@ def test_wire_primitives():
     assert P.parse("ValueInfoProto", P.serialize(P.make_value_info("s", 1, None))).type.tensor_type.shape is None
 
 
+def test_scalar_fields_sent_with_another_wire_type_are_value_errors():
+    """the schema fixes a scalar field's wire type; a float attribute sent as a varint (it used to come back as an int
+    and surface later as struct.error in serialize), a float sent as fixed64 or an int64 sent as fixed32 are malformed input."""
+    import struct
+
+    def attribute(field, wire, payload):                                    # AttributeProto { name: "a", <field>: payload }
+        a = bytearray(b"\x0a\x01a")
+        P._put_varint(a, (field << 3) | wire)
+        return bytes(a) + payload
+
+    ok = P.parse("AttributeProto", attribute(2, 5, struct.pack("<f", 1.5)))       # f = 1.5, fixed32: the schema's type
+    assert ok.f == 1.5
+    for field, wire, payload in ((2, 0, b"\x05"),                           # f as varint
+                                 (2, 1, struct.pack("<d", 1.5)),             # f as fixed64
+                                 (3, 5, struct.pack("<f", 2.0)),             # i (int64) as fixed32
+                                 (3, 1, struct.pack("<d", 2.0))):            # i as fixed64
+        with pytest.raises(ValueError, match="wire type"):
+            P.parse("AttributeProto", attribute(field, wire, payload))
+
+
+def test_a_half_precision_model_is_refused_by_name_not_returned_untouched():
+    """constant fp16 weights under MatMul: `quantize` used to log a warning per node and return the model with a
+    success status and nothing rewritten."""
+    from onnx_quantize_amd import QConfig, QWeightArgs, quantize
+    from onnx_quantize_amd.onnx_proto import DataType, Message, make_node, make_value_info, numpy_to_tensor, serialize
+
+    w = numpy_to_tensor("W", np.ones((8, 4), np.float16))
+    assert w.data_type == DataType.FLOAT16
+    g = Message("GraphProto", name="half", node=[make_node("MatMul", ["X", "W"], ["Y"], name="fc")], initializer=[w],
+                input=[make_value_info("X", DataType.FLOAT16, ["N", 8])], output=[make_value_info("Y", DataType.FLOAT16, ["N", 4])])
+    m = Message("ModelProto", ir_version=10, graph=g, opset_import=[Message("OperatorSetIdProto", domain="", version=21)])
+    with pytest.raises(NotImplementedError, match="float32"):
+        quantize(serialize(m), QConfig(weights=QWeightArgs()))
+
+
 def test_malformed_files_are_value_errors():
     """A model file is input from outside: whatever a mutated file does to the parser, it ends in ValueError (or parses) --
     no IndexError / struct.error / RecursionError, no hang.  4000 random mutations of a real file + a nesting bomb."""
