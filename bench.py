@@ -322,15 +322,16 @@ def seam_bench(w_host: np.ndarray, digest: dict, count: int = 12) -> dict:
         last = _prepare_for_matmul_nbits(q, s, z, qc)
     t_plugin = time.perf_counter() - t0
     # device-resident seam (upload per call).  Host-side effects (page faults of fresh arrays) make single passes scatter by
-    # a factor of two between boxes: three passes, the median is reported and all three are listed.
+    # a factor of two between boxes, and the first pass of a process is 8-14 ms per weight everywhere (the runtime's own staging
+    # warms up): five passes, the median is reported and all five are listed.
     trials = []
-    for _ in range(3):
+    for _ in range(5):
         mats = fresh()
         t0 = time.perf_counter()
         for i, w in enumerate(mats):
             last = seam.weight_arrays(_Value(f"w{i}", w), qc, None, True)
         trials.append(time.perf_counter() - t0)
-    t_after = sorted(trials)[1]
+    t_after = sorted(trials)[len(trials) // 2]
     ok_after = check(*last)
     rate = lambda t: round(params / t / 1e6, 1)  # noqa: E731
     return {"what": "host->host through quantize_weights' arrays (qrules/_common.py:133-137), uint4 g128 4096x11008, "

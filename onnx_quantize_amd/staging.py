@@ -16,6 +16,7 @@ A download's cost is the FIRST TOUCH of its fresh destination (every result of a
 there is nothing to reuse): 9.6-14.8 GB/s into `np.empty` against 51 GB/s into memory touched before.  Destinations of 4 MiB
 and more are therefore faulted in by four threads at once (`madvise(MADV_POPULATE_WRITE)` on a quarter each) before the one
 blocking copy: 23.5 GB/s (`scripts/lab_upload_paths.py`; one thread, huge pages or a page-locked destination gain nothing).
+A destination whose first and last page are resident already (`mincore`: memory the allocator hands out again) is left alone.
 
 Nothing here computes anything: torch is used for device memory and copies only.
 """
@@ -66,7 +67,13 @@ def _prefault_setup(st: dict) -> None:
         madvise.restype = ctypes.c_int
     except (OSError, AttributeError):
         madvise = None
-    st.update(pool=ThreadPoolExecutor(_PREFAULT_THREADS, thread_name_prefix="oq-prefault"), madvise=madvise,
+    try:
+        mincore = ctypes.CDLL(None, use_errno=True).mincore
+        mincore.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p]
+        mincore.restype = ctypes.c_int
+    except (OSError, AttributeError):
+        mincore = None
+    st.update(pool=ThreadPoolExecutor(_PREFAULT_THREADS, thread_name_prefix="oq-prefault"), madvise=madvise, mincore=mincore,
               page=os.sysconf("SC_PAGE_SIZE"), works=madvise is not None)
     st["pid"] = os.getpid()                                # last: the state is complete when a reader sees its own pid
 
@@ -83,6 +90,14 @@ def _prefault(out: np.ndarray) -> None:
     lo, hi = addr + (-addr % page), addr + out.nbytes - (addr + out.nbytes) % page
     if hi - lo < _PREFAULT_MIN_BYTES:
         return
+    if st["mincore"] is not None:
+        # memory the allocator hands out AGAIN (a caller that frees every result before the next one: the single-weight seam) is
+        # resident already; populating it once more cost that loop 0.18 ms per 22 MB result (scripts/lab_seam_prefault.py).  Two
+        # system calls on one page each tell: fresh memory has neither its first nor its last page
+        first, last = ctypes.create_string_buffer(1), ctypes.create_string_buffer(1)
+        if (st["mincore"](lo, page, first) == 0 and st["mincore"](hi - page, page, last) == 0
+                and (first.raw[0] & 1) and (last.raw[0] & 1)):
+            return
     step = -(-(hi - lo) // _PREFAULT_THREADS)
     step += -step % page
     starts = range(lo, hi, step)

@@ -4,7 +4,7 @@
 # directly after `--`.
 #   ROUND=r05 scripts/profile.sh [rtn] [strategies] [packed] [shapes] [searches] [awq] [gptq] [file]      (default: all but file)
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -38,6 +38,11 @@ for w in $WHAT; do
       trace awq $P;;
     gptq)
       trace gptq python3 $R/bench_gptq.py --layers 8 --no-cpu-baseline --hessian-methods "" --extra-passes corrected;;
+    pmc)        # the launches whose roofline.traffic had no counter record (calibration minmax, Hessian SYRK): round 6
+      for t in calibration hessian; do
+        P="python3 $R/scripts/pmc_targets.py $t"
+        trace pmc_$t $P; pmc pmc_$t FETCH_SIZE $P; pmc pmc_$t WRITE_SIZE $P
+      done;;
     file)       # the file path: calibration walk on torch-ROCm + own GEMM, Hessians, factors, loops, packs
       trace file_gptq python3 $R/bench_model.py --layers 4 --config gptq_int4_g128 --samples 16 --seq 2048 --repeat 1
       trace file_awq python3 $R/bench_model.py --layers 4 --config awq_uint4_g128 --samples 16 --seq 2048 --repeat 1;;
