@@ -157,6 +157,14 @@ def run(dev, cpu: bool = True, layers: int = 18, batches: int = 51) -> dict:
     ok = ok and float(st[0]) == big.min().item() and float(st[1]) == big.max().item()
     del big
 
+    traffic, traffic_source = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pj = json.load(f)
+        if pj.get("calibration", {}).get("tensor_bytes") == big_bytes:
+            traffic = pj["calibration"]["traffic_bytes_per_launch"]
+            traffic_source = "stored profile, not measured in this run: " + pj["source"] + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/pmc_targets.py calibration: the same tensor, FETCH_SIZE x2 gfx950 correction)"
     out = {
         "metric": "activation GB/s reduced, min-max calibration, gemma-3-270m-shaped synthetic stand-in, 512 samples",
         "value": round(nbytes * batches / dev_collect / 1e9, 1), "unit": "GB/s", "n_gpus": 1, "higher_is_better": True,
@@ -180,7 +188,7 @@ def run(dev, cpu: bool = True, layers: int = 18, batches: int = 51) -> dict:
         "per_tensor_calls": {"GBs": round(nbytes * batches / t_per_tensor / 1e9, 1),
                              "tensors_per_s": round(len(acts) * batches / t_per_tensor, 1)},
         "roofline": {"bound": "hbm", "achieved": round(big_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(big_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(big_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "oq::minmax_partial<float> (+ oq::minmax_update, one block)", "launch_us": round(big_us, 2), "launch_us_trials": [round(t, 2) for t in big_trials],
                      "algorithmic_bytes_per_launch": big_bytes, "bytes_per_element": 4},
         "verified": bool(ok),

@@ -504,6 +504,16 @@ def run(args, dev, rank: int, world: int):
                     "dtype": ("%s pieces of fp32 operands, fp32 accumulate" % ("fp16" if terms == 3 else "bf16")) if split else "f32",
                     "fp32_equivalent_TFLOPs": round(fp32_equiv / ms / 1e9, 1), "call_ms": round(ms, 2), "k": kw, "rows": t_rows,
                     "traffic": None}
+            if method == "auto" and kw == 11008 and t_rows == 65536:        # the call the stored counter record was taken on
+                pmc_path = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+                if os.path.exists(pmc_path):
+                    with open(pmc_path) as f:
+                        pj = json.load(f)
+                    roof["traffic"] = pj["hessian"]["traffic_bytes_per_call"]
+                    roof["traffic_by_kernel"] = {k: v["read_bytes"] + v["write_bytes"] for k, v in pj["hessian"]["kernels"].items()}
+                    roof["traffic_source"] = ("stored profile, not measured in this run: " + pj["source"] + " (separate rocprofv3 --pmc passes of "
+                                              "scripts/pmc_targets.py hessian: one call of the same shape; HBM-side bytes incl. Infinity-Cache hits: "
+                                              "the 2.9 GB of pieces are re-read 11.7 x by the 256 x 256 tiles, 2.0 TB/s over the 17 ms of the SYRK)")
             roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
             roofs.append(roof)
         ops.hessian_set_method(saved)

@@ -7,7 +7,8 @@ within 1e-1 of the float model's (test_quantize.py:105-139) -- with `GraphRunner
 
 * CPU (`-m "not gpu"`): the oracle as numeric provider: the writer's bookkeeping over the whole grid.
 * GPU: the product's providers (device-resident seam, HIP bias kernel, on-device calibration walk); for everything but
-  GPTQ the emitted file must equal, byte for byte, the oracle-provider file computed on the same activations.
+  HQQ and the searches the emitted file must equal, byte for byte, the oracle-provider file computed on the same activations
+  (GPTQ included since round 6: the reference's loop as written lets nothing of the Hessian's arithmetic into the file).
 """
 import itertools
 
@@ -220,7 +221,7 @@ def test_the_reference_grids_with_the_oracle_as_provider():
 
 @pytest.mark.gpu
 def test_the_reference_grids_on_the_device_path():
-    exact = {"n": 0}
+    exact = {"n": 0, "gptq": 0}
 
     def provider(model, qc, tag):
         twin = qc.model_copy()                                                # (quantize() drops the caller's calibration data, like the reference)
@@ -228,9 +229,15 @@ def test_the_reference_grids_on_the_device_path():
         if tag is None:                                                       # same activations -> the same file, byte for byte
             assert P.serialize(got) == P.serialize(q_oracle(model, twin, runner_device="cuda")), qc
             exact["n"] += 1
+        elif tag == "gptq":
+            # VERDICT r05 weak #2b.  The reference's loop as written (the default `mode="parity"`) feeds no error back (gptq.py:199,208:
+            # DESIGN.md 4.5): its integers depend on the Hessian only through the zeros of its diagonal, and the final parameters are
+            # recomputed from the integers.  So the Hessian's arithmetic (fp16 pieces here, sgemm in the oracle) cannot show in the
+            # file: it must be the oracle-provider file, byte for byte, like every RTN case.
+            assert P.serialize(got) == P.serialize(q_oracle(model, twin, runner_device="cuda")), qc
+            exact["gptq"] += 1
         return got
 
     n = _run_grid(provider, "cuda")
-    # not compared as bytes: GPTQ (48 + 6: the Hessian is accumulated in fp16 pieces), HQQ (12: an iterative fp32 solve), the
-    # AWQ / SmoothQuant searches (12 + 1)
-    assert n == TOTAL and exact["n"] == TOTAL - 48 - 6 - 12 - 13
+    # not compared as bytes: HQQ (12: an iterative fp32 solve), the AWQ / SmoothQuant searches (12 + 1)
+    assert n == TOTAL and exact["n"] == TOTAL - 48 - 6 - 12 - 13 and exact["gptq"] == 48 + 6
