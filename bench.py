@@ -40,7 +40,14 @@ Prints ONE JSON line (contract in the task description) with these extra objects
                 (bench_gptq.run): wall, M-param/s, the Hessian kernels' MFMA rooflines, a CPU baseline, `verified`;
                 `corrected` = the same model with the error-correcting loop, `wall_by_hessian_method` = the whole-model
                 wall with the Hessian on the fp32 MFMA kernel next to the default split-operand one
+  model_file_7b north_star's sentence, file to file (round 6): a 7B-shaped ONNX file (224 weights, 25.9 GB) -> GPTQ QInt4 g128 of all of
+                them -> an ONNX file, in the reference's default behaviour (`parity`) and `corrected`, 65 536 calibration tokens through
+                the graph, phases apart, one weight of each file verified against the per-layer device path (~1 min, N = 1 only)
+  rccl_selftest N = 1: a child process brings up a one-rank `nccl` communicator before any other GPU call and runs every kind of
+                exchange the N-rank path issues (`bench.py --nccl-selftest`, sharding.collectives_selftest): ms per step
   gather        N > 1: seconds, bytes and ranks of the end-of-run RCCL gather
+
+`python bench.py --gpus N --nccl-selftest` (N >= 1) runs only that self-test on N ranks and exits 0 / 1.
 """
 from __future__ import annotations
 
