@@ -56,6 +56,10 @@ struct RtnArgs {
     uint8_t* zp;
     float* scale_t;   // optional staging [kgroups, N] (coalesced); transposed to `scale` by transpose_qparams
     uint8_t* zp_t;
+    // Round 6 (template mode TR): staging in the caller's zeroed STATE, transposed inside this launch by `ncol_tiles` blocks appended to
+    // the grid (see transposer_block).  tr_zp: 8 bytes per four columns, each zero point in 16 bits with bit 8 set.
+    float* tr_scale;
+    uint2* tr_zp;
     QGrid grid;
     int32_t layout;
     int32_t wpg;      // waves per group
@@ -147,11 +151,135 @@ __device__ __forceinline__ void tile_of_block(const RtnArgs& a, uint32_t bid, ui
 // Fused one-pass kernel.  One block = GPB groups (stacked along K) x 256 columns; one group =
 // WPG waves x RPW rows.  Registers per lane: RPW x 4 fp32 of W.
 // ---------------------------------------------------------------------------------------------
-template <int RPW, bool VEC4, bool EMIT_Q, bool NT = false>
+// ---------------------------------------------------------------------------------------------
+// The [K/g, N] -> [N, K/g] transposition of the staged parameters INSIDE the fused launch (round 6; template mode TR, stateful entry
+// point only, packed nibbles of up to 32 k-groups: see the host's rule).  The separate transpose launch is 5 us of which the kernel
+// itself needs 1.5 (rocprofv3: 43.0 + 5.0 us against 43.2-44.5 us per call).
+// Every main block stores its parameters into the caller's zeroed state with agent-scope (`sc1`) word stores -- four scales and two
+// words of zero-point pairs (16 bits each, bit 8 set) per lane -- and waits for nothing: a scale is never zero (utils.py:266-268)
+// and a pair word never is, so every WORD says by itself whether it has been written.  `ncol_tiles` blocks are appended to the
+// grid; they are dispatched behind the last main block, into slots no main block is waiting for, and each takes one column tile:
+// poll ONE word of the tile's last k-group until it is there (the k-groups of a column tile finish roughly in order), read all of
+// the tile's words with `sc1` loads -- re-reading the few that are not written yet --, transpose them through the 16 KB of LDS the
+// fold uses, store whole 128-byte lines of the result, and put the zeros back (the state is what the next call finds).
+// Also built: the transposition by the block of each column tile's LAST k-group after its own stores (no appended blocks) --
+// bit-exact, slower than the second launch (packed 44.5 -> 45.0 us, bytes 45.5 -> 48.9): the last round of blocks then carries
+// the read-back's round trips on top of its own work.
+// Forward progress: a main block never waits; an appended block waits only for main blocks of its own launch, and there are at
+// most `ncol_tiles` of them -- a few dozen of the device's workgroup slots -- so the blocks they wait for always find a slot whatever
+// the dispatch order.  (Launches of DIFFERENT streams could in principle fill the device with waiting blocks: the host orders them
+// through the ticket chain of rtn_resident.hip.)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool lab_spin_over(uint32_t spins) {
+#ifdef OQ_SPIN_LIMIT      /* lab builds: give up instead of hanging the box (the result is garbage then) */
+    return spins >= static_cast<uint32_t>(OQ_SPIN_LIMIT);
+#else
+    (void)spins;
+    return false;
+#endif
+}
+__device__ __forceinline__ void transposer_block(const RtnArgs& a, uint32_t col_tile, float4 (&s_lo)[kMaxWaves][kWave], float4 (&s_hi)[kMaxWaves][kWave]) {
+    const int tid = threadIdx.x;
+    const int64_t N = a.N, kgroups = a.kgroups;
+    float* lds_lo = reinterpret_cast<float*>(&s_lo[0][0]);      // rows 0-15 of a 32 x 128 tile (2048 floats)
+    float* lds_hi = reinterpret_cast<float*>(&s_hi[0][0]);      // rows 16-31
+    // one poll: the first granule of the column tile's LAST k-group
+    if (tid == 0) {
+        const u32x4* probe = reinterpret_cast<const u32x4*>(a.tr_scale + (kgroups - 1) * N + static_cast<int64_t>(col_tile) * kColsPerWave);
+        u32x4 v;
+        for (uint32_t spins = 0;; ++spins) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(probe) : "memory");
+            if (v[0] != 0u || lab_spin_over(spins)) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __syncthreads();
+    for (int64_t kb = 0; kb < kgroups; kb += 32) {
+        for (int half = 0; half < 2; ++half) {
+            const int64_t cbase = static_cast<int64_t>(col_tile) * kColsPerWave + half * 128;
+            if (cbase >= N) break;                                         // uniform
+            // ---- scales: 32 rows x 32 granules of four columns, two per thread
+            u32x4 sv[2];
+            u32x2 zv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, r = idx >> 5, gq = idx & 31;
+                const int64_t kg = kb + r, col = cbase + gq * 4;
+                sv[j] = u32x4{1u, 1u, 1u, 1u};
+                zv[j] = u32x2{0x01000100u, 0x01000100u};
+                if (kg < kgroups && col < N) {
+                    const u32x4* ps = reinterpret_cast<const u32x4*>(a.tr_scale + kg * N + col);
+                    const u32x2* pz = reinterpret_cast<const u32x2*>(a.tr_zp + (kg * N + col) / 4);
+                    for (uint32_t spins = 0;; ++spins) {
+                        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(sv[j]), "=&v"(zv[j]) : "v"(ps), "v"(pz) : "memory");
+                        if ((sv[j][0] != 0u && sv[j][1] != 0u && sv[j][2] != 0u && sv[j][3] != 0u && zv[j][0] != 0u && zv[j][1] != 0u) || lab_spin_over(spins)) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    // the zeros go back: the state is what the next call finds
+                    const u32x4 z4 = {0u, 0u, 0u, 0u};
+                    const u32x2 z2 = {0u, 0u};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1" : : "v"(ps), "v"(z4), "v"(pz), "v"(z2) : "memory");
+                }
+                float* row = (r < 16 ? lds_lo : lds_hi) + (r & 15) * 128;
+                *reinterpret_cast<u32x4*>(row + ((gq + r) & 31) * 4) = sv[j];       // granule index rotated by the row: the transposed reads spread over the banks
+            }
+            __syncthreads();
+            // ---- out: column c (128) x four consecutive k-groups per thread, eight threads = one column's 128 bytes; two per thread
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, kq = idx & 7, c = idx >> 3;
+                const int64_t col = cbase + c, kg0 = kb + kq * 4;
+                if (col < N && kg0 < kgroups) {
+                    float o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = kq * 4 + i;
+                        o[i] = ((r < 16 ? lds_lo : lds_hi) + (r & 15) * 128)[(((c >> 2) + r) & 31) * 4 + (c & 3)];
+                    }
+                    *reinterpret_cast<float4*>(a.scale + col * kgroups + kg0) = make_float4(o[0], o[1], o[2], o[3]);      // kgroups % 4 == 0 (host)
+                }
+            }
+            __syncthreads();
+            // ---- zero points through the same LDS: one byte per entry, [32 rows][128 columns]
+            uint8_t* zl = reinterpret_cast<uint8_t*>(lds_lo);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, r = idx >> 5, gq = idx & 31;
+                *reinterpret_cast<uint32_t*>(zl + r * 128 + ((gq + r) & 31) * 4) =
+                    (zv[j][0] & 0xffu) | ((zv[j][0] >> 8) & 0xff00u) | ((zv[j][1] & 0xffu) << 16) | ((zv[j][1] << 8) & 0xff000000u);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = tid + 512 * j, kq = idx & 7, c = idx >> 3;
+                const int64_t col = cbase + c, kg0 = kb + kq * 4;
+                if (col < N && kg0 < kgroups) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = kq * 4 + i;
+                        w |= static_cast<uint32_t>(zl[r * 128 + (((c >> 2) + r) & 31) * 4 + (c & 3)]) << (8 * i);
+                    }
+                    *reinterpret_cast<uint32_t*>(a.zp + col * kgroups + kg0) = w;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int RPW, bool VEC4, bool EMIT_Q, bool NT = false, bool TR = false>      // TR: parameters staged in the caller's state and transposed inside the launch
 __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArgs a_in) {
     __shared__ float4 s_mn[kMaxWaves][kWave];
     __shared__ float4 s_mx[kMaxWaves][kWave];
 
+    if constexpr (TR) {
+        if (blockIdx.x >= a_in.ncol_tiles * a_in.nrow_tiles) {      // uniform: one of the blocks appended to the grid
+            transposer_block(a_in, blockIdx.x - a_in.ncol_tiles * a_in.nrow_tiles, s_mn, s_mx);
+            return;
+        }
+    }
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int wig = wave % a_in.wpg;   // wave inside its group
@@ -258,7 +386,19 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     }
 
     if (wig == 0) {
-        if (VEC4 && a.scale_t != nullptr) {
+        if constexpr (TR) {
+            // staged in the caller's state for the block that transposes this column tile: agent-scope (`sc1`) word stores, nothing to wait
+            // for.  Every word says by itself whether it has been written: a scale is never zero, a zero-point pair carries bits 8 and 24
+            if (col_ok[0]) {
+                const int64_t o = kg * a.N + tile_col0 + lane * 4;
+                uint32_t* ps = reinterpret_cast<uint32_t*>(a.tr_scale + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) __hip_atomic_store(ps + i, __float_as_uint(cq[i].scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t* pz = reinterpret_cast<uint32_t*>(a.tr_zp + o / 4);
+                __hip_atomic_store(pz, 0x01000100u | (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pz + 1, 0x01000100u | (static_cast<uint32_t>(cq[2].zp) & 0xffu) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (VEC4 && a.scale_t != nullptr) {
             // staged [kg, n]: 16 B + 4 B per lane, fully coalesced (the n-major scatter of 4-byte pieces at a
             // 128-byte stride costs ~7 us on this matrix: partial-line writes)
             if (col_ok[0]) {
@@ -269,7 +409,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
             }
         }
     }
-    if (!(VEC4 && a.scale_t != nullptr)) {
+    if (!TR && !(VEC4 && a.scale_t != nullptr)) {
         // rtn.py:98-109 result layout: row n*(K/g)+kg of the [N*K/g, 1] arrays.  Every wave of the group holds the same
         // parameters, so the 256 scattered 4-byte + 1-byte stores of a group (128-byte stride) are dealt over its waves:
         // eight (column slot, half wave) pairs, the owner of pair p (= p % wpg, three bits each in `pair_owner`) stores it.
@@ -301,6 +441,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
         for (int i = 0; i < 4; ++i) v[r][i] = f[i];
     }
 
+    do {      // the layout's stores; `break` instead of `return`: every wave reaches the tail below
     if (a.layout == OQ_LAYOUT_KN) {
         const uint32_t flip = bias ? 0x80808080u : 0u;
         if constexpr (VEC4) {
@@ -356,7 +497,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                     uint8_t* dst = a.q + ((row0 + j + (odd ? 8 : 0)) * a.N + tile_col0 + (lane & ~1) * 4) / 2;
                     if (pair_ok) *reinterpret_cast<uint32_t*>(dst) = out;
                 }
-                return;
+                break;
             }
         }
         if (col_ok[0]) {
@@ -428,7 +569,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                     }
                     if (col < a.N) *reinterpret_cast<uint4*>(a.q + (col * a.kgroups + kg0) * blob + part * 16) = t;
                 }
-                return;
+                break;
             }
         }
 #pragma unroll
@@ -468,6 +609,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
             }
         }
     }
+    } while (false);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1194,6 +1336,13 @@ static void launch_fused(int rpw, const RtnArgs& a, dim3 grid, dim3 block, hipSt
         case 4: hipLaunchKernelGGL((rtn_group_fused<4, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
         case 8: hipLaunchKernelGGL((rtn_group_fused<8, VEC4, EMIT_Q>), grid, block, 0, s, a); break;
         case 16:
+            if constexpr (VEC4 && EMIT_Q) {
+                if (a.tr_scale != nullptr) {      // the host sets it only with rpw == 16, eight waves per group, vec4, emit_q
+                    if (a.nt) hipLaunchKernelGGL((rtn_group_fused<16, true, true, true, true>), grid, block, 0, s, a);
+                    else hipLaunchKernelGGL((rtn_group_fused<16, true, true, false, true>), grid, block, 0, s, a);
+                    break;
+                }
+            }
             if (a.nt) hipLaunchKernelGGL((rtn_group_fused<16, VEC4, EMIT_Q, true>), grid, block, 0, s, a);
             else hipLaunchKernelGGL((rtn_group_fused<16, VEC4, EMIT_Q, false>), grid, block, 0, s, a);
             break;
@@ -1201,6 +1350,11 @@ static void launch_fused(int rpw, const RtnArgs& a, dim3 grid, dim3 block, hipSt
     }
 }
 
+// the zeroed state of the in-launch transposition: [kgroups, N] fp32 scales + one 8-byte {four zero points, marker} granule per four columns
+static size_t fused_state_bytes(int64_t K, int64_t N, int64_t g) {
+    const int64_t kgroups = K / g;
+    return static_cast<size_t>((kgroups * N * 4 + 255) / 256 * 256 + kgroups * N * 2 + 256);
+}
 static size_t stage_ws(int64_t K, int64_t N, int64_t g) {  // [kgroups, N] fp32 scales + bytes, 256-byte aligned halves
     const int64_t kgroups = K / g;
     return static_cast<size_t>((kgroups * N * 4 + 255) / 256 * 256 + (kgroups * N + 255) / 256 * 256);
@@ -1238,6 +1392,8 @@ namespace oq {
 bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, const void* q, int32_t strategy, int64_t g, int32_t layout,
                            bool emit_q, size_t workspace_bytes);
 bool rtn_stream_is_capturing(hipStream_t s);
+int32_t ticket_chain_begin(hipStream_t s);
+void ticket_chain_end(hipStream_t s);
 int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
                           float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state);
 size_t rtn_resident_workspace(int64_t K, int64_t N, int32_t strategy, int64_t g);
@@ -1440,6 +1596,23 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.scale_t = static_cast<float*>(workspace);
             a.zp_t = static_cast<uint8_t*>(workspace) + (batch * kgroups * N * 4 + 255) / 256 * 256;
         }
+        // Round 6: with the caller's zeroed state (oq_rtn_quantize_stateful_f32) the staged parameters are transposed inside the
+        // launch, by blocks appended to the grid, instead of by a second launch (see transposer_block)
+        a.tr_scale = nullptr; a.tr_zp = nullptr;
+        // Measured (scripts/lab_kn_inlaunch.py, same box, staged + launch -> in the launch, us): packed nibbles 4096 x 11008 43.0-44.5 ->
+        // 41.3-42.1, 4096 x 27648 95.2 -> 93.6, 4096 x 32000 108.2 -> 107.7, 4096 x 11000 48.4 -> 47.3; 8192 x 11008 (64 k-groups: two
+        // passes of the transposer) 77.6 -> 78.6; [K,N] BYTES 44.7-45.7 -> 46.2-47.0 (the main blocks write twice as much and the
+        // tail is longer): packed nibbles of up to 32 k-groups only.  Speed only.
+        const bool in_launch = staged && tune_s.stage < 0 && emit_q && layout == OQ_LAYOUT_KN_PACKED4 && kgroups <= 32 &&
+                               rpw == 16 && wpg == kMaxWaves && batch == 1 && g_batch.table == nullptr &&
+                               kgroups % 4 == 0 && N % 4 == 0 && g_state.state != nullptr && g_state.bytes >= fused_state_bytes(K, N, g) &&
+                               (reinterpret_cast<uintptr_t>(scale_out) & 15u) == 0 && (reinterpret_cast<uintptr_t>(zp8) & 3u) == 0 &&
+                               !rtn_stream_is_capturing(s);
+        if (in_launch) {
+            a.tr_scale = static_cast<float*>(g_state.state);
+            a.tr_zp = reinterpret_cast<uint2*>(static_cast<uint8_t*>(g_state.state) + (kgroups * N * 4 + 255) / 256 * 256);
+            a.scale_t = nullptr; a.zp_t = nullptr;
+        }
         a.wpg = wpg;
         a.pair_owner = 0;
         for (uint32_t pr = 0; pr < 8; ++pr) a.pair_owner |= (pr % static_cast<uint32_t>(wpg)) << (3 * pr);
@@ -1465,7 +1638,11 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.spb_log2 = 0;
         a.xg_log2 = tune.xg >= 0 ? static_cast<uint32_t>(tune.xg > 4 ? 4 : tune.xg) : (sixteen ? 1u : 0u);
         set_block_order(a);
-        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles, static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles + (in_launch ? a.ncol_tiles : 0u), static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        if (in_launch) {      // its appended blocks wait for its main blocks: ordered against every other waiting launch of the device
+            st = ticket_chain_begin(s);
+            if (st != OQ_OK) return st;
+        }
         if (vec4) {
             if (emit_q) launch_fused<true, true>(rpw, a, grid_dim, block, s);
             else launch_fused<true, false>(rpw, a, grid_dim, block, s);
@@ -1474,6 +1651,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             else launch_fused<false, false>(rpw, a, grid_dim, block, s);
         }
         st = check_launch("rtn_group_fused");
+        if (in_launch) { ticket_chain_end(s); return st; }
         if (st != OQ_OK || !staged) return st;
         hipLaunchKernelGGL(transpose_qparams,
                            dim3(static_cast<uint32_t>(ceil_div(N, 32)), static_cast<uint32_t>(ceil_div(kgroups, 32)), static_cast<uint32_t>(batch)),
@@ -1559,7 +1737,8 @@ size_t oq_rtn_state_bytes(int64_t K, int64_t N, int32_t strategy, int64_t group_
     int64_t g;
     if (oq::resolve_group(strategy, K, group_size, &g) != OQ_OK || K % g != 0) return 0;
     int rpw = 0, wpg = 0;
-    if (strategy == OQ_GROUP && oq::fused_shape(g, &rpw, &wpg)) return 0;     // the fused group kernels keep no state
+    if (strategy == OQ_GROUP && oq::fused_shape(g, &rpw, &wpg))      // the fused group kernels: the staging of the in-launch parameter transposition
+        return (rpw == 16 && wpg == oq::kMaxWaves && (K / g) % 4 == 0 && N % 4 == 0 && K / g > 1) ? oq::fused_state_bytes(K, N, g) : 0;
     return oq::rtn_resident_workspace(K, N, strategy, g);
 }
 

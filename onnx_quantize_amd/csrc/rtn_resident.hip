@@ -1014,41 +1014,62 @@ bool rtn_stream_is_capturing(hipStream_t s) {
 static int32_t rtn_resident_launch(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
                                    float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state);
 
-int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
-                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
+// The chain as two calls around a launch (also used by rtn.hip for the fused group launch whose appended blocks wait for its
+// main blocks).  `ticket_chain_begin` takes the device's mutex, makes `s` wait as described above and returns OQ_OK holding the
+// mutex; `ticket_chain_end` records the event (eager form) and releases it.  A failing begin holds nothing.
+static thread_local TicketChain* t_chain_held = nullptr;
+int32_t ticket_chain_begin(hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OQ_ERR_LAUNCH, "rtn: no current device");
 #ifdef OQ_NO_TICKET_CHAIN      /* lab: what the chain costs a single stream */
-    return rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
+    return OQ_OK;
 #endif
     OQ_REQUIRE(!rtn_stream_is_capturing(s), OQ_ERR_UNSUPPORTED, "rtn: a ticketed kernel cannot be captured into a graph (its replays would be ordered against nothing)");
     const uintptr_t id = reinterpret_cast<uintptr_t>(s);      // an opaque key from here on
     TicketChain& c = g_chain[dev];
-    std::lock_guard<std::mutex> lock(c.m);      // wait + launch + record are one step of the chain
+    c.m.lock();                                                // wait + launch + record are one step of the chain
     if (c.any && !c.eager && c.last_id != id) {
-        if (hipDeviceSynchronize() != hipSuccess) return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
+        if (hipDeviceSynchronize() != hipSuccess) { c.m.unlock(); return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel"); }
         c.eager = true;
     }
     if (c.eager) {
         if (c.ev == nullptr && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) {
             c.ev = nullptr;
+            c.m.unlock();
             return fail(OQ_ERR_LAUNCH, "rtn: cannot create the event that orders ticketed launches");
         }
-        if (c.recorded && c.last_id != id && hipStreamWaitEvent(s, c.ev, 0) != hipSuccess)
+        if (c.recorded && c.last_id != id && hipStreamWaitEvent(s, c.ev, 0) != hipSuccess) {
+            c.m.unlock();
             return fail(OQ_ERR_LAUNCH, "rtn: cannot order the launch behind the previous ticketed kernel");
-    }
-    const int32_t st = rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
-    if (c.eager) {      // also after a launch that failed half way (its clear launch may be in the stream)
-        if (hipEventRecord(c.ev, s) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipDeviceSynchronize();       // nothing of this call may still run when the next one starts
-            c.recorded = false;
-        } else {
-            c.recorded = true;
         }
     }
-    c.last_id = id;
-    c.any = true;
+    t_chain_held = &c;
+    return OQ_OK;
+}
+void ticket_chain_end(hipStream_t s) {
+    TicketChain* c = t_chain_held;
+    if (c == nullptr) return;                                  // OQ_NO_TICKET_CHAIN
+    t_chain_held = nullptr;
+    if (c->eager) {      // also after a launch that failed half way (its clear launch may be in the stream)
+        if (hipEventRecord(c->ev, s) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();       // nothing of this call may still run when the next one starts
+            c->recorded = false;
+        } else {
+            c->recorded = true;
+        }
+    }
+    c->last_id = reinterpret_cast<uintptr_t>(s);
+    c->any = true;
+    c->m.unlock();
+}
+
+int32_t rtn_resident_impl(const float* W, int64_t K, int64_t N, int64_t ldw, const QGrid& grid, int32_t strategy, int64_t g, uint8_t* q,
+                          float* scale, uint8_t* zp, int32_t layout, void* workspace, size_t workspace_bytes, hipStream_t s, bool zeroed_state) {
+    const int32_t pre = ticket_chain_begin(s);
+    if (pre != OQ_OK) return pre;
+    const int32_t st = rtn_resident_launch(W, K, N, ldw, grid, strategy, g, q, scale, zp, layout, workspace, workspace_bytes, s, zeroed_state);
+    ticket_chain_end(s);
     return st;
 }
 

@@ -26,7 +26,9 @@ def test_headline_kernels_keep_their_occupancy(tmp_path):
     for m in re.finditer(r"Function Name: (\S+).*?VGPRs: (\d+).*?Occupancy \[waves/SIMD\]: (\d+).*?VGPRs Spill: (\d+)", r.stderr, re.S):
         report[m.group(1)] = tuple(int(m.group(i)) for i in (2, 3, 4))
     wave = report["_ZN2oq14rtn_group_waveILi8ELb1ELi5EEEvNS_7RtnArgsE"]            # MatMulNBits blob, g = 128: the headline launch
-    fused = report["_ZN2oq15rtn_group_fusedILi16ELb1ELb1ELb1EEEvNS_7RtnArgsE"]     # [K, N] bytes, g = 128
+    fused = report["_ZN2oq15rtn_group_fusedILi16ELb1ELb1ELb1ELb0EEEvNS_7RtnArgsE"]     # [K, N] bytes, g = 128
+    fused_tr = report["_ZN2oq15rtn_group_fusedILi16ELb1ELb1ELb1ELb1EEEvNS_7RtnArgsE"]  # the same with the parameters transposed inside the launch (round 6)
+    assert fused_tr[0] <= 128 and fused_tr[1] >= 4 and fused_tr[2] == 0, fused_tr
     assert wave[0] <= 96 and wave[1] >= 5 and wave[2] == 0, wave
     assert fused[0] <= 128 and fused[1] >= 4 and fused[2] == 0, fused
     for name, (vgprs, occ, spill) in report.items():

@@ -867,7 +867,8 @@ def test_stateful_entry_point_leaves_its_state_zero_and_equals_the_plain_call(op
         assert all(torch.equal(a, b) for a, b in zip(*outs)), (k, n, strategy)
         eq, es, ez = O.rtn_quantize(w.cpu().numpy(), "int8", strategy, g)
         np.testing.assert_array_equal(outs[0][0].cpu().numpy(), eq)
-    assert lib.oq_rtn_state_bytes(4096, 4096, L.STRATEGY_CODE["group"], 128) == 0       # the fused group kernels keep no state
+    assert lib.oq_rtn_state_bytes(4096, 4096, L.STRATEGY_CODE["group"], 64) == 0        # 64-row groups: the fused kernel keeps no state
+    assert lib.oq_rtn_state_bytes(4096, 4096, L.STRATEGY_CODE["group"], 128) >= 32 * 4096 * 6   # 128-row groups: the staging of the in-launch transposition
 
 
 @pytest.mark.gpu
@@ -950,3 +951,47 @@ def test_ticketed_strategies_under_graph_capture_take_the_three_launch_path(ops)
         torch.cuda.synchronize()
         assert torch.equal(out[0], q0) and out[1].cpu().numpy().tobytes() == s0.cpu().numpy().tobytes() and torch.equal(out[2].reshape(z0.shape), z0)
         assert torch.equal(q1, q0) and torch.equal(z1, z0)
+
+
+@pytest.mark.gpu
+def test_packed_nibbles_with_the_parameters_transposed_inside_the_launch():
+    """Round 6: with the caller's zeroed state the packed-nibble group call of up to 32 k-groups stages its parameters in the state
+    (self-validating words) and appended blocks transpose them inside the launch (rtn.hip::transposer_block).  Same bytes as the
+    plain entry point (staged + a transpose launch), the state is zero again after every call, ragged widths and calls in a
+    row on one state buffer included."""
+    import ctypes as C
+
+    import torch
+    from onnx_quantize_amd.hip import _lib as L
+
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(606)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    state = torch.zeros(8 << 20, dtype=torch.uint8, device="cuda")
+    for (k, n, qtype) in ((4096, 11008, "int4"), (4096, 11000, "uint4"), (2048, 5376, "int4"), (4096, 2824, "int4"), (512, 6664, "uint4")):
+        g = 128
+        groups = n * (k // g)
+        scode = L.STRATEGY_CODE["group"]
+        assert 0 < lib.oq_rtn_state_bytes(k, n, scode, g) <= state.numel()
+        ws = torch.empty(lib.oq_rtn_workspace_bytes(k, n, scode, g, 0) + 256, dtype=torch.uint8, device="cuda")
+        want = None
+        for rep in range(3):
+            w = torch.randn((k, n), generator=gen, device="cuda") * (0.1 + rep)
+            got = []
+            for use_state in (False, True):
+                q = torch.full((k * n // 2,), 0x5a, dtype=torch.uint8, device="cuda")
+                sc = torch.full((groups,), -1.0, dtype=torch.float32, device="cuda")
+                zp = torch.full((groups,), 0x33, dtype=torch.uint8, device="cuda")
+                st = lib.oq_rtn_quantize_stateful_f32(C.c_void_p(w.data_ptr()), k, n, n, L.QTYPE_CODE[qtype], scode, g, 0, 0, 1.0, 0,
+                                                      C.c_void_p(q.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(zp.data_ptr()), L.OQ_LAYOUT_KN_PACKED4,
+                                                      C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(state.data_ptr() if use_state else 0),
+                                                      state.numel() if use_state else 0, stream)
+                assert st == 0, lib.oq_last_error()
+                got.append((q, sc, zp))
+            torch.cuda.synchronize()
+            assert int(state.count_nonzero()) == 0, (k, n, rep)
+            assert all(torch.equal(a, b) for a, b in zip(*got)), (k, n, qtype, rep)
+            if rep == 0:      # and the values are the oracle's
+                eq, es, ez = O.rtn_quantize(w.cpu().numpy(), qtype, "group", g)
+                assert es.reshape(-1).tobytes() == got[1][1].cpu().numpy().tobytes()
+                np.testing.assert_array_equal(got[1][2].cpu().numpy().view(ez.dtype).reshape(-1), ez.reshape(-1))
