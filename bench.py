@@ -828,16 +828,16 @@ def main() -> None:
             st = fn(wp, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, oqp, sp, zp, olayout, wsp, wsn, stream)
             if st != 0:
                 L.check(st)
-        for i in range(10):
+        for i in range(20):
             ostep(i)
         torch.cuda.synchronize()
         o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         o0.record()
-        for i in range(100):
+        for i in range(200):
             ostep(i)
         o1.record()
         torch.cuda.synchronize()
-        other_us = o0.elapsed_time(o1) * 10.0
+        other_us = o0.elapsed_time(o1) * 5.0
         for i in range(len(calls)):          # restore the headline layout's outputs for the digest check below
             step(i)
         torch.cuda.synchronize()
@@ -862,22 +862,49 @@ def main() -> None:
                                                   wsp, wsn, pstp, pstn, stream)
             if st != 0:
                 L.check(st)
-        for i in range(10):
+        for i in range(20):
             pstep(i)
         torch.cuda.synchronize()
         p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         p0.record()
-        for i in range(100):
+        for i in range(200):
             pstep(i)
         p1.record()
         torch.cuda.synchronize()
-        p_us = p0.elapsed_time(p1) * 10.0
+        p_us = p0.elapsed_time(p1) * 5.0
+        # the same call without the state (staged parameters + a transpose launch: what rounds 4-5 measured), same process, right behind
+        def pstep2(i: int) -> None:
+            wp, _, sp, _ = calls[i % len(calls)]
+            st = fn(wp, K_DIM, N_DIM, N_DIM, L.OQ_INT4, L.OQ_GROUP, GROUP, 0, 0, 1.0, 0, pqp, sp, pzp, L.OQ_LAYOUT_KN_PACKED4, wsp, wsn, stream)
+            if st != 0:
+                L.check(st)
+        for i in range(20):
+            pstep2(i)
+        torch.cuda.synchronize()
+        p2, p3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p2.record()
+        for i in range(200):
+            pstep2(i)
+        p3.record()
+        torch.cuda.synchronize()
+        p_us_two = p2.elapsed_time(p3) * 5.0
+        for i in range(20):          # and the stateful call once more: the order of the two measurements must not decide
+            pstep(i)
+        torch.cuda.synchronize()
+        p4, p5 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        p4.record()
+        for i in range(200):
+            pstep(i)
+        p5.record()
+        torch.cuda.synchronize()
+        p_us_again = p4.elapsed_time(p5) * 5.0
         palg = algorithmic_bytes("nbits")            # W once + half a byte per value + (scale, zero point) per group: the same count
         packed_kn = {"what": "int4 g128 RTN of the same matrix in OQ_LAYOUT_KN_PACKED4 ([K, N/2] nibble pairs, core/_pack.py order), "
                              "rtn_group_fused<16>, parameters transposed inside the launch (stateful entry point: zeroed, self-cleaning state); "
                              "22.5 MB of integers written instead of 45",
-                     "qtype": "int4", "launch_us": round(p_us, 2), "achieved_GBs": round(palg / (p_us * 1e-6) / 1e9, 1),
-                     "frac": round(palg / (p_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                     "qtype": "int4", "launch_us": round(min(p_us, p_us_again), 2), "launch_us_runs": [round(p_us, 2), round(p_us_again, 2)],
+                     "launch_us_staged_plus_transpose_launch": round(p_us_two, 2), "achieved_GBs": round(palg / (min(p_us, p_us_again) * 1e-6) / 1e9, 1),
+                     "frac": round(palg / (min(p_us, p_us_again) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         if rank == 0:
             with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
                 dpk = json.load(f).get("headline_int4_g128_packed")
