@@ -178,14 +178,22 @@ __device__ __forceinline__ bool lab_spin_over(uint32_t spins) {
     return false;
 #endif
 }
-__device__ __forceinline__ void transposer_block(const RtnArgs& a, uint32_t col_tile, float4 (&s_lo)[kMaxWaves][kWave], float4 (&s_hi)[kMaxWaves][kWave]) {
+// One appended block = COLS columns of the result (all k-groups): 32 x COLS / 4 granules per pass of 32 k-groups, TWO per thread,
+// both loads in flight at once (four one after the other cost the wave kernel 6 us of round trips at the tail of the launch).
+// NTHREADS = 512, COLS = 128 (fused kernel).  `s_f`: 32 x COLS floats, `s_z`: 32 x COLS bytes.  (Built for the blob's wave kernel as well,
+// 256 threads x 64 columns, the wave's 32 scales leaving as ONE line instead of 32: 39.2 -> 41.5 us -- with no second launch to remove, the
+// appended blocks' round trips behind the last main block cost more than the scattered stores: docs/LAB_NOTES_r06.md.)
+template <int NTHREADS, int COLS>
+__device__ __forceinline__ void transposer_block(const RtnArgs& a, uint32_t part, float* s_f, uint8_t* s_z) {
+    constexpr int GQ = COLS / 4;                       // granules per row
+    static_assert(32 * GQ == 2 * NTHREADS, "two granules per thread");
     const int tid = threadIdx.x;
     const int64_t N = a.N, kgroups = a.kgroups;
-    float* lds_lo = reinterpret_cast<float*>(&s_lo[0][0]);      // rows 0-15 of a 32 x 128 tile (2048 floats)
-    float* lds_hi = reinterpret_cast<float*>(&s_hi[0][0]);      // rows 16-31
-    // one poll: the first granule of the column tile's LAST k-group
+    const int64_t cbase = static_cast<int64_t>(part) * COLS;
+    if (cbase >= N) return;                            // uniform
+    // one poll: the first word of this column range in the LAST k-group
     if (tid == 0) {
-        const u32x4* probe = reinterpret_cast<const u32x4*>(a.tr_scale + (kgroups - 1) * N + static_cast<int64_t>(col_tile) * kColsPerWave);
+        const u32x4* probe = reinterpret_cast<const u32x4*>(a.tr_scale + (kgroups - 1) * N + cbase);
         u32x4 v;
         for (uint32_t spins = 0;; ++spins) {
             asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(probe) : "memory");
@@ -195,77 +203,63 @@ __device__ __forceinline__ void transposer_block(const RtnArgs& a, uint32_t col_
     }
     __syncthreads();
     for (int64_t kb = 0; kb < kgroups; kb += 32) {
-        for (int half = 0; half < 2; ++half) {
-            const int64_t cbase = static_cast<int64_t>(col_tile) * kColsPerWave + half * 128;
-            if (cbase >= N) break;                                         // uniform
-            // ---- scales: 32 rows x 32 granules of four columns, two per thread
-            u32x4 sv[2];
-            u32x2 zv[2];
+        // ---- in: 32 rows x GQ granules of four columns (16 bytes of scales + 8 bytes of zero-point pairs)
+        u32x4 sv[2];
+        u32x2 zv[2];
+        const u32x4* ps[2];
+        const u32x2* pz[2];
+        bool live[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + 512 * j, r = idx >> 5, gq = idx & 31;
-                const int64_t kg = kb + r, col = cbase + gq * 4;
-                sv[j] = u32x4{1u, 1u, 1u, 1u};
-                zv[j] = u32x2{0x01000100u, 0x01000100u};
-                if (kg < kgroups && col < N) {
-                    const u32x4* ps = reinterpret_cast<const u32x4*>(a.tr_scale + kg * N + col);
-                    const u32x2* pz = reinterpret_cast<const u32x2*>(a.tr_zp + (kg * N + col) / 4);
-                    for (uint32_t spins = 0;; ++spins) {
-                        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
-                                     : "=&v"(sv[j]), "=&v"(zv[j]) : "v"(ps), "v"(pz) : "memory");
-                        if ((sv[j][0] != 0u && sv[j][1] != 0u && sv[j][2] != 0u && sv[j][3] != 0u && zv[j][0] != 0u && zv[j][1] != 0u) || lab_spin_over(spins)) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    // the zeros go back: the state is what the next call finds
-                    const u32x4 z4 = {0u, 0u, 0u, 0u};
-                    const u32x2 z2 = {0u, 0u};
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1" : : "v"(ps), "v"(z4), "v"(pz), "v"(z2) : "memory");
-                }
-                float* row = (r < 16 ? lds_lo : lds_hi) + (r & 15) * 128;
-                *reinterpret_cast<u32x4*>(row + ((gq + r) & 31) * 4) = sv[j];       // granule index rotated by the row: the transposed reads spread over the banks
-            }
-            __syncthreads();
-            // ---- out: column c (128) x four consecutive k-groups per thread, eight threads = one column's 128 bytes; two per thread
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + 512 * j, kq = idx & 7, c = idx >> 3;
-                const int64_t col = cbase + c, kg0 = kb + kq * 4;
-                if (col < N && kg0 < kgroups) {
-                    float o[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = kq * 4 + i;
-                        o[i] = ((r < 16 ? lds_lo : lds_hi) + (r & 15) * 128)[(((c >> 2) + r) & 31) * 4 + (c & 3)];
-                    }
-                    *reinterpret_cast<float4*>(a.scale + col * kgroups + kg0) = make_float4(o[0], o[1], o[2], o[3]);      // kgroups % 4 == 0 (host)
-                }
-            }
-            __syncthreads();
-            // ---- zero points through the same LDS: one byte per entry, [32 rows][128 columns]
-            uint8_t* zl = reinterpret_cast<uint8_t*>(lds_lo);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + 512 * j, r = idx >> 5, gq = idx & 31;
-                *reinterpret_cast<uint32_t*>(zl + r * 128 + ((gq + r) & 31) * 4) =
-                    (zv[j][0] & 0xffu) | ((zv[j][0] >> 8) & 0xff00u) | ((zv[j][1] & 0xffu) << 16) | ((zv[j][1] << 8) & 0xff000000u);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int idx = tid + 512 * j, kq = idx & 7, c = idx >> 3;
-                const int64_t col = cbase + c, kg0 = kb + kq * 4;
-                if (col < N && kg0 < kgroups) {
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = kq * 4 + i;
-                        w |= static_cast<uint32_t>(zl[r * 128 + (((c >> 2) + r) & 31) * 4 + (c & 3)]) << (8 * i);
-                    }
-                    *reinterpret_cast<uint32_t*>(a.zp + col * kgroups + kg0) = w;
-                }
-            }
-            __syncthreads();
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + NTHREADS * j, r = idx / GQ, gq = idx % GQ;
+            const int64_t kg = kb + r, col = cbase + gq * 4;
+            live[j] = kg < kgroups && col < N;
+            const int64_t o = live[j] ? kg * N + col : (kgroups - 1) * N + cbase;      // a valid address for the lanes outside: loaded, not used
+            ps[j] = reinterpret_cast<const u32x4*>(a.tr_scale + o);
+            pz[j] = reinterpret_cast<const u32x2*>(a.tr_zp + o / 4);
         }
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx2 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx2 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(sv[0]), "=&v"(zv[0]), "=&v"(sv[1]), "=&v"(zv[1]) : "v"(ps[0]), "v"(pz[0]), "v"(ps[1]), "v"(pz[1]) : "memory");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + NTHREADS * j, r = idx / GQ, gq = idx % GQ;
+            if (live[j]) {
+                for (uint32_t spins = 0; !((sv[j][0] != 0u && sv[j][1] != 0u && sv[j][2] != 0u && sv[j][3] != 0u && zv[j][0] != 0u && zv[j][1] != 0u) ||
+                                           lab_spin_over(spins)); ++spins) {      // rare: a granule that was not written yet
+                    __builtin_amdgcn_s_sleep(8);
+                    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx2 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(sv[j]), "=&v"(zv[j]) : "v"(ps[j]), "v"(pz[j]) : "memory");
+                }
+                // the zeros go back: the state is what the next call finds
+                const u32x4 z4 = {0u, 0u, 0u, 0u};
+                const u32x2 z2 = {0u, 0u};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx2 %2, %3, off sc1" : : "v"(ps[j]), "v"(z4), "v"(pz[j]), "v"(z2) : "memory");
+            }
+            const int at = r * COLS + ((gq + r) % GQ) * 4;      // granule index rotated by the row: the transposed reads spread over the banks
+            *reinterpret_cast<u32x4*>(s_f + at) = sv[j];
+            *reinterpret_cast<uint32_t*>(s_z + at) = (zv[j][0] & 0xffu) | ((zv[j][0] >> 8) & 0xff00u) | ((zv[j][1] & 0xffu) << 16) | ((zv[j][1] << 8) & 0xff000000u);
+        }
+        __syncthreads();
+        // ---- out: column c x four consecutive k-groups per thread, eight threads = one column's 128 bytes of scales / 32 of zero points
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + NTHREADS * j, kq = idx & 7, c = idx >> 3;
+            const int64_t col = cbase + c, kg0 = kb + kq * 4;
+            if (col < N && kg0 < kgroups) {
+                float o[4];
+                uint32_t w = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = kq * 4 + i, at = r * COLS + (((c >> 2) + r) % GQ) * 4 + (c & 3);
+                    o[i] = s_f[at];
+                    w |= static_cast<uint32_t>(s_z[at]) << (8 * i);
+                }
+                *reinterpret_cast<float4*>(a.scale + col * kgroups + kg0) = make_float4(o[0], o[1], o[2], o[3]);      // kgroups % 4 == 0 (host)
+                *reinterpret_cast<uint32_t*>(a.zp + col * kgroups + kg0) = w;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -275,8 +269,10 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
     __shared__ float4 s_mx[kMaxWaves][kWave];
 
     if constexpr (TR) {
-        if (blockIdx.x >= a_in.ncol_tiles * a_in.nrow_tiles) {      // uniform: one of the blocks appended to the grid
-            transposer_block(a_in, blockIdx.x - a_in.ncol_tiles * a_in.nrow_tiles, s_mn, s_mx);
+        if (blockIdx.x >= a_in.ncol_tiles * a_in.nrow_tiles) {      // uniform: one of the blocks appended to the grid: 128 columns each
+            __shared__ __attribute__((aligned(16))) float s_tr_f[32 * 128];
+            __shared__ __attribute__((aligned(16))) uint8_t s_tr_z[32 * 128];
+            transposer_block<kMaxWaves * kWave, 128>(a_in, blockIdx.x - a_in.ncol_tiles * a_in.nrow_tiles, s_tr_f, s_tr_z);
             return;
         }
     }
@@ -391,6 +387,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
             // for.  Every word says by itself whether it has been written: a scale is never zero, a zero-point pair carries bits 8 and 24
             if (col_ok[0]) {
                 const int64_t o = kg * a.N + tile_col0 + lane * 4;
+                // (the same as one 16-byte and one 8-byte `sc1` granule per lane costs this instantiation 130+ registers: word stores, 64 lanes x 6
+                // per block, are what tests/test_kernel_resources.py lets through)
                 uint32_t* ps = reinterpret_cast<uint32_t*>(a.tr_scale + o);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) __hip_atomic_store(ps + i, __float_as_uint(cq[i].scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1520,6 +1518,7 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
             a.W = W; a.K = K; a.N = N; a.ldw = ldw; a.g = g; a.kgroups = kgroups;
             a.q = q8; a.scale = scale_out; a.zp = zp8; a.grid = grid; a.layout = layout;
             a.scale_t = nullptr; a.zp_t = nullptr; a.wpg = 1; a.stage_q = 0; a.pair_owner = 0;
+            a.tr_scale = nullptr; a.tr_zp = nullptr;
             const int64_t batch = g_batch.count;
             a.w_stride = g_batch.w_stride; a.q_stride = g_batch.q_stride; a.p_stride = N * kgroups; a.table = g_batch.table;
             const int lpr = static_cast<int>(1024 / g);
@@ -1638,7 +1637,8 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         a.spb_log2 = 0;
         a.xg_log2 = tune.xg >= 0 ? static_cast<uint32_t>(tune.xg > 4 ? 4 : tune.xg) : (sixteen ? 1u : 0u);
         set_block_order(a);
-        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles + (in_launch ? a.ncol_tiles : 0u), static_cast<uint32_t>(batch)), block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
+        const dim3 grid_dim(a.ncol_tiles * a.nrow_tiles + (in_launch ? static_cast<uint32_t>(ceil_div(N, 128)) : 0u), static_cast<uint32_t>(batch)),
+            block(static_cast<uint32_t>(a.wpg * a.gpb * kWave));
         if (in_launch) {      // its appended blocks wait for its main blocks: ordered against every other waiting launch of the device
             st = ticket_chain_begin(s);
             if (st != OQ_OK) return st;
