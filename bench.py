@@ -823,9 +823,14 @@ def main() -> None:
         oq = torch.empty(K_DIM * N_DIM if other == "kn" else K_DIM * N_DIM // 2, dtype=torch.uint8, device=dev)
         oqp = C.c_void_p(oq.data_ptr())
 
+        # [K,N] bytes: the stateful entry point (what ops.rtn_quantize and the seam call): parameters transposed inside the launch (round 6)
+        ostate = torch.zeros(lib.oq_rtn_state_bytes(K_DIM, N_DIM, L.OQ_GROUP, GROUP) + 256, dtype=torch.uint8, device=dev)
+        ostp, ostn = (C.c_void_p(ostate.data_ptr()), ostate.numel()) if other == "kn" else (C.c_void_p(0), 0)
+
         def ostep(i: int) -> None:
             wp, _, sp, zp = calls[i % len(calls)]
-            st = fn(wp, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, oqp, sp, zp, olayout, wsp, wsn, stream)
+            st = lib.oq_rtn_quantize_stateful_f32(wp, K_DIM, N_DIM, N_DIM, L.OQ_UINT4, L.OQ_GROUP, GROUP, sym, 0, 1.0, 0, oqp, sp, zp, olayout, wsp, wsn,
+                                                  ostp, ostn, stream)
             if st != 0:
                 L.check(st)
         for i in range(20):
@@ -838,6 +843,14 @@ def main() -> None:
         o1.record()
         torch.cuda.synchronize()
         other_us = o0.elapsed_time(o1) * 5.0
+        o2, o3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # once more: the first 200 launches of a process run slower
+        o2.record()
+        for i in range(200):
+            ostep(i)
+        o3.record()
+        torch.cuda.synchronize()
+        other_runs = [round(other_us, 2), round(o2.elapsed_time(o3) * 5.0, 2)]
+        other_us = min(other_runs)
         for i in range(len(calls)):          # restore the headline layout's outputs for the digest check below
             step(i)
         torch.cuda.synchronize()
@@ -1122,7 +1135,8 @@ def main() -> None:
         "batched_launch": batched,
         "model_rtn": model_rtn,
         "other_layout": None if other_us is None else {
-            "out_layout": other, "launch_us": round(other_us, 2),
+            "out_layout": other, "launch_us": round(other_us, 2), "launch_us_runs": other_runs,
+            "entry_point": "oq_rtn_quantize_stateful_f32 (zeroed, self-cleaning state: [K,N] parameters transposed inside the launch)",
             "achieved_GBs": round(alg / (other_us * 1e-6) / 1e9, 1), "frac": round(alg / (other_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -1598,11 +1598,13 @@ int32_t rtn_impl(const float* W, int64_t K, int64_t N, int64_t ldw, int32_t qtyp
         // Round 6: with the caller's zeroed state (oq_rtn_quantize_stateful_f32) the staged parameters are transposed inside the
         // launch, by blocks appended to the grid, instead of by a second launch (see transposer_block)
         a.tr_scale = nullptr; a.tr_zp = nullptr;
-        // Measured (scripts/lab_kn_inlaunch.py, same box, staged + launch -> in the launch, us): packed nibbles 4096 x 11008 43.0-44.5 ->
-        // 41.3-42.1, 4096 x 27648 95.2 -> 93.6, 4096 x 32000 108.2 -> 107.7, 4096 x 11000 48.4 -> 47.3; 8192 x 11008 (64 k-groups: two
-        // passes of the transposer) 77.6 -> 78.6; [K,N] BYTES 44.7-45.7 -> 46.2-47.0 (the main blocks write twice as much and the
-        // tail is longer): packed nibbles of up to 32 k-groups only.  Speed only.
-        const bool in_launch = staged && tune_s.stage < 0 && emit_q && layout == OQ_LAYOUT_KN_PACKED4 && kgroups <= 32 &&
+        // Measured (scripts/lab_kn_inlaunch.py, same box, staged + launch -> in the launch, us; the shipped transposer: one block per 128
+        // columns, two granules per thread in flight): packed nibbles 4096 x 11008 44.2-44.3 -> 41.3, 4096 x 11000 48.6 -> 45.3-45.4,
+        // 8192 x 11008 (two passes of 32 k-groups) 74.5-75.1 -> 73.4-74.1, 4096 x 27648 91.2-93.1 -> 91.2-91.6, 4096 x 32000 108.0-108.2 ->
+        // 106.7-107.5; [K,N] bytes int8 4096 x 11008 45.5-45.6 -> 43.2, 8192 x 11008 79.5-79.9 -> 78.8-79.0, 4096 x 27648 98.2-98.6 ->
+        // 97.7-98.3, 4096 x 32000 112.8-113.1 -> 113.7 (the one loss).  More than two passes put their round trips on the tail of the
+        // launch: up to 64 k-groups.  Speed only.
+        const bool in_launch = staged && tune_s.stage < 0 && emit_q && (layout == OQ_LAYOUT_KN_PACKED4 || layout == OQ_LAYOUT_KN) && kgroups <= 64 &&
                                rpw == 16 && wpg == kMaxWaves && batch == 1 && g_batch.table == nullptr &&
                                kgroups % 4 == 0 && N % 4 == 0 && g_state.state != nullptr && g_state.bytes >= fused_state_bytes(K, N, g) &&
                                (reinterpret_cast<uintptr_t>(scale_out) & 15u) == 0 && (reinterpret_cast<uintptr_t>(zp8) & 3u) == 0 &&

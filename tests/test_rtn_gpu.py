@@ -954,11 +954,11 @@ def test_ticketed_strategies_under_graph_capture_take_the_three_launch_path(ops)
 
 
 @pytest.mark.gpu
-def test_packed_nibbles_with_the_parameters_transposed_inside_the_launch():
-    """Round 6: with the caller's zeroed state the packed-nibble group call of up to 32 k-groups stages its parameters in the state
-    (self-validating words) and appended blocks transpose them inside the launch (rtn.hip::transposer_block).  Same bytes as the
-    plain entry point (staged + a transpose launch), the state is zero again after every call, ragged widths and calls in a
-    row on one state buffer included."""
+def test_kn_layouts_with_the_parameters_transposed_inside_the_launch():
+    """Round 6: with the caller's zeroed state the 128-row group call in the [K,N] layouts (bytes and packed nibbles, up to 64
+    k-groups) stages its parameters in the state (self-validating words) and appended blocks transpose them inside the launch
+    (rtn.hip::transposer_block).  Same bytes as the plain entry point (staged + a transpose launch), the state is zero again after
+    every call, ragged widths, two passes of the transposer and calls in a row on one state buffer included."""
     import ctypes as C
 
     import torch
@@ -968,30 +968,35 @@ def test_packed_nibbles_with_the_parameters_transposed_inside_the_launch():
     gen = torch.Generator(device="cuda").manual_seed(606)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     state = torch.zeros(8 << 20, dtype=torch.uint8, device="cuda")
-    for (k, n, qtype) in ((4096, 11008, "int4"), (4096, 11000, "uint4"), (2048, 5376, "int4"), (4096, 2824, "int4"), (512, 6664, "uint4")):
+    cases = [(4096, 11008, "int4", "packed"), (4096, 11000, "uint4", "packed"), (2048, 5376, "int4", "packed"), (4096, 2824, "int4", "packed"),
+             (512, 6664, "uint4", "packed"), (8192, 5376, "int4", "packed"),      # 64 k-groups: two passes of the transposer
+             (4096, 11008, "int8", "kn"), (4096, 5388, "uint4", "kn"), (8192, 5376, "uint8", "kn"), (1024, 11008, "int4", "kn")]
+    for (k, n, qtype, lay) in cases:
         g = 128
         groups = n * (k // g)
         scode = L.STRATEGY_CODE["group"]
+        layout = L.OQ_LAYOUT_KN_PACKED4 if lay == "packed" else L.OQ_LAYOUT_KN
         assert 0 < lib.oq_rtn_state_bytes(k, n, scode, g) <= state.numel()
         ws = torch.empty(lib.oq_rtn_workspace_bytes(k, n, scode, g, 0) + 256, dtype=torch.uint8, device="cuda")
-        want = None
         for rep in range(3):
             w = torch.randn((k, n), generator=gen, device="cuda") * (0.1 + rep)
             got = []
             for use_state in (False, True):
-                q = torch.full((k * n // 2,), 0x5a, dtype=torch.uint8, device="cuda")
+                q = torch.full((k * n // 2 if lay == "packed" else k * n,), 0x5a, dtype=torch.uint8, device="cuda")
                 sc = torch.full((groups,), -1.0, dtype=torch.float32, device="cuda")
                 zp = torch.full((groups,), 0x33, dtype=torch.uint8, device="cuda")
                 st = lib.oq_rtn_quantize_stateful_f32(C.c_void_p(w.data_ptr()), k, n, n, L.QTYPE_CODE[qtype], scode, g, 0, 0, 1.0, 0,
-                                                      C.c_void_p(q.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(zp.data_ptr()), L.OQ_LAYOUT_KN_PACKED4,
+                                                      C.c_void_p(q.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(zp.data_ptr()), layout,
                                                       C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(state.data_ptr() if use_state else 0),
                                                       state.numel() if use_state else 0, stream)
                 assert st == 0, lib.oq_last_error()
                 got.append((q, sc, zp))
             torch.cuda.synchronize()
             assert int(state.count_nonzero()) == 0, (k, n, rep)
-            assert all(torch.equal(a, b) for a, b in zip(*got)), (k, n, qtype, rep)
+            assert all(torch.equal(a, b) for a, b in zip(*got)), (k, n, qtype, lay, rep)
             if rep == 0:      # and the values are the oracle's
                 eq, es, ez = O.rtn_quantize(w.cpu().numpy(), qtype, "group", g)
                 assert es.reshape(-1).tobytes() == got[1][1].cpu().numpy().tobytes()
                 np.testing.assert_array_equal(got[1][2].cpu().numpy().view(ez.dtype).reshape(-1), ez.reshape(-1))
+                if lay == "kn":
+                    np.testing.assert_array_equal(got[1][0].cpu().numpy().view(eq.dtype).reshape(eq.shape), eq)
