@@ -111,11 +111,11 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
  *     launch runs.  One state buffer serves any sequence of calls of any shapes (each call needs its own size) on ONE stream; two
  *     calls that may run concurrently need two buffers.  state == NULL or too small: exactly oq_rtn_quantize_f32.  A call
  *     that fails on the device leaves the state undefined.
- *     Round 6: the fused group kernel uses the state too -- layout OQ_LAYOUT_KN_PACKED4, 128-row groups, at most 32 k-groups: the
- *     n-major parameters are staged in it as self-validating words and transposed INSIDE the launch by blocks appended to the grid
- *     (no second launch: 43-44 -> 41-42 us on 4096 x 11008); oq_rtn_state_bytes says how much it needs for a shape (0: the call
- *     keeps no state).  Those appended blocks wait for the main blocks of their own launch, so such calls are ordered like the
- *     ticketed ones (below).
+ *     Round 6: the fused group kernel uses the state too -- layouts OQ_LAYOUT_KN and OQ_LAYOUT_KN_PACKED4, 128-row groups, at most 64
+ *     k-groups: the n-major parameters are staged in it as self-validating words and transposed INSIDE the launch by blocks appended to
+ *     the grid (no second launch: 4096 x 11008 bytes 45.0 -> 43.1 us, packed nibbles 43.3-44.3 -> 40.9-41.2); oq_rtn_state_bytes says
+ *     how much it needs for a shape (0: the call keeps no state).  Those appended blocks wait for the main blocks of their own launch,
+ *     so such calls are ordered like the ticketed ones (below).
  *     Concurrency of the ticketed kernels (both entry points): inside a call a workgroup may wait for other workgroups of the
  *     SAME launch, which is safe on its own (see rtn_resident.hip); two such launches running at the same time on one device
  *     would compete for the CUs their waiting workgroups hold and could stop each other for good.  The library therefore
