@@ -59,9 +59,15 @@ def main():
         wsp, wsn = C.c_void_p(wsbuf.data_ptr()), wsbuf.numel()
         qt = L.QTYPE_CODE[args.qtype]
 
+        # the stateful entry point with a zeroed, self-cleaning state: what ops.rtn_quantize calls ([K,N] layouts: parameters transposed
+        # inside the launch since round 6); OQ_LAB_NO_STATE=1: the plain entry point (staged parameters + a transpose launch)
+        nstate = 0 if os.environ.get("OQ_LAB_NO_STATE") == "1" else lib.oq_rtn_state_bytes(k, n, L.OQ_GROUP, args.g)
+        state = torch.zeros(nstate + 256, dtype=torch.uint8, device="cuda")
+        stp, stn = (C.c_void_p(state.data_ptr()), state.numel()) if nstate else (C.c_void_p(0), 0)
+
         def step(i):
             qp, sp, zp = optr[i % 4]
-            st = lib.oq_rtn_quantize_f32(calls[i % rot][0], k, n, n, qt, L.OQ_GROUP, args.g, 0, 0, 1.0, 0, qp, sp, zp, layout, wsp, wsn, stream)
+            st = lib.oq_rtn_quantize_stateful_f32(calls[i % rot][0], k, n, n, qt, L.OQ_GROUP, args.g, 0, 0, 1.0, 0, qp, sp, zp, layout, wsp, wsn, stp, stn, stream)
             if st != 0:
                 L.check(st)
         step(0)
