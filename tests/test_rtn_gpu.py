@@ -1000,3 +1000,39 @@ def test_kn_layouts_with_the_parameters_transposed_inside_the_launch():
                 np.testing.assert_array_equal(got[1][2].cpu().numpy().view(ez.dtype).reshape(-1), ez.reshape(-1))
                 if lay == "kn":
                     np.testing.assert_array_equal(got[1][0].cpu().numpy().view(eq.dtype).reshape(eq.shape), eq)
+
+
+@pytest.mark.gpu
+def test_in_launch_transposition_random_shapes_against_the_oracle(ops):
+    """The shapes the property test above never reaches (its groups are at most six per column and its matrices too small for staged
+    parameters): 128-row groups x {4 ... 64} k-groups x wide and ragged widths through `ops.rtn_quantize` (stateful entry point: the
+    parameters are transposed inside the launch when the rule takes the shape, by a second launch otherwise) against the oracle --
+    integers, scales and zero points bit for bit; symmetric / reduce_range / clip_ratio drawn as well."""
+    import torch
+    rng = np.random.default_rng(20251005)
+    for _ in range(14):
+        kgroups = int(rng.choice([4, 8, 12, 16, 28, 32, 36, 64]))
+        n = int(rng.choice([2820, 4100, 5376, 6664, 8196, 11000, 11008, 2304]))
+        qtype = str(rng.choice(["int4", "uint4", "int8", "uint8"]))
+        layout = "kn_packed4" if (qtype in ("int4", "uint4") and n % 2 == 0 and rng.random() < 0.6) else "kn"
+        sym, red, clip = bool(rng.random() < 0.3), bool(rng.random() < 0.2), float(rng.choice([1.0, 0.9]))
+        k = 128 * kgroups
+        w = rng.standard_normal((k, n), dtype=np.float32) * np.float32(10.0) ** rng.integers(-3, 4, size=(1, n)).astype(np.float32)
+        w[:, ::7] = 0                                                      # whole zero groups: the tiny-scale guard (scale 1: never a zero word)
+        eq, es, ez = O.rtn_quantize(w, qtype, "group", 128, sym, red, clip)
+        wd = torch.from_numpy(w).cuda()
+        for rep in range(2):                                               # twice on the same state
+            q, s, z = ops.rtn_quantize(wd, qtype, "group", 128, sym, red, clip, layout=layout)
+            case = (kgroups, n, qtype, layout, sym, red, clip, rep)
+            assert s.cpu().numpy().reshape(np.shape(es)).tobytes() == np.asarray(es, np.float32).tobytes(), case
+            np.testing.assert_array_equal(z.cpu().numpy().reshape(np.shape(ez)), ez, err_msg=str(case))
+            if layout == "kn":
+                np.testing.assert_array_equal(q.cpu().numpy(), eq, err_msg=str(case))
+            else:
+                b = q.cpu().numpy().reshape(k, n // 2)
+                lo, hi = (b & 0x0F).astype(np.int8), (b >> 4).astype(np.int8)
+                if qtype == "int4":
+                    lo, hi = ((lo ^ 8) - 8).astype(np.int8), ((hi ^ 8) - 8).astype(np.int8)
+                full = np.empty((k, n), np.int8)
+                full[:, 0::2], full[:, 1::2] = lo, hi
+                np.testing.assert_array_equal(full.astype(np.int32), eq.astype(np.int32), err_msg=str(case))
