@@ -891,11 +891,16 @@ def test_ticketed_calls_from_threads_on_their_own_streams(ops):
     import threading
     import torch
     rng = np.random.default_rng(99)
-    cases = [((4096, 2048), "int8", "tensor"), ((4096, 1024), "uint8", "channel"), ((8192, 512), "int8", "channel"), ((2048, 4096), "uint8", "tensor")]
+    cases = [((4096, 2048), "int8", "tensor"), ((4096, 1024), "uint8", "channel"), ((8192, 512), "int8", "channel"), ((2048, 4096), "uint8", "tensor"),
+             ((4096, 8200), "int4", "group128")]      # round 6: [K,N] group call whose appended blocks wait for its main blocks (in-launch transposition)
+
+    def call(w, qtype, strategy):
+        return ops.rtn_quantize(w, qtype, "group", 128, layout="kn_packed4") if strategy == "group128" else ops.rtn_quantize(w, qtype, strategy, -1)
+
     ws = [dev(rng.standard_normal(shape, dtype=np.float32)) for shape, _, _ in cases]
     want = []
     for w, (_, qtype, strategy) in zip(ws, cases):
-        q, s_, z = ops.rtn_quantize(w, qtype, strategy, -1)
+        q, s_, z = call(w, qtype, strategy)
         want.append((q.cpu().numpy().copy(), s_.cpu().numpy().copy(), z.cpu().numpy().copy()))
     torch.cuda.synchronize()
     errors = []
@@ -907,7 +912,7 @@ def test_ticketed_calls_from_threads_on_their_own_streams(ops):
                 for it in range(9):
                     for j in range(len(cases)):
                         i = (j + tid) % len(cases)
-                        q, s_, z = ops.rtn_quantize(ws[i], cases[i][1], cases[i][2], -1)
+                        q, s_, z = call(ws[i], cases[i][1], cases[i][2])
                         if it % 3 == 2:        # a host round trip every third lap only: the other laps keep the streams full
                             stream.synchronize()
                             if not (np.array_equal(q.cpu().numpy(), want[i][0]) and s_.cpu().numpy().tobytes() == want[i][1].tobytes()
