@@ -387,14 +387,17 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
             // for.  Every word says by itself whether it has been written: a scale is never zero, a zero-point pair carries bits 8 and 24
             if (col_ok[0]) {
                 const int64_t o = kg * a.N + tile_col0 + lane * 4;
-                // (the same as one 16-byte and one 8-byte `sc1` granule per lane costs this instantiation 130+ registers: word stores, 64 lanes x 6
-                // per block, are what tests/test_kernel_resources.py lets through)
-                uint32_t* ps = reinterpret_cast<uint32_t*>(a.tr_scale + o);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) __hip_atomic_store(ps + i, __float_as_uint(cq[i].scale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                uint32_t* pz = reinterpret_cast<uint32_t*>(a.tr_zp + o / 4);
-                __hip_atomic_store(pz, 0x01000100u | (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pz + 1, 0x01000100u | (static_cast<uint32_t>(cq[2].zp) & 0xffu) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (one 16-byte and one 8-byte `sc1` granule per lane as inline assembly costs this instantiation 130+ registers; six word stores per
+                // lane are twice the fabric writes: [K,N] bytes 43.05 us against 42.5 with three 8-byte stores)
+                uint64_t* ps = reinterpret_cast<uint64_t*>(a.tr_scale + o);      // 8-byte agent-scope stores: half as many fabric writes as words
+                __hip_atomic_store(ps, static_cast<uint64_t>(__float_as_uint(cq[0].scale)) | (static_cast<uint64_t>(__float_as_uint(cq[1].scale)) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ps + 1, static_cast<uint64_t>(__float_as_uint(cq[2].scale)) | (static_cast<uint64_t>(__float_as_uint(cq[3].scale)) << 32),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t z01 = 0x01000100u | (static_cast<uint32_t>(cq[0].zp) & 0xffu) | ((static_cast<uint32_t>(cq[1].zp) & 0xffu) << 16);
+                const uint32_t z23 = 0x01000100u | (static_cast<uint32_t>(cq[2].zp) & 0xffu) | ((static_cast<uint32_t>(cq[3].zp) & 0xffu) << 16);
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(a.tr_zp + o / 4), static_cast<uint64_t>(z01) | (static_cast<uint64_t>(z23) << 32), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (VEC4 && a.scale_t != nullptr) {
             // staged [kg, n]: 16 B + 4 B per lane, fully coalesced (the n-major scatter of 4-byte pieces at a
