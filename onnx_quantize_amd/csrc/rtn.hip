@@ -81,6 +81,19 @@ struct RtnArgs {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// The [K,N] results leave as WRITE-THROUGH stores (`sc1`, agent scope).  A default-policy or `nt` store leaves its line dirty in the
+// XCD's L2, and what is dirty when the kernel ends is written back before the next launch of the stream starts: 45 MB stored by a
+// kernel cost 3.3-3.9 us between its last workgroup's end and the next kernel's first start against 1.2-1.4 us for the same bytes
+// written through, whenever in the kernel they were stored (scripts/lab_launch_gap.hip).  Beside the W stream a part of that
+// comes back as slower stores; what stays (same box, alternating, 4096 x 11008): bytes 42.1-42.4 -> 41.5-41.7 us, packed nibbles
+// 40.1-40.3 -> 39.25, 11008 x 4096 45.0 -> 44.5 and 43.7 -> 43.05.  Every store instruction there writes whole 128-byte lines.  The
+// MatMulNBits blob does NOT: its 16-byte pieces meet their neighbours (other k-groups: other waves) in the L2, written through they
+// are a fabric write each (38.3-38.4 -> 38.5-38.7 us): bit 0 stays off.  OQ_RTN_SC1 (lab builds): bit 0 the 4-bit blob of the
+// wave kernel, bit 1 the [K,N] bytes, bit 2 the packed [K,N/2] dwords.
+#ifndef OQ_RTN_SC1
+#define OQ_RTN_SC1 6
+#endif
+__device__ __forceinline__ void store_sc1(uint32_t w, uint32_t* p) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(w) : "memory"); }
 
 constexpr int kDefaultWps = 5;     // wave kernel build used when OQ_RTN_WPS is unset (see Tuning)
 constexpr int kColsPerWave = 256;  // 64 lanes x 4 columns: 1 KiB of one fp32 row per wave-instruction
@@ -454,7 +467,8 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                     w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][1], 1, w);
                     w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][2], 2, w);
                     w = __builtin_amdgcn_cvt_pk_u8_f32(v[r][3], 3, w);
-                    if constexpr (NT) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
+                    if constexpr ((OQ_RTN_SC1 & 2) != 0) store_sc1(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
+                    else if constexpr (NT) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
                     else *reinterpret_cast<uint32_t*>(o + r * a.N) = w ^ flip;
                 }
             }
@@ -496,7 +510,10 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
                     const uint32_t theirs = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mine), 0xb1 /* quad_perm:[1,0,3,2] */, 0xf, 0xf, false));
                     const uint32_t out = odd ? ((theirs >> 16) | (mine & 0xffff0000u)) : ((mine & 0xffffu) | (theirs << 16));
                     uint8_t* dst = a.q + ((row0 + j + (odd ? 8 : 0)) * a.N + tile_col0 + (lane & ~1) * 4) / 2;
-                    if (pair_ok) *reinterpret_cast<uint32_t*>(dst) = out;
+                    if (pair_ok) {
+                        if constexpr ((OQ_RTN_SC1 & 4) != 0) store_sc1(out, reinterpret_cast<uint32_t*>(dst));
+                        else *reinterpret_cast<uint32_t*>(dst) = out;
+                    }
                 }
                 break;
             }
@@ -847,7 +864,8 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
                 const u32x4 val = odd ? u32x4{r0, r1, m0, m1} : u32x4{m0, m1, r0, r1};
                 const idx_t col = c0 + (odd ? 2 + t : t);
                 u32x4* o = reinterpret_cast<u32x4*>(a.q + ((col * kgroups_i + kg_i) * (G / 2) + (h & ~1) * 8));
-                if (a.nt & 2) __builtin_nontemporal_store(val, o);
+                if constexpr ((OQ_RTN_SC1 & 1) != 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(o), "v"(val) : "memory");
+                else if (a.nt & 2) __builtin_nontemporal_store(val, o);
                 else *o = val;
             }
         } else if (a.grid.bits == 4) {

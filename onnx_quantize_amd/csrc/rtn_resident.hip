@@ -25,13 +25,13 @@
 // into one slot before the workgroup waits for the range of the tile in the other one, and that tile's rows are stored
 // while the next tile's rows are loaded into their place.
 // `rtn_tensor_onepass`: per-tensor.  ONE 8-wave workgroup per CU.  Phase A streams all tiles once (running min / max in
-// registers, no barrier per tile beyond the ticket exchange); a workgroup KEEPS the last two tiles it loaded in registers
-// (two slots written alternately, 128 of its <= 256 registers per lane) and the one before in 128 KB of LDS: 96 MB of the
-// matrix stay on the chip.  One returning add per workgroup counts the tiles and hands out an arrival slot for its partial
-// range and the ids of the tiles it keeps; the workgroup that completes the count folds the slots and broadcasts {go, keys};
-// kept tiles are quantized from registers / LDS; the rows of the other half tiles are dealt out statically and evenly over
-// all waves (no tickets, no barriers), re-read most-recent-first (the Infinity Cache still holds them) and software-pipelined
-// over the two register slots.  A matrix of up to 768 tiles is read exactly once and skips that phase altogether.
+// registers, no barrier per tile beyond the ticket exchange) through one register slot; a workgroup KEEPS the last FOUR tiles
+// it loaded -- the slot, two tiles parked in its ACCUMULATION registers, one in 128 KB of LDS: 128 MB of the matrix stay on
+// the chip.  One returning add per workgroup counts the tiles and hands out an arrival slot for its partial range and the ids
+// of the tiles it keeps; the workgroup that completes the count folds the slots and broadcasts {go, keys}; kept tiles are
+// quantized from registers / LDS; the rows of the other half tiles are dealt out statically and evenly over all waves (no
+// tickets, no barriers), re-read most-recent-first and software-pipelined over the two halves of the slot.  A matrix of up
+// to 1024 tiles is read exactly once and skips that phase altogether.
 #include "oq_common.hpp"
 
 #include <cstdlib>
@@ -47,7 +47,7 @@ constexpr int kResRows = 16;                      // rows per wave
 constexpr int kResTileRows = kResWaves * kResRows;  // 128, the chunk height of the two-pass path (rtn.hip kChunkRows)
 constexpr int kResCols = 256;                     // 64 lanes x 4 columns
 constexpr int kResHeader = 160;
-constexpr int kResMaxTensorTiles = 32768;         // bitmap of kept half tiles + its prefix sums in LDS (8 KB each): 1 G parameters; larger tensors take the three-launch path
+constexpr int kResMaxTensorTiles = 32768;         // bitmap of kept half tiles + its prefix sums in LDS (8 KB each): sized for this many tiles (the kernel takes up to kT4MaxTiles: 1 G parameters; larger tensors take the three-launch path)
 constexpr int kResTensorHeader = 128 + 64 * 32 + 64 * 32;   // tickets / counter, 512 arrival slots of 16 bytes, 64 result replicas (a 128-byte line each)
 constexpr int kResGroupTileRows = 128;            // tile height of rtn_resident_stream and of rtn_resident_groups<8> (see groups_tile_rows)
 constexpr int kResCtrPad = 32;                   // uint32 words per range counter: a 128-byte line each (hundreds of workgroups poll them)
@@ -152,8 +152,34 @@ __device__ __forceinline__ void load_tile(const ResidentArgs& a, int64_t row0, i
     }
 }
 
+// One dword of quantized bytes to HBM.  OQ_RES_STORE (lab): 0 = `nt` (streaming, but write-BACK: the lines stay dirty in the XCD's L2
+// until they are evicted or the kernel ends), 1 = default policy, 2 = `sc1` (agent scope: written through), 3 = `sc0 sc1`, 4 = `sc1 nt`,
+// 5 = `sc0 sc1 nt`.
+#ifndef OQ_RES_STORE
+#define OQ_RES_STORE 0
+#endif
+__device__ __forceinline__ void store_q_word(uint32_t w, uint32_t* p) {
+#if OQ_RES_STORE == 0
+    __builtin_nontemporal_store(w, p);
+#elif OQ_RES_STORE == 1
+    *p = w;
+#elif OQ_RES_STORE == 2
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+#elif OQ_RES_STORE == 3
+    asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(w) : "memory");
+#elif OQ_RES_STORE == 4
+    asm volatile("global_store_dword %0, %1, off sc1 nt" : : "v"(p), "v"(w) : "memory");
+#else
+    asm volatile("global_store_dword %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(w) : "memory");
+#endif
+}
+
 // K1 from registers + [K, N] byte stores (one dword = a lane's four columns of a row).
-template <int ROWS = kResRows>
+// GROUP > 1 (the kernels that run one or two waves per SIMD and so have nobody to fill the bubbles): the fast path of GROUP rows
+// as independent chains with ONE decision behind them -- the margin thr - |t - k| of every element folded into a running
+// NaN-propagating minimum on the vector ALU, instead of a compare + scalar OR per element and a ballot + branch per row (the
+// same decision: a < b exactly when b - a > 0, and a NaN fails both).
+template <int ROWS = kResRows, int GROUP = 1>
 __device__ __forceinline__ void quantize_store_tile(const ResidentArgs& a, const ColQ (&cq)[4], float (&v)[ROWS][4], int64_t row0,
                                                     int64_t row_end, int64_t tile_col0, int lane) {
     const int32_t qmin = a.grid.qmin, qmax = a.grid.qmax;
@@ -162,21 +188,53 @@ __device__ __forceinline__ void quantize_store_tile(const ResidentArgs& a, const
     const uint32_t flip = bias ? 0x80808080u : 0u;
     const bool col_ok = tile_col0 + lane * 4 < a.N;
     uint8_t* o = a.q + row0 * a.N + tile_col0 + lane * 4;
+    if constexpr (GROUP == 1) {
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        float f[4];
-        bool unsafe = false;
+        for (int r = 0; r < ROWS; ++r) {
+            float f[4];
+            bool unsafe = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(v[r][i], cq[i], lo_b, hi_b, unsafe);
-        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {   // wave-uniform, rare: redo this row with the IEEE divide
+            for (int i = 0; i < 4; ++i) f[i] = quantize_fast_biased(v[r][i], cq[i], lo_b, hi_b, unsafe);
+            if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {   // wave-uniform, rare: redo this row with the IEEE divide
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(v[r][i], cq[i], qmin, qmax, bias);
+                for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(v[r][i], cq[i], qmin, qmax, bias);
+            }
+            uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
+            w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
+            if (col_ok && row0 + r < row_end) store_q_word(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
         }
-        uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[0], 0, 0);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(f[1], 1, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(f[2], 2, w);
-        w = __builtin_amdgcn_cvt_pk_u8_f32(f[3], 3, w);
-        if (col_ok && row0 + r < row_end) __builtin_nontemporal_store(w ^ flip, reinterpret_cast<uint32_t*>(o + r * a.N));
+    } else {
+        static_assert(ROWS % GROUP == 0, "whole groups");
+#pragma unroll
+        for (int rg = 0; rg < ROWS; rg += GROUP) {
+            float f[GROUP][4];
+            float margin = INFINITY;
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = v[rg + r][i] * cq[i].rinv;
+                    const float k = rintf(t);
+                    margin = nmin(margin, cq[i].thr - fabsf(t - k));
+                    f[r][i] = __builtin_amdgcn_fmed3f(k + cq[i].zpb, lo_b, hi_b);
+                }
+            if (__builtin_amdgcn_ballot_w64(!(margin > 0.0f)) != 0) {   // wave-uniform, rare: redo these rows with the IEEE divide
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[r][i] = quantize_exact_biased(v[rg + r][i], cq[i], qmin, qmax, bias);
+            }
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r) {
+                uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(f[r][0], 0, 0);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(f[r][1], 1, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(f[r][2], 2, w);
+                w = __builtin_amdgcn_cvt_pk_u8_f32(f[r][3], 3, w);
+                if (col_ok && row0 + rg + r < row_end) store_q_word(w ^ flip, reinterpret_cast<uint32_t*>(o + (rg + r) * a.N));
+            }
+        }
     }
 }
 
@@ -578,96 +636,154 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_resident_stream(const
 // resident workgroups is; a workgroup that starts late finds no ticket, adds nothing and waits like the others.  Phase B
 // never waits either.
 // ---------------------------------------------------------------------------------------------
-constexpr int kHalfRows = kResTileRows / 2;                      // phase-B unit: half a tile, 64 rows x 256 columns (a team of four waves)
+// ---------------------------------------------------------------------------------------------
+// rtn_tensor_onepass: per-tensor, W read once where the chip can hold it and 1.26 times on 4096 x 11008.
+//
+// ONE 8-wave workgroup per CU (two waves per SIMD: 256 registers per lane each, which a kernel that names accumulation registers
+// gets as 128 architectural + 128 accumulation registers).  A tile is 128 x 256 = 16 rows per wave = 64 registers per lane.
+// Phase A streams all tiles once (tickets; running min / max in registers) through ONE register slot V; in front of every load
+// but the first the tile in V moves to a PARK, the three parks in turn: two in the ACCUMULATION REGISTERS (v_accvgpr_write_b32 /
+// v_accvgpr_read_b32: one VALU instruction per dword, no LDS, no memory -- the matrix cores these registers exist for are idle
+// here) and one in 128 KB of LDS.  So V and the parks hold the last FOUR tiles a workgroup loaded: 512 KB per CU, 128 MB of the
+// matrix stay on the chip across the hand-off; a matrix of up to 1024 tiles is read exactly once, 4096 x 11008 re-reads 46 MB.
+// (Rounds 4-6 kept THREE tiles -- two register slots written alternately + LDS -- and re-read 80 MB: 73.5 us against 65 on
+// 4096 x 11008, 100 against 96 on 8192 x 8192, same box; a third REGISTER slot was tried in round 4 and spilled to scratch in
+// every formulation, a fourth tile in the XCD's L2 in round 6: docs/LAB_NOTES_r06.md.)
+// One returning add per workgroup counts the tiles and hands out an arrival slot for its partial range and the ids of the tiles
+// it keeps; the workgroup that completes the count folds the slots and broadcasts {go, keys}; kept tiles are quantized from
+// registers / LDS; the rows of the other half tiles are dealt out statically and evenly over all waves (no tickets, no
+// barriers), re-read most-recent-first and software-pipelined over the two halves of V.
+//
+// The same with ONE wave per SIMD (4-wave workgroups, 32 rows per wave, 256 + 256 registers) streams phase A just as fast but
+// needs 6.8 us instead of 2.3 to quantize and store a tile -- a single wave per SIMD has nobody to fill its bubbles --: 80.4-87.5 us.
+// The template parameter is kept for that measurement; only <8> is instantiated.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHalfRows = kResTileRows / 2;                      // phase-B unit: half a tile, 64 rows x 256 columns
 constexpr int kParkBytes = kResWaves * kResRows * kWave * 16;    // one tile: 128 KB
-
-
 constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+#ifndef OQ_T4_GROUP
+#define OQ_T4_GROUP 4   /* rows per decision of the quantize + store code (quantize_store_tile) */
+#endif
+constexpr uint32_t kT4MaxTiles = 32766;               // the fourth kept tile travels as tile + 1 in 15 bits of its arrival slot
 
-// tile -> first row of this wave's 16 rows, first column
-__device__ __forceinline__ void tile_origin(uint32_t tile, uint32_t ncol, int wave, int64_t& row0, int64_t& col0) {
+// The parks are PHYSICAL accumulation registers named in the assembly text: a[0..127] and a[128..255].  (As operands of the `a`
+// register class they went through the register allocator, which copied them at every join of the control flow: 738
+// v_accvgpr_mov and 1.2 KB of scratch per lane.)  The compiler allocates no accumulation register of its own in this kernel --
+// it would only ever use them to spill architectural ones, and the kernel stays below 256 of those
+// (tests/test_kernel_resources.py counts the v_accvgpr instructions of the code object: exactly the ones written here) --;
+// the clobber statement at the top of the kernel makes the kernel descriptor reserve all 256.
+template <int BASE, int H, int HR>
+__device__ __forceinline__ void acc_put_half(const float (&v)[HR][4]) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+        asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v[r][0]), "n"(BASE + (H * HR + r) * 4 + 0));
+        asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v[r][1]), "n"(BASE + (H * HR + r) * 4 + 1));
+        asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v[r][2]), "n"(BASE + (H * HR + r) * 4 + 2));
+        asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(v[r][3]), "n"(BASE + (H * HR + r) * 4 + 3));
+    }
+}
+template <int BASE, int H, int HR>
+__device__ __forceinline__ void acc_get_half(float (&v)[HR][4]) {
+#pragma unroll
+    for (int r = 0; r < HR; ++r) {
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v[r][0]) : "n"(BASE + (H * HR + r) * 4 + 0));
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v[r][1]) : "n"(BASE + (H * HR + r) * 4 + 1));
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v[r][2]) : "n"(BASE + (H * HR + r) * 4 + 2));
+        asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(v[r][3]) : "n"(BASE + (H * HR + r) * 4 + 3));
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void tile4_origin(uint32_t tile, uint32_t ncol, int wave, int64_t& row0, int64_t& col0) {
     const uint32_t row_tile = tile / ncol, col_tile = tile - row_tile * ncol;
-    row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * kResRows;
+    row0 = static_cast<int64_t>(row_tile) * kResTileRows + wave * ROWS;
     col0 = static_cast<int64_t>(col_tile) * kResCols;
 }
 
-// One phase-A step into a register slot: the tile the slot held goes to the LDS park buffer (overwriting the tile parked
-// before, which will be read a second time in phase B), the new tile is loaded and folded.
-__device__ __forceinline__ void tensor_step(const ResidentArgs& a, uint32_t tile, uint32_t ncol, int lane, int wave, float4* park,
-                                            float (&v)[kResRows][4], uint32_t& held, uint32_t& parked, float& rmn, float& rmx) {
-    if (held != kNoTile) {   // uniform
-#pragma unroll
-        for (int r = 0; r < kResRows; ++r) park[r * kWave] = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
-        parked = held;
-    }
-    held = tile;
-    int64_t row0, col0;
-    tile_origin(tile, ncol, wave, row0, col0);
-    load_tile<OQ_RES_A_NT>(a, row0 < a.K ? row0 : a.K - 1, a.K, col0, lane, v);
-#pragma unroll
-    for (int r = 0; r < kResRows; ++r)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            rmn = nmin(rmn, v[r][i]);
-            rmx = nmax(rmx, v[r][i]);
-        }
-}
-
-// One workgroup per CU (8 waves, up to 256 registers per lane): TWO tiles in registers + ONE in 128 KB of LDS.
-__global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const ResidentArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char park_lds[];   // kParkBytes: [wave 8][row 16][lane 64] x 16 B
-    __shared__ float s_mn[kResWaves], s_mx[kResWaves];
-    __shared__ uint32_t s_ticket, s_keys[3];
+template <int WAVES>
+__global__ __launch_bounds__(WAVES* kWave, WAVES / 4) void rtn_tensor_onepass(const ResidentArgs a) {
+    constexpr int ROWS = kResTileRows / WAVES;        // rows per wave: 32 (one wave per SIMD) or 16 (two)
+    constexpr int HR = ROWS / 2;                      // V is two halves
+    constexpr int THREADS = WAVES * kWave;
+    constexpr int A0 = 0, A1 = ROWS * 4;              // first accumulation register of the two parks
+    constexpr int GROUP = OQ_T4_GROUP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char park_lds[];   // kParkBytes: [wave][row of the wave][lane 64] x 16 B
+    __shared__ float s_mn[WAVES], s_mx[WAVES];
+    __shared__ uint32_t s_ticket, s_keys[3], s_wsum[WAVES];
     __shared__ uint32_t s_held[kResMaxTensorTiles / 16];          // two bits per tile: its halves
     __shared__ uint32_t s_pref[kResMaxTensorTiles / 16], s_total;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: row bases are scalar
     const uint32_t ntiles = a.ntiles, ncol = a.ncol_tiles, nunits = 2u * ntiles;
-    float4* park = reinterpret_cast<float4*>(park_lds) + (wave * kResRows) * kWave + lane;   // this lane's slot of row 0
+    float4* park = reinterpret_cast<float4*>(park_lds) + (wave * ROWS) * kWave + lane;   // this lane's slot of row 0
 
-    float v0[kResRows][4], v1[kResRows][4];          // the two register slots
+    float v[2][HR][4];                          // V: two halves of 16 rows
+    if constexpr (WAVES == 4) asm volatile("" : : : "a0", "a255");   // the descriptor reserves the two parks (see acc_put_half): a[0..255]
+    else asm volatile("" : : : "a0", "a127");                        // a[0..127]
     float rmn = INFINITY, rmx = -INFINITY;
-    uint32_t processed = 0, parked = kNoTile, held0 = kNoTile, held1 = kNoTile;
-    bool first = false;
+    uint32_t processed = 0, idV = kNoTile, idA0 = kNoTile, idA1 = kNoTile, idL = kNoTile;
+#ifdef OQ_TENSOR_STAMPS
+    if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + 7] = g_tensor_stamps[blockIdx.x * 8 + 5];   // the end of the previous call
+#endif
     OQ_STAMP(0);
     if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
     __syncthreads();
     uint32_t t = s_ticket;
     __syncthreads();
-    first = t == 0;
-    // Tile index = ticket (column tiles fastest: co-resident workgroups stream whole rows).  The slots are written
-    // alternately, so the registers hold the last TWO tiles a workgroup loaded and the LDS park buffer the one before:
-    // 3 tiles = 384 KB per CU, 96 MB of the matrix stay on the chip across the hand-off.  (Two 8-wave workgroups per CU
-    // with 1.5 tiles each hold the same, but streamed slower: phase A ended at 39 us instead of 32 on 4096 x 11008, with
-    // half-tile tickets at 46.)
-    while (t < ntiles) {
-        {
-            if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);   // the next ticket travels while this tile loads
-            tensor_step(a, t, ncol, lane, wave, park, v0, held0, parked, rmn, rmx);
-            ++processed;
-            __syncthreads();
-            const uint32_t nxt = s_ticket;
-            __syncthreads();
-            t = nxt;
-            if (t >= ntiles) break;   // uniform
+    const bool first = t == 0;
+
+    // one phase-A step: the next ticket travels, tile `t` is loaded into V and folded
+    auto load_fold = [&]() {
+        __builtin_amdgcn_sched_barrier(0);            // no load of this tile in front of the park of the previous one: it would take a second set of 128 registers
+        if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
+        idV = t;
+        int64_t row0, col0;
+        tile4_origin<ROWS>(t, ncol, wave, row0, col0);
+        const int64_t r_hi = row0 + HR;
+        load_tile<OQ_RES_A_NT, HR>(a, row0 < a.K ? row0 : a.K - 1, a.K, col0, lane, v[0]);
+        load_tile<OQ_RES_A_NT, HR>(a, r_hi < a.K ? r_hi : a.K - 1, a.K, col0, lane, v[1]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < HR; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    rmn = nmin(rmn, v[h][r][i]);
+                    rmx = nmax(rmx, v[h][r][i]);
+                }
+        ++processed;
+        __syncthreads();
+        const uint32_t nxt = s_ticket;
+        __syncthreads();
+        t = nxt;
+    };
+    // The tile in V moves to a park in front of every load but the first, the parks in turn: V and the three parks hold the
+    // last FOUR tiles a workgroup loaded.  ONE loop body, so that V is loaded at one place of the code (three unrolled copies
+    // met at the loop's exits with V in three different register assignments: the joins were made through scratch); the parks
+    // are chosen by a uniform branch and define nothing the compiler sees.
+    for (uint32_t turn = 0; t < ntiles; ++turn) {
+        if (turn != 0u) {
+            const uint32_t where = (turn - 1u) % 3u;
+            if (where == 0u) {
+                acc_put_half<A0, 0>(v[0]);
+                acc_put_half<A0, 1>(v[1]);
+                idA0 = idV;
+            } else if (where == 1u) {
+                acc_put_half<A1, 0>(v[0]);
+                acc_put_half<A1, 1>(v[1]);
+                idA1 = idV;
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < HR; ++r) park[(h * HR + r) * kWave] = make_float4(v[h][r][0], v[h][r][1], v[h][r][2], v[h][r][3]);
+                idL = idV;
+            }
         }
-        {
-            if (threadIdx.x == 0) s_ticket = agent_add(a.tickets, 1u);
-            tensor_step(a, t, ncol, lane, wave, park, v1, held1, parked, rmn, rmx);
-            ++processed;
-            __syncthreads();
-            const uint32_t nxt = s_ticket;
-            __syncthreads();
-            t = nxt;
-        }
+        load_fold();
     }
-    // Publish.  512 workgroups adding to ONE key pair and polling ONE counter serialise at the memory side (an atomic on a
-    // contended line takes 11-13 ns: MI355X_MICROARCH.md "fanin"; the first build of this kernel spent 40 us here).  So: ONE
-    // returning add per workgroup counts its tiles (low 16 bits) and hands out an arrival number (high bits); the partial
-    // range goes, as one 16-byte store {max key, min key, kept tiles}, into the slot of that number -- no atomics on shared keys, no
-    // drain in front of the add; the workgroup whose add completes the count reads the slots of all arrivals (re-reading the
-    // rare one whose store is still in flight), folds them and broadcasts {go, keys} to 64 replica lines; everybody polls
-    // its own replica (8 pollers per line).
-    uint32_t* replica = a.key_nmin + (blockIdx.x & 63u) * 32u;      // {go, final max key, final complemented min key}
+    // Publish: as rtn_tensor_onepass (one returning add per workgroup, one 16-byte arrival slot, the last finisher folds the
+    // slots and broadcasts {go, keys} to 64 replica lines).  The slot names up to four kept tiles.
+    uint32_t* replica = a.key_nmin + (blockIdx.x & 63u) * 32u;
     OQ_STAMP(1);
 #ifdef OQ_TENSOR_STAMPS
     if (threadIdx.x == 0) g_tensor_stamps[blockIdx.x * 8 + 6] = processed;
@@ -679,14 +795,13 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int w = 1; w < kResWaves; ++w) { rmn = nmin(rmn, s_mn[w]); rmx = nmax(rmx, s_mx[w]); }
+            for (int w = 1; w < WAVES; ++w) { rmn = nmin(rmn, s_mn[w]); rmx = nmax(rmx, s_mx[w]); }
             const uint32_t before = agent_add(a.counters, (1u << 16) | processed);
             const uint32_t arrival = before >> 16;
-            // the slot also says which tiles this workgroup keeps (registers: held0, held1; LDS: `parked`), as tile + 1 in
-            // 16 bits each (0: none; slot 0 always holds one): everybody builds the bitmap of kept tiles from the slots, no
-            // shared bitmap, no atomics, no drain
-            // bit 31 of the last word: this workgroup dropped a tile (it loaded more than the three it keeps)
-            const u32x4r slot = {key_of_max(rmx), key_of_min(rmn), (held0 + 1u) | ((held1 + 1u) << 16), (parked + 1u) | (processed > 3u ? 0x80000000u : 0u)};
+            // kept tiles as tile + 1 (0: none; V always holds one): V | A0 << 16, A1 | LDS << 16 (15 bits); bit 31: this
+            // workgroup dropped a tile (it loaded more than the four it keeps)
+            const u32x4r slot = {key_of_max(rmx), key_of_min(rmn), (idV + 1u) | ((idA0 + 1u) << 16),
+                                 (idA1 + 1u) | ((idL + 1u) << 16) | (processed > 4u ? 0x80000000u : 0u)};
             asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(a.key_max + arrival * 4u), "v"(slot) : "memory");
             s_ticket = ((before & 0xffffu) + processed == ntiles) ? arrival + 1u : 0u;   // the last finisher learns how many arrived
         }
@@ -713,17 +828,13 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
             __syncthreads();
             if (wave == 0) {
 #pragma unroll
-                for (int w = 0; w < kResWaves; ++w) { kmx = max(kmx, __float_as_uint(s_mn[w])); kmn = max(kmn, __float_as_uint(s_mx[w])); }
-                // {go, max key, min key} as ONE 16-byte agent-scope store per replica: a 16-byte piece of a line is written by
-                // one request (MI355X_MICROARCH.md: 16-byte sc1 granules are observed untorn), so no drain between keys and `go`
+                for (int w = 0; w < WAVES; ++w) { kmx = max(kmx, __float_as_uint(s_mn[w])); kmn = max(kmn, __float_as_uint(s_mx[w])); }
                 uint32_t* rep = a.key_nmin + lane * 32;
                 const u32x4r line = {1u, kmx, kmn, arrivals | dropped};   // bit 31: somebody dropped a tile, i.e. phase B has work
                 asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(rep), "v"(line) : "memory");
             }
         }
     }
-    // One 16-byte agent-scope load per poll returns {go, max key, min key} together (the keys were performed before `go`
-    // was stored, and a 16-byte piece of a line is read in one request), so no second round trip for the keys.
     if (threadIdx.x == 0) {
         u32x4r line;
         do {
@@ -732,10 +843,8 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
         } while (line[0] == 0u);
         s_keys[0] = line[1];
         s_keys[1] = line[2];
-        s_keys[2] = line[3];      // how many workgroups arrived = how many slots describe kept tiles; bit 31: phase B has work
+        s_keys[2] = line[3];
     }
-    // Every slot is complete once `go` is up (the last finisher read them all).  One slot per thread: its load is issued here
-    // and lands while the kept tiles are quantized below; the bitmap of kept halves is then built in LDS from the slots.
     __syncthreads();
     OQ_STAMP(2);
     const bool any_dropped = (s_keys[2] & 0x80000000u) != 0u;      // uniform over the grid
@@ -744,7 +853,7 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
         asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(my_slot) : "v"(a.key_max + threadIdx.x * 4u) : "memory");
     const uint32_t nwords = (nunits + 31u) / 32u;
     if (any_dropped)
-        for (uint32_t i = threadIdx.x; i < nwords; i += kResWaves * kWave) s_held[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < nwords; i += THREADS) s_held[i] = 0u;
     const float gmx = max_of_key(s_keys[0]), gmn = min_of_key(s_keys[1]);
     const int32_t bias = a.grid.qmin < 0 ? 128 : 0;
     ColQ cq[4];
@@ -754,38 +863,41 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
         a.scale[0] = cq[0].scale;
         a.zp[0] = static_cast<uint8_t>(cq[0].zp);
     }
-    if (held0 != kNoTile) {   // uniform
-        int64_t row0, col0;
-        tile_origin(held0, ncol, wave, row0, col0);
-        quantize_store_tile(a, cq, v0, row0, a.K, col0, lane);
-    }
-    OQ_STAMP(3);
-    // Phase B: the half tiles nobody kept (skipped when nobody dropped a tile: up to 768 tiles, 96 MB, are read exactly
-    // once).  No tickets and no barriers: the bitmap is the same for everybody, so the ROWS of the unheld halves -- flattened,
-    // most recently read half first (the Infinity Cache still holds them) -- are dealt out statically and evenly over all
-    // waves of the grid; a wave walks its share in steps of up to 16 rows inside one half.  (Whole halves per team of four
-    // waves left 2.4 units per team on 4096 x 11008: three rounds for some, two for the others, 9 us between the first and
-    // the last workgroup to finish.)  The steps are software-pipelined over the two register slots, and the first step's
-    // loads are issued BEFORE the second kept tile and the parked tile are stored: a stretch of stores alone ran at
-    // 2 TB/s (24 MB in 11.5 us), reads beside them are almost free.  Safe without residency assumptions: nobody waits in
-    // this phase; a workgroup that starts late does its share late.
+    // The kept tiles go into the bitmap BEFORE V's stores leave: a wait for the slot behind the stores would wait for the stores
+    // too (one counter, in order: 2.6 us from here to the bitmap); the rest of the bitmap work runs while they travel.
     uint32_t total = 0, pos = 0, stop = 0;
     if (any_dropped) {
         __syncthreads();                                   // s_held zeroed
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(my_slot) : : "memory");
         {
-            const uint32_t ids[3] = {my_slot[2] & 0xffffu, my_slot[2] >> 16, my_slot[3] & 0xffffu};
+            const uint32_t ids[4] = {my_slot[2] & 0xffffu, my_slot[2] >> 16, my_slot[3] & 0xffffu, (my_slot[3] >> 16) & 0x7fffu};
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 4; ++i)
                 if (ids[i] != 0u) atomicOr(&s_held[(ids[i] - 1u) >> 4], 3u << ((2u * (ids[i] - 1u)) & 31u));   // both halves of the tile
         }
-        __syncthreads();                                   // s_held complete
-        // s_pref[w] = unheld halves in words [0, w): four words per thread, a wave scan, the waves' sums through LDS
+    }
+    if (idV != kNoTile) {   // uniform
+        int64_t row0, col0;
+        tile4_origin<ROWS>(idV, ncol, wave, row0, col0);
+        quantize_store_tile<HR, GROUP>(a, cq, v[0], row0, a.K, col0, lane);
+        quantize_store_tile<HR, GROUP>(a, cq, v[1], row0 + HR, a.K, col0, lane);
+    }
+    OQ_STAMP(3);
+    // Phase B: as rtn_tensor_onepass (the rows of the unheld halves, most recently read first, dealt out statically and evenly
+    // over all waves of the grid), pipelined over the two halves of V; the first step's loads are issued before the parked
+    // tiles are stored.
+    // Once every wave has its slot this workgroup has read the state for the last time: it counts itself out HERE, not at its
+    // end, so that the cleaner finds the count complete when it gets there and the zeroing hides behind the others' phase B.
+    if (any_dropped) {
+        __syncthreads();                                   // s_held complete: every wave's slot has landed
+        if (a.done != nullptr && !first && threadIdx.x == 0) agent_add(a.done, 1u);
+        // s_pref[w] = unheld halves in words [0, w): 2048 / THREADS words per thread, a wave scan, the waves' sums through LDS
         {
-            uint32_t c[4], cnt = 0;
+            constexpr int WPT = 2048 / THREADS;
+            uint32_t c[WPT], cnt = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t w = threadIdx.x * 4u + i;
+            for (int i = 0; i < WPT; ++i) {
+                const uint32_t w = threadIdx.x * WPT + i;
                 uint32_t bits = w < nwords ? ~s_held[w] : 0u;
                 if (w == nwords - 1u && (nunits & 31u)) bits &= (1u << (nunits & 31u)) - 1u;
                 c[i] = __popc(bits);
@@ -797,35 +909,36 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
                 const uint32_t up = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl), off, 64));
                 if (lane >= off) incl += up;
             }
-            if (lane == 63) s_mn[wave] = __uint_as_float(incl);
+            if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
             uint32_t run = incl - cnt;
 #pragma unroll
-            for (int w = 0; w < kResWaves; ++w)
-                if (w < wave) run += __float_as_uint(s_mn[w]);
+            for (int w = 0; w < WAVES; ++w)
+                if (w < wave) run += s_wsum[w];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint32_t w = threadIdx.x * 4u + i;
+            for (int i = 0; i < WPT; ++i) {
+                const uint32_t w = threadIdx.x * WPT + i;
                 if (w < nwords) s_pref[w] = run;
                 run += c[i];
             }
-            if (threadIdx.x == kResWaves * kWave - 1) s_total = run;
+            if (threadIdx.x == THREADS - 1) s_total = run;
         }
         __syncthreads();
         total = s_total;
         const uint32_t total_rows = total * kHalfRows;
-        const uint32_t nwv = gridDim.x * kResWaves, per = (total_rows + nwv - 1u) / nwv;
-        pos = (blockIdx.x * kResWaves + wave) * per;
+        const uint32_t nwv = gridDim.x * WAVES, per = (total_rows + nwv - 1u) / nwv;
+        pos = (blockIdx.x * WAVES + wave) * per;
         stop = pos + per < total_rows ? pos + per : total_rows;
+    } else if (a.done != nullptr && !first && threadIdx.x == 0) {
+        agent_add(a.done, 1u);                             // the replica line was this workgroup's last read of the state
     }
     OQ_STAMP(4);
-    // the next step of this wave's share: rows [row0, row_end) x columns [col0, col0 + 256) of one unheld half; false at the end
     int64_t a_row0 = 0, a_end = 0, a_col0 = 0, b_row0 = 0, b_end = 0, b_col0 = 0;
     auto next_step = [&](int64_t& row0, int64_t& row_end, int64_t& col0) -> bool {
         while (pos < stop) {
             const uint32_t j = pos / kHalfRows, r_in = pos - j * kHalfRows;
             uint32_t n = kHalfRows - r_in;
-            n = n < static_cast<uint32_t>(kResRows) ? n : static_cast<uint32_t>(kResRows);
+            n = n < static_cast<uint32_t>(HR) ? n : static_cast<uint32_t>(HR);
             n = n < stop - pos ? n : stop - pos;
             pos += n;
             const uint32_t want = total - 1u - j;          // rank of the half among the unheld ones, ascending
@@ -848,41 +961,52 @@ __global__ __launch_bounds__(kResWaves* kWave, 2) void rtn_tensor_onepass(const 
         return false;
     };
     bool a_live = next_step(a_row0, a_end, a_col0);
-    if (a_live) load_tile(a, a_row0, a_end, a_col0, lane, v0);         // in flight while the other kept tiles are stored
-    if (held1 != kNoTile) {   // uniform
+    if (a_live) load_tile<true, HR>(a, a_row0, a_end, a_col0, lane, v[0]);         // in flight while the parked tiles are stored
+    if (idA0 != kNoTile) {   // uniform
         int64_t row0, col0;
-        tile_origin(held1, ncol, wave, row0, col0);
-        quantize_store_tile(a, cq, v1, row0, a.K, col0, lane);
+        tile4_origin<ROWS>(idA0, ncol, wave, row0, col0);
+        acc_get_half<A0, 0>(v[1]);
+        quantize_store_tile<HR, GROUP>(a, cq, v[1], row0, a.K, col0, lane);
+        acc_get_half<A0, 1>(v[1]);
+        quantize_store_tile<HR, GROUP>(a, cq, v[1], row0 + HR, a.K, col0, lane);
     }
-    if (parked != kNoTile) {   // uniform: back from LDS into the same lanes' registers
+    if (idA1 != kNoTile) {   // uniform
+        int64_t row0, col0;
+        tile4_origin<ROWS>(idA1, ncol, wave, row0, col0);
+        acc_get_half<A1, 0>(v[1]);
+        quantize_store_tile<HR, GROUP>(a, cq, v[1], row0, a.K, col0, lane);
+        acc_get_half<A1, 1>(v[1]);
+        quantize_store_tile<HR, GROUP>(a, cq, v[1], row0 + HR, a.K, col0, lane);
+    }
+    if (idL != kNoTile) {   // uniform: back from LDS into the same lanes' registers
+        int64_t row0, col0;
+        tile4_origin<ROWS>(idL, ncol, wave, row0, col0);
 #pragma unroll
-        for (int r = 0; r < kResRows; ++r) {
-            const float4 x = park[r * kWave];
-            v1[r][0] = x.x; v1[r][1] = x.y; v1[r][2] = x.z; v1[r][3] = x.w;
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                const float4 x = park[(h * HR + r) * kWave];
+                v[1][r][0] = x.x; v[1][r][1] = x.y; v[1][r][2] = x.z; v[1][r][3] = x.w;
+            }
+            quantize_store_tile<HR, GROUP>(a, cq, v[1], row0 + h * HR, a.K, col0, lane);
         }
-        int64_t prow0, pcol0;
-        tile_origin(parked, ncol, wave, prow0, pcol0);
-        quantize_store_tile(a, cq, v1, prow0, a.K, pcol0, lane);
     }
     bool b_live = next_step(b_row0, b_end, b_col0);
-    if (b_live) load_tile(a, b_row0, b_end, b_col0, lane, v1);
+    if (b_live) load_tile<true, HR>(a, b_row0, b_end, b_col0, lane, v[1]);
     while (a_live || b_live) {
         if (a_live) {
-            quantize_store_tile(a, cq, v0, a_row0, a_end, a_col0, lane);
+            quantize_store_tile<HR, GROUP>(a, cq, v[0], a_row0, a_end, a_col0, lane);
             a_live = next_step(a_row0, a_end, a_col0);
-            if (a_live) load_tile(a, a_row0, a_end, a_col0, lane, v0);
+            if (a_live) load_tile<true, HR>(a, a_row0, a_end, a_col0, lane, v[0]);
         }
         if (b_live) {
-            quantize_store_tile(a, cq, v1, b_row0, b_end, b_col0, lane);
+            quantize_store_tile<HR, GROUP>(a, cq, v[1], b_row0, b_end, b_col0, lane);
             b_live = next_step(b_row0, b_end, b_col0);
-            if (b_live) load_tile(a, b_row0, b_end, b_col0, lane, v1);
+            if (b_live) load_tile<true, HR>(a, b_row0, b_end, b_col0, lane, v[1]);
         }
     }
     OQ_STAMP(5);
-    if (a.done != nullptr) {   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
-        if (first) clean_state(a, gridDim.x - 1u, kResWaves * kWave);
-        else if (threadIdx.x == 0) agent_add(a.done, 1u);
-    }
+    if (a.done != nullptr && first) clean_state(a, gridDim.x - 1u, THREADS);   // uniform; `first` = the workgroup that took ticket 0 (it always exists)
 }
 
 // Tickets, counters and keys start from zero.  hipMemsetAsync's fill kernel took 4.6 us for these ~100 KB (rocprofv3,
@@ -893,11 +1017,11 @@ __global__ __launch_bounds__(256) void clear_words_kernel(uint4* p, uint32_t n16
 }
 
 // ------------------------------------------------------------------------------------ host side
-static int resident_blocks(const void* kernel, size_t dynamic_lds) {
+static int resident_blocks(const void* kernel, size_t dynamic_lds, int threads = kResWaves * kWave) {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kResWaves * kWave, dynamic_lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dynamic_lds) != hipSuccess) return 0;
     return cus * per_cu;
 }
 
@@ -972,7 +1096,7 @@ bool rtn_resident_eligible(int64_t K, int64_t N, int64_t ldw, const float* W, co
     if (K % g) return false;
     const int64_t chunks = ceil_div(g, strategy == OQ_TENSOR ? kResTileRows : groups_tile_rows(g, ranges_of(K, N, g)));
     const int64_t ntiles = ceil_div(N, kResCols) * (K / g) * chunks;
-    if (ntiles >= (1LL << 31) || (strategy == OQ_TENSOR && ntiles > kResMaxTensorTiles)) return false;
+    if (ntiles >= (1LL << 31) || (strategy == OQ_TENSOR && ntiles > static_cast<int64_t>(kT4MaxTiles))) return false;
     // forward progress needs `chunks` running workgroups (see the kernels): at most 3/4 of what THIS device holds of the kernel
     // that would run (192 of one workgroup on each of 256 CUs; a 32-CU partition takes ranges of up to 24 chunks)
     if (strategy != OQ_TENSOR && chunks > 1 && chunks * 4 > static_cast<int64_t>(groups_resident(g, ranges_of(K, N, g))) * 3) return false;
@@ -1103,16 +1227,17 @@ static int32_t rtn_resident_launch(const float* W, int64_t K, int64_t N, int64_t
         static int resident_of[64];
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(OQ_ERR_LAUNCH, "rtn: no current device");
+        const void* kernel = reinterpret_cast<const void*>(rtn_tensor_onepass<kResWaves>);
         if (resident_of[dev] == 0) {   // benign race: every thread computes the same value
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(rtn_tensor_onepass), hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes) != hipSuccess)
+            if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kParkBytes) != hipSuccess)
                 return fail(OQ_ERR_LAUNCH, "rtn: %d bytes of LDS refused", kParkBytes);
-            resident_of[dev] = resident_blocks(reinterpret_cast<const void*>(rtn_tensor_onepass), kParkBytes);
+            resident_of[dev] = resident_blocks(kernel, kParkBytes);
         }
         const int resident = resident_of[dev];
         OQ_REQUIRE(resident > 0, OQ_ERR_LAUNCH, "rtn: occupancy query failed");
         uint32_t blocks = a.ntiles < static_cast<uint32_t>(resident) ? a.ntiles : static_cast<uint32_t>(resident);
-        if (blocks > 512u) blocks = 512u;        // the arrival slots (and one slot per thread of the last finisher)
-        hipLaunchKernelGGL(rtn_tensor_onepass, dim3(blocks), dim3(kResWaves * kWave), kParkBytes, s, a);
+        if (blocks > static_cast<uint32_t>(kResWaves * kWave)) blocks = kResWaves * kWave;   // the arrival slots: one per thread of the last finisher
+        hipLaunchKernelGGL(rtn_tensor_onepass<kResWaves>, dim3(blocks), dim3(kResWaves * kWave), kParkBytes, s, a);
         return check_launch("rtn_tensor_onepass");
     }
     const int64_t ranges = static_cast<int64_t>(a.ncol_tiles) * a.kgroups;

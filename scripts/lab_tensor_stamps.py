@@ -29,6 +29,8 @@ live = st[:, 0] > 0
 st = st[live]
 t0 = st[:, 0].min()
 us = (st[:, :6] - t0) / 100.0
+if st[:, 7].max() > 0:
+    print(f"  previous call's last end -> this call's first start: {(t0 - st[:, 7].max()) / 100.0:.2f} us (first end {(t0 - st[:, 7].min()) / 100.0:.2f} us before)")
 names = ["start", "phase A done", "go seen", "kept stored", "parked+bitmap", "end"]
 print(f"{k}x{n}: {live.sum()} workgroups, tiles per workgroup min/mean/max {st[:, 6].min()}/{st[:, 6].mean():.2f}/{st[:, 6].max()}")
 for i, nm in enumerate(names):

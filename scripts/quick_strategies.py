@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--lib", default=None, help="lab: path of another build of liboq_hip.so")
     ap.add_argument("--json", default=None)
     ap.add_argument("--shapes", default="4096x11008,4096x4096,11008x4096,256x512,640x2048")
+    ap.add_argument("--only", default=None, help="one strategy only: channel | tensor | group")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     out = {"resident": os.environ.get("OQ_RTN_RESIDENT", "1"), "rows": []}
@@ -40,7 +41,7 @@ def main():
         ws = [torch.randn((k, n), generator=gen, device="cuda") for _ in range(rot)]
         for qtype, strategy, g in (("int8", "channel", -1), ("int8", "tensor", -1), ("uint4", "channel", -1), ("int8", "group", 512),
                                    ("int8", "group", 1024)):
-            if strategy == "group" and k % g:
+            if (strategy == "group" and k % g) or (args.only and strategy != args.only):
                 continue
             outs = ops.rtn_quantize(ws[0], qtype, strategy, g)
             dig = "/".join(sha(t) for t in outs)

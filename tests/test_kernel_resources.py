@@ -80,8 +80,9 @@ def test_gptq_loop_kernels_do_not_spill(tmp_path):
 def test_resident_rtn_kernels_keep_their_tiles_in_registers(tmp_path):
     """`rtn_resident_groups` (channel, tall groups: W read once) holds a 128 x 256 tile in 64 registers per lane while the range
     completes elsewhere; two 8-wave workgroups per CU (<= 128 registers, no scratch) are what keeps loads in flight while one of
-    them waits.  `rtn_tensor_onepass` runs ONE 8-wave workgroup per CU that keeps two tiles in registers (128 of <= 256) and
-    one in LDS; a spill would turn its kept tiles into scratch traffic."""
+    them waits.  `rtn_tensor_onepass` runs ONE 8-wave workgroup per CU that keeps a tile in 64 architectural registers, two in
+    its 128 accumulation registers -- named as PHYSICAL registers a[0..127] in the assembly text, so the register allocator
+    must not have placed anything of its own there -- and one in LDS; a spill would turn its kept tiles into scratch traffic."""
     from onnx_quantize_amd import _build
     src = os.path.join(ROOT, "onnx_quantize_amd", "csrc", "rtn_resident.hip")
     r = subprocess.run([HIPCC, *_build.flags_for(src), "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-o",
@@ -95,6 +96,25 @@ def test_resident_rtn_kernels_keep_their_tiles_in_registers(tmp_path):
         assert hits, (key, list(seen))
         for vgprs, scratch, occ in hits:
             assert vgprs <= max_vgprs and scratch == 0 and occ >= min_occ, (key, vgprs, scratch, occ)
+    # the per-tensor kernel's parks: the code object holds exactly the accumulation-register traffic the source writes (two parks
+    # of 64 registers, each written at one place and read back at one place) and no other use of an `a` register: the compiler
+    # turns to them only once the architectural registers run out (<= 128 here), and then it would take a[0], a[1], ... -- the parks
+    text = (tmp_path / "res.s").read_text()
+    m = re.search(r"^_ZN2oq18rtn_tensor_onepassILi8EEEvNS_12ResidentArgsE:.*?s_endpgm", text, re.S | re.M)
+    assert m, "kernel body not found"
+    body = m.group(0)
+    writes = re.findall(r"v_accvgpr_write_b32 (\S+),", body)
+    reads = re.findall(r"v_accvgpr_read_b32 \S+, (\S+)", body)
+    assert len(writes) == 128 and len(reads) == 128 and len(set(writes)) == 128 and len(set(reads)) == 128, (len(writes), len(reads))
+    assert all(w.startswith("a[") for w in writes) and all(r.startswith("a[") for r in reads), "an accumulation register the source did not name"
+    assert "v_accvgpr_mov" not in body
+    others = [ln for ln in body.splitlines() if "accvgpr" not in ln and re.search(r"[ ,]a(\[|\d)", ln.split(";")[0])]
+    assert not others, others[:5]
+    meta = [c for c in text.split("- .agpr_count:")[1:] if "_ZN2oq18rtn_tensor_onepassILi8EEEvNS_12ResidentArgsE\n" in c.split(".vgpr_count:")[0]]
+    assert len(meta) == 1
+    agpr = int(meta[0].split()[0])
+    total = int(re.search(r"\.vgpr_count:\s+(\d+)", meta[0]).group(1))
+    assert agpr == 128 and total <= 256, (agpr, total)      # the descriptor reserves a[0..127]; with the architectural ones: two waves per SIMD
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
