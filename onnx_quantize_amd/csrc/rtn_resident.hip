@@ -257,6 +257,9 @@ __device__ __forceinline__ void quantize_store_tile(const ResidentArgs& a, const
 // chunks <= 128 against 256 CUs) the missing tickets are always taken, loaded and published without waiting, and R
 // completes.  Workgroups that are not resident yet hold no ticket and nobody waits for them.
 // ---------------------------------------------------------------------------------------------
+#ifndef OQ_GROUPS_GROUP
+#define OQ_GROUPS_GROUP 2   /* rows per decision of K1 (quantize_store_tile): 4096 x 4096 int8 per channel 27.7 us with 1, 26.6 with 2, 26.9-27.9 with 4 (<= 128 registers) */
+#endif
 template <int WAVES, int ROWS, int WPS>
 __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const ResidentArgs a) {
     constexpr int kTileRows = WAVES * ROWS;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(WAVES* kWave, WPS) void rtn_resident_groups(const R
             }
         }
     }
-    quantize_store_tile<ROWS>(a, cq, v, row0, row_end, tile_col0, lane);
+    quantize_store_tile<ROWS, OQ_GROUPS_GROUP>(a, cq, v, row0, row_end, tile_col0, lane);
     if (a.done != nullptr) {   // uniform
         // every state access of this workgroup is complete (its key loads returned, its counter add was seen by its own poll)
         if (t + 1u == a.ntiles) clean_state(a, a.ntiles - 1u, WAVES * kWave);
