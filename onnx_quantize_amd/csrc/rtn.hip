@@ -93,6 +93,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef OQ_RTN_SC1
 #define OQ_RTN_SC1 6
 #endif
+// K1's fast path is proven row group by row group: OQ_WAVE_GROUP / OQ_FUSED_GROUP rows share ONE decision (a running
+// v_maximum3_f32 of the residuals against the narrowest band, then one ballot) where rounds 1-5 spent a compare and a scalar OR
+// per element and a ballot + branch per row.  Same box, alternating, 4096 x 11008: blob 38.8-39.0 -> 38.1 us (4096 x 4096 17.35 ->
+// 16.2), [K,N] bytes 41.7 -> 40.4, packed nibbles 39.3 -> 37.85.  Four rows per decision cost the wave kernel its fifth wave per
+// SIMD in effect (50.3 us) and the fused kernel its fourth (129 registers): two it is.
+#ifndef OQ_WAVE_GROUP
+#define OQ_WAVE_GROUP 2
+#endif
+#ifndef OQ_FUSED_GROUP
+#define OQ_FUSED_GROUP 2
+#endif
 __device__ __forceinline__ void store_sc1(uint32_t w, uint32_t* p) { asm volatile("global_store_dword %0, %1, off sc1" : : "v"(p), "v"(w) : "memory"); }
 
 constexpr int kDefaultWps = 5;     // wave kernel build used when OQ_RTN_WPS is unset (see Tuning)
@@ -441,6 +452,38 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
 
     // K1 from registers: v[r][i] <- clamped, biased level (an exact small float).
     const float lo_b = static_cast<float>(qmin + bias), hi_b = static_cast<float>(qmax + bias);
+#if OQ_FUSED_GROUP > 1
+    // one decision per OQ_FUSED_GROUP rows on a running NaN-propagating maximum of |t - k| (v_maximum3_f32 with |.| modifiers) against
+    // the narrowest band of the lane's four columns, instead of a compare + scalar OR per element and a ballot + branch per row
+    {
+        constexpr int GROUP = RPW % OQ_FUSED_GROUP == 0 ? OQ_FUSED_GROUP : 1;
+        const float thr_min = nmin(nmin(cq[0].thr, cq[1].thr), nmin(cq[2].thr, cq[3].thr));
+#pragma unroll
+        for (int rg = 0; rg < RPW; rg += GROUP) {
+            float f[GROUP][4];
+            float far = 0.0f;
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = v[rg + r][i] * cq[i].rinv;
+                    const float k = rintf(t);
+                    far = nmax(far, fabsf(t - k));
+                    f[r][i] = __builtin_amdgcn_fmed3f(k + cq[i].zpb, lo_b, hi_b);
+                }
+            if (__builtin_amdgcn_ballot_w64(!(far < thr_min)) != 0) {  // wave-uniform, rare: redo these rows with the IEEE divide
+#pragma unroll
+                for (int r = 0; r < GROUP; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f[r][i] = quantize_exact_biased(v[rg + r][i], cq[i], qmin, qmax, bias);
+            }
+#pragma unroll
+            for (int r = 0; r < GROUP; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rg + r][i] = f[r][i];
+        }
+    }
+#else
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         float f[4];
@@ -454,6 +497,7 @@ __global__ __launch_bounds__(kMaxWaves* kWave) void rtn_group_fused(const RtnArg
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[r][i] = f[i];
     }
+#endif
 
     do {      // the layout's stores; `break` instead of `return`: every wave reaches the tail below
     if (a.layout == OQ_LAYOUT_KN) {
@@ -808,6 +852,39 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
         const f32x2 rv[2] = {{rinv[0], rinv[1]}, {rinv[2], rinv[3]}};
         const f32x2 zm[2] = {{zpb[0] + kMagic, zpb[1] + kMagic}, {zpb[2] + kMagic, zpb[3] + kMagic}};
         const float lo_m = lo_b + kMagic, hi_m = hi_b + kMagic;
+#if OQ_WAVE_GROUP > 1
+        // one decision per OQ_WAVE_GROUP rows: the residuals fold into a running NaN-propagating maximum (one v_maximum3_f32 with |.|
+        // modifiers per pair) instead of two compares and two scalar ORs per pair and a ballot + branch per row
+#pragma unroll
+        for (int rg = 0; rg < 16; rg += OQ_WAVE_GROUP) {
+            float f[OQ_WAVE_GROUP][4];
+            float far = 0.0f;
+#pragma unroll
+            for (int r = 0; r < OQ_WAVE_GROUP; ++r)
+#pragma unroll
+                for (int p2 = 0; p2 < 2; ++p2) {
+                    const f32x2 x = {v[rg + r][2 * p2], v[rg + r][2 * p2 + 1]};
+                    const f32x2 u = __builtin_elementwise_fma(x, rv[p2], zm[p2]);
+                    const f32x2 res = __builtin_elementwise_fma(x, rv[p2], zm[p2] - u);
+                    far = nmax(far, nmax(fabsf(res.x), fabsf(res.y)));
+                    f[r][2 * p2] = __builtin_amdgcn_fmed3f(u.x, lo_m, hi_m);
+                    f[r][2 * p2 + 1] = __builtin_amdgcn_fmed3f(u.y, lo_m, hi_m);
+                }
+            if (__builtin_amdgcn_ballot_w64(!(far < thr)) != 0) {  // wave-uniform, rare: redo these rows with the IEEE divide
+                float se[4];
+                fallback_scales(se);
+#pragma unroll
+                for (int r = 0; r < OQ_WAVE_GROUP; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        f[r][i] = __uint_as_float(0x4B400000u + static_cast<uint32_t>(quantize_one(v[rg + r][i], se[i], static_cast<int32_t>(zpb[i]) - bias, qmin, qmax) + bias));
+            }
+#pragma unroll
+            for (int r = 0; r < OQ_WAVE_GROUP; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[rg + r][i] = f[r][i];
+        }
+#else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float f[4];
@@ -831,6 +908,7 @@ __global__ __launch_bounds__(WPS ? 256 : kMaxWaves* kWave, WPS ? WPS : 1) void r
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[r][i] = f[i];
         }
+#endif
         if (!col_ok || OQ_ATTR(a.nt, 16)) return;
         // qrules/_common.py:72-87: out-channel n, k-group kg -> G * bits / 8 bytes, k ascending, even k in the low nibble.
         // v[r][i] holds M + level: the level is byte 0 of its bits (the other three bytes are those of M).
