@@ -113,7 +113,7 @@ int32_t oq_rtn_quantize_f32(const float* W, int64_t K, int64_t N, int64_t ldw, i
  *     that fails on the device leaves the state undefined.
  *     Round 6: the fused group kernel uses the state too -- layouts OQ_LAYOUT_KN and OQ_LAYOUT_KN_PACKED4, 128-row groups, at most 64
  *     k-groups: the n-major parameters are staged in it as self-validating words and transposed INSIDE the launch by blocks appended to
- *     the grid (no second launch: 4096 x 11008 bytes 45.0 -> 42.5 us, packed nibbles 43.3-44.3 -> 40.9-41.2); oq_rtn_state_bytes says
+ *     the grid (no second launch: 4096 x 11008 bytes 45.0 -> 42.5 us, packed nibbles 43.3-44.3 -> 40.0-40.6; with write-through stores and K1 by row groups 40.4 / 37.9); oq_rtn_state_bytes says
  *     how much it needs for a shape (0: the call keeps no state).  Those appended blocks wait for the main blocks of their own launch,
  *     so such calls are ordered like the ticketed ones (below).
  *     Concurrency of the ticketed kernels (both entry points): inside a call a workgroup may wait for other workgroups of the
