@@ -568,6 +568,38 @@ def test_more_than_2_31_elements():
 
 
 @pytest.mark.gpu
+def test_per_tensor_at_the_tile_limit_of_the_one_pass_kernel():
+    """`rtn_tensor_onepass` names a kept tile as tile + 1 in 15 bits of its arrival slot: 32 766 tiles (128 x 256 each) are the
+    most it takes, a tensor of more goes to the three-launch path.  One tensor exactly at the limit (129 x 254 tiles = 1.07e9
+    elements) and one a tile row above it: scale / zero point against the oracle's qparams of the tensor's range, sampled row
+    strips (first, one in the middle of a tile, the last rows) against the oracle's K1 with those parameters, and the per-row
+    sums of ALL integers against a plain torch evaluation of the same formula (IEEE division)."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    n = 254 * 256
+    for k in (129 * 128, 130 * 128 - 3):
+        gen = torch.Generator(device="cuda").manual_seed(k)
+        w = torch.empty((k, n), device="cuda")
+        for r0 in range(0, k, 2048):                                    # generated in slabs: no 4 GB temporaries
+            w[r0:r0 + 2048].normal_(generator=gen)
+        w[k // 2, 5] = 9.5                                              # the range sits in the middle and at the very end
+        w[k - 1, n - 1] = -8.25
+        q, s, z = ops.rtn_quantize(w, "int8", "tensor")
+        _, es, ez = O.rtn_quantize(np.array([[-8.25, 9.5, 0.0, 1.0]], dtype=np.float32), "int8", "tensor")      # a tensor of the same range
+        es, ez = np.float32(np.asarray(es).reshape(-1)[0]), int(np.asarray(ez).reshape(-1)[0])
+        assert np.float32(s.cpu().numpy().reshape(-1)[0]).tobytes() == es.tobytes() and int(z.cpu().numpy().reshape(-1)[0]) == ez
+        for r0 in (0, 128 * 64 + 37, k - 9):
+            strip = w[r0:r0 + 9].cpu().numpy()
+            np.testing.assert_array_equal(q[r0:r0 + 9].cpu().numpy(), O.quantize(strip, es, ez, "int8", False, False))
+        scale_t = torch.tensor(float(es), dtype=torch.float32, device="cuda")
+        for r0 in range(0, k, 2048):                                    # every integer, slab by slab
+            ref = torch.clamp(torch.round(w[r0:r0 + 2048] / scale_t) + ez, -128, 127).to(torch.int8)
+            assert torch.equal(q[r0:r0 + 2048].view(torch.int8), ref), r0
+        del w, q
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
 def test_kernel_emitted_wire_format_equals_the_reference_function_output():
     """tests/golden/nbits.*: what `_prepare_for_matmul_nbits` (qrules/_common.py:65-123) made of the reference's own RTN /
     HQQ results, against what the kernels write directly (layout="nbits") + the zero-point packing kernel."""
