@@ -699,12 +699,14 @@ constexpr uint32_t kNoTile = 0xFFFFFFFFu;
 #endif
 constexpr uint32_t kT4MaxTiles = 32766;               // the fourth kept tile travels as tile + 1 in 15 bits of its arrival slot
 
-// The parks are PHYSICAL accumulation registers named in the assembly text: a[0..127] and a[128..255].  (As operands of the `a`
-// register class they went through the register allocator, which copied them at every join of the control flow: 738
-// v_accvgpr_mov and 1.2 KB of scratch per lane.)  The compiler allocates no accumulation register of its own in this kernel --
-// it would only ever use them to spill architectural ones, and the kernel stays below 256 of those
-// (tests/test_kernel_resources.py counts the v_accvgpr instructions of the code object: exactly the ones written here) --;
-// the clobber statement at the top of the kernel makes the kernel descriptor reserve all 256.
+// The parks are PHYSICAL accumulation registers named in the assembly text: a[0..63] and a[64..127] (a[0..127] and a[128..255] in
+// the one-wave-per-SIMD form).  As operands of the `a` register class they went through the register allocator, which copied them
+// at every join of the control flow: 738 v_accvgpr_mov and 1.2 KB of scratch per lane.  Named like this the compiler does not
+// know that they hold anything -- and it does place values of its own in a0, a1, ... once a kernel that names accumulation
+// registers runs out of architectural ones (128 here).  So the kernel is written to stay below that: V is loaded at ONE place of
+// the code, row addresses are scalar, nothing is scheduled across a park's move; tests/test_kernel_resources.py counts the
+// v_accvgpr instructions of the code object (exactly the ones written here, no other `a` operand) and fails the build otherwise.
+// The clobber statement at the top of the kernel makes the kernel descriptor reserve the registers.
 template <int BASE, int H, int HR>
 __device__ __forceinline__ void acc_put_half(const float (&v)[HR][4]) {
 #pragma unroll
