@@ -568,6 +568,33 @@ def test_more_than_2_31_elements():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("strategy,k,n", [("channel", 8192, 1280), ("tensor", 4096, 8448), ("channel", 4224, 11008)])
+def test_tie_bands_in_the_streamed_and_the_parked_paths(strategy, k, n):
+    """The exact-division redo of a row GROUP (round 6: one decision per two / four rows) in the kernels that small shapes never
+    reach: `rtn_resident_stream` (ranges taller than 4096 rows, or >= 1024 tiles) and `rtn_tensor_onepass` with more tiles than
+    the chip keeps (1056 > 1024: phase B and all three parks).  Weights are multiples of a quarter of the step the range gives
+    -- every other one sits exactly on a rounding tie -- plus a sprinkle of ordinary values; the whole result against the oracle."""
+    import torch
+    from onnx_quantize_amd.hip import ops
+    r = np.random.default_rng(k + n)
+    w = (r.integers(-510, 511, size=(k, n)) * 0.25).astype(np.float32)         # int8 range 255 levels over [-127.5, 127.5]: scale 1, ties at .5
+    w[0, :] = -127.5
+    w[1, :] = 127.5
+    mask = r.random((k, n)) < 0.05
+    w[mask] = np.clip(r.standard_normal(int(mask.sum())).astype(np.float32) * 40, -127.5, 127.5)
+    w[0, :] = -127.5
+    w[1, :] = 127.5
+    eq, es, ez = O.rtn_quantize(w, "int8", strategy)
+    q, s, z = ops.rtn_quantize(torch.from_numpy(w).cuda(), "int8", strategy)
+    assert s.cpu().numpy().reshape(np.shape(es)).tobytes() == np.asarray(es, np.float32).tobytes()
+    np.testing.assert_array_equal(z.cpu().numpy().reshape(np.shape(ez)), ez)
+    np.testing.assert_array_equal(q.cpu().numpy(), eq)
+    t = w / np.float32(np.asarray(es).reshape(-1)[0])
+    ties = np.abs(np.abs(t - np.floor(t)) - 0.5) < 1e-3
+    assert ties.mean() > 0.2                                                    # the data does what the docstring says
+
+
+@pytest.mark.gpu
 def test_per_tensor_at_the_tile_limit_of_the_one_pass_kernel():
     """`rtn_tensor_onepass` names a kept tile as tile + 1 in 15 bits of its arrival slot: 32 766 tiles (128 x 256 each) are the
     most it takes, a tensor of more goes to the three-launch path.  One tensor exactly at the limit (129 x 254 tiles = 1.07e9
