@@ -312,30 +312,44 @@ __global__ __launch_bounds__(512, 2) void awq_group_diff_kernel(const float* __r
     const float lo = static_cast<float>(grid.qmin), hi = static_cast<float>(grid.qmax);
     float m = 0.f;
     float* out = D + row0 * N + tile_col0 + lane * 4;
+    // K1's fast path is proven two rows at a time (rtn.hip, round 6): a running NaN-propagating maximum of |t - k| against the
+    // narrowest band of the lane's four columns, one ballot per pair of rows
+    const float thr_min = nmin(nmin(cq[0].thr, cq[1].thr), nmin(cq[2].thr, cq[3].thr));
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float x[4], f[4];
-        bool unsafe = false;
+    for (int rg = 0; rg < 16; rg += 2) {
+        float x[2][4], f[2][4];
+        float far = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            x[i] = scaled(r, i);
-            f[i] = quantize_fast_biased(x[i], cq[i], lo, hi, unsafe);
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x[r][i] = scaled(rg + r, i);
+                const float t = x[r][i] * cq[i].rinv;
+                const float k = rintf(t);
+                far = nmax(far, fabsf(t - k));
+                f[r][i] = __builtin_amdgcn_fmed3f(k + cq[i].zpb, lo, hi);
+            }
+        if (__builtin_amdgcn_ballot_w64(!(far < thr_min)) != 0) {   // wave-uniform, rare: redo these rows with the IEEE divide
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[r][i] = quantize_exact_biased(x[r][i], cq[i], grid.qmin, grid.qmax, 0);
         }
-        if (__builtin_amdgcn_ballot_w64(unsafe) != 0) {   // wave-uniform, rare: redo this row with the IEEE divide
 #pragma unroll
-            for (int i = 0; i < 4; ++i) f[i] = quantize_exact_biased(x[i], cq[i], grid.qmin, grid.qmax, 0);
-        }
-        const float wv[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
-        float d[4];
+        for (int r2 = 0; r2 < 2; ++r2) {
+            const int r = rg + r2;
+            const float wv[4] = {w[r].x, w[r].y, w[r].z, w[r].w};
+            float d[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float w_hat = (f[i] - cq[i].zpb) * cq[i].scale;          // utils.py:130-132 on exact small integers
-            if (row_scale != nullptr) w_hat = w_hat / sr[r];
-            d[i] = wv[i] - w_hat;
-            m = nmax(m, fabsf(d[i]));
+            for (int i = 0; i < 4; ++i) {
+                float w_hat = (f[r2][i] - cq[i].zpb) * cq[i].scale;          // utils.py:130-132 on exact small integers
+                if (row_scale != nullptr) w_hat = w_hat / sr[r];
+                d[i] = wv[i] - w_hat;
+                m = nmax(m, fabsf(d[i]));
+            }
+            if constexpr (PIECES) w[r] = make_float4(d[0], d[1], d[2], d[3]);      // the row's weights are dead: its differences take their place
+            else if (col_ok && group_ok) *reinterpret_cast<float4*>(out + r * N) = make_float4(d[0], d[1], d[2], d[3]);
         }
-        if constexpr (PIECES) w[r] = make_float4(d[0], d[1], d[2], d[3]);      // the row's weights are dead: its differences take their place
-        else if (col_ok && group_ok) *reinterpret_cast<float4*>(out + r * N) = make_float4(d[0], d[1], d[2], d[3]);
     }
     if constexpr (PIECES) {
         const float sc = piece_scale[0];                         // a power of two: the products are exact
