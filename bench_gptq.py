@@ -242,7 +242,7 @@ def run(args, dev, rank: int, world: int):
         """One timed pass over this rank's share of the model: Hessians, factors, loop, packing, the gather to rank 0.
         ``warm``: the first wave (or input) only, nothing gathered -- run once, untimed, before a timed pass so that every
         buffer size of a wave has been mapped: the first `hipMalloc` of the 15.5 GB factor workspace took anything from 5 ms to
-        2.4 s on the MI355X host (scripts/lab_alloc_trace.py, two of six processes), inside the factor phase."""
+        2.4 s on the MI355X host (scripts/lab_alloc_trace.py of round 3, pruned in round 4: git history; two of six processes), inside the factor phase."""
         results, timings, samples = {}, [], {}
         streamer = None
         # two-stream Hessian (ops.HessianPipeline): only the fp16-piece method has a separable preparation

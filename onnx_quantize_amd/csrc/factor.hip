@@ -440,7 +440,7 @@ static int32_t factor_batched(const float* H, int64_t K, int64_t h_stride, int64
         const int64_t rest2 = K - pend;
         if (rest2 >= kPieceUpdateMin && pieces_ok) {
             // the same update on the fp16 matrix cores (two fp16 pieces per operand element, three products: 22-bit operands,
-            // fp32 accumulate -- scripts/lab_factor_precision.py: the factor's error against float64 does not move, 5.8e-8 vs
+            // fp32 accumulate -- scripts/lab_factor_accuracy.py (lab_factor_precision.py until the pruning of round 4): the factor's error against float64 does not move, 5.8e-8 vs
             // 6.0e-8 at K = 11008): the panel Lt[O:pend, pend:] is a 512-row "batch of activations", the update a Hessian
             // accumulation with alpha = -1, beta = 1 into a block of P.  The X region (not needed before the inverse) holds
             // the pieces.  fp32 kernel: 83 TFLOP/s on the first update of K = 11008 (a read-modify-write of 3.5 GB).
